@@ -1,0 +1,394 @@
+"""Pins the CPU oracle (oracle/*.c) against every value-KAT the reference's own
+unit tests hold for the hot path, and against python-int /
+hashlib ground truth for the arkworks + sha2 semantics that no reference test pins.
+
+Fr::from(k) for negative k is (k mod r), as in ark-ff's From<i32>.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+Q = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+
+
+def F(ora, vals):
+    return ora.fr_from_ints(vals)
+
+
+def ints(ora, arr):
+    return ora.fr_to_ints(arr)
+
+
+def eq(ora, arr, expected):
+    assert ints(ora, arr) == [v % R for v in expected]
+
+
+# ---- arithmetic ground truth (python ints) ------------------------------------
+def test_fr_arith_matches_python_ints(ora):
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        a = int.from_bytes(rng.bytes(32), "little") % R
+        b = int.from_bytes(rng.bytes(32), "little") % R
+        A, B = F(ora, [a])[0], F(ora, [b])[0]
+        assert ints(ora, ora.fr_mul(A, B)) == [a * b % R]
+        assert ints(ora, ora.fr_add(A, B)) == [(a + b) % R]
+        assert ints(ora, ora.fr_sub(A, B)) == [(a - b) % R]
+        if a:
+            assert ints(ora, ora.fr_inv(A)) == [pow(a, -1, R)]
+    # edge values
+    for a, b in [(0, 0), (R - 1, R - 1), (R - 1, 1), (1, R - 1), (0, R - 1)]:
+        A, B = F(ora, [a])[0], F(ora, [b])[0]
+        assert ints(ora, ora.fr_mul(A, B)) == [a * b % R]
+        assert ints(ora, ora.fr_add(A, B)) == [(a + b) % R]
+        assert ints(ora, ora.fr_sub(A, B)) == [(a - b) % R]
+
+
+def test_fq_mul_matches_python_ints(ora):
+    rng = np.random.default_rng(2)
+    for _ in range(100):
+        a = int.from_bytes(rng.bytes(48), "little") % Q
+        b = int.from_bytes(rng.bytes(48), "little") % Q
+        assert ora.fq_to_ints(ora.fq_mul(ora.fq_from_ints([a])[0], ora.fq_from_ints([b])[0])) == [a * b % Q]
+
+
+def test_montgomery_constants_survey_8c(ora):
+    # R = 2^256 mod r little-endian limbs
+    one = F(ora, [1])[0]
+    assert [hex(int(x)) for x in one] == ["0x1fffffffe", "0x5884b7fa00034802", "0x998c4fefecbc4ff5", "0x1824b159acc5056f"]
+
+
+def test_sha256_nist_and_hashlib(ora):
+    assert ora.sha256(b"abc").hex() == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad"
+    assert ora.sha256(b"").hex() == "e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855"
+    rng = np.random.default_rng(3)
+    for n in [1, 55, 56, 63, 64, 65, 96, 119, 120, 128, 1000]:
+        m = rng.bytes(n)
+        assert ora.sha256(m) == hashlib.sha256(m).digest()
+
+
+def test_transcript_chain_matches_hashlib(ora):
+    # fiat_shamir.rs:17-29
+    t = ora.Transcript()
+    t.commit(b"hello")
+    t.commit(b"world")
+    d1 = hashlib.sha256(b"helloworld").digest()
+    assert t.challenge() == d1
+    t.commit(b"x" * 70)
+    d2 = hashlib.sha256(d1 + b"x" * 70).digest()
+    c = t.evaluate_challenge_into_field()
+    assert ints(ora, c) == [int.from_bytes(d2, "big") % R]
+    d3 = hashlib.sha256(d2).digest()   # nothing committed in between
+    assert t.challenge() == d3
+
+
+def test_from_be_bytes_mod_order(ora):
+    for b in [b"\xff" * 32, b"\x00" * 32, bytes(range(32)), b"\x01", b"\xff" * 40]:
+        assert ints(ora, ora.fr_from_be_bytes_mod_order(b)) == [int.from_bytes(b, "big") % R]
+
+
+# ---- sumcheck/src/utils.rs:70-93 ------------------------------------------------
+def test_convert_field_to_byte(ora):
+    assert ora.fr_to_bytes_be(F(ora, [1])[0]) == bytes(31) + b"\x01"
+    assert ora.fr_to_bytes_be(F(ora, [100])[0]) == bytes(31) + bytes([100])
+    assert ora.fr_to_bytes_be(F(ora, [90])[0]) != bytes(31) + bytes([10])
+    assert ora.fr_to_bytes_be(F(ora, [-1])[0]) == (R - 1).to_bytes(32, "big")
+
+
+# ---- evaluation_form.rs tests -----------------------------------------------------
+def test_add_mul_distinct(ora):  # :264-312
+    p1, p2 = F(ora, [0, 0, 2, 2]), F(ora, [0, 3, 0, 3])
+    eq(ora, ora.mle_add_distinct(p1, p2), [0, 3, 0, 3, 0, 3, 0, 3, 2, 5, 2, 5, 2, 5, 2, 5])
+    eq(ora, ora.mle_mul_distinct(p1, p2), [0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 0, 6, 0, 6, 0, 6])
+
+
+def test_partial_evaluation_1(ora):  # :315-325
+    eq(ora, ora.mle_partial_evaluation(F(ora, [3, 1, 2, 5]), F(ora, [5])[0], 0), [-2, 21])
+
+
+def test_partial_evaluation_2(ora):  # :328-359
+    poly = F(ora, [3, 9, 7, 13, 6, 12, 10, 18])
+    pts = F(ora, [3, 2])
+    for r, k, want in [(2, 0, 57), (3, 1, 72), (1, 2, 38)]:
+        folded = ora.mle_partial_evaluation(poly, F(ora, [r])[0], k)
+        eq(ora, ora.mle_evaluation(folded, pts), [want])
+
+
+def test_evaluation_1_2(ora):  # :362-405
+    eq(ora, ora.mle_evaluation(F(ora, [3, 1, 2, 5]), F(ora, [5, 6])), [136])
+    eq(ora, ora.mle_evaluation(F(ora, [3, 9, 7, 13, 6, 12, 10, 18]), F(ora, [2, 3, 1])), [39])
+    eq(ora, ora.mle_evaluation(F(ora, [0, 0, 0, 3, 0, 0, 2, 5]), F(ora, [2, 3, 4])), [48])
+
+
+def test_split_and_sum(ora):  # :408-438
+    eq(ora, ora.mle_half_sums(F(ora, [0, 0, 0, 2, 2, 2, 2, 4])), [2, 10])
+    eq(ora, ora.mle_half_sums(F(ora, [0, 0, 2, 7, 3, 3, 6, 11])), [9, 23])
+
+
+def test_sum_over_boolean_hypercube(ora):  # :441-462
+    eq(ora, ora.mle_sum(F(ora, [1, 2, 3, 4, 5, 6, 7, 8])), [36])
+
+
+def test_partial_evaluation_asserts(ora):  # utils.rs:30-34
+    with pytest.raises(AssertionError):
+        ora.mle_partial_evaluation(F(ora, [1, 2, 3, 4]), F(ora, [5])[0], 2)
+    with pytest.raises(AssertionError):
+        ora.mle_evaluation(F(ora, [1, 2, 3, 4]), F(ora, [5]))
+
+
+# ---- composed_multilinear.rs:134-184 --------------------------------------------------
+def test_composed_multilinear(ora):
+    m1, m2 = F(ora, [0, 1, 2, 3]), F(ora, [0, 0, 0, 1])
+    pts = F(ora, [2, 3])
+    e1, e2 = ints(ora, ora.mle_evaluation(m1, pts))[0], ints(ora, ora.mle_evaluation(m2, pts))[0]
+    assert e1 * e2 % R == 42
+    # element_wise_product sum = 3 (composed_sumcheck.rs:108-113)
+    eq(ora, ora.composed_sum(np.stack([m1, m2])), [3])
+
+
+# ---- sums: sumcheck.rs:108-122, composed_sumcheck.rs:108-140, multi_composed:195-214 ---
+def test_sum_calculations(ora):
+    s, _, _ = ora.sumcheck_prove(F(ora, [0, 0, 0, 2, 2, 2, 2, 4]))
+    eq(ora, s, [12])
+    eq(ora, ora.composed_sum(np.stack([F(ora, [3, 3, 5, 5]), F(ora, [0, 0, 0, 1])])), [5])
+    eq(ora, ora.composed_sum(np.stack([F(ora, [0, 1, 2, 3])])), [6])
+    eq(ora, ora.composed_sum(np.stack([F(ora, [0, 0, 0, 2, 2, 2, 2, 4])])), [12])
+    eq(ora, ora.multi_composed_sum(np.stack([F(ora, [0, 1, 2, 3]), F(ora, [0, 0, 0, 1])]), [1, 1]), [7])
+    eq(ora, ora.multi_composed_sum(np.stack([F(ora, [0, 0, 0, 2]), F(ora, [0, 3, 0, 3])]), [1, 1]), [8])
+
+
+# ---- prove -> verify round trips on the reference's own test inputs ------------------
+SUMCHECK_INPUTS = [
+    [0, 0, 2, 7, 3, 3, 6, 11],
+    [0, 0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0],
+    [1, 3, 5, 7, 2, 4, 6, 8, 3, 5, 7, 9, 4, 6, 8, 10],
+]
+
+
+@pytest.mark.parametrize("vals", SUMCHECK_INPUTS)
+def test_sumcheck_prove_verify(ora, vals):  # sumcheck.rs:126-202
+    ev = F(ora, vals)
+    s, rp, ch = ora.sumcheck_prove(ev)
+    assert ora.sumcheck_verify(ev, s, rp)
+    bad = rp.copy()
+    bad[0, 0, 0] ^= np.uint64(1)
+    assert not ora.sumcheck_verify(ev, s, bad)
+
+
+def test_sumcheck_survey_restatement_vector(ora):
+    # independent python model of sumcheck.rs:127-136 input
+    s, rp, ch = ora.sumcheck_prove(F(ora, [0, 0, 2, 7, 3, 3, 6, 11]))
+    eq(ora, s, [32])
+    eq(ora, rp[0], [9, 23])
+    assert ints(ora, ch[0]) == [0x659f4be68a5057ee1a29039e2802f1822068341d5761b46feb4eb935379bfac4]
+    # and straight from hashlib: sha256(be32(32) || be32(9) || be32(23)) mod r
+    d = hashlib.sha256((32).to_bytes(32, "big") + (9).to_bytes(32, "big") + (23).to_bytes(32, "big")).digest()
+    assert ints(ora, ch[0]) == [int.from_bytes(d, "big") % R]
+
+
+@pytest.mark.parametrize("tables", [
+    [[3, 3, 5, 5], [0, 0, 0, 1]],
+    [[0, 0, 2, 7, 3, 3, 6, 11]],
+    [SUMCHECK_INPUTS[1]],
+    [SUMCHECK_INPUTS[2]],
+])
+def test_composed_prove_verify(ora, tables):  # composed_sumcheck.rs:143-241
+    t = np.stack([F(ora, v) for v in tables])
+    rp, ch = ora.composed_prove(t)
+    s = ora.composed_sum(t)
+    assert ora.composed_verify(t, s, rp)
+    bad = rp.copy()
+    bad[0, 0, 0] ^= np.uint64(1)
+    assert not ora.composed_verify(t, s, bad)
+
+
+def _gkr_example(ora):
+    # multi_composed_sumcheck.rs:266-311
+    add_i = F(ora, [4, 4, 7, 7, 4, 4, 7, 9])
+    mul_i = F(ora, [3, 3, 3, 4, 3, 3, 5, 6])
+    w_b, w_c = F(ora, [0, 4]), F(ora, [0, 3])
+    two = F(ora, [2])[0]
+    lhs = [ora.mle_partial_evaluation(add_i, two, 0), ora.mle_add_distinct(w_b, w_c)]
+    rhs = [ora.mle_partial_evaluation(mul_i, two, 0), ora.mle_mul_distinct(w_b, w_c)]
+    return np.stack(lhs + rhs), [2, 2]
+
+
+def _multi_cases(ora):
+    p1, p2 = F(ora, [0, 0, 0, 2]), F(ora, [0, 3, 0, 3])
+    return [
+        (np.stack([p1, p2]), [1, 1]),
+        (np.stack([p1, p2, p2]), [1, 1, 1]),
+        (np.stack([p1, p2, p2, p1]), [2, 2]),
+        _gkr_example(ora),
+    ]
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_multi_composed_prove_verify(ora, case):  # multi_composed_sumcheck.rs:217-311
+    tables, ts = _multi_cases(ora)[case]
+    s = ora.multi_composed_sum(tables, ts)
+    rps, ch = ora.multi_composed_prove(tables, ts, s, partial=False)
+    assert ora.multi_composed_verify(tables, ts, s, rps) == 1
+    # prove_partial starts from a transcript without the table bytes -> different challenges
+    rps_p, ch_p = ora.multi_composed_prove(tables, ts, s, partial=True)
+    assert not np.array_equal(ch, ch_p)
+    assert ora.sparse_to_bytes(rps[0]) == ora.sparse_to_bytes(rps_p[0])   # round 1 poly is challenge-free
+
+
+# ---- sparse_univariate.rs tests ------------------------------------------------------------
+def test_sparse_interpolation(ora):  # :361-384
+    s = ora.sparse_interpolation(F(ora, [1, 2, 4]), F(ora, [2, 3, 11]))
+    assert s.monomials() == [(3, 0), ((-2) % R, 1), (1, 2)]
+    eq(ora, ora.sparse_evaluate(s, F(ora, [2])[0]), [3])
+
+
+def test_sparse_interpolation_1(ora):  # :387-448
+    def interp(pts):
+        return ora.sparse_interpolation(F(ora, [p[0] for p in pts]), F(ora, [p[1] for p in pts]))
+    eq(ora, ora.sparse_evaluate(interp([(0, 0), (1, 2)]), F(ora, [2])[0]), [4])
+    eq(ora, ora.sparse_evaluate(interp([(0, 5), (1, 7), (2, 13)]), F(ora, [2])[0]), [13])
+    eq(ora, ora.sparse_evaluate(interp([(0, 12), (1, 48), (3, 3150), (4, 11772), (5, 33452), (8, 315020)]),
+                                F(ora, [1])[0]), [48])
+    eq(ora, ora.sparse_evaluate(interp([(0, 0), (1, 5), (2, 14)]), F(ora, [2])[0]), [14])
+    s5 = interp([(1, 6), (2, 11), (3, 18), (4, 27), (5, 38)])
+    assert s5.monomials() == [(3, 0), (2, 1), (1, 2)]      # zero x^3, x^4 coefficients dropped (:55)
+    # zero constant term dropped too: 2x
+    assert interp([(0, 0), (1, 2)]).monomials() == [(2, 1)]
+
+
+def test_sparse_addition_keeps_zero_sums(ora):  # :250-299 and Add semantics :159-203
+    a = ora.sparse_interpolation(F(ora, [0, 1]), F(ora, [5, 5]))          # 5
+    b = ora.sparse_interpolation(F(ora, [0, 1]), F(ora, [0, 2]))          # 2x
+    assert ora.sparse_add(a, b).monomials() == [(5, 0), (2, 1)]
+    c = ora.sparse_interpolation(F(ora, [0, 1, 2]), F(ora, [5, 10, 25]))  # 5 + 5x^2
+    d = ora.sparse_interpolation(F(ora, [0, 1, 2]), F(ora, [0, 4, 12]))   # 2x + 2x^2
+    assert ora.sparse_add(c, d).monomials() == [(5, 0), (2, 1), (7, 2)]
+    neg = ora.sparse_interpolation(F(ora, [0, 1]), F(ora, [0, -2]))       # -2x
+    assert ora.sparse_add(b, neg).monomials() == [(0, 1)]                  # zero coefficient KEPT
+    assert ora.sparse_to_bytes(ora.sparse_add(b, neg)) == bytes(32) + bytes(31) + b"\x01"
+
+
+# ---- kzg/src/utils.rs:73-187 ---------------------------------------------------------------------
+def test_eq_points(ora):
+    eq(ora, ora.kzg_eq_points(F(ora, [2, 3, 4])), [-6, 8, 9, -12, 12, -16, -18, 24])
+
+
+def test_poly_quotient_remainder(ora):
+    def quotient(ev):
+        one, zero = F(ora, [1])[0], F(ora, [0])[0]
+        f1, f0 = ora.mle_partial_evaluation(ev, one, 0), ora.mle_partial_evaluation(ev, zero, 0)
+        return [(a - b) % R for a, b in zip(ints(ora, f1), ints(ora, f0))]
+    assert quotient(F(ora, [0, 7, 0, 5, 0, 7, 4, 9])) == [0, 0, 4, 4]
+    assert quotient(F(ora, [0, 7, 20, 25])) == [20, 18]
+    assert quotient(F(ora, [180, 169])) == [(-11) % R]
+    eq(ora, ora.mle_partial_evaluation(F(ora, [0, 7, 0, 5, 0, 7, 4, 9]), F(ora, [5])[0], 0), [0, 7, 20, 25])
+    eq(ora, ora.mle_partial_evaluation(F(ora, [0, 7, 20, 25]), F(ora, [9])[0], 0), [180, 169])
+    eq(ora, ora.mle_partial_evaluation(F(ora, [180, 169]), F(ora, [6])[0], 0), [114])
+
+
+# ---- domain.rs:154-168, dense_univariate.rs:464-509 ----------------------------------------------------
+def test_domain_roots(ora):
+    w = ora.fr_get_root_of_unity(16)
+    assert ints(ora, w) == [14788168760825820622209131888203028446852016562542525606630160374691593895118]
+    assert ints(ora, ora.fr_inv(w)) == [26753076894533791554649012143113393549300550745003194222677083919072199473480]
+
+
+def test_dense_mul_kats(ora):
+    eq(ora, ora.dense_mul(F(ora, [1, 3, 2]), F(ora, [3, 2])), [3, 11, 12, 4])
+    eq(ora, ora.dense_mul(F(ora, [6, 5, 3]), F(ora, [5, 4, 2])), [30, 49, 47, 22, 6])
+    eq(ora, ora.dense_mul(F(ora, [1, 3, 2]), F(ora, [3])), [3, 9, 6])
+
+
+def test_ntt_multiply_matches_schoolbook_and_roundtrip(ora):
+    eq(ora, ora.univariate_multiply(F(ora, [1, 3, 2]), F(ora, [3, 2])), [3, 11, 12, 4])
+    eq(ora, ora.univariate_multiply(F(ora, [6, 5, 3]), F(ora, [5, 4, 2])), [30, 49, 47, 22, 6])
+    a, b = ora.random_fr(37, 11), ora.random_fr(50, 12)
+    assert np.array_equal(ora.univariate_multiply(a, b), ora.dense_mul(a, b))
+    x = ora.random_fr(64, 13)
+    assert np.array_equal(ora.domain_ifft(ora.domain_fft(x, 64), 64), x)
+    # NTT definition: out[i] = sum_j x[j] w^(ij)
+    xs = ints(ora, x[:8])
+    w = ints(ora, ora.fr_get_root_of_unity(8))[0]
+    want = [sum(xs[j] * pow(w, i * j, R) for j in range(8)) % R for i in range(8)]
+    assert ints(ora, ora.domain_fft(x[:8], 8)) == want
+
+
+# ---- G1 / KZG ----------------------------------------------------------------------------------------------
+def test_g1_group_law(ora):
+    g = ora.g1_generator()
+    assert ora.g1_is_on_curve(ora.g1_to_affine(g))
+    assert ora.g1_affine_ints(ora.g1_to_affine(ora.g1_add(ora.g1_mul_int(g, R - 1), g)))[2]   # r*G = identity
+    rG = ora.g1_to_affine(ora.g1_mul_int(g, R - 1))
+    x, y, inf = ora.g1_affine_ints(rG)
+    gx, gy, _ = ora.g1_affine_ints(ora.g1_to_affine(g))
+    assert (x, y) == (gx, (-gy) % Q) and not inf               # (r-1)G = -G
+    a, b = ora.g1_mul_int(g, 1234567), ora.g1_mul_int(g, 7654321)
+    assert ora.g1_affine_ints(ora.g1_to_affine(ora.g1_add(a, b))) == \
+        ora.g1_affine_ints(ora.g1_to_affine(ora.g1_mul_int(g, 1234567 + 7654321)))
+    assert ora.g1_affine_ints(ora.g1_to_affine(ora.g1_add(a, a))) == \
+        ora.g1_affine_ints(ora.g1_to_affine(ora.g1_mul_int(g, 2 * 1234567)))
+    neg_a = ora.g1_mul_int(g, R - 1234567)
+    assert ora.g1_affine_ints(ora.g1_to_affine(ora.g1_add(a, neg_a)))[2]
+    assert ora.g1_affine_ints(ora.g1_to_affine(ora.g1_add(a, ora.g1_identity()))) == \
+        ora.g1_affine_ints(ora.g1_to_affine(a))
+
+
+def test_multilinear_kzg_commit_identity(ora):
+    # multilinear_kzg.rs:133-148 data: commit == p(tau) * G ; SURVEY 8c restatement vector (28 * G)
+    vals = [0, 7, 0, 5, 0, 7, 4, 9]
+    tau = F(ora, [2, 3, 4])
+    srs = ora.kzg_multilinear_srs_g1(tau)
+    c = ora.kzg_commitment(F(ora, vals), srs, True)
+    eq(ora, ora.mle_evaluation(F(ora, vals), tau), [28])
+    x, y, inf = ora.g1_affine_ints(ora.g1_to_affine(c))
+    assert (x, y, inf) == ora.g1_affine_ints(ora.g1_to_affine(ora.g1_mul_int(ora.g1_generator(), 28)))
+    assert x == 0x16ad11e5d15f77c1143b1697344911b9c590110fdd8dd09df2e58bfd757269169deefe8be3544d4e049fb3776fb0bcfb
+    assert y == 0x0f5c8be5f27fc19eee337785e43d18414a8ff04995230f04509800252164cf47887a4a1864f18288652196af6272e7f6
+    with pytest.raises(AssertionError):
+        ora.kzg_commitment(F(ora, vals[:4]), srs, True)
+
+
+def test_multilinear_kzg_2_and_pippenger(ora):
+    # multilinear_kzg.rs:151-197 data
+    vals = [0, 0, 0, 2, 0, 0, 10, 12, 0, -12, 4, -6, 0, -12, 14, 4]
+    tau = F(ora, [12, 9, 28, 40])
+    srs = ora.kzg_multilinear_srs_g1(tau)
+    c = ora.kzg_commitment(F(ora, vals), srs, True)
+    p_tau = ints(ora, ora.mle_evaluation(F(ora, vals), tau))[0]
+    want = ora.g1_affine_ints(ora.g1_to_affine(ora.g1_mul_int(ora.g1_generator(), p_tau)))
+    assert ora.g1_affine_ints(ora.g1_to_affine(c)) == want
+    aff = ora.g1_batch_to_affine(srs)
+    assert ora.g1_affine_ints(ora.g1_to_affine(ora.msm_pippenger(F(ora, vals), aff))) == want
+
+
+def test_univariate_kzg_commit_identity(ora):
+    # univariate_kzg.rs:111-129 data: tau = 10, poly 1+2x+3x^2+4x^3+5x^4
+    tau = F(ora, [10])[0]
+    srs = ora.kzg_univariate_srs_g1(tau, 4)
+    coeffs = F(ora, [1, 2, 3, 4, 5])
+    c = ora.kzg_commitment(coeffs, srs, False)
+    p_tau = sum(k * 10 ** i for i, k in enumerate([1, 2, 3, 4, 5]))
+    eq(ora, ora.dense_evaluate(coeffs, tau), [p_tau])
+    assert ora.g1_affine_ints(ora.g1_to_affine(c)) == \
+        ora.g1_affine_ints(ora.g1_to_affine(ora.g1_mul_int(ora.g1_generator(), p_tau)))
+    # shorter polynomial than SRS is allowed (assert commented out, univariate_kzg.rs:43-48) ...
+    ora.kzg_commitment(coeffs[:3], srs, False)
+    # ... longer one indexes past the end (what the unregistered bench would hit)
+    with pytest.raises(IndexError):
+        ora.kzg_commitment(F(ora, [1, 2, 3, 4, 5, 6]), srs, False)
+
+
+def test_srs_with_identity_points(ora):
+    # kzg/benches/multilinear_kzg_benchmark.rs:17-22 uses tau = (0,1,2,...): eq-scalars that are 0 => G*0 = identity
+    tau = F(ora, [0, 1, 2])
+    srs = ora.kzg_multilinear_srs_g1(tau)
+    aff = ora.g1_batch_to_affine(srs)
+    assert int(aff[:, 12].sum()) > 0
+    vals = list(range(8))
+    c = ora.kzg_commitment(F(ora, vals), srs, True)
+    p_tau = ints(ora, ora.mle_evaluation(F(ora, vals), tau))[0]
+    assert ora.g1_affine_ints(ora.g1_to_affine(c)) == \
+        ora.g1_affine_ints(ora.g1_to_affine(ora.g1_mul_int(ora.g1_generator(), p_tau)))
+    assert ora.g1_affine_ints(ora.g1_to_affine(ora.msm_pippenger(F(ora, vals), aff))) == \
+        ora.g1_affine_ints(ora.g1_to_affine(c))
