@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X proving hot path.
+
+Metric (BASELINE.json): field-evals/s of the sumcheck prover over a 24-variable multilinear
+(2^24 BLS12-381 Fr evaluations) per GPU.  A "step" is one full pass of the hot path over one
+table: Sumcheck::poly_sum + Sumcheck::prove (sumcheck/benches/sumcheck_benchmark.rs:13-22 minus
+the verifier) -- fused half-sums + fold kernels with the Fiat-Shamir transcript on the device --
+with the table already resident in HBM.  value = (tables' entries consumed by all ranks) / time.
+
+Extra objects on the JSON line: `roofline` for the dominant kernel (the fused fold) from HIP
+events on the launch stream, and `cpu_baseline`: the CPU oracle (a C port of the reference
+algorithm, single-threaded like the reference) timed on rank 0 at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=24, help="log2 of the per-GPU table size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import zk_cryptography_amd as zk
+    from zk_cryptography_amd import _native as N
+
+    n = 1 << args.log_n
+    g = torch.Generator(device="cuda").manual_seed(0x5EED + rank)
+    # synthetic random field elements: four limbs each < 2^62, i.e. uniform residues below 2^254 < r
+    table = torch.randint(0, 2 ** 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    poly = zk.Multilinear(table)
+
+    def step():
+        sc = zk.Sumcheck(poly)
+        sc.poly_sum()
+        return sc.prove()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- roofline of the dominant kernel: HIP events around every fold launch on the launch stream
+    ctx = N.Context.get()
+    import ctypes as C
+    N.check(N.lib().zkhip_profile_enable(ctx.handle, 1), "profile_enable")
+    prof_steps = max(1, min(args.steps, 5))
+    for _ in range(prof_steps):
+        step()
+    ms, cnt, by = C.c_double(), C.c_uint64(), C.c_double()
+    N.check(N.lib().zkhip_profile_read(ctx.handle, b"fold_sums", C.byref(ms), C.byref(cnt), C.byref(by)), "profile_read")
+    N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
+    achieved = by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "fold_kernel<true> (fused fold + next-round half sums)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "launches": int(cnt.value), "avg_launch_us": round(1e3 * ms.value / max(1, cnt.value), 2),
+                "algorithmic_bytes_per_launch": "48 B x table entries (read 32n + write 16n)"}
+
+    # ---- CPU baseline: the oracle's single-threaded restatement of poly_sum + prove, rank 0 only
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as ora
+        cpu_log = min(args.log_n, 24)
+        ev = table[: 1 << cpu_log].cpu().numpy().view(np.uint64)
+        t1 = time.perf_counter()
+        ora.sumcheck_prove(ev)
+        cdt = time.perf_counter() - t1
+        cpu = {"value": round((1 << cpu_log) / cdt, 1), "unit": "field-evals/s", "cores": 1, "kind": "port",
+               "sample": "1 run of the C oracle's Sumcheck poly_sum+prove (2 Montgomery muls per fold output, as "
+                         "evaluation_form.rs:133) on the same 2^%d-entry table, %.2f s" % (cpu_log, cdt)}
+
+    if rank == 0:
+        total_evals = float(n) * world * args.steps
+        out = {
+            "metric": "field-evals/s (sumcheck prover, 2^%d evals per GPU)" % args.log_n,
+            "value": round(total_evals / dt, 1),
+            "unit": "field-evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (BLS12-381 Fr, 255-bit Montgomery)",
+            "data": "synthetic",
+            "config": {"workload": "24-var multilinear sumcheck prover (poly_sum + prove), BLS12-381 Fr" if args.log_n == 24
+                       else "%d-var multilinear sumcheck prover" % args.log_n,
+                       "evals_per_gpu": n, "sharding": "independent tables per GPU" if world > 1 else "single GPU"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+/*
+ * zkhip.h -- C ABI of libzkhip.so, the MI355X (gfx950) proving hot path behind the
+ * polynomial::Multilinear / sumcheck prover / kzg::commitment / Domain surfaces of
+ * aagbotemi/zk-cryptography.
+ *
+ * The reference has no FFI of its own (pure Rust traits); each entry point below is
+ * what a Rust shim implementing the cited trait method would bind.
+ *
+ * Conventions
+ *   - Fr element  = uint64_t[4]  little-endian limbs, Montgomery form (R = 2^256 mod r):
+ *                   the in-memory form of ark_ff Fp<MontBackend<FrConfig,4>,4> (BLS12-381 Fr).
+ *   - Fq element  = uint64_t[6]  same, R = 2^384 mod p.
+ *   - G1 affine   = uint64_t[12] (x[6], y[6]) + one uint8_t infinity flag per point in a
+ *                   separate array (what CurveGroup::normalize_batch yields).
+ *   - Pointers named d_* are DEVICE pointers (hipMalloc / torch CUDA tensor storage), h_* are
+ *     host pointers.  The library never takes ownership of caller buffers.
+ *   - Every call is enqueued on the context's HIP stream; calls that return values to h_*
+ *     buffers synchronise that stream before returning, the others do not.
+ *   - Return value: 0 on success, negative zkhip_status otherwise.  Shape errors that the
+ *     reference raises as assert!/panic! come back as ZKHIP_ERR_SHAPE / ZKHIP_ERR_INDEX.
+ *   - One context per host thread (or external locking); contexts are independent.
+ */
+#ifndef ZKHIP_H
+#define ZKHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ZKHIP_OK = 0,
+    ZKHIP_ERR_HIP = -1,      /* a HIP runtime call failed (zkhip_last_hip_error) */
+    ZKHIP_ERR_SHAPE = -2,    /* assert!/assert_eq! on sizes in the reference */
+    ZKHIP_ERR_INDEX = -3,    /* out-of-bounds index panic in the reference */
+    ZKHIP_ERR_ARG = -4,      /* null pointer / unsupported argument */
+    ZKHIP_ERR_NOMEM = -5
+} zkhip_status;
+
+typedef struct zkhip_ctx zkhip_ctx;
+
+/* ---- context / memory ------------------------------------------------------------ */
+int zkhip_version(void);
+const char *zkhip_status_string(int status);
+/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = create one. */
+int zkhip_ctx_create(zkhip_ctx **out, int device, void *stream);
+int zkhip_ctx_destroy(zkhip_ctx *ctx);
+int zkhip_ctx_set_stream(zkhip_ctx *ctx, void *stream);
+int zkhip_ctx_synchronize(zkhip_ctx *ctx);
+int zkhip_last_hip_error(zkhip_ctx *ctx);
+/* device memory for hosts that do not bring their own allocator */
+int zkhip_malloc(zkhip_ctx *ctx, void **d_ptr, size_t bytes);
+int zkhip_free(zkhip_ctx *ctx, void *d_ptr);
+int zkhip_memcpy_h2d(zkhip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int zkhip_memcpy_d2h(zkhip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* stream-ordered timing of the dominant kernel (used by bench.py's roofline leg):
+ * when enabled, every fold launch is bracketed by HIP events on the context's stream. */
+int zkhip_profile_enable(zkhip_ctx *ctx, int enable);
+int zkhip_profile_read(zkhip_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches, double *bytes);
+
+/* ---- Multilinear (polynomial/src/multilinear/evaluation_form.rs) -------------------- */
+/* MultilinearTrait::partial_evaluation (interface.rs:9-13, evaluation_form.rs:123-141):
+ * d_out[n/2] = fold of variable var_index at point r.  r may live on the host (h_r) or on the
+ * device (d_r, e.g. a challenge produced by the transcript); exactly one is non-NULL. */
+int zkhip_mle_partial_evaluation(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint64_t *h_r,
+                                 const uint64_t *d_r, uint32_t var_index, uint64_t *d_out);
+/* MultilinearTrait::partial_evaluations (evaluation_form.rs:143-159): successive folds; d_out must hold
+ * n >> n_pts elements.  h_pts: n_pts x 4. */
+int zkhip_mle_partial_evaluations(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint64_t *h_pts,
+                                  const uint32_t *h_var_indices, size_t n_pts, uint64_t *d_out);
+/* MultilinearTrait::evaluation (evaluation_form.rs:162-175): h_out[4]. n_pts must equal log2(n). */
+int zkhip_mle_evaluation(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint64_t *h_pts, size_t n_pts,
+                         uint64_t *h_out);
+/* split_poly_into_two_and_sum_each_part (:68-74) and sum_over_the_boolean_hypercube (:80-84) /
+ * Sumcheck::poly_sum (sumcheck.rs:25-27): h_out[12] = (lower-half sum, upper-half sum, total). */
+int zkhip_mle_half_sums(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, uint64_t *h_out);
+/* add_distinct / mul_distinct (:28-52): d_out[na*nb] */
+int zkhip_mle_add_distinct(zkhip_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb,
+                           uint64_t *d_out);
+int zkhip_mle_mul_distinct(zkhip_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb,
+                           uint64_t *d_out);
+/* Add / Sub / Mul<F> (:178-251): op 0 add, 1 sub (d_b: n elements), 2 scale (h_scalar[4]) */
+int zkhip_mle_elementwise(zkhip_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b,
+                          const uint64_t *h_scalar, size_t n, uint64_t *d_out);
+/* Multilinear::to_bytes (:54-62): 32 big-endian canonical bytes per element into d_out_bytes[32 n] */
+int zkhip_mle_to_bytes(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, uint8_t *d_out_bytes);
+
+/* ---- basic sumcheck prover (sumcheck/src/sumcheck.rs:25-61) -------------------------- */
+/* Sumcheck::prove (sumcheck.rs:29-61).  Inputs:
+ *   h_claimed_sum[4]     `self.sum` as the caller holds it (what poly_sum() stored, or the default
+ *                        zero): the transcript absorbs exactly this.  NULL = absorb the true sum,
+ *                        computed on the device in the same pass.
+ *   h_first_half_sums[8] optional (lower, upper) half sums of the table as returned by
+ *                        zkhip_mle_half_sums, so that poly_sum() + prove() stream the table once
+ *                        for the sum instead of twice.  NULL = computed here.
+ * Host outputs: h_sum[4] (the absorbed sum); h_round_polys[n_vars*2*4] (the Vec<Multilinear> of 2
+ * evaluations each, :11-15); h_challenges[n_vars*4].  d_evals is not modified. */
+int zkhip_sumcheck_prove(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint64_t *h_claimed_sum,
+                         const uint64_t *h_first_half_sums, uint64_t *h_sum, uint64_t *h_round_polys,
+                         uint64_t *h_challenges);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -75,34 +75,40 @@ static void m_sub(uint64_t *o, const uint64_t *a, const uint64_t *b, const mont_
     if (sub_n(t, a, b, M->n)) add_n(t, t, M->p, M->n);
     memcpy(o, t, 8 * M->n);
 }
-/* CIOS Montgomery product: o = a*b*R^-1 mod p, fully reduced. */
-static void m_mul(uint64_t *o, const uint64_t *a, const uint64_t *b, const mont_t *M) {
-    const int n = M->n;
-    uint64_t t[8] = {0};
-    for (int i = 0; i < n; ++i) {
-        uint64_t c = 0;
-        for (int j = 0; j < n; ++j) {
-            u128 s = (u128)a[j] * b[i] + t[j] + c;
-            t[j] = (uint64_t)s;
-            c = (uint64_t)(s >> 64);
-        }
-        u128 s = (u128)t[n] + c;
-        t[n] = (uint64_t)s;
-        t[n + 1] = (uint64_t)(s >> 64);
-        uint64_t m = t[0] * M->inv;
-        s = (u128)m * M->p[0] + t[0];
-        c = (uint64_t)(s >> 64);
-        for (int j = 1; j < n; ++j) {
-            s = (u128)m * M->p[j] + t[j] + c;
-            t[j - 1] = (uint64_t)s;
-            c = (uint64_t)(s >> 64);
-        }
-        s = (u128)t[n] + c;
-        t[n - 1] = (uint64_t)s;
-        t[n] = t[n + 1] + (uint64_t)(s >> 64);
+/* CIOS Montgomery product: o = a*b*R^-1 mod p, fully reduced.  Fixed-width bodies so the
+ * compiler unrolls them (this is also the CPU baseline; keep it an honest scalar port). */
+#define DEFINE_MONT_MUL(NAME, NL)                                                              \
+    static inline void NAME(uint64_t *o, const uint64_t *a, const uint64_t *b, const mont_t *M) { \
+        uint64_t t[NL + 2] = {0};                                                              \
+        for (int i = 0; i < NL; ++i) {                                                         \
+            uint64_t c = 0;                                                                    \
+            for (int j = 0; j < NL; ++j) {                                                     \
+                u128 s = (u128)a[j] * b[i] + t[j] + c;                                         \
+                t[j] = (uint64_t)s;                                                            \
+                c = (uint64_t)(s >> 64);                                                       \
+            }                                                                                  \
+            u128 s = (u128)t[NL] + c;                                                          \
+            t[NL] = (uint64_t)s;                                                               \
+            t[NL + 1] = (uint64_t)(s >> 64);                                                   \
+            uint64_t m = t[0] * M->inv;                                                        \
+            s = (u128)m * M->p[0] + t[0];                                                      \
+            c = (uint64_t)(s >> 64);                                                           \
+            for (int j = 1; j < NL; ++j) {                                                     \
+                s = (u128)m * M->p[j] + t[j] + c;                                              \
+                t[j - 1] = (uint64_t)s;                                                        \
+                c = (uint64_t)(s >> 64);                                                       \
+            }                                                                                  \
+            s = (u128)t[NL] + c;                                                               \
+            t[NL - 1] = (uint64_t)s;                                                           \
+            t[NL] = t[NL + 1] + (uint64_t)(s >> 64);                                           \
+        }                                                                                      \
+        if (t[NL] || geq(t, M->p, NL)) sub_n(t, t, M->p, NL);                                  \
+        for (int i = 0; i < NL; ++i) o[i] = t[i];                                              \
     }
-    if (t[n] || geq(t, M->p, n)) sub_n(t, t, M->p, n);
-    memcpy(o, t, 8 * n);
+DEFINE_MONT_MUL(m_mul4, 4)
+DEFINE_MONT_MUL(m_mul6, 6)
+static inline void m_mul(uint64_t *o, const uint64_t *a, const uint64_t *b, const mont_t *M) {
+    if (M->n == 4) m_mul4(o, a, b, M); else m_mul6(o, a, b, M);
 }
 static int m_is_zero(const uint64_t *a, int n) {
     uint64_t x = 0;
@@ -137,7 +143,7 @@ static void m_from_canonical(uint64_t *o, const uint64_t *a, const mont_t *M) { 
 /* ---- Fr ---------------------------------------------------------------- */
 void ora_fr_add(fr_t *o, const fr_t *a, const fr_t *b) { m_add(o->l, a->l, b->l, &FR); }
 void ora_fr_sub(fr_t *o, const fr_t *a, const fr_t *b) { m_sub(o->l, a->l, b->l, &FR); }
-void ora_fr_mul(fr_t *o, const fr_t *a, const fr_t *b) { m_mul(o->l, a->l, b->l, &FR); }
+void ora_fr_mul(fr_t *o, const fr_t *a, const fr_t *b) { m_mul4(o->l, a->l, b->l, &FR); }
 void ora_fr_neg(fr_t *o, const fr_t *a) {
     fr_t z = {{0, 0, 0, 0}};
     m_sub(o->l, z.l, a->l, &FR);
@@ -200,7 +206,7 @@ int ora_fr_get_root_of_unity(fr_t *o, uint64_t n) {
 /* ---- Fq ---------------------------------------------------------------- */
 void ora_fq_add(fq_t *o, const fq_t *a, const fq_t *b) { m_add(o->l, a->l, b->l, &FQ); }
 void ora_fq_sub(fq_t *o, const fq_t *a, const fq_t *b) { m_sub(o->l, a->l, b->l, &FQ); }
-void ora_fq_mul(fq_t *o, const fq_t *a, const fq_t *b) { m_mul(o->l, a->l, b->l, &FQ); }
+void ora_fq_mul(fq_t *o, const fq_t *a, const fq_t *b) { m_mul6(o->l, a->l, b->l, &FQ); }
 int ora_fq_inv(fq_t *o, const fq_t *a) { return m_inv(o->l, a->l, &FQ); }
 void ora_fq_to_canonical(uint64_t out[6], const fq_t *a) { m_to_canonical(out, a->l, &FQ); }
 void ora_fq_from_canonical(fq_t *o, const uint64_t in[6]) { m_from_canonical(o->l, in, &FQ); }

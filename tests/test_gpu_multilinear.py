@@ -1,0 +1,164 @@
+"""GPU parity: polynomial::Multilinear on the HIP path vs the CPU oracle (bit-exact), through
+the C ABI.  Test names follow polynomial/src/multilinear/evaluation_form.rs `mod tests`."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def zk():
+    import zk_cryptography_amd as z
+    return z
+
+
+def F(zk, vals):
+    return zk.Fr.from_ints(vals)
+
+
+def ints(zk, a):
+    return zk.Fr.to_ints(a)
+
+
+def test_add_mul_distinct(zk):
+    p1, p2 = zk.Multilinear(F(zk, [0, 0, 2, 2])), zk.Multilinear(F(zk, [0, 3, 0, 3]))
+    assert ints(zk, p1.add_distinct(p2).to_numpy()) == [0, 3, 0, 3, 0, 3, 0, 3, 2, 5, 2, 5, 2, 5, 2, 5]
+    assert ints(zk, p1.mul_distinct(p2).to_numpy()) == [0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 0, 6, 0, 6, 0, 6]
+
+
+def test_partial_evaluation_1(zk):
+    out = zk.Multilinear(F(zk, [3, 1, 2, 5])).partial_evaluation(F(zk, [5])[0], 0)
+    assert ints(zk, out.to_numpy()) == [(-2) % R, 21]
+
+
+def test_partial_evaluation_2(zk):
+    poly = zk.Multilinear(F(zk, [3, 9, 7, 13, 6, 12, 10, 18]))
+    pts = F(zk, [3, 2])
+    for r, k, want in [(2, 0, 57), (3, 1, 72), (1, 2, 38)]:
+        assert ints(zk, poly.partial_evaluation(F(zk, [r])[0], k).evaluation(pts)) == [want]
+
+
+def test_evaluation_1_and_2(zk):
+    assert ints(zk, zk.Multilinear(F(zk, [3, 1, 2, 5])).evaluation(F(zk, [5, 6]))) == [136]
+    assert ints(zk, zk.Multilinear(F(zk, [3, 9, 7, 13, 6, 12, 10, 18])).evaluation(F(zk, [2, 3, 1]))) == [39]
+    assert ints(zk, zk.Multilinear(F(zk, [0, 0, 0, 3, 0, 0, 2, 5])).evaluation(F(zk, [2, 3, 4]))) == [48]
+
+
+def test_split_poly_into_two_and_sum_each_part(zk):
+    assert ints(zk, zk.Multilinear(F(zk, [0, 0, 0, 2, 2, 2, 2, 4])).split_poly_into_two_and_sum_each_part().to_numpy()) == [2, 10]
+    assert ints(zk, zk.Multilinear(F(zk, [0, 0, 2, 7, 3, 3, 6, 11])).split_poly_into_two_and_sum_each_part().to_numpy()) == [9, 23]
+
+
+def test_sum_over_boolean_hypercube(zk):
+    assert ints(zk, zk.Multilinear(F(zk, [1, 2, 3, 4, 5, 6, 7, 8])).sum_over_the_boolean_hypercube()) == [36]
+
+
+def test_poly_subtraction_add_scale(zk):
+    a = zk.Multilinear(F(zk, [0, 0, 0, 5, 4, 4, 7, 12]))
+    b = zk.Multilinear(F(zk, [0, 0, 0, 2, 0, 0, 1, 3]))
+    assert ints(zk, (a - b).to_numpy()) == [0, 0, 0, 3, 4, 4, 6, 9]
+    assert ints(zk, (a + b).to_numpy()) == [0, 0, 0, 7, 4, 4, 8, 15]
+    assert ints(zk, (b - a).to_numpy()) == [0, 0, 0, (-3) % R, (-4) % R, (-4) % R, (-6) % R, (-9) % R]
+    assert ints(zk, (a * F(zk, [3])[0]).to_numpy()) == [0, 0, 0, 15, 12, 12, 21, 36]
+
+
+def test_shape_errors_like_the_reference(zk):
+    with pytest.raises(AssertionError):
+        zk.Multilinear(F(zk, [1, 2, 3]))                                       # evaluation_form.rs:16-20
+    with pytest.raises(AssertionError):
+        zk.Multilinear(F(zk, [1, 2, 3, 4])).evaluation(F(zk, [5]))             # :163-167
+    with pytest.raises(AssertionError):
+        zk.Multilinear(F(zk, [1, 2, 3, 4])).partial_evaluation(F(zk, [5])[0], 2)   # utils.rs:31-34
+    with pytest.raises(AssertionError):
+        zk.Multilinear(F(zk, [1, 2, 3, 4])).partial_evaluations(F(zk, [5, 6]), [0])  # :146-152
+    with pytest.raises(AssertionError):
+        zk.Multilinear(F(zk, [7])).partial_evaluation(F(zk, [5])[0], 0)        # n must be even
+
+
+def test_to_bytes(zk, ora):
+    a = ora.random_fr(64, 5)
+    assert zk.Multilinear(a).to_bytes() == ora.mle_to_bytes(a)
+    assert zk.Multilinear(F(zk, [1, 100])).to_bytes() == bytes(31) + b"\x01" + bytes(31) + bytes([100])
+
+
+# ---- random parity vs the oracle ------------------------------------------------------------
+@pytest.mark.parametrize("log_n", [1, 2, 5, 9, 10, 11, 13, 16])
+def test_fold_every_variable_matches_oracle(zk, ora, log_n):
+    n = 1 << log_n
+    a = ora.random_fr(n, 100 + log_n)
+    r = ora.random_fr(1, 7)[0]
+    poly = zk.Multilinear(a)
+    for k in sorted({0, 1, log_n // 2, log_n - 1} & set(range(log_n))):
+        want = ora.mle_partial_evaluation(a, r, k)
+        got = poly.partial_evaluation(r, k).to_numpy()
+        assert np.array_equal(got, want), "variable %d" % k
+
+
+def test_fold_edge_field_values(zk, ora):
+    # r in {0, 1, r-1}; table entries in {0, r-1, 1}: exercises the conditional subtract / borrow paths
+    vals = [0, R - 1, 1, R - 1, R - 1, 0, 2, R - 2] * 8
+    a = F(zk, vals)
+    for rv in [0, 1, R - 1, 2, (R + 1) // 2]:
+        r = F(zk, [rv])[0]
+        assert np.array_equal(zk.Multilinear(a).partial_evaluation(r, 0).to_numpy(), ora.mle_partial_evaluation(a, r, 0))
+
+
+@pytest.mark.parametrize("log_n", [1, 3, 10, 11, 12, 17])
+def test_evaluation_matches_oracle(zk, ora, log_n):
+    n = 1 << log_n
+    a = ora.random_fr(n, 200 + log_n)
+    pts = ora.random_fr(log_n, 9)
+    assert np.array_equal(zk.Multilinear(a).evaluation(pts), ora.mle_evaluation(a, pts))
+
+
+def test_partial_evaluations_matches_oracle(zk, ora):
+    a = ora.random_fr(1 << 12, 77)
+    pts = ora.random_fr(5, 78)
+    for idx in ([0, 0, 0, 0, 0], [3, 1, 0, 2, 1], [11, 10, 9, 8, 7], [0, 5, 0, 5, 0]):
+        want = ora.mle_partial_evaluations(a, pts, idx)
+        got = zk.Multilinear(a).partial_evaluations(pts, idx).to_numpy()
+        assert np.array_equal(got, want), idx
+    assert np.array_equal(zk.Multilinear(a).partial_evaluations(pts[:0], []).to_numpy(), a)
+
+
+@pytest.mark.parametrize("log_n", [1, 4, 10, 11, 15, 19])
+def test_half_sums_match_oracle(zk, ora, log_n):
+    a = ora.random_fr(1 << log_n, 300 + log_n)
+    m = zk.Multilinear(a)
+    assert np.array_equal(m.split_poly_into_two_and_sum_each_part().to_numpy(), ora.mle_half_sums(a))
+    assert np.array_equal(m.sum_over_the_boolean_hypercube(), ora.mle_sum(a))
+
+
+def test_distinct_random(zk, ora):
+    a, b = ora.random_fr(32, 1), ora.random_fr(64, 2)
+    assert np.array_equal(zk.Multilinear(a).add_distinct(zk.Multilinear(b)).to_numpy(), ora.mle_add_distinct(a, b))
+    assert np.array_equal(zk.Multilinear(a).mul_distinct(zk.Multilinear(b)).to_numpy(), ora.mle_mul_distinct(a, b))
+
+
+# ---- full-size (BASELINE config 2: 2^24 evals) through size-independent properties ------------
+def test_fold_2_24_linearity_and_spot_checks(zk, ora):
+    import torch
+    n = 1 << 24
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    t = torch.randint(0, 2 ** 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)   # limbs < 2^62: valid residues
+    poly = zk.Multilinear(t)
+    r = ora.random_fr(1, 99)[0]
+    folded = poly.partial_evaluation(r, 0)
+    # spot-check 4096 scattered outputs against the oracle's scalar formula
+    idx = torch.randint(0, n // 2, (4096,), generator=torch.Generator().manual_seed(5))
+    lo = t[idx.cuda()].cpu().numpy().view(np.uint64)
+    hi = t[(idx + n // 2).cuda()].cpu().numpy().view(np.uint64)
+    got = folded.evaluations[idx.cuda()].cpu().numpy().view(np.uint64)
+    pair = np.concatenate([lo, hi])          # fold of [lo.., hi..] at variable 0 pairs lo[i] with hi[i]
+    assert np.array_equal(got, ora.mle_partial_evaluation(pair, r, 0))
+    # sum is preserved by the fold identity: sum(fold(f, r)) = (1-r)*S_lo + r*S_hi
+    hs = poly._half_sums()
+    one = ora.fr_from_ints([1])[0]
+    want = ora.fr_add(ora.fr_mul(ora.fr_sub(one, r), hs[0]), ora.fr_mul(r, hs[1]))
+    assert np.array_equal(folded.sum_over_the_boolean_hypercube(), want)
+    # evaluation at a boolean point returns the table entry (idempotence of the MLE on the hypercube)
+    j = 0xABCDE5
+    pt = ora.fr_from_ints([(j >> (23 - k)) & 1 for k in range(24)])
+    assert np.array_equal(poly.evaluation(pt), t[j].cpu().numpy().view(np.uint64))

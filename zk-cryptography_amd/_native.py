@@ -1,0 +1,98 @@
+"""ctypes loader for csrc/libzkhip.so (the C ABI of include/zkhip.h) + context handling.
+
+PyTorch supplies device memory (int64 CUDA tensors viewed as uint64 limbs), the HIP
+stream and torch.distributed; it is plumbing only -- all arithmetic happens in libzkhip.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libzkhip.so")
+
+ZKHIP_OK, ERR_HIP, ERR_SHAPE, ERR_INDEX, ERR_ARG, ERR_NOMEM = 0, -1, -2, -3, -4, -5
+
+
+class ZkhipError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "zkhip.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []) + ["libzkhip.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ZkhipError("libzkhip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.zkhip_status_string.restype = C.c_char_p
+    return _lib
+
+
+def check(status, what=""):
+    if status == ZKHIP_OK:
+        return
+    msg = lib().zkhip_status_string(status).decode()
+    if status == ERR_SHAPE:
+        raise AssertionError("%s: %s" % (what, msg))      # the reference panics (assert!/assert_eq!)
+    if status == ERR_INDEX:
+        raise IndexError("%s: %s" % (what, msg))
+    raise ZkhipError("%s: %s (status %d)" % (what, msg, status))
+
+
+class Context:
+    """One libzkhip context per (process, device), enqueueing on torch's current stream."""
+
+    _instances = {}
+
+    def __init__(self, device_index):
+        import torch
+        if not torch.cuda.is_available():
+            raise ZkhipError("no GPU visible: zk_cryptography_amd has no CPU fallback")
+        self.torch = torch
+        self.device = torch.device("cuda", device_index)
+        self.handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            check(lib().zkhip_ctx_create(C.byref(self.handle), C.c_int(device_index), C.c_void_p(stream)), "ctx_create")
+        self._stream = stream
+
+    @classmethod
+    def get(cls, device_index=None):
+        import torch
+        if device_index is None:
+            device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        ctx = cls._instances.get(device_index)
+        if ctx is None:
+            ctx = cls._instances[device_index] = Context(device_index)
+        ctx.sync_stream()
+        return ctx
+
+    def sync_stream(self):
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        if s != self._stream and s != 0:
+            check(lib().zkhip_ctx_set_stream(self.handle, C.c_void_p(s)), "set_stream")
+            self._stream = s
+
+    def synchronize(self):
+        check(lib().zkhip_ctx_synchronize(self.handle), "synchronize")
+
+
+def ptr(t):
+    """device pointer of a contiguous torch tensor"""
+    assert t.is_contiguous()
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,109 @@
+// ctx.hpp -- per-device context of libzkhip: stream, workspaces, event-based kernel timing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/zkhip.h"
+
+#define ZK_MAX_ROUNDS 40          /* tables up to 2^40 entries: far beyond 288 GB */
+#define ZK_MAX_PARTIALS 4096      /* (lo, hi) pairs: >= the largest grid any reducing kernel uses */
+
+// fixed carve-up of the small device scratch (offsets in uint64_t units)
+enum : size_t {
+    ZK_SMALL_R = 0,                                           // 4:  one field element (fold point / scalar)
+    ZK_SMALL_RES = 16,                                        // 16: small results
+    ZK_SMALL_STATE = 64,                                      // 64: SumcheckDev / transcript state
+    ZK_SMALL_PTS = 256,                                       // 4*ZK_MAX_ROUNDS evaluation points
+    ZK_SMALL_CHALLENGES = ZK_SMALL_PTS + 4 * ZK_MAX_ROUNDS,   // 4*ZK_MAX_ROUNDS
+    ZK_SMALL_ROUNDPOLYS = ZK_SMALL_CHALLENGES + 4 * ZK_MAX_ROUNDS,   // up to 8 coefficients x 2 words... 64*ZK_MAX_ROUNDS
+    ZK_SMALL_PARTIALS = ZK_SMALL_ROUNDPOLYS + 64 * ZK_MAX_ROUNDS,    // 8 * ZK_MAX_PARTIALS * 8 (composed: up to 8 sums/block)
+    ZK_SMALL_END = ZK_SMALL_PARTIALS + 4 * 8 * ZK_MAX_PARTIALS
+};
+#define ZK_SMALL_BYTES (ZK_SMALL_END * 8)
+
+// pinned host staging (uint64_t units)
+enum : size_t {
+    ZK_PIN_R = 0,
+    ZK_PIN_RES = 16,
+    ZK_PIN_PTS = 64,
+    ZK_PIN_PROOF = ZK_PIN_PTS + 4 * ZK_MAX_ROUNDS,
+    ZK_PIN_END = ZK_PIN_PROOF + 4 + 8 * ZK_MAX_ROUNDS + 4 * ZK_MAX_ROUNDS + 64 * ZK_MAX_ROUNDS
+};
+#define ZK_PINNED_BYTES (ZK_PIN_END * 8)
+
+#define ZK_HIP(ctx, call)                                   \
+    do {                                                    \
+        hipError_t _e = (call);                             \
+        if (_e != hipSuccess) {                             \
+            (ctx)->last_hip = (int)_e;                      \
+            return ZKHIP_ERR_HIP;                           \
+        }                                                   \
+    } while (0)
+#define ZK_TRY(expr)                 \
+    do {                             \
+        int _s = (expr);             \
+        if (_s != ZKHIP_OK) return _s; \
+    } while (0)
+
+struct ZkProfEvent { hipEvent_t start, stop; };
+struct ZkProfRecord { const char* name; size_t event; double bytes; };
+
+struct zkhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int last_hip = 0;
+    void* d_ws = nullptr;       // large workspace (ping-pong tables, MSM buckets, ...)
+    size_t ws_bytes = 0;
+    void* d_small = nullptr;    // fixed small scratch, layout above
+    void* h_pinned = nullptr;
+    bool profiling = false;
+    std::vector<ZkProfEvent> prof_events;
+    size_t prof_used = 0;
+    std::vector<ZkProfRecord> prof_records;
+
+    int activate() {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) { last_hip = (int)e; return ZKHIP_ERR_HIP; }
+        return ZKHIP_OK;
+    }
+    uint64_t* small_u64(size_t off) { return (uint64_t*)d_small + off; }
+    uint64_t* pinned_u64(size_t off) { return (uint64_t*)h_pinned + off; }
+    // grow-only workspace; growth synchronises (never inside a steady-state timed loop)
+    int reserve_ws(size_t bytes) {
+        if (bytes <= ws_bytes) return ZKHIP_OK;
+        hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { last_hip = (int)e; return ZKHIP_ERR_HIP; }
+        if (d_ws) hipFree(d_ws);
+        d_ws = nullptr;
+        ws_bytes = 0;
+        e = hipMalloc(&d_ws, bytes);
+        if (e != hipSuccess) { last_hip = (int)e; return ZKHIP_ERR_NOMEM; }
+        ws_bytes = bytes;
+        return ZKHIP_OK;
+    }
+};
+
+// Brackets one kernel launch with HIP events on the context's stream when profiling is on.
+struct ProfScope {
+    zkhip_ctx* c;
+    size_t idx = 0;
+    bool on;
+    ProfScope(zkhip_ctx* ctx, const char* name, double bytes) : c(ctx), on(ctx->profiling) {
+        if (!on) return;
+        if (c->prof_used == c->prof_events.size()) {
+            ZkProfEvent ev;
+            hipEventCreate(&ev.start);
+            hipEventCreate(&ev.stop);
+            c->prof_events.push_back(ev);
+        }
+        idx = c->prof_used++;
+        hipEventRecord(c->prof_events[idx].start, c->stream);
+        c->prof_records.push_back({name, idx, bytes});
+    }
+    ~ProfScope() {
+        if (on) hipEventRecord(c->prof_events[idx].stop, c->stream);
+    }
+};

@@ -1,0 +1,262 @@
+// fp.hpp -- Montgomery prime-field arithmetic for gfx950 (CDNA4), device side.
+//
+// Replaces, on the GPU, the ark-ff `Fp<MontBackend<_, N>, N>` operations the
+// reference reaches from polynomial/src/multilinear/evaluation_form.rs:133
+// (Fr mul/add/sub) and from `mul_bigint` in kzg/src/univariate_kzg.rs:53 /
+// kzg/src/multilinear_kzg.rs:46 (Fq inside the G1 group law).
+//
+// Representation: N32 saturated 32-bit limbs, little-endian, Montgomery form with
+// R = 2^(32*N32) -- bit-identical in memory to arkworks' [u64; N32/2].  All
+// results are fully reduced (canonical Montgomery residues), so equality with the
+// reference is equality of limbs.
+//
+// The multiplier is product-scanning (FIPS) Montgomery: one 96-bit column
+// accumulator fed by v_mad_u64_u32 (32x32+64 -> 64, carry-out in VCC) followed by
+// a v_addc_co_u32 into the top word.  2*N32^2 mads per product; the modulus limbs
+// ride in SGPRs (constant bus) so they cost no VGPRs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zk {
+
+// acc(96 bit: lo64, hi32) += a * b
+__device__ __forceinline__ void mac96(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(lo), "+v"(hi)
+        : "v"(a), "v"(b)
+        : "vcc");
+}
+// same with a wave-uniform multiplier held in an SGPR (modulus limb)
+__device__ __forceinline__ void mac96_s(uint64_t& lo, uint32_t& hi, uint32_t s_const, uint32_t b) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(lo), "+v"(hi)
+        : "s"(s_const), "v"(b)
+        : "vcc");
+}
+
+template <class P>
+struct Fp {
+    static constexpr int N = P::N32;
+    uint32_t l[N];
+
+    __device__ __forceinline__ static Fp zero() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.l[i] = 0;
+        return r;
+    }
+    __device__ __forceinline__ static Fp one() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.l[i] = P::r1(i);
+        return r;
+    }
+    __device__ __forceinline__ bool is_zero() const {
+        uint32_t x = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) x |= l[i];
+        return x == 0;
+    }
+    __device__ __forceinline__ bool operator==(const Fp& o) const {
+        uint32_t x = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) x |= l[i] ^ o.l[i];
+        return x == 0;
+    }
+
+    // r = a - p if a >= p (a < 2p)
+    __device__ __forceinline__ void reduce_once() {
+        uint32_t t[N];
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            uint64_t d = (uint64_t)l[i] - P::p(i) - borrow;
+            t[i] = (uint32_t)d;
+            borrow = (d >> 32) & 1;
+        }
+        if (!borrow) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) l[i] = t[i];
+        }
+    }
+
+    __device__ __forceinline__ friend Fp operator+(const Fp& a, const Fp& b) {
+        Fp r;
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            c += (uint64_t)a.l[i] + b.l[i];
+            r.l[i] = (uint32_t)c;
+            c >>= 32;
+        }
+        // P::SPARE_BITS >= 1: a + b < 2p < 2^(32N), no carry out
+        r.reduce_once();
+        return r;
+    }
+    __device__ __forceinline__ friend Fp operator-(const Fp& a, const Fp& b) {
+        Fp r;
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            uint64_t d = (uint64_t)a.l[i] - b.l[i] - borrow;
+            r.l[i] = (uint32_t)d;
+            borrow = (d >> 32) & 1;
+        }
+        // add p back when a < b (mask instead of branch: lanes diverge on data)
+        uint32_t mask = 0u - (uint32_t)borrow;
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            c += (uint64_t)r.l[i] + (P::p(i) & mask);
+            r.l[i] = (uint32_t)c;
+            c >>= 32;
+        }
+        return r;
+    }
+    __device__ __forceinline__ Fp neg() const { return zero() - *this; }
+    __device__ __forceinline__ Fp dbl() const { return *this + *this; }
+
+    // Montgomery product a*b*R^-1 mod p, product scanning.
+    __device__ __forceinline__ friend Fp operator*(const Fp& a, const Fp& b) {
+        uint32_t m[N];
+        Fp r;
+        uint64_t lo = 0;
+        uint32_t hi = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+#pragma unroll
+            for (int i = 0; i < k; ++i) {
+                mac96(lo, hi, a.l[i], b.l[k - i]);
+                mac96_s(lo, hi, P::p(k - i), m[i]);
+            }
+            mac96(lo, hi, a.l[k], b.l[0]);
+            m[k] = P::mul_inv((uint32_t)lo);
+            mac96_s(lo, hi, P::p(0), m[k]);
+            lo = (lo >> 32) | ((uint64_t)hi << 32);
+            hi = 0;
+        }
+#pragma unroll
+        for (int k = N; k < 2 * N - 1; ++k) {
+#pragma unroll
+            for (int i = k - N + 1; i < N; ++i) {
+                mac96(lo, hi, a.l[i], b.l[k - i]);
+                mac96_s(lo, hi, P::p(k - i), m[i]);
+            }
+            r.l[k - N] = (uint32_t)lo;
+            lo = (lo >> 32) | ((uint64_t)hi << 32);
+            hi = 0;
+        }
+        r.l[N - 1] = (uint32_t)lo;
+        // inputs < p and p < 2^(32N-1)  =>  result < 2p < 2^(32N): no overflow word
+        r.reduce_once();
+        return r;
+    }
+    __device__ __forceinline__ Fp sqr() const { return (*this) * (*this); }
+
+    // Montgomery form -> canonical integer (into_bigint): multiply by 1
+    __device__ __forceinline__ Fp from_mont() const {
+        Fp o = zero();
+        o.l[0] = 1;
+        return (*this) * o;
+    }
+    // canonical integer (< p) -> Montgomery form: multiply by R^2
+    __device__ __forceinline__ Fp to_mont() const {
+        Fp r2;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r2.l[i] = P::r2(i);
+        return (*this) * r2;
+    }
+};
+
+// ---- BLS12-381 scalar field Fr (255 bit), 8 x u32 -----------------------------------
+struct FrParams {
+    static constexpr int N32 = 8;
+    static constexpr int SPARE_BITS = 1;
+    __device__ __forceinline__ static constexpr uint32_t p(int i) {
+        constexpr uint32_t v[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
+                                   0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+        return v[i];
+    }
+    __device__ __forceinline__ static constexpr uint32_t r1(int i) {   // R mod r
+        constexpr uint32_t v[8] = {0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau,
+                                   0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u};
+        return v[i];
+    }
+    __device__ __forceinline__ static constexpr uint32_t r2(int i) {   // R^2 mod r
+        constexpr uint32_t v[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu,
+                                   0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
+        return v[i];
+    }
+    // -r^-1 mod 2^32 = 0xffffffff  =>  x * inv = -x
+    __device__ __forceinline__ static uint32_t mul_inv(uint32_t x) { return 0u - x; }
+};
+
+// ---- BLS12-381 base field Fq (381 bit), 12 x u32 --------------------------------------
+struct FqParams {
+    static constexpr int N32 = 12;
+    static constexpr int SPARE_BITS = 3;
+    __device__ __forceinline__ static constexpr uint32_t p(int i) {
+        constexpr uint32_t v[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                                    0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+        return v[i];
+    }
+    __device__ __forceinline__ static constexpr uint32_t r1(int i) {
+        constexpr uint32_t v[12] = {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu, 0x53c758bau, 0x5f489857u,
+                                    0x70525745u, 0x77ce5853u, 0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u};
+        return v[i];
+    }
+    __device__ __forceinline__ static constexpr uint32_t r2(int i) {
+        constexpr uint32_t v[12] = {0x1c341746u, 0xf4df1f34u, 0x09d104f1u, 0x0a76e6a6u, 0x4c95b6d5u, 0x8de5476cu,
+                                    0x939d83c0u, 0x67eb88a9u, 0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
+        return v[i];
+    }
+    __device__ __forceinline__ static uint32_t mul_inv(uint32_t x) { return x * 0xfffcfffdu; }
+};
+
+using Fr = Fp<FrParams>;
+using Fq = Fp<FqParams>;
+
+// ---- global memory access: one element = N32*4 contiguous bytes (arkworks layout) -------
+__device__ __forceinline__ Fr load_fr(const uint64_t* __restrict__ base, size_t idx) {
+    const uint4* p = reinterpret_cast<const uint4*>(base + 4 * idx);
+    uint4 a = p[0], b = p[1];
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void store_fr(uint64_t* __restrict__ base, size_t idx, const Fr& v) {
+    uint4* p = reinterpret_cast<uint4*>(base + 4 * idx);
+    p[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    p[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// ---- wavefront (64 lanes) + workgroup tree reduction with modular add ---------------------
+__device__ __forceinline__ Fr shfl_down_fr(const Fr& v, int delta) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < Fr::N; ++i) r.l[i] = __shfl_down(v.l[i], delta, 64);
+    return r;
+}
+__device__ __forceinline__ Fr wave_reduce_fr(Fr v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = v + shfl_down_fr(v, d);
+    return v;   // lane 0 holds the sum
+}
+// Sum over the workgroup; result valid in thread 0.  smem: (blockDim/64) Fr slots.
+__device__ __forceinline__ Fr block_reduce_fr(Fr v, Fr* smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63) >> 6;
+    v = wave_reduce_fr(v);
+    if (lane == 0) smem[wave] = v;
+    __syncthreads();
+    Fr acc = Fr::zero();
+    if (threadIdx.x == 0) {
+        acc = smem[0];
+        for (int w = 1; w < n_waves; ++w) acc = acc + smem[w];
+    }
+    __syncthreads();
+    return acc;
+}
+
+}  // namespace zk

@@ -1,0 +1,203 @@
+// mle_kernels.hpp -- multilinear evaluation-form kernels for gfx950.
+//
+// Replaces Multilinear::partial_evaluation / evaluation / sums
+// (polynomial/src/multilinear/evaluation_form.rs:68-84,123-175) and the index
+// generator pick_pairs_with_random_index (polynomial/src/utils.rs:26-53), whose
+// pair list (i, i + n>>(k+1)) is computed in closed form here.
+//
+// HBM-bound streaming kernels: every lane moves whole 32-byte elements with
+// 16-byte vector accesses, grid-stride over a grid of a few workgroups per CU.
+// Algorithmic traffic of one fold of an n-entry table: read 32n + write 16n
+// = 48n bytes.
+#pragma once
+#include "fp.hpp"
+#include "transcript.hpp"
+
+namespace zk {
+
+constexpr int MLE_BLOCK = 256;
+constexpr int MLE_MAX_GRID = 256 * 8;   // 8 workgroups of 4 waves per CU: 32 waves/CU
+constexpr int TAIL_LOG = 10;            // tables of <= 2^10 entries (32 KiB) finish inside one workgroup's LDS
+constexpr int TAIL_N = 1 << TAIL_LOG;
+
+// out[j] = lo + r*(hi - lo)  ==  r*hi + (1-r)*lo  (evaluation_form.rs:133), one Montgomery product.
+// Both sides are canonical residues of the same field element, so limbs are identical.
+__device__ __forceinline__ Fr fold_pair(const Fr& lo, const Fr& hi, const Fr& r) { return lo + r * (hi - lo); }
+
+// input index of the "lo" partner of output j when folding variable k of an n-entry table:
+// half = n >> (k+1) ; i = (j / half) * 2*half + (j % half)         (utils.rs:36-50)
+__device__ __forceinline__ size_t fold_lo_index(size_t j, uint32_t log_half) {
+    return ((j >> log_half) << (log_half + 1)) | (j & (((size_t)1 << log_half) - 1));
+}
+
+// Fold one variable.  WITH_SUMS additionally emits, per workgroup, the sums of its outputs that fall
+// in the lower / upper half of the OUTPUT table (= next sumcheck round's
+// split_poly_into_two_and_sum_each_part, evaluation_form.rs:68-74), saving a re-read of the output.
+template <bool WITH_SUMS>
+__global__ __launch_bounds__(MLE_BLOCK) void fold_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                         size_t n_out, uint32_t log_half,
+                                                         const uint64_t* __restrict__ r_ptr,
+                                                         uint64_t* __restrict__ partials) {
+    __shared__ Fr red[MLE_BLOCK / 64];
+    const Fr r = load_fr(r_ptr, 0);
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    const size_t half_in = (size_t)1 << log_half;
+    const size_t half_out = n_out >> 1;
+    Fr s_lo = Fr::zero(), s_hi = Fr::zero();
+    for (size_t j = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; j < n_out; j += 2 * stride) {
+        const size_t j2 = j + stride;
+        const bool has2 = j2 < n_out;
+        const size_t i1 = fold_lo_index(j, log_half);
+        const size_t i2 = has2 ? fold_lo_index(j2, log_half) : i1;
+        Fr a1 = load_fr(in, i1), b1 = load_fr(in, i1 + half_in);
+        Fr a2 = load_fr(in, i2), b2 = load_fr(in, i2 + half_in);
+        Fr o1 = fold_pair(a1, b1, r);
+        store_fr(out, j, o1);
+        if (WITH_SUMS) {
+            if (j < half_out) s_lo = s_lo + o1; else s_hi = s_hi + o1;
+        }
+        if (has2) {
+            Fr o2 = fold_pair(a2, b2, r);
+            store_fr(out, j2, o2);
+            if (WITH_SUMS) {
+                if (j2 < half_out) s_lo = s_lo + o2; else s_hi = s_hi + o2;
+            }
+        }
+    }
+    if (WITH_SUMS) {
+        Fr t_lo = block_reduce_fr(s_lo, red);
+        Fr t_hi = block_reduce_fr(s_hi, red);
+        if (threadIdx.x == 0) {
+            store_fr(partials, 2 * (size_t)blockIdx.x, t_lo);
+            store_fr(partials, 2 * (size_t)blockIdx.x + 1, t_hi);
+        }
+    }
+}
+
+// Per-workgroup (lower-half sum, upper-half sum) of a table: split_poly_into_two_and_sum_each_part
+// (evaluation_form.rs:68-74); their sum is sum_over_the_boolean_hypercube (:80-84) / poly_sum (sumcheck.rs:25-27).
+__global__ __launch_bounds__(MLE_BLOCK) void half_sums_kernel(const uint64_t* __restrict__ in, size_t n,
+                                                              uint64_t* __restrict__ partials) {
+    __shared__ Fr red[MLE_BLOCK / 64];
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    const size_t half = n >> 1;
+    Fr s_lo = Fr::zero(), s_hi = Fr::zero();
+    for (size_t j = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; j < n; j += 2 * stride) {
+        const size_t j2 = j + stride;
+        Fr a = load_fr(in, j);
+        Fr b = (j2 < n) ? load_fr(in, j2) : Fr::zero();
+        if (j < half) s_lo = s_lo + a; else s_hi = s_hi + a;
+        if (j2 < half) s_lo = s_lo + b; else s_hi = s_hi + b;
+    }
+    Fr t_lo = block_reduce_fr(s_lo, red);
+    Fr t_hi = block_reduce_fr(s_hi, red);
+    if (threadIdx.x == 0) {
+        store_fr(partials, 2 * (size_t)blockIdx.x, t_lo);
+        store_fr(partials, 2 * (size_t)blockIdx.x + 1, t_hi);
+    }
+}
+
+// Workgroup-wide reduction of n_partials (lo, hi) pairs; result in thread 0.
+__device__ __forceinline__ void reduce_partials(const uint64_t* __restrict__ partials, uint32_t n_partials, Fr* red,
+                                                Fr& lo, Fr& hi) {
+    Fr s_lo = Fr::zero(), s_hi = Fr::zero();
+    for (uint32_t b = threadIdx.x; b < n_partials; b += blockDim.x) {
+        s_lo = s_lo + load_fr(partials, 2 * (size_t)b);
+        s_hi = s_hi + load_fr(partials, 2 * (size_t)b + 1);
+    }
+    lo = block_reduce_fr(s_lo, red);
+    hi = block_reduce_fr(s_hi, red);
+}
+
+// Single-workgroup reduction: out[0] = lower-half sum, out[1] = upper-half sum, out[2] = total.
+__global__ __launch_bounds__(MLE_BLOCK) void finish_sums_kernel(const uint64_t* __restrict__ partials,
+                                                                uint32_t n_partials, uint64_t* __restrict__ out) {
+    __shared__ Fr red[MLE_BLOCK / 64];
+    Fr lo, hi;
+    reduce_partials(partials, n_partials, red, lo, hi);
+    if (threadIdx.x == 0) {
+        store_fr(out, 0, lo);
+        store_fr(out, 1, hi);
+        store_fr(out, 2, lo + hi);
+    }
+}
+
+// Finish an evaluation inside one workgroup: folds variable 0 repeatedly with points pts[0..n_pts) until the
+// table (n <= TAIL_N entries, staged in LDS) has n >> n_pts entries left; writes them to out.
+__global__ __launch_bounds__(MLE_BLOCK) void fold_tail_kernel(const uint64_t* __restrict__ in, uint32_t n,
+                                                              const uint64_t* __restrict__ pts, uint32_t n_pts,
+                                                              uint64_t* __restrict__ out) {
+    __shared__ Fr tab[TAIL_N];
+    for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) tab[j] = load_fr(in, j);
+    __syncthreads();
+    uint32_t cur = n;
+    for (uint32_t p = 0; p < n_pts; ++p) {
+        const Fr r = load_fr(pts, p);
+        const uint32_t half = cur >> 1;
+        Fr o[TAIL_N / 2 / MLE_BLOCK];
+#pragma unroll
+        for (int u = 0; u < TAIL_N / 2 / MLE_BLOCK; ++u) {
+            uint32_t j = threadIdx.x + u * MLE_BLOCK;
+            if (j < half) o[u] = fold_pair(tab[j], tab[j + half], r);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < TAIL_N / 2 / MLE_BLOCK; ++u) {
+            uint32_t j = threadIdx.x + u * MLE_BLOCK;
+            if (j < half) tab[j] = o[u];
+        }
+        __syncthreads();
+        cur = half;
+    }
+    for (uint32_t j = threadIdx.x; j < cur; j += MLE_BLOCK) store_fr(out, j, tab[j]);
+}
+
+// Outer sum / outer product of two tables (evaluation_form.rs:28-52): out[i*nb + j] = a[i] (+|*) b[j]
+template <bool MUL>
+__global__ __launch_bounds__(MLE_BLOCK) void distinct_kernel(const uint64_t* __restrict__ a,
+                                                             const uint64_t* __restrict__ b, size_t nb, size_t n_out,
+                                                             uint64_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    for (size_t q = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; q < n_out; q += stride) {
+        Fr x = load_fr(a, q / nb), y = load_fr(b, q % nb);
+        store_fr(out, q, MUL ? x * y : x + y);
+    }
+}
+
+// Elementwise ops used by the callers either side of the path (Add/Sub/Mul<F>, evaluation_form.rs:178-251)
+template <int OP>   // 0 add, 1 sub, 2 scale by *s
+__global__ __launch_bounds__(MLE_BLOCK) void elementwise_kernel(const uint64_t* __restrict__ a,
+                                                                const uint64_t* __restrict__ b, size_t n,
+                                                                uint64_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    Fr s = Fr::zero();
+    if (OP == 2) s = load_fr(b, 0);
+    for (size_t q = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; q < n; q += stride) {
+        Fr x = load_fr(a, q);
+        Fr o = (OP == 0) ? x + load_fr(b, q) : (OP == 1) ? x - load_fr(b, q) : x * s;
+        store_fr(out, q, o);
+    }
+}
+
+// Canonical big-endian bytes of every element (Multilinear::to_bytes, evaluation_form.rs:54-62)
+__global__ __launch_bounds__(MLE_BLOCK) void to_bytes_kernel(const uint64_t* __restrict__ in, size_t n,
+                                                             uint32_t* __restrict__ out_words) {
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    for (size_t q = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; q < n; q += stride) {
+        Fr c = load_fr(in, q).from_mont();
+        uint4* p = reinterpret_cast<uint4*>(out_words + 8 * q);
+        p[0] = make_uint4(__builtin_bswap32(c.l[7]), __builtin_bswap32(c.l[6]), __builtin_bswap32(c.l[5]),
+                          __builtin_bswap32(c.l[4]));
+        p[1] = make_uint4(__builtin_bswap32(c.l[3]), __builtin_bswap32(c.l[2]), __builtin_bswap32(c.l[1]),
+                          __builtin_bswap32(c.l[0]));
+    }
+}
+
+inline int mle_grid(size_t n_items) {
+    size_t g = (n_items + MLE_BLOCK - 1) / MLE_BLOCK;
+    if (g < 1) g = 1;
+    if (g > (size_t)MLE_MAX_GRID) g = MLE_MAX_GRID;
+    return (int)g;
+}
+
+}  // namespace zk

@@ -1,0 +1,144 @@
+// transcript.hpp -- device-resident Fiat-Shamir transcript for gfx950.
+//
+// Replaces transcripts/fiat-shamir/src/fiat_shamir.rs:10-40 (SHA-256 hash chain:
+// commit = update; challenge = finalize, reset, re-seed with the digest;
+// evaluate_challenge_into_field = from_be_bytes_mod_order) so that the sumcheck
+// round loop never leaves the GPU between rounds.  One lane runs it; the state
+// lives in global memory between kernels.
+#pragma once
+#include "fp.hpp"
+
+namespace zk {
+
+struct Sha256State {
+    uint32_t h[8];
+    uint32_t buf[16];   // pending block, big-endian words
+    uint32_t fill;      // bytes pending in buf (always a multiple of 4 here: we only absorb 32-byte items)
+    uint32_t pad_;
+    uint64_t len;       // total bytes absorbed
+};
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_rotateright32(x, n); }
+
+__device__ inline void sha256_compress(uint32_t (&h)[8], const uint32_t (&blk)[16]) {
+    constexpr uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+        0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+        0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+        0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = blk[i];
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        if (i >= 16) {
+            uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+            uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+            w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        }
+        uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+        uint32_t ch = (e & f) ^ (~e & g);
+        uint32_t t1 = hh + S1 + ch + K[i] + w[i & 15];
+        uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+        uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+        uint32_t t2 = S0 + mj;
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+// Register-resident transcript (loaded from / stored to a Sha256State in global memory).
+struct Transcript {
+    uint32_t h[8];
+    uint32_t buf[16];
+    uint32_t fill_words;   // words pending
+    uint64_t len;
+
+    __device__ __forceinline__ void init() {   // FiatShamirTranscript::new  fiat_shamir.rs:11-15
+        h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
+        h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+        fill_words = 0;
+        len = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) buf[i] = 0;
+    }
+    __device__ __forceinline__ void load(const Sha256State* s) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = s->h[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) buf[i] = s->buf[i];
+        fill_words = s->fill >> 2;
+        len = s->len;
+    }
+    __device__ __forceinline__ void store(Sha256State* s) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s->h[i] = h[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s->buf[i] = buf[i];
+        s->fill = fill_words << 2;
+        s->len = len;
+    }
+    // absorb 8 big-endian words (32 bytes).  fill_words stays a multiple of 8, so the
+    // dynamic index below only takes the values 0 and 8.
+    __device__ __forceinline__ void commit_words8(const uint32_t (&wds)[8]) {   // commit  fiat_shamir.rs:17-19
+        if (fill_words == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) buf[i] = wds[i];
+            fill_words = 8;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) buf[8 + i] = wds[i];
+            sha256_compress(h, buf);
+            fill_words = 0;
+        }
+        len += 32;
+    }
+    // into_bigint().to_bytes_be() of a Montgomery-form element, absorbed (sumcheck/src/utils.rs:7-9)
+    __device__ __forceinline__ void commit_fr(const Fr& v_mont) {
+        Fr c = v_mont.from_mont();
+        uint32_t wds[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wds[i] = c.l[7 - i];   // big-endian byte string == words MSW first
+        commit_words8(wds);
+    }
+    // challenge(): finalize_reset + update(digest)   fiat_shamir.rs:21-25
+    __device__ __forceinline__ void challenge(uint32_t (&digest)[8]) {
+        uint64_t bits = len * 8;
+        if (fill_words == 0) {
+            buf[0] = 0x80000000u;
+#pragma unroll
+            for (int i = 1; i < 14; ++i) buf[i] = 0;
+        } else {   // 8 words pending
+            buf[8] = 0x80000000u;
+#pragma unroll
+            for (int i = 9; i < 14; ++i) buf[i] = 0;
+        }
+        buf[14] = (uint32_t)(bits >> 32);
+        buf[15] = (uint32_t)bits;
+        sha256_compress(h, buf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) digest[i] = h[i];
+        init();
+        commit_words8(digest);
+    }
+    // evaluate_challenge_into_field: from_be_bytes_mod_order(digest)  fiat_shamir.rs:27-29.
+    // digest < 2^256 < 3r, so at most two subtractions of r bring it into range.  Returns Montgomery form.
+    __device__ __forceinline__ Fr challenge_fr() {
+        uint32_t d[8];
+        challenge(d);
+        Fr v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v.l[i] = d[7 - i];
+        v.reduce_once();
+        v.reduce_once();
+        return v.to_mont();
+    }
+};
+
+}  // namespace zk

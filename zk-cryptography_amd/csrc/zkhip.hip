@@ -1,0 +1,390 @@
+// zkhip.hip -- C-ABI entry points (include/zkhip.h) and host-side launch logic.
+// gfx950 only.  No CPU fallback: every entry point launches HIP kernels or fails.
+#include "../../include/zkhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ctx.hpp"
+#include "mle_kernels.hpp"
+#include "sumcheck_kernels.hpp"
+
+using namespace zk;
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+extern "C" int zkhip_version(void) { return 1; }
+
+extern "C" const char* zkhip_status_string(int s) {
+    switch (s) {
+        case ZKHIP_OK: return "ok";
+        case ZKHIP_ERR_HIP: return "HIP runtime error";
+        case ZKHIP_ERR_SHAPE: return "shape assertion failed";
+        case ZKHIP_ERR_INDEX: return "index out of bounds";
+        case ZKHIP_ERR_ARG: return "invalid argument";
+        case ZKHIP_ERR_NOMEM: return "out of memory";
+        default: return "unknown";
+    }
+}
+
+extern "C" int zkhip_ctx_create(zkhip_ctx** out, int device, void* stream) {
+    if (!out) return ZKHIP_ERR_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return ZKHIP_ERR_HIP;
+    zkhip_ctx* c = new zkhip_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return ZKHIP_ERR_HIP; }
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZKHIP_ERR_HIP; }
+        c->own_stream = true;
+    }
+    if (hipHostMalloc(&c->h_pinned, ZK_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) { delete c; return ZKHIP_ERR_HIP; }
+    if (hipMalloc(&c->d_small, ZK_SMALL_BYTES) != hipSuccess) { delete c; return ZKHIP_ERR_NOMEM; }
+    *out = c;
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
+    if (!c) return ZKHIP_ERR_ARG;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto& e : c->prof_events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
+    if (c->d_ws) hipFree(c->d_ws);
+    if (c->d_small) hipFree(c->d_small);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_ctx_set_stream(zkhip_ctx* c, void* stream) {
+    if (!c || !stream) return ZKHIP_ERR_ARG;
+    if (c->own_stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); c->own_stream = false; }
+    c->stream = (hipStream_t)stream;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_ctx_synchronize(zkhip_ctx* c) {
+    if (!c) return ZKHIP_ERR_ARG;
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_last_hip_error(zkhip_ctx* c) { return c ? c->last_hip : 0; }
+
+extern "C" int zkhip_malloc(zkhip_ctx* c, void** d_ptr, size_t bytes) {
+    if (!c || !d_ptr) return ZKHIP_ERR_ARG;
+    hipSetDevice(c->device);
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+    if (e != hipSuccess) { c->last_hip = (int)e; return ZKHIP_ERR_NOMEM; }
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_free(zkhip_ctx* c, void* d_ptr) {
+    if (!c) return ZKHIP_ERR_ARG;
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    ZK_HIP(c, hipFree(d_ptr));
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_memcpy_h2d(zkhip_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
+    if (!c) return ZKHIP_ERR_ARG;
+    ZK_HIP(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_memcpy_d2h(zkhip_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+    if (!c) return ZKHIP_ERR_ARG;
+    ZK_HIP(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_profile_enable(zkhip_ctx* c, int enable) {
+    if (!c) return ZKHIP_ERR_ARG;
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    c->profiling = enable != 0;
+    c->prof_used = 0;
+    c->prof_records.clear();
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_profile_read(zkhip_ctx* c, const char* kernel, double* total_ms, uint64_t* launches, double* bytes) {
+    if (!c || !kernel) return ZKHIP_ERR_ARG;
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    double ms = 0, by = 0;
+    uint64_t cnt = 0;
+    for (auto& r : c->prof_records) {
+        if (std::strcmp(r.name, kernel) != 0) continue;
+        float t = 0;
+        ZK_HIP(c, hipEventElapsedTime(&t, c->prof_events[r.event].start, c->prof_events[r.event].stop));
+        ms += t; by += r.bytes; ++cnt;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = cnt;
+    if (bytes) *bytes = by;
+    return ZKHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------
+static inline uint32_t log2_exact(size_t n) {
+    uint32_t k = 0;
+    while (((size_t)1 << k) < n) ++k;
+    return k;
+}
+static inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+
+// fold variable var_index of an n-entry table; r on device. with_sums -> partials (returns grid size in *np)
+static int launch_fold(zkhip_ctx* c, const uint64_t* d_in, size_t n, const uint64_t* d_r, uint32_t var_index,
+                       uint64_t* d_out, bool with_sums, uint64_t* d_partials, uint32_t* np) {
+    const size_t n_out = n / 2;
+    const uint32_t log_half = log2_exact(n) - 1 - var_index;
+    const int grid = mle_grid((n_out + 1) / 2);
+    ProfScope ps(c, with_sums ? "fold_sums" : "fold", 48.0 * (double)n);
+    if (with_sums)
+        hipLaunchKernelGGL(fold_kernel<true>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_in, d_out, n_out, log_half,
+                           d_r, d_partials);
+    else
+        hipLaunchKernelGGL(fold_kernel<false>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_in, d_out, n_out, log_half,
+                           d_r, d_partials);
+    if (np) *np = (uint32_t)grid;
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Multilinear
+// ---------------------------------------------------------------------------------------
+extern "C" int zkhip_mle_partial_evaluation(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_r,
+                                            const uint64_t* d_r, uint32_t var_index, uint64_t* d_out) {
+    if (!c || !d_evals || !d_out || (!h_r == !d_r)) return ZKHIP_ERR_ARG;
+    if (!is_pow2(n) || n < 2) return ZKHIP_ERR_SHAPE;                 // utils.rs:30  (and Multilinear::new :16-20)
+    if (!((size_t)var_index < n / 2)) return ZKHIP_ERR_SHAPE;          // utils.rs:31-34
+    if (var_index >= log2_exact(n)) return ZKHIP_ERR_SHAPE;            // reference would return an empty table
+    ZK_TRY(c->activate());
+    if (h_r) {
+        uint64_t* slot = c->small_u64(ZK_SMALL_R);
+        std::memcpy(c->pinned_u64(ZK_PIN_R), h_r, 32);
+        ZK_HIP(c, hipMemcpyAsync(slot, c->pinned_u64(ZK_PIN_R), 32, hipMemcpyHostToDevice, c->stream));
+        d_r = slot;
+    }
+    return launch_fold(c, d_evals, n, d_r, var_index, d_out, false, nullptr, nullptr);
+}
+
+// Successive folds of variable 0 (or of h_var_indices) with points already on the device.
+static int fold_chain(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* d_pts,
+                      const uint32_t* var_indices, size_t n_pts, uint64_t* d_out) {
+    // ping-pong buffers: A holds n/2, B holds n/4
+    if (n_pts == 0) {
+        ZK_HIP(c, hipMemcpyAsync(d_out, d_evals, n * 32, hipMemcpyDeviceToDevice, c->stream));
+        return ZKHIP_OK;
+    }
+    const size_t need = (n / 2 + n / 4 + 8) * 32;
+    ZK_TRY(c->reserve_ws(need));
+    uint64_t* A = (uint64_t*)c->d_ws;
+    uint64_t* B = A + 4 * (n / 2);
+    const uint64_t* cur = d_evals;
+    size_t cn = n;
+    for (size_t p = 0; p < n_pts; ++p) {
+        const uint32_t k = var_indices ? var_indices[p] : 0;
+        if (cn < 2 || !((size_t)k < cn / 2) || k >= log2_exact(cn)) return ZKHIP_ERR_SHAPE;
+        const bool all_zero_tail = !var_indices || [&] {
+            for (size_t q = p; q < n_pts; ++q) if (var_indices[q]) return false;
+            return true;
+        }();
+        if (all_zero_tail && cn <= (size_t)TAIL_N) {
+            // finish every remaining fold inside one workgroup
+            ProfScope ps(c, "fold_tail", 0.0);
+            hipLaunchKernelGGL(fold_tail_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, cur, (uint32_t)cn,
+                               d_pts + 4 * p, (uint32_t)(n_pts - p), d_out);
+            ZK_HIP(c, hipGetLastError());
+            return ZKHIP_OK;
+        }
+        const bool last = (p + 1 == n_pts);
+        uint64_t* dst = last ? d_out : ((p & 1) ? B : A);
+        ZK_TRY(launch_fold(c, cur, cn, d_pts + 4 * p, k, dst, false, nullptr, nullptr));
+        cur = dst;
+        cn /= 2;
+    }
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_mle_partial_evaluations(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_pts,
+                                             const uint32_t* h_var_indices, size_t n_pts, uint64_t* d_out) {
+    if (!c || !d_evals || !d_out || (n_pts && (!h_pts || !h_var_indices))) return ZKHIP_ERR_ARG;
+    if (!is_pow2(n)) return ZKHIP_ERR_SHAPE;
+    if (n_pts > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    uint64_t* d_pts = c->small_u64(ZK_SMALL_PTS);
+    if (n_pts) {
+        std::memcpy(c->pinned_u64(ZK_PIN_PTS), h_pts, 32 * n_pts);
+        ZK_HIP(c, hipMemcpyAsync(d_pts, c->pinned_u64(ZK_PIN_PTS), 32 * n_pts, hipMemcpyHostToDevice, c->stream));
+    }
+    return fold_chain(c, d_evals, n, d_pts, h_var_indices, n_pts, d_out);
+}
+
+extern "C" int zkhip_mle_evaluation(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_pts,
+                                    size_t n_pts, uint64_t* h_out) {
+    if (!c || !d_evals || !h_out || (n_pts && !h_pts)) return ZKHIP_ERR_ARG;
+    if (!is_pow2(n)) return ZKHIP_ERR_SHAPE;
+    if (n_pts != log2_exact(n)) return ZKHIP_ERR_SHAPE;                // assert_eq! evaluation_form.rs:163-167
+    ZK_TRY(c->activate());
+    uint64_t* d_pts = c->small_u64(ZK_SMALL_PTS);
+    uint64_t* d_res = c->small_u64(ZK_SMALL_RES);
+    if (n_pts) {
+        std::memcpy(c->pinned_u64(ZK_PIN_PTS), h_pts, 32 * n_pts);
+        ZK_HIP(c, hipMemcpyAsync(d_pts, c->pinned_u64(ZK_PIN_PTS), 32 * n_pts, hipMemcpyHostToDevice, c->stream));
+    }
+    ZK_TRY(fold_chain(c, d_evals, n, d_pts, nullptr, n_pts, d_res));
+    ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_res, 32, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(h_out, c->pinned_u64(ZK_PIN_RES), 32);
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_mle_half_sums(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint64_t* h_out) {
+    if (!c || !d_evals || !h_out) return ZKHIP_ERR_ARG;
+    if (n == 0) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    uint64_t* d_partials = c->small_u64(ZK_SMALL_PARTIALS);
+    uint64_t* d_res = c->small_u64(ZK_SMALL_RES);
+    const int grid = mle_grid((n + 1) / 2);
+    {
+        ProfScope ps(c, "half_sums", 32.0 * (double)n);
+        hipLaunchKernelGGL(half_sums_kernel, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_evals, n, d_partials);
+    }
+    hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_partials, (uint32_t)grid, d_res);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_res, 96, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(h_out, c->pinned_u64(ZK_PIN_RES), 96);
+    return ZKHIP_OK;
+}
+
+static int distinct(zkhip_ctx* c, bool mul, const uint64_t* d_a, size_t na, const uint64_t* d_b, size_t nb,
+                    uint64_t* d_out) {
+    if (!c || !d_a || !d_b || !d_out) return ZKHIP_ERR_ARG;
+    if (!is_pow2(na * nb)) return ZKHIP_ERR_SHAPE;   // Self::new(new_evaluations) asserts a power of two
+    ZK_TRY(c->activate());
+    const size_t n_out = na * nb;
+    const int grid = mle_grid(n_out);
+    if (mul)
+        hipLaunchKernelGGL(distinct_kernel<true>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_a, d_b, nb, n_out, d_out);
+    else
+        hipLaunchKernelGGL(distinct_kernel<false>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_a, d_b, nb, n_out, d_out);
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_mle_add_distinct(zkhip_ctx* c, const uint64_t* d_a, size_t na, const uint64_t* d_b, size_t nb,
+                                      uint64_t* d_out) { return distinct(c, false, d_a, na, d_b, nb, d_out); }
+extern "C" int zkhip_mle_mul_distinct(zkhip_ctx* c, const uint64_t* d_a, size_t na, const uint64_t* d_b, size_t nb,
+                                      uint64_t* d_out) { return distinct(c, true, d_a, na, d_b, nb, d_out); }
+
+extern "C" int zkhip_mle_elementwise(zkhip_ctx* c, int op, const uint64_t* d_a, const uint64_t* d_b,
+                                     const uint64_t* h_scalar, size_t n, uint64_t* d_out) {
+    if (!c || !d_a || !d_out || op < 0 || op > 2) return ZKHIP_ERR_ARG;
+    if (op == 2 ? !h_scalar : !d_b) return ZKHIP_ERR_ARG;
+    ZK_TRY(c->activate());
+    const int grid = mle_grid(n);
+    if (op == 2) {
+        uint64_t* slot = c->small_u64(ZK_SMALL_R);
+        std::memcpy(c->pinned_u64(ZK_PIN_R), h_scalar, 32);
+        ZK_HIP(c, hipMemcpyAsync(slot, c->pinned_u64(ZK_PIN_R), 32, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(elementwise_kernel<2>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_a, slot, n, d_out);
+    } else if (op == 0) {
+        hipLaunchKernelGGL(elementwise_kernel<0>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_a, d_b, n, d_out);
+    } else {
+        hipLaunchKernelGGL(elementwise_kernel<1>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_a, d_b, n, d_out);
+    }
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_mle_to_bytes(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint8_t* d_out_bytes) {
+    if (!c || !d_evals || !d_out_bytes) return ZKHIP_ERR_ARG;
+    ZK_TRY(c->activate());
+    hipLaunchKernelGGL(to_bytes_kernel, dim3(mle_grid(n)), dim3(MLE_BLOCK), 0, c->stream, d_evals, n,
+                       (uint32_t*)d_out_bytes);
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// basic sumcheck prover
+// ---------------------------------------------------------------------------------------
+extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_claimed_sum,
+                                    const uint64_t* h_first_half_sums, uint64_t* h_sum, uint64_t* h_round_polys,
+                                    uint64_t* h_challenges) {
+    if (!c || !d_evals || !h_sum) return ZKHIP_ERR_ARG;
+    if (!is_pow2(n)) return ZKHIP_ERR_SHAPE;   // Multilinear::new evaluation_form.rs:16-20
+    const uint32_t n_vars = log2_exact(n);
+    if (n_vars > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
+    if (n_vars && (!h_round_polys || !h_challenges)) return ZKHIP_ERR_ARG;
+    ZK_TRY(c->activate());
+    if (n == 1) {   // no rounds: nothing is proven; report the sum the transcript would have absorbed
+        if (h_claimed_sum) { std::memcpy(h_sum, h_claimed_sum, 32); return ZKHIP_OK; }
+        ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_evals, 32, hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(c, hipStreamSynchronize(c->stream));
+        std::memcpy(h_sum, c->pinned_u64(ZK_PIN_RES), 32);
+        return ZKHIP_OK;
+    }
+    ZK_TRY(c->reserve_ws((n / 2 + n / 4 + 8) * 32));
+    uint64_t* A = (uint64_t*)c->d_ws;
+    uint64_t* B = A + 4 * (n / 2);
+    SumcheckDev* st = (SumcheckDev*)c->small_u64(ZK_SMALL_STATE);
+    uint64_t* d_partials = c->small_u64(ZK_SMALL_PARTIALS);
+    uint64_t* d_rp = c->small_u64(ZK_SMALL_ROUNDPOLYS);
+    uint64_t* d_ch = c->small_u64(ZK_SMALL_CHALLENGES);
+    uint64_t* d_fin = c->small_u64(ZK_SMALL_RES);
+
+    const uint64_t* cur = d_evals;
+    size_t cn = n;
+    uint32_t round = 0, first = 1, np = 0;
+    if (h_claimed_sum) {   // prove(&self) absorbs self.sum, whatever the caller put there (sumcheck.rs:33-35)
+        std::memcpy(c->pinned_u64(ZK_PIN_R), h_claimed_sum, 32);
+        ZK_HIP(c, hipMemcpyAsync(st->sum, c->pinned_u64(ZK_PIN_R), 32, hipMemcpyHostToDevice, c->stream));
+        first = 2;
+    }
+    if (cn > (size_t)TAIL_N) {
+        if (h_first_half_sums) {   // poly_sum() already streamed the table once: reuse its two half sums
+            std::memcpy(c->pinned_u64(ZK_PIN_RES), h_first_half_sums, 64);
+            ZK_HIP(c, hipMemcpyAsync(d_partials, c->pinned_u64(ZK_PIN_RES), 64, hipMemcpyHostToDevice, c->stream));
+            np = 1;
+        } else {
+            const int grid = mle_grid((cn + 1) / 2);
+            ProfScope ps(c, "half_sums", 32.0 * (double)cn);
+            hipLaunchKernelGGL(half_sums_kernel, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, cur, cn, d_partials);
+            np = (uint32_t)grid;
+        }
+        while (cn > (size_t)TAIL_N) {
+            hipLaunchKernelGGL(sumcheck_round_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_partials, np, st, round,
+                               first, d_rp, d_ch);
+            first = 0;
+            uint64_t* dst = (round & 1) ? B : A;
+            const bool next_is_tail = (cn / 2) <= (size_t)TAIL_N;
+            ZK_TRY(launch_fold(c, cur, cn, d_ch + 4 * round, 0, dst, !next_is_tail, d_partials, &np));
+            cur = dst;
+            cn /= 2;
+            ++round;
+        }
+    }
+    hipLaunchKernelGGL(sumcheck_tail_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, cur, (uint32_t)cn, st, round, first,
+                       d_rp, d_ch, d_fin);
+    ZK_HIP(c, hipGetLastError());
+    // results -> host
+    uint64_t* pin = c->pinned_u64(ZK_PIN_PROOF);
+    ZK_HIP(c, hipMemcpyAsync(pin, st->sum, 32, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(pin + 4, d_rp, 64 * (size_t)n_vars, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(pin + 4 + 8 * ZK_MAX_ROUNDS, d_ch, 32 * (size_t)n_vars, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(h_sum, pin, 32);
+    std::memcpy(h_round_polys, pin + 4, 64 * (size_t)n_vars);
+    std::memcpy(h_challenges, pin + 4 + 8 * ZK_MAX_ROUNDS, 32 * (size_t)n_vars);
+    return ZKHIP_OK;
+}

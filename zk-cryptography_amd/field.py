@@ -1,0 +1,41 @@
+"""Host-side BLS12-381 Fr helpers (python ints <-> arkworks' Montgomery limb layout).
+
+Conversions only -- these are the `Fr::from(..)` / `into_bigint()` a caller does at the
+boundary; no hot-path arithmetic happens here.
+"""
+import numpy as np
+
+R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+_R = pow(2, 256, R_MOD)
+_RINV = pow(_R, -1, R_MOD)
+_MASK = 0xFFFFFFFFFFFFFFFF
+
+
+class Fr:
+    MODULUS = R_MOD
+
+    @staticmethod
+    def from_ints(vals):
+        """Fr::from(v) for each v (negative allowed) -> uint64 [n,4] Montgomery limbs"""
+        out = np.empty((len(vals), 4), dtype=np.uint64)
+        for i, v in enumerate(vals):
+            m = (int(v) % R_MOD) * _R % R_MOD
+            out[i] = [(m >> (64 * k)) & _MASK for k in range(4)]
+        return out
+
+    @staticmethod
+    def from_int(v):
+        return Fr.from_ints([v])[0]
+
+    @staticmethod
+    def to_ints(arr):
+        arr = np.asarray(arr, dtype=np.uint64).reshape(-1, 4)
+        return [sum(int(row[k]) << (64 * k) for k in range(4)) * _RINV % R_MOD for row in arr]
+
+    @staticmethod
+    def random(n, seed):
+        """n uniform elements of [0, 2^254) as Montgomery residues (synthetic bench/test inputs)"""
+        rng = np.random.Generator(np.random.PCG64(seed))
+        a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+        return a
