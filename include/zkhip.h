@@ -43,7 +43,8 @@ typedef struct zkhip_ctx zkhip_ctx;
 /* ---- context / memory ------------------------------------------------------------ */
 int zkhip_version(void);
 const char *zkhip_status_string(int status);
-/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = create one. */
+/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = the
+ * device's default (null) stream. */
 int zkhip_ctx_create(zkhip_ctx **out, int device, void *stream);
 int zkhip_ctx_destroy(zkhip_ctx *ctx);
 int zkhip_ctx_set_stream(zkhip_ctx *ctx, void *stream);

@@ -38,6 +38,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ZkhipError("libzkhip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(there is no CPU fallback)")
+        # torch wheels bundle their own libamdhip64.so.7; import torch FIRST so that libzkhip binds to the
+        # same HIP runtime instance (we exchange device pointers and streams with torch).
+        import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
         _lib.zkhip_status_string.restype = C.c_char_p
     return _lib
@@ -47,6 +50,8 @@ def check(status, what=""):
     if status == ZKHIP_OK:
         return
     msg = lib().zkhip_status_string(status).decode()
+    if status == ERR_HIP:
+        msg += " (hipError %d)" % lib().zkhip_last_hip_error(None)
     if status == ERR_SHAPE:
         raise AssertionError("%s: %s" % (what, msg))      # the reference panics (assert!/assert_eq!)
     if status == ERR_INDEX:
@@ -84,7 +89,7 @@ class Context:
 
     def sync_stream(self):
         s = self.torch.cuda.current_stream(self.device).cuda_stream
-        if s != self._stream and s != 0:
+        if s != self._stream:
             check(lib().zkhip_ctx_set_stream(self.handle, C.c_void_p(s)), "set_stream")
             self._stream = s
 

@@ -19,6 +19,7 @@ using namespace zk;
 // ---------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------
+static int g_last_hip = 0;   // last HIP error seen without a context (ctx_create)
 extern "C" int zkhip_version(void) { return 1; }
 
 extern "C" const char* zkhip_status_string(int s) {
@@ -36,17 +37,13 @@ extern "C" const char* zkhip_status_string(int s) {
 extern "C" int zkhip_ctx_create(zkhip_ctx** out, int device, void* stream) {
     if (!out) return ZKHIP_ERR_ARG;
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return ZKHIP_ERR_HIP;
+    hipError_t e0 = hipGetDeviceCount(&count);
+    if (e0 != hipSuccess || device < 0 || device >= count) { g_last_hip = (int)e0; return ZKHIP_ERR_HIP; }
     zkhip_ctx* c = new zkhip_ctx();
     c->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete c; return ZKHIP_ERR_HIP; }
-    if (stream) {
-        c->stream = (hipStream_t)stream;
-        c->own_stream = false;
-    } else {
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZKHIP_ERR_HIP; }
-        c->own_stream = true;
-    }
+    c->stream = (hipStream_t)stream;   // NULL = the device's default (null) stream, ordered with everything
+    c->own_stream = false;
     if (hipHostMalloc(&c->h_pinned, ZK_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) { delete c; return ZKHIP_ERR_HIP; }
     if (hipMalloc(&c->d_small, ZK_SMALL_BYTES) != hipSuccess) { delete c; return ZKHIP_ERR_NOMEM; }
     *out = c;
@@ -67,8 +64,7 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
 }
 
 extern "C" int zkhip_ctx_set_stream(zkhip_ctx* c, void* stream) {
-    if (!c || !stream) return ZKHIP_ERR_ARG;
-    if (c->own_stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); c->own_stream = false; }
+    if (!c) return ZKHIP_ERR_ARG;
     c->stream = (hipStream_t)stream;
     return ZKHIP_OK;
 }
@@ -77,7 +73,7 @@ extern "C" int zkhip_ctx_synchronize(zkhip_ctx* c) {
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     return ZKHIP_OK;
 }
-extern "C" int zkhip_last_hip_error(zkhip_ctx* c) { return c ? c->last_hip : 0; }
+extern "C" int zkhip_last_hip_error(zkhip_ctx* c) { return c ? c->last_hip : g_last_hip; }
 
 extern "C" int zkhip_malloc(zkhip_ctx* c, void** d_ptr, size_t bytes) {
     if (!c || !d_ptr) return ZKHIP_ERR_ARG;
