@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <set>
 #include <vector>
 
 #include "../../include/zkhip.h"
@@ -67,6 +68,15 @@ struct zkhip_ctx {
     int activate() {
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) { last_hip = (int)e; return ZKHIP_ERR_HIP; }
+        return ZKHIP_OK;
+    }
+    std::set<const void*> big_lds_done;
+    // kernels that carve more than 64 KiB of the CU's 160 KiB LDS need the attribute raised once per function
+    int allow_big_lds(const void* fn, size_t bytes) {
+        if (bytes <= 64 * 1024 || big_lds_done.count(fn)) return ZKHIP_OK;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { last_hip = (int)e; return ZKHIP_ERR_HIP; }
+        big_lds_done.insert(fn);
         return ZKHIP_OK;
     }
     uint64_t* small_u64(size_t off) { return (uint64_t*)d_small + off; }

@@ -259,4 +259,21 @@ __device__ __forceinline__ Fr block_reduce_fr(Fr v, Fr* smem) {
     return acc;
 }
 
+// Two sums at once (one barrier set, two independent dependency chains for the scheduler to interleave).
+__device__ __forceinline__ void block_reduce_fr2(Fr& a, Fr& b, Fr* smem /* 2 * n_waves */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        Fr ta = shfl_down_fr(a, d), tb = shfl_down_fr(b, d);
+        a = a + ta;
+        b = b + tb;
+    }
+    if (lane == 0) { smem[2 * wave] = a; smem[2 * wave + 1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < n_waves; ++w) { a = a + smem[2 * w]; b = b + smem[2 * w + 1]; }
+    }
+    __syncthreads();
+}
+
 }  // namespace zk

@@ -17,7 +17,7 @@ namespace zk {
 
 constexpr int MLE_BLOCK = 256;
 constexpr int MLE_MAX_GRID = 256 * 8;   // 8 workgroups of 4 waves per CU: 32 waves/CU
-constexpr int TAIL_LOG = 10;            // tables of <= 2^10 entries (32 KiB) finish inside one workgroup's LDS
+constexpr int TAIL_LOG = 12;            // tables of <= 2^12 entries (128 KiB of the CU's 160 KiB LDS) finish inside one workgroup
 constexpr int TAIL_N = 1 << TAIL_LOG;
 
 // out[j] = lo + r*(hi - lo)  ==  r*hi + (1-r)*lo  (evaluation_form.rs:133), one Montgomery product.
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(MLE_BLOCK) void fold_kernel(const uint64_t* __restr
                                                          size_t n_out, uint32_t log_half,
                                                          const uint64_t* __restrict__ r_ptr,
                                                          uint64_t* __restrict__ partials) {
-    __shared__ Fr red[MLE_BLOCK / 64];
+    __shared__ Fr red[2 * MLE_BLOCK / 64];
     const Fr r = load_fr(r_ptr, 0);
     const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
     const size_t half_in = (size_t)1 << log_half;
@@ -65,11 +65,10 @@ __global__ __launch_bounds__(MLE_BLOCK) void fold_kernel(const uint64_t* __restr
         }
     }
     if (WITH_SUMS) {
-        Fr t_lo = block_reduce_fr(s_lo, red);
-        Fr t_hi = block_reduce_fr(s_hi, red);
+        block_reduce_fr2(s_lo, s_hi, red);
         if (threadIdx.x == 0) {
-            store_fr(partials, 2 * (size_t)blockIdx.x, t_lo);
-            store_fr(partials, 2 * (size_t)blockIdx.x + 1, t_hi);
+            store_fr(partials, 2 * (size_t)blockIdx.x, s_lo);
+            store_fr(partials, 2 * (size_t)blockIdx.x + 1, s_hi);
         }
     }
 }
@@ -78,41 +77,53 @@ __global__ __launch_bounds__(MLE_BLOCK) void fold_kernel(const uint64_t* __restr
 // (evaluation_form.rs:68-74); their sum is sum_over_the_boolean_hypercube (:80-84) / poly_sum (sumcheck.rs:25-27).
 __global__ __launch_bounds__(MLE_BLOCK) void half_sums_kernel(const uint64_t* __restrict__ in, size_t n,
                                                               uint64_t* __restrict__ partials) {
-    __shared__ Fr red[MLE_BLOCK / 64];
+    __shared__ Fr red[2 * MLE_BLOCK / 64];
     const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
     const size_t half = n >> 1;
     Fr s_lo = Fr::zero(), s_hi = Fr::zero();
-    for (size_t j = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; j < n; j += 2 * stride) {
-        const size_t j2 = j + stride;
-        Fr a = load_fr(in, j);
-        Fr b = (j2 < n) ? load_fr(in, j2) : Fr::zero();
-        if (j < half) s_lo = s_lo + a; else s_hi = s_hi + a;
-        if (j2 < half) s_lo = s_lo + b; else s_hi = s_hi + b;
+    for (size_t j = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; j < n; j += 4 * stride) {
+        Fr v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t ju = j + u * stride;
+            v[u] = (ju < n) ? load_fr(in, ju) : Fr::zero();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t ju = j + u * stride;
+            if (ju < half) s_lo = s_lo + v[u]; else s_hi = s_hi + v[u];
+        }
     }
-    Fr t_lo = block_reduce_fr(s_lo, red);
-    Fr t_hi = block_reduce_fr(s_hi, red);
+    block_reduce_fr2(s_lo, s_hi, red);
     if (threadIdx.x == 0) {
-        store_fr(partials, 2 * (size_t)blockIdx.x, t_lo);
-        store_fr(partials, 2 * (size_t)blockIdx.x + 1, t_hi);
+        store_fr(partials, 2 * (size_t)blockIdx.x, s_lo);
+        store_fr(partials, 2 * (size_t)blockIdx.x + 1, s_hi);
     }
 }
 
 // Workgroup-wide reduction of n_partials (lo, hi) pairs; result in thread 0.
 __device__ __forceinline__ void reduce_partials(const uint64_t* __restrict__ partials, uint32_t n_partials, Fr* red,
                                                 Fr& lo, Fr& hi) {
-    Fr s_lo = Fr::zero(), s_hi = Fr::zero();
-    for (uint32_t b = threadIdx.x; b < n_partials; b += blockDim.x) {
-        s_lo = s_lo + load_fr(partials, 2 * (size_t)b);
-        s_hi = s_hi + load_fr(partials, 2 * (size_t)b + 1);
+    lo = Fr::zero();
+    hi = Fr::zero();
+    for (uint32_t b = threadIdx.x; b < n_partials; b += 4 * blockDim.x) {   // 8 loads in flight per lane
+        Fr vl[4], vh[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t bu = b + u * blockDim.x;
+            vl[u] = (bu < n_partials) ? load_fr(partials, 2 * (size_t)bu) : Fr::zero();
+            vh[u] = (bu < n_partials) ? load_fr(partials, 2 * (size_t)bu + 1) : Fr::zero();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { lo = lo + vl[u]; hi = hi + vh[u]; }
     }
-    lo = block_reduce_fr(s_lo, red);
-    hi = block_reduce_fr(s_hi, red);
+    block_reduce_fr2(lo, hi, red);
 }
 
 // Single-workgroup reduction: out[0] = lower-half sum, out[1] = upper-half sum, out[2] = total.
 __global__ __launch_bounds__(MLE_BLOCK) void finish_sums_kernel(const uint64_t* __restrict__ partials,
                                                                 uint32_t n_partials, uint64_t* __restrict__ out) {
-    __shared__ Fr red[MLE_BLOCK / 64];
+    __shared__ Fr red[2 * MLE_BLOCK / 64];
     Fr lo, hi;
     reduce_partials(partials, n_partials, red, lo, hi);
     if (threadIdx.x == 0) {
@@ -127,25 +138,16 @@ __global__ __launch_bounds__(MLE_BLOCK) void finish_sums_kernel(const uint64_t* 
 __global__ __launch_bounds__(MLE_BLOCK) void fold_tail_kernel(const uint64_t* __restrict__ in, uint32_t n,
                                                               const uint64_t* __restrict__ pts, uint32_t n_pts,
                                                               uint64_t* __restrict__ out) {
-    __shared__ Fr tab[TAIL_N];
+    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
+    Fr* tab = reinterpret_cast<Fr*>(zk_dyn_lds);   // TAIL_N entries
     for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) tab[j] = load_fr(in, j);
     __syncthreads();
     uint32_t cur = n;
     for (uint32_t p = 0; p < n_pts; ++p) {
         const Fr r = load_fr(pts, p);
         const uint32_t half = cur >> 1;
-        Fr o[TAIL_N / 2 / MLE_BLOCK];
-#pragma unroll
-        for (int u = 0; u < TAIL_N / 2 / MLE_BLOCK; ++u) {
-            uint32_t j = threadIdx.x + u * MLE_BLOCK;
-            if (j < half) o[u] = fold_pair(tab[j], tab[j + half], r);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < TAIL_N / 2 / MLE_BLOCK; ++u) {
-            uint32_t j = threadIdx.x + u * MLE_BLOCK;
-            if (j < half) tab[j] = o[u];
-        }
+        // in place: lane j reads (j, j+half) and writes j; no other lane touches index j this round
+        for (uint32_t j = threadIdx.x; j < half; j += MLE_BLOCK) tab[j] = fold_pair(tab[j], tab[j + half], r);
         __syncthreads();
         cur = half;
     }

@@ -10,11 +10,48 @@
 
 namespace zk {
 
+#ifdef ZK_STAMPS   // diagnostic build only (make libzkhip_diag.so): in-kernel s_memtime stamps into a buffer of their own
+__device__ unsigned long long g_zk_stamps[64 * 8];
+#define ZK_STAMP(slot)                                                                              \
+    do {                                                                                            \
+        if (threadIdx.x == 0) {                                                                     \
+            unsigned long long _t;                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");              \
+            g_zk_stamps[(round & 63) * 8 + (slot)] = _t;                                            \
+        }                                                                                           \
+    } while (0)
+#else
+#define ZK_STAMP(slot) do { } while (0)
+#endif
+
 // Device-resident prover bookkeeping (one per context).
 struct SumcheckDev {
     Sha256State transcript;
     uint64_t sum[4];   // claimed sum (Montgomery)
 };
+
+// One round of the transcript (sumcheck.rs:33-35,42-46) executed by wave 0 of the workgroup: lanes 0..2 convert
+// (sum, lo, hi) out of Montgomery form side by side -- one product's latency instead of three -- then every lane
+// of the wave runs the same SHA-256 chain (uniform control flow) and lane 0 publishes.  `conv` is LDS scratch.
+__device__ __forceinline__ Fr transcript_round(Transcript& tr, Fr* conv, const Fr& sum, const Fr& lo, const Fr& hi,
+                                               bool absorb_sum) {
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) { conv[0] = sum; conv[1] = lo; conv[2] = hi; }
+    __builtin_amdgcn_wave_barrier();
+    Fr mine = conv[lane < 3 ? lane : 2];
+    Fr canon = fr_from_mont_outlined(mine);
+    Fr c_sum, c_lo, c_hi;
+#pragma unroll
+    for (int i = 0; i < Fr::N; ++i) {
+        c_sum.l[i] = __shfl(canon.l[i], 0, 64);
+        c_lo.l[i] = __shfl(canon.l[i], 1, 64);
+        c_hi.l[i] = __shfl(canon.l[i], 2, 64);
+    }
+    if (absorb_sum) tr.commit_canonical(c_sum);
+    tr.commit_canonical(c_lo);
+    tr.commit_canonical(c_hi);
+    return tr.challenge_fr();
+}
 
 // Closes round `round` while the table is still large.
 //   partials: n_partials x (lo, hi) partial half-sums of the CURRENT table (from half_sums_kernel or the
@@ -27,26 +64,35 @@ __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_round_kernel(const uint64_
                                                                    uint32_t round, uint32_t first,
                                                                    uint64_t* __restrict__ round_polys,
                                                                    uint64_t* __restrict__ challenges) {
-    __shared__ Fr red[MLE_BLOCK / 64];
+    __shared__ Fr red[2 * MLE_BLOCK / 64];
+    __shared__ Fr conv[4];
     Fr lo, hi;
+    ZK_STAMP(0);
     reduce_partials(partials, n_partials, red, lo, hi);
-    if (threadIdx.x == 0) {
+    ZK_STAMP(1);
+    if (threadIdx.x == 0) { conv[1] = lo; conv[2] = hi; }
+    __syncthreads();
+    if (threadIdx.x < 64) {   // wave 0, uniform
+        lo = conv[1];
+        hi = conv[2];
         Transcript tr;
+        Fr sum = Fr::zero();
         if (first) {
-            Fr sum = (first == 2) ? load_fr(st->sum, 0) : lo + hi;
-            store_fr(st->sum, 0, sum);
+            sum = (first == 2) ? load_fr(st->sum, 0) : lo + hi;
             tr.init();
-            tr.commit_fr(sum);
         } else {
             tr.load(&st->transcript);
         }
-        tr.commit_fr(lo);   // uni_poly.to_bytes()  sumcheck.rs:42
-        tr.commit_fr(hi);
-        Fr r = tr.challenge_fr();   // :46
-        tr.store(&st->transcript);
-        store_fr(round_polys, 2 * (size_t)round, lo);
-        store_fr(round_polys, 2 * (size_t)round + 1, hi);
-        store_fr(challenges, round, r);
+        ZK_STAMP(2);
+        Fr r = transcript_round(tr, conv, sum, lo, hi, first != 0);   // sumcheck.rs:33-35,42,46
+        ZK_STAMP(3);
+        if (threadIdx.x == 0) {
+            if (first) store_fr(st->sum, 0, sum);
+            tr.store(&st->transcript);
+            store_fr(round_polys, 2 * (size_t)round, lo);
+            store_fr(round_polys, 2 * (size_t)round + 1, hi);
+            store_fr(challenges, round, r);
+        }
     }
 }
 
@@ -57,13 +103,16 @@ __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_tail_kernel(const uint64_t
                                                                   uint64_t* __restrict__ round_polys,
                                                                   uint64_t* __restrict__ challenges,
                                                                   uint64_t* __restrict__ final_eval) {
-    __shared__ Fr tab[TAIL_N];
-    __shared__ Fr red[MLE_BLOCK / 64];
-    __shared__ Fr r_sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
+    Fr* tab = reinterpret_cast<Fr*>(zk_dyn_lds);   // TAIL_N entries
+    Fr* red = tab + TAIL_N;                        // 2 * MLE_BLOCK / 64
+    Fr* conv = red + 2 * MLE_BLOCK / 64;           // 4
+    Fr* r_shp = conv + 4;                          // 1
+#define r_sh (*r_shp)
     for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) tab[j] = load_fr(in, j);
     __syncthreads();
     Transcript tr;
-    if (threadIdx.x == 0 && !first) tr.load(&st->transcript);
+    if (threadIdx.x < 64 && !first) tr.load(&st->transcript);
     uint32_t cur = n, round = round0;
     while (cur > 1) {
         const uint32_t half = cur >> 1;
@@ -72,37 +121,32 @@ __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_tail_kernel(const uint64_t
             s_lo = s_lo + tab[j];
             s_hi = s_hi + tab[j + half];
         }
-        Fr lo = block_reduce_fr(s_lo, red);
-        Fr hi = block_reduce_fr(s_hi, red);
-        if (threadIdx.x == 0) {
-            if (first && round == round0) {
-                Fr sum = (first == 2) ? load_fr(st->sum, 0) : lo + hi;
-                store_fr(st->sum, 0, sum);
+        Fr lo = s_lo, hi = s_hi;
+        block_reduce_fr2(lo, hi, red);
+        if (threadIdx.x == 0) { conv[1] = lo; conv[2] = hi; }
+        __syncthreads();
+        if (threadIdx.x < 64) {   // wave 0, uniform
+            lo = conv[1];
+            hi = conv[2];
+            const bool absorb_sum = first && round == round0;
+            Fr sum = Fr::zero();
+            if (absorb_sum) {
+                sum = (first == 2) ? load_fr(st->sum, 0) : lo + hi;
                 tr.init();
-                tr.commit_fr(sum);
             }
-            tr.commit_fr(lo);
-            tr.commit_fr(hi);
-            Fr r = tr.challenge_fr();
-            r_sh = r;
-            store_fr(round_polys, 2 * (size_t)round, lo);
-            store_fr(round_polys, 2 * (size_t)round + 1, hi);
-            store_fr(challenges, round, r);
+            Fr r = transcript_round(tr, conv, sum, lo, hi, absorb_sum);
+            if (threadIdx.x == 0) {
+                if (absorb_sum) store_fr(st->sum, 0, sum);
+                r_sh = r;
+                store_fr(round_polys, 2 * (size_t)round, lo);
+                store_fr(round_polys, 2 * (size_t)round + 1, hi);
+                store_fr(challenges, round, r);
+            }
         }
         __syncthreads();
         const Fr r = r_sh;
-        Fr o[TAIL_N / 2 / MLE_BLOCK];
-#pragma unroll
-        for (int u = 0; u < TAIL_N / 2 / MLE_BLOCK; ++u) {
-            uint32_t j = threadIdx.x + u * MLE_BLOCK;
-            if (j < half) o[u] = fold_pair(tab[j], tab[j + half], r);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < TAIL_N / 2 / MLE_BLOCK; ++u) {
-            uint32_t j = threadIdx.x + u * MLE_BLOCK;
-            if (j < half) tab[j] = o[u];
-        }
+        // in place: lane j reads (j, j+half) and writes j; no other lane touches index j this round
+        for (uint32_t j = threadIdx.x; j < half; j += MLE_BLOCK) tab[j] = fold_pair(tab[j], tab[j + half], r);
         __syncthreads();
         cur = half;
         ++round;
@@ -111,6 +155,8 @@ __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_tail_kernel(const uint64_t
         tr.store(&st->transcript);
         store_fr(final_eval, 0, tab[0]);
     }
+#undef r_sh
 }
+constexpr size_t TAIL_LDS_BYTES = (size_t)(TAIL_N + 2 * MLE_BLOCK / 64 + 4 + 1) * sizeof(Fr);
 
 }  // namespace zk

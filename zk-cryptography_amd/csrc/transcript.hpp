@@ -20,37 +20,80 @@ struct Sha256State {
 
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_rotateright32(x, n); }
 
-__device__ inline void sha256_compress(uint32_t (&h)[8], const uint32_t (&blk)[16]) {
-    constexpr uint32_t K[64] = {
-        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
-        0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
-        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
-        0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
-        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
-        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
-        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
-        0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+__constant__ uint32_t SHA256_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+// One compression.  Kept out of line and rolled (16 rounds + 3 x 16 rounds with the message schedule):
+// the transcript runs on a single wave, where instruction fetch of a fully unrolled body costs more
+// than the loop.  v_bitop3_b32 folds each 3-input boolean (xor3 / choose / majority) into one instruction.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t choose(uint32_t e, uint32_t f, uint32_t g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA); }
+__device__ __forceinline__ uint32_t majority(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
+
+#define ZK_SHA_ROUND(a, b, c, d, e, f, g, h, kw)                                      \
+    {                                                                                 \
+        uint32_t t1 = h + xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)) + choose(e, f, g) + (kw); \
+        uint32_t t2 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)) + majority(a, b, c);          \
+        d += t1;                                                                      \
+        h = t1 + t2;                                                                  \
+    }
+#define ZK_SHA_8ROUNDS(W, KB)                                    \
+    ZK_SHA_ROUND(a, b, c, d, e, f, g, hh, SHA256_K[KB + 0] + W[0]) \
+    ZK_SHA_ROUND(hh, a, b, c, d, e, f, g, SHA256_K[KB + 1] + W[1]) \
+    ZK_SHA_ROUND(g, hh, a, b, c, d, e, f, SHA256_K[KB + 2] + W[2]) \
+    ZK_SHA_ROUND(f, g, hh, a, b, c, d, e, SHA256_K[KB + 3] + W[3]) \
+    ZK_SHA_ROUND(e, f, g, hh, a, b, c, d, SHA256_K[KB + 4] + W[4]) \
+    ZK_SHA_ROUND(d, e, f, g, hh, a, b, c, SHA256_K[KB + 5] + W[5]) \
+    ZK_SHA_ROUND(c, d, e, f, g, hh, a, b, SHA256_K[KB + 6] + W[6]) \
+    ZK_SHA_ROUND(b, c, d, e, f, g, hh, a, SHA256_K[KB + 7] + W[7])
+
+__device__ __noinline__ void sha256_compress(uint32_t (&h)[8], const uint32_t (&blk)[16]) {
     uint32_t w[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) w[i] = blk[i];
     uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    {
+        const uint32_t* W = w;
+        ZK_SHA_8ROUNDS(W, 0)
+        W = w + 8;
+        ZK_SHA_8ROUNDS(W, 8)
+    }
+#pragma unroll 1
+    for (int base = 16; base < 64; base += 16) {
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-        if (i >= 16) {
-            uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-            uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
-            uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
-            w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        for (int j = 0; j < 16; ++j) {
+            uint32_t w15 = w[(j + 1) & 15], w2 = w[(j + 14) & 15];
+            uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+            uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
+            w[j] = w[j] + s0 + w[(j + 9) & 15] + s1;
         }
-        uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
-        uint32_t ch = (e & f) ^ (~e & g);
-        uint32_t t1 = hh + S1 + ch + K[i] + w[i & 15];
-        uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
-        uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
-        uint32_t t2 = S0 + mj;
-        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        const uint32_t* W = w;
+        ZK_SHA_8ROUNDS(W, base)
+        W = w + 8;
+        ZK_SHA_8ROUNDS(W, base + 8)
     }
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+// Out-of-line Montgomery product for the single-wave control paths (keeps those kernels small).
+__device__ __noinline__ Fr fr_mul_outlined(const Fr& a, const Fr& b) { return a * b; }
+__device__ __forceinline__ Fr fr_from_mont_outlined(const Fr& a) {
+    Fr o = Fr::zero();
+    o.l[0] = 1;
+    return fr_mul_outlined(a, o);
+}
+__device__ __forceinline__ Fr fr_to_mont_outlined(const Fr& a) {
+    Fr r2;
+#pragma unroll
+    for (int i = 0; i < Fr::N; ++i) r2.l[i] = FrParams::r2(i);
+    return fr_mul_outlined(a, r2);
 }
 
 // Register-resident transcript (loaded from / stored to a Sha256State in global memory).
@@ -99,9 +142,16 @@ struct Transcript {
         }
         len += 32;
     }
+    // to_bytes_be() of an element already converted to its canonical integer (into_bigint), absorbed
+    __device__ __forceinline__ void commit_canonical(const Fr& c) {
+        uint32_t wds[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wds[i] = c.l[7 - i];
+        commit_words8(wds);
+    }
     // into_bigint().to_bytes_be() of a Montgomery-form element, absorbed (sumcheck/src/utils.rs:7-9)
     __device__ __forceinline__ void commit_fr(const Fr& v_mont) {
-        Fr c = v_mont.from_mont();
+        Fr c = fr_from_mont_outlined(v_mont);
         uint32_t wds[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) wds[i] = c.l[7 - i];   // big-endian byte string == words MSW first
@@ -137,7 +187,7 @@ struct Transcript {
         for (int i = 0; i < 8; ++i) v.l[i] = d[7 - i];
         v.reduce_once();
         v.reduce_once();
-        return v.to_mont();
+        return fr_to_mont_outlined(v);
     }
 };
 

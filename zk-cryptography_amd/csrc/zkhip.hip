@@ -197,7 +197,8 @@ static int fold_chain(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uin
         if (all_zero_tail && cn <= (size_t)TAIL_N) {
             // finish every remaining fold inside one workgroup
             ProfScope ps(c, "fold_tail", 0.0);
-            hipLaunchKernelGGL(fold_tail_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, cur, (uint32_t)cn,
+            ZK_TRY(c->allow_big_lds((const void*)fold_tail_kernel, TAIL_LDS_BYTES));
+            hipLaunchKernelGGL(fold_tail_kernel, dim3(1), dim3(MLE_BLOCK), TAIL_LDS_BYTES, c->stream, cur, (uint32_t)cn,
                                d_pts + 4 * p, (uint32_t)(n_pts - p), d_out);
             ZK_HIP(c, hipGetLastError());
             return ZKHIP_OK;
@@ -370,7 +371,8 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
             ++round;
         }
     }
-    hipLaunchKernelGGL(sumcheck_tail_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, cur, (uint32_t)cn, st, round, first,
+    ZK_TRY(c->allow_big_lds((const void*)sumcheck_tail_kernel, TAIL_LDS_BYTES));
+    hipLaunchKernelGGL(sumcheck_tail_kernel, dim3(1), dim3(MLE_BLOCK), TAIL_LDS_BYTES, c->stream, cur, (uint32_t)cn, st, round, first,
                        d_rp, d_ch, d_fin);
     ZK_HIP(c, hipGetLastError());
     // results -> host
@@ -384,3 +386,11 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
     std::memcpy(h_challenges, pin + 4 + 8 * ZK_MAX_ROUNDS, 32 * (size_t)n_vars);
     return ZKHIP_OK;
 }
+
+#ifdef ZK_STAMPS
+extern "C" int zkhip_debug_read_stamps(zkhip_ctx* c, unsigned long long* h_out /*64*8*/) {
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    ZK_HIP(c, hipMemcpyFromSymbol(h_out, HIP_SYMBOL(zk::g_zk_stamps), 64 * 8 * 8));
+    return ZKHIP_OK;
+}
+#endif
