@@ -101,6 +101,32 @@ int zkhip_sumcheck_prove(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, cons
                          const uint64_t *h_first_half_sums, uint64_t *h_sum, uint64_t *h_round_polys,
                          uint64_t *h_challenges);
 
+/* ---- KZG commit = multi-scalar multiplication over G1 -------------------------------------- */
+/* MultilinearKZG::commitment (kzg/src/multilinear_kzg.rs:33-48; require_equal_len = 1 reproduces its
+ * assert_eq!(srs.len(), evaluations.len())) and UnivariateKZG::commitment (kzg/src/univariate_kzg.rs:37-58;
+ * require_equal_len = 0: the first n_scalars SRS points are used, and n_scalars > n_points is the
+ * out-of-bounds panic at :53 -> ZKHIP_ERR_INDEX).
+ *   d_points_xy  n_points x 12 : affine SRS points (x[6], y[6]), Montgomery Fq limbs, resident in HBM
+ *   d_points_inf n_points bytes: 1 = point at infinity (NULL = none)
+ *   d_scalars    n_scalars x 4 : polynomial evaluations / coefficients, Montgomery Fr limbs
+ * Output (host): h_out_xy[12] affine commitment, *h_out_inf = 1 if it is the identity.  Parity with the
+ * reference is on these affine coordinates (Jacobian X,Y,Z are algorithm dependent). */
+int zkhip_kzg_commit(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t *d_points_inf, size_t n_points,
+                     const uint64_t *d_scalars, size_t n_scalars, int require_equal_len, uint64_t *h_out_xy,
+                     uint8_t *h_out_inf);
+/* SRS generation on the device (G1 side; the G2 powers are only used by the pairing verifier, out of scope).
+ *   multilinear: TrustedSetup::generate_powers_of_tau_in_g1 (kzg/src/trusted_setup.rs:25-35):
+ *                point i = G * prod_j (bit_j(i) ? tau_j : 1 - tau_j), hypercube bits MSB first; 2^n_vars points.
+ *   univariate:  UnivariateKZG::generate_srs (kzg/src/univariate_kzg.rs:18-35): point i = G * tau^i, i = 0..=max_degree.
+ * Outputs are DEVICE arrays in the layout zkhip_kzg_commit consumes: d_out_xy[n*12], d_out_inf[n]. */
+int zkhip_srs_multilinear_g1(zkhip_ctx *ctx, const uint64_t *h_tau, uint32_t n_vars, uint64_t *d_out_xy,
+                             uint8_t *d_out_inf);
+int zkhip_srs_univariate_g1(zkhip_ctx *ctx, const uint64_t *h_tau, size_t max_degree, uint64_t *d_out_xy,
+                            uint8_t *d_out_inf);
+/* Sum of n affine points given on the host (combining per-GPU partial commitments after an all-gather). */
+int zkhip_g1_sum_affine(const uint64_t *h_points_xy, const uint8_t *h_points_inf, size_t n, uint64_t *h_out_xy,
+                        uint8_t *h_out_inf);
+
 #ifdef __cplusplus
 }
 #endif

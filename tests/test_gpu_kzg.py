@@ -1,0 +1,138 @@
+"""GPU parity: KZG commit (Pippenger MSM on gfx950) and SRS generation vs the CPU oracle's restatement of the
+reference's naive sum of mul_bigint; equality on affine coordinates.  Names follow kzg/src/*_kzg.rs tests."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def zk():
+    import zk_cryptography_amd as z
+    return z
+
+
+def _aff(ora, jac):
+    a = ora.g1_to_affine(jac)
+    return a[:12].copy(), bool(a[12])
+
+
+def _same(zk, got, want_xy, want_inf):
+    assert got.infinity == want_inf
+    if not want_inf:
+        assert np.array_equal(got.xy, want_xy)
+
+
+def test_kzg_1_commitment(zk, ora):   # multilinear_kzg.rs:133-148 data; commit == p(tau) * G = 28 G
+    vals = [0, 7, 0, 5, 0, 7, 4, 9]
+    tau = zk.Fr.from_ints([2, 3, 4])
+    srs = zk.TrustedSetup.setup(tau)
+    com = zk.MultilinearKZG.commitment(zk.Multilinear(zk.Fr.from_ints(vals)), srs)
+    want = ora.kzg_commitment(zk.Fr.from_ints(vals), ora.kzg_multilinear_srs_g1(tau), True)
+    _same(zk, com, *_aff(ora, want))
+    x, y = com.coords()
+    assert x == 0x16ad11e5d15f77c1143b1697344911b9c590110fdd8dd09df2e58bfd757269169deefe8be3544d4e049fb3776fb0bcfb
+    assert y == 0x0f5c8be5f27fc19eee337785e43d18414a8ff04995230f04509800252164cf47887a4a1864f18288652196af6272e7f6
+
+
+def test_kzg_2_commitment(zk, ora):   # multilinear_kzg.rs:151-197 data
+    vals = [0, 0, 0, 2, 0, 0, 10, 12, 0, -12, 4, -6, 0, -12, 14, 4]
+    tau = zk.Fr.from_ints([12, 9, 28, 40])
+    srs = zk.TrustedSetup.setup(tau)
+    com = zk.MultilinearKZG.commitment(zk.Multilinear(zk.Fr.from_ints(vals)), srs)
+    want = ora.kzg_commitment(zk.Fr.from_ints(vals), ora.kzg_multilinear_srs_g1(tau), True)
+    _same(zk, com, *_aff(ora, want))
+    tampered = zk.TrustedSetup.setup(zk.Fr.from_ints([12, 19, 28, 40]))
+    assert not (zk.MultilinearKZG.commitment(zk.Multilinear(zk.Fr.from_ints(vals)), tampered) == com)
+
+
+def test_univariate_kzg_commitment(zk, ora):   # univariate_kzg.rs:111-129 data
+    tau = zk.Fr.from_int(10)
+    srs = zk.UnivariateKZG.generate_srs(tau, 4)
+    coeffs = zk.Fr.from_ints([1, 2, 3, 4, 5])
+    com = zk.UnivariateKZG.commitment(zk.DenseUnivariatePolynomial(coeffs), srs)
+    want = ora.kzg_commitment(coeffs, ora.kzg_univariate_srs_g1(tau, 4), False)
+    _same(zk, com, *_aff(ora, want))
+    p_tau = sum(k * 10 ** i for i, k in enumerate([1, 2, 3, 4, 5]))
+    _same(zk, com, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), p_tau)))
+    # shorter polynomial than the SRS is fine; a longer one indexes out of bounds (univariate_kzg.rs:53)
+    zk.UnivariateKZG.commitment(zk.DenseUnivariatePolynomial(coeffs[:3]), srs)
+    with pytest.raises(IndexError):
+        zk.UnivariateKZG.commitment(zk.DenseUnivariatePolynomial(zk.Fr.from_ints([1, 2, 3, 4, 5, 6])), srs)
+    with pytest.raises(AssertionError):    # multilinear_kzg.rs:36-41
+        zk.MultilinearKZG.commitment(zk.Multilinear(zk.Fr.from_ints([1, 2, 3, 4])), srs)
+
+
+@pytest.mark.parametrize("n_vars", [1, 3, 6])
+def test_srs_multilinear_matches_oracle(zk, ora, n_vars):
+    tau = ora.random_fr(n_vars, 31 + n_vars)
+    srs = zk.TrustedSetup.setup(tau)
+    want = ora.g1_batch_to_affine(ora.kzg_multilinear_srs_g1(tau))
+    assert np.array_equal(srs.powers_of_tau_in_g1.cpu().numpy().view(np.uint64), want[:, :12])
+    assert np.array_equal(srs.inf.cpu().numpy(), want[:, 12].astype(np.uint8))
+
+
+def test_srs_univariate_matches_oracle(zk, ora):
+    tau = ora.random_fr(1, 77)[0]
+    srs = zk.UnivariateKZG.generate_srs(tau, 40)
+    want = ora.g1_batch_to_affine(ora.kzg_univariate_srs_g1(tau, 40))
+    assert np.array_equal(srs.powers_of_tau_in_g1.cpu().numpy().view(np.uint64), want[:, :12])
+
+
+def test_srs_with_identity_points_and_zero_scalars(zk, ora):
+    # kzg/benches/multilinear_kzg_benchmark.rs:17-22: tau = (0,1,2,...) => eq-scalars that are 0 => G*0 = identity
+    tau = zk.Fr.from_ints([0, 1, 2, 3])
+    srs = zk.TrustedSetup.setup(tau)
+    assert int(srs.inf.sum().item()) > 0
+    vals = zk.Fr.from_ints([0, 5, 0, 0, 7, 0, 1, R - 1, 2, 3, 0, 0, 9, 9, 9, 1])
+    com = zk.MultilinearKZG.commitment(zk.Multilinear(vals), srs)
+    want = ora.kzg_commitment(vals, ora.kzg_multilinear_srs_g1(tau), True)
+    _same(zk, com, *_aff(ora, want))
+    zero = zk.MultilinearKZG.commitment(zk.Multilinear(zk.Fr.from_ints([0] * 16)), srs)
+    assert zero.infinity
+
+
+def test_commit_duplicate_and_inverse_points(zk, ora):
+    # all SRS points equal (P + P doublings inside buckets) and scalars that cancel (P + (-P))
+    g = ora.g1_batch_to_affine(np.stack([ora.g1_generator()] * 64))
+    srs = zk.TrustedSetup(g[:, :12], g[:, 12].astype(np.uint8))
+    sc = zk.Fr.from_ints([5] * 32 + [R - 5] * 32)
+    assert zk.MultilinearKZG.commitment(zk.Multilinear(sc), srs).infinity
+    sc2 = zk.Fr.from_ints([3] * 64)
+    com = zk.MultilinearKZG.commitment(zk.Multilinear(sc2), srs)
+    _same(zk, com, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), 192)))
+
+
+@pytest.mark.parametrize("log_n", [4, 8, 10, 12])
+def test_commit_random_matches_naive_oracle(zk, ora, log_n):
+    n = 1 << log_n
+    tau = ora.random_fr(log_n, 500 + log_n)
+    srs = zk.TrustedSetup.setup(tau)
+    sc = ora.random_fr(n, 600 + log_n)
+    com = zk.MultilinearKZG.commitment(zk.Multilinear(sc), srs)
+    if log_n <= 8:      # the reference algorithm itself (naive double-and-add) is affordable
+        want = ora.kzg_commitment(sc, ora.kzg_multilinear_srs_g1(tau), True)
+    else:               # commit == p(tau) * G  (and the CPU bucket method agrees)
+        p_tau = ora.fr_to_ints(ora.mle_evaluation(sc, tau))[0]
+        want = ora.g1_mul_int(ora.g1_generator(), p_tau)
+        pts = np.concatenate([srs.powers_of_tau_in_g1.cpu().numpy().view(np.uint64),
+                              srs.inf.cpu().numpy().astype(np.uint64)[:, None]], axis=1)
+        assert ora.g1_affine_ints(ora.g1_to_affine(ora.msm_pippenger(sc, pts))) == ora.g1_affine_ints(ora.g1_to_affine(want))
+    _same(zk, com, *_aff(ora, want))
+
+
+def test_commit_2_20_identity(zk, ora):
+    """BASELINE config 3 size: 2^20-point SRS generated on the device from tau; commit == p(tau) * G where
+    p(tau) comes from the (independently verified) GPU evaluation and the product from the oracle."""
+    import torch
+    log_n = 20
+    tau = ora.random_fr(log_n, 4242)
+    srs = zk.TrustedSetup.setup(tau)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    t = torch.randint(0, 2 ** 62, (1 << log_n, 4), dtype=torch.int64, device="cuda", generator=g)
+    poly = zk.Multilinear(t)
+    com = zk.MultilinearKZG.commitment(poly, srs)
+    p_tau = zk.Fr.to_ints(poly.evaluation(tau))[0]
+    _same(zk, com, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), p_tau)))

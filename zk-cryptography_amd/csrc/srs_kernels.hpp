@@ -1,0 +1,128 @@
+// srs_kernels.hpp -- structured reference string generation on the device (gfx950).
+//
+// Replaces TrustedSetup::generate_powers_of_tau_in_g1 (kzg/src/trusted_setup.rs:25-35, with
+// check_for_zero_and_one / generate_array_of_points kzg/src/utils.rs:19-40 over boolean_hypercube
+// polynomial/src/utils.rs:141-157) and UnivariateKZG::generate_srs (kzg/src/univariate_kzg.rs:18-35):
+// N independent fixed-base scalar multiplications G * s_i, then one batched conversion to affine
+// (the SRS is stored affine in HBM so that the commit path can use mixed additions).
+#pragma once
+#include "g1.hpp"
+
+namespace zk {
+
+constexpr int SRS_BLOCK = 256;
+
+// eq scalars of the multilinear SRS: s_i = prod_j (bit_j(i) ? tau_j : 1 - tau_j), bit 0 = MSB (variable 0)
+__global__ __launch_bounds__(SRS_BLOCK) void srs_eq_scalars_kernel(const uint64_t* __restrict__ tau, uint32_t n_vars,
+                                                                   uint64_t* __restrict__ out) {
+    const size_t n = (size_t)1 << n_vars;
+    const size_t stride = (size_t)gridDim.x * SRS_BLOCK;
+    const Fr one = Fr::one();
+    for (size_t i = (size_t)blockIdx.x * SRS_BLOCK + threadIdx.x; i < n; i += stride) {
+        Fr acc = one;
+        for (uint32_t j = 0; j < n_vars; ++j) {
+            Fr t = load_fr(tau, j);
+            if (!((i >> (n_vars - 1 - j)) & 1)) t = one - t;
+            acc = acc * t;
+        }
+        store_fr(out, i, acc);
+    }
+}
+
+// powers of tau: s_i = tau^i (tau.pow([i]) univariate_kzg.rs:26)
+__global__ __launch_bounds__(SRS_BLOCK) void srs_power_scalars_kernel(const uint64_t* __restrict__ tau, size_t n,
+                                                                      uint64_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * SRS_BLOCK;
+    const Fr t = load_fr(tau, 0);
+    for (size_t i = (size_t)blockIdx.x * SRS_BLOCK + threadIdx.x; i < n; i += stride) {
+        Fr acc = Fr::one();
+        bool started = false;
+        for (int b = 63; b >= 0; --b) {
+            if (started) acc = acc * acc;
+            if ((i >> b) & 1) { acc = acc * t; started = true; }
+        }
+        store_fr(out, i, acc);
+    }
+}
+
+__device__ __forceinline__ G1Affine g1_generator() {
+    constexpr uint32_t gx[12] = {0xfd530c16u, 0x5cb38790u, 0x9976fff5u, 0x7817fc67u, 0x143ba1c1u, 0x154f95c7u,
+                                 0xf3d0e747u, 0xf0ae6acdu, 0x21dbf440u, 0xedce6eccu, 0x9e0bfb75u, 0x12017741u};
+    constexpr uint32_t gy[12] = {0x0ce72271u, 0xbaac93d5u, 0x7918fd8eu, 0x8c22631au, 0x570725ceu, 0xdd595f13u,
+                                 0x50405194u, 0x51ac5829u, 0xad0059c0u, 0x0e1c8c3fu, 0x5008a26au, 0x0bbc3efcu};
+    G1Affine g;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { g.x.l[i] = gx[i]; g.y.l[i] = gy[i]; }
+    return g;
+}
+
+// out[i] = G * scalars[i]  (Group::mul_bigint(point.into_bigint()) trusted_setup.rs:33): MSB-first double-and-add
+__global__ __launch_bounds__(SRS_BLOCK) void srs_fixed_base_kernel(const uint64_t* __restrict__ scalars, size_t n,
+                                                                   uint64_t* __restrict__ out_xyzz) {
+    const size_t i = (size_t)blockIdx.x * SRS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const Fr k = load_fr(scalars, i).from_mont();
+    const G1Affine g = g1_generator();
+    G1Xyzz acc = G1Xyzz::identity();
+    for (int w = 7; w >= 0; --w) {
+        uint32_t word = k.l[7];
+#pragma unroll
+        for (int q = 7; q >= 0; --q) if (q == w) word = k.l[q];
+        for (int b = 31; b >= 0; --b) {
+            acc = g1_double(acc);
+            if ((word >> b) & 1) g1_madd(acc, g, false);
+        }
+    }
+    store_xyzz(out_xyzz, i, acc);
+}
+
+// a^(p-2) in Fq (Fermat)
+__device__ __noinline__ Fq fq_inverse(Fq a) {
+    Fq acc = Fq::one();
+    for (int w = 11; w >= 0; --w) {
+        uint32_t e = FqParams::p(0) - 2;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) if (q == w) e = (q == 0) ? FqParams::p(0) - 2 : FqParams::p(q);
+        for (int b = 31; b >= 0; --b) {
+            acc = fq_sqr(acc);
+            if ((e >> b) & 1) acc = fq_mul(acc, a);
+        }
+    }
+    return acc;
+}
+
+// XYZZ -> affine (x = X/ZZ, y = Y/ZZZ) with Montgomery's batch-inversion trick over CHUNK points per lane.
+constexpr int SRS_CHUNK = 8;
+__global__ __launch_bounds__(SRS_BLOCK) void srs_batch_affine_kernel(const uint64_t* __restrict__ in_xyzz, size_t n,
+                                                                     uint64_t* __restrict__ out_xy,
+                                                                     uint8_t* __restrict__ out_inf) {
+    const size_t t = (size_t)blockIdx.x * SRS_BLOCK + threadIdx.x;
+    const size_t base = t * SRS_CHUNK;
+    if (base >= n) return;
+    const int cnt = (int)((n - base) < (size_t)SRS_CHUNK ? (n - base) : SRS_CHUNK);
+    Fq prefix[SRS_CHUNK];
+    Fq acc = Fq::one();
+    for (int k = 0; k < cnt; ++k) {
+        prefix[k] = acc;
+        Fq zz = load_fq(in_xyzz + 24 * (base + k) + 12), zzz = load_fq(in_xyzz + 24 * (base + k) + 18);
+        if (!zz.is_zero()) acc = fq_mul(acc, fq_mul(zz, zzz));
+    }
+    Fq inv = fq_inverse(acc);
+    for (int k = cnt - 1; k >= 0; --k) {
+        G1Xyzz p = load_xyzz(in_xyzz, base + k);
+        if (p.zz.is_zero()) {
+            store_fq(out_xy + 12 * (base + k), Fq::zero());
+            store_fq(out_xy + 12 * (base + k) + 6, Fq::zero());
+            out_inf[base + k] = 1;
+            continue;
+        }
+        Fq d = fq_mul(p.zz, p.zzz);
+        Fq dinv = fq_mul(inv, prefix[k]);     // 1 / (zz * zzz) of this point
+        inv = fq_mul(inv, d);
+        store_fq(out_xy + 12 * (base + k), fq_mul(p.x, fq_mul(dinv, p.zzz)));
+        store_fq(out_xy + 12 * (base + k) + 6, fq_mul(p.y, fq_mul(dinv, p.zz)));
+        out_inf[base + k] = 0;
+    }
+}
+
+}  // namespace zk
