@@ -101,6 +101,28 @@ int zkhip_sumcheck_prove(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, cons
                          const uint64_t *h_first_half_sums, uint64_t *h_sum, uint64_t *h_round_polys,
                          uint64_t *h_challenges);
 
+/* ---- composed sumcheck provers (sumcheck/src/composed/) --------------------------------------- */
+/* A product term is K tables (ComposedMultilinear, polynomial/src/composed/composed_multilinear.rs:8-18) of n
+ * entries each, given as a HOST array of K DEVICE pointers.  K <= 5; at most 4 terms. */
+/* ComposedSumcheck::calculate_poly_sum (composed_sumcheck.rs:28-30): sum_x prod_k f_k(x) -> h_sum[4] */
+int zkhip_composed_sum(zkhip_ctx *ctx, const uint64_t *const *h_table_ptrs, uint32_t k, size_t n, uint64_t *h_sum);
+/* ComposedSumcheck::prove (composed_sumcheck.rs:32-67): h_round_polys[n_vars*(k+1)*4] (evaluations at
+ * 0..=k per round), h_challenges[n_vars*4]. */
+int zkhip_composed_prove(zkhip_ctx *ctx, const uint64_t *const *h_table_ptrs, uint32_t k, size_t n,
+                         uint64_t *h_round_polys, uint64_t *h_challenges);
+/* MultiComposedSumcheckProver::calculate_poly_sum (multi_composed_sumcheck.rs:36-45) */
+int zkhip_multi_composed_sum(zkhip_ctx *ctx, const uint64_t *const *h_table_ptrs, const uint32_t *h_term_sizes,
+                             uint32_t n_terms, size_t n, uint64_t *h_sum);
+/* MultiComposedSumcheckProver::prove (partial = 0, :47-54: every table's bytes are absorbed first) and
+ * ::prove_partial (partial = 1, :56-62), both through prove_internal (:64-121).
+ *   h_table_ptrs: sum(h_term_sizes) device pointers, term after term;  h_sum[4]: the claimed sum.
+ * Outputs: h_round_poly_lens[n_vars] = #monomials of each round's SparseUnivariatePolynomial;
+ *          h_round_polys[n_vars*7*8] = per round up to 7 monomials (coeff[4], pow[4]) in Montgomery form;
+ *          h_challenges[n_vars*4]. */
+int zkhip_multi_composed_prove(zkhip_ctx *ctx, const uint64_t *const *h_table_ptrs, const uint32_t *h_term_sizes,
+                               uint32_t n_terms, size_t n, const uint64_t *h_sum, int partial,
+                               uint32_t *h_round_poly_lens, uint64_t *h_round_polys, uint64_t *h_challenges);
+
 /* ---- KZG commit = multi-scalar multiplication over G1 -------------------------------------- */
 /* MultilinearKZG::commitment (kzg/src/multilinear_kzg.rs:33-48; require_equal_len = 1 reproduces its
  * assert_eq!(srs.len(), evaluations.len())) and UnivariateKZG::commitment (kzg/src/univariate_kzg.rs:37-58;

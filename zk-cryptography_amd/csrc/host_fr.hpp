@@ -1,0 +1,136 @@
+// host_fr.hpp -- host-side helpers of the composed sumcheck provers (product code, not the test oracle):
+//   * BLS12-381 Fr Montgomery arithmetic, used once per prove to build the small interpolation matrices
+//     (evaluations at x = 0..d  ->  coefficients) that the device transcript kernel applies each round;
+//   * SHA-256, used by MultiComposedSumcheckProver::prove's initial absorption of every table's bytes
+//     (multi_composed_sumcheck.rs:51-53): O(N) hashing is sequential by construction, so the GPU converts
+//     the tables to canonical big-endian bytes in parallel and the host hashes the stream.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+namespace zkhost {
+
+typedef unsigned __int128 u128;
+struct Fr { uint64_t l[4]; };
+static const uint64_t FR_P[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+static const uint64_t FR_R1[4] = {0x00000001fffffffeULL, 0x5884b7fa00034802ULL, 0x998c4fefecbc4ff5ULL, 0x1824b159acc5056fULL};
+static const uint64_t FR_R2[4] = {0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL};
+static const uint64_t FR_INV = 0xfffffffeffffffffULL;
+
+inline bool fr_geq_p(const uint64_t* t) {
+    for (int i = 3; i >= 0; --i) { if (t[i] > FR_P[i]) return true; if (t[i] < FR_P[i]) return false; }
+    return true;
+}
+inline void fr_sub_p(uint64_t* t) {
+    uint64_t br = 0;
+    for (int i = 0; i < 4; ++i) { u128 d = (u128)t[i] - FR_P[i] - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+}
+inline Fr fr_zero() { Fr z; memset(z.l, 0, 32); return z; }
+inline Fr fr_one() { Fr o; memcpy(o.l, FR_R1, 32); return o; }
+inline Fr fr_add(const Fr& a, const Fr& b) {
+    Fr r; uint64_t c = 0;
+    for (int i = 0; i < 4; ++i) { u128 s = (u128)a.l[i] + b.l[i] + c; r.l[i] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+    if (c || fr_geq_p(r.l)) fr_sub_p(r.l);
+    return r;
+}
+inline Fr fr_sub(const Fr& a, const Fr& b) {
+    Fr r; uint64_t br = 0;
+    for (int i = 0; i < 4; ++i) { u128 d = (u128)a.l[i] - b.l[i] - br; r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+    if (br) { uint64_t c = 0; for (int i = 0; i < 4; ++i) { u128 s = (u128)r.l[i] + FR_P[i] + c; r.l[i] = (uint64_t)s; c = (uint64_t)(s >> 64); } }
+    return r;
+}
+inline Fr fr_mul(const Fr& a, const Fr& b) {
+    uint64_t t[6] = {0};
+    for (int i = 0; i < 4; ++i) {
+        uint64_t c = 0;
+        for (int j = 0; j < 4; ++j) { u128 s = (u128)a.l[j] * b.l[i] + t[j] + c; t[j] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+        u128 s = (u128)t[4] + c; t[4] = (uint64_t)s; t[5] = (uint64_t)(s >> 64);
+        uint64_t m = t[0] * FR_INV;
+        s = (u128)m * FR_P[0] + t[0]; c = (uint64_t)(s >> 64);
+        for (int j = 1; j < 4; ++j) { s = (u128)m * FR_P[j] + t[j] + c; t[j - 1] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+        s = (u128)t[4] + c; t[3] = (uint64_t)s; t[4] = t[5] + (uint64_t)(s >> 64);
+    }
+    if (t[4] || fr_geq_p(t)) fr_sub_p(t);
+    Fr r; memcpy(r.l, t, 32); return r;
+}
+inline Fr fr_from_u64(uint64_t v) { Fr c = fr_zero(); c.l[0] = v; Fr r2; memcpy(r2.l, FR_R2, 32); return fr_mul(c, r2); }
+inline Fr fr_inv(const Fr& a) {   // Fermat
+    uint64_t e[4]; memcpy(e, FR_P, 32); e[0] -= 2;
+    Fr acc = fr_one();
+    for (int i = 255; i >= 0; --i) { acc = fr_mul(acc, acc); if ((e[i / 64] >> (i % 64)) & 1) acc = fr_mul(acc, a); }
+    return acc;
+}
+
+// M[k][i] = coefficient of x^k in the Lagrange basis polynomial L_i over the nodes 0..d  (row-major, (d+1)^2 entries)
+inline std::vector<Fr> interpolation_matrix(int d) {
+    const int n = d + 1;
+    std::vector<Fr> m((size_t)n * n, fr_zero());
+    for (int i = 0; i < n; ++i) {
+        std::vector<Fr> poly(1, fr_one());
+        Fr denom = fr_one();
+        for (int j = 0; j < n; ++j) {
+            if (j == i) continue;
+            std::vector<Fr> nxt(poly.size() + 1, fr_zero());
+            Fr xj = fr_from_u64((uint64_t)j);
+            for (size_t k = 0; k < poly.size(); ++k) {
+                nxt[k] = fr_sub(nxt[k], fr_mul(poly[k], xj));
+                nxt[k + 1] = fr_add(nxt[k + 1], poly[k]);
+            }
+            poly.swap(nxt);
+            denom = fr_mul(denom, fr_sub(fr_from_u64((uint64_t)i), xj));
+        }
+        Fr dinv = fr_inv(denom);
+        for (int k = 0; k < n; ++k) m[(size_t)k * n + i] = fr_mul(poly[k], dinv);
+    }
+    return m;
+}
+
+// ---- SHA-256 (streaming) ---------------------------------------------------------------------------------
+struct Sha256 {
+    uint32_t h[8];
+    uint8_t buf[64];
+    uint64_t len;
+    Sha256() { reset(); }
+    void reset() {
+        static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+        memcpy(h, iv, 32); len = 0;
+    }
+    static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+    void compress(const uint8_t* b) {
+        static const uint32_t K[64] = {
+            0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+            0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+            0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+            0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+            0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+            0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+        uint32_t w[64];
+        for (int i = 0; i < 16; ++i) w[i] = ((uint32_t)b[4 * i] << 24) | ((uint32_t)b[4 * i + 1] << 16) | ((uint32_t)b[4 * i + 2] << 8) | b[4 * i + 3];
+        for (int i = 16; i < 64; ++i) {
+            uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; ++i) {
+            uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+            uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & bb) ^ (a & c) ^ (bb & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    void update(const uint8_t* d, size_t n) {
+        size_t fill = (size_t)(len % 64);
+        len += n;
+        if (fill) {
+            size_t take = 64 - fill; if (take > n) take = n;
+            memcpy(buf + fill, d, take); d += take; n -= take; fill += take;
+            if (fill == 64) compress(buf); else return;
+        }
+        while (n >= 64) { compress(d); d += 64; n -= 64; }
+        if (n) memcpy(buf, d, n);
+    }
+};
+
+}  // namespace zkhost
