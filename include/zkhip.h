@@ -149,6 +149,18 @@ int zkhip_srs_univariate_g1(zkhip_ctx *ctx, const uint64_t *h_tau, size_t max_de
 int zkhip_g1_sum_affine(const uint64_t *h_points_xy, const uint8_t *h_points_inf, size_t n, uint64_t *h_out_xy,
                         uint8_t *h_out_inf);
 
+/* ---- NTT / Domain / polynomial product (polynomial/src/univariate/) ------------------------- */
+/* Domain::new (domain.rs:31-48) for a power-of-two size: generator = F::get_root_of_unity(size), its inverse,
+ * and size^-1, all Montgomery Fr (host outputs, 4 limbs each).  size > 2^32 -> ZKHIP_ERR_SHAPE (unwrap panic). */
+int zkhip_domain_params(uint64_t size, uint64_t *h_generator, uint64_t *h_generator_inv, uint64_t *h_size_inv);
+/* Domain::fft_internal / ifft_internal (domain.rs:120-133) = serial_fft (polynomial/src/utils.rs:281-315) with
+ * omega, resp. omega^-1 followed by the scaling with size^-1; in place on d_data[2^log_n], natural order in/out. */
+int zkhip_ntt(zkhip_ctx *ctx, uint64_t *d_data, uint32_t log_n, int inverse);
+int zkhip_pointwise_mul(zkhip_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
+/* UnivariateEval::multiply (evaluation.rs:59-86): d_out[na + nb - 1] = coefficients of a * b via three transforms. */
+int zkhip_univariate_multiply(zkhip_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb,
+                              uint64_t *d_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,3 +162,20 @@ def test_fold_2_24_linearity_and_spot_checks(zk, ora):
     j = 0xABCDE5
     pt = ora.fr_from_ints([(j >> (23 - k)) & 1 for k in range(24)])
     assert np.array_equal(poly.evaluation(pt), t[j].cpu().numpy().view(np.uint64))
+
+
+def test_back_to_back_calls_with_different_points_do_not_race(zk, ora):
+    """Entry points return before the stream has run; host parameters must be captured at launch.
+    Many folds with different points are queued behind a long kernel, then checked."""
+    import torch
+    big = zk.Multilinear(torch.randint(0, 2 ** 62, (1 << 22, 4), dtype=torch.int64, device="cuda"))
+    a = ora.random_fr(1 << 12, 1)
+    poly = zk.Multilinear(a)
+    rs = ora.random_fr(16, 2)
+    _ = big.partial_evaluation(rs[0], 0)            # keeps the stream busy while the host races ahead
+    outs = [poly.partial_evaluation(rs[i], 0) for i in range(16)]
+    scaled = [poly * rs[i] for i in range(16)]
+    for i in range(16):
+        assert np.array_equal(outs[i].to_numpy(), ora.mle_partial_evaluation(a, rs[i], 0))
+        want = [x * y % zk.Fr.MODULUS for x, y in zip(zk.Fr.to_ints(a[:4]), zk.Fr.to_ints(rs[i:i + 1]) * 4)]
+        assert zk.Fr.to_ints(scaled[i].to_numpy()[:4]) == want

@@ -17,3 +17,4 @@ from zk_cryptography_amd.kzg import (DenseUnivariatePolynomial, G1Affine, Multil
 from zk_cryptography_amd.composed import (ComposedMultilinear, ComposedSumcheck, ComposedSumcheckProof,  # noqa: F401
                                           MultiComposedSumcheckProof, MultiComposedSumcheckProver,
                                           SparseUnivariatePolynomial)
+from zk_cryptography_amd.univariate import Domain, UnivariateEval  # noqa: F401

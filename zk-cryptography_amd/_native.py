@@ -24,7 +24,7 @@ def build(force=False):
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "zkhip.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []) + ["libzkhip.so"])
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"] + (["-B"] if force else []) + ["libzkhip.so"])
     return LIB_PATH
 
 

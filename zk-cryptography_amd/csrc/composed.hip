@@ -1,0 +1,204 @@
+// composed.hip -- C-ABI entry points of the composed / multi-composed sumcheck provers.
+// gfx950 only.  No CPU fallback: every entry point launches HIP kernels or fails.
+#include "../../include/zkhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "ctx.hpp"
+#include "host_util.hpp"
+#include "composed_kernels.hpp"
+#include "host_fr.hpp"
+
+using namespace zk;
+
+// ---------------------------------------------------------------------------------------
+// composed / multi-composed sumcheck provers
+// ---------------------------------------------------------------------------------------
+template <int K>
+static void launch_product_sum(zkhip_ctx* c, const TablePtrs& tp, size_t n, int grid, uint64_t* partials) {
+    hipLaunchKernelGGL(product_sum_kernel<K>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, partials);
+}
+template <int K>
+static void launch_round(zkhip_ctx* c, bool fold, const TablePtrs& tp, size_t n, const uint64_t* r, uint32_t rec,
+                         uint32_t rec_off, uint64_t* partials, int grid) {
+    if (fold)
+        hipLaunchKernelGGL((composed_round_kernel<K, true>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
+    else
+        hipLaunchKernelGGL((composed_round_kernel<K, false>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
+}
+#define ZK_DISPATCH_K(k, CALL)                 \
+    switch (k) {                               \
+        case 1: CALL(1); break;                \
+        case 2: CALL(2); break;                \
+        case 3: CALL(3); break;                \
+        case 4: CALL(4); break;                \
+        case 5: CALL(5); break;                \
+        default: return ZKHIP_ERR_ARG;         \
+    }
+
+static int product_sums(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes, uint32_t n_terms, size_t n,
+                        uint64_t* h_sum) {
+    if (!c || !ptrs || !term_sizes || !h_sum) return ZKHIP_ERR_ARG;
+    if (n == 0 || n_terms == 0 || n_terms > CMP_MAX_TERMS) return ZKHIP_ERR_ARG;
+    ZK_TRY(c->activate());
+    uint64_t* d_partials = c->small_u64(ZK_SMALL_PARTIALS);
+    uint64_t* d_res = c->small_u64(ZK_SMALL_RES);
+    const int grid = mle_grid(n);
+    size_t off = 0;
+    for (uint32_t p = 0; p < n_terms; ++p) {
+        TablePtrs tp = {};
+        for (uint32_t q = 0; q < term_sizes[p] && q < CMP_MAX_K; ++q) tp.in[q] = ptrs[off + q];
+#define CALL(KK) launch_product_sum<KK>(c, tp, n, grid, d_partials)
+        ZK_DISPATCH_K(term_sizes[p], CALL)
+#undef CALL
+        hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_partials, (uint32_t)grid, d_res, p ? 1u : 0u);
+        off += term_sizes[p];
+    }
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_res, 32, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(h_sum, c->pinned_u64(ZK_PIN_RES), 32);
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_composed_sum(zkhip_ctx* c, const uint64_t* const* ptrs, uint32_t k, size_t n, uint64_t* h_sum) {
+    return product_sums(c, ptrs, &k, 1, n, h_sum);
+}
+extern "C" int zkhip_multi_composed_sum(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes,
+                                        uint32_t n_terms, size_t n, uint64_t* h_sum) {
+    return product_sums(c, ptrs, term_sizes, n_terms, n, h_sum);
+}
+
+// shared driver.  multi = 0: ComposedSumcheck (one term).  first_mode: see composed_transcript_kernel.
+static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes, uint32_t n_terms,
+                               size_t n, int multi, const uint64_t* h_sum, int partial, uint32_t* h_lens,
+                               uint64_t* h_round_polys, uint64_t* h_challenges) {
+    if (!c || !ptrs || !term_sizes) return ZKHIP_ERR_ARG;
+    if (n_terms == 0 || n_terms > CMP_MAX_TERMS) return ZKHIP_ERR_ARG;
+    if (!is_pow2(n)) return ZKHIP_ERR_SHAPE;
+    const uint32_t n_vars = log2_exact(n);
+    if (n_vars > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
+    if (n_vars == 0) return ZKHIP_OK;   // `for _ in 0..n_vars` never runs
+    if (!h_round_polys || !h_challenges || (multi && (!h_sum || !h_lens))) return ZKHIP_ERR_ARG;
+    ZK_TRY(c->activate());
+    ComposedMeta meta = {};
+    meta.n_terms = n_terms;
+    meta.multi = (uint32_t)multi;
+    uint32_t total = 0, rec = 0;
+    for (uint32_t p = 0; p < n_terms; ++p) {
+        if (term_sizes[p] < 1 || term_sizes[p] > CMP_MAX_K) return ZKHIP_ERR_ARG;
+        meta.k[p] = term_sizes[p];
+        meta.rec_off[p] = rec;
+        rec += term_sizes[p] + 1;
+        total += term_sizes[p];
+    }
+    meta.rec = rec;
+    if (rec > CMP_MAX_REC) return ZKHIP_ERR_ARG;
+    // workspace: per table a ping (n/2) and a pong (n/4) buffer, then the state
+    const size_t per_table = (n / 2 + n / 4 + 2) * 32;
+    const size_t state_off = (total * per_table + 255) & ~(size_t)255;
+    const size_t bytes_off = state_off + ((sizeof(ComposedDev) + 255) & ~(size_t)255);
+    ZK_TRY(c->reserve_ws(bytes_off + (multi && !partial ? 32 * n : 0)));
+    char* ws = (char*)c->d_ws;
+    ComposedDev* st = (ComposedDev*)(ws + state_off);
+    uint64_t* d_partials = c->small_u64(ZK_SMALL_PARTIALS);
+    uint64_t* d_rp = c->small_u64(ZK_SMALL_ROUNDPOLYS);
+    uint64_t* d_ch = c->small_u64(ZK_SMALL_CHALLENGES);
+
+    uint32_t first = 1;
+    if (multi) {
+        // interpolation matrices for the degrees in use
+        std::vector<uint64_t> mats((CMP_MAX_K + 1) * (CMP_MAX_K + 1) * (CMP_MAX_K + 1) * 4, 0);
+        for (uint32_t p = 0; p < n_terms; ++p) {
+            const int d = (int)term_sizes[p];
+            std::vector<zkhost::Fr> m = zkhost::interpolation_matrix(d);
+            std::memcpy(&mats[(size_t)d * (CMP_MAX_K + 1) * (CMP_MAX_K + 1) * 4], m.data(), m.size() * 32);
+        }
+        ZK_HIP(c, hipMemcpyAsync(st->interp, mats.data(), mats.size() * 8, hipMemcpyHostToDevice, c->stream));
+        ZK_HIP(c, hipMemcpyAsync(st->sum, h_sum, 32, hipMemcpyHostToDevice, c->stream));
+        if (!partial) {
+            // prove(): transcript.commit(&composed_poly_to_bytes(&poly)) first (multi_composed_sumcheck.rs:51-53).
+            // The GPU produces the canonical big-endian bytes, the host hashes the (inherently sequential) stream.
+            uint8_t* d_bytes = (uint8_t*)(ws + bytes_off);
+            std::vector<uint8_t> h_bytes(32 * n);
+            zkhost::Sha256 sha;
+            for (uint32_t q = 0; q < total; ++q) {
+                hipLaunchKernelGGL(to_bytes_kernel, dim3(mle_grid(n)), dim3(MLE_BLOCK), 0, c->stream, ptrs[q], n, (uint32_t*)d_bytes);
+                ZK_HIP(c, hipMemcpyAsync(h_bytes.data(), d_bytes, 32 * n, hipMemcpyDeviceToHost, c->stream));
+                ZK_HIP(c, hipStreamSynchronize(c->stream));
+                sha.update(h_bytes.data(), 32 * n);
+            }
+            Sha256State hs = {};
+            std::memcpy(hs.h, sha.h, 32);
+            const uint32_t fill = (uint32_t)(sha.len % 64);
+            for (uint32_t i = 0; i < fill / 4; ++i)
+                hs.buf[i] = ((uint32_t)sha.buf[4 * i] << 24) | ((uint32_t)sha.buf[4 * i + 1] << 16) | ((uint32_t)sha.buf[4 * i + 2] << 8) | sha.buf[4 * i + 3];
+            hs.fill = fill;
+            hs.len = sha.len;
+            ZK_HIP(c, hipMemcpyAsync(&st->transcript, &hs, sizeof(hs), hipMemcpyHostToDevice, c->stream));
+            ZK_HIP(c, hipStreamSynchronize(c->stream));   // hs / mats are stack/heap temporaries
+            first = 2;
+        } else {
+            ZK_HIP(c, hipStreamSynchronize(c->stream));
+        }
+    }
+
+    // current table pointers
+    std::vector<const uint64_t*> cur(ptrs, ptrs + total);
+    size_t cn = n;
+    for (uint32_t round = 0; round < n_vars; ++round) {
+        const bool fold = round > 0;
+        const size_t work = fold ? cn / 4 : cn / 2;
+        const int grid = mle_grid(work ? work : 1);
+        uint32_t off = 0;
+        for (uint32_t p = 0; p < n_terms; ++p) {
+            TablePtrs tp = {};
+            // ping-pong: folds happen in rounds 1, 2, ...; round r writes n >> r entries.  Odd rounds use the
+            // n/2-entry buffer, even rounds the n/4-entry one.
+            for (uint32_t q = 0; q < term_sizes[p]; ++q) {
+                tp.in[q] = cur[off + q];
+                char* base = ws + (size_t)(off + q) * per_table;
+                tp.out[q] = (uint64_t*)((round & 1) ? base : base + (n / 2 + 1) * 32);
+            }
+            ProfScope ps(c, "composed_round", 0.0);
+#define CALL(KK) launch_round<KK>(c, fold, tp, cn, fold ? d_ch + 4 * (round - 1) : nullptr, meta.rec, meta.rec_off[p], d_partials, grid)
+            ZK_DISPATCH_K(term_sizes[p], CALL)
+#undef CALL
+            if (fold) for (uint32_t q = 0; q < term_sizes[p]; ++q) cur[off + q] = tp.out[q];
+            off += term_sizes[p];
+        }
+        if (fold) cn /= 2;
+        hipLaunchKernelGGL(composed_transcript_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_partials, (uint32_t)grid, meta, st,
+                           round, first, d_rp, d_ch);
+        first = 0;
+    }
+    ZK_HIP(c, hipGetLastError());
+    std::vector<uint64_t> h_rp(64 * (size_t)n_vars);
+    ZK_HIP(c, hipMemcpyAsync(h_rp.data(), d_rp, 64 * 8 * (size_t)n_vars, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(h_challenges, d_ch, 32 * (size_t)n_vars, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t r = 0; r < n_vars; ++r) {
+        if (!multi) {
+            std::memcpy(h_round_polys + (size_t)r * (term_sizes[0] + 1) * 4, &h_rp[64 * r], (term_sizes[0] + 1) * 32);
+        } else {
+            h_lens[r] = (uint32_t)h_rp[64 * r];
+            std::memcpy(h_round_polys + (size_t)r * CMP_MAX_MONO * 8, &h_rp[64 * r + 8], CMP_MAX_MONO * 64);
+        }
+    }
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_composed_prove(zkhip_ctx* c, const uint64_t* const* ptrs, uint32_t k, size_t n, uint64_t* h_round_polys,
+                                    uint64_t* h_challenges) {
+    return composed_prove_impl(c, ptrs, &k, 1, n, 0, nullptr, 1, nullptr, h_round_polys, h_challenges);
+}
+extern "C" int zkhip_multi_composed_prove(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes,
+                                          uint32_t n_terms, size_t n, const uint64_t* h_sum, int partial,
+                                          uint32_t* h_lens, uint64_t* h_round_polys, uint64_t* h_challenges) {
+    return composed_prove_impl(c, ptrs, term_sizes, n_terms, n, 1, h_sum, partial, h_lens, h_round_polys, h_challenges);
+}
+

@@ -52,7 +52,7 @@ __device__ __forceinline__ void accumulate_round_evals(const Fr (&lo)[K], const 
 //                 j + n/4, store them, and evaluate the NEXT round polynomial on that folded pair.
 // Per workgroup, the K+1 sums go to partials[(block * rec + rec_off + t)].
 template <int K, bool FOLD>
-__global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TablePtrs tp, size_t n, const uint64_t* __restrict__ r_ptr,
+static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TablePtrs tp, size_t n, const uint64_t* __restrict__ r_ptr,
                                                                    uint32_t rec, uint32_t rec_off,
                                                                    uint64_t* __restrict__ partials) {
     __shared__ Fr red[MLE_BLOCK / 64];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TablePtrs tp,
 
 // sum_j prod_k table_k[j]  (ComposedSumcheck::calculate_poly_sum composed_sumcheck.rs:28-30): one partial per workgroup
 template <int K>
-__global__ __launch_bounds__(MLE_BLOCK) void product_sum_kernel(TablePtrs tp, size_t n, uint64_t* __restrict__ partials) {
+static __global__ __launch_bounds__(MLE_BLOCK) void product_sum_kernel(TablePtrs tp, size_t n, uint64_t* __restrict__ partials) {
     __shared__ Fr red[MLE_BLOCK / 64];
     const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
     Fr s = Fr::zero();
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(MLE_BLOCK) void product_sum_kernel(TablePtrs tp, si
     if (threadIdx.x == 0) store_fr(partials, blockIdx.x, s);
 }
 // out[0] = sum of n_partials values (+ *accumulate_into if given)
-__global__ __launch_bounds__(MLE_BLOCK) void finish_sum_kernel(const uint64_t* __restrict__ partials, uint32_t n_partials,
+static __global__ __launch_bounds__(MLE_BLOCK) void finish_sum_kernel(const uint64_t* __restrict__ partials, uint32_t n_partials,
                                                                uint64_t* __restrict__ out, uint32_t accumulate) {
     __shared__ Fr red[MLE_BLOCK / 64];
     Fr s = Fr::zero();
@@ -147,7 +147,7 @@ struct ComposedDev {
 //          0 = continue.
 // Output per round (round_out + 64 * round, in u64):
 //   multi == 0: K+1 evaluations (4 u64 each);  multi == 1: [0] = #monomials, then (coeff, pow) pairs of 8 u64 from [8].
-__global__ __launch_bounds__(MLE_BLOCK) void composed_transcript_kernel(const uint64_t* __restrict__ partials,
+static __global__ __launch_bounds__(MLE_BLOCK) void composed_transcript_kernel(const uint64_t* __restrict__ partials,
                                                                         uint32_t n_partials, ComposedMeta meta,
                                                                         ComposedDev* st, uint32_t round, uint32_t first,
                                                                         uint64_t* __restrict__ round_out,

@@ -20,6 +20,23 @@ constexpr int MLE_MAX_GRID = 256 * 8;   // 8 workgroups of 4 waves per CU: 32 wa
 constexpr int TAIL_LOG = 12;            // tables of <= 2^12 entries (128 KiB of the CU's 160 KiB LDS) finish inside one workgroup
 constexpr int TAIL_N = 1 << TAIL_LOG;
 
+// Small host-side parameters travel as kernel arguments (captured at launch), never through a shared staging
+// buffer: entry points return before the stream has run, so a staging slot could be overwritten by the next call.
+struct FrArg { uint64_t v[4]; };
+struct PtsArg { uint64_t v[4 * 40]; };   // up to ZK_MAX_ROUNDS points
+__device__ __forceinline__ Fr fr_from_arg(const FrArg& a) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.l[2 * i] = (uint32_t)a.v[i]; r.l[2 * i + 1] = (uint32_t)(a.v[i] >> 32); }
+    return r;
+}
+__device__ __forceinline__ Fr fr_from_pts(const PtsArg& a, uint32_t k) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.l[2 * i] = (uint32_t)a.v[4 * k + i]; r.l[2 * i + 1] = (uint32_t)(a.v[4 * k + i] >> 32); }
+    return r;
+}
+
 // out[j] = lo + r*(hi - lo)  ==  r*hi + (1-r)*lo  (evaluation_form.rs:133), one Montgomery product.
 // Both sides are canonical residues of the same field element, so limbs are identical.
 __device__ __forceinline__ Fr fold_pair(const Fr& lo, const Fr& hi, const Fr& r) { return lo + r * (hi - lo); }
@@ -34,12 +51,12 @@ __device__ __forceinline__ size_t fold_lo_index(size_t j, uint32_t log_half) {
 // in the lower / upper half of the OUTPUT table (= next sumcheck round's
 // split_poly_into_two_and_sum_each_part, evaluation_form.rs:68-74), saving a re-read of the output.
 template <bool WITH_SUMS>
-__global__ __launch_bounds__(MLE_BLOCK) void fold_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+static __global__ __launch_bounds__(MLE_BLOCK) void fold_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                                                          size_t n_out, uint32_t log_half,
-                                                         const uint64_t* __restrict__ r_ptr,
+                                                         const uint64_t* __restrict__ r_ptr, FrArg r_val,
                                                          uint64_t* __restrict__ partials) {
     __shared__ Fr red[2 * MLE_BLOCK / 64];
-    const Fr r = load_fr(r_ptr, 0);
+    const Fr r = r_ptr ? load_fr(r_ptr, 0) : fr_from_arg(r_val);   // device-resident challenge, or a host point by value
     const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
     const size_t half_in = (size_t)1 << log_half;
     const size_t half_out = n_out >> 1;
@@ -75,7 +92,7 @@ __global__ __launch_bounds__(MLE_BLOCK) void fold_kernel(const uint64_t* __restr
 
 // Per-workgroup (lower-half sum, upper-half sum) of a table: split_poly_into_two_and_sum_each_part
 // (evaluation_form.rs:68-74); their sum is sum_over_the_boolean_hypercube (:80-84) / poly_sum (sumcheck.rs:25-27).
-__global__ __launch_bounds__(MLE_BLOCK) void half_sums_kernel(const uint64_t* __restrict__ in, size_t n,
+static __global__ __launch_bounds__(MLE_BLOCK) void half_sums_kernel(const uint64_t* __restrict__ in, size_t n,
                                                               uint64_t* __restrict__ partials) {
     __shared__ Fr red[2 * MLE_BLOCK / 64];
     const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
@@ -121,7 +138,7 @@ __device__ __forceinline__ void reduce_partials(const uint64_t* __restrict__ par
 }
 
 // Single-workgroup reduction: out[0] = lower-half sum, out[1] = upper-half sum, out[2] = total.
-__global__ __launch_bounds__(MLE_BLOCK) void finish_sums_kernel(const uint64_t* __restrict__ partials,
+static __global__ __launch_bounds__(MLE_BLOCK) void finish_sums_kernel(const uint64_t* __restrict__ partials,
                                                                 uint32_t n_partials, uint64_t* __restrict__ out) {
     __shared__ Fr red[2 * MLE_BLOCK / 64];
     Fr lo, hi;
@@ -135,8 +152,8 @@ __global__ __launch_bounds__(MLE_BLOCK) void finish_sums_kernel(const uint64_t* 
 
 // Finish an evaluation inside one workgroup: folds variable 0 repeatedly with points pts[0..n_pts) until the
 // table (n <= TAIL_N entries, staged in LDS) has n >> n_pts entries left; writes them to out.
-__global__ __launch_bounds__(MLE_BLOCK) void fold_tail_kernel(const uint64_t* __restrict__ in, uint32_t n,
-                                                              const uint64_t* __restrict__ pts, uint32_t n_pts,
+static __global__ __launch_bounds__(MLE_BLOCK) void fold_tail_kernel(const uint64_t* __restrict__ in, uint32_t n,
+                                                              PtsArg pts, uint32_t first_pt, uint32_t n_pts,
                                                               uint64_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
     Fr* tab = reinterpret_cast<Fr*>(zk_dyn_lds);   // TAIL_N entries
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(MLE_BLOCK) void fold_tail_kernel(const uint64_t* __
     __syncthreads();
     uint32_t cur = n;
     for (uint32_t p = 0; p < n_pts; ++p) {
-        const Fr r = load_fr(pts, p);
+        const Fr r = fr_from_pts(pts, first_pt + p);
         const uint32_t half = cur >> 1;
         // in place: lane j reads (j, j+half) and writes j; no other lane touches index j this round
         for (uint32_t j = threadIdx.x; j < half; j += MLE_BLOCK) tab[j] = fold_pair(tab[j], tab[j + half], r);
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(MLE_BLOCK) void fold_tail_kernel(const uint64_t* __
 
 // Outer sum / outer product of two tables (evaluation_form.rs:28-52): out[i*nb + j] = a[i] (+|*) b[j]
 template <bool MUL>
-__global__ __launch_bounds__(MLE_BLOCK) void distinct_kernel(const uint64_t* __restrict__ a,
+static __global__ __launch_bounds__(MLE_BLOCK) void distinct_kernel(const uint64_t* __restrict__ a,
                                                              const uint64_t* __restrict__ b, size_t nb, size_t n_out,
                                                              uint64_t* __restrict__ out) {
     const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
@@ -167,13 +184,13 @@ __global__ __launch_bounds__(MLE_BLOCK) void distinct_kernel(const uint64_t* __r
 }
 
 // Elementwise ops used by the callers either side of the path (Add/Sub/Mul<F>, evaluation_form.rs:178-251)
-template <int OP>   // 0 add, 1 sub, 2 scale by *s
-__global__ __launch_bounds__(MLE_BLOCK) void elementwise_kernel(const uint64_t* __restrict__ a,
-                                                                const uint64_t* __restrict__ b, size_t n,
+template <int OP>   // 0 add, 1 sub, 2 scale by `scalar`
+static __global__ __launch_bounds__(MLE_BLOCK) void elementwise_kernel(const uint64_t* __restrict__ a,
+                                                                const uint64_t* __restrict__ b, FrArg scalar, size_t n,
                                                                 uint64_t* __restrict__ out) {
     const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
     Fr s = Fr::zero();
-    if (OP == 2) s = load_fr(b, 0);
+    if (OP == 2) s = fr_from_arg(scalar);
     for (size_t q = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; q < n; q += stride) {
         Fr x = load_fr(a, q);
         Fr o = (OP == 0) ? x + load_fr(b, q) : (OP == 1) ? x - load_fr(b, q) : x * s;
@@ -182,7 +199,7 @@ __global__ __launch_bounds__(MLE_BLOCK) void elementwise_kernel(const uint64_t* 
 }
 
 // Canonical big-endian bytes of every element (Multilinear::to_bytes, evaluation_form.rs:54-62)
-__global__ __launch_bounds__(MLE_BLOCK) void to_bytes_kernel(const uint64_t* __restrict__ in, size_t n,
+static __global__ __launch_bounds__(MLE_BLOCK) void to_bytes_kernel(const uint64_t* __restrict__ in, size_t n,
                                                              uint32_t* __restrict__ out_words) {
     const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
     for (size_t q = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; q < n; q += stride) {

@@ -1,0 +1,167 @@
+// msm.hip -- C-ABI entry points of the KZG commit path (MSM over G1) and SRS generation.
+// gfx950 only.  No CPU fallback: every entry point launches HIP kernels or fails.
+#include "../../include/zkhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "ctx.hpp"
+#include "host_util.hpp"
+#include "host_g1.hpp"
+#include "mle_kernels.hpp"
+#include "msm_kernels.hpp"
+#include "srs_kernels.hpp"
+
+using namespace zk;
+
+// ---------------------------------------------------------------------------------------
+// KZG commit (MSM)
+// ---------------------------------------------------------------------------------------
+static MsmPlan msm_plan(size_t n) {
+    uint32_t lg = 0;
+    while (((size_t)1 << lg) < n) ++lg;
+    uint32_t c = lg > 2 ? lg - 2 : 4;            // about 8 points per bucket per window on small inputs
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    MsmPlan pl;
+    pl.c = c;
+    pl.n_windows = (256 + c - 1) / c;
+    pl.nb = 1u << (c - 1);
+    pl.ns = pl.nb / MSM_SEG;
+    pl.n_bits = c - 1 - MSM_SEG_LOG;
+    pl.n_terms = 1 + pl.n_bits;
+    return pl;
+}
+
+extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf,
+                                size_t n_points, const uint64_t* d_scalars, size_t n_scalars, int require_equal_len,
+                                uint64_t* h_out_xy, uint8_t* h_out_inf) {
+    if (!c || !h_out_xy || !h_out_inf) return ZKHIP_ERR_ARG;
+    if (require_equal_len && n_points != n_scalars) return ZKHIP_ERR_SHAPE;   // multilinear_kzg.rs:36-41
+    if (n_scalars > n_points) return ZKHIP_ERR_INDEX;                          // univariate_kzg.rs:53
+    const size_t n = n_scalars;
+    if (n == 0) { std::memset(h_out_xy, 0, 96); *h_out_inf = 1; return ZKHIP_OK; }   // P::G1::default()
+    if (!d_points_xy || !d_scalars) return ZKHIP_ERR_ARG;
+    if (n >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    const MsmPlan pl = msm_plan(n);
+    const size_t n_buckets = (size_t)pl.n_windows * pl.nb;
+    const size_t n_segments = (size_t)pl.n_windows * pl.ns;
+    const size_t n_out = (size_t)pl.n_windows * pl.n_terms;
+    // workspace carve-up (all 256-byte aligned)
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_counts = 0;
+    const size_t o_offsets = o_counts + al(n_buckets * 4);
+    const size_t o_cursor = o_offsets + al(n_buckets * 4);
+    const size_t o_sorted = o_cursor + al(n_buckets * 4);
+    const size_t o_buckets = o_sorted + al(n * pl.n_windows * 4);
+    const size_t o_segs = o_buckets + al(n_buckets * 192);
+    const size_t o_sega = o_segs + al(n_segments * 192);
+    const size_t o_terms = o_sega + al(n_segments * 192);
+    const size_t total = o_terms + al(n_out * 192);
+    ZK_TRY(c->reserve_ws(total));
+    char* ws = (char*)c->d_ws;
+    uint32_t* counts = (uint32_t*)(ws + o_counts);
+    uint32_t* offsets = (uint32_t*)(ws + o_offsets);
+    uint32_t* cursor = (uint32_t*)(ws + o_cursor);
+    uint32_t* sorted = (uint32_t*)(ws + o_sorted);
+    uint64_t* buckets = (uint64_t*)(ws + o_buckets);
+    uint64_t* segs = (uint64_t*)(ws + o_segs);
+    uint64_t* sega = (uint64_t*)(ws + o_sega);
+    uint64_t* terms = (uint64_t*)(ws + o_terms);
+
+    ZK_HIP(c, hipMemsetAsync(counts, 0, n_buckets * 4, c->stream));
+    const int grid_n = (int)std::min<size_t>((n + MSM_BLOCK - 1) / MSM_BLOCK, 256 * 8);
+    {
+        ProfScope ps(c, "msm_hist", 32.0 * (double)n);
+        hipLaunchKernelGGL(msm_hist_kernel, dim3(grid_n), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl, counts);
+    }
+    hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, c->stream, counts, (uint32_t)n_buckets, offsets, cursor);
+    {
+        ProfScope ps(c, "msm_scatter", 32.0 * (double)n);
+        hipLaunchKernelGGL(msm_scatter_kernel, dim3(grid_n), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl, cursor, sorted);
+    }
+    {
+        ProfScope ps(c, "msm_accumulate", 128.0 * (double)n);
+        hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK)), dim3(MSM_BLOCK), 0,
+                           c->stream, d_points_xy, sorted, offsets, counts, (uint32_t)n_buckets, buckets);
+    }
+    {
+        ProfScope ps(c, "msm_segment", 0.0);
+        hipLaunchKernelGGL(msm_segment_kernel, dim3((unsigned)((n_segments + MSM_BLOCK - 1) / MSM_BLOCK)), dim3(MSM_BLOCK), 0,
+                           c->stream, buckets, (uint32_t)n_segments, segs, sega);
+    }
+    {
+        ProfScope ps(c, "msm_terms", 0.0);
+        hipLaunchKernelGGL(msm_terms_kernel, dim3((unsigned)n_out), dim3(MSM_BLOCK), MSM_BLOCK * 192, c->stream, segs, sega, pl, terms);
+    }
+    ZK_HIP(c, hipGetLastError());
+    std::vector<uint64_t> h_terms(n_out * 24);
+    ZK_HIP(c, hipMemcpyAsync(h_terms.data(), terms, n_out * 192, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    // host epilogue: sum over (window w, term t) of 2^exp * point
+    std::vector<zkhost::Xyzz> pts(n_out);
+    std::vector<uint32_t> exps(n_out);
+    for (size_t i = 0; i < n_out; ++i) {
+        std::memcpy(&pts[i], &h_terms[24 * i], 192);
+        const uint32_t w = (uint32_t)(i / pl.n_terms), t = (uint32_t)(i % pl.n_terms);
+        exps[i] = w * pl.c + (t == 0 ? 0 : MSM_SEG_LOG + (t - 1));
+    }
+    zkhost::Xyzz res = zkhost::weighted_sum_pow2(pts, exps);
+    *h_out_inf = zkhost::xyzz_to_affine(res, h_out_xy) ? 0 : 1;
+    return ZKHIP_OK;
+}
+
+// scalars (device, n x 4) -> affine SRS points
+static int srs_from_scalars(zkhip_ctx* c, const uint64_t* d_scalars, size_t n, uint64_t* d_out_xy, uint8_t* d_out_inf) {
+    // workspace layout: [scalars n*32 (owned by caller region)] ... we only need n*192 for XYZZ here
+    uint64_t* xyzz = (uint64_t*)((char*)c->d_ws + ((n * 32 + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(srs_fixed_base_kernel, dim3((unsigned)((n + SRS_BLOCK - 1) / SRS_BLOCK)), dim3(SRS_BLOCK), 0, c->stream,
+                       d_scalars, n, xyzz);
+    const size_t n_threads = (n + SRS_CHUNK - 1) / SRS_CHUNK;
+    hipLaunchKernelGGL(srs_batch_affine_kernel, dim3((unsigned)((n_threads + SRS_BLOCK - 1) / SRS_BLOCK)), dim3(SRS_BLOCK), 0,
+                       c->stream, xyzz, n, d_out_xy, d_out_inf);
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_srs_multilinear_g1(zkhip_ctx* c, const uint64_t* h_tau, uint32_t n_vars, uint64_t* d_out_xy,
+                                        uint8_t* d_out_inf) {
+    if (!c || !d_out_xy || !d_out_inf || (n_vars && !h_tau)) return ZKHIP_ERR_ARG;
+    if (n_vars > 30 || n_vars > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    const size_t n = (size_t)1 << n_vars;
+    ZK_TRY(c->reserve_ws(((n * 32 + 255) & ~(size_t)255) + n * 192));
+    PtsArg tau = {};
+    if (n_vars) std::memcpy(tau.v, h_tau, 32 * (size_t)n_vars);
+    uint64_t* d_scalars = (uint64_t*)c->d_ws;
+    hipLaunchKernelGGL(srs_eq_scalars_kernel, dim3(mle_grid(n)), dim3(SRS_BLOCK), 0, c->stream, tau, n_vars, d_scalars);
+    return srs_from_scalars(c, d_scalars, n, d_out_xy, d_out_inf);
+}
+
+extern "C" int zkhip_srs_univariate_g1(zkhip_ctx* c, const uint64_t* h_tau, size_t max_degree, uint64_t* d_out_xy,
+                                       uint8_t* d_out_inf) {
+    if (!c || !d_out_xy || !d_out_inf || !h_tau) return ZKHIP_ERR_ARG;
+    ZK_TRY(c->activate());
+    const size_t n = max_degree + 1;
+    ZK_TRY(c->reserve_ws(((n * 32 + 255) & ~(size_t)255) + n * 192));
+    FrArg tau = {};
+    std::memcpy(tau.v, h_tau, 32);
+    uint64_t* d_scalars = (uint64_t*)c->d_ws;
+    hipLaunchKernelGGL(srs_power_scalars_kernel, dim3(mle_grid(n)), dim3(SRS_BLOCK), 0, c->stream, tau, n, d_scalars);
+    return srs_from_scalars(c, d_scalars, n, d_out_xy, d_out_inf);
+}
+
+extern "C" int zkhip_g1_sum_affine(const uint64_t* h_points_xy, const uint8_t* h_points_inf, size_t n,
+                                   uint64_t* h_out_xy, uint8_t* h_out_inf) {
+    if ((n && !h_points_xy) || !h_out_xy || !h_out_inf) return ZKHIP_ERR_ARG;
+    zkhost::Xyzz acc = zkhost::xyzz_identity();
+    for (size_t i = 0; i < n; ++i)
+        acc = zkhost::xyzz_add(acc, zkhost::xyzz_from_affine(h_points_xy + 12 * i, h_points_inf && h_points_inf[i]));
+    *h_out_inf = zkhost::xyzz_to_affine(acc, h_out_xy) ? 0 : 1;
+    return ZKHIP_OK;
+}
+

@@ -55,7 +55,7 @@ struct DigitStream {
 };
 
 // pass 1: histogram
-__global__ __launch_bounds__(MSM_BLOCK) void msm_hist_kernel(const uint64_t* __restrict__ scalars,
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_hist_kernel(const uint64_t* __restrict__ scalars,
                                                              const uint8_t* __restrict__ inf, size_t n, MsmPlan pl,
                                                              uint32_t* __restrict__ counts) {
     const size_t stride = (size_t)gridDim.x * MSM_BLOCK;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(MSM_BLOCK) void msm_hist_kernel(const uint64_t* __r
 }
 
 // pass 2: exclusive scan of `total` counters by ONE workgroup (total is at most a few hundred thousand)
-__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ counts, uint32_t total,
+static __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ counts, uint32_t total,
                                                         uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor) {
     __shared__ uint32_t part[1024];
     const uint32_t per = (total + 1023) / 1024;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
 }
 
 // pass 3: counting-sort scatter; entry = point index | sign << 31
-__global__ __launch_bounds__(MSM_BLOCK) void msm_scatter_kernel(const uint64_t* __restrict__ scalars,
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_scatter_kernel(const uint64_t* __restrict__ scalars,
                                                                 const uint8_t* __restrict__ inf, size_t n, MsmPlan pl,
                                                                 uint32_t* __restrict__ cursor,
                                                                 uint32_t* __restrict__ sorted) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(MSM_BLOCK) void msm_scatter_kernel(const uint64_t* 
 }
 
 // pass 4: one lane per bucket
-__global__ __launch_bounds__(MSM_BLOCK) void msm_accumulate_kernel(const uint64_t* __restrict__ points,
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_accumulate_kernel(const uint64_t* __restrict__ points,
                                                                    const uint32_t* __restrict__ sorted,
                                                                    const uint32_t* __restrict__ offsets,
                                                                    const uint32_t* __restrict__ counts,
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(MSM_BLOCK) void msm_accumulate_kernel(const uint64_
 }
 
 // pass 5: one lane per segment of L buckets: S = sum_j B_j, A = sum_j (j+1) B_j  (running sum from the top)
-__global__ __launch_bounds__(MSM_BLOCK) void msm_segment_kernel(const uint64_t* __restrict__ buckets,
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_segment_kernel(const uint64_t* __restrict__ buckets,
                                                                 uint32_t n_segments, uint64_t* __restrict__ seg_s,
                                                                 uint64_t* __restrict__ seg_a) {
     const uint32_t s = blockIdx.x * MSM_BLOCK + threadIdx.x;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(MSM_BLOCK) void msm_segment_kernel(const uint64_t* 
 
 // pass 6: one workgroup per (window, term).  term 0: sum of A_s over the window's segments;
 // term 1+k: sum of S_s over the segments whose index has bit k set.
-__global__ __launch_bounds__(MSM_BLOCK) void msm_terms_kernel(const uint64_t* __restrict__ seg_s,
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_terms_kernel(const uint64_t* __restrict__ seg_s,
                                                               const uint64_t* __restrict__ seg_a, MsmPlan pl,
                                                               uint64_t* __restrict__ terms) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];

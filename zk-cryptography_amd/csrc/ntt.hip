@@ -1,0 +1,147 @@
+// ntt.hip -- C-ABI entry points of the NTT / Domain / polynomial product path.
+// gfx950 only.  No CPU fallback: every entry point launches HIP kernels or fails.
+#include "../../include/zkhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "ctx.hpp"
+#include "host_fr.hpp"
+#include "host_util.hpp"
+#include "ntt_kernels.hpp"
+
+using namespace zk;
+
+// F::get_root_of_unity(2^log_n) (domain.rs:38): the 2^32-th root 7^((r-1)/2^32), squared (32 - log_n) times
+static zkhost::Fr root_of_unity(uint32_t log_n) {
+    zkhost::Fr g = zkhost::fr_from_u64(7);
+    uint64_t e[4];
+    uint64_t rm1[4] = {zkhost::FR_P[0] - 1, zkhost::FR_P[1], zkhost::FR_P[2], zkhost::FR_P[3]};
+    for (int i = 0; i < 4; ++i) e[i] = (rm1[i] >> 32) | (i < 3 ? (rm1[i + 1] << 32) : 0);
+    zkhost::Fr w = zkhost::fr_one();
+    for (int i = 255; i >= 0; --i) {
+        w = zkhost::fr_mul(w, w);
+        if ((e[i / 64] >> (i % 64)) & 1) w = zkhost::fr_mul(w, g);
+    }
+    for (uint32_t i = log_n; i < 32; ++i) w = zkhost::fr_mul(w, w);
+    return w;
+}
+
+extern "C" int zkhip_domain_params(uint64_t size, uint64_t* h_generator, uint64_t* h_generator_inv, uint64_t* h_size_inv) {
+    if (!is_pow2((size_t)size) || !h_generator || !h_generator_inv || !h_size_inv) return ZKHIP_ERR_ARG;
+    const uint32_t log_n = log2_exact((size_t)size);
+    if (log_n > 32) return ZKHIP_ERR_SHAPE;   // get_root_of_unity(..).unwrap() panics beyond the 2-adicity
+    zkhost::Fr w = root_of_unity(log_n);
+    zkhost::Fr wi = zkhost::fr_inv(w);
+    zkhost::Fr ni = zkhost::fr_inv(zkhost::fr_from_u64(size));
+    std::memcpy(h_generator, w.l, 32);
+    std::memcpy(h_generator_inv, wi.l, 32);
+    std::memcpy(h_size_inv, ni.l, 32);
+    return ZKHIP_OK;
+}
+
+struct TwiddleKey {
+    zkhip_ctx* c; uint32_t log_n; int inverse;
+    bool operator<(const TwiddleKey& o) const {
+        if (c != o.c) return c < o.c;
+        if (log_n != o.log_n) return log_n < o.log_n;
+        return inverse < o.inverse;
+    }
+};
+static std::map<TwiddleKey, uint64_t*> g_twiddles;   // device tables, kept for the life of the process
+
+static int get_twiddles(zkhip_ctx* c, uint32_t log_n, int inverse, uint64_t** out) {
+    TwiddleKey key{c, log_n, inverse};
+    auto it = g_twiddles.find(key);
+    if (it != g_twiddles.end()) { *out = it->second; return ZKHIP_OK; }
+    const uint32_t log_half = log_n ? log_n - 1 : 0;
+    const size_t half = (size_t)1 << log_half;
+    zkhost::Fr w = root_of_unity(log_n);
+    if (inverse) w = zkhost::fr_inv(w);
+    std::vector<zkhost::Fr> pw(log_half ? log_half : 1);
+    for (uint32_t k = 0; k < log_half; ++k) { pw[k] = w; w = zkhost::fr_mul(w, w); }
+    uint64_t *d_tab = nullptr, *d_pw = nullptr;
+    ZK_HIP(c, hipMalloc(&d_tab, half * 32));
+    ZK_HIP(c, hipMalloc(&d_pw, pw.size() * 32));
+    ZK_HIP(c, hipMemcpyAsync(d_pw, pw.data(), pw.size() * 32, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(ntt_twiddle_kernel, dim3(mle_grid(half)), dim3(MLE_BLOCK), 0, c->stream, d_pw, log_half, d_tab);
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    ZK_HIP(c, hipFree(d_pw));
+    g_twiddles[key] = d_tab;
+    *out = d_tab;
+    return ZKHIP_OK;
+}
+
+// d_data (n = 2^log_n, in place).  Forward: serial_fft with omega; inverse: omega^-1 then scale by n^-1.
+static int ntt_inplace(zkhip_ctx* c, uint64_t* d_data, uint32_t log_n, int inverse, uint64_t* d_scratch) {
+    const size_t n = (size_t)1 << log_n;
+    if (log_n == 0) return ZKHIP_OK;
+    uint64_t* tw = nullptr;
+    ZK_TRY(get_twiddles(c, log_n, inverse, &tw));
+    const uint32_t tile = (uint32_t)std::min<size_t>(NTT_TILE, n);
+    {
+        ProfScope ps(c, "ntt_first_stages", 64.0 * (double)n);
+        hipLaunchKernelGGL(ntt_first_stages_kernel, dim3((unsigned)(n / tile)), dim3(MLE_BLOCK), 0, c->stream, d_data, d_scratch,
+                           log_n, tw);
+    }
+    for (uint32_t s = NTT_TILE_LOG; s < log_n; ++s) {
+        ProfScope ps(c, "ntt_stage", 64.0 * (double)n);
+        hipLaunchKernelGGL(ntt_stage_kernel, dim3(mle_grid(n / 2)), dim3(MLE_BLOCK), 0, c->stream, d_scratch, log_n, s, tw);
+    }
+    if (inverse) {
+        zkhost::Fr ni = zkhost::fr_inv(zkhost::fr_from_u64((uint64_t)n));
+        FrArg sc;
+        std::memcpy(sc.v, ni.l, 32);
+        hipLaunchKernelGGL(elementwise_kernel<2>, dim3(mle_grid(n)), dim3(MLE_BLOCK), 0, c->stream, d_scratch,
+                           (const uint64_t*)nullptr, sc, n, d_data);
+    } else {
+        ZK_HIP(c, hipMemcpyAsync(d_data, d_scratch, n * 32, hipMemcpyDeviceToDevice, c->stream));
+    }
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_ntt(zkhip_ctx* c, uint64_t* d_data, uint32_t log_n, int inverse) {
+    if (!c || !d_data) return ZKHIP_ERR_ARG;
+    if (log_n > 30) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    const size_t n = (size_t)1 << log_n;
+    ZK_TRY(c->reserve_ws(n * 32));
+    return ntt_inplace(c, d_data, log_n, inverse, (uint64_t*)c->d_ws);
+}
+
+extern "C" int zkhip_pointwise_mul(zkhip_ctx* c, const uint64_t* d_a, const uint64_t* d_b, size_t n, uint64_t* d_out) {
+    if (!c || !d_a || !d_b || !d_out) return ZKHIP_ERR_ARG;
+    ZK_TRY(c->activate());
+    hipLaunchKernelGGL(pointwise_mul_kernel, dim3(mle_grid(n)), dim3(MLE_BLOCK), 0, c->stream, d_a, d_b, n, d_out);
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_univariate_multiply(zkhip_ctx* c, const uint64_t* d_a, size_t na, const uint64_t* d_b, size_t nb,
+                                         uint64_t* d_out) {
+    if (!c || !d_a || !d_b || !d_out) return ZKHIP_ERR_ARG;
+    if (na == 0 || nb == 0) return ZKHIP_ERR_SHAPE;   // len_a + len_b - 1 underflows in the reference (evaluation.rs:66)
+    ZK_TRY(c->activate());
+    const size_t unscaled = na + nb - 1;
+    uint32_t log_n = 0;
+    while (((size_t)1 << log_n) < unscaled) ++log_n;
+    if (log_n > 30) return ZKHIP_ERR_SHAPE;
+    const size_t n = (size_t)1 << log_n;
+    ZK_TRY(c->reserve_ws(3 * n * 32));
+    uint64_t* scratch = (uint64_t*)c->d_ws;
+    uint64_t* ea = scratch + 4 * n;
+    uint64_t* eb = ea + 4 * n;
+    ZK_HIP(c, hipMemsetAsync(ea, 0, 2 * n * 32, c->stream));                                        // resize(.., F::ZERO) :73-74
+    ZK_HIP(c, hipMemcpyAsync(ea, d_a, na * 32, hipMemcpyDeviceToDevice, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(eb, d_b, nb * 32, hipMemcpyDeviceToDevice, c->stream));
+    ZK_TRY(ntt_inplace(c, ea, log_n, 0, scratch));                                                   // domain.fft :76-77
+    ZK_TRY(ntt_inplace(c, eb, log_n, 0, scratch));
+    hipLaunchKernelGGL(pointwise_mul_kernel, dim3(mle_grid(n)), dim3(MLE_BLOCK), 0, c->stream, ea, eb, n, ea);   // :79-82
+    ZK_TRY(ntt_inplace(c, ea, log_n, 1, scratch));                                                   // domain.ifft :84
+    ZK_HIP(c, hipMemcpyAsync(d_out, ea, unscaled * 32, hipMemcpyDeviceToDevice, c->stream));         // truncate :85
+    return ZKHIP_OK;
+}

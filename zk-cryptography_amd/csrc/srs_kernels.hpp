@@ -7,13 +7,14 @@
 // (the SRS is stored affine in HBM so that the commit path can use mixed additions).
 #pragma once
 #include "g1.hpp"
+#include "mle_kernels.hpp"
 
 namespace zk {
 
 constexpr int SRS_BLOCK = 256;
 
 // eq scalars of the multilinear SRS: s_i = prod_j (bit_j(i) ? tau_j : 1 - tau_j), bit 0 = MSB (variable 0)
-__global__ __launch_bounds__(SRS_BLOCK) void srs_eq_scalars_kernel(const uint64_t* __restrict__ tau, uint32_t n_vars,
+static __global__ __launch_bounds__(SRS_BLOCK) void srs_eq_scalars_kernel(PtsArg tau, uint32_t n_vars,
                                                                    uint64_t* __restrict__ out) {
     const size_t n = (size_t)1 << n_vars;
     const size_t stride = (size_t)gridDim.x * SRS_BLOCK;
@@ -21,7 +22,7 @@ __global__ __launch_bounds__(SRS_BLOCK) void srs_eq_scalars_kernel(const uint64_
     for (size_t i = (size_t)blockIdx.x * SRS_BLOCK + threadIdx.x; i < n; i += stride) {
         Fr acc = one;
         for (uint32_t j = 0; j < n_vars; ++j) {
-            Fr t = load_fr(tau, j);
+            Fr t = fr_from_pts(tau, j);
             if (!((i >> (n_vars - 1 - j)) & 1)) t = one - t;
             acc = acc * t;
         }
@@ -30,10 +31,10 @@ __global__ __launch_bounds__(SRS_BLOCK) void srs_eq_scalars_kernel(const uint64_
 }
 
 // powers of tau: s_i = tau^i (tau.pow([i]) univariate_kzg.rs:26)
-__global__ __launch_bounds__(SRS_BLOCK) void srs_power_scalars_kernel(const uint64_t* __restrict__ tau, size_t n,
+static __global__ __launch_bounds__(SRS_BLOCK) void srs_power_scalars_kernel(FrArg tau, size_t n,
                                                                       uint64_t* __restrict__ out) {
     const size_t stride = (size_t)gridDim.x * SRS_BLOCK;
-    const Fr t = load_fr(tau, 0);
+    const Fr t = fr_from_arg(tau);
     for (size_t i = (size_t)blockIdx.x * SRS_BLOCK + threadIdx.x; i < n; i += stride) {
         Fr acc = Fr::one();
         bool started = false;
@@ -57,7 +58,7 @@ __device__ __forceinline__ G1Affine g1_generator() {
 }
 
 // out[i] = G * scalars[i]  (Group::mul_bigint(point.into_bigint()) trusted_setup.rs:33): MSB-first double-and-add
-__global__ __launch_bounds__(SRS_BLOCK) void srs_fixed_base_kernel(const uint64_t* __restrict__ scalars, size_t n,
+static __global__ __launch_bounds__(SRS_BLOCK) void srs_fixed_base_kernel(const uint64_t* __restrict__ scalars, size_t n,
                                                                    uint64_t* __restrict__ out_xyzz) {
     const size_t i = (size_t)blockIdx.x * SRS_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -93,7 +94,7 @@ __device__ __noinline__ Fq fq_inverse(Fq a) {
 
 // XYZZ -> affine (x = X/ZZ, y = Y/ZZZ) with Montgomery's batch-inversion trick over CHUNK points per lane.
 constexpr int SRS_CHUNK = 8;
-__global__ __launch_bounds__(SRS_BLOCK) void srs_batch_affine_kernel(const uint64_t* __restrict__ in_xyzz, size_t n,
+static __global__ __launch_bounds__(SRS_BLOCK) void srs_batch_affine_kernel(const uint64_t* __restrict__ in_xyzz, size_t n,
                                                                      uint64_t* __restrict__ out_xy,
                                                                      uint8_t* __restrict__ out_inf) {
     const size_t t = (size_t)blockIdx.x * SRS_BLOCK + threadIdx.x;

@@ -57,18 +57,21 @@ __device__ __forceinline__ Fr transcript_round(Transcript& tr, Fr* conv, const F
 //   partials: n_partials x (lo, hi) partial half-sums of the CURRENT table (from half_sums_kernel or the
 //             previous round's fold_kernel<true>); for world > 1 they are the all-gathered per-rank sums.
 //   first:    round 0 also starts the transcript and absorbs the claimed sum (sumcheck.rs:31-35):
-//             1 = the sum is lo + hi (computed here), 2 = the caller's `self.sum`, already in st->sum.
+//             1 = the sum is lo + hi (computed here), 2 = the caller's `self.sum`, passed by value (claimed).
+//   have_hs:  the first round's (lo, hi) were already computed by poly_sum() and arrive by value (hs_lo, hs_hi).
 // Writes round_polys[round] = (lo, hi) and challenges[round] (both Montgomery form).
-__global__ __launch_bounds__(MLE_BLOCK) void sumcheck_round_kernel(const uint64_t* __restrict__ partials,
+static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_round_kernel(const uint64_t* __restrict__ partials,
                                                                    uint32_t n_partials, SumcheckDev* st,
-                                                                   uint32_t round, uint32_t first,
+                                                                   uint32_t round, uint32_t first, FrArg claimed,
+                                                                   uint32_t have_hs, FrArg hs_lo, FrArg hs_hi,
                                                                    uint64_t* __restrict__ round_polys,
                                                                    uint64_t* __restrict__ challenges) {
     __shared__ Fr red[2 * MLE_BLOCK / 64];
     __shared__ Fr conv[4];
     Fr lo, hi;
     ZK_STAMP(0);
-    reduce_partials(partials, n_partials, red, lo, hi);
+    if (have_hs) { lo = fr_from_arg(hs_lo); hi = fr_from_arg(hs_hi); }
+    else reduce_partials(partials, n_partials, red, lo, hi);
     ZK_STAMP(1);
     if (threadIdx.x == 0) { conv[1] = lo; conv[2] = hi; }
     __syncthreads();
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_round_kernel(const uint64_
         Transcript tr;
         Fr sum = Fr::zero();
         if (first) {
-            sum = (first == 2) ? load_fr(st->sum, 0) : lo + hi;
+            sum = (first == 2) ? fr_from_arg(claimed) : lo + hi;
             tr.init();
         } else {
             tr.load(&st->transcript);
@@ -98,9 +101,9 @@ __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_round_kernel(const uint64_
 
 // Runs ALL remaining rounds of a table of n <= TAIL_N entries inside one workgroup (table in LDS):
 // per round half-sums -> transcript -> challenge -> fold (sumcheck.rs:40-51).  `first` as above.
-__global__ __launch_bounds__(MLE_BLOCK) void sumcheck_tail_kernel(const uint64_t* __restrict__ in, uint32_t n,
+static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_tail_kernel(const uint64_t* __restrict__ in, uint32_t n,
                                                                   SumcheckDev* st, uint32_t round0, uint32_t first,
-                                                                  uint64_t* __restrict__ round_polys,
+                                                                  FrArg claimed, uint64_t* __restrict__ round_polys,
                                                                   uint64_t* __restrict__ challenges,
                                                                   uint64_t* __restrict__ final_eval) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_tail_kernel(const uint64_t
             const bool absorb_sum = first && round == round0;
             Fr sum = Fr::zero();
             if (absorb_sum) {
-                sum = (first == 2) ? load_fr(st->sum, 0) : lo + hi;
+                sum = (first == 2) ? fr_from_arg(claimed) : lo + hi;
                 tr.init();
             }
             Fr r = transcript_round(tr, conv, sum, lo, hi, absorb_sum);
