@@ -33,12 +33,24 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
     g = torch.Generator(device="cuda").manual_seed(0x5EED1001 + rank)
     poly = zk.Multilinear(torch.randint(0, 2 ** 62, (n, 4), dtype=torch.int64, device="cuda", generator=g))
     steps = max(2, min(args.steps, 10))
+    from zk_cryptography_amd import distributed as D
+
+    def commit():
+        if world == 1:
+            return zk.MultilinearKZG.commitment(poly, srs)
+        # N > 1: this rank's (scalars, SRS) are one shard of a world * 2^log_n commit; partial commitments
+        # (104 B per rank) are all-gathered and summed on every rank
+        def local():
+            c = zk.MultilinearKZG.commitment(poly, srs)
+            return c.xy, c.infinity
+        return D.sharded_commit(local, D.hip_sum_affine, world, None, dist, device="cuda")
+
     for _ in range(2):
-        com = zk.MultilinearKZG.commitment(poly, srs)
+        com = commit()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        com = zk.MultilinearKZG.commitment(poly, srs)
+        com = commit()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -109,10 +121,16 @@ def main():
     table = torch.randint(0, 2 ** 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
     poly = zk.Multilinear(table)
 
+    from zk_cryptography_amd import distributed as D
+
     def step():
-        sc = zk.Sumcheck(poly)
-        sc.poly_sum()
-        return sc.prove()
+        if world == 1:
+            sc = zk.Sumcheck(poly)
+            sc.poly_sum()
+            return sc.prove()
+        # N > 1: ONE prover over the world * 2^log_n-entry table whose rank-interleaved shard is `table`
+        # (per-round 64-byte all-gather over RCCL/xGMI + replicated transcript)
+        return D.ShardedSumcheck(D.HipSumcheckEngine(table), world, None, dist).prove()
 
     def barrier():
         if world > 1:
@@ -184,7 +202,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "24-var multilinear sumcheck prover (poly_sum + prove), BLS12-381 Fr" if args.log_n == 24
                        else "%d-var multilinear sumcheck prover" % args.log_n,
-                       "evals_per_gpu": n, "sharding": "independent tables per GPU" if world > 1 else "single GPU"},
+                       "evals_per_gpu": n, "sharding": ("one %d-entry table sharded by low index bits over %d GPUs, 64 B all-gather per round" % (n * world, world))
+                       if world > 1 else "single GPU"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "msm": msm,

@@ -101,6 +101,35 @@ int zkhip_sumcheck_prove(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, cons
                          const uint64_t *h_first_half_sums, uint64_t *h_sum, uint64_t *h_round_polys,
                          uint64_t *h_challenges);
 
+/* ---- the same prover, split per phase, for a table SHARDED over several GPUs ---------------------
+ * The N = n_local * world entries are partitioned by their low index bits: rank g holds entry i = j*world + g
+ * at local index j.  Rounds fold variable 0 (the most significant index bit), so every fold is local; per
+ * round each rank contributes its two partial half sums (64 bytes), the host all-gathers them (RCCL over xGMI
+ * through torch.distributed, or any other transport) and every rank absorbs the same sums into its own copy
+ * of the transcript.  Once the whole remaining table fits one workgroup's LDS it is all-gathered and the
+ * last rounds run replicated inside one kernel.  Modular addition is not an RCCL reduction, hence all-gather + local add.
+ *   begin -> { local_half_sums -> [all-gather] -> absorb -> fold } x log2(n_local)
+ *         -> local_value -> [all-gather] -> tail -> finish                                            */
+typedef struct zkhip_sc_state zkhip_sc_state;
+int zkhip_sc_begin(zkhip_ctx *ctx, const uint64_t *d_local_evals, size_t n_local, zkhip_sc_state **out);
+int zkhip_sc_local_len(zkhip_sc_state *st, size_t *n_local_now);
+int zkhip_sc_local_half_sums(zkhip_sc_state *st, uint64_t *d_out /* [2][4] */);
+/* d_gathered[world][2][4]: every rank's (lower, upper) partial sums in rank order.  First round only:
+ * h_claimed_sum as in zkhip_sumcheck_prove (NULL = the true sum). */
+int zkhip_sc_absorb(zkhip_sc_state *st, const uint64_t *d_gathered, uint32_t world, const uint64_t *h_claimed_sum);
+int zkhip_sc_fold(zkhip_sc_state *st);
+/* copy of the current local table (n_local_now entries) -- gathered by the host once the whole remaining
+ * table (n_local_now * world entries) fits one workgroup's LDS (zkhip_sc_tail_capacity entries) */
+int zkhip_sc_local_table(zkhip_sc_state *st, uint64_t *d_out);
+int zkhip_sc_tail_capacity(void);
+/* d_values[m][4]: the whole remaining table in natural order (entry j*world + g = rank g's local entry j),
+ * m a power of two <= zkhip_sc_tail_capacity(); runs ALL remaining log2(m) rounds replicated.  h_claimed_sum
+ * only matters when no round has been absorbed yet. */
+int zkhip_sc_tail(zkhip_sc_state *st, const uint64_t *d_values, uint32_t m, const uint64_t *h_claimed_sum);
+/* copies out the proof (as zkhip_sumcheck_prove; *n_rounds rounds were recorded) and releases the state */
+int zkhip_sc_finish(zkhip_sc_state *st, uint64_t *h_sum, uint64_t *h_round_polys, uint64_t *h_challenges,
+                    uint32_t *n_rounds);
+
 /* ---- composed sumcheck provers (sumcheck/src/composed/) --------------------------------------- */
 /* A product term is K tables (ComposedMultilinear, polynomial/src/composed/composed_multilinear.rs:8-18) of n
  * entries each, given as a HOST array of K DEVICE pointers.  K <= 5; at most 4 terms. */

@@ -58,6 +58,7 @@ struct zkhip_ctx {
     int last_hip = 0;
     void* d_ws = nullptr;       // large workspace (ping-pong tables, MSM buckets, ...)
     size_t ws_bytes = 0;
+    bool ws_lent = false;       // the workspace currently backs a split-phase prover state
     void* d_small = nullptr;    // fixed small scratch, layout above
     void* h_pinned = nullptr;
     bool profiling = false;

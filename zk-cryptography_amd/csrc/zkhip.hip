@@ -372,6 +372,144 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
 }
 
 
+// ---------------------------------------------------------------------------------------
+// split-phase prover for a table sharded over several GPUs
+// ---------------------------------------------------------------------------------------
+struct zkhip_sc_state {
+    zkhip_ctx* c;
+    const uint64_t* cur;     // current local table
+    size_t cn;               // its length
+    uint64_t *A, *B;         // ping-pong buffers (n/2, n/4 entries)
+    uint64_t* small;         // [SumcheckDev 64 u64][round polys 8*R][challenges 4*R][partials 8*MLE_MAX_GRID][tail 4*TAIL_N]
+    uint32_t round, np;
+    bool partials_valid;
+    bool owns_tables;        // false: A/B live in the context workspace (the common, single-state case)
+    SumcheckDev* dev() { return (SumcheckDev*)small; }
+    uint64_t* rp() { return small + 64; }
+    uint64_t* ch() { return rp() + 8 * ZK_MAX_ROUNDS; }
+    uint64_t* partials() { return ch() + 4 * ZK_MAX_ROUNDS; }
+    uint64_t* fin() { return partials() + 8 * (size_t)MLE_MAX_GRID; }
+};
+
+extern "C" int zkhip_sc_begin(zkhip_ctx* c, const uint64_t* d_local, size_t n_local, zkhip_sc_state** out) {
+    if (!c || !d_local || !out) return ZKHIP_ERR_ARG;
+    if (!is_pow2(n_local)) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    zkhip_sc_state* st = new zkhip_sc_state();
+    st->c = c; st->cur = d_local; st->cn = n_local; st->round = 0; st->np = 0; st->partials_valid = false;
+    st->A = st->B = st->small = nullptr;
+    const size_t small_u64 = 64 + 12 * (size_t)ZK_MAX_ROUNDS + 8 * (size_t)MLE_MAX_GRID + 16;
+    if (hipMalloc(&st->small, small_u64 * 8) != hipSuccess) { delete st; return ZKHIP_ERR_NOMEM; }
+    st->owns_tables = false;
+    if (n_local >= 2) {
+        const size_t bytes = (n_local / 2 + n_local / 4 + 4) * 32;
+        if (!c->ws_lent) {               // steady state: no allocation per prove
+            int rc = c->reserve_ws(bytes);
+            if (rc != ZKHIP_OK) { hipFree(st->small); delete st; return rc; }
+            st->A = (uint64_t*)c->d_ws;
+            c->ws_lent = true;
+        } else {                         // several states alive at once (tests drive shards in lockstep)
+            if (hipMalloc(&st->A, bytes) != hipSuccess) { hipFree(st->small); delete st; return ZKHIP_ERR_NOMEM; }
+            st->owns_tables = true;
+        }
+    }
+    st->B = st->A ? st->A + 4 * (n_local / 2) : nullptr;
+    *out = st;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_sc_local_len(zkhip_sc_state* st, size_t* n) {
+    if (!st || !n) return ZKHIP_ERR_ARG;
+    *n = st->cn;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_sc_local_half_sums(zkhip_sc_state* st, uint64_t* d_out) {
+    if (!st || !d_out) return ZKHIP_ERR_ARG;
+    if (st->cn < 2) return ZKHIP_ERR_SHAPE;
+    zkhip_ctx* c = st->c;
+    ZK_TRY(c->activate());
+    if (!st->partials_valid) {   // first round (later rounds: the fold already produced them)
+        const int grid = mle_grid((st->cn + 3) / 4);
+        ProfScope ps(c, "half_sums", 32.0 * (double)st->cn);
+        hipLaunchKernelGGL(half_sums_kernel, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, st->cur, st->cn, st->partials());
+        st->np = (uint32_t)grid;
+    }
+    hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, st->partials(), st->np, st->fin());
+    ZK_HIP(c, hipMemcpyAsync(d_out, st->fin(), 64, hipMemcpyDeviceToDevice, c->stream));
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_sc_absorb(zkhip_sc_state* st, const uint64_t* d_gathered, uint32_t world, const uint64_t* h_claimed) {
+    if (!st || !d_gathered || world == 0) return ZKHIP_ERR_ARG;
+    if (st->round >= ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
+    zkhip_ctx* c = st->c;
+    ZK_TRY(c->activate());
+    FrArg claimed = {}, z = {};
+    uint32_t first = st->round == 0 ? 1 : 0;
+    if (first && h_claimed) { std::memcpy(claimed.v, h_claimed, 32); first = 2; }
+    hipLaunchKernelGGL(sumcheck_round_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_gathered, world, st->dev(), st->round,
+                       first, claimed, 0u, z, z, st->rp(), st->ch());
+    ZK_HIP(c, hipGetLastError());
+    st->round++;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_sc_fold(zkhip_sc_state* st) {
+    if (!st) return ZKHIP_ERR_ARG;
+    if (st->cn < 2 || st->round == 0) return ZKHIP_ERR_SHAPE;
+    zkhip_ctx* c = st->c;
+    ZK_TRY(c->activate());
+    uint64_t* dst = (st->cur == st->A) ? st->B : st->A;
+    const bool sums = st->cn >= 4;   // the folded table still has two halves to sum
+    ZK_TRY(launch_fold(c, st->cur, st->cn, st->ch() + 4 * (st->round - 1), nullptr, 0, dst, sums, st->partials(), &st->np));
+    st->partials_valid = sums;
+    st->cur = dst;
+    st->cn /= 2;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_sc_local_value(zkhip_sc_state* st, uint64_t* d_out) {
+    if (!st || !d_out) return ZKHIP_ERR_ARG;
+    if (st->cn != 1) return ZKHIP_ERR_SHAPE;
+    ZK_HIP(st->c, hipMemcpyAsync(d_out, st->cur, 32, hipMemcpyDeviceToDevice, st->c->stream));
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_sc_local_table(zkhip_sc_state* st, uint64_t* d_out) {
+    if (!st || !d_out) return ZKHIP_ERR_ARG;
+    ZK_HIP(st->c, hipMemcpyAsync(d_out, st->cur, 32 * st->cn, hipMemcpyDeviceToDevice, st->c->stream));
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_sc_tail_capacity(void) { return TAIL_N; }
+extern "C" int zkhip_sc_tail(zkhip_sc_state* st, const uint64_t* d_values, uint32_t m, const uint64_t* h_claimed) {
+    if (!st || !d_values) return ZKHIP_ERR_ARG;
+    if (!is_pow2(m) || m > (uint32_t)TAIL_N) return ZKHIP_ERR_SHAPE;
+    if (m == 1) return ZKHIP_OK;
+    zkhip_ctx* c = st->c;
+    ZK_TRY(c->activate());
+    ZK_TRY(c->allow_big_lds((const void*)sumcheck_tail_kernel, TAIL_LDS_BYTES));
+    FrArg z = {};
+    uint32_t first = st->round == 0 ? 1u : 0u;
+    if (first && h_claimed) { std::memcpy(z.v, h_claimed, 32); first = 2; }
+    hipLaunchKernelGGL(sumcheck_tail_kernel, dim3(1), dim3(MLE_BLOCK), TAIL_LDS_BYTES, c->stream, d_values, m, st->dev(),
+                       st->round, first, z, st->rp(), st->ch(), st->fin());
+    ZK_HIP(c, hipGetLastError());
+    st->round += log2_exact(m);
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_sc_finish(zkhip_sc_state* st, uint64_t* h_sum, uint64_t* h_rp, uint64_t* h_ch, uint32_t* n_rounds) {
+    if (!st) return ZKHIP_ERR_ARG;
+    zkhip_ctx* c = st->c;
+    int rc = ZKHIP_OK;
+    if (c->activate() != ZKHIP_OK) rc = ZKHIP_ERR_HIP;
+    if (rc == ZKHIP_OK && h_sum && hipMemcpyAsync(h_sum, st->dev()->sum, 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
+    if (rc == ZKHIP_OK && h_rp && st->round && hipMemcpyAsync(h_rp, st->rp(), 64 * (size_t)st->round, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
+    if (rc == ZKHIP_OK && h_ch && st->round && hipMemcpyAsync(h_ch, st->ch(), 32 * (size_t)st->round, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
+    if (n_rounds) *n_rounds = st->round;
+    if (st->A && st->owns_tables) hipFree(st->A);
+    if (st->A && !st->owns_tables) c->ws_lent = false;
+    hipFree(st->small);
+    delete st;
+    return rc;
+}
+
 #ifdef ZK_STAMPS
 extern "C" int zkhip_debug_read_stamps(zkhip_ctx* c, unsigned long long* h_out /*64*8*/) {
     ZK_HIP(c, hipStreamSynchronize(c->stream));

@@ -1,0 +1,154 @@
+"""Multi-GPU host logic: one process per GPU, torch.distributed over RCCL/xGMI (backend "nccl" on ROCm).
+
+Only the hot path's two sharding schemes live here:
+
+* ShardedSumcheck -- the evaluation table of N = n_local * world entries is partitioned by the LOW index
+  bits (rank g holds entry j*world + g at local index j).  Sumcheck rounds fold variable 0 = the most
+  significant index bit, so every fold is local; per round the ranks exchange 64 bytes each (their partial
+  half sums) with one all-gather and add them locally (modular addition is not an RCCL reduction).
+  The transcript is replicated deterministically.  The last log2(world) rounds run replicated on the
+  all-gathered `world` remaining values.
+* sharded_commit -- (scalars, SRS points) are split the same way; each rank runs a full sub-MSM and the
+  `world` partial commitments (104 bytes each) are all-gathered and summed.
+
+The per-rank compute sits behind a small "engine" interface so that the exchange protocol can be exercised
+on CPU (gloo) in tests with a checker engine; the product engine below is the HIP one.
+"""
+import ctypes as C
+
+import numpy as np
+
+from zk_cryptography_amd import _native as N
+
+
+def shard_interleaved(full, rank, world):
+    """rank's shard of a full table / SRS: entries rank, rank + world, ... (works on numpy and torch)."""
+    return full[rank::world]
+
+
+class HipSumcheckEngine:
+    """Split-phase prover state on this rank's GPU (zkhip_sc_* in include/zkhip.h)."""
+
+    def __init__(self, local_table):
+        import torch
+        self.torch = torch
+        self.table = local_table          # int64 [n_local, 4] CUDA tensor, kept alive for the duration
+        self.ctx = N.Context.get(local_table.device.index)
+        self.st = C.c_void_p()
+        N.check(N.lib().zkhip_sc_begin(self.ctx.handle, N.ptr(local_table), C.c_size_t(local_table.shape[0]),
+                                       C.byref(self.st)), "sc_begin")
+
+    def new_buffer(self, *shape):
+        return self.torch.empty(shape, dtype=self.torch.int64, device=self.table.device)
+
+    def local_len(self):
+        n = C.c_size_t(0)
+        N.check(N.lib().zkhip_sc_local_len(self.st, C.byref(n)), "sc_local_len")
+        return n.value
+
+    def local_half_sums(self, out):
+        N.check(N.lib().zkhip_sc_local_half_sums(self.st, N.ptr(out)), "sc_local_half_sums")
+
+    def absorb(self, gathered, world, claimed_sum=None):
+        cs = np.ascontiguousarray(claimed_sum, dtype=np.uint64) if claimed_sum is not None else None
+        N.check(N.lib().zkhip_sc_absorb(self.st, N.ptr(gathered), C.c_uint32(world),
+                                        cs.ctypes.data_as(C.c_void_p) if cs is not None else None), "sc_absorb")
+
+    def fold(self):
+        N.check(N.lib().zkhip_sc_fold(self.st), "sc_fold")
+
+    def local_value(self, out):
+        N.check(N.lib().zkhip_sc_local_value(self.st, N.ptr(out)), "sc_local_value")
+
+    def local_table(self, out):
+        N.check(N.lib().zkhip_sc_local_table(self.st, N.ptr(out)), "sc_local_table")
+
+    def tail_capacity(self):
+        return N.lib().zkhip_sc_tail_capacity()
+
+    def tail(self, values, m, claimed_sum=None):
+        cs = np.ascontiguousarray(claimed_sum, dtype=np.uint64) if claimed_sum is not None else None
+        N.check(N.lib().zkhip_sc_tail(self.st, N.ptr(values), C.c_uint32(m),
+                                      cs.ctypes.data_as(C.c_void_p) if cs is not None else None), "sc_tail")
+
+    def finish(self, n_rounds):
+        s = np.empty(4, dtype=np.uint64)
+        rp = np.empty((max(n_rounds, 1), 2, 4), dtype=np.uint64)
+        ch = np.empty((max(n_rounds, 1), 4), dtype=np.uint64)
+        got = C.c_uint32(0)
+        N.check(N.lib().zkhip_sc_finish(self.st, s.ctypes.data_as(C.c_void_p), rp.ctypes.data_as(C.c_void_p),
+                                        ch.ctypes.data_as(C.c_void_p), C.byref(got)), "sc_finish")
+        self.st = None
+        assert got.value == n_rounds
+        return s, rp[:n_rounds], ch[:n_rounds]
+
+
+def _all_gather(dist, group, out, inp, world):
+    if world == 1:
+        out.view(-1)[:] = inp.view(-1)
+    else:
+        dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=group)   # flat: rank-major concatenation
+
+
+class ShardedSumcheck:
+    """Sumcheck::prove (sumcheck/src/sumcheck.rs:29-61) over a table sharded by low index bits.
+
+    Every rank returns the same (sum, round_polys [n_vars, 2, 4], challenges [n_vars, 4]) -- the values a
+    single-GPU / reference prover yields on the full table."""
+
+    def __init__(self, engine, world=1, group=None, dist=None):
+        self.e = engine
+        self.world = world
+        self.group = group
+        self.dist = dist
+        if world & (world - 1):
+            raise AssertionError("world size must be a power of two (the table has 2^n entries)")
+
+    def prove(self, claimed_sum=None):
+        e, world = self.e, self.world
+        send = e.new_buffer(2, 4)
+        recv = e.new_buffer(world, 2, 4)
+        n_local = e.local_len()
+        total_rounds = (n_local * world).bit_length() - 1
+        cap = e.tail_capacity()
+        rnd = 0
+        while n_local * world > cap and n_local > 1:
+            e.local_half_sums(send)                                     # 64 bytes per rank
+            _all_gather(self.dist, self.group, recv, send, world)       # C1: RCCL all-gather over xGMI
+            e.absorb(recv, world, claimed_sum if rnd == 0 else None)    # local modular add + transcript -> challenge
+            e.fold()                                                    # local: partners share the low index bits
+            n_local //= 2
+            rnd += 1
+        if n_local * world > 1:
+            # the whole remaining table now fits one workgroup's LDS: gather it and finish replicated
+            mine = e.new_buffer(n_local, 4)
+            e.local_table(mine)
+            gathered = e.new_buffer(world, n_local, 4)
+            _all_gather(self.dist, self.group, gathered, mine, world)
+            full = gathered.transpose(0, 1).contiguous().view(n_local * world, 4)   # entry j*world + g <- rank g, local j
+            e.tail(full, n_local * world, claimed_sum if rnd == 0 else None)
+        return e.finish(total_rounds)
+
+
+def sharded_commit(local_commit, sum_affine, world=1, group=None, dist=None, device=None):
+    """KZG commit over (scalars, SRS) sharded across ranks.
+
+    local_commit() -> (xy uint64[12], inf bool): this rank's sub-MSM;  sum_affine(xy [world,12], inf [world]) ->
+    (xy, inf): group sum of the partial commitments.  Returns the full commitment on every rank."""
+    import torch
+    xy, inf = local_commit()
+    rec = torch.zeros(13, dtype=torch.int64, device=device)
+    rec[:12] = torch.from_numpy(np.ascontiguousarray(xy, dtype=np.uint64).view(np.int64)).to(rec.device)
+    rec[12] = 1 if inf else 0
+    out = torch.empty((world, 13), dtype=torch.int64, device=rec.device)
+    _all_gather(dist, group, out, rec, world)                            # C2: 104 bytes per rank
+    h = out.cpu().numpy().view(np.uint64)
+    return sum_affine(np.ascontiguousarray(h[:, :12]), np.ascontiguousarray(h[:, 12].astype(np.uint8)))
+
+
+def hip_sum_affine(xy, inf):
+    out = np.empty(12, dtype=np.uint64)
+    oinf = C.c_uint8(0)
+    N.check(N.lib().zkhip_g1_sum_affine(xy.ctypes.data_as(C.c_void_p), inf.ctypes.data_as(C.c_void_p),
+                                        C.c_size_t(xy.shape[0]), out.ctypes.data_as(C.c_void_p), C.byref(oinf)), "g1_sum")
+    return out, bool(oinf.value)
