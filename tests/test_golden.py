@@ -1,0 +1,63 @@
+"""Both the CPU oracle (-m "not gpu") and the HIP path (-m gpu) must reproduce the committed vectors of
+tests/golden/hot_path_vectors.json (restatement-derived; see tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hot_path_vectors.json")))
+
+
+def hx(ora, arr):
+    return ["%064x" % v for v in ora.fr_to_ints(arr)]
+
+
+def test_oracle_reproduces_golden(ora):
+    for e in G["sumcheck"]:
+        s, rp, ch = ora.sumcheck_prove(ora.fr_from_ints(e["evals"]))
+        assert hx(ora, s)[0] == e["sum"] and [hx(ora, r) for r in rp] == e["round_polys"] and hx(ora, ch) == e["challenges"]
+    for e in G["composed"]:
+        rp, ch = ora.composed_prove(np.stack([ora.fr_from_ints(v) for v in e["tables"]]))
+        assert [hx(ora, r) for r in rp] == e["round_polys"] and hx(ora, ch) == e["challenges"]
+    for e in G["multi_composed"]:
+        flat = np.stack([ora.fr_from_ints(t) for term in e["terms"] for t in term])
+        sizes = [len(t) for t in e["terms"]]
+        s = ora.multi_composed_sum(flat, sizes)
+        rps, ch = ora.multi_composed_prove(flat, sizes, s, e["partial"])
+        assert ora.multi_composed_proof_bytes(rps).hex() == e["proof_bytes"] and hx(ora, ch) == e["challenges"]
+    for e in G["ntt"]:
+        v = ora.fr_from_ints(e["input"])
+        assert hx(ora, ora.domain_fft(v, 16)) == e["fft"] and hx(ora, ora.domain_ifft(v, 16)) == e["ifft"]
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_golden(ora):
+    import zk_cryptography_amd as zk
+    F = zk.Fr.from_ints
+    for e in G["sumcheck"]:
+        sc = zk.Sumcheck(zk.Multilinear(F(e["evals"])))
+        sc.poly_sum()
+        proof, ch = sc.prove()
+        assert hx(ora, proof.sum)[0] == e["sum"] and [hx(ora, r) for r in proof.univariate_poly] == e["round_polys"]
+        assert hx(ora, ch) == e["challenges"]
+    for e in G["composed"]:
+        proof, ch = zk.ComposedSumcheck(zk.ComposedMultilinear([F(v) for v in e["tables"]])).prove()
+        assert [hx(ora, r) for r in proof.round_polys] == e["round_polys"] and hx(ora, ch) == e["challenges"]
+    for e in G["multi_composed"]:
+        poly = [zk.ComposedMultilinear([F(t) for t in term]) for term in e["terms"]]
+        s = zk.MultiComposedSumcheckProver.calculate_poly_sum(poly)
+        fn = zk.MultiComposedSumcheckProver.prove_partial if e["partial"] else zk.MultiComposedSumcheckProver.prove
+        proof, ch = fn(poly, s)
+        assert proof.to_bytes().hex() == e["proof_bytes"] and hx(ora, ch) == e["challenges"]
+    for e in G["kzg"]:
+        if e["kind"] == "multilinear":
+            com = zk.MultilinearKZG.commitment(zk.Multilinear(F(e["evals"])), zk.TrustedSetup.setup(F(e["tau"])))
+        else:
+            com = zk.UnivariateKZG.commitment(zk.DenseUnivariatePolynomial(F(e["coeffs"])), zk.UnivariateKZG.generate_srs(F([e["tau"]])[0], 4))
+        x, y = com.coords()
+        assert ("%096x" % x, "%096x" % y, com.infinity) == (e["x"], e["y"], e["inf"])
+    for e in G["ntt"]:
+        d = zk.Domain(16)
+        assert hx(ora, d.fft(F(e["input"])).cpu().numpy().view(np.uint64)) == e["fft"]
+        assert hx(ora, d.ifft(F(e["input"])).cpu().numpy().view(np.uint64)) == e["ifft"]
