@@ -158,14 +158,14 @@ def main():
     for _ in range(prof_steps):
         step()
     ms, cnt, by = C.c_double(), C.c_uint64(), C.c_double()
-    N.check(N.lib().zkhip_profile_read(ctx.handle, b"fold_sums", C.byref(ms), C.byref(cnt), C.byref(by)), "profile_read")
+    N.check(N.lib().zkhip_profile_read(ctx.handle, b"multifold", C.byref(ms), C.byref(cnt), C.byref(by)), "profile_read")
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
     achieved = by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "fold_kernel<true> (fused fold + next-round half sums)",
+    roofline = {"bound": "hbm", "kernel": "multifold_kernel (k-variable fold of the table + block sums of its output)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "launches": int(cnt.value), "avg_launch_us": round(1e3 * ms.value / max(1, cnt.value), 2),
-                "algorithmic_bytes_per_launch": "48 B x table entries (read 32n + write 16n)"}
+                "algorithmic_bytes_per_launch": "32 B x (table entries read + folded entries written), k variables per launch"}
 
     # ---- CPU baseline: the oracle's single-threaded restatement of poly_sum + prove, rank 0 only
     cpu = None

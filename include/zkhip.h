@@ -88,18 +88,24 @@ int zkhip_mle_elementwise(zkhip_ctx *ctx, int op, const uint64_t *d_a, const uin
 int zkhip_mle_to_bytes(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, uint8_t *d_out_bytes);
 
 /* ---- basic sumcheck prover (sumcheck/src/sumcheck.rs:25-61) -------------------------- */
+/* Block sums of a table: d_out[(2^log_blocks + 1) * 4] = the sums of its 2^log_blocks equal consecutive blocks
+ * followed by the total (= Sumcheck::poly_sum, sumcheck.rs:25-27, which also goes to h_total[4] if non-NULL).
+ * The prover consumes them (see zkhip_sumcheck_prove) so that poly_sum() + prove() stream the table once for
+ * the sums instead of twice.  zkhip_sumcheck_plan_log_blocks(n) is the granularity the prover wants (0: none). */
+int zkhip_sumcheck_plan_log_blocks(size_t n);
+int zkhip_mle_block_sums(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, uint32_t log_blocks, uint64_t *d_out,
+                         uint64_t *h_total);
 /* Sumcheck::prove (sumcheck.rs:29-61).  Inputs:
- *   h_claimed_sum[4]     `self.sum` as the caller holds it (what poly_sum() stored, or the default
- *                        zero): the transcript absorbs exactly this.  NULL = absorb the true sum,
- *                        computed on the device in the same pass.
- *   h_first_half_sums[8] optional (lower, upper) half sums of the table as returned by
- *                        zkhip_mle_half_sums, so that poly_sum() + prove() stream the table once
- *                        for the sum instead of twice.  NULL = computed here.
+ *   h_claimed_sum[4]  `self.sum` as the caller holds it (what poly_sum() stored, or the default zero): the
+ *                     transcript absorbs exactly this.  NULL = absorb the true sum, computed on the device.
+ *   d_block_sums      optional device array from zkhip_mle_block_sums(.., log_blocks, ..); NULL = computed here.
  * Host outputs: h_sum[4] (the absorbed sum); h_round_polys[n_vars*2*4] (the Vec<Multilinear> of 2
- * evaluations each, :11-15); h_challenges[n_vars*4].  d_evals is not modified. */
+ * evaluations each, :11-15); h_challenges[n_vars*4].  d_evals is not modified.
+ * Internally k rounds of transcript run on 2^k block sums, then one k-variable fold pass follows
+ * (csrc/multifold_kernels.hpp); the values are those of the round-by-round loop, bit for bit. */
 int zkhip_sumcheck_prove(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint64_t *h_claimed_sum,
-                         const uint64_t *h_first_half_sums, uint64_t *h_sum, uint64_t *h_round_polys,
-                         uint64_t *h_challenges);
+                         const uint64_t *d_block_sums, uint32_t log_blocks, uint64_t *h_sum,
+                         uint64_t *h_round_polys, uint64_t *h_challenges);
 
 /* ---- the same prover, split per phase, for a table SHARDED over several GPUs ---------------------
  * The N = n_local * world entries are partitioned by their low index bits: rank g holds entry i = j*world + g

@@ -43,6 +43,7 @@ def lib():
         import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
         _lib.zkhip_status_string.restype = C.c_char_p
+        _lib.zkhip_sumcheck_plan_log_blocks.argtypes = [C.c_size_t]
     return _lib
 
 

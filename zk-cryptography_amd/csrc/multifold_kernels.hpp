@@ -1,0 +1,282 @@
+// multifold_kernels.hpp -- the basic sumcheck prover restructured around k-variable folds (gfx950).
+//
+// Same observable behaviour as Sumcheck::prove (sumcheck/src/sumcheck.rs:29-61): identical sum, round
+// polynomials and challenges.  The restructuring uses two exact identities of the multilinear fold
+// (polynomial/src/multilinear/evaluation_form.rs:123-141) when variable 0 (the most significant index bit) is
+// folded first, as every sumcheck round does (sumcheck.rs:50):
+//   (1) block sums commute with the fold: if B[b] = sum_j T[b*m + j] (2^k blocks of m entries), then the block
+//       sums of fold(T, r) are fold(B, r).  The round polynomial (lower-half sum, upper-half sum) of each of the
+//       next k rounds is therefore the round polynomial of the 2^k-entry table B: k rounds of transcript run on
+//       B alone, inside one workgroup, BEFORE the big table is touched again;
+//   (2) k folds collapse into one pass: T_k[j] = sum_b eq_b(r_1..r_k) T[b*m + j], eq_b = prod_i (b_i ? r_i : 1-r_i).
+// A 2^24-entry prover thus streams the table twice (block sums, then one 8-variable fold that also emits the
+// block sums of its output) instead of ~5.3 times, and issues ~8 kernels instead of ~30.
+// Field arithmetic is exact, so the values equal the round-by-round ones bit for bit.
+//
+// The k-variable fold accumulates sum_b w_b * T_b as an unreduced 17-limb integer (15 column accumulators of
+// 96 bits: 64 mads + 64 carry adds per term, half of a Montgomery product) and reduces once per output with
+// a 9-word REDC; the weights carry an extra factor 2^32 that the ninth word removes.
+#pragma once
+#include "sumcheck_kernels.hpp"
+
+namespace zk {
+
+constexpr int MF_MAX_LOGK = 8;
+constexpr int MF_SLICES = 4;          // waves of a workgroup split the 2^k terms of the same 64 outputs
+constexpr int MF_OUT_PER_WG = 64;
+
+// per-workgroup sum of a contiguous chunk of `chunk` entries (chunk a power of two, >= MLE_BLOCK)
+static __global__ __launch_bounds__(MLE_BLOCK) void chunk_sums_kernel(const uint64_t* __restrict__ in, uint32_t chunk,
+                                                                      uint64_t* __restrict__ partials) {
+    __shared__ Fr red[MLE_BLOCK / 64];
+    const uint64_t* base = in + 4 * (size_t)blockIdx.x * chunk;
+    Fr s = Fr::zero();
+    for (uint32_t j = threadIdx.x; j < chunk; j += 4 * MLE_BLOCK) {
+        Fr v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (j + u * MLE_BLOCK < chunk) ? load_fr(base, j + u * MLE_BLOCK) : Fr::zero();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s = s + v[u];
+    }
+    s = block_reduce_fr(s, red);
+    if (threadIdx.x == 0) store_fr(partials, blockIdx.x, s);
+}
+
+// out[b] = sum of the group-th consecutive partials, b < n_blocks; out[n_blocks] = total
+static __global__ __launch_bounds__(MLE_BLOCK) void group_sums_kernel(const uint64_t* __restrict__ partials, uint32_t group,
+                                                                      uint32_t n_blocks, uint64_t* __restrict__ out) {
+    __shared__ Fr red[MLE_BLOCK / 64];
+    Fr tot = Fr::zero();
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += MLE_BLOCK) {
+        Fr s = Fr::zero();
+        for (uint32_t g = 0; g < group; ++g) s = s + load_fr(partials, (size_t)b * group + g);
+        store_fr(out, b, s);
+        tot = tot + s;
+    }
+    tot = block_reduce_fr(tot, red);
+    if (threadIdx.x == 0) store_fr(out, n_blocks, tot);
+}
+
+struct SmallArgs {
+    const uint64_t* src;    // mode 0: the table itself (2^log_n entries); mode 1: partial sums, `group` per block
+    uint32_t group;         // mode 1: consecutive partials per table entry (0 = mode 0)
+    uint32_t log_n;         // working table has 2^log_n entries (<= TAIL_N)
+    uint32_t n_rounds;      // rounds to run, <= log_n
+    uint32_t round0;        // index of the first round run here
+    uint32_t first;         // 0 continue; 1 start the transcript, sum = lo + hi; 2 start it, sum = claimed
+    FrArg claimed;
+    uint64_t* weights_out;  // nullable: 2^n_rounds fold weights eq_b(r) * 2^32 (Montgomery form)
+    uint64_t* final_out;    // nullable: the table left after n_rounds folds
+};
+
+// n_rounds sumcheck rounds (half sums -> transcript -> challenge -> fold, sumcheck.rs:40-51) of a table that
+// lives in LDS, optionally recording the weights of the equivalent k-variable fold.
+static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallArgs a, SumcheckDev* st,
+                                                                          uint64_t* __restrict__ round_polys,
+                                                                          uint64_t* __restrict__ challenges) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
+    Fr* tab = reinterpret_cast<Fr*>(zk_dyn_lds);        // 2^log_n entries
+    const uint32_t n = 1u << a.log_n;
+    Fr* wa = tab + n;                                   // weights, ping
+    Fr* wb = wa + (1u << MF_MAX_LOGK);                  // weights, pong
+    Fr* red = wb + (1u << MF_MAX_LOGK);                 // 2 * MLE_BLOCK / 64
+    Fr* conv = red + 2 * MLE_BLOCK / 64;                // 4
+    Fr* r_shp = conv + 4;                               // 1
+    for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) {
+        if (a.group == 0) {
+            tab[j] = load_fr(a.src, j);
+        } else {
+            Fr s = Fr::zero();
+            for (uint32_t g = 0; g < a.group; ++g) s = s + load_fr(a.src, (size_t)j * a.group + g);
+            tab[j] = s;
+        }
+    }
+    if (threadIdx.x == 0 && a.weights_out) {
+        Fr w0;   // Montgomery form of 2^32: the k-variable fold reduces with 9 words instead of 8
+        constexpr uint32_t c[8] = {0xcaaf6b13u, 0x355094eau, 0x69a568efu, 0xf6b10cb3u, 0x40cc3869u, 0xe2c926a6u, 0xed269aadu, 0x736a6d3bu};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w0.l[i] = c[i];
+        wa[0] = w0;
+    }
+    __syncthreads();
+    Transcript tr;
+    if (threadIdx.x < 64 && !a.first) tr.load(&st->transcript);
+    uint32_t cur = n, round = a.round0, n_w = 1;
+    for (uint32_t it = 0; it < a.n_rounds; ++it) {
+        const uint32_t half = cur >> 1;
+        Fr lo = Fr::zero(), hi = Fr::zero();
+        for (uint32_t j = threadIdx.x; j < half; j += MLE_BLOCK) {
+            lo = lo + tab[j];
+            hi = hi + tab[j + half];
+        }
+        block_reduce_fr2(lo, hi, red);
+        if (threadIdx.x == 0) { conv[1] = lo; conv[2] = hi; }
+        __syncthreads();
+        if (threadIdx.x < 64) {   // wave 0, uniform
+            lo = conv[1];
+            hi = conv[2];
+            const bool absorb_sum = a.first && it == 0;
+            Fr sum = Fr::zero();
+            if (absorb_sum) {
+                sum = (a.first == 2) ? fr_from_arg(a.claimed) : lo + hi;
+                tr.init();
+            }
+            Fr r = transcript_round(tr, conv, sum, lo, hi, absorb_sum);
+            if (threadIdx.x == 0) {
+                if (absorb_sum) store_fr(st->sum, 0, sum);
+                *r_shp = r;
+                store_fr(round_polys, 2 * (size_t)round, lo);
+                store_fr(round_polys, 2 * (size_t)round + 1, hi);
+                store_fr(challenges, round, r);
+            }
+        }
+        __syncthreads();
+        const Fr r = *r_shp;
+        // in place: lane j reads (j, j+half) and writes j; no other lane touches index j this round
+        for (uint32_t j = threadIdx.x; j < half; j += MLE_BLOCK) tab[j] = fold_pair(tab[j], tab[j + half], r);
+        if (a.weights_out) {   // eq weights: index gains the new variable as its least significant bit
+            Fr* src = (it & 1) ? wb : wa;
+            Fr* dst = (it & 1) ? wa : wb;
+            for (uint32_t b = threadIdx.x; b < n_w; b += MLE_BLOCK) {
+                Fr w1 = src[b] * r;
+                dst[2 * b + 1] = w1;
+                dst[2 * b] = src[b] - w1;
+            }
+            n_w <<= 1;
+        }
+        __syncthreads();
+        cur = half;
+        ++round;
+    }
+    if (threadIdx.x == 0) tr.store(&st->transcript);
+    if (a.weights_out) {
+        Fr* w = (a.n_rounds & 1) ? wb : wa;
+        for (uint32_t b = threadIdx.x; b < n_w; b += MLE_BLOCK) store_fr(a.weights_out, b, w[b]);
+    }
+    if (a.final_out)
+        for (uint32_t j = threadIdx.x; j < cur; j += MLE_BLOCK) store_fr(a.final_out, j, tab[j]);
+}
+constexpr size_t SMALL_LDS_FIXED = (size_t)(2 * (1 << MF_MAX_LOGK) + 2 * MLE_BLOCK / 64 + 4 + 1) * sizeof(Fr);
+
+// ---- the k-variable fold -------------------------------------------------------------------------------
+// Unreduced accumulator: column c collects every limb product w[i]*t[j] with i + j = c.
+struct WideAcc {
+    uint64_t lo[15];
+    uint32_t hi[15];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int c = 0; c < 15; ++c) { lo[c] = 0; hi[c] = 0; }
+    }
+    __device__ __forceinline__ void mac(const Fr& w, const Fr& t) {
+#pragma unroll
+        for (int c = 0; c < 15; ++c) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = c - i;
+                if (j >= 0 && j < 8) mac96(lo[c], hi[c], w.l[i], t.l[j]);
+            }
+        }
+    }
+};
+
+// x = sum_c col[c] * 2^(32c) as 17 limbs, then 9-word Montgomery reduction: returns x * 2^-288 mod r, canonical
+__device__ __forceinline__ Fr wide_reduce(const uint64_t (&lo)[15], const uint32_t (&hi)[15]) {
+    uint32_t x[18];
+    uint64_t carry = 0;     // running value above the current limb (< 2^64 + small)
+    uint32_t carry_hi = 0;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) {
+        // add column c (96 bits) at limb c to the running carry (carry: 64 bit + carry_hi: 32 bit)
+        uint64_t s = carry + lo[c];
+        uint32_t ov = s < carry ? 1u : 0u;
+        x[c] = (uint32_t)s;
+        carry = (s >> 32) | ((uint64_t)(carry_hi + hi[c] + ov) << 32);
+        carry_hi = 0;   // (carry_hi + hi[c] + ov) < 2^32: hi[c] counts at most 2^11 carries
+    }
+    x[15] = (uint32_t)carry;
+    x[16] = (uint32_t)(carry >> 32);
+    x[17] = 0;
+    // word-serial REDC, 9 words: after step i, limb i is zero
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const uint32_t m = FrParams::mul_inv(x[i]);
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint64_t s = (uint64_t)m * FrParams::p(j) + x[i + j] + c;
+            x[i + j] = (uint32_t)s;
+            c = s >> 32;
+        }
+#pragma unroll
+        for (int j = i + 8; j < 18; ++j) {
+            uint64_t s = (uint64_t)x[j] + c;
+            x[j] = (uint32_t)s;
+            c = s >> 32;
+        }
+    }
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = x[9 + i];
+    // x < 2^518  =>  x / 2^288 + r < 2r: one conditional subtraction (x[17] is zero)
+    r.reduce_once();
+    return r;
+}
+
+// out[j] = sum_{b < 2^k} w[b] * in[b*m + j], j < m.  Workgroup = 64 consecutive outputs x 4 term slices.
+// Also writes the workgroup's sum of outputs to partials[blockIdx.x] (block sums of the output table).
+static __global__ __launch_bounds__(MLE_BLOCK) void multifold_kernel(const uint64_t* __restrict__ in, size_t m, uint32_t k,
+                                                                     const uint64_t* __restrict__ weights,
+                                                                     uint64_t* __restrict__ out,
+                                                                     uint64_t* __restrict__ partials) {
+    __shared__ Fr w_lds[1 << MF_MAX_LOGK];
+    __shared__ uint32_t comb[(MF_SLICES - 1) * 45 * 64];
+    const uint32_t n_terms = 1u << k;
+    for (uint32_t b = threadIdx.x; b < n_terms; b += MLE_BLOCK) w_lds[b] = load_fr(weights, b);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t slice = threadIdx.x >> 6;
+    const uint32_t per = n_terms / MF_SLICES;                 // k >= 2
+    const size_t j = (size_t)blockIdx.x * MF_OUT_PER_WG + lane;
+    WideAcc acc;
+    acc.clear();
+    const uint32_t b0 = slice * per;
+    const uint64_t* p = in + 4 * ((size_t)b0 * m + j);
+    const size_t row = 4 * m;
+    for (uint32_t t = 0; t < per; t += 4) {                   // per is a multiple of 4 when k >= 4; guarded otherwise
+        Fr v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (t + u < per) v[u] = load_fr(p + (size_t)(t + u) * row, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (t + u < per) acc.mac(w_lds[b0 + t + u], v[u]);
+    }
+    // combine the slices' unreduced accumulators in wave 0
+    if (slice != 0) {
+        uint32_t* dst = comb + ((slice - 1) * 45) * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < 15; ++c) {
+            dst[(3 * c + 0) * 64] = (uint32_t)acc.lo[c];
+            dst[(3 * c + 1) * 64] = (uint32_t)(acc.lo[c] >> 32);
+            dst[(3 * c + 2) * 64] = acc.hi[c];
+        }
+    }
+    __syncthreads();
+    if (slice == 0) {
+#pragma unroll
+        for (int s = 0; s < MF_SLICES - 1; ++s) {
+            const uint32_t* src = comb + (s * 45) * 64 + lane;
+#pragma unroll
+            for (int c = 0; c < 15; ++c) {
+                const uint64_t l = (uint64_t)src[(3 * c + 0) * 64] | ((uint64_t)src[(3 * c + 1) * 64] << 32);
+                const uint64_t sum = acc.lo[c] + l;
+                acc.hi[c] += src[(3 * c + 2) * 64] + (sum < l ? 1u : 0u);
+                acc.lo[c] = sum;
+            }
+        }
+        Fr o = wide_reduce(acc.lo, acc.hi);
+        store_fr(out, j, o);
+        Fr s = wave_reduce_fr(o);
+        if (lane == 0) store_fr(partials, blockIdx.x, s);
+    }
+}
+
+}  // namespace zk

@@ -15,6 +15,7 @@
 #include "host_util.hpp"
 #include "mle_kernels.hpp"
 #include "sumcheck_kernels.hpp"
+#include "multifold_kernels.hpp"
 
 using namespace zk;
 
@@ -298,9 +299,59 @@ extern "C" int zkhip_mle_to_bytes(zkhip_ctx* c, const uint64_t* d_evals, size_t 
 // ---------------------------------------------------------------------------------------
 // basic sumcheck prover
 // ---------------------------------------------------------------------------------------
+// Stage plan of the prover: a table of cur_n > TAIL_N entries is folded by k variables at once, k chosen so
+// that tables up to 2^20 entries land exactly on the LDS tail and larger ones shrink 256-fold per pass.
+static inline uint32_t stage_k(size_t cur_n) {
+    if (cur_n <= (size_t)TAIL_N) return 0;
+    const uint32_t lg = log2_exact(cur_n);
+    uint32_t k = lg - TAIL_LOG;
+    if (k < 2) k = 2;
+    if (k > MF_MAX_LOGK) k = MF_MAX_LOGK;
+    return k;
+}
+extern "C" int zkhip_sumcheck_plan_log_blocks(size_t n) { return is_pow2(n) ? (int)stage_k(n) : 0; }
+
+static int launch_small(zkhip_ctx* c, const SmallArgs& a, SumcheckDev* st, uint64_t* d_rp, uint64_t* d_ch) {
+    const size_t lds = ((size_t)1 << a.log_n) * sizeof(Fr) + SMALL_LDS_FIXED;
+    ZK_TRY(c->allow_big_lds((const void*)sumcheck_small_kernel, TAIL_N * sizeof(Fr) + SMALL_LDS_FIXED));
+    ProfScope ps(c, "sumcheck_small", 0.0);
+    hipLaunchKernelGGL(sumcheck_small_kernel, dim3(1), dim3(MLE_BLOCK), lds, c->stream, a, st, d_rp, d_ch);
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+// (2^log_blocks block sums, then the total) of a table, on the device
+extern "C" int zkhip_mle_block_sums(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint32_t log_blocks,
+                                    uint64_t* d_out, uint64_t* h_total) {
+    if (!c || !d_evals || !d_out) return ZKHIP_ERR_ARG;
+    if (!is_pow2(n) || log_blocks > MF_MAX_LOGK || ((size_t)1 << log_blocks) > n) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    const size_t m = n >> log_blocks;
+    const uint32_t chunk = (uint32_t)std::min<size_t>(m, 4096);
+    const size_t n_chunks = n / chunk;
+    uint64_t* d_partials;
+    if (n_chunks <= 8 * (size_t)ZK_MAX_PARTIALS) d_partials = c->small_u64(ZK_SMALL_PARTIALS);
+    else { ZK_TRY(c->reserve_ws(n_chunks * 32)); d_partials = (uint64_t*)c->d_ws; }
+    if (chunk >= (uint32_t)MLE_BLOCK) {
+        ProfScope ps(c, "chunk_sums", 32.0 * (double)n);
+        hipLaunchKernelGGL(chunk_sums_kernel, dim3((unsigned)n_chunks), dim3(MLE_BLOCK), 0, c->stream, d_evals, chunk, d_partials);
+        hipLaunchKernelGGL(group_sums_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_partials, (uint32_t)(m / chunk),
+                           1u << log_blocks, d_out);
+    } else {   // tiny table: every entry is its own partial
+        hipLaunchKernelGGL(group_sums_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_evals, (uint32_t)m, 1u << log_blocks, d_out);
+    }
+    ZK_HIP(c, hipGetLastError());
+    if (h_total) {
+        ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_out + 4 * ((size_t)1 << log_blocks), 32, hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(c, hipStreamSynchronize(c->stream));
+        std::memcpy(h_total, c->pinned_u64(ZK_PIN_RES), 32);
+    }
+    return ZKHIP_OK;
+}
+
 extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_claimed_sum,
-                                    const uint64_t* h_first_half_sums, uint64_t* h_sum, uint64_t* h_round_polys,
-                                    uint64_t* h_challenges) {
+                                    const uint64_t* d_block_sums, uint32_t log_blocks, uint64_t* h_sum,
+                                    uint64_t* h_round_polys, uint64_t* h_challenges) {
     if (!c || !d_evals || !h_sum) return ZKHIP_ERR_ARG;
     if (!is_pow2(n)) return ZKHIP_ERR_SHAPE;   // Multilinear::new evaluation_form.rs:16-20
     const uint32_t n_vars = log2_exact(n);
@@ -314,51 +365,70 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
         std::memcpy(h_sum, c->pinned_u64(ZK_PIN_RES), 32);
         return ZKHIP_OK;
     }
-    ZK_TRY(c->reserve_ws((n / 2 + n / 4 + 8) * 32));
-    uint64_t* A = (uint64_t*)c->d_ws;
-    uint64_t* B = A + 4 * (n / 2);
+    // workspace: stage tables (n/4 + n/16 + ...), partial sums, fold weights
+    const size_t tab_entries = n / 4 + n / 16 + 64;
+    const size_t part_entries = std::max<size_t>(n / 4096, n / 256) + 64;   // chunk sums of stage 0, per-workgroup sums of stage outputs
+    const size_t w_entries = (size_t)1 << MF_MAX_LOGK;
+    ZK_TRY(c->reserve_ws((tab_entries + 2 * part_entries + w_entries) * 32));
+    uint64_t* tabA = (uint64_t*)c->d_ws;
+    uint64_t* tabB = tabA + 4 * (n / 4 + 32);
+    uint64_t* partA = (uint64_t*)c->d_ws + 4 * tab_entries;
+    uint64_t* partB = partA + 4 * part_entries;
+    uint64_t* d_w = partB + 4 * part_entries;
     SumcheckDev* st = (SumcheckDev*)c->small_u64(ZK_SMALL_STATE);
-    uint64_t* d_partials = c->small_u64(ZK_SMALL_PARTIALS);
     uint64_t* d_rp = c->small_u64(ZK_SMALL_ROUNDPOLYS);
     uint64_t* d_ch = c->small_u64(ZK_SMALL_CHALLENGES);
     uint64_t* d_fin = c->small_u64(ZK_SMALL_RES);
 
+    FrArg claimed = {};
+    uint32_t first = 1;
+    if (h_claimed_sum) { std::memcpy(claimed.v, h_claimed_sum, 32); first = 2; }   // prove(&self) absorbs self.sum (sumcheck.rs:33-35)
+
     const uint64_t* cur = d_evals;
     size_t cn = n;
-    uint32_t round = 0, first = 1, np = 0, have_hs = 0;
-    FrArg claimed = {}, hs_lo = {}, hs_hi = {};
-    if (h_claimed_sum) {   // prove(&self) absorbs self.sum, whatever the caller put there (sumcheck.rs:33-35)
-        std::memcpy(claimed.v, h_claimed_sum, 32);
-        first = 2;
-    }
-    if (cn > (size_t)TAIL_N) {
-        if (h_first_half_sums) {   // poly_sum() already streamed the table once: reuse its two half sums
-            std::memcpy(hs_lo.v, h_first_half_sums, 32);
-            std::memcpy(hs_hi.v, h_first_half_sums + 4, 32);
-            have_hs = 1;
+    uint32_t round = 0, stage = 0;
+    const uint64_t* parts = nullptr;   // partial sums of `cur`, `group` consecutive ones per block of this stage
+    uint32_t n_parts = 0;
+    while (cn > (size_t)TAIL_N) {
+        const uint32_t k = stage_k(cn);
+        const size_t m = cn >> k;
+        SmallArgs a = {};
+        if (stage == 0 && d_block_sums && log_blocks >= k) {            // poly_sum() already streamed the table once
+            a.src = d_block_sums;
+            a.group = 1u << (log_blocks - k);
+        } else if (stage == 0) {
+            const uint32_t chunk = 4096;                                // m >= 4096 here
+            ProfScope ps(c, "chunk_sums", 32.0 * (double)cn);
+            hipLaunchKernelGGL(chunk_sums_kernel, dim3((unsigned)(cn / chunk)), dim3(MLE_BLOCK), 0, c->stream, cur, chunk, partA);
+            a.src = partA;
+            a.group = (uint32_t)(m / chunk);
         } else {
-            const int grid = mle_grid((cn + 1) / 2);
-            ProfScope ps(c, "half_sums", 32.0 * (double)cn);
-            hipLaunchKernelGGL(half_sums_kernel, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, cur, cn, d_partials);
-            np = (uint32_t)grid;
+            a.src = parts;
+            a.group = (uint32_t)(n_parts >> k);
         }
-        while (cn > (size_t)TAIL_N) {
-            hipLaunchKernelGGL(sumcheck_round_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_partials, np, st, round,
-                               first, claimed, have_hs, hs_lo, hs_hi, d_rp, d_ch);
-            first = 0;
-            have_hs = 0;
-            uint64_t* dst = (round & 1) ? B : A;
-            const bool next_is_tail = (cn / 2) <= (size_t)TAIL_N;
-            ZK_TRY(launch_fold(c, cur, cn, d_ch + 4 * round, nullptr, 0, dst, !next_is_tail, d_partials, &np));
-            cur = dst;
-            cn /= 2;
-            ++round;
+        a.log_n = k; a.n_rounds = k; a.round0 = round; a.first = first; a.claimed = claimed;
+        a.weights_out = d_w; a.final_out = nullptr;
+        ZK_TRY(launch_small(c, a, st, d_rp, d_ch));
+        first = 0;
+        uint64_t* dst = (stage & 1) ? tabB : tabA;
+        uint64_t* pdst = (stage & 1) ? partB : partA;
+        {
+            ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m);
+            hipLaunchKernelGGL(multifold_kernel, dim3((unsigned)(m / MF_OUT_PER_WG)), dim3(MLE_BLOCK), 0, c->stream, cur, m, k, d_w, dst, pdst);
         }
+        parts = pdst;
+        n_parts = (uint32_t)(m / MF_OUT_PER_WG);
+        cur = dst;
+        cn = m;
+        round += k;
+        ++stage;
     }
-    ZK_TRY(c->allow_big_lds((const void*)sumcheck_tail_kernel, TAIL_LDS_BYTES));
-    hipLaunchKernelGGL(sumcheck_tail_kernel, dim3(1), dim3(MLE_BLOCK), TAIL_LDS_BYTES, c->stream, cur, (uint32_t)cn, st, round, first,
-                       claimed, d_rp, d_ch, d_fin);
-    ZK_HIP(c, hipGetLastError());
+    {
+        SmallArgs a = {};
+        a.src = cur; a.group = 0; a.log_n = log2_exact(cn); a.n_rounds = a.log_n; a.round0 = round; a.first = first;
+        a.claimed = claimed; a.weights_out = nullptr; a.final_out = d_fin;
+        ZK_TRY(launch_small(c, a, st, d_rp, d_ch));
+    }
     // results -> host
     uint64_t* pin = c->pinned_u64(ZK_PIN_PROOF);
     ZK_HIP(c, hipMemcpyAsync(pin, st->sum, 32, hipMemcpyDeviceToHost, c->stream));
@@ -370,7 +440,6 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
     std::memcpy(h_challenges, pin + 4 + 8 * ZK_MAX_ROUNDS, 32 * (size_t)n_vars);
     return ZKHIP_OK;
 }
-
 
 // ---------------------------------------------------------------------------------------
 // split-phase prover for a table sharded over several GPUs

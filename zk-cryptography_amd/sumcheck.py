@@ -28,17 +28,24 @@ class Sumcheck:
         """Sumcheck::new (sumcheck.rs:18-23)"""
         self.poly = poly if isinstance(poly, Multilinear) else Multilinear(poly)
         self.sum = np.zeros(4, dtype=np.uint64)   # Default::default()
-        self._half_sums = None
+        self._block_sums = None                    # device tensor kept by poly_sum() for prove()
+        self._log_blocks = 0
 
     def poly_sum(self):
-        """sumcheck.rs:25-27.  One streaming pass; the two half sums it produces on the way are kept
-        so that prove() does not re-read the table for its first round polynomial."""
-        if len(self.poly) == 1:
+        """sumcheck.rs:25-27.  One streaming pass; the block sums it produces on the way stay on the device so that
+        prove() does not re-read the table for its first rounds."""
+        import torch
+        n = len(self.poly)
+        if n == 1:
             self.sum = self.poly.to_numpy()[0].copy()
             return
-        hs = self.poly._half_sums()
-        self._half_sums = np.ascontiguousarray(hs[:2])
-        self.sum = hs[2].copy()
+        lb = N.lib().zkhip_sumcheck_plan_log_blocks(C.c_size_t(n))
+        buf = torch.empty(((1 << lb) + 1, 4), dtype=torch.int64, device=self.poly.evaluations.device)
+        tot = np.empty(4, dtype=np.uint64)
+        N.check(N.lib().zkhip_mle_block_sums(self.poly._ctx.handle, N.ptr(self.poly.evaluations), C.c_size_t(n),
+                                             C.c_uint32(lb), N.ptr(buf), tot.ctypes.data_as(C.c_void_p)), "block_sums")
+        self._block_sums, self._log_blocks = (buf, lb) if lb else (None, 0)
+        self.sum = tot
 
     def prove(self):
         """sumcheck.rs:29-61 -> (SumcheckProof, challenges uint64 [n_vars, 4]).
@@ -52,8 +59,8 @@ class Sumcheck:
         st = N.lib().zkhip_sumcheck_prove(self.poly._ctx.handle, N.ptr(self.poly.evaluations),
                                           C.c_size_t(len(self.poly)),
                                           np.ascontiguousarray(self.sum, dtype=np.uint64).ctypes.data_as(C.c_void_p),
-                                          self._half_sums.ctypes.data_as(C.c_void_p) if self._half_sums is not None else None,
-                                          s.ctypes.data_as(C.c_void_p),
+                                          N.ptr(self._block_sums) if self._block_sums is not None else None,
+                                          C.c_uint32(self._log_blocks), s.ctypes.data_as(C.c_void_p),
                                           rp.ctypes.data_as(C.c_void_p), ch.ctypes.data_as(C.c_void_p))
         N.check(st, "sumcheck_prove")
         return SumcheckProof(self.poly, s, rp[:nv]), ch[:nv]
