@@ -97,14 +97,16 @@ int zkhip_mle_block_sums(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, uint
                          uint64_t *h_total);
 /* Sumcheck::prove (sumcheck.rs:29-61).  Inputs:
  *   h_claimed_sum[4]  `self.sum` as the caller holds it (what poly_sum() stored, or the default zero): the
- *                     transcript absorbs exactly this.  NULL = absorb the true sum, computed on the device.
+ *                     transcript absorbs exactly this.  Alternatively d_claimed_sum[4]: the same value still on
+ *                     the device (zkhip_mle_block_sums leaves the total at d_out + 4 * 2^log_blocks), which spares
+ *                     poly_sum() a device->host round trip.  Both NULL = absorb the true sum, computed here.
  *   d_block_sums      optional device array from zkhip_mle_block_sums(.., log_blocks, ..); NULL = computed here.
  * Host outputs: h_sum[4] (the absorbed sum); h_round_polys[n_vars*2*4] (the Vec<Multilinear> of 2
  * evaluations each, :11-15); h_challenges[n_vars*4].  d_evals is not modified.
  * Internally k rounds of transcript run on 2^k block sums, then one k-variable fold pass follows
  * (csrc/multifold_kernels.hpp); the values are those of the round-by-round loop, bit for bit. */
 int zkhip_sumcheck_prove(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint64_t *h_claimed_sum,
-                         const uint64_t *d_block_sums, uint32_t log_blocks, uint64_t *h_sum,
+                         const uint64_t *d_claimed_sum, const uint64_t *d_block_sums, uint32_t log_blocks, uint64_t *h_sum,
                          uint64_t *h_round_polys, uint64_t *h_challenges);
 
 /* ---- the same prover, split per phase, for a table SHARDED over several GPUs ---------------------

@@ -239,6 +239,12 @@ __device__ __forceinline__ Fr shfl_down_fr(const Fr& v, int delta) {
     for (int i = 0; i < Fr::N; ++i) r.l[i] = __shfl_down(v.l[i], delta, 64);
     return r;
 }
+__device__ __forceinline__ Fr shfl_fr(const Fr& v, int src_lane) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < Fr::N; ++i) r.l[i] = __shfl(v.l[i], src_lane, 64);
+    return r;
+}
 __device__ __forceinline__ Fr wave_reduce_fr(Fr v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = v + shfl_down_fr(v, d);

@@ -22,7 +22,6 @@
 namespace zk {
 
 constexpr int MF_MAX_LOGK = 8;
-constexpr int MF_SLICES = 4;          // waves of a workgroup split the 2^k terms of the same 64 outputs
 constexpr int MF_OUT_PER_WG = 64;
 
 // per-workgroup sum of a contiguous chunk of `chunk` entries (chunk a power of two, >= MLE_BLOCK)
@@ -57,106 +56,144 @@ static __global__ __launch_bounds__(MLE_BLOCK) void group_sums_kernel(const uint
     if (threadIdx.x == 0) store_fr(out, n_blocks, tot);
 }
 
+constexpr int TREE_MAX_LOG = 10;   // the serial kernel keeps tables of up to 2^10 entries (and their sum trees) in LDS
+
 struct SmallArgs {
-    const uint64_t* src;    // mode 0: the table itself (2^log_n entries); mode 1: partial sums, `group` per block
+    const uint64_t* src;    // mode 0: the table itself (2^log_n entries); mode 1: partial sums, `group` per entry
     uint32_t group;         // mode 1: consecutive partials per table entry (0 = mode 0)
-    uint32_t log_n;         // working table has 2^log_n entries (<= TAIL_N)
+    uint32_t log_n;         // working table has 2^log_n entries (<= 2^TREE_MAX_LOG)
     uint32_t n_rounds;      // rounds to run, <= log_n
     uint32_t round0;        // index of the first round run here
-    uint32_t first;         // 0 continue; 1 start the transcript, sum = lo + hi; 2 start it, sum = claimed
+    uint32_t first;         // 0 continue; 1 start the transcript, sum = lo + hi; 2 sum = claimed; 3 sum = *d_claimed
     FrArg claimed;
+    const uint64_t* d_claimed;
     uint64_t* weights_out;  // nullable: 2^n_rounds fold weights eq_b(r) * 2^32 (Montgomery form)
     uint64_t* final_out;    // nullable: the table left after n_rounds folds
 };
 
-// n_rounds sumcheck rounds (half sums -> transcript -> challenge -> fold, sumcheck.rs:40-51) of a table that
-// lives in LDS, optionally recording the weights of the equivalent k-variable fold.
+// n_rounds sumcheck rounds (half sums -> transcript -> challenge -> fold, sumcheck.rs:40-51) of a small table.
+//
+// The table sits in LDS together with its SUM TREE (node q = 2^l + b holds the sum of block b when the table is
+// cut into 2^l blocks; the leaves are the table).  Folding the table at variable 0 folds every level the same way:
+//     new[q] = old[q + p] + r * (old[q + 2p] - old[q + p]),  p = largest power of two <= q,
+// so after a fold the next round polynomial (lo, hi) = new[2], new[3] is available WITHOUT a reduction, and every
+// node is independent work.  Wave 0 runs nothing but the transcript chain (the critical path) plus the two
+// products that give it the next (lo, hi); waves 1-3 fold the rest of the tree (and the k-variable fold weights)
+// behind it.  One barrier per round; the trees and the challenge slot are double-buffered.
 static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallArgs a, SumcheckDev* st,
                                                                           uint64_t* __restrict__ round_polys,
                                                                           uint64_t* __restrict__ challenges) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
-    Fr* tab = reinterpret_cast<Fr*>(zk_dyn_lds);        // 2^log_n entries
     const uint32_t n = 1u << a.log_n;
-    Fr* wa = tab + n;                                   // weights, ping
-    Fr* wb = wa + (1u << MF_MAX_LOGK);                  // weights, pong
-    Fr* red = wb + (1u << MF_MAX_LOGK);                 // 2 * MLE_BLOCK / 64
-    Fr* conv = red + 2 * MLE_BLOCK / 64;                // 4
-    Fr* r_shp = conv + 4;                               // 1
-    for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) {
-        if (a.group == 0) {
-            tab[j] = load_fr(a.src, j);
-        } else {
+    Fr* tree0 = reinterpret_cast<Fr*>(zk_dyn_lds);      // 2n nodes each
+    Fr* tree1 = tree0 + 2 * n;
+    Fr* w0 = tree1 + 2 * n;                             // weights, ping / pong
+    Fr* w1 = w0 + (1u << MF_MAX_LOGK);
+    Fr* scratch = w1 + (1u << MF_MAX_LOGK);             // MLE_BLOCK
+    Fr* conv = scratch + MLE_BLOCK;                     // 4
+    Fr* r_sh = conv + 4;                                // 2
+    // ---- leaves
+    if (a.group == 0) {
+        for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) tree0[n + j] = load_fr(a.src, j);
+    } else {
+        const uint32_t total = n * a.group;
+        const uint32_t run = total > (uint32_t)MLE_BLOCK ? total / MLE_BLOCK : 1;   // consecutive partials per thread
+        if (threadIdx.x * run < total) {
             Fr s = Fr::zero();
-            for (uint32_t g = 0; g < a.group; ++g) s = s + load_fr(a.src, (size_t)j * a.group + g);
-            tab[j] = s;
+            for (uint32_t g = 0; g < run; ++g) s = s + load_fr(a.src, (size_t)threadIdx.x * run + g);
+            scratch[threadIdx.x] = s;
+        }
+        __syncthreads();
+        const uint32_t tpe = a.group / run;   // scratch slots per entry (run <= group because n <= MLE_BLOCK in this mode)
+        for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) {
+            Fr s = scratch[j * tpe];
+            for (uint32_t g = 1; g < tpe; ++g) s = s + scratch[j * tpe + g];
+            tree0[n + j] = s;
         }
     }
     if (threadIdx.x == 0 && a.weights_out) {
-        Fr w0;   // Montgomery form of 2^32: the k-variable fold reduces with 9 words instead of 8
+        Fr one32;   // Montgomery form of 2^32: the k-variable fold reduces with 9 words instead of 8
         constexpr uint32_t c[8] = {0xcaaf6b13u, 0x355094eau, 0x69a568efu, 0xf6b10cb3u, 0x40cc3869u, 0xe2c926a6u, 0xed269aadu, 0x736a6d3bu};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) w0.l[i] = c[i];
-        wa[0] = w0;
+        for (int i = 0; i < 8; ++i) one32.l[i] = c[i];
+        w0[0] = one32;
     }
     __syncthreads();
-    Transcript tr;
-    if (threadIdx.x < 64 && !a.first) tr.load(&st->transcript);
-    uint32_t cur = n, round = a.round0, n_w = 1;
-    for (uint32_t it = 0; it < a.n_rounds; ++it) {
-        const uint32_t half = cur >> 1;
-        Fr lo = Fr::zero(), hi = Fr::zero();
-        for (uint32_t j = threadIdx.x; j < half; j += MLE_BLOCK) {
-            lo = lo + tab[j];
-            hi = hi + tab[j + half];
-        }
-        block_reduce_fr2(lo, hi, red);
-        if (threadIdx.x == 0) { conv[1] = lo; conv[2] = hi; }
+    // ---- inner levels, bottom up
+    for (uint32_t lvl = a.log_n; lvl-- > 1;) {
+        const uint32_t cnt = 1u << lvl;
+        for (uint32_t b = threadIdx.x; b < cnt; b += MLE_BLOCK) tree0[cnt + b] = tree0[2 * cnt + 2 * b] + tree0[2 * cnt + 2 * b + 1];
         __syncthreads();
-        if (threadIdx.x < 64) {   // wave 0, uniform
-            lo = conv[1];
-            hi = conv[2];
+    }
+    const bool wave0 = threadIdx.x < 64;
+    Transcript tr;
+    if (wave0 && !a.first) tr.load(&st->transcript);
+    Fr lo = tree0[2], hi = tree0[3];
+    uint32_t depth = a.log_n, round = a.round0, n_w = 1;
+    for (uint32_t it = 0; it < a.n_rounds; ++it) {
+        Fr* told = (it & 1) ? tree1 : tree0;
+        Fr* tnew = (it & 1) ? tree0 : tree1;
+        Fr* wold = (it & 1) ? w1 : w0;
+        Fr* wnew = (it & 1) ? w0 : w1;
+        if (wave0) {
             const bool absorb_sum = a.first && it == 0;
             Fr sum = Fr::zero();
             if (absorb_sum) {
-                sum = (a.first == 2) ? fr_from_arg(a.claimed) : lo + hi;
+                sum = (a.first == 2) ? fr_from_arg(a.claimed) : (a.first == 3) ? load_fr(a.d_claimed, 0) : lo + hi;
                 tr.init();
             }
             Fr r = transcript_round(tr, conv, sum, lo, hi, absorb_sum);
             if (threadIdx.x == 0) {
                 if (absorb_sum) store_fr(st->sum, 0, sum);
-                *r_shp = r;
+                r_sh[it & 1] = r;
                 store_fr(round_polys, 2 * (size_t)round, lo);
                 store_fr(round_polys, 2 * (size_t)round + 1, hi);
                 store_fr(challenges, round, r);
             }
         }
-        __syncthreads();
-        const Fr r = *r_shp;
-        // in place: lane j reads (j, j+half) and writes j; no other lane touches index j this round
-        for (uint32_t j = threadIdx.x; j < half; j += MLE_BLOCK) tab[j] = fold_pair(tab[j], tab[j + half], r);
-        if (a.weights_out) {   // eq weights: index gains the new variable as its least significant bit
-            Fr* src = (it & 1) ? wb : wa;
-            Fr* dst = (it & 1) ? wa : wb;
-            for (uint32_t b = threadIdx.x; b < n_w; b += MLE_BLOCK) {
-                Fr w1 = src[b] * r;
-                dst[2 * b + 1] = w1;
-                dst[2 * b] = src[b] - w1;
+        __syncthreads();   // challenge published; tree `told` complete
+        const Fr r = r_sh[it & 1];
+        if (wave0) {
+            if (depth >= 2) {   // next round polynomial straight from level 2 of the old tree
+                const uint32_t q = 2 + (threadIdx.x & 1);
+                Fr v = fold_pair(told[q + 2], told[q + 4], r);
+                lo = shfl_fr(v, 0);
+                hi = shfl_fr(v, 1);
             }
-            n_w <<= 1;
+        } else {
+            const uint32_t helper = threadIdx.x - 64, n_helpers = MLE_BLOCK - 64;
+            const uint32_t nodes = 1u << (depth - 1);   // new tree has nodes 1 .. 2^(depth-1+1)-1 = 2*nodes - 1
+            for (uint32_t q = 1 + helper; q < 2 * nodes; q += n_helpers) {
+                const uint32_t p = 1u << (31 - __builtin_clz(q));
+                tnew[q] = fold_pair(told[q + p], told[q + 2 * p], r);
+            }
+            if (a.weights_out) {   // eq weights: the index gains the new variable as its least significant bit
+                for (uint32_t b = helper; b < n_w; b += n_helpers) {
+                    Fr w1v = wold[b] * r;
+                    wnew[2 * b + 1] = w1v;
+                    wnew[2 * b] = wold[b] - w1v;
+                }
+            }
         }
-        __syncthreads();
-        cur = half;
+        n_w <<= 1;
+        --depth;
         ++round;
     }
+    __syncthreads();
     if (threadIdx.x == 0) tr.store(&st->transcript);
     if (a.weights_out) {
-        Fr* w = (a.n_rounds & 1) ? wb : wa;
+        Fr* w = (a.n_rounds & 1) ? w1 : w0;
         for (uint32_t b = threadIdx.x; b < n_w; b += MLE_BLOCK) store_fr(a.weights_out, b, w[b]);
     }
-    if (a.final_out)
-        for (uint32_t j = threadIdx.x; j < cur; j += MLE_BLOCK) store_fr(a.final_out, j, tab[j]);
+    if (a.final_out) {
+        Fr* t = (a.n_rounds & 1) ? tree1 : tree0;
+        const uint32_t cnt = 1u << depth;
+        for (uint32_t j = threadIdx.x; j < cnt; j += MLE_BLOCK) store_fr(a.final_out, j, t[cnt + j]);
+    }
 }
-constexpr size_t SMALL_LDS_FIXED = (size_t)(2 * (1 << MF_MAX_LOGK) + 2 * MLE_BLOCK / 64 + 4 + 1) * sizeof(Fr);
+__host__ __device__ constexpr size_t small_lds_bytes(uint32_t log_n) {
+    return ((size_t)4 * ((size_t)1 << log_n) + 2 * (1u << MF_MAX_LOGK) + MLE_BLOCK + 4 + 2) * 32;
+}
 
 // ---- the k-variable fold -------------------------------------------------------------------------------
 // Unreduced accumulator: column c collects every limb product w[i]*t[j] with i + j = c.
@@ -222,57 +259,41 @@ __device__ __forceinline__ Fr wide_reduce(const uint64_t (&lo)[15], const uint32
     return r;
 }
 
-// out[j] = sum_{b < 2^k} w[b] * in[b*m + j], j < m.  Workgroup = 64 consecutive outputs x 4 term slices.
+// out[j] = sum_{b < 2^k} w[b] * in[b*m + j], j < m.  A workgroup owns 64 consecutive outputs; its S = blockDim/64
+// waves split the 2^k terms.  Every wave reduces its own unreduced partial sum (the weights' 2^32 factor makes
+// each 9-word REDC a proper Montgomery residue, so the partial results simply add), wave 0 adds the S residues.
 // Also writes the workgroup's sum of outputs to partials[blockIdx.x] (block sums of the output table).
-static __global__ __launch_bounds__(MLE_BLOCK) void multifold_kernel(const uint64_t* __restrict__ in, size_t m, uint32_t k,
-                                                                     const uint64_t* __restrict__ weights,
-                                                                     uint64_t* __restrict__ out,
-                                                                     uint64_t* __restrict__ partials) {
+static __global__ __launch_bounds__(1024) void multifold_kernel(const uint64_t* __restrict__ in, size_t m, uint32_t k,
+                                                                const uint64_t* __restrict__ weights,
+                                                                uint64_t* __restrict__ out,
+                                                                uint64_t* __restrict__ partials) {
     __shared__ Fr w_lds[1 << MF_MAX_LOGK];
-    __shared__ uint32_t comb[(MF_SLICES - 1) * 45 * 64];
+    __shared__ Fr part[16 * 64];
     const uint32_t n_terms = 1u << k;
-    for (uint32_t b = threadIdx.x; b < n_terms; b += MLE_BLOCK) w_lds[b] = load_fr(weights, b);
+    for (uint32_t b = threadIdx.x; b < n_terms; b += blockDim.x) w_lds[b] = load_fr(weights, b);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t slice = threadIdx.x >> 6;
-    const uint32_t per = n_terms / MF_SLICES;                 // k >= 2
+    const uint32_t n_slices = blockDim.x >> 6;
+    const uint32_t per = n_terms / n_slices;                  // host guarantees n_slices <= n_terms
     const size_t j = (size_t)blockIdx.x * MF_OUT_PER_WG + lane;
     WideAcc acc;
     acc.clear();
     const uint32_t b0 = slice * per;
     const uint64_t* p = in + 4 * ((size_t)b0 * m + j);
     const size_t row = 4 * m;
-    for (uint32_t t = 0; t < per; t += 4) {                   // per is a multiple of 4 when k >= 4; guarded otherwise
+    for (uint32_t t = 0; t < per; t += 4) {
         Fr v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) if (t + u < per) v[u] = load_fr(p + (size_t)(t + u) * row, 0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) if (t + u < per) acc.mac(w_lds[b0 + t + u], v[u]);
     }
-    // combine the slices' unreduced accumulators in wave 0
-    if (slice != 0) {
-        uint32_t* dst = comb + ((slice - 1) * 45) * 64 + lane;
-#pragma unroll
-        for (int c = 0; c < 15; ++c) {
-            dst[(3 * c + 0) * 64] = (uint32_t)acc.lo[c];
-            dst[(3 * c + 1) * 64] = (uint32_t)(acc.lo[c] >> 32);
-            dst[(3 * c + 2) * 64] = acc.hi[c];
-        }
-    }
+    Fr o = wide_reduce(acc.lo, acc.hi);
+    if (slice != 0) part[(slice - 1) * 64 + lane] = o;
     __syncthreads();
     if (slice == 0) {
-#pragma unroll
-        for (int s = 0; s < MF_SLICES - 1; ++s) {
-            const uint32_t* src = comb + (s * 45) * 64 + lane;
-#pragma unroll
-            for (int c = 0; c < 15; ++c) {
-                const uint64_t l = (uint64_t)src[(3 * c + 0) * 64] | ((uint64_t)src[(3 * c + 1) * 64] << 32);
-                const uint64_t sum = acc.lo[c] + l;
-                acc.hi[c] += src[(3 * c + 2) * 64] + (sum < l ? 1u : 0u);
-                acc.lo[c] = sum;
-            }
-        }
-        Fr o = wide_reduce(acc.lo, acc.hi);
+        for (uint32_t s2 = 1; s2 < n_slices; ++s2) o = o + part[(s2 - 1) * 64 + lane];
         store_fr(out, j, o);
         Fr s = wave_reduce_fr(o);
         if (lane == 0) store_fr(partials, blockIdx.x, s);

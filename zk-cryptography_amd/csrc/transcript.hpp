@@ -84,10 +84,32 @@ __device__ __noinline__ void sha256_compress(uint32_t (&h)[8], const uint32_t (&
 
 // Out-of-line Montgomery product for the single-wave control paths (keeps those kernels small).
 __device__ __noinline__ Fr fr_mul_outlined(const Fr& a, const Fr& b) { return a * b; }
-__device__ __forceinline__ Fr fr_from_mont_outlined(const Fr& a) {
-    Fr o = Fr::zero();
-    o.l[0] = 1;
-    return fr_mul_outlined(a, o);
+// Montgomery form -> canonical integer (into_bigint): the reduction half of a product only (x * 1 has no
+// multiplication part): 8 words of word-serial REDC, 64 mads instead of 128.
+__device__ __noinline__ Fr fr_from_mont_outlined(const Fr& a) {
+    uint32_t x[9];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = a.l[i];
+    x[8] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t m = FrParams::mul_inv(x[0]);
+        uint64_t c = ((uint64_t)m * FrParams::p(0) + x[0]) >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            uint64_t s = (uint64_t)m * FrParams::p(j) + x[j] + c;
+            x[j - 1] = (uint32_t)s;
+            c = s >> 32;
+        }
+        uint64_t s = (uint64_t)x[8] + c;
+        x[7] = (uint32_t)s;
+        x[8] = (uint32_t)(s >> 32);
+    }
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = x[i];
+    r.reduce_once();   // a < r  =>  result < r already; kept for inputs up to 2r
+    return r;
 }
 __device__ __forceinline__ Fr fr_to_mont_outlined(const Fr& a) {
     Fr r2;

@@ -302,18 +302,17 @@ extern "C" int zkhip_mle_to_bytes(zkhip_ctx* c, const uint64_t* d_evals, size_t 
 // Stage plan of the prover: a table of cur_n > TAIL_N entries is folded by k variables at once, k chosen so
 // that tables up to 2^20 entries land exactly on the LDS tail and larger ones shrink 256-fold per pass.
 static inline uint32_t stage_k(size_t cur_n) {
-    if (cur_n <= (size_t)TAIL_N) return 0;
+    if (cur_n <= ((size_t)1 << TREE_MAX_LOG)) return 0;      // finishes inside the serial kernel
     const uint32_t lg = log2_exact(cur_n);
-    uint32_t k = lg - TAIL_LOG;
-    if (k < 2) k = 2;
+    uint32_t k = lg - 8;                                       // aim at a 2^8-entry table (1 fold product per helper lane)
     if (k > MF_MAX_LOGK) k = MF_MAX_LOGK;
-    return k;
+    return k;                                                  // >= 3 here
 }
 extern "C" int zkhip_sumcheck_plan_log_blocks(size_t n) { return is_pow2(n) ? (int)stage_k(n) : 0; }
 
 static int launch_small(zkhip_ctx* c, const SmallArgs& a, SumcheckDev* st, uint64_t* d_rp, uint64_t* d_ch) {
-    const size_t lds = ((size_t)1 << a.log_n) * sizeof(Fr) + SMALL_LDS_FIXED;
-    ZK_TRY(c->allow_big_lds((const void*)sumcheck_small_kernel, TAIL_N * sizeof(Fr) + SMALL_LDS_FIXED));
+    const size_t lds = small_lds_bytes(a.log_n);
+    ZK_TRY(c->allow_big_lds((const void*)sumcheck_small_kernel, small_lds_bytes(TREE_MAX_LOG)));
     ProfScope ps(c, "sumcheck_small", 0.0);
     hipLaunchKernelGGL(sumcheck_small_kernel, dim3(1), dim3(MLE_BLOCK), lds, c->stream, a, st, d_rp, d_ch);
     ZK_HIP(c, hipGetLastError());
@@ -350,7 +349,8 @@ extern "C" int zkhip_mle_block_sums(zkhip_ctx* c, const uint64_t* d_evals, size_
 }
 
 extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_claimed_sum,
-                                    const uint64_t* d_block_sums, uint32_t log_blocks, uint64_t* h_sum,
+                                    const uint64_t* d_claimed_sum, const uint64_t* d_block_sums, uint32_t log_blocks,
+                                    uint64_t* h_sum,
                                     uint64_t* h_round_polys, uint64_t* h_challenges) {
     if (!c || !d_evals || !h_sum) return ZKHIP_ERR_ARG;
     if (!is_pow2(n)) return ZKHIP_ERR_SHAPE;   // Multilinear::new evaluation_form.rs:16-20
@@ -360,7 +360,7 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
     ZK_TRY(c->activate());
     if (n == 1) {   // no rounds: nothing is proven; report the sum the transcript would have absorbed
         if (h_claimed_sum) { std::memcpy(h_sum, h_claimed_sum, 32); return ZKHIP_OK; }
-        ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_evals, 32, hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_claimed_sum ? d_claimed_sum : d_evals, 32, hipMemcpyDeviceToHost, c->stream));
         ZK_HIP(c, hipStreamSynchronize(c->stream));
         std::memcpy(h_sum, c->pinned_u64(ZK_PIN_RES), 32);
         return ZKHIP_OK;
@@ -383,13 +383,14 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
     FrArg claimed = {};
     uint32_t first = 1;
     if (h_claimed_sum) { std::memcpy(claimed.v, h_claimed_sum, 32); first = 2; }   // prove(&self) absorbs self.sum (sumcheck.rs:33-35)
+    else if (d_claimed_sum) first = 3;
 
     const uint64_t* cur = d_evals;
     size_t cn = n;
     uint32_t round = 0, stage = 0;
     const uint64_t* parts = nullptr;   // partial sums of `cur`, `group` consecutive ones per block of this stage
     uint32_t n_parts = 0;
-    while (cn > (size_t)TAIL_N) {
+    while (stage_k(cn) != 0) {
         const uint32_t k = stage_k(cn);
         const size_t m = cn >> k;
         SmallArgs a = {};
@@ -397,7 +398,7 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
             a.src = d_block_sums;
             a.group = 1u << (log_blocks - k);
         } else if (stage == 0) {
-            const uint32_t chunk = 4096;                                // m >= 4096 here
+            const uint32_t chunk = (uint32_t)std::min<size_t>(m, 4096);   // m >= 256 here
             ProfScope ps(c, "chunk_sums", 32.0 * (double)cn);
             hipLaunchKernelGGL(chunk_sums_kernel, dim3((unsigned)(cn / chunk)), dim3(MLE_BLOCK), 0, c->stream, cur, chunk, partA);
             a.src = partA;
@@ -406,7 +407,7 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
             a.src = parts;
             a.group = (uint32_t)(n_parts >> k);
         }
-        a.log_n = k; a.n_rounds = k; a.round0 = round; a.first = first; a.claimed = claimed;
+        a.log_n = k; a.n_rounds = k; a.round0 = round; a.first = first; a.claimed = claimed; a.d_claimed = d_claimed_sum;
         a.weights_out = d_w; a.final_out = nullptr;
         ZK_TRY(launch_small(c, a, st, d_rp, d_ch));
         first = 0;
@@ -414,7 +415,10 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
         uint64_t* pdst = (stage & 1) ? partB : partA;
         {
             ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m);
-            hipLaunchKernelGGL(multifold_kernel, dim3((unsigned)(m / MF_OUT_PER_WG)), dim3(MLE_BLOCK), 0, c->stream, cur, m, k, d_w, dst, pdst);
+            // few outputs -> more waves per output so that the chip still sees >= 4 waves per SIMD on the CUs in use
+            uint32_t slices = (m / MF_OUT_PER_WG >= 512) ? 4 : 16;
+            if (slices > (1u << k)) slices = 1u << k;
+            hipLaunchKernelGGL(multifold_kernel, dim3((unsigned)(m / MF_OUT_PER_WG)), dim3(64 * slices), 0, c->stream, cur, m, k, d_w, dst, pdst);
         }
         parts = pdst;
         n_parts = (uint32_t)(m / MF_OUT_PER_WG);
@@ -426,7 +430,7 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
     {
         SmallArgs a = {};
         a.src = cur; a.group = 0; a.log_n = log2_exact(cn); a.n_rounds = a.log_n; a.round0 = round; a.first = first;
-        a.claimed = claimed; a.weights_out = nullptr; a.final_out = d_fin;
+        a.claimed = claimed; a.d_claimed = d_claimed_sum; a.weights_out = nullptr; a.final_out = d_fin;
         ZK_TRY(launch_small(c, a, st, d_rp, d_ch));
     }
     // results -> host

@@ -27,13 +27,28 @@ class Sumcheck:
     def __init__(self, poly):
         """Sumcheck::new (sumcheck.rs:18-23)"""
         self.poly = poly if isinstance(poly, Multilinear) else Multilinear(poly)
-        self.sum = np.zeros(4, dtype=np.uint64)   # Default::default()
+        self._sum_host = np.zeros(4, dtype=np.uint64)   # Default::default()
+        self._sum_dev = None                       # poly_sum() leaves the sum on the device until someone reads it
         self._block_sums = None                    # device tensor kept by poly_sum() for prove()
         self._log_blocks = 0
 
+    @property
+    def sum(self):
+        """`self.sum` (private in the reference, sumcheck.rs:7-10): fetched from the device on first read."""
+        if self._sum_dev is not None:
+            self._sum_host = self._sum_dev.cpu().numpy().view(np.uint64).reshape(4).copy()
+            self._sum_dev = None
+        return self._sum_host
+
+    @sum.setter
+    def sum(self, v):
+        self._sum_host = np.ascontiguousarray(v, dtype=np.uint64).reshape(4)
+        self._sum_dev = None
+
     def poly_sum(self):
-        """sumcheck.rs:25-27.  One streaming pass; the block sums it produces on the way stay on the device so that
-        prove() does not re-read the table for its first rounds."""
+        """sumcheck.rs:25-27.  One streaming pass, asynchronous: the sum and the block sums it produces on the way
+        stay on the device, so that prove() neither re-reads the table for its first rounds nor waits for a
+        device->host copy of the sum."""
         import torch
         n = len(self.poly)
         if n == 1:
@@ -41,11 +56,10 @@ class Sumcheck:
             return
         lb = N.lib().zkhip_sumcheck_plan_log_blocks(C.c_size_t(n))
         buf = torch.empty(((1 << lb) + 1, 4), dtype=torch.int64, device=self.poly.evaluations.device)
-        tot = np.empty(4, dtype=np.uint64)
         N.check(N.lib().zkhip_mle_block_sums(self.poly._ctx.handle, N.ptr(self.poly.evaluations), C.c_size_t(n),
-                                             C.c_uint32(lb), N.ptr(buf), tot.ctypes.data_as(C.c_void_p)), "block_sums")
+                                             C.c_uint32(lb), N.ptr(buf), None), "block_sums")
         self._block_sums, self._log_blocks = (buf, lb) if lb else (None, 0)
-        self.sum = tot
+        self._sum_dev = buf[1 << lb]
 
     def prove(self):
         """sumcheck.rs:29-61 -> (SumcheckProof, challenges uint64 [n_vars, 4]).
@@ -58,7 +72,8 @@ class Sumcheck:
         ch = np.empty((max(nv, 1), 4), dtype=np.uint64)
         st = N.lib().zkhip_sumcheck_prove(self.poly._ctx.handle, N.ptr(self.poly.evaluations),
                                           C.c_size_t(len(self.poly)),
-                                          np.ascontiguousarray(self.sum, dtype=np.uint64).ctypes.data_as(C.c_void_p),
+                                          None if self._sum_dev is not None else self._sum_host.ctypes.data_as(C.c_void_p),
+                                          N.ptr(self._sum_dev) if self._sum_dev is not None else None,
                                           N.ptr(self._block_sums) if self._block_sums is not None else None,
                                           C.c_uint32(self._log_blocks), s.ctypes.data_as(C.c_void_p),
                                           rp.ctypes.data_as(C.c_void_p), ch.ctypes.data_as(C.c_void_p))
