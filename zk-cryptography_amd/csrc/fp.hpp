@@ -35,6 +35,10 @@ __device__ __forceinline__ void mac96_s(uint64_t& lo, uint32_t& hi, uint32_t s_c
         : "vcc");
 }
 
+}  // namespace zk
+#include "fp_mul_gen.hpp"
+namespace zk {
+
 template <class P>
 struct Fp {
     static constexpr int N = P::N32;
@@ -119,6 +123,17 @@ struct Fp {
 
     // Montgomery product a*b*R^-1 mod p, product scanning.
     __device__ __forceinline__ friend Fp operator*(const Fp& a, const Fp& b) {
+        if constexpr (N == 8) {
+            Fp r;
+            mont_mul_unrolled_8<P>(r.l, a.l, b.l);
+            r.reduce_once();
+            return r;
+        } else if constexpr (N == 12) {
+            Fp r;
+            mont_mul_unrolled_12<P>(r.l, a.l, b.l);
+            r.reduce_once();
+            return r;
+        }
         uint32_t m[N];
         Fp r;
         uint64_t lo = 0;

@@ -56,7 +56,10 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     const size_t o_counts = 0;
     const size_t o_offsets = o_counts + al(n_buckets * 4);
     const size_t o_cursor = o_offsets + al(n_buckets * 4);
-    const size_t o_sorted = o_cursor + al(n_buckets * 4);
+    const size_t o_order = o_cursor + al(n_buckets * 4);
+    const size_t o_tiles = o_order + al(n_buckets * 4);
+    const size_t o_bins = o_tiles + al(((n_buckets + SCAN_TILE - 1) / SCAN_TILE) * 4);
+    const size_t o_sorted = o_bins + al(MSM_COUNT_BINS * 4);
     const size_t o_buckets = o_sorted + al(n * pl.n_windows * 4);
     const size_t o_segs = o_buckets + al(n_buckets * 192);
     const size_t o_sega = o_segs + al(n_segments * 192);
@@ -68,6 +71,9 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     uint32_t* offsets = (uint32_t*)(ws + o_offsets);
     uint32_t* cursor = (uint32_t*)(ws + o_cursor);
     uint32_t* sorted = (uint32_t*)(ws + o_sorted);
+    uint32_t* order = (uint32_t*)(ws + o_order);
+    uint32_t* tiles = (uint32_t*)(ws + o_tiles);
+    uint32_t* bins = (uint32_t*)(ws + o_bins);
     uint64_t* buckets = (uint64_t*)(ws + o_buckets);
     uint64_t* segs = (uint64_t*)(ws + o_segs);
     uint64_t* sega = (uint64_t*)(ws + o_sega);
@@ -79,7 +85,20 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
         ProfScope ps(c, "msm_hist", 32.0 * (double)n);
         hipLaunchKernelGGL(msm_hist_kernel, dim3(grid_n), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl, counts);
     }
-    hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, c->stream, counts, (uint32_t)n_buckets, offsets, cursor);
+    {
+        const uint32_t n_tiles = (uint32_t)((n_buckets + SCAN_TILE - 1) / SCAN_TILE);
+        if (n_tiles > 65536) return ZKHIP_ERR_SHAPE;
+        ProfScope ps(c, "msm_scan", 0.0);
+        hipLaunchKernelGGL(msm_scan_tiles_kernel, dim3(n_tiles), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, tiles);
+        hipLaunchKernelGGL(msm_scan_top_kernel, dim3(1), dim3(1024), 0, c->stream, tiles, n_tiles);
+        hipLaunchKernelGGL(msm_scan_finish_kernel, dim3(n_tiles), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, tiles, offsets, cursor);
+        // bucket order by descending point count
+        const unsigned gb = (unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK);
+        ZK_HIP(c, hipMemsetAsync(bins, 0, MSM_COUNT_BINS * 4, c->stream));
+        hipLaunchKernelGGL(msm_order_hist_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins);
+        hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bins);
+        hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins, order);
+    }
     {
         ProfScope ps(c, "msm_scatter", 32.0 * (double)n);
         hipLaunchKernelGGL(msm_scatter_kernel, dim3(grid_n), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl, cursor, sorted);
@@ -87,7 +106,7 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     {
         ProfScope ps(c, "msm_accumulate", 128.0 * (double)n);
         hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK)), dim3(MSM_BLOCK), 0,
-                           c->stream, d_points_xy, sorted, offsets, counts, (uint32_t)n_buckets, buckets);
+                           c->stream, d_points_xy, sorted, offsets, counts, order, (uint32_t)n_buckets, buckets);
     }
     {
         ProfScope ps(c, "msm_segment", 0.0);

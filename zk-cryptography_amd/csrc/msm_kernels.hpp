@@ -71,28 +71,109 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_hist_kernel(const uint64
     }
 }
 
-// pass 2: exclusive scan of `total` counters by ONE workgroup (total is at most a few hundred thousand)
-static __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ counts, uint32_t total,
-                                                        uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor) {
-    __shared__ uint32_t part[1024];
-    const uint32_t per = (total + 1023) / 1024;
-    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, total);
+// pass 2: exclusive scan of `total` counters in three small launches (tile sums, scan of the tile sums, tile scans)
+constexpr int SCAN_TILE = 1024;   // counters per workgroup (4 per lane)
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_scan_tiles_kernel(const uint32_t* __restrict__ counts, uint32_t total,
+                                                                          uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t red[MSM_BLOCK / 64];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
     uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; ++i) s += counts[i];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (base + u < total) s += counts[base + u];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// exclusive scan of n_tiles (<= 64 K) tile sums by one workgroup, in place
+static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t* __restrict__ tile_sums, uint32_t n_tiles) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n_tiles + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, n_tiles);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += tile_sums[i];
     part[threadIdx.x] = s;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
         uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
         __syncthreads();
         part[threadIdx.x] += v;
         __syncthreads();
     }
     uint32_t run = part[threadIdx.x] - s;
-    for (uint32_t i = lo; i < hi; ++i) {
-        offsets[i] = run;
-        cursor[i] = run;
-        run += counts[i];
+    for (uint32_t i = lo; i < hi; ++i) { uint32_t c = tile_sums[i]; tile_sums[i] = run; run += c; }
+}
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_scan_finish_kernel(const uint32_t* __restrict__ counts, uint32_t total,
+                                                                           const uint32_t* __restrict__ tile_offsets,
+                                                                           uint32_t* __restrict__ offsets,
+                                                                           uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t wsum[MSM_BLOCK / 64];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+    uint32_t c[4], s = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { c[u] = (base + u < total) ? counts[base + u] : 0; s += c[u]; }
+    // inclusive scan of the lanes' sums inside the wave, then across the 4 waves
+    uint32_t incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t v = __shfl_up(incl, d, 64); if ((int)(threadIdx.x & 63) >= d) incl += v; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) woff += wsum[w];
+    uint32_t run = tile_offsets[blockIdx.x] + woff + incl - s;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (base + u < total) { offsets[base + u] = run; cursor[base + u] = run; }
+        run += c[u];
     }
+}
+
+// Bucket processing order: buckets sorted by their point count, heaviest first, so that the 64 lanes of a wave
+// walk lists of (nearly) equal length.  Counting sort over the clamped count.
+constexpr uint32_t MSM_COUNT_BINS = 1024;
+// (counts cluster around their mean, so the bins are few and hot: aggregate in LDS, one global atomic per bin and workgroup)
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_order_hist_kernel(const uint32_t* __restrict__ counts, uint32_t n_buckets,
+                                                                          uint32_t* __restrict__ bins) {
+    __shared__ uint32_t local[MSM_COUNT_BINS];
+    for (uint32_t i = threadIdx.x; i < MSM_COUNT_BINS; i += MSM_BLOCK) local[i] = 0;
+    __syncthreads();
+    const uint32_t b = blockIdx.x * MSM_BLOCK + threadIdx.x;
+    if (b < n_buckets) atomicAdd(&local[MSM_COUNT_BINS - 1 - min(counts[b], MSM_COUNT_BINS - 1)], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < MSM_COUNT_BINS; i += MSM_BLOCK)
+        if (local[i]) atomicAdd(&bins[i], local[i]);
+}
+static __global__ __launch_bounds__(1024) void msm_order_scan_kernel(uint32_t* __restrict__ bins) {
+    __shared__ uint32_t part[1024];
+    const uint32_t v = bins[threadIdx.x];
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t t = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    bins[threadIdx.x] = part[threadIdx.x] - v;
+}
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_order_scatter_kernel(const uint32_t* __restrict__ counts, uint32_t n_buckets,
+                                                                             uint32_t* __restrict__ bins,
+                                                                             uint32_t* __restrict__ order) {
+    __shared__ uint32_t local[MSM_COUNT_BINS];   // per-bin count of this workgroup, then its base position
+    for (uint32_t i = threadIdx.x; i < MSM_COUNT_BINS; i += MSM_BLOCK) local[i] = 0;
+    __syncthreads();
+    const uint32_t b = blockIdx.x * MSM_BLOCK + threadIdx.x;
+    uint32_t key = 0, rank = 0;
+    if (b < n_buckets) {
+        key = MSM_COUNT_BINS - 1 - min(counts[b], MSM_COUNT_BINS - 1);
+        rank = atomicAdd(&local[key], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < MSM_COUNT_BINS; i += MSM_BLOCK)
+        if (local[i]) local[i] = atomicAdd(&bins[i], local[i]);
+    __syncthreads();
+    if (b < n_buckets) order[local[key] + rank] = b;
 }
 
 // pass 3: counting-sort scatter; entry = point index | sign << 31
@@ -120,9 +201,11 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_accumulate_kernel(const 
                                                                    const uint32_t* __restrict__ sorted,
                                                                    const uint32_t* __restrict__ offsets,
                                                                    const uint32_t* __restrict__ counts,
+                                                                   const uint32_t* __restrict__ order,
                                                                    uint32_t n_buckets, uint64_t* __restrict__ buckets) {
-    const uint32_t b = blockIdx.x * MSM_BLOCK + threadIdx.x;
-    if (b >= n_buckets) return;
+    const uint32_t t = blockIdx.x * MSM_BLOCK + threadIdx.x;
+    if (t >= n_buckets) return;
+    const uint32_t b = order[t];
     const uint32_t start = offsets[b], cnt = counts[b];
     G1Xyzz acc = G1Xyzz::identity();
     for (uint32_t k = 0; k < cnt; ++k) {
