@@ -161,9 +161,17 @@ def main():
     N.check(N.lib().zkhip_profile_read(ctx.handle, b"multifold", C.byref(ms), C.byref(cnt), C.byref(by)), "profile_read")
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
     achieved = by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "multifold_kernel (k-variable fold of the table + block sums of its output)",
+    # HBM bytes of that launch from the PMC counters (separate rocprofv3 --pmc passes; profiles/r01/pmc_traffic.json)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+        if args.log_n == 24:
+            traffic = pmc["kernels"]["zk::multifold_kernel grid=262144"]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
+    roofline = {"bound": "hbm", "kernel": "multifold_kernel<64> (8-variable fold of the 2^24 table + block sums of its output)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches": int(cnt.value), "avg_launch_us": round(1e3 * ms.value / max(1, cnt.value), 2),
                 "algorithmic_bytes_per_launch": "32 B x (table entries read + folded entries written), k variables per launch"}
 

@@ -22,7 +22,6 @@
 namespace zk {
 
 constexpr int MF_MAX_LOGK = 8;
-constexpr int MF_OUT_PER_WG = 64;
 
 // per-workgroup sum of a contiguous chunk of `chunk` entries (chunk a power of two, >= MLE_BLOCK)
 static __global__ __launch_bounds__(MLE_BLOCK) void chunk_sums_kernel(const uint64_t* __restrict__ in, uint32_t chunk,
@@ -259,24 +258,31 @@ __device__ __forceinline__ Fr wide_reduce(const uint64_t (&lo)[15], const uint32
     return r;
 }
 
-// out[j] = sum_{b < 2^k} w[b] * in[b*m + j], j < m.  A workgroup owns 64 consecutive outputs; its S = blockDim/64
-// waves split the 2^k terms.  Every wave reduces its own unreduced partial sum (the weights' 2^32 factor makes
-// each 9-word REDC a proper Montgomery residue, so the partial results simply add), wave 0 adds the S residues.
+// out[j] = sum_{b < 2^k} w[b] * in[b*m + j], j < m.
+// A wave covers G consecutive outputs x (64/G) term groups; a workgroup's S = blockDim/64 waves split the 2^k terms
+// further, so one output is shared by S * 64/G lanes.  Every lane reduces its own unreduced partial sum (the
+// weights' 2^32 factor makes each 9-word REDC a proper Montgomery residue, so partial results simply add); the
+// groups of a wave combine by shuffles, the waves through LDS.  G = 64 streams big tables (2 KiB per wave-load);
+// G = 16 keeps the chip busy when only a few hundred outputs are left.
 // Also writes the workgroup's sum of outputs to partials[blockIdx.x] (block sums of the output table).
+template <int G>
 static __global__ __launch_bounds__(1024) void multifold_kernel(const uint64_t* __restrict__ in, size_t m, uint32_t k,
                                                                 const uint64_t* __restrict__ weights,
                                                                 uint64_t* __restrict__ out,
                                                                 uint64_t* __restrict__ partials) {
+    constexpr int TG = 64 / G;                                // term groups inside a wave
     __shared__ Fr w_lds[1 << MF_MAX_LOGK];
-    __shared__ Fr part[16 * 64];
+    __shared__ Fr part[16 * G];
     const uint32_t n_terms = 1u << k;
     for (uint32_t b = threadIdx.x; b < n_terms; b += blockDim.x) w_lds[b] = load_fr(weights, b);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t slice = threadIdx.x >> 6;
-    const uint32_t n_slices = blockDim.x >> 6;
-    const uint32_t per = n_terms / n_slices;                  // host guarantees n_slices <= n_terms
-    const size_t j = (size_t)blockIdx.x * MF_OUT_PER_WG + lane;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t n_waves = blockDim.x >> 6;
+    const uint32_t slice = wave * TG + lane / G;              // term slice of this lane
+    const uint32_t per = n_terms / (n_waves * TG);            // host guarantees >= 1
+    const uint32_t oj = lane % G;
+    const size_t j = (size_t)blockIdx.x * G + oj;
     WideAcc acc;
     acc.clear();
     const uint32_t b0 = slice * per;
@@ -290,11 +296,17 @@ static __global__ __launch_bounds__(1024) void multifold_kernel(const uint64_t* 
         for (int u = 0; u < 4; ++u) if (t + u < per) acc.mac(w_lds[b0 + t + u], v[u]);
     }
     Fr o = wide_reduce(acc.lo, acc.hi);
-    if (slice != 0) part[(slice - 1) * 64 + lane] = o;
+#pragma unroll
+    for (int d = 32; d >= G; d >>= 1) o = o + shfl_down_fr(o, d);   // lanes < G now hold the wave's sums
+    if (wave != 0 && lane < G) part[(wave - 1) * G + lane] = o;
     __syncthreads();
-    if (slice == 0) {
-        for (uint32_t s2 = 1; s2 < n_slices; ++s2) o = o + part[(s2 - 1) * 64 + lane];
-        store_fr(out, j, o);
+    if (wave == 0) {
+        if (lane < G) {
+            for (uint32_t w2 = 1; w2 < n_waves; ++w2) o = o + part[(w2 - 1) * G + lane];
+            store_fr(out, j, o);
+        } else {
+            o = Fr::zero();
+        }
         Fr s = wave_reduce_fr(o);
         if (lane == 0) store_fr(partials, blockIdx.x, s);
     }

@@ -367,7 +367,7 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
     }
     // workspace: stage tables (n/4 + n/16 + ...), partial sums, fold weights
     const size_t tab_entries = n / 4 + n / 16 + 64;
-    const size_t part_entries = std::max<size_t>(n / 4096, n / 256) + 64;   // chunk sums of stage 0, per-workgroup sums of stage outputs
+    const size_t part_entries = std::max<size_t>(n / 4096, n / 256) + 1024;   // chunk sums of stage 0, per-workgroup sums of stage outputs
     const size_t w_entries = (size_t)1 << MF_MAX_LOGK;
     ZK_TRY(c->reserve_ws((tab_entries + 2 * part_entries + w_entries) * 32));
     uint64_t* tabA = (uint64_t*)c->d_ws;
@@ -413,15 +413,20 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
         first = 0;
         uint64_t* dst = (stage & 1) ? tabB : tabA;
         uint64_t* pdst = (stage & 1) ? partB : partA;
-        {
+        uint32_t out_per_wg;
+        if (m >= 8192) {          // streaming shape: 64 outputs per workgroup, 4 waves split the terms
+            out_per_wg = 64;
             ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m);
-            // few outputs -> more waves per output so that the chip still sees >= 4 waves per SIMD on the CUs in use
-            uint32_t slices = (m / MF_OUT_PER_WG >= 512) ? 4 : 16;
-            if (slices > (1u << k)) slices = 1u << k;
-            hipLaunchKernelGGL(multifold_kernel, dim3((unsigned)(m / MF_OUT_PER_WG)), dim3(64 * slices), 0, c->stream, cur, m, k, d_w, dst, pdst);
+            hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), 0, c->stream, cur, m, k, d_w, dst, pdst);
+        } else {                  // few outputs left: 16 per workgroup, up to 64 lanes share one output
+            out_per_wg = 16;
+            uint32_t waves = 16;
+            while (waves * 4 > (1u << k)) waves >>= 1;   // at least one term per lane group (k >= 3 here)
+            ProfScope ps(c, "multifold_small", 32.0 * (double)cn + 32.0 * (double)m);
+            hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), 0, c->stream, cur, m, k, d_w, dst, pdst);
         }
         parts = pdst;
-        n_parts = (uint32_t)(m / MF_OUT_PER_WG);
+        n_parts = (uint32_t)(m / out_per_wg);
         cur = dst;
         cn = m;
         round += k;
