@@ -134,6 +134,17 @@ int zkhip_sc_tail_capacity(void);
  * m a power of two <= zkhip_sc_tail_capacity(); runs ALL remaining log2(m) rounds replicated.  h_claimed_sum
  * only matters when no round has been absorbed yet. */
 int zkhip_sc_tail(zkhip_sc_state *st, const uint64_t *d_values, uint32_t m, const uint64_t *h_claimed_sum);
+/* Stage form of the same protocol (what zk_cryptography_amd.distributed uses): instead of one exchange per round,
+ * one exchange per STAGE of k rounds -- the ranks all-gather their 2^k partial block sums (32 * 2^k bytes each),
+ * every rank runs the k rounds of transcript on the summed block sums, then folds its shard by k variables in one
+ * pass (csrc/multifold_kernels.hpp).  A 2^27-entry table over 8 GPUs needs 3 such exchanges plus the final gather.
+ *   begin -> { stage_plan(k > 0) -> stage_block_sums -> [all-gather] -> stage_absorb -> stage_fold }*
+ *         -> stage_plan(k == 0) -> local_table -> [all-gather + interleave] -> tail -> finish */
+int zkhip_sc_stage_plan(zkhip_sc_state *st, uint32_t world, uint32_t *k_out);
+int zkhip_sc_stage_block_sums(zkhip_sc_state *st, uint64_t *d_out /* [2^k][4] */);
+/* d_gathered[world][2^k][4] in rank order; h_claimed_sum as in zkhip_sc_absorb (first stage only) */
+int zkhip_sc_stage_absorb(zkhip_sc_state *st, const uint64_t *d_gathered, uint32_t world, const uint64_t *h_claimed_sum);
+int zkhip_sc_stage_fold(zkhip_sc_state *st);
 /* copies out the proof (as zkhip_sumcheck_prove; *n_rounds rounds were recorded) and releases the state */
 int zkhip_sc_finish(zkhip_sc_state *st, uint64_t *h_sum, uint64_t *h_round_polys, uint64_t *h_challenges,
                     uint32_t *n_rounds);

@@ -19,8 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class OracleSumcheckEngine:
     """Same split-phase interface as HipSumcheckEngine, computed by the oracle (test double)."""
 
-    def __init__(self, ora, local_table):
+    def __init__(self, ora, local_table, use_stages=True):
         self.ora = ora
+        self.use_stages = use_stages
         self.cur = np.ascontiguousarray(local_table, dtype=np.uint64)
         self.tr = ora.Transcript()
         self.rps, self.chs, self.sum = [], [], None
@@ -62,6 +63,36 @@ class OracleSumcheckEngine:
     def local_table(self, out):
         out.copy_(torch.from_numpy(self.cur.view(np.int64)))
 
+    # ---- stage form: one exchange per k rounds
+    def stage_plan(self, world):
+        n_glob = self.cur.shape[0] * world
+        if not self.use_stages or n_glob <= self.cap:
+            return 0
+        k = min(3, (n_glob // self.cap).bit_length() - 1, self.cur.shape[0].bit_length() - 1)
+        self.k = k
+        return k
+
+    def stage_block_sums(self, out):
+        m = self.cur.shape[0] >> self.k
+        sums = np.stack([self.ora.mle_sum(self.cur[b * m:(b + 1) * m]) for b in range(1 << self.k)])
+        out.copy_(torch.from_numpy(sums.view(np.int64)))
+
+    def stage_absorb(self, gathered, world, claimed_sum=None):
+        g = gathered.numpy().view(np.uint64)
+        t = g[0].copy()
+        for r in range(1, world):
+            t = np.stack([self.ora.fr_add(t[b], g[r, b]) for b in range(t.shape[0])])
+        self.stage_rs = []
+        for _ in range(self.k):                      # k rounds on the block sums alone
+            hs = self.ora.mle_half_sums(t)
+            r = self._round(hs[0], hs[1], claimed_sum, not self.rps)
+            t = self.ora.mle_partial_evaluation(t, r, 0)
+            self.stage_rs.append(r)
+
+    def stage_fold(self):
+        for r in self.stage_rs:
+            self.cur = self.ora.mle_partial_evaluation(self.cur, r, 0)
+
     def tail_capacity(self):
         return self.cap
 
@@ -87,9 +118,12 @@ def _worker(rank, world, port, log_n, q):
         from zk_cryptography_amd import distributed as D
         full = ora.random_fr(1 << log_n, 4242)
         shard = D.shard_interleaved(full, rank, world)
-        s, rp, ch = D.ShardedSumcheck(OracleSumcheckEngine(ora, shard), world, None, dist).prove()
         ws, wrp, wch = ora.sumcheck_prove(full)
-        ok_sc = np.array_equal(s, ws) and np.array_equal(rp, wrp) and np.array_equal(ch, wch)
+        ok_sc = True
+        for use_stages in (True, False):     # stage form (one exchange per k rounds) and round form
+            eng = OracleSumcheckEngine(ora, shard, use_stages)
+            s, rp, ch = D.ShardedSumcheck(eng, world, None, dist).prove()
+            ok_sc = ok_sc and np.array_equal(s, ws) and np.array_equal(rp, wrp) and np.array_equal(ch, wch)
 
         # sharded KZG commit: SRS and scalars split the same way
         nv = 5

@@ -80,3 +80,48 @@ def test_orchestration_over_nccl_world_1(zk, ora):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log_n", [(2, 14), (4, 13), (8, 20), (2, 22), (8, 12), (4, 5)])
+def test_stage_form_shards_in_lockstep_match_full_prover(zk, ora, world, log_n):
+    """Stage form (one exchange per k rounds) with `world` shards driven in lockstep on one GPU."""
+    import torch
+    from zk_cryptography_amd import distributed as D
+    full = ora.random_fr(1 << log_n, 199 + log_n)
+    engines = []
+    for g in range(world):
+        t = torch.from_numpy(np.ascontiguousarray(D.shard_interleaved(full, g, world)).view(np.int64)).cuda()
+        engines.append(D.HipSumcheckEngine(t))
+    n_local = (1 << log_n) // world
+    n_exchanges = 0
+    while True:
+        ks = [e.stage_plan(world) for e in engines]
+        assert len(set(ks)) == 1
+        k = ks[0]
+        if k == 0:
+            break
+        mine = []
+        for e in engines:
+            b = e.new_buffer(1 << k, 4)
+            e.stage_block_sums(b)
+            mine.append(b)
+        gathered = torch.stack(mine).contiguous()
+        for e in engines:
+            e.stage_absorb(gathered, world)
+            e.stage_fold()
+        n_local >>= k
+        n_exchanges += 1
+    tabs = []
+    for e in engines:
+        t = e.new_buffer(n_local, 4)
+        e.local_table(t)
+        tabs.append(t)
+    rest = torch.stack(tabs).transpose(0, 1).contiguous().view(n_local * world, 4)
+    outs = []
+    for e in engines:
+        e.tail(rest, n_local * world)
+        outs.append(e.finish(log_n))
+    ws, wrp, wch = ora.sumcheck_prove(full)
+    for s, rp, ch in outs:
+        assert np.array_equal(s, ws) and np.array_equal(rp, wrp) and np.array_equal(ch, wch)
+    assert n_exchanges <= 3

@@ -59,7 +59,8 @@ constexpr int TREE_MAX_LOG = 10;   // the serial kernel keeps tables of up to 2^
 
 struct SmallArgs {
     const uint64_t* src;    // mode 0: the table itself (2^log_n entries); mode 1: partial sums, `group` per entry
-    uint32_t group;         // mode 1: consecutive partials per table entry (0 = mode 0)
+    uint32_t group;         // mode 1: partials per table entry (0 = mode 0)
+    uint32_t stride;        // mode 1: 0 = entry j owns partials j*group .. +group; else partial g of entry j is src[g*stride + j]
     uint32_t log_n;         // working table has 2^log_n entries (<= 2^TREE_MAX_LOG)
     uint32_t n_rounds;      // rounds to run, <= log_n
     uint32_t round0;        // index of the first round run here
@@ -94,6 +95,12 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
     // ---- leaves
     if (a.group == 0) {
         for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) tree0[n + j] = load_fr(a.src, j);
+    } else if (a.stride != 0) {   // all-gathered per-rank block sums: add the ranks' contributions in rank order
+        for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) {
+            Fr s = load_fr(a.src, j);
+            for (uint32_t g = 1; g < a.group; ++g) s = s + load_fr(a.src, (size_t)g * a.stride + j);
+            tree0[n + j] = s;
+        }
     } else {
         const uint32_t total = n * a.group;
         const uint32_t run = total > (uint32_t)MLE_BLOCK ? total / MLE_BLOCK : 1;   // consecutive partials per thread

@@ -462,6 +462,15 @@ struct zkhip_sc_state {
     uint32_t round, np;
     bool partials_valid;
     bool owns_tables;        // false: A/B live in the context workspace (the common, single-state case)
+    // stage form
+    uint64_t* stage_buf;     // [weights 4*256][partials X 4*P][partials Y 4*P][block sums 4*257]
+    size_t stage_parts_cap;
+    uint32_t stage_k_cur, stage_world, stage_idx, n_parts;
+    const uint64_t* parts;
+    uint64_t* sw() { return stage_buf; }
+    uint64_t* spx() { return stage_buf + 4 * 256; }
+    uint64_t* spy() { return spx() + 4 * stage_parts_cap; }
+    uint64_t* sbs() { return spy() + 4 * stage_parts_cap; }
     SumcheckDev* dev() { return (SumcheckDev*)small; }
     uint64_t* rp() { return small + 64; }
     uint64_t* ch() { return rp() + 8 * ZK_MAX_ROUNDS; }
@@ -492,7 +501,94 @@ extern "C" int zkhip_sc_begin(zkhip_ctx* c, const uint64_t* d_local, size_t n_lo
         }
     }
     st->B = st->A ? st->A + 4 * (n_local / 2) : nullptr;
+    st->stage_parts_cap = std::max<size_t>(n_local / 256, 64) + 64;
+    st->stage_k_cur = 0; st->stage_world = 1; st->stage_idx = 0; st->n_parts = 0; st->parts = nullptr;
+    st->stage_buf = nullptr;
+    if (hipMalloc(&st->stage_buf, (256 + 2 * st->stage_parts_cap + 257 + 8) * 32) != hipSuccess) {
+        if (st->A && st->owns_tables) hipFree(st->A);
+        if (st->A && !st->owns_tables) c->ws_lent = false;
+        hipFree(st->small); delete st; return ZKHIP_ERR_NOMEM;
+    }
     *out = st;
+    return ZKHIP_OK;
+}
+
+// ---- stage form -------------------------------------------------------------------------------------
+extern "C" int zkhip_sc_stage_plan(zkhip_sc_state* st, uint32_t world, uint32_t* k_out) {
+    if (!st || !k_out || !is_pow2(world)) return ZKHIP_ERR_ARG;
+    uint32_t k = stage_k(st->cn * world);
+    while (k && (st->cn >> k) < 16) --k;       // the local k-variable fold needs >= 16 outputs per workgroup
+    if (k < 3) k = 0;                           // too little left: gather the tables and finish replicated
+    st->stage_k_cur = k;
+    st->stage_world = world;
+    *k_out = k;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_sc_stage_block_sums(zkhip_sc_state* st, uint64_t* d_out) {
+    if (!st || !d_out || st->stage_k_cur == 0) return ZKHIP_ERR_ARG;
+    zkhip_ctx* c = st->c;
+    ZK_TRY(c->activate());
+    const uint32_t k = st->stage_k_cur;
+    const size_t m = st->cn >> k;
+    if (st->stage_idx == 0) {
+        const uint32_t chunk = (uint32_t)std::min<size_t>(m, 4096);
+        if (chunk >= (uint32_t)MLE_BLOCK) {
+            ProfScope ps(c, "chunk_sums", 32.0 * (double)st->cn);
+            hipLaunchKernelGGL(chunk_sums_kernel, dim3((unsigned)(st->cn / chunk)), dim3(MLE_BLOCK), 0, c->stream, st->cur, chunk, st->spx());
+            hipLaunchKernelGGL(group_sums_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, st->spx(), (uint32_t)(m / chunk), 1u << k, st->sbs());
+        } else {
+            hipLaunchKernelGGL(group_sums_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, st->cur, (uint32_t)m, 1u << k, st->sbs());
+        }
+    } else {
+        hipLaunchKernelGGL(group_sums_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, st->parts, st->n_parts >> k, 1u << k, st->sbs());
+    }
+    ZK_HIP(c, hipMemcpyAsync(d_out, st->sbs(), 32 * ((size_t)1 << k), hipMemcpyDeviceToDevice, c->stream));
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_sc_stage_absorb(zkhip_sc_state* st, const uint64_t* d_gathered, uint32_t world, const uint64_t* h_claimed) {
+    if (!st || !d_gathered || st->stage_k_cur == 0 || world != st->stage_world) return ZKHIP_ERR_ARG;
+    zkhip_ctx* c = st->c;
+    ZK_TRY(c->activate());
+    const uint32_t k = st->stage_k_cur;
+    SmallArgs a = {};
+    a.src = d_gathered; a.group = world; a.stride = 1u << k;
+    a.log_n = k; a.n_rounds = k; a.round0 = st->round;
+    a.first = st->round == 0 ? 1u : 0u;
+    if (a.first && h_claimed) { std::memcpy(a.claimed.v, h_claimed, 32); a.first = 2; }
+    a.weights_out = st->sw(); a.final_out = nullptr;
+    ZK_TRY(launch_small(c, a, st->dev(), st->rp(), st->ch()));
+    st->round += k;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_sc_stage_fold(zkhip_sc_state* st) {
+    if (!st || st->stage_k_cur == 0) return ZKHIP_ERR_ARG;
+    zkhip_ctx* c = st->c;
+    ZK_TRY(c->activate());
+    const uint32_t k = st->stage_k_cur;
+    const size_t m = st->cn >> k;
+    uint64_t* dst = (st->cur == st->A) ? st->B : st->A;     // m <= n_local/8 fits either buffer
+    uint64_t* pdst = (st->parts == st->spx() || st->stage_idx == 0) ? st->spy() : st->spx();
+    uint32_t out_per_wg;
+    if (m >= 8192) {
+        out_per_wg = 64;
+        ProfScope ps(c, "multifold", 32.0 * (double)st->cn + 32.0 * (double)m);
+        hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), 0, c->stream, st->cur, m, k, st->sw(), dst, pdst);
+    } else {
+        out_per_wg = 16;
+        uint32_t waves = 16;
+        while (waves * 4 > (1u << k)) waves >>= 1;
+        ProfScope ps(c, "multifold_small", 32.0 * (double)st->cn + 32.0 * (double)m);
+        hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), 0, c->stream, st->cur, m, k, st->sw(), dst, pdst);
+    }
+    ZK_HIP(c, hipGetLastError());
+    st->parts = pdst;
+    st->n_parts = (uint32_t)(m / out_per_wg);
+    st->cur = dst;
+    st->cn = m;
+    st->partials_valid = false;
+    st->stage_k_cur = 0;
+    st->stage_idx++;
     return ZKHIP_OK;
 }
 extern "C" int zkhip_sc_local_len(zkhip_sc_state* st, size_t* n) {
@@ -554,21 +650,20 @@ extern "C" int zkhip_sc_local_table(zkhip_sc_state* st, uint64_t* d_out) {
     ZK_HIP(st->c, hipMemcpyAsync(d_out, st->cur, 32 * st->cn, hipMemcpyDeviceToDevice, st->c->stream));
     return ZKHIP_OK;
 }
-extern "C" int zkhip_sc_tail_capacity(void) { return TAIL_N; }
+extern "C" int zkhip_sc_tail_capacity(void) { return 1 << TREE_MAX_LOG; }
 extern "C" int zkhip_sc_tail(zkhip_sc_state* st, const uint64_t* d_values, uint32_t m, const uint64_t* h_claimed) {
     if (!st || !d_values) return ZKHIP_ERR_ARG;
-    if (!is_pow2(m) || m > (uint32_t)TAIL_N) return ZKHIP_ERR_SHAPE;
+    if (!is_pow2(m) || m > (1u << TREE_MAX_LOG)) return ZKHIP_ERR_SHAPE;
     if (m == 1) return ZKHIP_OK;
     zkhip_ctx* c = st->c;
     ZK_TRY(c->activate());
-    ZK_TRY(c->allow_big_lds((const void*)sumcheck_tail_kernel, TAIL_LDS_BYTES));
-    FrArg z = {};
-    uint32_t first = st->round == 0 ? 1u : 0u;
-    if (first && h_claimed) { std::memcpy(z.v, h_claimed, 32); first = 2; }
-    hipLaunchKernelGGL(sumcheck_tail_kernel, dim3(1), dim3(MLE_BLOCK), TAIL_LDS_BYTES, c->stream, d_values, m, st->dev(),
-                       st->round, first, z, st->rp(), st->ch(), st->fin());
-    ZK_HIP(c, hipGetLastError());
-    st->round += log2_exact(m);
+    SmallArgs a = {};
+    a.src = d_values; a.group = 0; a.stride = 0; a.log_n = log2_exact(m); a.n_rounds = a.log_n; a.round0 = st->round;
+    a.first = st->round == 0 ? 1u : 0u;
+    if (a.first && h_claimed) { std::memcpy(a.claimed.v, h_claimed, 32); a.first = 2; }
+    a.weights_out = nullptr; a.final_out = st->fin();
+    ZK_TRY(launch_small(c, a, st->dev(), st->rp(), st->ch()));
+    st->round += a.log_n;
     return ZKHIP_OK;
 }
 extern "C" int zkhip_sc_finish(zkhip_sc_state* st, uint64_t* h_sum, uint64_t* h_rp, uint64_t* h_ch, uint32_t* n_rounds) {
@@ -584,6 +679,7 @@ extern "C" int zkhip_sc_finish(zkhip_sc_state* st, uint64_t* h_sum, uint64_t* h_
     if (st->A && st->owns_tables) hipFree(st->A);
     if (st->A && !st->owns_tables) c->ws_lent = false;
     hipFree(st->small);
+    if (st->stage_buf) hipFree(st->stage_buf);
     delete st;
     return rc;
 }

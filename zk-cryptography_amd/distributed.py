@@ -60,6 +60,22 @@ class HipSumcheckEngine:
     def local_value(self, out):
         N.check(N.lib().zkhip_sc_local_value(self.st, N.ptr(out)), "sc_local_value")
 
+    def stage_plan(self, world):
+        k = C.c_uint32(0)
+        N.check(N.lib().zkhip_sc_stage_plan(self.st, C.c_uint32(world), C.byref(k)), "sc_stage_plan")
+        return k.value
+
+    def stage_block_sums(self, out):
+        N.check(N.lib().zkhip_sc_stage_block_sums(self.st, N.ptr(out)), "sc_stage_block_sums")
+
+    def stage_absorb(self, gathered, world, claimed_sum=None):
+        cs = np.ascontiguousarray(claimed_sum, dtype=np.uint64) if claimed_sum is not None else None
+        N.check(N.lib().zkhip_sc_stage_absorb(self.st, N.ptr(gathered), C.c_uint32(world),
+                                              cs.ctypes.data_as(C.c_void_p) if cs is not None else None), "sc_stage_absorb")
+
+    def stage_fold(self):
+        N.check(N.lib().zkhip_sc_stage_fold(self.st), "sc_stage_fold")
+
     def local_table(self, out):
         N.check(N.lib().zkhip_sc_local_table(self.st, N.ptr(out)), "sc_local_table")
 
@@ -106,19 +122,35 @@ class ShardedSumcheck:
 
     def prove(self, claimed_sum=None):
         e, world = self.e, self.world
-        send = e.new_buffer(2, 4)
-        recv = e.new_buffer(world, 2, 4)
         n_local = e.local_len()
         total_rounds = (n_local * world).bit_length() - 1
-        cap = e.tail_capacity()
-        rnd = 0
-        while n_local * world > cap and n_local > 1:
-            e.local_half_sums(send)                                     # 64 bytes per rank
-            _all_gather(self.dist, self.group, recv, send, world)       # C1: RCCL all-gather over xGMI
-            e.absorb(recv, world, claimed_sum if rnd == 0 else None)    # local modular add + transcript -> challenge
-            e.fold()                                                    # local: partners share the low index bits
-            n_local //= 2
-            rnd += 1
+        absorbed = False
+        if getattr(e, "use_stages", True) and hasattr(e, "stage_plan"):
+            # stage form: one exchange per k rounds (32 * 2^k bytes per rank), then one local k-variable fold
+            while True:
+                k = e.stage_plan(world)
+                if k == 0:
+                    break
+                mine = e.new_buffer(1 << k, 4)
+                e.stage_block_sums(mine)
+                gathered = e.new_buffer(world, 1 << k, 4)
+                _all_gather(self.dist, self.group, gathered, mine, world)      # C1: RCCL all-gather over xGMI
+                e.stage_absorb(gathered, world, None if absorbed else claimed_sum)
+                absorbed = True
+                e.stage_fold()
+                n_local >>= k
+        else:
+            # round form: one 64-byte exchange per round
+            send = e.new_buffer(2, 4)
+            recv = e.new_buffer(world, 2, 4)
+            cap = e.tail_capacity()
+            while n_local * world > cap and n_local > 1:
+                e.local_half_sums(send)
+                _all_gather(self.dist, self.group, recv, send, world)
+                e.absorb(recv, world, None if absorbed else claimed_sum)       # local modular add + transcript -> challenge
+                absorbed = True
+                e.fold()                                                        # local: partners share the low index bits
+                n_local //= 2
         if n_local * world > 1:
             # the whole remaining table now fits one workgroup's LDS: gather it and finish replicated
             mine = e.new_buffer(n_local, 4)
@@ -126,7 +158,7 @@ class ShardedSumcheck:
             gathered = e.new_buffer(world, n_local, 4)
             _all_gather(self.dist, self.group, gathered, mine, world)
             full = gathered.transpose(0, 1).contiguous().view(n_local * world, 4)   # entry j*world + g <- rank g, local j
-            e.tail(full, n_local * world, claimed_sum if rnd == 0 else None)
+            e.tail(full, n_local * world, None if absorbed else claimed_sum)
         return e.finish(total_rounds)
 
 
