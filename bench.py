@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--msm-log-n", type=int, default=20, help="log2 of the per-GPU SRS size of the KZG commit leg")
     ap.add_argument("--no-msm", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="diagnostic: run the sharded prover protocol even on one GPU")
     args = ap.parse_args()
 
     import numpy as np
@@ -124,7 +125,7 @@ def main():
     from zk_cryptography_amd import distributed as D
 
     def step():
-        if world == 1:
+        if world == 1 and not args.force_sharded:
             sc = zk.Sumcheck(poly)
             sc.poly_sum()
             return sc.prove()

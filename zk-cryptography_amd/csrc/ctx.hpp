@@ -59,6 +59,8 @@ struct zkhip_ctx {
     void* d_ws = nullptr;       // large workspace (ping-pong tables, MSM buckets, ...)
     size_t ws_bytes = 0;
     bool ws_lent = false;       // the workspace currently backs a split-phase prover state
+    // one cached set of small split-phase buffers, so that a steady stream of sharded proves never allocates
+    void* sc_small = nullptr; void* sc_stage = nullptr; size_t sc_stage_cap = 0; bool sc_lent = false;
     void* d_small = nullptr;    // fixed small scratch, layout above
     void* h_pinned = nullptr;
     bool profiling = false;

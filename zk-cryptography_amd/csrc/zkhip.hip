@@ -60,6 +60,8 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     for (auto& e : c->prof_events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
     if (c->d_ws) hipFree(c->d_ws);
     if (c->d_small) hipFree(c->d_small);
+    if (c->sc_small) hipFree(c->sc_small);
+    if (c->sc_stage) hipFree(c->sc_stage);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -462,6 +464,7 @@ struct zkhip_sc_state {
     uint32_t round, np;
     bool partials_valid;
     bool owns_tables;        // false: A/B live in the context workspace (the common, single-state case)
+    bool uses_cache;         // small + stage buffers borrowed from the context
     // stage form
     uint64_t* stage_buf;     // [weights 4*256][partials X 4*P][partials Y 4*P][block sums 4*257]
     size_t stage_parts_cap;
@@ -486,29 +489,36 @@ extern "C" int zkhip_sc_begin(zkhip_ctx* c, const uint64_t* d_local, size_t n_lo
     st->c = c; st->cur = d_local; st->cn = n_local; st->round = 0; st->np = 0; st->partials_valid = false;
     st->A = st->B = st->small = nullptr;
     const size_t small_u64 = 64 + 12 * (size_t)ZK_MAX_ROUNDS + 8 * (size_t)MLE_MAX_GRID + 16;
-    if (hipMalloc(&st->small, small_u64 * 8) != hipSuccess) { delete st; return ZKHIP_ERR_NOMEM; }
+    st->stage_parts_cap = std::max<size_t>(n_local / 256, 64) + 64;
+    st->uses_cache = false;
+    if (!c->sc_lent && c->sc_small && c->sc_stage_cap >= st->stage_parts_cap) {
+        st->small = (uint64_t*)c->sc_small;
+        st->stage_buf = (uint64_t*)c->sc_stage;
+        st->stage_parts_cap = c->sc_stage_cap;
+        st->uses_cache = true;
+        c->sc_lent = true;
+    } else {
+        if (hipMalloc(&st->small, small_u64 * 8) != hipSuccess) { delete st; return ZKHIP_ERR_NOMEM; }
+        st->stage_buf = nullptr;
+        if (hipMalloc(&st->stage_buf, (256 + 2 * st->stage_parts_cap + 257 + 8) * 32) != hipSuccess) {
+            hipFree(st->small); delete st; return ZKHIP_ERR_NOMEM;
+        }
+    }
     st->owns_tables = false;
     if (n_local >= 2) {
         const size_t bytes = (n_local / 2 + n_local / 4 + 4) * 32;
         if (!c->ws_lent) {               // steady state: no allocation per prove
             int rc = c->reserve_ws(bytes);
-            if (rc != ZKHIP_OK) { hipFree(st->small); delete st; return rc; }
+            if (rc != ZKHIP_OK) { if (st->uses_cache) c->sc_lent = false; else { hipFree(st->small); hipFree(st->stage_buf); } delete st; return rc; }
             st->A = (uint64_t*)c->d_ws;
             c->ws_lent = true;
         } else {                         // several states alive at once (tests drive shards in lockstep)
-            if (hipMalloc(&st->A, bytes) != hipSuccess) { hipFree(st->small); delete st; return ZKHIP_ERR_NOMEM; }
+            if (hipMalloc(&st->A, bytes) != hipSuccess) { if (st->uses_cache) c->sc_lent = false; else { hipFree(st->small); hipFree(st->stage_buf); } delete st; return ZKHIP_ERR_NOMEM; }
             st->owns_tables = true;
         }
     }
     st->B = st->A ? st->A + 4 * (n_local / 2) : nullptr;
-    st->stage_parts_cap = std::max<size_t>(n_local / 256, 64) + 64;
     st->stage_k_cur = 0; st->stage_world = 1; st->stage_idx = 0; st->n_parts = 0; st->parts = nullptr;
-    st->stage_buf = nullptr;
-    if (hipMalloc(&st->stage_buf, (256 + 2 * st->stage_parts_cap + 257 + 8) * 32) != hipSuccess) {
-        if (st->A && st->owns_tables) hipFree(st->A);
-        if (st->A && !st->owns_tables) c->ws_lent = false;
-        hipFree(st->small); delete st; return ZKHIP_ERR_NOMEM;
-    }
     *out = st;
     return ZKHIP_OK;
 }
@@ -678,8 +688,14 @@ extern "C" int zkhip_sc_finish(zkhip_sc_state* st, uint64_t* h_sum, uint64_t* h_
     if (n_rounds) *n_rounds = st->round;
     if (st->A && st->owns_tables) hipFree(st->A);
     if (st->A && !st->owns_tables) c->ws_lent = false;
-    hipFree(st->small);
-    if (st->stage_buf) hipFree(st->stage_buf);
+    if (st->uses_cache) {
+        c->sc_lent = false;
+    } else if (!c->sc_small) {           // keep this set for the next prove instead of freeing it
+        c->sc_small = st->small; c->sc_stage = st->stage_buf; c->sc_stage_cap = st->stage_parts_cap;
+    } else {
+        hipFree(st->small);
+        if (st->stage_buf) hipFree(st->stage_buf);
+    }
     delete st;
     return rc;
 }
