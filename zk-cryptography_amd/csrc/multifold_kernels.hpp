@@ -201,6 +201,25 @@ __host__ __device__ constexpr size_t small_lds_bytes(uint32_t log_n) {
     return ((size_t)4 * ((size_t)1 << log_n) + 2 * (1u << MF_MAX_LOGK) + MLE_BLOCK + 4 + 2) * 32;
 }
 
+// Fold weights of k known points (MultilinearTrait::evaluation folds variable 0 repeatedly, evaluation_form.rs:162-175):
+// w[b] = 2^32 * prod_i (b_i ? r_i : 1 - r_i), b_1 = most significant bit of b.  One lane per weight.
+static __global__ __launch_bounds__(MLE_BLOCK) void eq_weights_kernel(PtsArg pts, uint32_t first, uint32_t k,
+                                                                      uint64_t* __restrict__ out) {
+    const uint32_t b = blockIdx.x * MLE_BLOCK + threadIdx.x;
+    if (b >= (1u << k)) return;
+    Fr w;
+    constexpr uint32_t c[8] = {0xcaaf6b13u, 0x355094eau, 0x69a568efu, 0xf6b10cb3u, 0x40cc3869u, 0xe2c926a6u, 0xed269aadu, 0x736a6d3bu};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w.l[i] = c[i];
+    const Fr one = Fr::one();
+    for (uint32_t i = 0; i < k; ++i) {
+        Fr r = fr_from_pts(pts, first + i);
+        if (!((b >> (k - 1 - i)) & 1)) r = one - r;
+        w = w * r;
+    }
+    store_fr(out, b, w);
+}
+
 // ---- the k-variable fold -------------------------------------------------------------------------------
 // Unreduced accumulator: column c collects every limb product w[i]*t[j] with i + j = c.
 struct WideAcc {

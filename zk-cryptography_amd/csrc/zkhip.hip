@@ -178,13 +178,42 @@ static int fold_chain(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uin
         ZK_HIP(c, hipMemcpyAsync(d_out, d_evals, n * 32, hipMemcpyDeviceToDevice, c->stream));
         return ZKHIP_OK;
     }
-    const size_t need = (n / 2 + n / 4 + 8) * 32;
+    const size_t need = (n / 2 + n / 4 + 8) * 32 + (256 + n / 1024 + 4096) * 32;
     ZK_TRY(c->reserve_ws(need));
     uint64_t* A = (uint64_t*)c->d_ws;
     uint64_t* B = A + 4 * (n / 2);
+    uint64_t* d_w = B + 4 * (n / 4 + 4);
+    uint64_t* d_dummy = d_w + 4 * 256;            // per-workgroup output sums of the k-variable fold (unused here)
     const uint64_t* cur = d_evals;
     size_t cn = n;
-    for (size_t p = 0; p < n_pts; ++p) {
+    size_t p0 = 0;
+    if (!var_indices) {
+        // every point folds variable 0: collapse k of them per pass (weights = eq table of those points)
+        uint32_t stage = 0;
+        while (cn > (size_t)TAIL_N && n_pts - p0 >= 3) {
+            uint32_t k = log2_exact(cn) - TAIL_LOG;
+            if (k > MF_MAX_LOGK) k = MF_MAX_LOGK;
+            if (k > n_pts - p0) k = (uint32_t)(n_pts - p0);
+            if (k < 3) break;
+            const size_t m = cn >> k;
+            const bool last = (p0 + k == n_pts);
+            uint64_t* dst = last ? d_out : ((stage & 1) ? B : A);
+            hipLaunchKernelGGL(eq_weights_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, pa, (uint32_t)p0, k, d_w);
+            if (m >= 8192) {
+                ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m);
+                hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), 0, c->stream, cur, m, k, d_w, dst, d_dummy);
+            } else {
+                uint32_t waves = 16;
+                while (waves * 4 > (1u << k)) waves >>= 1;
+                ProfScope ps(c, "multifold_small", 32.0 * (double)cn + 32.0 * (double)m);
+                hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), 0, c->stream, cur, m, k, d_w, dst, d_dummy);
+            }
+            ZK_HIP(c, hipGetLastError());
+            cur = dst; cn = m; p0 += k; ++stage;
+            if (last) return ZKHIP_OK;
+        }
+    }
+    for (size_t p = p0; p < n_pts; ++p) {
         const uint32_t k = var_indices ? var_indices[p] : 0;
         if (cn < 2 || !((size_t)k < cn / 2) || k >= log2_exact(cn)) return ZKHIP_ERR_SHAPE;
         const bool all_zero_tail = !var_indices || [&] {
@@ -201,7 +230,7 @@ static int fold_chain(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uin
             return ZKHIP_OK;
         }
         const bool last = (p + 1 == n_pts);
-        uint64_t* dst = last ? d_out : ((p & 1) ? B : A);
+        uint64_t* dst = last ? d_out : ((cur == A) ? B : A);
         ZK_TRY(launch_fold(c, cur, cn, nullptr, h_pts + 4 * p, k, dst, false, nullptr, nullptr));
         cur = dst;
         cn /= 2;
