@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -87,9 +88,13 @@ static int ntt_inplace(zkhip_ctx* c, uint64_t* d_data, uint32_t log_n, int inver
         hipLaunchKernelGGL(ntt_first_stages_kernel, dim3((unsigned)(n / tile)), dim3(MLE_BLOCK), 0, c->stream, d_data, d_scratch,
                            log_n, tw);
     }
-    for (uint32_t s = NTT_TILE_LOG; s < log_n; ++s) {
-        ProfScope ps(c, "ntt_stage", 64.0 * (double)n);
-        hipLaunchKernelGGL(ntt_stage_kernel, dim3(mle_grid(n / 2)), dim3(MLE_BLOCK), 0, c->stream, d_scratch, log_n, s, tw);
+    for (uint32_t s = NTT_TILE_LOG; s < log_n;) {
+        uint32_t T = std::min<uint32_t>(NTT_MID_MAX, log_n - s);
+        if (log_n - s > NTT_MID_MAX && log_n - s < 2 * NTT_MID_MAX) T = (log_n - s + 1) / 2;   // balance the last two passes
+        ProfScope ps(c, "ntt_mid_stages", 64.0 * (double)n);
+        hipLaunchKernelGGL(ntt_mid_stages_kernel, dim3((unsigned)(n >> NTT_MID_TILE_LOG)), dim3(MLE_BLOCK), 0, c->stream,
+                           d_scratch, log_n, s, T, tw);
+        s += T;
     }
     if (inverse) {
         zkhost::Fr ni = zkhost::fr_inv(zkhost::fr_from_u64((uint64_t)n));

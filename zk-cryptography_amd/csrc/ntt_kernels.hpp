@@ -78,6 +78,49 @@ static __global__ __launch_bounds__(MLE_BLOCK) void ntt_stage_kernel(uint64_t* _
     }
 }
 
+// T consecutive stages s0 .. s0+T-1 (butterfly distances 2^s0 ..) in one pass.  Index i = hi | mid | lo with `mid` the T
+// bits those stages pair up: for fixed (hi, lo) the 2^T elements form an independent sub-transform.  A workgroup
+// stages 2^T mids x NTT_COLS consecutive `lo` values (512-byte contiguous pieces) in LDS, runs the T stages there
+// and writes the tile back in place.
+constexpr int NTT_MID_TILE_LOG = 10;              // 1024 elements = 32 KiB of LDS: several workgroups per CU hide the HBM latency
+constexpr int NTT_MID_MAX = 6;                    // stages per pass; the tile is 2^T mids x (1024 >> T) consecutive lo values
+static __global__ __launch_bounds__(MLE_BLOCK) void ntt_mid_stages_kernel(uint64_t* __restrict__ data, uint32_t log_n,
+                                                                          uint32_t s0, uint32_t T,
+                                                                          const uint64_t* __restrict__ tw) {
+    __shared__ Fr tab[1 << NTT_MID_TILE_LOG];
+    const uint32_t cols_log = NTT_MID_TILE_LOG - T;             // >= 4: pieces of >= 512 contiguous bytes
+    const uint32_t cols = 1u << cols_log;
+    const uint32_t lo_chunks = 1u << (s0 - cols_log);
+    const size_t hi = blockIdx.x / lo_chunks;
+    const uint32_t lo0 = (blockIdx.x % lo_chunks) << cols_log;
+    const size_t base = (hi << (s0 + T)) | lo0;
+    constexpr uint32_t tile = 1u << NTT_MID_TILE_LOG;
+    for (uint32_t q = threadIdx.x; q < tile; q += MLE_BLOCK) {
+        const uint32_t mid = q >> cols_log, c = q & (cols - 1);
+        tab[q] = load_fr(data, base + ((size_t)mid << s0) + c);
+    }
+    __syncthreads();
+    for (uint32_t t = 0; t < T; ++t) {
+        const uint32_t s = s0 + t;
+        const size_t tw_stride = (size_t)1 << (log_n - s - 1);
+        for (uint32_t b = threadIdx.x; b < tile / 2; b += MLE_BLOCK) {
+            const uint32_t c = b & (cols - 1), q = b >> cols_log;
+            const uint32_t mid0 = ((q >> t) << (t + 1)) | (q & ((1u << t) - 1));
+            const uint32_t i0 = (mid0 << cols_log) | c, i1 = i0 + (cols << t);
+            const size_t j = ((size_t)(mid0 & ((1u << t) - 1)) << s0) | (lo0 + c);   // position inside the 2^s block
+            Fr tt = tab[i1] * load_fr(tw, j * tw_stride);
+            Fr u = tab[i0];
+            tab[i1] = u - tt;
+            tab[i0] = u + tt;
+        }
+        __syncthreads();
+    }
+    for (uint32_t q = threadIdx.x; q < tile; q += MLE_BLOCK) {
+        const uint32_t mid = q >> cols_log, c = q & (cols - 1);
+        store_fr(data, base + ((size_t)mid << s0) + c, tab[q]);
+    }
+}
+
 // out[i] = a[i] * b[i]   (evaluation.rs:79-82)
 static __global__ __launch_bounds__(MLE_BLOCK) void pointwise_mul_kernel(const uint64_t* __restrict__ a,
                                                                   const uint64_t* __restrict__ b, size_t n,
