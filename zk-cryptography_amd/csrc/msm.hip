@@ -60,10 +60,11 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     const size_t o_tiles = o_order + al(n_buckets * 4);
     const size_t o_bins = o_tiles + al(((n_buckets + SCAN_TILE - 1) / SCAN_TILE) * 4);
     const size_t o_sorted = o_bins + al(MSM_COUNT_BINS * 4);
-    const size_t o_buckets = o_sorted + al(n * pl.n_windows * 4);
-    const size_t o_segs = o_buckets + al(n_buckets * 192);
-    const size_t o_sega = o_segs + al(n_segments * 192);
-    const size_t o_terms = o_sega + al(n_segments * 192);
+    const size_t o_points = o_sorted + al(n * pl.n_windows * 4);        // SRS in the internal 28-bit-limb layout
+    const size_t o_buckets = o_points + al(n * 128);
+    const size_t o_segs = o_buckets + al(n_buckets * 256);
+    const size_t o_sega = o_segs + al(n_segments * 256);
+    const size_t o_terms = o_sega + al(n_segments * 256);
     const size_t total = o_terms + al(n_out * 192);
     ZK_TRY(c->reserve_ws(total));
     char* ws = (char*)c->d_ws;
@@ -74,13 +75,18 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     uint32_t* order = (uint32_t*)(ws + o_order);
     uint32_t* tiles = (uint32_t*)(ws + o_tiles);
     uint32_t* bins = (uint32_t*)(ws + o_bins);
-    uint64_t* buckets = (uint64_t*)(ws + o_buckets);
-    uint64_t* segs = (uint64_t*)(ws + o_segs);
-    uint64_t* sega = (uint64_t*)(ws + o_sega);
+    uint32_t* points_u = (uint32_t*)(ws + o_points);
+    uint32_t* buckets = (uint32_t*)(ws + o_buckets);
+    uint32_t* segs = (uint32_t*)(ws + o_segs);
+    uint32_t* sega = (uint32_t*)(ws + o_sega);
     uint64_t* terms = (uint64_t*)(ws + o_terms);
 
     ZK_HIP(c, hipMemsetAsync(counts, 0, n_buckets * 4, c->stream));
     const int grid_n = (int)std::min<size_t>((n + MSM_BLOCK - 1) / MSM_BLOCK, 256 * 8);
+    {
+        ProfScope ps(c, "msm_convert_points", 224.0 * (double)n);
+        hipLaunchKernelGGL(msm_convert_points_kernel, dim3(grid_n), dim3(MSM_BLOCK), 0, c->stream, d_points_xy, n, points_u);
+    }
     {
         ProfScope ps(c, "msm_hist", 32.0 * (double)n);
         hipLaunchKernelGGL(msm_hist_kernel, dim3(grid_n), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl, counts);
@@ -106,7 +112,7 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     {
         ProfScope ps(c, "msm_accumulate", 128.0 * (double)n);
         hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK)), dim3(MSM_BLOCK), 0,
-                           c->stream, d_points_xy, sorted, offsets, counts, order, (uint32_t)n_buckets, buckets);
+                           c->stream, points_u, sorted, offsets, counts, order, (uint32_t)n_buckets, buckets);
     }
     {
         ProfScope ps(c, "msm_segment", 0.0);
@@ -115,7 +121,7 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     }
     {
         ProfScope ps(c, "msm_terms", 0.0);
-        hipLaunchKernelGGL(msm_terms_kernel, dim3((unsigned)n_out), dim3(MSM_BLOCK), MSM_BLOCK * 192, c->stream, segs, sega, pl, terms);
+        hipLaunchKernelGGL(msm_terms_kernel, dim3((unsigned)n_out), dim3(MSM_BLOCK), MSM_BLOCK * 256, c->stream, segs, sega, pl, terms);
     }
     ZK_HIP(c, hipGetLastError());
     std::vector<uint64_t> h_terms(n_out * 24);

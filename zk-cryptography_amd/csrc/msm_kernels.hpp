@@ -19,6 +19,7 @@
 // MSM is integer-ALU bound (about 10 Fq products of ~900 instructions per added point), not HBM bound.
 #pragma once
 #include "g1.hpp"
+#include "g1u.hpp"
 
 namespace zk {
 
@@ -196,68 +197,94 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_scatter_kernel(const uin
     }
 }
 
-// pass 4: one lane per bucket
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_accumulate_kernel(const uint64_t* __restrict__ points,
+// pass 0: SRS points from the arkworks layout (96 B) into the internal unsaturated layout (128 B), once per commit
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_convert_points_kernel(const uint64_t* __restrict__ points, size_t n,
+                                                                              uint32_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * MSM_BLOCK;
+    for (size_t i = (size_t)blockIdx.x * MSM_BLOCK + threadIdx.x; i < n; i += stride) {
+        G1Affine a = load_affine(points, i);
+        store_fqu(out + 32 * i, fqu_from_ark(a.x));
+        store_fqu(out + 32 * i + 16, fqu_from_ark(a.y));
+    }
+}
+
+// pass 4: one lane per bucket (in the order given by `order`: heaviest buckets first, equal lengths inside a wave)
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_accumulate_kernel(const uint32_t* __restrict__ points,
                                                                    const uint32_t* __restrict__ sorted,
                                                                    const uint32_t* __restrict__ offsets,
                                                                    const uint32_t* __restrict__ counts,
                                                                    const uint32_t* __restrict__ order,
-                                                                   uint32_t n_buckets, uint64_t* __restrict__ buckets) {
+                                                                   uint32_t n_buckets, uint32_t* __restrict__ buckets) {
     const uint32_t t = blockIdx.x * MSM_BLOCK + threadIdx.x;
     if (t >= n_buckets) return;
     const uint32_t b = order[t];
     const uint32_t start = offsets[b], cnt = counts[b];
-    G1Xyzz acc = G1Xyzz::identity();
+    G1XyzzU acc = G1XyzzU::identity();
+    // software pipeline: the next point's index and coordinates (a dependent pair of random loads) are in flight
+    // while the current addition (~6 k instructions) runs
+    uint32_t e_next = cnt ? sorted[start] : 0u;
+    G1AffineU p_next = load_affine_u(points, e_next & 0x7fffffffu);
     for (uint32_t k = 0; k < cnt; ++k) {
-        const uint32_t e = sorted[start + k];
-        G1Affine p = load_affine(points, e & 0x7fffffffu);
-        g1_madd(acc, p, (e >> 31) != 0);
+        const uint32_t e = e_next;
+        const G1AffineU p = p_next;
+        if (k + 1 < cnt) {
+            e_next = sorted[start + k + 1];
+            p_next = load_affine_u(points, e_next & 0x7fffffffu);
+        }
+        g1u_madd(acc, p, (e >> 31) != 0);
     }
-    store_xyzz(buckets, b, acc);
+    store_xyzz_u(buckets, b, acc);
 }
 
 // pass 5: one lane per segment of L buckets: S = sum_j B_j, A = sum_j (j+1) B_j  (running sum from the top)
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_segment_kernel(const uint64_t* __restrict__ buckets,
-                                                                uint32_t n_segments, uint64_t* __restrict__ seg_s,
-                                                                uint64_t* __restrict__ seg_a) {
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_segment_kernel(const uint32_t* __restrict__ buckets,
+                                                                uint32_t n_segments, uint32_t* __restrict__ seg_s,
+                                                                uint32_t* __restrict__ seg_a) {
     const uint32_t s = blockIdx.x * MSM_BLOCK + threadIdx.x;
     if (s >= n_segments) return;
-    G1Xyzz running = G1Xyzz::identity(), acc = G1Xyzz::identity();
+    G1XyzzU running = G1XyzzU::identity(), acc = G1XyzzU::identity();
     for (int j = MSM_SEG - 1; j >= 0; --j) {
-        G1Xyzz bkt = load_xyzz(buckets, (size_t)s * MSM_SEG + j);
-        g1_add(running, bkt);
-        g1_add(acc, running);
+        G1XyzzU bkt = load_xyzz_u(buckets, (size_t)s * MSM_SEG + j);
+        g1u_add(running, bkt);
+        g1u_add(acc, running);
     }
-    store_xyzz(seg_s, s, running);
-    store_xyzz(seg_a, s, acc);
+    store_xyzz_u(seg_s, s, running);
+    store_xyzz_u(seg_a, s, acc);
 }
 
 // pass 6: one workgroup per (window, term).  term 0: sum of A_s over the window's segments;
-// term 1+k: sum of S_s over the segments whose index has bit k set.
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_terms_kernel(const uint64_t* __restrict__ seg_s,
-                                                              const uint64_t* __restrict__ seg_a, MsmPlan pl,
+// term 1+k: sum of S_s over the segments whose index has bit k set.  The result leaves in the arkworks layout
+// (XYZZ, 4 x 48 B) for the host epilogue.
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_terms_kernel(const uint32_t* __restrict__ seg_s,
+                                                              const uint32_t* __restrict__ seg_a, MsmPlan pl,
                                                               uint64_t* __restrict__ terms) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
-    uint64_t* lds = reinterpret_cast<uint64_t*>(zk_dyn_lds);   // MSM_BLOCK x 24 u64
+    uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);   // MSM_BLOCK x 64 u32
     const uint32_t w = blockIdx.x / pl.n_terms, t = blockIdx.x % pl.n_terms;
-    const uint64_t* src = (t == 0 ? seg_a : seg_s) + (size_t)w * pl.ns * 24;
-    G1Xyzz acc = G1Xyzz::identity();
+    const uint32_t* src = (t == 0 ? seg_a : seg_s) + (size_t)w * pl.ns * 64;
+    G1XyzzU acc = G1XyzzU::identity();
     for (uint32_t s = threadIdx.x; s < pl.ns; s += MSM_BLOCK) {
         if (t != 0 && !((s >> (t - 1)) & 1)) continue;
-        G1Xyzz v = load_xyzz(src, s);
-        g1_add(acc, v);
+        G1XyzzU v = load_xyzz_u(src, s);
+        g1u_add(acc, v);
     }
-    store_xyzz(lds, threadIdx.x, acc);
+    store_xyzz_u(lds, threadIdx.x, acc);
     __syncthreads();
     for (int d = MSM_BLOCK / 2; d >= 1; d >>= 1) {
         if ((int)threadIdx.x < d) {
-            G1Xyzz o = load_xyzz(lds, threadIdx.x + d);
-            g1_add(acc, o);
-            store_xyzz(lds, threadIdx.x, acc);
+            G1XyzzU o = load_xyzz_u(lds, threadIdx.x + d);
+            g1u_add(acc, o);
+            store_xyzz_u(lds, threadIdx.x, acc);
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) store_xyzz(terms, blockIdx.x, acc);
+    if (threadIdx.x == 0) {
+        uint64_t* o = terms + 24 * (size_t)blockIdx.x;
+        store_fq(o, fqu_to_ark(acc.x));
+        store_fq(o + 6, fqu_to_ark(acc.y));
+        store_fq(o + 12, fqu_to_ark(acc.zz));
+        store_fq(o + 18, fqu_to_ark(acc.zzz));
+    }
 }
 
 }  // namespace zk
