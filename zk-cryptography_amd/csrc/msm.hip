@@ -33,6 +33,9 @@ static MsmPlan msm_plan(size_t n) {
     pl.ns = pl.nb / MSM_SEG;
     pl.n_bits = c - 1 - MSM_SEG_LOG;
     pl.n_terms = 1 + pl.n_bits;
+    pl.sub_bits = (c - 1) < 8 ? (c - 1) : 8;
+    pl.parts_pw = pl.nb >> pl.sub_bits;
+    pl.n_parts = pl.n_windows * pl.parts_pw;     // c = 16: 16 * 128 = 2048; small c: n_windows <= 64
     return pl;
 }
 
@@ -60,7 +63,12 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     const size_t o_tiles = o_order + al(n_buckets * 4);
     const size_t o_bins = o_tiles + al(((n_buckets + SCAN_TILE - 1) / SCAN_TILE) * 4);
     const size_t o_sorted = o_bins + al(MSM_COUNT_BINS * 4);
-    const size_t o_points = o_sorted + al(n * pl.n_windows * 4);        // SRS in the internal 28-bit-limb layout
+    const size_t n_wgs = (n + SORT_TILE - 1) / SORT_TILE;
+    const size_t o_items = o_sorted + al(n * pl.n_windows * 4);
+    const size_t o_wgc = o_items + al(n * pl.n_windows * 8);
+    const size_t o_pcnt = o_wgc + al(n_wgs * pl.n_parts * 4);
+    const size_t o_poff = o_pcnt + al((pl.n_parts + 1) * 4);
+    const size_t o_points = o_poff + al((pl.n_parts + 1) * 4);          // SRS in the internal 28-bit-limb layout
     const size_t o_buckets = o_points + al(n * 128);
     const size_t o_segs = o_buckets + al(n_buckets * 256);
     const size_t o_sega = o_segs + al(n_segments * 256);
@@ -76,38 +84,37 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     uint32_t* tiles = (uint32_t*)(ws + o_tiles);
     uint32_t* bins = (uint32_t*)(ws + o_bins);
     uint32_t* points_u = (uint32_t*)(ws + o_points);
+    uint2* items = (uint2*)(ws + o_items);
+    uint32_t* wg_counts = (uint32_t*)(ws + o_wgc);
+    uint32_t* part_count = (uint32_t*)(ws + o_pcnt);
+    uint32_t* part_off = (uint32_t*)(ws + o_poff);
     uint32_t* buckets = (uint32_t*)(ws + o_buckets);
     uint32_t* segs = (uint32_t*)(ws + o_segs);
     uint32_t* sega = (uint32_t*)(ws + o_sega);
     uint64_t* terms = (uint64_t*)(ws + o_terms);
 
-    ZK_HIP(c, hipMemsetAsync(counts, 0, n_buckets * 4, c->stream));
+    if (pl.n_parts > (uint32_t)SORT_MAX_PARTS) return ZKHIP_ERR_SHAPE;
     const int grid_n = (int)std::min<size_t>((n + MSM_BLOCK - 1) / MSM_BLOCK, 256 * 8);
     {
         ProfScope ps(c, "msm_convert_points", 224.0 * (double)n);
         hipLaunchKernelGGL(msm_convert_points_kernel, dim3(grid_n), dim3(MSM_BLOCK), 0, c->stream, d_points_xy, n, points_u);
     }
-    {
-        ProfScope ps(c, "msm_hist", 32.0 * (double)n);
-        hipLaunchKernelGGL(msm_hist_kernel, dim3(grid_n), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl, counts);
+    {   // two-level counting sort of the (point, window) pairs by bucket; also yields counts[] and offsets[]
+        ProfScope ps(c, "msm_sort", 32.0 * (double)n);
+        hipLaunchKernelGGL(msm_sort_count_kernel, dim3((unsigned)n_wgs), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl, wg_counts);
+        hipLaunchKernelGGL(msm_sort_bases_kernel, dim3((pl.n_parts + MSM_BLOCK - 1) / MSM_BLOCK), dim3(MSM_BLOCK), 0, c->stream, wg_counts,
+                           (uint32_t)n_wgs, pl.n_parts, part_count);
+        hipLaunchKernelGGL(msm_sort_part_scan_kernel, dim3(1), dim3(1024), 0, c->stream, part_count, pl.n_parts, part_off);
+        hipLaunchKernelGGL(msm_sort_scatter_kernel, dim3((unsigned)n_wgs), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl,
+                           wg_counts, part_off, items);
+        hipLaunchKernelGGL(msm_sort_local_kernel, dim3(pl.n_parts), dim3(MSM_BLOCK), 0, c->stream, items, part_off, pl, sorted, counts, offsets);
     }
-    {
-        const uint32_t n_tiles = (uint32_t)((n_buckets + SCAN_TILE - 1) / SCAN_TILE);
-        if (n_tiles > 65536) return ZKHIP_ERR_SHAPE;
-        ProfScope ps(c, "msm_scan", 0.0);
-        hipLaunchKernelGGL(msm_scan_tiles_kernel, dim3(n_tiles), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, tiles);
-        hipLaunchKernelGGL(msm_scan_top_kernel, dim3(1), dim3(1024), 0, c->stream, tiles, n_tiles);
-        hipLaunchKernelGGL(msm_scan_finish_kernel, dim3(n_tiles), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, tiles, offsets, cursor);
-        // bucket order by descending point count
+    {   // bucket order by descending point count
         const unsigned gb = (unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK);
         ZK_HIP(c, hipMemsetAsync(bins, 0, MSM_COUNT_BINS * 4, c->stream));
         hipLaunchKernelGGL(msm_order_hist_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins);
         hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bins);
         hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins, order);
-    }
-    {
-        ProfScope ps(c, "msm_scatter", 32.0 * (double)n);
-        hipLaunchKernelGGL(msm_scatter_kernel, dim3(grid_n), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl, cursor, sorted);
     }
     {
         ProfScope ps(c, "msm_accumulate", 128.0 * (double)n);

@@ -35,6 +35,9 @@ struct MsmPlan {
     uint32_t ns;         // segments per window = nb / L
     uint32_t n_bits;     // bits of the segment index = c - 1 - log2 L
     uint32_t n_terms;    // 1 + n_bits
+    uint32_t sub_bits;   // low bits of the bucket index resolved inside a partition (<= 8)
+    uint32_t parts_pw;   // partitions per window = nb >> sub_bits
+    uint32_t n_parts;    // n_windows * parts_pw (<= 2048)
 };
 
 // Signed base-2^c digit stream of a canonical scalar (8 x u32, little endian); digits lie in [-nb, nb].
@@ -194,6 +197,138 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_scatter_kernel(const uin
             const uint32_t pos = atomicAdd(&cursor[w * pl.nb + mag - 1], 1u);
             sorted[pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
         }
+    }
+}
+
+// ---- counting sort in two levels, without global atomics -------------------------------------------------
+// Level 1 splits the (point, window) pairs by (window, high bits of the bucket) into <= 2048 partitions; a workgroup
+// counts its tile in LDS (sort_count), a column scan turns the per-workgroup counts into exclusive write positions
+// (sort_bases), and the same tile walk scatters 8-byte items (sort_scatter).  Level 2 runs one workgroup per
+// partition: the low <= 8 bucket bits are resolved in LDS, which also yields every bucket's count and offset.
+constexpr int SORT_TILE = 2048;          // scalars per workgroup tile (8 per lane)
+constexpr int SORT_MAX_PARTS = 2048;
+
+__device__ __forceinline__ uint32_t msm_partition_of(uint32_t w, uint32_t mag, const MsmPlan& pl) {
+    return w * pl.parts_pw + ((mag - 1) >> pl.sub_bits);
+}
+
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_count_kernel(const uint64_t* __restrict__ scalars,
+                                                                          const uint8_t* __restrict__ inf, size_t n, MsmPlan pl,
+                                                                          uint32_t* __restrict__ wg_counts) {
+    __shared__ uint32_t local[SORT_MAX_PARTS];
+    for (uint32_t i = threadIdx.x; i < pl.n_parts; i += MSM_BLOCK) local[i] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SORT_TILE;
+    for (uint32_t u = 0; u < SORT_TILE / MSM_BLOCK; ++u) {
+        const size_t i = base + u * MSM_BLOCK + threadIdx.x;
+        if (i >= n || (inf && inf[i])) continue;
+        DigitStream ds(load_fr(scalars, i).from_mont());
+        for (uint32_t w = 0; w < pl.n_windows; ++w) {
+            const int32_t d = ds.next(pl);
+            if (d == 0) continue;
+            atomicAdd(&local[msm_partition_of(w, d < 0 ? (uint32_t)(-d) : (uint32_t)d, pl)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < pl.n_parts; i += MSM_BLOCK) wg_counts[(size_t)blockIdx.x * pl.n_parts + i] = local[i];
+}
+
+// per partition: exclusive scan of the workgroups' counts (in place) and the partition total
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_bases_kernel(uint32_t* __restrict__ wg_counts, uint32_t n_wgs,
+                                                                          uint32_t n_parts, uint32_t* __restrict__ part_count) {
+    const uint32_t p = blockIdx.x * MSM_BLOCK + threadIdx.x;
+    if (p >= n_parts) return;
+    uint32_t run = 0;
+    for (uint32_t g = 0; g < n_wgs; ++g) {
+        const uint32_t c = wg_counts[(size_t)g * n_parts + p];
+        wg_counts[(size_t)g * n_parts + p] = run;
+        run += c;
+    }
+    part_count[p] = run;
+}
+// exclusive scan of <= 2048 partition totals by one workgroup; part_off[n_parts] = grand total
+static __global__ __launch_bounds__(1024) void msm_sort_part_scan_kernel(const uint32_t* __restrict__ part_count, uint32_t n_parts,
+                                                                         uint32_t* __restrict__ part_off) {
+    __shared__ uint32_t part[1024];
+    const uint32_t a = 2 * threadIdx.x, b = a + 1;
+    const uint32_t va = a < n_parts ? part_count[a] : 0, vb = b < n_parts ? part_count[b] : 0;
+    part[threadIdx.x] = va + vb;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const uint32_t excl = part[threadIdx.x] - (va + vb);
+    if (a < n_parts) part_off[a] = excl;
+    if (b < n_parts) part_off[b] = excl + va;
+    if (threadIdx.x == 1023) part_off[n_parts] = part[1023];
+}
+
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_scatter_kernel(const uint64_t* __restrict__ scalars,
+                                                                            const uint8_t* __restrict__ inf, size_t n, MsmPlan pl,
+                                                                            const uint32_t* __restrict__ wg_bases,
+                                                                            const uint32_t* __restrict__ part_off,
+                                                                            uint2* __restrict__ items) {
+    __shared__ uint32_t cur[SORT_MAX_PARTS];
+    for (uint32_t i = threadIdx.x; i < pl.n_parts; i += MSM_BLOCK)
+        cur[i] = part_off[i] + wg_bases[(size_t)blockIdx.x * pl.n_parts + i];
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SORT_TILE;
+    const uint32_t sub_mask = (1u << pl.sub_bits) - 1;
+    for (uint32_t u = 0; u < SORT_TILE / MSM_BLOCK; ++u) {
+        const size_t i = base + u * MSM_BLOCK + threadIdx.x;
+        if (i >= n || (inf && inf[i])) continue;
+        DigitStream ds(load_fr(scalars, i).from_mont());
+        for (uint32_t w = 0; w < pl.n_windows; ++w) {
+            const int32_t d = ds.next(pl);
+            if (d == 0) continue;
+            const bool neg = d < 0;
+            const uint32_t mag = neg ? (uint32_t)(-d) : (uint32_t)d;
+            const uint32_t pos = atomicAdd(&cur[msm_partition_of(w, mag, pl)], 1u);
+            items[pos] = make_uint2((uint32_t)i | (neg ? 0x80000000u : 0u), (mag - 1) & sub_mask);
+        }
+    }
+}
+
+// level 2: one workgroup per partition; writes the final order plus counts / offsets of its 2^sub_bits buckets
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_local_kernel(const uint2* __restrict__ items,
+                                                                          const uint32_t* __restrict__ part_off, MsmPlan pl,
+                                                                          uint32_t* __restrict__ sorted,
+                                                                          uint32_t* __restrict__ counts,
+                                                                          uint32_t* __restrict__ offsets) {
+    __shared__ uint32_t bins[256];
+    __shared__ uint32_t scan[256];
+    const uint32_t p = blockIdx.x;
+    const uint32_t lo = part_off[p], hi = part_off[p + 1];
+    const uint32_t n_sub = 1u << pl.sub_bits;
+    if (threadIdx.x < 256) bins[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t q = lo + threadIdx.x; q < hi; q += MSM_BLOCK) atomicAdd(&bins[items[q].y], 1u);
+    __syncthreads();
+    // exclusive scan of the (<= 256) bins
+    const uint32_t v = threadIdx.x < n_sub ? bins[threadIdx.x] : 0;
+    scan[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        uint32_t t = threadIdx.x >= d ? scan[threadIdx.x - d] : 0;
+        __syncthreads();
+        scan[threadIdx.x] += t;
+        __syncthreads();
+    }
+    const uint32_t excl = scan[threadIdx.x] - v;
+    if (threadIdx.x < n_sub) {
+        const uint32_t w = p / pl.parts_pw, top = p % pl.parts_pw;
+        const uint32_t bucket = w * pl.nb + (top << pl.sub_bits) + threadIdx.x;
+        counts[bucket] = v;
+        offsets[bucket] = lo + excl;
+        bins[threadIdx.x] = lo + excl;      // becomes the write cursor
+    }
+    __syncthreads();
+    for (uint32_t q = lo + threadIdx.x; q < hi; q += MSM_BLOCK) {
+        const uint2 it = items[q];
+        sorted[atomicAdd(&bins[it.y], 1u)] = it.x;
     }
 }
 
