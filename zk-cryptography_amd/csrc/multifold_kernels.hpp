@@ -77,29 +77,33 @@ struct SmallArgs {
 // cut into 2^l blocks; the leaves are the table).  Folding the table at variable 0 folds every level the same way:
 //     new[q] = old[q + p] + r * (old[q + 2p] - old[q + p]),  p = largest power of two <= q,
 // so after a fold the next round polynomial (lo, hi) = new[2], new[3] is available WITHOUT a reduction, and every
-// node is independent work.  Wave 0 runs nothing but the transcript chain (the critical path) plus the two
-// products that give it the next (lo, hi); waves 1-3 fold the rest of the tree (and the k-variable fold weights)
-// behind it.  One barrier per round; the trees and the challenge slot are double-buffered.
+// node is independent work.
+// The tree is kept in CANONICAL (non-Montgomery) form: the transcript absorbs canonical bytes, so (lo, hi) need no
+// conversion, and a product of a Montgomery-form challenge with a canonical difference is again canonical.
+// Wave 0 runs nothing but the transcript chain plus ONE product per round (challenge_canonical * E, where
+// E = to_mont(hi' - lo') was prepared a round earlier); waves 1-3 convert the challenge, fold the rest of the tree
+// and the k-variable fold weights, and write the outputs (Montgomery form) behind it.  One barrier per round; the
+// trees, E and the challenge slot are double-buffered.
 static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallArgs a, SumcheckDev* st,
                                                                           uint64_t* __restrict__ round_polys,
                                                                           uint64_t* __restrict__ challenges) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
     const uint32_t n = 1u << a.log_n;
-    Fr* tree0 = reinterpret_cast<Fr*>(zk_dyn_lds);      // 2n nodes each
+    Fr* tree0 = reinterpret_cast<Fr*>(zk_dyn_lds);      // 2n nodes each, canonical values
     Fr* tree1 = tree0 + 2 * n;
-    Fr* w0 = tree1 + 2 * n;                             // weights, ping / pong
+    Fr* w0 = tree1 + 2 * n;                             // weights (Montgomery), ping / pong
     Fr* w1 = w0 + (1u << MF_MAX_LOGK);
     Fr* scratch = w1 + (1u << MF_MAX_LOGK);             // MLE_BLOCK
-    Fr* conv = scratch + MLE_BLOCK;                     // 4
-    Fr* r_sh = conv + 4;                                // 2
-    // ---- leaves
+    Fr* e_sh = scratch + MLE_BLOCK;                     // 2 x 2: to_mont(level-2 differences) of tree0 / tree1
+    Fr* r_sh = e_sh + 4;                                // 2: canonical challenge, double-buffered
+    // ---- leaves (sums are taken in Montgomery form, then converted once)
     if (a.group == 0) {
-        for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) tree0[n + j] = load_fr(a.src, j);
+        for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) tree0[n + j] = load_fr(a.src, j).from_mont();
     } else if (a.stride != 0) {   // all-gathered per-rank block sums: add the ranks' contributions in rank order
         for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) {
             Fr s = load_fr(a.src, j);
             for (uint32_t g = 1; g < a.group; ++g) s = s + load_fr(a.src, (size_t)g * a.stride + j);
-            tree0[n + j] = s;
+            tree0[n + j] = s.from_mont();
         }
     } else {
         const uint32_t total = n * a.group;
@@ -114,7 +118,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
         for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) {
             Fr s = scratch[j * tpe];
             for (uint32_t g = 1; g < tpe; ++g) s = s + scratch[j * tpe + g];
-            tree0[n + j] = s;
+            tree0[n + j] = s.from_mont();
         }
     }
     if (threadIdx.x == 0 && a.weights_out) {
@@ -131,47 +135,69 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
         for (uint32_t b = threadIdx.x; b < cnt; b += MLE_BLOCK) tree0[cnt + b] = tree0[2 * cnt + 2 * b] + tree0[2 * cnt + 2 * b + 1];
         __syncthreads();
     }
+    if (threadIdx.x < 2 && a.log_n >= 2) e_sh[threadIdx.x] = (tree0[6 + threadIdx.x] - tree0[4 + threadIdx.x]).to_mont();
+    __syncthreads();
     const bool wave0 = threadIdx.x < 64;
     Transcript tr;
     if (wave0 && !a.first) tr.load(&st->transcript);
-    Fr lo = tree0[2], hi = tree0[3];
+    Fr lo = tree0[2], hi = tree0[3];     // canonical
     uint32_t depth = a.log_n, round = a.round0, n_w = 1;
     for (uint32_t it = 0; it < a.n_rounds; ++it) {
         Fr* told = (it & 1) ? tree1 : tree0;
         Fr* tnew = (it & 1) ? tree0 : tree1;
         Fr* wold = (it & 1) ? w1 : w0;
         Fr* wnew = (it & 1) ? w0 : w1;
+        Fr* eold = e_sh + 2 * (it & 1);
+        Fr* enew = e_sh + 2 * ((it & 1) ^ 1);
+        const bool absorb_sum = a.first && it == 0;
         if (wave0) {
-            const bool absorb_sum = a.first && it == 0;
-            Fr sum = Fr::zero();
             if (absorb_sum) {
-                sum = (a.first == 2) ? fr_from_arg(a.claimed) : (a.first == 3) ? load_fr(a.d_claimed, 0) : lo + hi;
+                Fr sum_c = (a.first == 2) ? fr_from_mont_outlined(fr_from_arg(a.claimed))
+                         : (a.first == 3) ? fr_from_mont_outlined(load_fr(a.d_claimed, 0)) : lo + hi;
                 tr.init();
+                tr.commit_canonical(sum_c);
             }
-            Fr r = transcript_round(tr, conv, sum, lo, hi, absorb_sum);
-            if (threadIdx.x == 0) {
-                if (absorb_sum) store_fr(st->sum, 0, sum);
-                r_sh[it & 1] = r;
-                store_fr(round_polys, 2 * (size_t)round, lo);
-                store_fr(round_polys, 2 * (size_t)round + 1, hi);
-                store_fr(challenges, round, r);
-            }
+            tr.commit_canonical(lo);     // uni_poly.to_bytes()  sumcheck.rs:42
+            tr.commit_canonical(hi);
+            Fr c = tr.challenge_canonical();   // :46, still canonical
+            if (threadIdx.x == 0) r_sh[it & 1] = c;
         }
-        __syncthreads();   // challenge published; tree `told` complete
-        const Fr r = r_sh[it & 1];
+        __syncthreads();   // challenge published; tree `told` and `eold` complete
+        const Fr c = r_sh[it & 1];
         if (wave0) {
-            if (depth >= 2) {   // next round polynomial straight from level 2 of the old tree
-                const uint32_t q = 2 + (threadIdx.x & 1);
-                Fr v = fold_pair(told[q + 2], told[q + 4], r);
+            if (depth >= 2) {   // next round polynomial straight from level 2 of the old tree: lo' = t[4] + c * (t[6] - t[4])
+                const uint32_t q = threadIdx.x & 1;
+                Fr v = told[4 + q] + fr_mul_outlined(c, eold[q]);
                 lo = shfl_fr(v, 0);
                 hi = shfl_fr(v, 1);
             }
         } else {
+            const Fr r = fr_to_mont_outlined(c);       // every helper wave converts for itself (no extra sync)
             const uint32_t helper = threadIdx.x - 64, n_helpers = MLE_BLOCK - 64;
-            const uint32_t nodes = 1u << (depth - 1);   // new tree has nodes 1 .. 2^(depth-1+1)-1 = 2*nodes - 1
+            if (helper == 0) {   // outputs of this round, in Montgomery form as the reference holds them
+                Fr lo_m = told[2].to_mont(), hi_m = told[3].to_mont();
+                if (absorb_sum) {
+                    Fr sum_m = (a.first == 2) ? fr_from_arg(a.claimed) : (a.first == 3) ? load_fr(a.d_claimed, 0) : lo_m + hi_m;
+                    store_fr(st->sum, 0, sum_m);
+                }
+                store_fr(round_polys, 2 * (size_t)round, lo_m);
+                store_fr(round_polys, 2 * (size_t)round + 1, hi_m);
+                store_fr(challenges, round, r);
+            }
+            const uint32_t nodes = 1u << (depth - 1);   // the new tree has nodes 1 .. 2*nodes - 1
+            if (helper >= 62 && helper < 64 && depth >= 3) {
+                // lanes 62, 63 of helper wave 0: new level 2 pair (q, q+2) and the product wave 0 will need next round
+                const uint32_t q = 4 + (helper - 62);
+                Fr va = told[q + 4] + r * (told[q + 8] - told[q + 4]);           // new[q],   p = 4
+                Fr vb = told[q + 6] + r * (told[q + 10] - told[q + 6]);          // new[q+2], p = 4
+                tnew[q] = va;
+                tnew[q + 2] = vb;
+                enew[helper - 62] = (vb - va).to_mont();
+            }
             for (uint32_t q = 1 + helper; q < 2 * nodes; q += n_helpers) {
+                if (depth >= 3 && q >= 4 && q < 8) continue;                     // done above
                 const uint32_t p = 1u << (31 - __builtin_clz(q));
-                tnew[q] = fold_pair(told[q + p], told[q + 2 * p], r);
+                tnew[q] = told[q + p] + r * (told[q + 2 * p] - told[q + p]);
             }
             if (a.weights_out) {   // eq weights: the index gains the new variable as its least significant bit
                 for (uint32_t b = helper; b < n_w; b += n_helpers) {
@@ -194,7 +220,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
     if (a.final_out) {
         Fr* t = (a.n_rounds & 1) ? tree1 : tree0;
         const uint32_t cnt = 1u << depth;
-        for (uint32_t j = threadIdx.x; j < cnt; j += MLE_BLOCK) store_fr(a.final_out, j, t[cnt + j]);
+        for (uint32_t j = threadIdx.x; j < cnt; j += MLE_BLOCK) store_fr(a.final_out, j, t[cnt + j].to_mont());
     }
 }
 __host__ __device__ constexpr size_t small_lds_bytes(uint32_t log_n) {

@@ -201,7 +201,8 @@ struct Transcript {
     }
     // evaluate_challenge_into_field: from_be_bytes_mod_order(digest)  fiat_shamir.rs:27-29.
     // digest < 2^256 < 3r, so at most two subtractions of r bring it into range.  Returns Montgomery form.
-    __device__ __forceinline__ Fr challenge_fr() {
+    // canonical integer of the challenge (digest mod r); the Montgomery form is one more product away
+    __device__ __forceinline__ Fr challenge_canonical() {
         uint32_t d[8];
         challenge(d);
         Fr v;
@@ -209,8 +210,9 @@ struct Transcript {
         for (int i = 0; i < 8; ++i) v.l[i] = d[7 - i];
         v.reduce_once();
         v.reduce_once();
-        return fr_to_mont_outlined(v);
+        return v;
     }
+    __device__ __forceinline__ Fr challenge_fr() { return fr_to_mont_outlined(challenge_canonical()); }
 };
 
 }  // namespace zk
