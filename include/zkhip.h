@@ -60,6 +60,13 @@ int zkhip_memcpy_d2h(zkhip_ctx *ctx, void *h_dst, const void *d_src, size_t byte
 int zkhip_profile_enable(zkhip_ctx *ctx, int enable);
 int zkhip_profile_read(zkhip_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches, double *bytes);
 
+/* ---- host-side Fr helpers (what `Fr::from(..)`, `into_bigint()` and the field operators are to a Rust caller) --- */
+int zkhip_fr_from_i64(int64_t v, uint64_t *h_out);                       /* Fr::from(v): Montgomery limbs of v mod r */
+int zkhip_fr_to_canonical(const uint64_t *h_in, uint64_t *h_out);         /* into_bigint(): canonical LE limbs */
+int zkhip_fr_add(const uint64_t *h_a, const uint64_t *h_b, uint64_t *h_out);
+int zkhip_fr_sub(const uint64_t *h_a, const uint64_t *h_b, uint64_t *h_out);
+int zkhip_fr_mul(const uint64_t *h_a, const uint64_t *h_b, uint64_t *h_out);
+
 /* ---- Multilinear (polynomial/src/multilinear/evaluation_form.rs) -------------------- */
 /* MultilinearTrait::partial_evaluation (interface.rs:9-13, evaluation_form.rs:123-141):
  * d_out[n/2] = fold of variable var_index at point r.  r may live on the host (h_r) or on the

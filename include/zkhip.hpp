@@ -1,0 +1,378 @@
+// zkhip.hpp -- C++ host mirror of the reference's Rust surfaces for the hot path, header-only over the C ABI
+// (include/zkhip.h).  No Rust toolchain exists in the build image, so this C++ layer plays the role of the Rust
+// shim: same type and method names, same argument meaning, and the reference's assert!/panic! surface as C++
+// exceptions (zkc::Panic carries the reference's message).  Device memory comes from zkhip_malloc; nothing here
+// needs PyTorch.
+//
+//   polynomial::Multilinear / MultilinearTrait         polynomial/src/multilinear/evaluation_form.rs, interface.rs:9-13
+//   polynomial::ComposedMultilinear                    polynomial/src/composed/composed_multilinear.rs
+//   sumcheck::{Sumcheck, ComposedSumcheck, MultiComposedSumcheckProver}   sumcheck/src/**
+//   kzg::{TrustedSetup, MultilinearKZG, UnivariateKZG} kzg/src/{trusted_setup,multilinear_kzg,univariate_kzg}.rs
+//   polynomial::univariate::{Domain, UnivariateEval, DenseUnivariatePolynomial}
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "zkhip.h"
+
+namespace zkc {
+
+struct Panic : std::runtime_error { using std::runtime_error::runtime_error; };
+
+inline void check(int st, const char* what) {
+    if (st == ZKHIP_OK) return;
+    throw Panic(std::string(what) + ": " + zkhip_status_string(st));
+}
+
+// ---- Fr (ark_test_curves::bls12_381::Fr as the reference's tests use it) -----------------------------------
+struct Fr {
+    uint64_t l[4];
+    static Fr from(int64_t v) { Fr r; zkhip_fr_from_i64(v, r.l); return r; }
+    static Fr zero() { return from(0); }
+    static Fr one() { return from(1); }
+    bool operator==(const Fr& o) const { return std::memcmp(l, o.l, 32) == 0; }
+    bool operator!=(const Fr& o) const { return !(*this == o); }
+    Fr operator+(const Fr& o) const { Fr r; zkhip_fr_add(l, o.l, r.l); return r; }
+    Fr operator-(const Fr& o) const { Fr r; zkhip_fr_sub(l, o.l, r.l); return r; }
+    Fr operator*(const Fr& o) const { Fr r; zkhip_fr_mul(l, o.l, r.l); return r; }
+    std::vector<uint8_t> to_bytes_be() const {   // into_bigint().to_bytes_be()
+        uint64_t c[4];
+        zkhip_fr_to_canonical(l, c);
+        std::vector<uint8_t> b(32);
+        for (int i = 0; i < 4; ++i) for (int k = 0; k < 8; ++k) b[31 - (8 * i + k)] = (uint8_t)(c[i] >> (8 * k));
+        return b;
+    }
+};
+static_assert(sizeof(Fr) == 32, "Fr must be 4 x u64");
+
+// ---- context + device memory -------------------------------------------------------------------------------
+class Context {
+  public:
+    explicit Context(int device = 0) { check(zkhip_ctx_create(&c_, device, nullptr), "zkhip_ctx_create"); }
+    ~Context() { if (c_) zkhip_ctx_destroy(c_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    zkhip_ctx* raw() const { return c_; }
+    static Context& instance() { static Context ctx(0); return ctx; }
+  private:
+    zkhip_ctx* c_ = nullptr;
+};
+
+class DeviceBuffer {   // owns `bytes` of device memory
+  public:
+    DeviceBuffer() = default;
+    explicit DeviceBuffer(size_t bytes) : bytes_(bytes) { check(zkhip_malloc(Context::instance().raw(), &p_, bytes ? bytes : 1), "zkhip_malloc"); }
+    ~DeviceBuffer() { if (p_) zkhip_free(Context::instance().raw(), p_); }
+    DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; o.bytes_ = 0; }
+    DeviceBuffer& operator=(DeviceBuffer&& o) noexcept { std::swap(p_, o.p_); std::swap(bytes_, o.bytes_); return *this; }
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    uint64_t* u64() const { return (uint64_t*)p_; }
+    uint8_t* u8() const { return (uint8_t*)p_; }
+    size_t bytes() const { return bytes_; }
+    void upload(const void* h, size_t n) { check(zkhip_memcpy_h2d(Context::instance().raw(), p_, h, n), "h2d"); }
+    void download(void* h, size_t n) const { check(zkhip_memcpy_d2h(Context::instance().raw(), h, p_, n), "d2h"); }
+  private:
+    void* p_ = nullptr;
+    size_t bytes_ = 0;
+};
+
+inline zkhip_ctx* ctx() { return Context::instance().raw(); }
+
+// ---- polynomial::Multilinear ------------------------------------------------------------------------------------
+class Multilinear {
+  public:
+    size_t n_vars = 0;
+    // Multilinear::new (evaluation_form.rs:12-26)
+    explicit Multilinear(const std::vector<Fr>& evaluations) : n_(evaluations.size()), dev_(std::make_shared<DeviceBuffer>(32 * evaluations.size())) {
+        if (n_ == 0 || (n_ & (n_ - 1))) throw Panic("Number of evaluations must be a power of 2");
+        while (((size_t)1 << n_vars) < n_) ++n_vars;
+        dev_->upload(evaluations.data(), 32 * n_);
+    }
+    size_t len() const { return n_; }
+    const uint64_t* device() const { return dev_->u64(); }
+    std::vector<Fr> evaluations() const { std::vector<Fr> v(n_); dev_->download(v.data(), 32 * n_); return v; }
+    bool operator==(const Multilinear& o) const { return n_vars == o.n_vars && evaluations() == o.evaluations(); }
+
+    // MultilinearTrait (interface.rs:9-13)
+    Multilinear partial_evaluation(const Fr& eval_point, size_t variable_index) const {   // evaluation_form.rs:123-141
+        if (n_ % 2 != 0) throw Panic("n must be even");                                     // utils.rs:30
+        if (!(variable_index < n_ / 2)) throw Panic("variable_index must be less than n/2"); // utils.rs:31-34
+        Multilinear out(n_ / 2, n_vars - 1);
+        check(zkhip_mle_partial_evaluation(ctx(), device(), n_, eval_point.l, nullptr, (uint32_t)variable_index, out.dev_->u64()),
+              "variable_index must be less than n/2");
+        return out;
+    }
+    Multilinear partial_evaluations(const std::vector<Fr>& points, const std::vector<size_t>& variable_indices) const {   // :143-159
+        if (points.size() != variable_indices.size())
+            throw Panic("The length of evaluation_points and variable_indices should be the same");
+        std::vector<uint32_t> idx(variable_indices.begin(), variable_indices.end());
+        Multilinear out(n_ >> points.size(), n_vars - points.size());
+        check(zkhip_mle_partial_evaluations(ctx(), device(), n_, points.empty() ? nullptr : points[0].l, idx.data(), points.size(), out.dev_->u64()),
+              "partial_evaluations");
+        return out;
+    }
+    Fr evaluation(const std::vector<Fr>& evaluation_points) const {   // :162-175
+        if (evaluation_points.size() != n_vars) throw Panic("Number of evaluation points must match the number of variables");
+        Fr r;
+        check(zkhip_mle_evaluation(ctx(), device(), n_, evaluation_points.empty() ? nullptr : evaluation_points[0].l, evaluation_points.size(), r.l),
+              "evaluation");
+        return r;
+    }
+    Multilinear split_poly_into_two_and_sum_each_part() const {   // :68-74
+        uint64_t h[12];
+        check(zkhip_mle_half_sums(ctx(), device(), n_, h), "half_sums");
+        Fr lo, hi;
+        std::memcpy(lo.l, h, 32); std::memcpy(hi.l, h + 4, 32);
+        return Multilinear(std::vector<Fr>{lo, hi});
+    }
+    Fr sum_over_the_boolean_hypercube() const {   // :80-84
+        if (n_ == 1) return evaluations()[0];
+        uint64_t h[12];
+        check(zkhip_mle_half_sums(ctx(), device(), n_, h), "half_sums");
+        Fr t; std::memcpy(t.l, h + 8, 32); return t;
+    }
+    Multilinear add_distinct(const Multilinear& rhs) const { return distinct(rhs, false); }   // :28-39
+    Multilinear mul_distinct(const Multilinear& rhs) const { return distinct(rhs, true); }    // :41-52
+    std::vector<uint8_t> to_bytes() const {   // :54-62
+        DeviceBuffer b(32 * n_);
+        check(zkhip_mle_to_bytes(ctx(), device(), n_, b.u8()), "to_bytes");
+        std::vector<uint8_t> out(32 * n_);
+        b.download(out.data(), out.size());
+        return out;
+    }
+    Multilinear operator+(const Multilinear& o) const { return elementwise(0, &o, nullptr); }   // :178-194
+    Multilinear operator-(const Multilinear& o) const { return elementwise(1, &o, nullptr); }   // :208-224
+    Multilinear operator*(const Fr& s) const { return elementwise(2, nullptr, &s); }            // :235-251
+
+  private:
+    Multilinear(size_t n, size_t nv) : n_vars(nv), n_(n), dev_(std::make_shared<DeviceBuffer>(32 * (n ? n : 1))) {}
+    Multilinear distinct(const Multilinear& rhs, bool mul) const {
+        Multilinear out(n_ * rhs.n_, n_vars + rhs.n_vars);
+        check((mul ? zkhip_mle_mul_distinct : zkhip_mle_add_distinct)(ctx(), device(), n_, rhs.device(), rhs.n_, out.dev_->u64()), "distinct");
+        return out;
+    }
+    Multilinear elementwise(int op, const Multilinear* o, const Fr* s) const {
+        Multilinear out(n_, n_vars);
+        check(zkhip_mle_elementwise(ctx(), op, device(), o ? o->device() : nullptr, s ? s->l : nullptr, n_, out.dev_->u64()), "elementwise");
+        return out;
+    }
+    size_t n_ = 0;
+    std::shared_ptr<DeviceBuffer> dev_;
+    friend class Sumcheck;
+    friend class ComposedMultilinear;
+};
+
+// ---- sumcheck::Sumcheck (sumcheck/src/sumcheck.rs) --------------------------------------------------------------
+struct SumcheckProof {
+    Multilinear poly;
+    Fr sum;
+    std::vector<Multilinear> univariate_poly;   // one 2-evaluation polynomial per round (:11-15)
+};
+class Sumcheck {
+  public:
+    explicit Sumcheck(Multilinear poly) : poly_(std::move(poly)), sum_(Fr::zero()) {}   // Sumcheck::new :18-23
+    void poly_sum() { sum_ = poly_.sum_over_the_boolean_hypercube(); }                  // :25-27
+    const Fr& sum() const { return sum_; }
+    std::pair<SumcheckProof, std::vector<Fr>> prove() const {                           // :29-61
+        const size_t nv = poly_.n_vars;
+        std::vector<Fr> rp(2 * (nv ? nv : 1)), ch(nv ? nv : 1);
+        Fr s;
+        check(zkhip_sumcheck_prove(ctx(), poly_.device(), poly_.len(), sum_.l, nullptr, nullptr, 0, s.l, rp[0].l, ch[0].l), "sumcheck_prove");
+        SumcheckProof proof{poly_, s, {}};
+        for (size_t i = 0; i < nv; ++i) proof.univariate_poly.emplace_back(std::vector<Fr>{rp[2 * i], rp[2 * i + 1]});
+        ch.resize(nv);
+        return {std::move(proof), std::move(ch)};
+    }
+  private:
+    Multilinear poly_;
+    Fr sum_;
+};
+
+// ---- polynomial::ComposedMultilinear + composed provers ---------------------------------------------------------
+class ComposedMultilinear {
+  public:
+    explicit ComposedMultilinear(std::vector<Multilinear> polys) : polys(std::move(polys)) {   // composed_multilinear.rs:12-18
+        for (auto& p : this->polys) if (p.n_vars != this->polys[0].n_vars) throw Panic("assertion failed: polys.iter().all(|p| p.n_vars == n_vars)");
+    }
+    std::vector<Multilinear> polys;
+    size_t n_vars() const { return polys[0].n_vars; }
+    size_t max_degree() const { return polys.size(); }                                         // :101-103
+    ComposedMultilinear partial_evaluation(const Fr& r, size_t k) const {                      // :63-75
+        std::vector<Multilinear> out;
+        for (auto& p : polys) out.push_back(p.partial_evaluation(r, k));
+        return ComposedMultilinear(std::move(out));
+    }
+    Fr evaluation(const std::vector<Fr>& pts) const {                                          // :51-61
+        Fr acc = Fr::one();
+        for (auto& p : polys) acc = acc * p.evaluation(pts);
+        return acc;
+    }
+    std::vector<const uint64_t*> ptrs() const { std::vector<const uint64_t*> v; for (auto& p : polys) v.push_back(p.device()); return v; }
+};
+
+struct ComposedSumcheckProof { std::vector<std::vector<Fr>> round_polys; };   // composed_sumcheck.rs:15-18 (poly omitted: caller holds it)
+class ComposedSumcheck {
+  public:
+    explicit ComposedSumcheck(ComposedMultilinear poly) : poly(std::move(poly)) {}
+    ComposedMultilinear poly;
+    static Fr calculate_poly_sum(const ComposedMultilinear& p) {                               // composed_sumcheck.rs:28-30
+        Fr s; auto ptrs = p.ptrs();
+        check(zkhip_composed_sum(ctx(), ptrs.data(), (uint32_t)ptrs.size(), p.polys[0].len(), s.l), "composed_sum");
+        return s;
+    }
+    std::pair<ComposedSumcheckProof, std::vector<Fr>> prove() const {                          // :32-67
+        const size_t nv = poly.n_vars(), k = poly.polys.size();
+        std::vector<Fr> rp((k + 1) * (nv ? nv : 1)), ch(nv ? nv : 1);
+        auto ptrs = poly.ptrs();
+        check(zkhip_composed_prove(ctx(), ptrs.data(), (uint32_t)k, poly.polys[0].len(), rp[0].l, ch[0].l), "composed_prove");
+        ComposedSumcheckProof proof;
+        for (size_t r = 0; r < nv; ++r) proof.round_polys.emplace_back(rp.begin() + r * (k + 1), rp.begin() + (r + 1) * (k + 1));
+        ch.resize(nv);
+        return {std::move(proof), std::move(ch)};
+    }
+};
+
+struct UnivariateMonomial { Fr coeff, pow; };                                                  // sparse_univariate.rs:11-15
+struct SparseUnivariatePolynomial {
+    std::vector<UnivariateMonomial> monomial;
+    std::vector<uint8_t> to_bytes() const {                                                    // :27-34
+        std::vector<uint8_t> out;
+        for (auto& m : monomial) { auto c = m.coeff.to_bytes_be(), p = m.pow.to_bytes_be(); out.insert(out.end(), c.begin(), c.end()); out.insert(out.end(), p.begin(), p.end()); }
+        return out;
+    }
+};
+struct MultiComposedSumcheckProof {                                                            // multi_composed_sumcheck.rs:12-16
+    std::vector<SparseUnivariatePolynomial> round_polys;
+    Fr sum;
+    std::vector<uint8_t> to_bytes() const { std::vector<uint8_t> o; for (auto& r : round_polys) { auto b = r.to_bytes(); o.insert(o.end(), b.begin(), b.end()); } return o; }
+};
+class MultiComposedSumcheckProver {
+  public:
+    static Fr calculate_poly_sum(const std::vector<ComposedMultilinear>& poly) {               // :36-45
+        std::vector<const uint64_t*> ptrs; std::vector<uint32_t> sizes;
+        flatten(poly, ptrs, sizes);
+        Fr s;
+        check(zkhip_multi_composed_sum(ctx(), ptrs.data(), sizes.data(), (uint32_t)sizes.size(), poly[0].polys[0].len(), s.l), "multi_composed_sum");
+        return s;
+    }
+    static std::pair<MultiComposedSumcheckProof, std::vector<Fr>> prove(const std::vector<ComposedMultilinear>& poly, const Fr& sum) { return run(poly, sum, 0); }          // :47-54
+    static std::pair<MultiComposedSumcheckProof, std::vector<Fr>> prove_partial(const std::vector<ComposedMultilinear>& poly, const Fr& sum) { return run(poly, sum, 1); }  // :56-62
+  private:
+    static void flatten(const std::vector<ComposedMultilinear>& poly, std::vector<const uint64_t*>& ptrs, std::vector<uint32_t>& sizes) {
+        for (auto& t : poly) { for (auto& p : t.polys) ptrs.push_back(p.device()); sizes.push_back((uint32_t)t.polys.size()); }
+    }
+    static std::pair<MultiComposedSumcheckProof, std::vector<Fr>> run(const std::vector<ComposedMultilinear>& poly, const Fr& sum, int partial) {
+        std::vector<const uint64_t*> ptrs; std::vector<uint32_t> sizes;
+        flatten(poly, ptrs, sizes);
+        const size_t nv = poly[0].n_vars();
+        std::vector<uint32_t> lens(nv ? nv : 1);
+        std::vector<uint64_t> rp(7 * 8 * (nv ? nv : 1));
+        std::vector<Fr> ch(nv ? nv : 1);
+        check(zkhip_multi_composed_prove(ctx(), ptrs.data(), sizes.data(), (uint32_t)sizes.size(), poly[0].polys[0].len(), sum.l, partial, lens.data(), rp.data(), ch[0].l),
+              "multi_composed_prove");
+        MultiComposedSumcheckProof proof;
+        proof.sum = sum;
+        for (size_t r = 0; r < nv; ++r) {
+            SparseUnivariatePolynomial sp;
+            for (uint32_t m = 0; m < lens[r]; ++m) {
+                UnivariateMonomial mono;
+                std::memcpy(mono.coeff.l, &rp[(r * 7 + m) * 8], 32);
+                std::memcpy(mono.pow.l, &rp[(r * 7 + m) * 8 + 4], 32);
+                sp.monomial.push_back(mono);
+            }
+            proof.round_polys.push_back(std::move(sp));
+        }
+        ch.resize(nv);
+        return {std::move(proof), std::move(ch)};
+    }
+};
+
+// ---- kzg ----------------------------------------------------------------------------------------------------------
+struct G1Affine {   // the commitment, affine Montgomery Fq limbs (x[6], y[6]) + infinity
+    uint64_t xy[12];
+    bool infinity;
+    bool operator==(const G1Affine& o) const { return infinity == o.infinity && (infinity || std::memcmp(xy, o.xy, 96) == 0); }
+};
+struct DenseUnivariatePolynomial {                                                            // dense_univariate.rs:15-17
+    explicit DenseUnivariatePolynomial(const std::vector<Fr>& c) : n(c.size()), dev(std::make_shared<DeviceBuffer>(32 * (c.size() ? c.size() : 1))) { if (n) dev->upload(c.data(), 32 * n); }
+    DenseUnivariatePolynomial(size_t n_, std::shared_ptr<DeviceBuffer> d) : n(n_), dev(std::move(d)) {}
+    std::vector<Fr> coefficients() const { std::vector<Fr> v(n); if (n) dev->download(v.data(), 32 * n); return v; }
+    size_t n;
+    std::shared_ptr<DeviceBuffer> dev;
+};
+class TrustedSetup {                                                                           // trusted_setup.rs:9-13 (G1 side)
+  public:
+    static TrustedSetup setup(const std::vector<Fr>& eval_points) {                            // :15-35
+        TrustedSetup s((size_t)1 << eval_points.size());
+        check(zkhip_srs_multilinear_g1(ctx(), eval_points.empty() ? nullptr : eval_points[0].l, (uint32_t)eval_points.size(), s.pts_->u64(), s.inf_->u8()), "setup");
+        return s;
+    }
+    size_t len() const { return n_; }
+    const uint64_t* points() const { return pts_->u64(); }
+    const uint8_t* inf() const { return inf_->u8(); }
+    explicit TrustedSetup(size_t n) : n_(n), pts_(std::make_shared<DeviceBuffer>(96 * n)), inf_(std::make_shared<DeviceBuffer>(n)) {}
+    std::shared_ptr<DeviceBuffer> pts_, inf_;
+  private:
+    size_t n_;
+};
+inline G1Affine commit_impl(const TrustedSetup& srs, const uint64_t* d_scalars, size_t n, int require_equal) {
+    G1Affine g; uint8_t inf = 0;
+    int st = zkhip_kzg_commit(ctx(), srs.points(), srs.inf(), srs.len(), d_scalars, n, require_equal, g.xy, &inf);
+    if (st == ZKHIP_ERR_SHAPE) throw Panic("The length of powers_of_tau_in_g1 and the length of the evaluations of the polynomial should tally!");
+    if (st == ZKHIP_ERR_INDEX) throw std::out_of_range("index out of bounds: the len of powers_of_tau_in_g1 is smaller than the polynomial");
+    check(st, "kzg_commit");
+    g.infinity = inf != 0;
+    return g;
+}
+struct MultilinearKZG {
+    static G1Affine commitment(const Multilinear& poly, const TrustedSetup& srs) { return commit_impl(srs, poly.device(), poly.len(), 1); }   // multilinear_kzg.rs:33-48
+};
+struct UnivariateKZG {
+    static TrustedSetup generate_srs(const Fr& tau, size_t max_degree) {                       // univariate_kzg.rs:18-35
+        TrustedSetup s(max_degree + 1);
+        check(zkhip_srs_univariate_g1(ctx(), tau.l, max_degree, s.pts_->u64(), s.inf_->u8()), "generate_srs");
+        return s;
+    }
+    static G1Affine commitment(const DenseUnivariatePolynomial& poly, const TrustedSetup& srs) { return commit_impl(srs, poly.dev->u64(), poly.n, 0); }   // :37-58
+};
+
+// ---- polynomial::univariate::{Domain, UnivariateEval} -------------------------------------------------------------------
+class Domain {
+  public:
+    uint64_t size;
+    Fr generator, group_gen_inverse, group_size_inverse;
+    explicit Domain(size_t num_of_coeffs) {                                                     // domain.rs:31-48
+        size = 1;
+        while (size < num_of_coeffs) size <<= 1;
+        check(zkhip_domain_params(size, generator.l, group_gen_inverse.l, group_size_inverse.l), "called `Option::unwrap()` on a `None` value");
+    }
+    std::vector<Fr> fft(const std::vector<Fr>& coeffs) const { return transform(coeffs, 0); }   // :108-112
+    std::vector<Fr> ifft(const std::vector<Fr>& evals) const { return transform(evals, 1); }    // :114-118
+  private:
+    std::vector<Fr> transform(const std::vector<Fr>& v, int inverse) const {
+        std::vector<Fr> buf(size, Fr::zero());
+        for (size_t i = 0; i < v.size() && i < size; ++i) buf[i] = v[i];
+        DeviceBuffer d(32 * size);
+        d.upload(buf.data(), 32 * size);
+        uint32_t lg = 0; while (((uint64_t)1 << lg) < size) ++lg;
+        check(zkhip_ntt(ctx(), d.u64(), lg, inverse), "ntt");
+        d.download(buf.data(), 32 * size);
+        return buf;
+    }
+};
+struct UnivariateEval {
+    static DenseUnivariatePolynomial multiply(const DenseUnivariatePolynomial& a, const DenseUnivariatePolynomial& b) {   // evaluation.rs:59-86
+        if (a.n == 0 || b.n == 0) throw Panic("attempt to subtract with overflow");
+        auto out = std::make_shared<DeviceBuffer>(32 * (a.n + b.n - 1));
+        check(zkhip_univariate_multiply(ctx(), a.dev->u64(), a.n, b.dev->u64(), b.n, out->u64()), "multiply");
+        return DenseUnivariatePolynomial(a.n + b.n - 1, out);
+    }
+};
+
+}  // namespace zkc

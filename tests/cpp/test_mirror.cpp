@@ -1,0 +1,212 @@
+// test_mirror.cpp -- the reference's own unit tests (same names, same inputs, same expected values) run against the
+// C++ host mirror (include/zkhip.hpp) on the GPU, plus bit-exact comparisons with the CPU oracle on random inputs.
+// Built and run by tests/test_cpp_mirror.py.  Exit code 0 = all passed.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../include/zkhip.hpp"
+extern "C" {
+#include "../../oracle/zkoracle.h"
+}
+
+using namespace zkc;
+static int g_failed = 0, g_run = 0;
+#define EXPECT(cond)                                                                  \
+    do {                                                                              \
+        if (!(cond)) { std::printf("  FAILED %s:%d  %s\n", __FILE__, __LINE__, #cond); ++g_failed; } \
+    } while (0)
+#define TEST(name) static void name(); static struct name##_reg { name##_reg() { tests().push_back({#name, name}); } } name##_inst; static void name()
+struct T { const char* n; void (*f)(); };
+static std::vector<T>& tests() { static std::vector<T> v; return v; }
+
+static std::vector<Fr> F(std::initializer_list<long> v) { std::vector<Fr> o; for (long x : v) o.push_back(Fr::from(x)); return o; }
+static std::vector<Fr> random_fr(size_t n, uint64_t seed) {
+    std::mt19937_64 g(seed);
+    std::vector<Fr> v(n);
+    for (auto& e : v) { for (int i = 0; i < 4; ++i) e.l[i] = g(); e.l[3] &= 0x3FFFFFFFFFFFFFFFULL; }
+    return v;
+}
+static const fr_t* O(const std::vector<Fr>& v) { return reinterpret_cast<const fr_t*>(v.data()); }
+static fr_t* O(std::vector<Fr>& v) { return reinterpret_cast<fr_t*>(v.data()); }
+template <class Fn> static bool panics(Fn f) { try { f(); } catch (const std::exception&) { return true; } return false; }
+
+// ---- polynomial/src/multilinear/evaluation_form.rs `mod tests` ------------------------------------------------
+TEST(test_add_mul_distinct) {
+    Multilinear p1(F({0, 0, 2, 2})), p2(F({0, 3, 0, 3}));
+    EXPECT(p1.add_distinct(p2) == Multilinear(F({0, 3, 0, 3, 0, 3, 0, 3, 2, 5, 2, 5, 2, 5, 2, 5})));
+    EXPECT(p1.mul_distinct(p2) == Multilinear(F({0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 0, 6, 0, 6, 0, 6})));
+}
+TEST(test_partial_evaluation_1) {
+    Multilinear poly(F({3, 1, 2, 5}));
+    EXPECT(poly.partial_evaluation(Fr::from(5), 0) == Multilinear(F({-2, 21})));
+}
+TEST(test_partial_evaluation_2) {
+    Multilinear poly(F({3, 9, 7, 13, 6, 12, 10, 18}));
+    EXPECT(poly.partial_evaluation(Fr::from(2), 0).evaluation(F({3, 2})) == Fr::from(57));
+    EXPECT(poly.partial_evaluation(Fr::from(3), 1).evaluation(F({3, 2})) == Fr::from(72));
+    EXPECT(poly.partial_evaluation(Fr::from(1), 2).evaluation(F({3, 2})) == Fr::from(38));
+}
+TEST(test_evaluation_1) {
+    EXPECT(Multilinear(F({3, 1, 2, 5})).evaluation(F({5, 6})) == Fr::from(136));
+    EXPECT(Multilinear(F({3, 1, 2, 5})).evaluation(F({5, 6})) != Fr::from(3));
+    EXPECT(Multilinear(F({3, 9, 7, 13, 6, 12, 10, 18})).evaluation(F({2, 3, 1})) == Fr::from(39));
+}
+TEST(test_evaluation_2) { EXPECT(Multilinear(F({0, 0, 0, 3, 0, 0, 2, 5})).evaluation(F({2, 3, 4})) == Fr::from(48)); }
+TEST(test_split_poly_into_two_and_sum_each_part) {
+    EXPECT(Multilinear(F({0, 0, 0, 2, 2, 2, 2, 4})).split_poly_into_two_and_sum_each_part() == Multilinear(F({2, 10})));
+    EXPECT(Multilinear(F({0, 0, 2, 7, 3, 3, 6, 11})).split_poly_into_two_and_sum_each_part() == Multilinear(F({9, 23})));
+}
+TEST(test_sum_over_boolean_hypercube) { EXPECT(Multilinear(F({1, 2, 3, 4, 5, 6, 7, 8})).sum_over_the_boolean_hypercube() == Fr::from(36)); }
+TEST(test_poly_subtraction) {
+    EXPECT(Multilinear(F({0, 0, 0, 5, 4, 4, 7, 12})) - Multilinear(F({0, 0, 0, 2, 0, 0, 1, 3})) == Multilinear(F({0, 0, 0, 3, 4, 4, 6, 9})));
+}
+TEST(test_panics_like_the_reference) {
+    EXPECT(panics([] { Multilinear m(F({1, 2, 3})); }));                                        // evaluation_form.rs:16-20
+    EXPECT(panics([] { Multilinear(F({1, 2, 3, 4})).evaluation(F({5})); }));                      // :163-167
+    EXPECT(panics([] { Multilinear(F({1, 2, 3, 4})).partial_evaluation(Fr::from(5), 2); }));      // utils.rs:31-34
+    EXPECT(panics([] { Multilinear(F({1, 2, 3, 4})).partial_evaluations(F({5, 6}), {0}); }));     // :146-152
+}
+// ---- sumcheck/src/utils.rs:70-93 ------------------------------------------------------------------------------------
+TEST(test_convert_field_to_byte) {
+    auto one = Fr::from(1).to_bytes_be(), hundred = Fr::from(100).to_bytes_be();
+    std::vector<uint8_t> e1(32, 0), e100(32, 0);
+    e1[31] = 1; e100[31] = 100;
+    EXPECT(one == e1 && hundred == e100);
+    EXPECT(Multilinear(F({1, 100})).to_bytes() == [&] { auto v = e1; v.insert(v.end(), e100.begin(), e100.end()); return v; }());
+}
+// ---- sumcheck/src/sumcheck.rs `mod tests` ---------------------------------------------------------------------------
+TEST(test_sum_calculation) {
+    Sumcheck prover(Multilinear(F({0, 0, 0, 2, 2, 2, 2, 4})));
+    prover.poly_sum();
+    EXPECT(prover.sum() == Fr::from(12));
+}
+static void sum_check_proof(const std::vector<Fr>& evals) {
+    Sumcheck sc{Multilinear(evals)};
+    sc.poly_sum();
+    auto [proof, challenges] = sc.prove();
+    const size_t nv = proof.poly.n_vars;
+    std::vector<Fr> rp(2 * nv), och(nv), gpu_rp;
+    Fr osum;
+    ora_sumcheck_prove(O(evals), evals.size(), (fr_t*)&osum, O(rp), O(och));
+    for (auto& u : proof.univariate_poly) for (auto& e : u.evaluations()) gpu_rp.push_back(e);
+    EXPECT(proof.sum == osum && gpu_rp == rp && challenges == och);
+    EXPECT(ora_sumcheck_verify(O(evals), evals.size(), (const fr_t*)&proof.sum, O(gpu_rp)) == 1);   // `verify == true`
+}
+TEST(test_sum_check_proof) { sum_check_proof(F({0, 0, 2, 7, 3, 3, 6, 11})); }
+TEST(test_sum_check_proof_2) { sum_check_proof(F({0, 0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0})); }
+TEST(test_sum_check_proof_3) { sum_check_proof(F({1, 3, 5, 7, 2, 4, 6, 8, 3, 5, 7, 9, 4, 6, 8, 10})); }
+TEST(test_sum_check_proof_random_2_16) { sum_check_proof(random_fr(1 << 16, 7)); }
+// ---- composed ----------------------------------------------------------------------------------------------------------
+TEST(test_composed_sum_calculation) {
+    EXPECT(ComposedSumcheck::calculate_poly_sum(ComposedMultilinear({Multilinear(F({0, 1, 2, 3})), Multilinear(F({0, 0, 0, 1}))})) == Fr::from(3));
+    EXPECT(ComposedSumcheck::calculate_poly_sum(ComposedMultilinear({Multilinear(F({3, 3, 5, 5})), Multilinear(F({0, 0, 0, 1}))})) == Fr::from(5));
+    EXPECT(ComposedSumcheck::calculate_poly_sum(ComposedMultilinear({Multilinear(F({0, 1, 2, 3}))})) == Fr::from(6));
+    EXPECT(ComposedMultilinear({Multilinear(F({0, 1, 2, 3})), Multilinear(F({0, 0, 0, 1}))}).evaluation(F({2, 3})) == Fr::from(42));
+}
+TEST(test_composed_sum_check_proof) {
+    std::vector<std::vector<Fr>> tabs = {F({3, 3, 5, 5}), F({0, 0, 0, 1})};
+    ComposedSumcheck sc(ComposedMultilinear({Multilinear(tabs[0]), Multilinear(tabs[1])}));
+    auto [proof, ch] = sc.prove();
+    std::vector<Fr> flat = tabs[0]; flat.insert(flat.end(), tabs[1].begin(), tabs[1].end());
+    std::vector<Fr> rp(3 * 2), och(2), grp;
+    ora_composed_prove(O(flat), 2, 4, O(rp), O(och));
+    for (auto& r : proof.round_polys) grp.insert(grp.end(), r.begin(), r.end());
+    EXPECT(grp == rp && ch == och);
+    Fr s = ComposedSumcheck::calculate_poly_sum(sc.poly);
+    EXPECT(ora_composed_verify(O(flat), 2, 4, (const fr_t*)&s, O(grp)) == 1);
+}
+TEST(test_multi_composed_sum_check_proof_2_on_gkr_example) {   // multi_composed_sumcheck.rs:266-311
+    Multilinear add_i(F({4, 4, 7, 7, 4, 4, 7, 9})), mul_i(F({3, 3, 3, 4, 3, 3, 5, 6})), w_b(F({0, 4})), w_c(F({0, 3}));
+    ComposedMultilinear lhs({add_i.partial_evaluation(Fr::from(2), 0), w_b.add_distinct(w_c)});
+    ComposedMultilinear rhs({mul_i.partial_evaluation(Fr::from(2), 0), w_b.mul_distinct(w_c)});
+    std::vector<ComposedMultilinear> multi = {lhs, rhs};
+    Fr sum = MultiComposedSumcheckProver::calculate_poly_sum(multi);
+    auto [proof, ch] = MultiComposedSumcheckProver::prove(multi, sum);
+    std::vector<Fr> flat;
+    for (auto& t : multi) for (auto& p : t.polys) { auto e = p.evaluations(); flat.insert(flat.end(), e.begin(), e.end()); }
+    size_t sizes[2] = {2, 2};
+    std::vector<ora_sparse_t> orp(2);
+    std::vector<Fr> och(2);
+    Fr osum;
+    ora_multi_composed_sum((fr_t*)&osum, O(flat), sizes, 2, 4);
+    EXPECT(osum == sum);
+    ora_multi_composed_prove(O(flat), sizes, 2, 4, (const fr_t*)&sum, 0, orp.data(), O(och));
+    std::vector<uint8_t> obytes;
+    for (auto& r : orp) { uint8_t b[64 * ORA_SPARSE_MAX]; size_t n = ora_sparse_to_bytes(b, &r); obytes.insert(obytes.end(), b, b + n); }
+    EXPECT(proof.to_bytes() == obytes && ch == och);
+    EXPECT(ora_multi_composed_verify(O(flat), sizes, 2, 4, (const fr_t*)&sum, orp.data(), 2) == 1);
+    auto [pp, chp] = MultiComposedSumcheckProver::prove_partial(multi, sum);
+    EXPECT(chp != ch);
+}
+// ---- kzg ---------------------------------------------------------------------------------------------------------------
+static bool same_point(const G1Affine& g, const g1_jac_t& want) {
+    g1_affine_t a;
+    ora_g1_to_affine(&a, &want);
+    return (g.infinity == (a.inf != 0)) && (g.infinity || std::memcmp(g.xy, &a, 96) == 0);
+}
+TEST(test_kzg_1) {   // multilinear_kzg.rs:133-148 (commitment half)
+    auto vals = F({0, 7, 0, 5, 0, 7, 4, 9}), tau = F({2, 3, 4});
+    TrustedSetup srs = TrustedSetup::setup(tau);
+    G1Affine commit = MultilinearKZG::commitment(Multilinear(vals), srs);
+    std::vector<g1_jac_t> osrs(8);
+    ora_kzg_multilinear_srs_g1(osrs.data(), O(tau), 3);
+    g1_jac_t want;
+    EXPECT(ora_kzg_commitment(&want, O(vals), 8, osrs.data(), 8, 1) == 0);
+    EXPECT(same_point(commit, want));
+    EXPECT(panics([&] { MultilinearKZG::commitment(Multilinear(F({1, 2, 3, 4})), srs); }));     // assert_eq! :36-41
+}
+TEST(test_univariate_kzg) {   // univariate_kzg.rs:111-129 (commitment half)
+    auto coeffs = F({1, 2, 3, 4, 5});
+    TrustedSetup srs = UnivariateKZG::generate_srs(Fr::from(10), 4);
+    G1Affine commit = UnivariateKZG::commitment(DenseUnivariatePolynomial(coeffs), srs);
+    std::vector<g1_jac_t> osrs(5);
+    Fr tau = Fr::from(10);
+    ora_kzg_univariate_srs_g1(osrs.data(), (const fr_t*)&tau, 4);
+    g1_jac_t want;
+    ora_kzg_commitment(&want, O(coeffs), 5, osrs.data(), 5, 0);
+    EXPECT(same_point(commit, want));
+    EXPECT(panics([&] { UnivariateKZG::commitment(DenseUnivariatePolynomial(F({1, 2, 3, 4, 5, 6})), srs); }));   // index out of bounds :53
+}
+TEST(test_kzg_random_2_10) {
+    auto tau = random_fr(10, 3), sc = random_fr(1 << 10, 4);
+    G1Affine commit = MultilinearKZG::commitment(Multilinear(sc), TrustedSetup::setup(tau));
+    Fr p_tau;
+    ora_mle_evaluation((fr_t*)&p_tau, O(sc), sc.size(), O(tau), 10);
+    uint64_t canon[4];
+    ora_fr_to_canonical(canon, (const fr_t*)&p_tau);
+    g1_jac_t g, want;
+    ora_g1_generator(&g);
+    ora_g1_mul_bigint(&want, &g, canon, 4);          // commit == p(tau) * G
+    EXPECT(same_point(commit, want));
+}
+// ---- domain / NTT ---------------------------------------------------------------------------------------------------------
+TEST(test_domain_new) {   // domain.rs:154-168 (the decimal strings are checked through the oracle's KAT-pinned root)
+    Domain d(10);
+    EXPECT(d.size == 16);
+    Fr w;
+    ora_fr_get_root_of_unity((fr_t*)&w, 16);
+    EXPECT(d.generator == w && d.generator * d.group_gen_inverse == Fr::one());
+}
+TEST(test_multiply) {
+    auto c = UnivariateEval::multiply(DenseUnivariatePolynomial(F({6, 5, 3})), DenseUnivariatePolynomial(F({5, 4, 2}))).coefficients();
+    EXPECT(c == F({30, 49, 47, 22, 6}));                                                       // dense_univariate.rs:480-496 values
+    auto a = random_fr(300, 5), b = random_fr(211, 6);
+    std::vector<Fr> want(510);
+    ora_univariate_multiply(O(want), O(a), 300, O(b), 211);
+    EXPECT(UnivariateEval::multiply(DenseUnivariatePolynomial(a), DenseUnivariatePolynomial(b)).coefficients() == want);
+    Domain d(64);
+    auto x = random_fr(64, 8);
+    EXPECT(d.ifft(d.fft(x)) == x);
+}
+
+int main() {
+    for (auto& t : tests()) {
+        int before = g_failed;
+        try { t.f(); } catch (const std::exception& e) { std::printf("  EXCEPTION in %s: %s\n", t.n, e.what()); ++g_failed; }
+        std::printf("%s %s\n", g_failed == before ? "ok    " : "FAILED", t.n);
+        ++g_run;
+    }
+    std::printf("%d tests, %d failed\n", g_run, g_failed);
+    return g_failed ? 1 : 0;
+}

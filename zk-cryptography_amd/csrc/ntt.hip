@@ -150,3 +150,33 @@ extern "C" int zkhip_univariate_multiply(zkhip_ctx* c, const uint64_t* d_a, size
     ZK_HIP(c, hipMemcpyAsync(d_out, ea, unscaled * 32, hipMemcpyDeviceToDevice, c->stream));         // truncate :85
     return ZKHIP_OK;
 }
+
+// ---- host-side Fr helpers ------------------------------------------------------------------------------
+extern "C" int zkhip_fr_from_i64(int64_t v, uint64_t* h_out) {
+    if (!h_out) return ZKHIP_ERR_ARG;
+    zkhost::Fr m = zkhost::fr_from_u64(v < 0 ? (uint64_t)(-(v + 1)) + 1 : (uint64_t)v);
+    if (v < 0) m = zkhost::fr_sub(zkhost::fr_zero(), m);
+    std::memcpy(h_out, m.l, 32);
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_fr_to_canonical(const uint64_t* h_in, uint64_t* h_out) {
+    if (!h_in || !h_out) return ZKHIP_ERR_ARG;
+    zkhost::Fr a, one = zkhost::fr_zero();
+    std::memcpy(a.l, h_in, 32);
+    one.l[0] = 1;
+    zkhost::Fr c = zkhost::fr_mul(a, one);
+    std::memcpy(h_out, c.l, 32);
+    return ZKHIP_OK;
+}
+#define ZK_FR_BINOP(NAME, FN)                                                                   \
+    extern "C" int NAME(const uint64_t* h_a, const uint64_t* h_b, uint64_t* h_out) {            \
+        if (!h_a || !h_b || !h_out) return ZKHIP_ERR_ARG;                                       \
+        zkhost::Fr a, b;                                                                        \
+        std::memcpy(a.l, h_a, 32); std::memcpy(b.l, h_b, 32);                                   \
+        zkhost::Fr c = zkhost::FN(a, b);                                                        \
+        std::memcpy(h_out, c.l, 32);                                                            \
+        return ZKHIP_OK;                                                                        \
+    }
+ZK_FR_BINOP(zkhip_fr_add, fr_add)
+ZK_FR_BINOP(zkhip_fr_sub, fr_sub)
+ZK_FR_BINOP(zkhip_fr_mul, fr_mul)
