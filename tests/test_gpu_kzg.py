@@ -136,3 +136,30 @@ def test_commit_2_20_identity(zk, ora):
     com = zk.MultilinearKZG.commitment(poly, srs)
     p_tau = zk.Fr.to_ints(poly.evaluation(tau))[0]
     _same(zk, com, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), p_tau)))
+
+
+@pytest.mark.parametrize("log_n", [12, 14, 17])
+@pytest.mark.parametrize("kind", ["ones", "bits", "bytes", "minus_one", "uniform"])
+def test_commit_skewed_scalars(zk, ora, log_n, kind):
+    """Scalars that pile most points into a few buckets (constant / 0-1 / small-valued tables -- what multilinear
+    tables usually hold -- and, for `uniform` at 2^14 / 2^17, the sparse top window): the heavy buckets are split into
+    chunks (msm_kernels.hpp pass 4b/4c).  commit == p(tau) * G whatever the bucket population is."""
+    n = 1 << log_n
+    tau = ora.random_fr(log_n, 900 + log_n)
+    srs = zk.TrustedSetup.setup(tau)
+    rng = np.random.default_rng(log_n)
+    if kind == "ones":
+        ints = np.ones(n, dtype=np.int64)
+    elif kind == "bits":
+        ints = rng.integers(0, 2, n)
+    elif kind == "bytes":
+        ints = rng.integers(0, 256, n)
+    elif kind == "minus_one":
+        ints = -np.ones(n, dtype=np.int64)
+    else:
+        ints = None
+    sc = ora.random_fr(n, 77 + log_n) if ints is None else zk.Fr.from_ints([int(v) for v in ints])
+    poly = zk.Multilinear(sc)
+    com = zk.MultilinearKZG.commitment(poly, srs)
+    p_tau = zk.Fr.to_ints(poly.evaluation(tau))[0]
+    _same(zk, com, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), p_tau)))

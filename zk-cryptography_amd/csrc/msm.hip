@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -23,9 +24,14 @@ using namespace zk;
 static MsmPlan msm_plan(size_t n) {
     uint32_t lg = 0;
     while (((size_t)1 << lg) < n) ++lg;
-    uint32_t c = lg > 2 ? lg - 2 : 4;            // about 8 points per bucket per window on small inputs
-    if (c < 4) c = 4;
-    if (c > 16) c = 16;
+    // One lane per bucket: the accumulate pass wants many short lists, so the window is as wide as the sort allows
+    // as soon as the bucket reduction is not the larger cost (measured with tools/perf_msm.py, ZKHIP_MSM_C sweep:
+    // c = 16 wins from 2^13 points on; below that every c ends at the ~1 ms latency floor of the reduction passes).
+    uint32_t c = lg >= 13 ? 16 : lg >= 10 ? 12 : 8;
+    if (const char* e = std::getenv("ZKHIP_MSM_C")) {   // tuning aid (tools/perf_msm.py); any 4 <= c <= 16 is correct
+        const int v = std::atoi(e);
+        if (v >= 4 && v <= 16) c = (uint32_t)v;
+    }
     MsmPlan pl;
     pl.c = c;
     pl.n_windows = (256 + c - 1) / c;
@@ -58,10 +64,8 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_counts = 0;
     const size_t o_offsets = o_counts + al(n_buckets * 4);
-    const size_t o_cursor = o_offsets + al(n_buckets * 4);
-    const size_t o_order = o_cursor + al(n_buckets * 4);
-    const size_t o_tiles = o_order + al(n_buckets * 4);
-    const size_t o_bins = o_tiles + al(((n_buckets + SCAN_TILE - 1) / SCAN_TILE) * 4);
+    const size_t o_order = o_offsets + al(n_buckets * 4);
+    const size_t o_bins = o_order + al(n_buckets * 4);
     const size_t o_sorted = o_bins + al(MSM_COUNT_BINS * 4);
     const size_t n_wgs = (n + SORT_TILE - 1) / SORT_TILE;
     const size_t o_items = o_sorted + al(n * pl.n_windows * 4);
@@ -73,15 +77,22 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     const size_t o_segs = o_buckets + al(n_buckets * 256);
     const size_t o_sega = o_segs + al(n_segments * 256);
     const size_t o_terms = o_sega + al(n_segments * 256);
-    const size_t total = o_terms + al(n_out * 192);
+    // heavy buckets (msm_kernels.hpp pass 4b/4c): more than heavy_min points, so at most n W / heavy_min of them;
+    // a bucket of k points files ceil(k / 8192) level-0 records and, above one record, a <= 256-way tree over them
+    const uint32_t heavy_min = (uint32_t)std::max<size_t>(32, 4 * ((n + pl.nb - 1) / pl.nb));
+    const size_t items_max = n * pl.n_windows;
+    const size_t rec_cap = items_max / heavy_min + items_max / MSM_HEAVY_REC + 2;
+    const size_t slots_cap = 3 * (items_max / MSM_HEAVY_REC) + 8;
+    const size_t o_ovf = o_terms + al(n_out * 192);
+    const size_t o_rec = o_ovf + al(sizeof(MsmOverflow));
+    const size_t o_part = o_rec + al(MSM_HEAVY_LEVELS * rec_cap * sizeof(MsmHeavyRec));
+    const size_t total = o_part + al(slots_cap * 256);
     ZK_TRY(c->reserve_ws(total));
     char* ws = (char*)c->d_ws;
     uint32_t* counts = (uint32_t*)(ws + o_counts);
     uint32_t* offsets = (uint32_t*)(ws + o_offsets);
-    uint32_t* cursor = (uint32_t*)(ws + o_cursor);
     uint32_t* sorted = (uint32_t*)(ws + o_sorted);
     uint32_t* order = (uint32_t*)(ws + o_order);
-    uint32_t* tiles = (uint32_t*)(ws + o_tiles);
     uint32_t* bins = (uint32_t*)(ws + o_bins);
     uint32_t* points_u = (uint32_t*)(ws + o_points);
     uint2* items = (uint2*)(ws + o_items);
@@ -92,6 +103,9 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     uint32_t* segs = (uint32_t*)(ws + o_segs);
     uint32_t* sega = (uint32_t*)(ws + o_sega);
     uint64_t* terms = (uint64_t*)(ws + o_terms);
+    MsmOverflow* ovf = (MsmOverflow*)(ws + o_ovf);
+    MsmHeavyRec* rec = (MsmHeavyRec*)(ws + o_rec);
+    uint32_t* partials = (uint32_t*)(ws + o_part);
 
     if (pl.n_parts > (uint32_t)SORT_MAX_PARTS) return ZKHIP_ERR_SHAPE;
     const int grid_n = (int)std::min<size_t>((n + MSM_BLOCK - 1) / MSM_BLOCK, 256 * 8);
@@ -107,11 +121,13 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
         hipLaunchKernelGGL(msm_sort_part_scan_kernel, dim3(1), dim3(1024), 0, c->stream, part_count, pl.n_parts, part_off);
         hipLaunchKernelGGL(msm_sort_scatter_kernel, dim3((unsigned)n_wgs), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl,
                            wg_counts, part_off, items);
-        hipLaunchKernelGGL(msm_sort_local_kernel, dim3(pl.n_parts), dim3(MSM_BLOCK), 0, c->stream, items, part_off, pl, sorted, counts, offsets);
+        hipLaunchKernelGGL(msm_sort_local_kernel, dim3(pl.n_parts), dim3(SORT_LOCAL_BLOCK), 0, c->stream, items, part_off, pl, sorted, counts, offsets);
     }
     {   // bucket order by descending point count
+        ProfScope ps(c, "msm_order", 0.0);
         const unsigned gb = (unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK);
         ZK_HIP(c, hipMemsetAsync(bins, 0, MSM_COUNT_BINS * 4, c->stream));
+        ZK_HIP(c, hipMemsetAsync(ovf, 0, sizeof(MsmOverflow), c->stream));
         hipLaunchKernelGGL(msm_order_hist_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins);
         hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bins);
         hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins, order);
@@ -119,7 +135,15 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     {
         ProfScope ps(c, "msm_accumulate", 128.0 * (double)n);
         hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK)), dim3(MSM_BLOCK), 0,
-                           c->stream, points_u, sorted, offsets, counts, order, (uint32_t)n_buckets, buckets);
+                           c->stream, points_u, sorted, offsets, counts, order, (uint32_t)n_buckets, heavy_min, ovf, rec, (uint32_t)rec_cap, buckets);
+    }
+    {   // heavy buckets (none with uniform scalars: four empty launches)
+        ProfScope ps(c, "msm_overflow", 0.0);
+        hipLaunchKernelGGL(msm_heavy_points_kernel, dim3(2048), dim3(MSM_BLOCK), MSM_BLOCK * 256, c->stream, points_u, sorted, ovf, rec,
+                           partials, buckets);
+        for (int level = 1; level < MSM_HEAVY_LEVELS; ++level)
+            hipLaunchKernelGGL(msm_heavy_tree_kernel, dim3(level == 1 ? 256 : 16), dim3(MSM_BLOCK), MSM_BLOCK * 256, c->stream, ovf,
+                               (uint32_t)level, rec + (size_t)level * rec_cap, partials, buckets);
     }
     {
         ProfScope ps(c, "msm_segment", 0.0);

@@ -6,10 +6,11 @@
 // which compute sum_i srs[i].mul_bigint(coeff[i].into_bigint()) by double-and-add.  The group element is
 // the same; the algorithm is Pippenger's:
 //   1. digits:   scalars leave Montgomery form (into_bigint) and are recoded into signed base-2^c digits;
-//                a histogram over (window, |digit|) buckets is built with global atomics;
-//   2. scan:     exclusive prefix sum of the histogram -> bucket offsets;
-//   3. scatter:  point indices (+ sign) are written bucket by bucket (counting sort);
-//   4. accumulate: one lane per bucket adds its points (mixed XYZZ additions);
+//   2. sort:     the (point, window) pairs are counting-sorted by bucket in two levels without global atomics
+//                (msm_sort_*), which also yields every bucket's count and offset;
+//   3. order:    buckets are ranked by point count, heaviest first;
+//   4. accumulate: one lane per bucket adds its points (mixed XYZZ additions); buckets far heavier than the
+//                mean are summed by whole workgroups instead (4b / 4c);
 //   5. segments: every L consecutive buckets are folded by a local running sum into
 //                S_s = sum B and A_s = sum (j+1) B  -- short dependency chains only;
 //   6. terms:    per window, sum_s A_s and, for every bit k of the segment index, T_k = sum_{s: bit k} S_s
@@ -58,81 +59,6 @@ struct DigitStream {
     }
 };
 
-// pass 1: histogram
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_hist_kernel(const uint64_t* __restrict__ scalars,
-                                                             const uint8_t* __restrict__ inf, size_t n, MsmPlan pl,
-                                                             uint32_t* __restrict__ counts) {
-    const size_t stride = (size_t)gridDim.x * MSM_BLOCK;
-    for (size_t i = (size_t)blockIdx.x * MSM_BLOCK + threadIdx.x; i < n; i += stride) {
-        if (inf && inf[i]) continue;
-        DigitStream ds(load_fr(scalars, i).from_mont());
-        for (uint32_t w = 0; w < pl.n_windows; ++w) {
-            const int32_t d = ds.next(pl);
-            if (d == 0) continue;
-            const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-            atomicAdd(&counts[w * pl.nb + mag - 1], 1u);
-        }
-    }
-}
-
-// pass 2: exclusive scan of `total` counters in three small launches (tile sums, scan of the tile sums, tile scans)
-constexpr int SCAN_TILE = 1024;   // counters per workgroup (4 per lane)
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_scan_tiles_kernel(const uint32_t* __restrict__ counts, uint32_t total,
-                                                                          uint32_t* __restrict__ tile_sums) {
-    __shared__ uint32_t red[MSM_BLOCK / 64];
-    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
-    uint32_t s = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) if (base + u < total) s += counts[base + u];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-// exclusive scan of n_tiles (<= 64 K) tile sums by one workgroup, in place
-static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t* __restrict__ tile_sums, uint32_t n_tiles) {
-    __shared__ uint32_t part[1024];
-    const uint32_t per = (n_tiles + 1023) / 1024;
-    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, n_tiles);
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; ++i) s += tile_sums[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - s;
-    for (uint32_t i = lo; i < hi; ++i) { uint32_t c = tile_sums[i]; tile_sums[i] = run; run += c; }
-}
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_scan_finish_kernel(const uint32_t* __restrict__ counts, uint32_t total,
-                                                                           const uint32_t* __restrict__ tile_offsets,
-                                                                           uint32_t* __restrict__ offsets,
-                                                                           uint32_t* __restrict__ cursor) {
-    __shared__ uint32_t wsum[MSM_BLOCK / 64];
-    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
-    uint32_t c[4], s = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { c[u] = (base + u < total) ? counts[base + u] : 0; s += c[u]; }
-    // inclusive scan of the lanes' sums inside the wave, then across the 4 waves
-    uint32_t incl = s;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t v = __shfl_up(incl, d, 64); if ((int)(threadIdx.x & 63) >= d) incl += v; }
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) woff += wsum[w];
-    uint32_t run = tile_offsets[blockIdx.x] + woff + incl - s;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if (base + u < total) { offsets[base + u] = run; cursor[base + u] = run; }
-        run += c[u];
-    }
-}
-
 // Bucket processing order: buckets sorted by their point count, heaviest first, so that the 64 lanes of a wave
 // walk lists of (nearly) equal length.  Counting sort over the clamped count.
 constexpr uint32_t MSM_COUNT_BINS = 1024;
@@ -178,26 +104,6 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_order_scatter_kernel(con
         if (local[i]) local[i] = atomicAdd(&bins[i], local[i]);
     __syncthreads();
     if (b < n_buckets) order[local[key] + rank] = b;
-}
-
-// pass 3: counting-sort scatter; entry = point index | sign << 31
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_scatter_kernel(const uint64_t* __restrict__ scalars,
-                                                                const uint8_t* __restrict__ inf, size_t n, MsmPlan pl,
-                                                                uint32_t* __restrict__ cursor,
-                                                                uint32_t* __restrict__ sorted) {
-    const size_t stride = (size_t)gridDim.x * MSM_BLOCK;
-    for (size_t i = (size_t)blockIdx.x * MSM_BLOCK + threadIdx.x; i < n; i += stride) {
-        if (inf && inf[i]) continue;
-        DigitStream ds(load_fr(scalars, i).from_mont());
-        for (uint32_t w = 0; w < pl.n_windows; ++w) {
-            const int32_t d = ds.next(pl);
-            if (d == 0) continue;
-            const bool neg = d < 0;
-            const uint32_t mag = neg ? (uint32_t)(-d) : (uint32_t)d;
-            const uint32_t pos = atomicAdd(&cursor[w * pl.nb + mag - 1], 1u);
-            sorted[pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
-        }
-    }
 }
 
 // ---- counting sort in two levels, without global atomics -------------------------------------------------
@@ -292,12 +198,28 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_scatter_kernel(cons
     }
 }
 
-// level 2: one workgroup per partition; writes the final order plus counts / offsets of its 2^sub_bits buckets
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_local_kernel(const uint2* __restrict__ items,
-                                                                          const uint32_t* __restrict__ part_off, MsmPlan pl,
-                                                                          uint32_t* __restrict__ sorted,
-                                                                          uint32_t* __restrict__ counts,
-                                                                          uint32_t* __restrict__ offsets) {
+// level 2: one workgroup per partition; writes the final order plus counts / offsets of its 2^sub_bits buckets.
+// Skewed scalars make partitions of very different sizes (all points of a 0/1 table fall into one), so the
+// workgroup is wide (1024 lanes of loads in flight) and a wave whose lanes all hold the same bucket -- the case that
+// would serialise 64-fold on one LDS word -- issues a single aggregated atomic.
+constexpr int SORT_LOCAL_BLOCK = 1024;
+__device__ __forceinline__ uint32_t msm_lds_rank(uint32_t* bins, uint32_t key) {   // atomicAdd(&bins[key], 1), aggregated
+    const uint64_t active = __ballot(1);
+    const uint32_t first = __builtin_amdgcn_readfirstlane(key);
+    if (__ballot(key == first) == active) {
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t below = __popcll(active & (((uint64_t)1 << lane) - 1));
+        uint32_t base = 0;
+        if (below == 0) base = atomicAdd(&bins[first], (uint32_t)__popcll(active));
+        return __builtin_amdgcn_readfirstlane(base) + below;
+    }
+    return atomicAdd(&bins[key], 1u);
+}
+static __global__ __launch_bounds__(SORT_LOCAL_BLOCK) void msm_sort_local_kernel(const uint2* __restrict__ items,
+                                                                                 const uint32_t* __restrict__ part_off, MsmPlan pl,
+                                                                                 uint32_t* __restrict__ sorted,
+                                                                                 uint32_t* __restrict__ counts,
+                                                                                 uint32_t* __restrict__ offsets) {
     __shared__ uint32_t bins[256];
     __shared__ uint32_t scan[256];
     const uint32_t p = blockIdx.x;
@@ -305,20 +227,20 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_local_kernel(const 
     const uint32_t n_sub = 1u << pl.sub_bits;
     if (threadIdx.x < 256) bins[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t q = lo + threadIdx.x; q < hi; q += MSM_BLOCK) atomicAdd(&bins[items[q].y], 1u);
+    for (uint32_t q = lo + threadIdx.x; q < hi; q += SORT_LOCAL_BLOCK) msm_lds_rank(bins, items[q].y);
     __syncthreads();
     // exclusive scan of the (<= 256) bins
     const uint32_t v = threadIdx.x < n_sub ? bins[threadIdx.x] : 0;
-    scan[threadIdx.x] = v;
+    if (threadIdx.x < 256) scan[threadIdx.x] = v;
     __syncthreads();
     for (uint32_t d = 1; d < 256; d <<= 1) {
-        uint32_t t = threadIdx.x >= d ? scan[threadIdx.x - d] : 0;
+        uint32_t t = (threadIdx.x < 256 && threadIdx.x >= d) ? scan[threadIdx.x - d] : 0;
         __syncthreads();
-        scan[threadIdx.x] += t;
+        if (threadIdx.x < 256) scan[threadIdx.x] += t;
         __syncthreads();
     }
-    const uint32_t excl = scan[threadIdx.x] - v;
     if (threadIdx.x < n_sub) {
+        const uint32_t excl = scan[threadIdx.x] - v;
         const uint32_t w = p / pl.parts_pw, top = p % pl.parts_pw;
         const uint32_t bucket = w * pl.nb + (top << pl.sub_bits) + threadIdx.x;
         counts[bucket] = v;
@@ -326,9 +248,9 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_local_kernel(const 
         bins[threadIdx.x] = lo + excl;      // becomes the write cursor
     }
     __syncthreads();
-    for (uint32_t q = lo + threadIdx.x; q < hi; q += MSM_BLOCK) {
+    for (uint32_t q = lo + threadIdx.x; q < hi; q += SORT_LOCAL_BLOCK) {
         const uint2 it = items[q];
-        sorted[atomicAdd(&bins[it.y], 1u)] = it.x;
+        sorted[msm_lds_rank(bins, it.y)] = it.x;
     }
 }
 
@@ -343,17 +265,29 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_convert_points_kernel(co
     }
 }
 
-// pass 4: one lane per bucket (in the order given by `order`: heaviest buckets first, equal lengths inside a wave)
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_accumulate_kernel(const uint32_t* __restrict__ points,
-                                                                   const uint32_t* __restrict__ sorted,
-                                                                   const uint32_t* __restrict__ offsets,
-                                                                   const uint32_t* __restrict__ counts,
-                                                                   const uint32_t* __restrict__ order,
-                                                                   uint32_t n_buckets, uint32_t* __restrict__ buckets) {
-    const uint32_t t = blockIdx.x * MSM_BLOCK + threadIdx.x;
-    if (t >= n_buckets) return;
-    const uint32_t b = order[t];
-    const uint32_t start = offsets[b], cnt = counts[b];
+// pass 4: one lane per bucket (in the order given by `order`: heaviest buckets first, equal lengths inside a wave).
+// Skewed scalars (small table values, constant polynomials, a sparse top window) can put a large share of all
+// points into a handful of buckets, and one lane adding 2^20 points one after the other would take seconds.  A
+// bucket holding more than `heavy_min` points is therefore not walked by its lane: the lane files it as records of
+// <= 8192 points for pass 4b, where a whole workgroup sums a record (<= 32 points per lane, then a tree in LDS),
+// and, when the bucket spans several records, as a tree of <= 256-way sums over the record sums for pass 4c.
+// With uniform scalars no bucket is heavy and 4b / 4c find empty lists.
+constexpr uint32_t MSM_HEAVY_LANE_MAX = 32;                       // points per lane inside a record
+constexpr uint32_t MSM_HEAVY_REC = MSM_BLOCK * MSM_HEAVY_LANE_MAX;   // points per record
+constexpr int MSM_HEAVY_LEVELS = 4;                               // 0: records of points; 1..3: 256-way sums of sums
+struct MsmHeavyRec {
+    uint32_t first;    // level 0: position in `sorted`; level >= 1: slot in the partial-sum array
+    uint32_t count;    // points / partial sums covered
+    uint32_t dst;      // slot of the result, or the bucket index when `final`
+    uint32_t final;
+};
+struct MsmOverflow {
+    uint32_t n_slots;
+    uint32_t n_rec[MSM_HEAVY_LEVELS];
+};
+
+__device__ __forceinline__ G1XyzzU msm_sum_run(const uint32_t* __restrict__ points, const uint32_t* __restrict__ sorted,
+                                               uint32_t start, uint32_t cnt) {
     G1XyzzU acc = G1XyzzU::identity();
     // software pipeline: the next point's index and coordinates (a dependent pair of random loads) are in flight
     // while the current addition (~6 k instructions) runs
@@ -368,7 +302,121 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_accumulate_kernel(const 
         }
         g1u_madd(acc, p, (e >> 31) != 0);
     }
-    store_xyzz_u(buckets, b, acc);
+    return acc;
+}
+
+// files bucket b (cnt points from `start`) into the record lists; rec[l] has room for rec_cap records per level
+__device__ __noinline__ void msm_file_heavy(uint32_t b, uint32_t start, uint32_t cnt, MsmOverflow* __restrict__ ovf,
+                                            MsmHeavyRec* __restrict__ rec, uint32_t rec_cap) {
+    uint32_t groups = (cnt + MSM_HEAVY_REC - 1) / MSM_HEAVY_REC;
+    MsmHeavyRec r;
+    if (groups == 1) {
+        r.first = start; r.count = cnt; r.dst = b; r.final = 1;
+        rec[atomicAdd(&ovf->n_rec[0], 1u)] = r;
+        return;
+    }
+    uint32_t slot = atomicAdd(&ovf->n_slots, groups);
+    uint32_t at = atomicAdd(&ovf->n_rec[0], groups);
+    for (uint32_t g = 0; g < groups; ++g) {
+        r.first = start + g * MSM_HEAVY_REC; r.count = min(MSM_HEAVY_REC, cnt - g * MSM_HEAVY_REC); r.dst = slot + g; r.final = 0;
+        rec[at + g] = r;
+    }
+    uint32_t first = slot, count = groups;
+    for (int level = 1; level < MSM_HEAVY_LEVELS; ++level) {
+        MsmHeavyRec* lst = rec + (size_t)level * rec_cap;
+        groups = (count + MSM_BLOCK - 1) / MSM_BLOCK;
+        if (groups == 1) {
+            r.first = first; r.count = count; r.dst = b; r.final = 1;
+            lst[atomicAdd(&ovf->n_rec[level], 1u)] = r;
+            return;
+        }
+        slot = atomicAdd(&ovf->n_slots, groups);
+        at = atomicAdd(&ovf->n_rec[level], groups);
+        for (uint32_t g = 0; g < groups; ++g) {
+            r.first = first + g * MSM_BLOCK; r.count = min((uint32_t)MSM_BLOCK, count - g * MSM_BLOCK); r.dst = slot + g; r.final = 0;
+            lst[at + g] = r;
+        }
+        first = slot; count = groups;
+    }
+}
+
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_accumulate_kernel(const uint32_t* __restrict__ points,
+                                                                   const uint32_t* __restrict__ sorted,
+                                                                   const uint32_t* __restrict__ offsets,
+                                                                   const uint32_t* __restrict__ counts,
+                                                                   const uint32_t* __restrict__ order,
+                                                                   uint32_t n_buckets, uint32_t heavy_min,
+                                                                   MsmOverflow* __restrict__ ovf, MsmHeavyRec* __restrict__ rec,
+                                                                   uint32_t rec_cap, uint32_t* __restrict__ buckets) {
+    const uint32_t t = blockIdx.x * MSM_BLOCK + threadIdx.x;
+    if (t >= n_buckets) return;
+    const uint32_t b = order[t];
+    const uint32_t start = offsets[b], cnt = counts[b];
+    if (cnt > heavy_min) {
+        msm_file_heavy(b, start, cnt, ovf, rec, rec_cap);   // passes 4b / 4c write buckets[b]
+        return;
+    }
+    store_xyzz_u(buckets, b, msm_sum_run(points, sorted, start, cnt));
+}
+
+// tree sum over the first `width` lanes' values (width a power of two <= MSM_BLOCK); the result is lane 0's `acc`
+__device__ __forceinline__ void msm_block_tree_sum(G1XyzzU& acc, uint32_t width, uint32_t* __restrict__ lds) {
+    if (threadIdx.x < width) store_xyzz_u(lds, threadIdx.x, acc);
+    __syncthreads();
+    for (uint32_t d = width >> 1; d >= 1; d >>= 1) {
+        if (threadIdx.x < d) {
+            G1XyzzU o = load_xyzz_u(lds, threadIdx.x + d);
+            g1u_add(acc, o);
+            store_xyzz_u(lds, threadIdx.x, acc);
+        }
+        __syncthreads();
+    }
+}
+
+// pass 4b: one workgroup per level-0 record (fixed grid; the list length is read on the device)
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_heavy_points_kernel(const uint32_t* __restrict__ points,
+                                                                     const uint32_t* __restrict__ sorted,
+                                                                     const MsmOverflow* __restrict__ ovf,
+                                                                     const MsmHeavyRec* __restrict__ rec,
+                                                                     uint32_t* __restrict__ partials,
+                                                                     uint32_t* __restrict__ buckets) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
+    uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);   // MSM_BLOCK x 64 u32
+    const uint32_t n_rec = ovf->n_rec[0];
+    for (uint32_t i = blockIdx.x; i < n_rec; i += gridDim.x) {
+        const MsmHeavyRec r = rec[i];
+        // at least 8 points per lane (the tree's general additions stay a small share of the work), at most 32
+        const uint32_t per = max(8u, (r.count + MSM_BLOCK - 1) / MSM_BLOCK);
+        const uint32_t lanes = (r.count + per - 1) / per;
+        uint32_t width = 1;
+        while (width < lanes) width <<= 1;
+        G1XyzzU acc = G1XyzzU::identity();
+        if (threadIdx.x < lanes) {
+            const uint32_t lo = threadIdx.x * per;
+            acc = msm_sum_run(points, sorted, r.first + lo, min(per, r.count - lo));
+        }
+        msm_block_tree_sum(acc, width, lds);
+        if (threadIdx.x == 0) store_xyzz_u(r.final ? buckets : partials, r.dst, acc);
+    }
+}
+
+// pass 4c (one launch per level >= 1): one workgroup per record sums <= 256 partial sums
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_heavy_tree_kernel(const MsmOverflow* __restrict__ ovf, uint32_t level,
+                                                                   const MsmHeavyRec* __restrict__ rec,
+                                                                   uint32_t* __restrict__ partials,
+                                                                   uint32_t* __restrict__ buckets) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
+    uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);
+    const uint32_t n_rec = ovf->n_rec[level];
+    for (uint32_t i = blockIdx.x; i < n_rec; i += gridDim.x) {
+        const MsmHeavyRec r = rec[i];
+        uint32_t width = 1;
+        while (width < r.count) width <<= 1;
+        G1XyzzU acc = G1XyzzU::identity();
+        if (threadIdx.x < r.count) acc = load_xyzz_u(partials, r.first + threadIdx.x);
+        msm_block_tree_sum(acc, width, lds);
+        if (threadIdx.x == 0) store_xyzz_u(r.final ? buckets : partials, r.dst, acc);
+    }
 }
 
 // pass 5: one lane per segment of L buckets: S = sum_j B_j, A = sum_j (j+1) B_j  (running sum from the top)
