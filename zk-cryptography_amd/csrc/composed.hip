@@ -73,7 +73,7 @@ extern "C" int zkhip_multi_composed_sum(zkhip_ctx* c, const uint64_t* const* ptr
     return product_sums(c, ptrs, term_sizes, n_terms, n, h_sum);
 }
 
-// shared driver.  multi = 0: ComposedSumcheck (one term).  first_mode: see composed_transcript_kernel.
+// shared driver.  multi = 0: ComposedSumcheck (one term).  first_mode: see close_round.
 static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes, uint32_t n_terms,
                                size_t n, int multi, const uint64_t* h_sum, int partial, uint32_t* h_lens,
                                uint64_t* h_round_polys, uint64_t* h_challenges) {
@@ -147,11 +147,26 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
         }
     }
 
-    // current table pointers
+    // Rounds on tables too large for one workgroup's LDS: one launch per term (fold at the previous challenge + the
+    // round's sums) and one that closes the round.  From the round whose tables fit the LDS on, one launch finishes
+    // the proof.
+    const uint32_t tail_len = composed_tail_len(total);
     std::vector<const uint64_t*> cur(ptrs, ptrs + total);
-    size_t cn = n;
+    size_t cn = n;   // entries of the tables `cur` points to
     for (uint32_t round = 0; round < n_vars; ++round) {
         const bool fold = round > 0;
+        const size_t after = fold ? cn / 2 : cn;   // entries the round's sums run over
+        CloseArgs ca = {};
+        ca.meta = meta; ca.st = st; ca.round = round; ca.first = first; ca.round_out = d_rp; ca.challenges = d_ch;
+        if (after <= tail_len) {
+            TailTables tt = {};
+            for (uint32_t q = 0; q < total; ++q) tt.in[q] = cur[q];
+            ZK_TRY(c->allow_big_lds((const void*)composed_tail_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
+            ProfScope ps(c, "composed_tail", 0.0);
+            hipLaunchKernelGGL(composed_tail_kernel, dim3(1), dim3(CMP_TAIL_BLOCK), total * after * 32, c->stream, tt, total, (uint32_t)after,
+                               fold ? 1u : 0u, fold ? d_ch + 4 * (round - 1) : nullptr, ca, n_vars - round);
+            break;
+        }
         const size_t work = fold ? cn / 4 : cn / 2;
         const int grid = mle_grid(work ? work : 1);
         uint32_t off = 0;
@@ -172,8 +187,7 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
             off += term_sizes[p];
         }
         if (fold) cn /= 2;
-        hipLaunchKernelGGL(composed_transcript_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_partials, (uint32_t)grid, meta, st,
-                           round, first, d_rp, d_ch);
+        hipLaunchKernelGGL(composed_close_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_partials, (uint32_t)grid, ca);
         first = 0;
     }
     ZK_HIP(c, hipGetLastError());

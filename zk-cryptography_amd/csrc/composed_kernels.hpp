@@ -46,11 +46,117 @@ __device__ __forceinline__ void accumulate_round_evals(const Fr (&lo)[K], const 
     }
 }
 
+// ---- closing a round ------------------------------------------------------------------------------------
+struct ComposedMeta {
+    uint32_t n_terms;
+    uint32_t k[CMP_MAX_TERMS];         // tables per term (= degree of the term's round polynomial)
+    uint32_t rec_off[CMP_MAX_TERMS];   // offset of the term's K+1 sums inside a workgroup record
+    uint32_t rec;                      // sums per record
+    uint32_t multi;                    // 0: ComposedSumcheck transcript (raw evaluations), 1: multi-composed (sparse coefficients)
+};
+// Device-resident state.  interp[d] is the (d+1)x(d+1) matrix taking evaluations at x = 0..d to coefficients
+// (Montgomery form), uploaded by the host once per prove.
+struct ComposedDev {
+    Sha256State transcript;
+    uint64_t sum[4];
+    uint64_t interp[CMP_MAX_K + 1][(CMP_MAX_K + 1) * (CMP_MAX_K + 1)][4];
+};
+struct CloseShared {                   // LDS scratch of close_round
+    Fr evals[CMP_MAX_REC];             // the round's sums: term p's evaluations at t = 0..K_p from rec_off[p]
+    Fr term_coeff[CMP_MAX_TERMS][CMP_MAX_MONO];
+    Fr canon[CMP_MAX_MONO];            // canonical integers of what the transcript absorbs, in order
+    uint32_t pow_of[CMP_MAX_MONO];
+    uint32_t n_items;
+    Fr challenge;                      // Montgomery form, for the caller
+};
+
+// Closes a round with the whole workgroup (>= 64 threads; every thread must call): sh.evals hold the sums.
+// Builds the round polynomial, absorbs it, derives the challenge (left in sh.challenge and challenges[round]).
+//   first: 1 = the transcript is started here (ComposedSumcheck: nothing absorbed before, composed_sumcheck.rs:33;
+//              multi-composed prove_partial: the claimed sum, multi_composed_sumcheck.rs:60,70),
+//          2 = the transcript state was prepared by the host (multi-composed `prove`: all table bytes were
+//              hashed first, :51-53) and the claimed sum is absorbed here,
+//          0 = continue.
+// Output per round (round_out + 64 * round, in u64):
+//   multi == 0: K+1 evaluations (4 u64 each);  multi == 1: [0] = #monomials, then (coeff, pow) pairs of 8 u64 from [8].
+// Only the hash chain is serial (thread 0); interpolation products and Montgomery conversions run one per lane.
+__device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta& meta, ComposedDev* st, Sha256State* tr_state,
+                                            uint32_t round, uint32_t first, uint64_t* __restrict__ round_out,
+                                            uint64_t* __restrict__ challenges) {
+    uint64_t* out = round_out + 64 * (size_t)round;
+    const uint32_t tid = threadIdx.x;
+    if (!meta.multi) {
+        // transcript.commit(&vec_to_bytes(&round_poly))  composed_sumcheck.rs:51: the raw evaluations
+        if (tid <= meta.k[0]) {
+            const Fr e = sh.evals[tid];
+            store_fr(out, tid, e);
+            sh.canon[tid] = fr_from_mont_outlined(e);
+        }
+        if (tid == 0) sh.n_items = meta.k[0] + 1;
+    } else {
+        // round_poly = sum over terms of interpolation(evals at x = 0..K)  (:79-95); coefficients that are zero
+        // are dropped per term (sparse_univariate.rs:55) but a zero produced by the sum is kept (:159-203).
+        if (tid < meta.rec) {
+            uint32_t p = 0;
+            while (p + 1 < meta.n_terms && tid >= meta.rec_off[p + 1]) ++p;
+            const uint32_t d = meta.k[p], k = tid - meta.rec_off[p];
+            Fr c = Fr::zero();
+            for (uint32_t i = 0; i <= d; ++i)
+                c = c + fr_mul_outlined(load_fr(&st->interp[d][k * (d + 1) + i][0], 0), sh.evals[meta.rec_off[p] + i]);
+            sh.term_coeff[p][k] = c;
+        }
+        __syncthreads();
+        if (tid < 64) {   // lanes 0..6 of wave 0: one power each
+            Fr coeff = Fr::zero();
+            bool present = false;
+            if (tid < CMP_MAX_MONO) {
+                for (uint32_t p = 0; p < meta.n_terms; ++p) {
+                    if (tid > meta.k[p]) continue;
+                    const Fr c = sh.term_coeff[p][tid];
+                    if (!c.is_zero()) { coeff = coeff + c; present = true; }
+                }
+            }
+            const uint64_t mask = __ballot(present);
+            if (present) {
+                const uint32_t at = __popcll(mask & (((uint64_t)1 << tid) - 1));
+                sh.canon[at] = fr_from_mont_outlined(coeff);
+                sh.pow_of[at] = tid;
+                store_fr(out + 8, 2 * at, coeff);
+                Fr powm = Fr::zero();
+                powm.l[0] = tid;
+                store_fr(out + 8, 2 * at + 1, fr_to_mont_outlined(powm));
+            }
+            if (tid == 0) { sh.n_items = (uint32_t)__popcll(mask); out[0] = (uint64_t)__popcll(mask); }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        Transcript tr;
+        if (first == 1) tr.init(); else tr.load(tr_state);
+        if (meta.multi && first) tr.commit_fr(load_fr(st->sum, 0));   // multi_composed_sumcheck.rs:70
+        const uint32_t n_items = sh.n_items;
+        for (uint32_t i = 0; i < n_items; ++i) {
+            tr.commit_canonical(sh.canon[i]);
+            if (meta.multi) {   // coeff || pow, 32 bytes big-endian each (sparse_univariate.rs:27-34)
+                uint32_t pw[8] = {0, 0, 0, 0, 0, 0, 0, sh.pow_of[i]};
+                tr.commit_words8(pw);
+            }
+        }
+        const Fr r = tr.challenge_fr();
+        tr.store(tr_state);
+        store_fr(challenges, round, r);
+        sh.challenge = r;
+    }
+    __syncthreads();
+}
+
 // One round of one product term.
 //   FOLD = false: evaluate the round polynomial of the tables as they are (first round): pairs (j, j + n/2).
 //   FOLD = true : fold every table at *r_ptr first (in[j], in[j + n/2] -> out[j]) for the two outputs j and
 //                 j + n/4, store them, and evaluate the NEXT round polynomial on that folded pair.
-// Per workgroup, the K+1 sums go to partials[(block * rec + rec_off + t)].
+// Per workgroup, the K+1 sums go to partials[(block * rec + rec_off + t)]; composed_close_kernel sums the records
+// and closes the round.  (Closing inside this kernel by the last workgroup to finish was measured and dropped: on
+// eight XCDs with private L2s the agent-scope release every workgroup then needs costs more than a launch.)
 template <int K, bool FOLD>
 static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TablePtrs tp, size_t n, const uint64_t* __restrict__ r_ptr,
                                                                    uint32_t rec, uint32_t rec_off,
@@ -98,6 +204,28 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TableP
     }
 }
 
+struct CloseArgs {
+    ComposedMeta meta;
+    ComposedDev* st;
+    uint32_t round, first;
+    uint64_t* round_out;
+    uint64_t* challenges;
+};
+// sums the n_partials workgroup records of a round (wave w takes the values v = w, w + 4, ...) and closes it
+static __global__ __launch_bounds__(MLE_BLOCK) void composed_close_kernel(const uint64_t* __restrict__ partials, uint32_t n_partials,
+                                                                   CloseArgs ca) {
+    __shared__ CloseShared sh;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t v = wave; v < ca.meta.rec; v += MLE_BLOCK / 64) {
+        Fr s = Fr::zero();
+        for (uint32_t b = lane; b < n_partials; b += 64) s = s + load_fr(partials, (size_t)b * ca.meta.rec + v);
+        s = wave_reduce_fr(s);
+        if (lane == 0) sh.evals[v] = s;
+    }
+    __syncthreads();
+    close_round(sh, ca.meta, ca.st, &ca.st->transcript, ca.round, ca.first, ca.round_out, ca.challenges);
+}
+
 // sum_j prod_k table_k[j]  (ComposedSumcheck::calculate_poly_sum composed_sumcheck.rs:28-30): one partial per workgroup
 template <int K>
 static __global__ __launch_bounds__(MLE_BLOCK) void product_sum_kernel(TablePtrs tp, size_t n, uint64_t* __restrict__ partials) {
@@ -123,87 +251,113 @@ static __global__ __launch_bounds__(MLE_BLOCK) void finish_sum_kernel(const uint
     if (threadIdx.x == 0) store_fr(out, 0, accumulate ? s + load_fr(out, 0) : s);
 }
 
-// ---- per-round control kernel -------------------------------------------------------------------------
-struct ComposedMeta {
-    uint32_t n_terms;
-    uint32_t k[CMP_MAX_TERMS];         // tables per term (= degree of the term's round polynomial)
-    uint32_t rec_off[CMP_MAX_TERMS];   // offset of the term's K+1 sums inside a workgroup record
-    uint32_t rec;                      // sums per record
-    uint32_t multi;                    // 0: ComposedSumcheck transcript (raw evaluations), 1: multi-composed (sparse coefficients)
+// ---- the last rounds in one launch ------------------------------------------------------------------------
+// Once all tables of the claim fit the LDS (CMP_TAIL_ENTRIES field elements, 128 KiB) the remaining rounds run inside
+// one workgroup: tables are loaded once (folded at the previous challenge on the way in), every round evaluates the
+// terms' sums from LDS, closes the round (close_round) and folds in place.  A 2^20 claim spends half of its rounds here.
+constexpr int CMP_TAIL_BLOCK = 512;
+constexpr uint32_t CMP_TAIL_ENTRIES = 4096;
+struct TailTables {
+    const uint64_t* in[CMP_MAX_TERMS * CMP_MAX_K];
 };
-// Device-resident state.  interp[d] is the (d+1)x(d+1) matrix taking evaluations at x = 0..d to coefficients
-// (Montgomery form), uploaded by the host once per prove.
-struct ComposedDev {
-    Sha256State transcript;
-    uint64_t sum[4];
-    uint64_t interp[CMP_MAX_K + 1][(CMP_MAX_K + 1) * (CMP_MAX_K + 1)][4];
-};
+inline uint32_t composed_tail_len(uint32_t total_tables) {   // entries per table the tail can hold
+    uint32_t m = 1;
+    while (2 * m * total_tables <= CMP_TAIL_ENTRIES) m *= 2;
+    return m;
+}
+__device__ __forceinline__ Fr lds_load_fr(const uint32_t* base, uint32_t idx) {
+    const uint4* p = reinterpret_cast<const uint4*>(base + 8 * idx);
+    uint4 a = p[0], b = p[1];
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void lds_store_fr(uint32_t* base, uint32_t idx, const Fr& v) {
+    uint4* p = reinterpret_cast<uint4*>(base + 8 * idx);
+    p[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    p[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+// one term: per-wave sums of the K+1 evaluations over the pairs (j, j + cn/2) of its K tables (table k at tab + k * m)
+template <int K>
+__device__ __forceinline__ void tail_term_sums(const uint32_t* tab, uint32_t m, uint32_t cn, Fr* wave_part /* [rec] of this wave */,
+                                               uint32_t rec_off) {
+    Fr sums[K + 1];
+#pragma unroll
+    for (int t = 0; t <= K; ++t) sums[t] = Fr::zero();
+    const uint32_t half = cn >> 1;
+    if ((threadIdx.x & ~63u) < half) {   // waves without a pair keep their zeros
+        for (uint32_t j = threadIdx.x; j < half; j += CMP_TAIL_BLOCK) {
+            Fr lo[K], hi[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { lo[k] = lds_load_fr(tab, k * m + j); hi[k] = lds_load_fr(tab, k * m + j + half); }
+            accumulate_round_evals<K>(lo, hi, sums);
+        }
+#pragma unroll
+        for (int t = 0; t <= K; ++t) sums[t] = wave_reduce_fr(sums[t]);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int t = 0; t <= K; ++t) wave_part[rec_off + t] = sums[t];
+    }
+}
 
-// Closes a round: reduce the workgroup records, build the round polynomial, absorb it, derive the challenge.
-//   first: 1 = the transcript is started here (ComposedSumcheck: nothing absorbed before, composed_sumcheck.rs:33;
-//              multi-composed prove_partial: the claimed sum, multi_composed_sumcheck.rs:60,70),
-//          2 = the transcript state was prepared by the host (multi-composed `prove`: all table bytes were
-//              hashed first, :51-53) and the claimed sum is absorbed here,
-//          0 = continue.
-// Output per round (round_out + 64 * round, in u64):
-//   multi == 0: K+1 evaluations (4 u64 each);  multi == 1: [0] = #monomials, then (coeff, pow) pairs of 8 u64 from [8].
-static __global__ __launch_bounds__(MLE_BLOCK) void composed_transcript_kernel(const uint64_t* __restrict__ partials,
-                                                                        uint32_t n_partials, ComposedMeta meta,
-                                                                        ComposedDev* st, uint32_t round, uint32_t first,
-                                                                        uint64_t* __restrict__ round_out,
-                                                                        uint64_t* __restrict__ challenges) {
-    __shared__ Fr red[MLE_BLOCK / 64];
-    __shared__ Fr evals[CMP_MAX_REC];
-    for (uint32_t v = 0; v < meta.rec; ++v) {
-        Fr s = Fr::zero();
-        for (uint32_t b = threadIdx.x; b < n_partials; b += MLE_BLOCK) s = s + load_fr(partials, (size_t)b * meta.rec + v);
-        s = block_reduce_fr(s, red);
-        if (threadIdx.x == 0) evals[v] = s;
+static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(TailTables tt, uint32_t total, uint32_t m, uint32_t load_fold,
+                                                                       const uint64_t* __restrict__ r_ptr, CloseArgs ca,
+                                                                       uint32_t n_rounds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
+    uint32_t* tab = reinterpret_cast<uint32_t*>(zk_dyn_lds);   // total tables x m elements
+    __shared__ CloseShared sh;
+    __shared__ Fr wave_part[CMP_TAIL_BLOCK / 64][CMP_MAX_REC];
+    __shared__ Sha256State trs;
+    {
+        Fr r = Fr::zero();
+        if (load_fold) r = load_fr(r_ptr, 0);
+        for (uint32_t idx = threadIdx.x; idx < total * m; idx += CMP_TAIL_BLOCK) {
+            const uint32_t q = idx / m, j = idx % m;
+            Fr v = load_fr(tt.in[q], j);
+            if (load_fold) v = fold_pair(v, load_fr(tt.in[q], (size_t)j + m), r);
+            lds_store_fr(tab, idx, v);
+        }
+        if (threadIdx.x < sizeof(Sha256State) / 4)
+            reinterpret_cast<uint32_t*>(&trs)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&ca.st->transcript)[threadIdx.x];
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    Transcript tr;
-    if (first == 1) tr.init(); else tr.load(&st->transcript);
-    uint64_t* out = round_out + 64 * (size_t)round;
-    if (!meta.multi) {
-        // transcript.commit(&vec_to_bytes(&round_poly))  composed_sumcheck.rs:51
-        for (uint32_t t = 0; t <= meta.k[0]; ++t) {
-            tr.commit_fr(evals[t]);
-            store_fr(out, t, evals[t]);
-        }
-    } else {
-        if (first) tr.commit_fr(load_fr(st->sum, 0));   // multi_composed_sumcheck.rs:70
-        // round_poly = sum over terms of interpolation(evals at x = 0..K)  (:79-95); coefficients that are zero
-        // are dropped per term (sparse_univariate.rs:55) but a zero produced by the sum is kept (:159-203).
-        Fr coeff[CMP_MAX_MONO];
-        bool present[CMP_MAX_MONO];
-        for (int k = 0; k < CMP_MAX_MONO; ++k) { coeff[k] = Fr::zero(); present[k] = false; }
-        for (uint32_t p = 0; p < meta.n_terms; ++p) {
-            const uint32_t d = meta.k[p];
-            for (uint32_t k = 0; k <= d; ++k) {
-                Fr c = Fr::zero();
-                for (uint32_t i = 0; i <= d; ++i)
-                    c = c + fr_mul_outlined(load_fr(&st->interp[d][k * (d + 1) + i][0], 0), evals[meta.rec_off[p] + i]);
-                if (!c.is_zero()) { coeff[k] = coeff[k] + c; present[k] = true; }
+    uint32_t cn = m, first = ca.first;
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t round = ca.round; round < ca.round + n_rounds; ++round) {
+        uint32_t q0 = 0;
+        for (uint32_t p = 0; p < ca.meta.n_terms; ++p) {
+            const uint32_t* base = tab + 8 * (size_t)q0 * m;
+            switch (ca.meta.k[p]) {
+                case 1: tail_term_sums<1>(base, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
+                case 2: tail_term_sums<2>(base, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
+                case 3: tail_term_sums<3>(base, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
+                case 4: tail_term_sums<4>(base, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
+                default: tail_term_sums<5>(base, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
             }
+            q0 += ca.meta.k[p];
         }
-        uint32_t n_mono = 0;
-        for (uint32_t k = 0; k < CMP_MAX_MONO; ++k) {
-            if (!present[k]) continue;
-            tr.commit_fr(coeff[k]);                 // coeff || pow, 32 bytes big-endian each (sparse_univariate.rs:27-34)
-            uint32_t pw[8] = {0, 0, 0, 0, 0, 0, 0, k};
-            tr.commit_words8(pw);
-            store_fr(out + 8, 2 * n_mono, coeff[k]);
-            Fr powm = Fr::zero();
-            powm.l[0] = k;
-            store_fr(out + 8, 2 * n_mono + 1, fr_to_mont_outlined(powm));
-            ++n_mono;
+        __syncthreads();
+        if (threadIdx.x < ca.meta.rec) {
+            Fr s = wave_part[0][threadIdx.x];
+            for (uint32_t w = 1; w < CMP_TAIL_BLOCK / 64; ++w) s = s + wave_part[w][threadIdx.x];
+            sh.evals[threadIdx.x] = s;
         }
-        out[0] = n_mono;
+        __syncthreads();
+        close_round(sh, ca.meta, ca.st, &trs, round, first, ca.round_out, ca.challenges);
+        first = 0;
+        if (cn == 2) break;   // the fold after the last round has no consumer
+        const Fr r = sh.challenge;
+        const uint32_t half = cn >> 1;
+        for (uint32_t idx = threadIdx.x; idx < total * half; idx += CMP_TAIL_BLOCK) {
+            const uint32_t q = idx / half, j = idx % half;
+            const Fr lo = lds_load_fr(tab, q * m + j), hi = lds_load_fr(tab, q * m + j + half);
+            lds_store_fr(tab, q * m + j, fold_pair(lo, hi, r));
+        }
+        __syncthreads();
+        cn = half;
     }
-    Fr r = tr.challenge_fr();
-    tr.store(&st->transcript);
-    store_fr(challenges, round, r);
 }
 
 }  // namespace zk
