@@ -71,6 +71,16 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by.value / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                         "avg_launch_us": round(1e3 * ms.value, 1),
                         "algorithmic_bytes_per_launch": "128 B x points (96 B affine point + 32 B scalar)"}}
+    # what actually bounds that kernel: issue of v_mad_u64_u32.  One bucket addition = 10 products in the 14 x 28-bit
+    # representation = 4060 multiply-adds; a launch adds one point per non-zero digit (16 windows x points, all but
+    # 2^-16 of them).  Peak = 1024 SIMDs x 64 lanes / 4.9 cycles per wave-instruction x 2.4 GHz as measured by
+    # tools/ubench.hip (profiles/r01/ubench_alu_gfx950.txt).
+    mads = 4060.0 * 16.0 * n * (1.0 - 2.0 ** -16)
+    peak_tmads = 1024 * 64 / 4.9 * 2.4e9 / 1e12
+    out["roofline_alu"] = {"bound": "valu", "kernel": "msm_accumulate_kernel", "achieved": round(mads / (ms.value * 1e-3) / 1e12, 2),
+                           "peak": round(peak_tmads, 2), "unit": "T v_mad_u64_u32 lane-ops/s",
+                           "frac": round(mads / (ms.value * 1e-3) / 1e12 / peak_tmads, 4),
+                           "ops_per_launch": "4060 multiply-adds x 16 windows x points"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as ora
         m = 1 << 15                                                     # bounded sample of the naive reference algorithm (~7 s)

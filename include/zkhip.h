@@ -200,6 +200,23 @@ int zkhip_srs_multilinear_g1(zkhip_ctx *ctx, const uint64_t *h_tau, uint32_t n_v
                              uint8_t *d_out_inf);
 int zkhip_srs_univariate_g1(zkhip_ctx *ctx, const uint64_t *h_tau, size_t max_degree, uint64_t *d_out_xy,
                             uint8_t *d_out_inf);
+/* MultilinearKZGInterface::open (kzg/src/multilinear_kzg.rs:50-88): evaluation of the table at h_points plus one
+ * G1 proof per variable.  Round i takes the quotient q_i = f_i(1, .) - f_i(0, .) (kzg/src/utils.rs:12-17), blows it up
+ * to all n variables (add_to_front, evaluation_form.rs:86-96: the quotient repeated 2^(i+1) times) and commits it
+ * against the whole SRS, then continues with the remainder f_{i+1} = f_i(z_i, .) (utils.rs:5-10).  A commitment to a
+ * repeated table is sum_j q_i[j] * S_i[j] with S_i[j] = sum_rep SRS[rep * |q_i| + j]; the S_i ("folded SRS", n - 1
+ * points in all) depend on the SRS only:
+ *   zkhip_srs_fold_levels : d_out_xy[(n-1)*12], d_out_inf[n-1] <- S_0 (n/2 points), S_1 (n/4), ..., S_{nv-1} (1);
+ *   zkhip_kzg_open        : d_folded_* = that array, or NULL to derive it inside the call.
+ * Outputs (host): h_evaluation[4]; h_proofs_xy[n_vars*12], h_proofs_inf[n_vars] (affine, as zkhip_kzg_commit).
+ * Shape errors as in the reference: n_points != n (multilinear_kzg.rs:36-41), n_eval_points != n_vars
+ * (evaluation_form.rs:163-167), n_vars < 2 (`variable_index - 1` underflows at :73) -> ZKHIP_ERR_SHAPE. */
+int zkhip_srs_fold_levels(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t *d_points_inf, size_t n_points,
+                          uint64_t *d_out_xy, uint8_t *d_out_inf);
+int zkhip_kzg_open(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint64_t *h_points, size_t n_eval_points,
+                   const uint64_t *d_points_xy, const uint8_t *d_points_inf, size_t n_points,
+                   const uint64_t *d_folded_xy, const uint8_t *d_folded_inf, uint64_t *h_evaluation,
+                   uint64_t *h_proofs_xy, uint8_t *h_proofs_inf);
 /* Sum of n affine points given on the host (combining per-GPU partial commitments after an all-gather). */
 int zkhip_g1_sum_affine(const uint64_t *h_points_xy, const uint8_t *h_points_inf, size_t n, uint64_t *h_out_xy,
                         uint8_t *h_out_inf);

@@ -316,7 +316,7 @@ class TrustedSetup {                                                            
     size_t len() const { return n_; }
     const uint64_t* points() const { return pts_->u64(); }
     const uint8_t* inf() const { return inf_->u8(); }
-    explicit TrustedSetup(size_t n) : n_(n), pts_(std::make_shared<DeviceBuffer>(96 * n)), inf_(std::make_shared<DeviceBuffer>(n)) {}
+    explicit TrustedSetup(size_t n) : pts_(std::make_shared<DeviceBuffer>(96 * n)), inf_(std::make_shared<DeviceBuffer>(n)), n_(n) {}
     std::shared_ptr<DeviceBuffer> pts_, inf_;
   private:
     size_t n_;
@@ -330,8 +330,29 @@ inline G1Affine commit_impl(const TrustedSetup& srs, const uint64_t* d_scalars, 
     g.infinity = inf != 0;
     return g;
 }
+struct MultilinearKZGProof {                                                                   // multilinear_kzg.rs:17-21
+    Fr evaluation;
+    std::vector<G1Affine> proofs;
+};
 struct MultilinearKZG {
     static G1Affine commitment(const Multilinear& poly, const TrustedSetup& srs) { return commit_impl(srs, poly.device(), poly.len(), 1); }   // multilinear_kzg.rs:33-48
+    static MultilinearKZGProof open(const Multilinear& poly, const std::vector<Fr>& evaluation_points, const TrustedSetup& srs) {             // :50-88
+        MultilinearKZGProof pr;
+        const size_t nv = evaluation_points.size();
+        std::vector<uint64_t> xy(12 * (nv ? nv : 1));
+        std::vector<uint8_t> inf(nv ? nv : 1);
+        int st = zkhip_kzg_open(ctx(), poly.device(), poly.len(), nv ? evaluation_points[0].l : nullptr, nv, srs.points(), srs.inf(), srs.len(),
+                                nullptr, nullptr, pr.evaluation.l, xy.data(), inf.data());
+        if (st == ZKHIP_ERR_SHAPE) throw Panic("open: evaluation points / SRS length must match the polynomial (n_vars >= 2)");
+        check(st, "kzg_open");
+        for (size_t i = 0; i < nv; ++i) {
+            G1Affine g;
+            std::memcpy(g.xy, &xy[12 * i], 96);
+            g.infinity = inf[i] != 0;
+            pr.proofs.push_back(g);
+        }
+        return pr;
+    }
 };
 struct UnivariateKZG {
     static TrustedSetup generate_srs(const Fr& tau, size_t max_degree) {                       // univariate_kzg.rs:18-35

@@ -256,6 +256,59 @@ int ora_kzg_commitment(g1_jac_t *out, const fr_t *coeffs, size_t n_coeffs, const
     return 0;
 }
 
+/* MultilinearKZG::open, multilinear_kzg.rs:50-88, step by step as the reference does it: every round commits the
+ * quotient blown up to all n variables against the WHOLE srs (n naive commitments of 2^n terms each).
+ *   get_poly_quotient  kzg/src/utils.rs:12-17   f(1, .) - f(0, .)
+ *   get_poly_remainder kzg/src/utils.rs:5-10    f(z, .)
+ *   add_to_front       evaluation_form.rs:86-96 (the table repeated 2 * 2^variable_length times)
+ *   duplicate_evaluation :112-119, used in the last round with add_to_front(variable_index - 1)
+ * Returns -1 on the shape panics (point count, srs length), -2 when n_vars < 2 (`variable_index - 1` underflows),
+ * -3 on "Evaluation and final remainder mismatch!". */
+int ora_kzg_open(fr_t *evaluation, g1_jac_t *proofs, const fr_t *evals, size_t n, const fr_t *points, size_t n_points,
+                 const g1_jac_t *srs, size_t n_srs) {
+    size_t n_vars = 0;
+    while (((size_t)1 << n_vars) < n) ++n_vars;
+    if (((size_t)1 << n_vars) != n || n_points != n_vars || n_srs != n) return -1;
+    if (n_vars < 2) return -2;
+    if (ora_mle_evaluation(evaluation, evals, n, points, n_points) != 0) return -1;
+    fr_t *poly = (fr_t *)malloc(n * sizeof(fr_t));
+    fr_t *f1 = (fr_t *)malloc(n * sizeof(fr_t)), *f0 = (fr_t *)malloc(n * sizeof(fr_t));
+    fr_t *blown = (fr_t *)malloc(n * sizeof(fr_t));
+    memcpy(poly, evals, n * sizeof(fr_t));
+    fr_t one, zero, final_remainder;
+    ora_fr_one(&one);
+    ora_fr_zero(&zero);
+    ora_fr_zero(&final_remainder);
+    size_t cn = n;
+    int rc = 0;
+    for (size_t i = 0; i < n_vars; ++i) {
+        ora_mle_partial_evaluation(f1, poly, cn, &one, 0);
+        ora_mle_partial_evaluation(f0, poly, cn, &zero, 0);
+        const size_t q = cn / 2;
+        for (size_t j = 0; j < q; ++j) ora_fr_sub(&f1[j], &f1[j], &f0[j]);   /* quotient */
+        size_t base_len, reps;
+        if (i != n_vars - 1) {
+            base_len = q;
+            reps = (size_t)2 << i;                    /* add_to_front(&i): 2 * 2^i copies */
+        } else {
+            base_len = 2 * q;                         /* duplicate_evaluation, then add_to_front(&(i - 1)) */
+            f1[1] = f1[0];
+            reps = (size_t)2 << (i - 1);
+            ora_mle_evaluation(&final_remainder, poly, cn, &points[i], 1);
+        }
+        for (size_t r = 0; r < reps; ++r) memcpy(&blown[r * base_len], f1, base_len * sizeof(fr_t));
+        if (reps * base_len != n || ora_kzg_commitment(&proofs[i], blown, n, srs, n_srs, 1) != 0) { rc = -1; break; }
+        if (i != n_vars - 1) {
+            ora_mle_partial_evaluation(f0, poly, cn, &points[i], 0);      /* remainder */
+            memcpy(poly, f0, q * sizeof(fr_t));
+        }
+        cn = q;
+    }
+    if (rc == 0 && !ora_fr_eq(evaluation, &final_remainder)) rc = -3;
+    free(poly); free(f1); free(f0); free(blown);
+    return rc;
+}
+
 /* CPU bucket-method MSM: NOT the reference's algorithm (the reference is the naive
  * sum above); provided so that large-size GPU results can be cross-checked in
  * seconds and as a context number.  Unsigned windows of c bits. */

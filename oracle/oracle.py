@@ -469,6 +469,24 @@ def kzg_commitment(coeffs, srs_jac, require_equal_len):
     return o
 
 
+def kzg_open(evals, points, srs_jac):
+    """MultilinearKZG::open (multilinear_kzg.rs:50-88), naive -> (evaluation [4], proofs [n_vars, 18] Jacobian)"""
+    evals = _fr(evals).reshape(-1, 4)
+    points = _fr(points).reshape(-1, 4)
+    srs = np.ascontiguousarray(srs_jac, dtype=np.uint64).reshape(-1, 18)
+    ev = np.empty(4, dtype=np.uint64)
+    proofs = np.empty((max(points.shape[0], 1), 18), dtype=np.uint64)
+    rc = lib().ora_kzg_open(_p(ev), _p(proofs), _p(evals), C.c_size_t(evals.shape[0]), _p(points), C.c_size_t(points.shape[0]),
+                            _p(srs), C.c_size_t(srs.shape[0]))
+    if rc == -1:
+        raise AssertionError("shape mismatch (points / srs length)")
+    if rc == -2:
+        raise OverflowError("attempt to subtract with overflow (variable_index - 1, multilinear_kzg.rs:73)")
+    if rc == -3:
+        raise RuntimeError("Evaluation and final remainder mismatch!")
+    return ev, proofs[: points.shape[0]]
+
+
 def msm_pippenger(scalars, pts_affine):
     scalars = _fr(scalars).reshape(-1, 4)
     pts = np.ascontiguousarray(pts_affine, dtype=np.uint64).reshape(-1, 13)

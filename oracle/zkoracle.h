@@ -140,6 +140,9 @@ void ora_kzg_univariate_srs_g1(g1_jac_t *out, const fr_t *tau, size_t max_degree
 int  ora_kzg_commitment(g1_jac_t *out, const fr_t *coeffs, size_t n_coeffs, const g1_jac_t *srs, size_t n_srs,
                         int require_equal_len);
 /* same sum computed by a CPU bucket method -- context number only, not the reference algorithm */
+/* MultilinearKZG::open (multilinear_kzg.rs:50-88), naive as the reference; proofs[n_vars] Jacobian */
+int  ora_kzg_open(fr_t *evaluation, g1_jac_t *proofs, const fr_t *evals, size_t n, const fr_t *points, size_t n_points,
+                  const g1_jac_t *srs, size_t n_srs);
 void ora_msm_pippenger(g1_jac_t *out, const fr_t *scalars, const g1_affine_t *pts, size_t n);
 
 /* ---- NTT / Domain / multiply (utils.rs:281-324, domain.rs, evaluation.rs) -- */

@@ -156,6 +156,24 @@ TEST(test_kzg_1) {   // multilinear_kzg.rs:133-148 (commitment half)
     EXPECT(same_point(commit, want));
     EXPECT(panics([&] { MultilinearKZG::commitment(Multilinear(F({1, 2, 3, 4})), srs); }));     // assert_eq! :36-41
 }
+static void kzg_open_case(const std::vector<Fr>& vals, const std::vector<Fr>& tau, const std::vector<Fr>& z) {
+    TrustedSetup srs = TrustedSetup::setup(tau);
+    MultilinearKZGProof proof = MultilinearKZG::open(Multilinear(vals), z, srs);
+    std::vector<g1_jac_t> osrs(vals.size()), want(tau.size());
+    ora_kzg_multilinear_srs_g1(osrs.data(), O(tau), tau.size());
+    Fr ev;
+    EXPECT(ora_kzg_open((fr_t*)&ev, want.data(), O(vals), vals.size(), O(z), z.size(), osrs.data(), osrs.size()) == 0);
+    EXPECT(proof.evaluation == ev && proof.proofs.size() == tau.size());
+    for (size_t i = 0; i < want.size() && i < proof.proofs.size(); ++i) EXPECT(same_point(proof.proofs[i], want[i]));
+}
+TEST(test_kzg_1_open) {   // multilinear_kzg.rs:131-155 (open half; the pairing verifier is out of scope)
+    kzg_open_case(F({0, 7, 0, 5, 0, 7, 4, 9}), F({2, 3, 4}), F({5, 9, 6}));
+    EXPECT(MultilinearKZG::open(Multilinear(F({0, 7, 0, 5, 0, 7, 4, 9})), F({5, 9, 6}), TrustedSetup::setup(F({2, 3, 4}))).evaluation == Fr::from(114));
+    EXPECT(panics([&] { MultilinearKZG::open(Multilinear(F({0, 7, 0, 5, 0, 7, 4, 9})), F({5, 9}), TrustedSetup::setup(F({2, 3, 4}))); }));
+}
+TEST(test_kzg_2_open) {   // multilinear_kzg.rs:157-197
+    kzg_open_case(F({0, 0, 0, 2, 0, 0, 10, 12, 0, -12, 4, -6, 0, -12, 14, 4}), F({12, 9, 28, 40}), F({54, 90, 76, 160}));
+}
 TEST(test_univariate_kzg) {   // univariate_kzg.rs:111-129 (commitment half)
     auto coeffs = F({1, 2, 3, 4, 5});
     TrustedSetup srs = UnivariateKZG::generate_srs(Fr::from(10), 4);

@@ -29,7 +29,7 @@ def hx(arr):
 
 def main():
     out = {"_about": "restatement-derived vectors; see make_golden.py", "sumcheck": [], "multi_composed": [], "composed": [],
-           "kzg": [], "ntt": []}
+           "kzg": [], "kzg_open": [], "ntt": []}
     for vals, src in [([0, 0, 2, 7, 3, 3, 6, 11], "sumcheck/src/sumcheck.rs:127-136"),
                       ([0, 0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0], "sumcheck/src/sumcheck.rs:146-163"),
                       ([1, 3, 5, 7, 2, 4, 6, 8, 3, 5, 7, 9, 4, 6, 8, 10], "sumcheck/src/sumcheck.rs:175-192")]:
@@ -58,6 +58,15 @@ def main():
     x, y, inf = ora.g1_affine_ints(ora.g1_to_affine(c))
     out["kzg"].append({"source": "kzg/src/univariate_kzg.rs:111-129", "kind": "univariate", "coeffs": [1, 2, 3, 4, 5], "tau": 10,
                        "x": "%096x" % x, "y": "%096x" % y, "inf": inf})
+    for vals, tau, z, src in [([0, 7, 0, 5, 0, 7, 4, 9], [2, 3, 4], [5, 9, 6], "kzg/src/multilinear_kzg.rs:131-155"),
+                              ([0, 0, 0, 2, 0, 0, 10, 12, 0, -12, 4, -6, 0, -12, 14, 4], [12, 9, 28, 40], [54, 90, 76, 160],
+                               "kzg/src/multilinear_kzg.rs:157-197")]:
+        ev, proofs = ora.kzg_open(ora.fr_from_ints(vals), ora.fr_from_ints(z), ora.kzg_multilinear_srs_g1(ora.fr_from_ints(tau)))
+        pts = []
+        for pr in proofs:
+            x, y, inf = ora.g1_affine_ints(ora.g1_to_affine(pr))
+            pts.append({"x": "%096x" % x, "y": "%096x" % y, "inf": inf})
+        out["kzg_open"].append({"source": src, "evals": vals, "tau": tau, "points": z, "evaluation": hx(ev.reshape(1, 4))[0], "proofs": pts})
     vec = list(range(1, 17))
     out["ntt"].append({"source": "Domain::new(16) (domain.rs:154-168 pins omega); input 1..16", "input": vec,
                        "fft": hx(ora.domain_fft(ora.fr_from_ints(vec), 16)), "ifft": hx(ora.domain_ifft(ora.fr_from_ints(vec), 16))})

@@ -26,6 +26,20 @@ def test_oracle_reproduces_golden(ora):
         s = ora.multi_composed_sum(flat, sizes)
         rps, ch = ora.multi_composed_prove(flat, sizes, s, e["partial"])
         assert ora.multi_composed_proof_bytes(rps).hex() == e["proof_bytes"] and hx(ora, ch) == e["challenges"]
+    for e in G["kzg"]:
+        if e["kind"] == "multilinear":
+            c = ora.kzg_commitment(ora.fr_from_ints(e["evals"]), ora.kzg_multilinear_srs_g1(ora.fr_from_ints(e["tau"])), True)
+        else:
+            c = ora.kzg_commitment(ora.fr_from_ints(e["coeffs"]), ora.kzg_univariate_srs_g1(ora.fr_from_ints([e["tau"]])[0], 4), False)
+        x, y, inf = ora.g1_affine_ints(ora.g1_to_affine(c))
+        assert ("%096x" % x, "%096x" % y, inf) == (e["x"], e["y"], e["inf"])
+    for e in G["kzg_open"]:
+        ev, proofs = ora.kzg_open(ora.fr_from_ints(e["evals"]), ora.fr_from_ints(e["points"]),
+                                  ora.kzg_multilinear_srs_g1(ora.fr_from_ints(e["tau"])))
+        assert hx(ora, ev.reshape(1, 4))[0] == e["evaluation"]
+        for got, want in zip(proofs, e["proofs"]):
+            x, y, inf = ora.g1_affine_ints(ora.g1_to_affine(got))
+            assert ("%096x" % x, "%096x" % y, inf) == (want["x"], want["y"], want["inf"])
     for e in G["ntt"]:
         v = ora.fr_from_ints(e["input"])
         assert hx(ora, ora.domain_fft(v, 16)) == e["fft"] and hx(ora, ora.domain_ifft(v, 16)) == e["ifft"]
@@ -57,6 +71,12 @@ def test_hip_path_reproduces_golden(ora):
             com = zk.UnivariateKZG.commitment(zk.DenseUnivariatePolynomial(F(e["coeffs"])), zk.UnivariateKZG.generate_srs(F([e["tau"]])[0], 4))
         x, y = com.coords()
         assert ("%096x" % x, "%096x" % y, com.infinity) == (e["x"], e["y"], e["inf"])
+    for e in G["kzg_open"]:
+        proof = zk.MultilinearKZG.open(zk.Multilinear(F(e["evals"])), F(e["points"]), zk.TrustedSetup.setup(F(e["tau"])))
+        assert hx(ora, proof.evaluation.reshape(1, 4))[0] == e["evaluation"]
+        for got, want in zip(proof.proofs, e["proofs"]):
+            x, y = got.coords() if not got.infinity else (0, 0)
+            assert ("%096x" % x, "%096x" % y, got.infinity) == (want["x"], want["y"], want["inf"])
     for e in G["ntt"]:
         d = zk.Domain(16)
         assert hx(ora, d.fft(F(e["input"])).cpu().numpy().view(np.uint64)) == e["fft"]

@@ -163,3 +163,68 @@ def test_commit_skewed_scalars(zk, ora, log_n, kind):
     com = zk.MultilinearKZG.commitment(poly, srs)
     p_tau = zk.Fr.to_ints(poly.evaluation(tau))[0]
     _same(zk, com, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), p_tau)))
+
+
+# ---- MultilinearKZG::open (multilinear_kzg.rs:50-88) ---------------------------------------------------------
+@pytest.mark.parametrize("vals,tau,z", [
+    ([0, 7, 0, 5, 0, 7, 4, 9], [2, 3, 4], [5, 9, 6]),                                                      # test_kzg_1
+    ([0, 0, 0, 2, 0, 0, 10, 12, 0, -12, 4, -6, 0, -12, 14, 4], [12, 9, 28, 40], [54, 90, 76, 160]),       # test_kzg_2
+])
+@pytest.mark.parametrize("cached", [True, False])
+def test_kzg_open_reference_data(zk, ora, vals, tau, z, cached):
+    srs = zk.TrustedSetup.setup(zk.Fr.from_ints(tau))
+    proof = zk.MultilinearKZG.open(zk.Multilinear(zk.Fr.from_ints(vals)), zk.Fr.from_ints(z), srs, cache_folded_srs=cached)
+    want_ev, want_proofs = ora.kzg_open(zk.Fr.from_ints(vals), zk.Fr.from_ints(z), ora.kzg_multilinear_srs_g1(zk.Fr.from_ints(tau)))
+    assert np.array_equal(proof.evaluation, want_ev)
+    if vals[1] == 7:
+        assert zk.Fr.to_ints(proof.evaluation) == [114]
+    assert len(proof.proofs) == len(tau)
+    for got, want in zip(proof.proofs, want_proofs):
+        _same(zk, got, *_aff(ora, want))
+
+
+@pytest.mark.parametrize("n_vars", [2, 5, 8])
+def test_kzg_open_random_matches_naive_oracle(zk, ora, n_vars):
+    tau, z = ora.random_fr(n_vars, 1100 + n_vars), ora.random_fr(n_vars, 1200 + n_vars)
+    vals = ora.random_fr(1 << n_vars, 1300 + n_vars)
+    srs = zk.TrustedSetup.setup(tau)
+    proof = zk.MultilinearKZG.open(zk.Multilinear(vals), z, srs)
+    want_ev, want_proofs = ora.kzg_open(vals, z, ora.kzg_multilinear_srs_g1(tau))
+    assert np.array_equal(proof.evaluation, want_ev)
+    for got, want in zip(proof.proofs, want_proofs):
+        _same(zk, got, *_aff(ora, want))
+
+
+def test_kzg_open_2_14_exponent_identity(zk, ora):
+    """Beyond what the naive oracle can do in seconds: proof_i == Q_i(tau) * G, Q_i the round's quotient evaluated at
+    the remaining tau (through the independently verified GPU folds), and the verifier's equation in the exponent."""
+    n_vars = 14
+    tau, z = ora.random_fr(n_vars, 71), ora.random_fr(n_vars, 72)
+    vals = ora.random_fr(1 << n_vars, 73)
+    srs = zk.TrustedSetup.setup(tau)
+    poly = zk.Multilinear(vals)
+    proof = zk.MultilinearKZG.open(poly, z, srs)
+    assert np.array_equal(proof.evaluation, poly.evaluation(z))
+    tau_i, z_i = zk.Fr.to_ints(tau), zk.Fr.to_ints(z)
+    one, zero = zk.Fr.from_int(1), zk.Fr.from_int(0)
+    f, acc = poly, 0
+    for i in range(n_vars):
+        q = f.partial_evaluation(one, 0) - f.partial_evaluation(zero, 0)
+        q_tau = zk.Fr.to_ints(q.evaluation(tau[i + 1:]) if i + 1 < n_vars else q.evaluations.cpu().numpy().view(np.uint64))[0]
+        _same(zk, proof.proofs[i], *_aff(ora, ora.g1_mul_int(ora.g1_generator(), q_tau)))
+        acc = (acc + q_tau * (tau_i[i] - z_i[i])) % R
+        f = f.partial_evaluation(z[i], 0)
+    p_tau = zk.Fr.to_ints(poly.evaluation(tau))[0]
+    assert (p_tau - zk.Fr.to_ints(proof.evaluation)[0]) % R == acc
+
+
+def test_kzg_open_shape_panics(zk, ora):
+    srs = zk.TrustedSetup.setup(zk.Fr.from_ints([2, 3, 4]))
+    poly = zk.Multilinear(zk.Fr.from_ints([0, 7, 0, 5, 0, 7, 4, 9]))
+    with pytest.raises(AssertionError):    # evaluation_form.rs:163-167
+        zk.MultilinearKZG.open(poly, zk.Fr.from_ints([5, 9]), srs)
+    with pytest.raises(AssertionError):    # multilinear_kzg.rs:36-41
+        zk.MultilinearKZG.open(zk.Multilinear(zk.Fr.from_ints([0, 7, 0, 5])), zk.Fr.from_ints([5, 9]), srs)
+    with pytest.raises(AssertionError):    # one variable: `variable_index - 1` underflows in the reference (:73)
+        zk.MultilinearKZG.open(zk.Multilinear(zk.Fr.from_ints([3, 4])), zk.Fr.from_ints([5]),
+                               zk.TrustedSetup.setup(zk.Fr.from_ints([2])))

@@ -392,3 +392,51 @@ def test_srs_with_identity_points(ora):
         ora.g1_affine_ints(ora.g1_to_affine(ora.g1_mul_int(ora.g1_generator(), p_tau)))
     assert ora.g1_affine_ints(ora.g1_to_affine(ora.msm_pippenger(F(ora, vals), aff))) == \
         ora.g1_affine_ints(ora.g1_to_affine(c))
+
+
+# ---- MultilinearKZG::open, multilinear_kzg.rs:50-88 (test data :131-197) ------------------------------------
+def _mle_eval_ints(vals, pts):
+    vals = [v % R for v in vals]
+    for p in pts:   # variable 0 = most significant index bit
+        h = len(vals) // 2
+        vals = [(vals[j] + p * (vals[j + h] - vals[j])) % R for j in range(h)]
+    return vals[0]
+
+
+@pytest.mark.parametrize("vals,tau,z", [
+    ([0, 7, 0, 5, 0, 7, 4, 9], [2, 3, 4], [5, 9, 6]),                                                      # test_kzg_1
+    ([0, 0, 0, 2, 0, 0, 10, 12, 0, -12, 4, -6, 0, -12, 14, 4], [12, 9, 28, 40], [54, 90, 76, 160]),       # test_kzg_2
+])
+def test_multilinear_kzg_open(ora, vals, tau, z):
+    """The reference only checks open through the pairing verifier (out of scope here).  With tau known the pairing
+    equation e(C - v G, g2) = sum_i e(pi_i, (tau_i - z_i) g2) is the exponent identity p(tau) - v = sum_i Q_i(tau)
+    (tau_i - z_i) with pi_i = Q_i(tau) G: both are checked, Q_i being the blown-up quotient of round i."""
+    n_vars = len(tau)
+    srs = ora.kzg_multilinear_srs_g1(F(ora, tau))
+    ev, proofs = ora.kzg_open(F(ora, vals), F(ora, z), srs)
+    v = _mle_eval_ints(vals, z)
+    assert ints(ora, ev) == [v]
+    if vals[1] == 7:
+        assert v == 114   # kzg/src/utils.rs:96 (remainder chain of the same data)
+    g = ora.g1_generator()
+    poly, acc = [x % R for x in vals], 0
+    for i in range(n_vars):
+        h = len(poly) // 2
+        q = [(poly[j + h] - poly[j]) % R for j in range(h)]
+        blown = q * (len(vals) // h)                    # add_to_front: the quotient repeated
+        q_tau = _mle_eval_ints(blown, tau)
+        assert q_tau == _mle_eval_ints(q, tau[i + 1:])  # repeating a table adds variables it does not depend on
+        assert ora.g1_affine_ints(ora.g1_to_affine(proofs[i])) == ora.g1_affine_ints(ora.g1_to_affine(ora.g1_mul_int(g, q_tau)))
+        acc = (acc + q_tau * (tau[i] - z[i])) % R
+        poly = [(poly[j] + z[i] * (poly[j + h] - poly[j])) % R for j in range(h)]
+    assert (_mle_eval_ints(vals, tau) - v) % R == acc
+
+
+def test_multilinear_kzg_open_shape_panics(ora):
+    srs = ora.kzg_multilinear_srs_g1(F(ora, [2, 3, 4]))
+    with pytest.raises(AssertionError):
+        ora.kzg_open(F(ora, [0, 7, 0, 5, 0, 7, 4, 9]), F(ora, [5, 9]), srs)
+    with pytest.raises(AssertionError):
+        ora.kzg_open(F(ora, [0, 7, 0, 5]), F(ora, [5, 9]), srs)
+    with pytest.raises(OverflowError):   # one variable: `variable_index - 1` underflows (multilinear_kzg.rs:73)
+        ora.kzg_open(F(ora, [3, 4]), F(ora, [5]), ora.kzg_multilinear_srs_g1(F(ora, [2])))

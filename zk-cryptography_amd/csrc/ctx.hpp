@@ -58,6 +58,8 @@ struct zkhip_ctx {
     int last_hip = 0;
     void* d_ws = nullptr;       // large workspace (ping-pong tables, MSM buckets, ...)
     size_t ws_bytes = 0;
+    void* d_aux = nullptr;      // second grow-only buffer for entry points that call others which own d_ws (kzg_open)
+    size_t aux_bytes = 0;
     bool ws_lent = false;       // the workspace currently backs a split-phase prover state
     // one cached set of small split-phase buffers, so that a steady stream of sharded proves never allocates
     void* sc_small = nullptr; void* sc_stage = nullptr; size_t sc_stage_cap = 0; bool sc_lent = false;
@@ -85,6 +87,18 @@ struct zkhip_ctx {
     uint64_t* small_u64(size_t off) { return (uint64_t*)d_small + off; }
     uint64_t* pinned_u64(size_t off) { return (uint64_t*)h_pinned + off; }
     // grow-only workspace; growth synchronises (never inside a steady-state timed loop)
+    int reserve_aux(size_t bytes) {
+        if (bytes <= aux_bytes) return ZKHIP_OK;
+        hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { last_hip = (int)e; return ZKHIP_ERR_HIP; }
+        if (d_aux) hipFree(d_aux);
+        d_aux = nullptr;
+        aux_bytes = 0;
+        e = hipMalloc(&d_aux, bytes);
+        if (e != hipSuccess) { last_hip = (int)e; return ZKHIP_ERR_NOMEM; }
+        aux_bytes = bytes;
+        return ZKHIP_OK;
+    }
     int reserve_ws(size_t bytes) {
         if (bytes <= ws_bytes) return ZKHIP_OK;
         hipError_t e = hipStreamSynchronize(stream);

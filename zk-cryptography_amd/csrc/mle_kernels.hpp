@@ -212,6 +212,21 @@ static __global__ __launch_bounds__(MLE_BLOCK) void to_bytes_kernel(const uint64
     }
 }
 
+// One round of MultilinearKZG::open on an n-entry table: quotient[j] = in[j + n/2] - in[j]  (get_poly_quotient,
+// kzg/src/utils.rs:12-17: f(1, .) - f(0, .)) and remainder[j] = in[j] + z (in[j + n/2] - in[j])  (get_poly_remainder,
+// :5-10), j < n/2, from one read of the table.
+static __global__ __launch_bounds__(MLE_BLOCK) void open_step_kernel(const uint64_t* __restrict__ in, size_t n, FrArg z_val,
+                                                              uint64_t* __restrict__ quotient, uint64_t* __restrict__ remainder) {
+    const Fr z = fr_from_arg(z_val);
+    const size_t h = n >> 1, stride = (size_t)gridDim.x * MLE_BLOCK;
+    for (size_t j = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; j < h; j += stride) {
+        const Fr lo = load_fr(in, j), hi = load_fr(in, j + h);
+        const Fr d = hi - lo;
+        store_fr(quotient, j, d);
+        store_fr(remainder, j, lo + z * d);
+    }
+}
+
 inline int mle_grid(size_t n_items) {
     size_t g = (n_items + MLE_BLOCK - 1) / MLE_BLOCK;
     if (g < 1) g = 1;

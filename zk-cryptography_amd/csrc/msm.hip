@@ -45,17 +45,9 @@ static MsmPlan msm_plan(size_t n) {
     return pl;
 }
 
-extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf,
-                                size_t n_points, const uint64_t* d_scalars, size_t n_scalars, int require_equal_len,
-                                uint64_t* h_out_xy, uint8_t* h_out_inf) {
-    if (!c || !h_out_xy || !h_out_inf) return ZKHIP_ERR_ARG;
-    if (require_equal_len && n_points != n_scalars) return ZKHIP_ERR_SHAPE;   // multilinear_kzg.rs:36-41
-    if (n_scalars > n_points) return ZKHIP_ERR_INDEX;                          // univariate_kzg.rs:53
-    const size_t n = n_scalars;
-    if (n == 0) { std::memset(h_out_xy, 0, 96); *h_out_inf = 1; return ZKHIP_OK; }   // P::G1::default()
-    if (!d_points_xy || !d_scalars) return ZKHIP_ERR_ARG;
-    if (n >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
-    ZK_TRY(c->activate());
+// sum_i scalars[i] * points[i] over the first n entries -> affine result on the host
+static int msm_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, const uint64_t* d_scalars, size_t n,
+                      uint64_t* h_out_xy, uint8_t* h_out_inf) {
     const MsmPlan pl = msm_plan(n);
     const size_t n_buckets = (size_t)pl.n_windows * pl.nb;
     const size_t n_segments = (size_t)pl.n_windows * pl.ns;
@@ -168,6 +160,101 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     }
     zkhost::Xyzz res = zkhost::weighted_sum_pow2(pts, exps);
     *h_out_inf = zkhost::xyzz_to_affine(res, h_out_xy) ? 0 : 1;
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf,
+                                size_t n_points, const uint64_t* d_scalars, size_t n_scalars, int require_equal_len,
+                                uint64_t* h_out_xy, uint8_t* h_out_inf) {
+    if (!c || !h_out_xy || !h_out_inf) return ZKHIP_ERR_ARG;
+    if (require_equal_len && n_points != n_scalars) return ZKHIP_ERR_SHAPE;   // multilinear_kzg.rs:36-41
+    if (n_scalars > n_points) return ZKHIP_ERR_INDEX;                          // univariate_kzg.rs:53
+    const size_t n = n_scalars;
+    if (n == 0) { std::memset(h_out_xy, 0, 96); *h_out_inf = 1; return ZKHIP_OK; }   // P::G1::default()
+    if (!d_points_xy || !d_scalars) return ZKHIP_ERR_ARG;
+    if (n >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    return msm_commit(c, d_points_xy, d_points_inf, d_scalars, n, h_out_xy, h_out_inf);
+}
+
+// ---------------------------------------------------------------------------------------
+// MultilinearKZG::open
+// ---------------------------------------------------------------------------------------
+// folded SRS levels S_0 .. S_{nv-1} (n - 1 affine points); d_tmp_xyzz: (n - 1) x 192 bytes of scratch
+static int fold_srs_levels(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, size_t n, uint64_t* d_tmp_xyzz,
+                           uint64_t* d_out_xy, uint8_t* d_out_inf) {
+    size_t h = n / 2, off = 0;
+    hipLaunchKernelGGL(srs_fold_affine_kernel, dim3((unsigned)((h + SRS_BLOCK - 1) / SRS_BLOCK)), dim3(SRS_BLOCK), 0, c->stream,
+                       d_points_xy, d_points_inf, h, d_tmp_xyzz);
+    while (h > 1) {
+        const size_t next = off + h;
+        h /= 2;
+        hipLaunchKernelGGL(srs_fold_xyzz_kernel, dim3((unsigned)((h + SRS_BLOCK - 1) / SRS_BLOCK)), dim3(SRS_BLOCK), 0, c->stream,
+                           d_tmp_xyzz + 24 * off, h, d_tmp_xyzz + 24 * next);
+        off = next;
+    }
+    const size_t total = n - 1, n_threads = (total + SRS_CHUNK - 1) / SRS_CHUNK;
+    hipLaunchKernelGGL(srs_batch_affine_kernel, dim3((unsigned)((n_threads + SRS_BLOCK - 1) / SRS_BLOCK)), dim3(SRS_BLOCK), 0, c->stream,
+                       d_tmp_xyzz, total, d_out_xy, d_out_inf);
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_srs_fold_levels(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, size_t n_points,
+                                     uint64_t* d_out_xy, uint8_t* d_out_inf) {
+    if (!c || !d_points_xy || !d_out_xy || !d_out_inf) return ZKHIP_ERR_ARG;
+    if (n_points < 2 || !is_pow2(n_points)) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    ZK_TRY(c->reserve_ws((n_points - 1) * 192));
+    return fold_srs_levels(c, d_points_xy, d_points_inf, n_points, (uint64_t*)c->d_ws, d_out_xy, d_out_inf);
+}
+
+extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_points, size_t n_eval_points,
+                              const uint64_t* d_points_xy, const uint8_t* d_points_inf, size_t n_points,
+                              const uint64_t* d_folded_xy, const uint8_t* d_folded_inf, uint64_t* h_evaluation,
+                              uint64_t* h_proofs_xy, uint8_t* h_proofs_inf) {
+    if (!c || !d_evals || !h_points || !d_points_xy || !h_evaluation || !h_proofs_xy || !h_proofs_inf) return ZKHIP_ERR_ARG;
+    if (!is_pow2(n)) return ZKHIP_ERR_SHAPE;
+    const uint32_t n_vars = log2_exact(n);
+    if (n_eval_points != n_vars) return ZKHIP_ERR_SHAPE;   // evaluation_form.rs:163-167
+    if (n_points != n) return ZKHIP_ERR_SHAPE;             // multilinear_kzg.rs:36-41
+    if (n_vars < 2) return ZKHIP_ERR_SHAPE;                // :73 `variable_index - 1` underflows
+    if (n >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
+    if ((d_folded_xy == nullptr) != (d_folded_inf == nullptr)) return ZKHIP_ERR_ARG;
+    ZK_TRY(c->activate());
+    // aux layout: quotient (n/2) | remainder ping (n/2) | pong (n/4) | [folded SRS xy, inf]
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_q = 0, o_ping = o_q + al(n / 2 * 32), o_pong = o_ping + al(n / 2 * 32);
+    const size_t o_fxy = o_pong + al((n / 4 + 1) * 32), o_finf = o_fxy + al((n - 1) * 96);
+    const bool own_fold = d_folded_xy == nullptr;
+    ZK_TRY(c->reserve_aux(own_fold ? o_finf + al(n - 1) : o_fxy));
+    char* aux = (char*)c->d_aux;
+    if (own_fold) {
+        ZK_TRY(c->reserve_ws((n - 1) * 192));
+        ProfScope ps(c, "open_fold_srs", 0.0);
+        ZK_TRY(fold_srs_levels(c, d_points_xy, d_points_inf, n, (uint64_t*)c->d_ws, (uint64_t*)(aux + o_fxy), (uint8_t*)(aux + o_finf)));
+        d_folded_xy = (const uint64_t*)(aux + o_fxy);
+        d_folded_inf = (const uint8_t*)(aux + o_finf);
+    }
+    uint64_t* d_q = (uint64_t*)(aux + o_q);
+    const uint64_t* cur = d_evals;
+    size_t cn = n, lvl_off = 0;
+    for (uint32_t i = 0; i < n_vars; ++i) {
+        FrArg z = {};
+        std::memcpy(z.v, h_points + 4 * (size_t)i, 32);
+        uint64_t* rem = (uint64_t*)(aux + ((i & 1) ? o_pong : o_ping));
+        hipLaunchKernelGGL(open_step_kernel, dim3(mle_grid(cn / 2)), dim3(MLE_BLOCK), 0, c->stream, cur, cn, z, d_q, rem);
+        ZK_HIP(c, hipGetLastError());
+        const size_t h = cn / 2;   // |q_i| = |S_i|
+        ZK_TRY(msm_commit(c, d_folded_xy + 12 * lvl_off, d_folded_inf + lvl_off, d_q, h, h_proofs_xy + 12 * (size_t)i, h_proofs_inf + i));
+        lvl_off += h;
+        cur = rem;
+        cn = h;
+    }
+    // the last remainder is poly(z): `evaluation`, and what the reference checks it against (:84-86)
+    ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), cur, 32, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(h_evaluation, c->pinned_u64(ZK_PIN_RES), 32);
     return ZKHIP_OK;
 }
 

@@ -126,4 +126,27 @@ static __global__ __launch_bounds__(SRS_BLOCK) void srs_batch_affine_kernel(cons
     }
 }
 
+
+// ---- folded SRS for MultilinearKZG::open ----------------------------------------------------------------
+// out[j] = P[j] + P[j + h] for the affine SRS (first fold level), result XYZZ
+static __global__ __launch_bounds__(SRS_BLOCK) void srs_fold_affine_kernel(const uint64_t* __restrict__ pts,
+                                                                    const uint8_t* __restrict__ inf, size_t h,
+                                                                    uint64_t* __restrict__ out_xyzz) {
+    const size_t j = (size_t)blockIdx.x * SRS_BLOCK + threadIdx.x;
+    if (j >= h) return;
+    G1Xyzz acc = G1Xyzz::identity();
+    if (!(inf && inf[j])) g1_madd(acc, load_affine(pts, j), false);
+    if (!(inf && inf[j + h])) g1_madd(acc, load_affine(pts, j + h), false);
+    store_xyzz(out_xyzz, j, acc);
+}
+// out[j] = in[j] + in[j + h] (further levels)
+static __global__ __launch_bounds__(SRS_BLOCK) void srs_fold_xyzz_kernel(const uint64_t* __restrict__ in_xyzz, size_t h,
+                                                                  uint64_t* __restrict__ out_xyzz) {
+    const size_t j = (size_t)blockIdx.x * SRS_BLOCK + threadIdx.x;
+    if (j >= h) return;
+    G1Xyzz acc = load_xyzz(in_xyzz, j);
+    g1_add(acc, load_xyzz(in_xyzz, j + h));
+    store_xyzz(out_xyzz, j, acc);
+}
+
 }  // namespace zk

@@ -1,8 +1,8 @@
 """kzg::{TrustedSetup, MultilinearKZG, UnivariateKZG} -- the commit path on the GPU.
 
 Mirrors kzg/src/interface.rs:10-55 for `commitment` (a Pippenger multi-scalar multiplication over
-BLS12-381 G1) and the G1 half of the trusted setup.  `open` and the pairing `verify` are out of scope
-(SURVEY 8a/8f).  A commitment is returned as affine coordinates (x, y Montgomery limbs + infinity flag):
+BLS12-381 G1), `open` (one commitment per variable against the folded SRS) and the G1 half of the trusted
+setup.  The pairing `verify` is out of scope.  A commitment is returned as affine coordinates (x, y Montgomery limbs + infinity flag):
 the reference's Jacobian representation is algorithm dependent, equality is defined on the affine point.
 """
 import ctypes as C
@@ -54,6 +54,18 @@ class TrustedSetup:
     def __len__(self):
         return self.powers_of_tau_in_g1.shape[0]
 
+    def folded(self):
+        """The SRS summed over its leading variables, level after level (n - 1 points): what commitments to the
+        blown-up quotients of `open` reduce to.  Depends on the SRS only; derived once and kept."""
+        if getattr(self, "_folded", None) is None:
+            n = len(self)
+            xy, inf = TrustedSetup._alloc(n - 1)
+            ctx = N.Context.get(self.powers_of_tau_in_g1.device.index)
+            N.check(N.lib().zkhip_srs_fold_levels(ctx.handle, N.ptr(self.powers_of_tau_in_g1), N.ptr(self.inf), C.c_size_t(n),
+                                                  N.ptr(xy), N.ptr(inf)), "srs_fold_levels")
+            self._folded = (xy, inf)
+        return self._folded
+
     @staticmethod
     def _alloc(n):
         import torch
@@ -82,12 +94,43 @@ def _commit(points, inf, n_points, scalars, n_scalars, require_equal_len):
     return G1Affine(out, oinf.value)
 
 
+class MultilinearKZGProof:
+    """kzg/src/multilinear_kzg.rs:17-21: evaluation (Montgomery limbs, uint64 [4]) + one G1 proof per variable"""
+
+    def __init__(self, evaluation, proofs):
+        self.evaluation = evaluation
+        self.proofs = proofs
+
+
 class MultilinearKZG:
     @staticmethod
     def commitment(poly, srs):
         """MultilinearKZGInterface::commitment (multilinear_kzg.rs:33-48)"""
         assert isinstance(poly, Multilinear)
         return _commit(srs.powers_of_tau_in_g1, srs.inf, len(srs), poly.evaluations, len(poly), True)
+
+    @staticmethod
+    def open(poly, evaluation_points, srs, cache_folded_srs=True):
+        """MultilinearKZGInterface::open (multilinear_kzg.rs:50-88)"""
+        assert isinstance(poly, Multilinear)
+        pts = _fr_host(evaluation_points)
+        nv = pts.shape[0]
+        ev = np.empty(4, dtype=np.uint64)
+        pxy = np.zeros((max(nv, 1), 12), dtype=np.uint64)
+        pinf = np.zeros(max(nv, 1), dtype=np.uint8)
+        ctx = N.Context.get(poly.evaluations.device.index)
+        n = len(poly)
+        if cache_folded_srs and len(srs) == n and n >= 4 and n & (n - 1) == 0:
+            fxy, finf = srs.folded()
+            fxy_p, finf_p = N.ptr(fxy), N.ptr(finf)
+        else:
+            fxy_p = finf_p = None
+        st = N.lib().zkhip_kzg_open(ctx.handle, N.ptr(poly.evaluations), C.c_size_t(n), pts.ctypes.data_as(C.c_void_p),
+                                    C.c_size_t(nv), N.ptr(srs.powers_of_tau_in_g1), N.ptr(srs.inf), C.c_size_t(len(srs)),
+                                    fxy_p, finf_p, ev.ctypes.data_as(C.c_void_p), pxy.ctypes.data_as(C.c_void_p),
+                                    pinf.ctypes.data_as(C.c_void_p))
+        N.check(st, "open: points / SRS length must match the polynomial (and n_vars >= 2)")
+        return MultilinearKZGProof(ev, [G1Affine(pxy[i], pinf[i]) for i in range(nv)])
 
 
 class UnivariateKZG:
