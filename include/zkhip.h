@@ -94,6 +94,19 @@ int zkhip_mle_elementwise(zkhip_ctx *ctx, int op, const uint64_t *d_a, const uin
 /* Multilinear::to_bytes (:54-62): 32 big-endian canonical bytes per element into d_out_bytes[32 n] */
 int zkhip_mle_to_bytes(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, uint8_t *d_out_bytes);
 
+/* ---- layered circuit: the GKR prover's table builders (circuit/src/circuit.rs) ----------------------------
+ * Gates arrive as host arrays (h_gate_type: 0 = Add, 1 = Mul; h_in0 / h_in1: input labels); values stay in HBM.
+ *   zkhip_circuit_layer_eval   one step of Circuit::evaluation (:31-57): d_out[g] = d_in[in0[g]] (+|*) d_in[in1[g]];
+ *                              a label >= n_in is the reference's index panic -> ZKHIP_ERR_INDEX
+ *   zkhip_circuit_add_mult_mle Circuit::add_mult_mle (:59-97): the dense 0/1 wiring tables of layer `layer_index`,
+ *                              d_add / d_mul of zkhip_gkr_mle_size(layer_index) elements each, a one at index
+ *                              gate << 2(l+1) | in0 << (l+1) | in1 (circuit/src/utils.rs:12-25) */
+size_t zkhip_gkr_mle_size(uint32_t layer_index);
+int zkhip_circuit_layer_eval(zkhip_ctx *ctx, const uint64_t *d_in, size_t n_in, const uint8_t *h_gate_type,
+                             const uint32_t *h_in0, const uint32_t *h_in1, size_t n_gates, uint64_t *d_out);
+int zkhip_circuit_add_mult_mle(zkhip_ctx *ctx, const uint8_t *h_gate_type, const uint32_t *h_in0, const uint32_t *h_in1,
+                               size_t n_gates, uint32_t layer_index, uint64_t *d_add, uint64_t *d_mul);
+
 /* ---- basic sumcheck prover (sumcheck/src/sumcheck.rs:25-61) -------------------------- */
 /* Block sums of a table: d_out[(2^log_blocks + 1) * 4] = the sums of its 2^log_blocks equal consecutive blocks
  * followed by the total (= Sumcheck::poly_sum, sumcheck.rs:25-27, which also goes to h_total[4] if non-NULL).

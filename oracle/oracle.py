@@ -496,6 +496,78 @@ def msm_pippenger(scalars, pts_affine):
     return o
 
 
+# ---- circuit + GKR (gkr.c) ---------------------------------------------------------------------
+GKR_MAX_LAYERS, GKR_MAX_ROUNDS = 12, 24
+
+
+class GkrProof(C.Structure):
+    _fields_ = [("n_proofs", C.c_size_t), ("sums", C.c_uint64 * (4 * GKR_MAX_LAYERS)), ("n_rounds", C.c_size_t * GKR_MAX_LAYERS),
+                ("round_polys", (Sparse * GKR_MAX_ROUNDS) * GKR_MAX_LAYERS), ("wb", C.c_uint64 * (4 * GKR_MAX_LAYERS)),
+                ("wc", C.c_uint64 * (4 * GKR_MAX_LAYERS)), ("w0", C.c_uint64 * 8)]
+
+    def layer(self, k):
+        """(sum [4], [Sparse per round], wb [4], wc [4]) of sumcheck proof k"""
+        return (np.array(self.sums[4 * k:4 * k + 4], dtype=np.uint64), [self.round_polys[k][r] for r in range(self.n_rounds[k])],
+                np.array(self.wb[4 * k:4 * k + 4], dtype=np.uint64), np.array(self.wc[4 * k:4 * k + 4], dtype=np.uint64))
+
+
+def _circuit_args(layers):
+    """layers: [[(gate_type, in0, in1), ...], ...] with gate_type 'add' | 'mul', layer 0 = output"""
+    n_gates = (C.c_size_t * len(layers))(*[len(l) for l in layers])
+    flat = [g for l in layers for g in l]
+    gt = np.array([0 if g[0] == "add" else 1 for g in flat], dtype=np.uint8)
+    i0 = np.array([g[1] for g in flat], dtype=np.uint32)
+    i1 = np.array([g[2] for g in flat], dtype=np.uint32)
+    return C.c_size_t(len(layers)), n_gates, gt, i0, i1
+
+
+def gkr_mle_size(layer_index):
+    lib().ora_gkr_mle_size.restype = C.c_size_t
+    return lib().ora_gkr_mle_size(C.c_size_t(layer_index))
+
+
+def circuit_evaluation(layers, inp):
+    """Circuit::evaluation (circuit.rs:31-57) -> list of uint64 [len, 4] arrays, output layer first, input last"""
+    inp = _fr(inp).reshape(-1, 4)
+    nl, ng, gt, i0, i1 = _circuit_args(layers)
+    total = inp.shape[0] + sum(len(l) for l in layers)
+    out = np.empty((total, 4), dtype=np.uint64)
+    lens = (C.c_size_t * (len(layers) + 1))()
+    rc = lib().ora_circuit_evaluation(nl, ng, _p(gt), _p(i0), _p(i1), _p(inp), C.c_size_t(inp.shape[0]), _p(out), lens)
+    if rc != 0:
+        raise IndexError("gate input out of range")
+    res, off = [], 0
+    for k in range(len(layers) + 1):
+        res.append(out[off:off + lens[k]].copy())
+        off += lens[k]
+    return res
+
+
+def circuit_add_mult_mle(layers, layer_index):
+    nl, ng, gt, i0, i1 = _circuit_args(layers)
+    size = gkr_mle_size(layer_index)
+    add, mul = np.empty((size, 4), dtype=np.uint64), np.empty((size, 4), dtype=np.uint64)
+    assert lib().ora_circuit_add_mult_mle(nl, ng, _p(gt), _p(i0), _p(i1), C.c_size_t(layer_index), _p(add), _p(mul)) == 0
+    return add, mul
+
+
+def gkr_prove(layers, evaluation):
+    nl, ng, gt, i0, i1 = _circuit_args(layers)
+    flat = np.ascontiguousarray(np.concatenate([_fr(e).reshape(-1, 4) for e in evaluation]))
+    lens = (C.c_size_t * len(evaluation))(*[len(e) for e in evaluation])
+    proof = GkrProof()
+    rc = lib().ora_gkr_prove(nl, ng, _p(gt), _p(i0), _p(i1), _p(flat), lens, C.byref(proof))
+    if rc != 0:
+        raise AssertionError("gkr_prove: shape error %d" % rc)
+    return proof
+
+
+def gkr_verify(layers, inp, proof):
+    inp = _fr(inp).reshape(-1, 4)
+    nl, ng, gt, i0, i1 = _circuit_args(layers)
+    return lib().ora_gkr_verify(nl, ng, _p(gt), _p(i0), _p(i1), _p(inp), C.c_size_t(inp.shape[0]), C.byref(proof)) == 1
+
+
 # ---- NTT ---------------------------------------------------------------------------------------
 def domain_fft(coeffs, size):
     coeffs = _fr(coeffs).reshape(-1, 4)

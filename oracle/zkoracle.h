@@ -119,6 +119,29 @@ int  ora_multi_composed_prove(const fr_t *tables, const size_t *term_sizes, size
 int  ora_multi_composed_verify(const fr_t *tables, const size_t *term_sizes, size_t n_terms, size_t n,
                                const fr_t *sum, const ora_sparse_t *round_polys, size_t n_rounds);
 
+/* ---- GKR (gkr/src/protocol.rs, gkr/src/utils.rs) over the layered circuit (circuit/src/circuit.rs) ----------
+ * A circuit travels as flat arrays: n_gates[l] gates in layer l (layer 0 = output), then per gate (layers
+ * concatenated) gate_type (0 = Add, 1 = Mul) and the two input labels. */
+#define ORA_GKR_MAX_LAYERS 12
+#define ORA_GKR_MAX_ROUNDS 24
+typedef struct {
+    size_t n_proofs;
+    fr_t sums[ORA_GKR_MAX_LAYERS];                                 /* ComposedSumcheckProof::sum */
+    size_t n_rounds[ORA_GKR_MAX_LAYERS];
+    ora_sparse_t round_polys[ORA_GKR_MAX_LAYERS][ORA_GKR_MAX_ROUNDS];
+    fr_t wb[ORA_GKR_MAX_LAYERS], wc[ORA_GKR_MAX_LAYERS];
+    fr_t w0[2];                                                    /* w_0_mle: [output, 0] */
+} ora_gkr_proof_t;
+size_t ora_gkr_mle_size(size_t layer_index);
+int  ora_circuit_evaluation(size_t n_layers, const size_t *n_gates, const uint8_t *gate_type, const uint32_t *in0,
+                            const uint32_t *in1, const fr_t *input, size_t n_input, fr_t *out, size_t *layer_len);
+int  ora_circuit_add_mult_mle(size_t n_layers, const size_t *n_gates, const uint8_t *gate_type, const uint32_t *in0,
+                              const uint32_t *in1, size_t layer_index, fr_t *add, fr_t *mul);
+int  ora_gkr_prove(size_t n_layers, const size_t *n_gates, const uint8_t *gate_type, const uint32_t *in0,
+                   const uint32_t *in1, const fr_t *layers, const size_t *layer_len, ora_gkr_proof_t *proof);
+int  ora_gkr_verify(size_t n_layers, const size_t *n_gates, const uint8_t *gate_type, const uint32_t *in0,
+                    const uint32_t *in1, const fr_t *input, size_t n_input, const ora_gkr_proof_t *proof);
+
 /* ---- G1 + KZG ------------------------------------------------------------- */
 void ora_g1_generator(g1_jac_t *o);
 void ora_g1_identity(g1_jac_t *o);

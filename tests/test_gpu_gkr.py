@@ -1,0 +1,95 @@
+"""GPU parity: circuit evaluation, wiring tables and GKRProtocol::prove vs the CPU oracle's restatement
+(oracle/gkr.c, pinned by the reference's circuit / GKR tests); names follow circuit/src/circuit.rs and
+gkr/src/protocol.rs tests.  The GPU proof must be bit-identical to the oracle's and pass its restated verifier."""
+import numpy as np
+import pytest
+
+from gkr_cases import CIRCUIT_2, CIRCUIT_3, GKR_1, GKR_2, random_circuit
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zk():
+    import zk_cryptography_amd as z
+    return z
+
+
+def _host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("case", [GKR_1, CIRCUIT_2, CIRCUIT_3])
+def test_circuit_evaluation(zk, case):   # circuit.rs:139-260
+    ev = zk.Circuit.from_tuples(case["layers"]).evaluation(zk.Fr.from_ints(case["input"]))
+    assert [zk.Fr.to_ints(_host(e)) for e in ev] == case["evaluation"]
+
+
+def test_circuit_evaluation_index_panic(zk):
+    with pytest.raises(IndexError):
+        zk.Circuit.from_tuples([[("add", 0, 4)]]).evaluation(zk.Fr.from_ints([1, 2, 3, 4]))
+
+
+@pytest.mark.parametrize("layer_index", [0, 1, 2])
+def test_get_add_n_mul_mle(zk, ora, layer_index):   # circuit.rs:262-518
+    c = zk.Circuit.from_tuples(CIRCUIT_3["layers"])
+    add, mul = c.add_mult_mle(layer_index)
+    want_add, want_mul = ora.circuit_add_mult_mle(CIRCUIT_3["layers"], layer_index)
+    assert np.array_equal(_host(add.evaluations), want_add) and np.array_equal(_host(mul.evaluations), want_mul)
+    assert add.n_vars == [3, 5, 8][layer_index]
+    if layer_index == 1:
+        assert zk.Fr.to_ints(mul.evaluation(zk.Fr.from_ints([1, 1, 0, 1, 1]))) == [1]
+        assert zk.Fr.to_ints(add.evaluation(zk.Fr.from_ints([0, 0, 0, 0, 1]))) == [1]
+
+
+def _to_oracle_proof(zk, ora, proof):
+    p = ora.GkrProof()
+    p.n_proofs = len(proof.sumcheck_proofs)
+    for k, sp in enumerate(proof.sumcheck_proofs):
+        p.sums[4 * k:4 * k + 4] = [int(v) for v in sp.sum]
+        p.n_rounds[k] = len(sp.round_polys)
+        for r, rp in enumerate(sp.round_polys):
+            s = p.round_polys[k][r]
+            s.len = len(rp.coeffs)
+            for m in range(len(rp.coeffs)):
+                s.coeff[4 * m:4 * m + 4] = [int(v) for v in rp.coeffs[m]]
+                s.pow[4 * m:4 * m + 4] = [int(v) for v in rp.pows[m]]
+        p.wb[4 * k:4 * k + 4] = [int(v) for v in proof.wb_s[k]]
+        p.wc[4 * k:4 * k + 4] = [int(v) for v in proof.wc_s[k]]
+    p.w0[0:8] = [int(v) for v in _host(proof.w_0_mle.evaluations).reshape(-1)]
+    return p
+
+
+def _check_against_oracle(zk, ora, layers, inp):
+    circuit = zk.Circuit.from_tuples(layers)
+    ev = circuit.evaluation(inp)
+    want_ev = ora.circuit_evaluation(layers, inp)
+    assert all(np.array_equal(_host(a), b) for a, b in zip(ev, want_ev))
+    proof = zk.GKRProtocol.prove(circuit, ev)
+    want = ora.gkr_prove(layers, want_ev)
+    assert len(proof.sumcheck_proofs) == want.n_proofs == len(layers)
+    for k, sp in enumerate(proof.sumcheck_proofs):
+        w_sum, w_rps, w_wb, w_wc = want.layer(k)
+        assert np.array_equal(sp.sum, w_sum)
+        assert sp.to_bytes() == ora.multi_composed_proof_bytes(w_rps)
+        assert np.array_equal(proof.wb_s[k], w_wb) and np.array_equal(proof.wc_s[k], w_wc)
+    assert ora.gkr_verify(layers, inp, _to_oracle_proof(zk, ora, proof))
+    return proof
+
+
+def test_gkr_protocol_1(zk, ora):   # protocol.rs:209-232
+    _check_against_oracle(zk, ora, GKR_1["layers"], zk.Fr.from_ints(GKR_1["input"]))
+
+
+def test_gkr_protocol_2(zk, ora):   # protocol.rs:234-286
+    circuit = zk.Circuit.from_tuples(GKR_2["layers"])
+    ev = circuit.evaluation(zk.Fr.from_ints(GKR_2["input"]))
+    assert zk.Fr.to_ints(_host(ev[0])) == [224]
+    proof = _check_against_oracle(zk, ora, GKR_2["layers"], zk.Fr.from_ints(GKR_2["input"]))
+    bad = list(GKR_2["input"]); bad[3] += 1
+    assert not ora.gkr_verify(GKR_2["layers"], zk.Fr.from_ints(bad), _to_oracle_proof(zk, ora, proof))
+
+
+@pytest.mark.parametrize("depth", [3, 6])
+def test_gkr_random_circuit(zk, ora, depth):   # Circuit::random (circuit.rs:99-122), gkr/benches
+    _check_against_oracle(zk, ora, random_circuit(depth), ora.random_fr(2 ** depth, 40 + depth))

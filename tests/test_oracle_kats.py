@@ -440,3 +440,53 @@ def test_multilinear_kzg_open_shape_panics(ora):
         ora.kzg_open(F(ora, [0, 7, 0, 5]), F(ora, [5, 9]), srs)
     with pytest.raises(OverflowError):   # one variable: `variable_index - 1` underflows (multilinear_kzg.rs:73)
         ora.kzg_open(F(ora, [3, 4]), F(ora, [5]), ora.kzg_multilinear_srs_g1(F(ora, [2])))
+
+
+# ---- circuit + GKR: circuit/src/circuit.rs, gkr/src/protocol.rs ---------------------------------------------
+from gkr_cases import CIRCUIT_2, CIRCUIT_3, GKR_1, GKR_2, random_circuit   # noqa: E402
+
+
+@pytest.mark.parametrize("case", [GKR_1, CIRCUIT_2, CIRCUIT_3])
+def test_circuit_evaluation(ora, case):   # circuit.rs:139-260
+    ev = ora.circuit_evaluation(case["layers"], F(ora, case["input"]))
+    assert [ints(ora, e) for e in ev] == case["evaluation"]
+
+
+def test_circuit_wiring_tables(ora):   # circuit.rs:262-518 (positions of the ones) and circuit/src/utils.rs:41-64
+    assert [ora.gkr_mle_size(i) for i in range(4)] == [8, 32, 256, 2048]
+    layers = CIRCUIT_3["layers"]
+    add0, mul0 = ora.circuit_add_mult_mle(layers, 0)
+    assert ints(ora, add0) == [0, 1, 0, 0, 0, 0, 0, 0] and not any(ints(ora, mul0))          # a=0 b=0 c=1
+    eq(ora, ora.mle_evaluation(add0, F(ora, [0, 0, 1])), [1])
+    add1, mul1 = ora.circuit_add_mult_mle(layers, 1)
+    assert len(add1) == 32
+    eq(ora, ora.mle_evaluation(add1, F(ora, [0, 0, 0, 0, 1])), [1])      # gate 0 = add(0, 1)
+    eq(ora, ora.mle_evaluation(mul1, F(ora, [1, 1, 0, 1, 1])), [1])      # gate 1 = mul(2, 3)
+    eq(ora, ora.mle_evaluation(mul1, F(ora, [1, 0, 0, 1, 1])), [0])
+    add2, mul2 = ora.circuit_add_mult_mle(layers, 2)
+    assert len(add2) == 256 and sum(ints(ora, add2)) == 1 and sum(ints(ora, mul2)) == 3
+    # gate 3 = mul(6, 7): a = 11, b = 110, c = 111
+    eq(ora, ora.mle_evaluation(mul2, F(ora, [1, 1, 1, 1, 0, 1, 1, 1])), [1])
+
+
+@pytest.mark.parametrize("case", [GKR_1, GKR_2])
+def test_gkr_prove_verify(ora, case):   # protocol.rs:209-286
+    ev = ora.circuit_evaluation(case["layers"], F(ora, case["input"]))
+    if "output" in case:
+        assert ints(ora, ev[0]) == [case["output"]]
+    proof = ora.gkr_prove(case["layers"], ev)
+    assert proof.n_proofs == len(case["layers"])
+    assert ora.gkr_verify(case["layers"], F(ora, case["input"]), proof)
+    # a proof for other inputs / a tampered evaluation is rejected
+    bad = list(case["input"]); bad[0] += 1
+    assert not ora.gkr_verify(case["layers"], F(ora, bad), proof)
+    proof.wb[0] ^= 1
+    assert not ora.gkr_verify(case["layers"], F(ora, case["input"]), proof)
+
+
+def test_gkr_random_circuit_depth_5(ora):   # Circuit::random, gkr/benches
+    layers = random_circuit(5)
+    inp = ora.random_fr(32, 99)
+    ev = ora.circuit_evaluation(layers, inp)
+    proof = ora.gkr_prove(layers, ev)
+    assert ora.gkr_verify(layers, inp, proof)

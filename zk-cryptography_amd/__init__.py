@@ -3,7 +3,8 @@
 Host-side mirror (Python over ctypes) of the reference's Rust surfaces for the hot path:
     polynomial::Multilinear / MultilinearTrait      -> zk_cryptography_amd.polynomial
     sumcheck::{Sumcheck, ComposedSumcheck, MultiComposedSumcheckProver} -> .sumcheck
-    kzg::{MultilinearKZG, UnivariateKZG}::commitment -> .kzg
+    kzg::{MultilinearKZG, UnivariateKZG}::commitment, MultilinearKZG::open -> .kzg
+    circuit::Circuit, gkr::GKRProtocol::prove -> .gkr
     polynomial::univariate::{Domain, UnivariateEval} -> .univariate
 Every operation runs hand-written HIP kernels in csrc/libzkhip.so through the C ABI of
 include/zkhip.h; there is no CPU fallback (a missing library or GPU raises).
@@ -18,3 +19,4 @@ from zk_cryptography_amd.composed import (ComposedMultilinear, ComposedSumcheck,
                                           MultiComposedSumcheckProof, MultiComposedSumcheckProver,
                                           SparseUnivariatePolynomial)
 from zk_cryptography_amd.univariate import Domain, UnivariateEval  # noqa: F401
+from zk_cryptography_amd.gkr import Circuit, CircuitLayer, FiatShamirTranscript, Gate, GKRProof, GKRProtocol  # noqa: F401

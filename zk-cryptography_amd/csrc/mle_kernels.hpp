@@ -227,6 +227,27 @@ static __global__ __launch_bounds__(MLE_BLOCK) void open_step_kernel(const uint6
     }
 }
 
+// Circuit::evaluation, one layer (circuit/src/circuit.rs:41-50): gate = (type u8 | in0 u32 | in1 u32) packed as 3 words
+static __global__ __launch_bounds__(MLE_BLOCK) void circuit_layer_kernel(const uint64_t* __restrict__ in, const uint32_t* __restrict__ gates,
+                                                                  size_t n_gates, uint64_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    for (size_t g = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; g < n_gates; g += stride) {
+        const uint32_t type = gates[3 * g], a = gates[3 * g + 1], b = gates[3 * g + 2];
+        const Fr x = load_fr(in, a), y = load_fr(in, b);
+        store_fr(out, g, type ? x * y : x + y);
+    }
+}
+// Circuit::add_mult_mle (circuit.rs:59-97): the tables are zeroed first; one lane per gate sets its one
+static __global__ __launch_bounds__(MLE_BLOCK) void wiring_ones_kernel(const uint32_t* __restrict__ gates, size_t n_gates, uint32_t shift,
+                                                                uint64_t* __restrict__ add, uint64_t* __restrict__ mul) {
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    for (size_t g = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; g < n_gates; g += stride) {
+        const uint32_t type = gates[3 * g], a = gates[3 * g + 1], b = gates[3 * g + 2];
+        const size_t idx = (g << (2 * shift)) | ((size_t)a << shift) | b;
+        store_fr(type ? mul : add, idx, Fr::one());
+    }
+}
+
 inline int mle_grid(size_t n_items) {
     size_t g = (n_items + MLE_BLOCK - 1) / MLE_BLOCK;
     if (g < 1) g = 1;

@@ -329,6 +329,64 @@ extern "C" int zkhip_mle_to_bytes(zkhip_ctx* c, const uint64_t* d_evals, size_t 
 }
 
 // ---------------------------------------------------------------------------------------
+// layered circuit (GKR table builders)
+// ---------------------------------------------------------------------------------------
+extern "C" size_t zkhip_gkr_mle_size(uint32_t layer_index) {   // circuit/src/utils.rs:1-10
+    if (layer_index == 0) return (size_t)1 << 3;
+    return (size_t)1 << (layer_index + 2 * (layer_index + 1));
+}
+// packs the host gate arrays into the workspace as (type, in0, in1) words
+static int upload_gates(zkhip_ctx* c, const uint8_t* h_gate_type, const uint32_t* h_in0, const uint32_t* h_in1, size_t n_gates,
+                        uint32_t** d_gates) {
+    std::vector<uint32_t> packed(3 * n_gates);
+    for (size_t g = 0; g < n_gates; ++g) {
+        packed[3 * g] = h_gate_type[g] ? 1u : 0u;
+        packed[3 * g + 1] = h_in0[g];
+        packed[3 * g + 2] = h_in1[g];
+    }
+    ZK_TRY(c->reserve_ws(12 * n_gates + 256));
+    ZK_HIP(c, hipMemcpyAsync(c->d_ws, packed.data(), 12 * n_gates, hipMemcpyHostToDevice, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));   // `packed` is a stack temporary
+    *d_gates = (uint32_t*)c->d_ws;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_circuit_layer_eval(zkhip_ctx* c, const uint64_t* d_in, size_t n_in, const uint8_t* h_gate_type,
+                                        const uint32_t* h_in0, const uint32_t* h_in1, size_t n_gates, uint64_t* d_out) {
+    if (!c || !d_in || !d_out || (n_gates && (!h_gate_type || !h_in0 || !h_in1))) return ZKHIP_ERR_ARG;
+    for (size_t g = 0; g < n_gates; ++g)
+        if (h_in0[g] >= n_in || h_in1[g] >= n_in) return ZKHIP_ERR_INDEX;   // current_input[e.inputs[k]] panics
+    if (n_gates == 0) return ZKHIP_OK;
+    ZK_TRY(c->activate());
+    uint32_t* d_gates = nullptr;
+    ZK_TRY(upload_gates(c, h_gate_type, h_in0, h_in1, n_gates, &d_gates));
+    hipLaunchKernelGGL(circuit_layer_kernel, dim3(mle_grid(n_gates)), dim3(MLE_BLOCK), 0, c->stream, d_in, d_gates, n_gates, d_out);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipStreamSynchronize(c->stream));   // the gate list lives in the shared workspace
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_circuit_add_mult_mle(zkhip_ctx* c, const uint8_t* h_gate_type, const uint32_t* h_in0, const uint32_t* h_in1,
+                                          size_t n_gates, uint32_t layer_index, uint64_t* d_add, uint64_t* d_mul) {
+    if (!c || !d_add || !d_mul || (n_gates && (!h_gate_type || !h_in0 || !h_in1))) return ZKHIP_ERR_ARG;
+    if (layer_index > 12) return ZKHIP_ERR_SHAPE;   // 2^(3 l + 2) elements
+    const size_t size = zkhip_gkr_mle_size(layer_index);
+    const uint32_t shift = layer_index + 1;
+    for (size_t g = 0; g < n_gates; ++g) {
+        const size_t idx = (g << (2 * shift)) | ((size_t)h_in0[g] << shift) | h_in1[g];
+        if (idx >= size) return ZKHIP_ERR_INDEX;     // add_evaluations[gate_decimal] out of bounds
+    }
+    ZK_TRY(c->activate());
+    ZK_HIP(c, hipMemsetAsync(d_add, 0, 32 * size, c->stream));   // F::zero() is all-zero limbs
+    ZK_HIP(c, hipMemsetAsync(d_mul, 0, 32 * size, c->stream));
+    if (n_gates == 0) return ZKHIP_OK;
+    uint32_t* d_gates = nullptr;
+    ZK_TRY(upload_gates(c, h_gate_type, h_in0, h_in1, n_gates, &d_gates));
+    hipLaunchKernelGGL(wiring_ones_kernel, dim3(mle_grid(n_gates)), dim3(MLE_BLOCK), 0, c->stream, d_gates, n_gates, shift, d_add, d_mul);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    return ZKHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // basic sumcheck prover
 // ---------------------------------------------------------------------------------------
 // Stage plan of the prover: a table of cur_n > TAIL_N entries is folded by k variables at once, k chosen so
