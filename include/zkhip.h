@@ -107,6 +107,19 @@ int zkhip_circuit_layer_eval(zkhip_ctx *ctx, const uint64_t *d_in, size_t n_in, 
 int zkhip_circuit_add_mult_mle(zkhip_ctx *ctx, const uint8_t *h_gate_type, const uint32_t *h_in0, const uint32_t *h_in1,
                                size_t n_gates, uint32_t layer_index, uint64_t *d_add, uint64_t *d_mul);
 
+/* GKRProtocol::prove (gkr/src/protocol.rs:21-117 with gkr/src/utils.rs:8-56) in one call, every table in HBM.
+ *   circuit    : n_layers layers, layer l with h_n_gates[l] gates (layer 0 = output); gate arrays concatenated
+ *   evaluation : h_layer_ptrs[k], k = 0..n_layers, DEVICE tables as Circuit::evaluation returns them (output first,
+ *                input last), h_layer_len[k] entries each.  The reference's shape panics (Multilinear::new on a
+ *                non-power-of-two layer, mismatching table sizes) -> ZKHIP_ERR_SHAPE.
+ * Outputs (host), one ComposedSumcheckProof per layer k < n_layers, R = 2 * n_layers rounds reserved per proof:
+ *   h_sums[k*4]; h_n_rounds[k]; h_round_poly_lens[k*R + r]; h_round_polys[(k*R + r)*7*8] (coeff[4], pow[4] pairs as
+ *   zkhip_multi_composed_prove); h_wb[k*4], h_wc[k*4] (GKRProof::wb_s / wc_s); h_w0[8] = w_0_mle = [output, 0]. */
+int zkhip_gkr_prove(zkhip_ctx *ctx, uint32_t n_layers, const size_t *h_n_gates, const uint8_t *h_gate_type,
+                    const uint32_t *h_in0, const uint32_t *h_in1, const uint64_t *const *h_layer_ptrs,
+                    const size_t *h_layer_len, uint64_t *h_sums, uint32_t *h_n_rounds, uint32_t *h_round_poly_lens,
+                    uint64_t *h_round_polys, uint64_t *h_wb, uint64_t *h_wc, uint64_t *h_w0);
+
 /* ---- basic sumcheck prover (sumcheck/src/sumcheck.rs:25-61) -------------------------- */
 /* Block sums of a table: d_out[(2^log_blocks + 1) * 4] = the sums of its 2^log_blocks equal consecutive blocks
  * followed by the total (= Sumcheck::poly_sum, sumcheck.rs:25-27, which also goes to h_total[4] if non-NULL).

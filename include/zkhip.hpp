@@ -11,6 +11,7 @@
 //   polynomial::univariate::{Domain, UnivariateEval, DenseUnivariatePolynomial}
 #pragma once
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -361,6 +362,83 @@ struct UnivariateKZG {
         return s;
     }
     static G1Affine commitment(const DenseUnivariatePolynomial& poly, const TrustedSetup& srs) { return commit_impl(srs, poly.dev->u64(), poly.n, 0); }   // :37-58
+};
+
+// ---- circuit::{Gate, CircuitLayer, Circuit}, gkr::GKRProtocol::prove -----------------------------------------------------
+enum class GateType { Add, Mul };                                                              // circuit/src/gate.rs:1-5
+struct Gate { GateType gate_type; size_t inputs[2]; };                                         // gate.rs:7-17
+struct CircuitLayer { std::vector<Gate> layer; };                                              // circuit.rs:8-11
+class Circuit {                                                                                // circuit.rs:13-16
+  public:
+    std::vector<CircuitLayer> layers;
+    explicit Circuit(std::vector<CircuitLayer> l) : layers(std::move(l)) {}
+    // device-resident layer values, output layer first, input last (Circuit::evaluation, circuit.rs:31-57)
+    struct Evaluation {
+        std::vector<std::shared_ptr<DeviceBuffer>> tables;
+        std::vector<size_t> lens;
+        std::vector<Fr> layer(size_t k) const { std::vector<Fr> v(lens[k]); tables[k]->download(v.data(), 32 * lens[k]); return v; }
+    };
+    Evaluation evaluation(const std::vector<Fr>& input) const {
+        Evaluation ev;
+        auto cur = std::make_shared<DeviceBuffer>(32 * input.size());
+        cur->upload(input.data(), 32 * input.size());
+        ev.tables.push_back(cur); ev.lens.push_back(input.size());
+        for (size_t li = layers.size(); li-- > 0;) {
+            std::vector<uint8_t> gt; std::vector<uint32_t> i0, i1;
+            arrays(layers[li], gt, i0, i1);
+            auto out = std::make_shared<DeviceBuffer>(32 * gt.size());
+            int st = zkhip_circuit_layer_eval(ctx(), ev.tables.back()->u64(), ev.lens.back(), gt.data(), i0.data(), i1.data(), gt.size(), out->u64());
+            if (st == ZKHIP_ERR_INDEX) throw std::out_of_range("index out of bounds: gate input");
+            check(st, "circuit_layer_eval");
+            ev.tables.push_back(out); ev.lens.push_back(gt.size());
+        }
+        std::reverse(ev.tables.begin(), ev.tables.end());
+        std::reverse(ev.lens.begin(), ev.lens.end());
+        return ev;
+    }
+    static void arrays(const CircuitLayer& l, std::vector<uint8_t>& gt, std::vector<uint32_t>& i0, std::vector<uint32_t>& i1) {
+        for (auto& g : l.layer) { gt.push_back(g.gate_type == GateType::Add ? 0 : 1); i0.push_back((uint32_t)g.inputs[0]); i1.push_back((uint32_t)g.inputs[1]); }
+    }
+};
+struct GKRProof {                                                                              // gkr/src/protocol.rs:10-15
+    std::vector<MultiComposedSumcheckProof> sumcheck_proofs;
+    std::vector<Fr> wb_s, wc_s;
+    std::vector<Fr> w_0_mle;
+};
+struct GKRProtocol {
+    static GKRProof prove(const Circuit& circuit, const Circuit::Evaluation& ev) {             // protocol.rs:21-117
+        const uint32_t nl = (uint32_t)circuit.layers.size(), stride = 2 * nl;
+        std::vector<size_t> n_gates;
+        std::vector<uint8_t> gt; std::vector<uint32_t> i0, i1;
+        for (auto& l : circuit.layers) { n_gates.push_back(l.layer.size()); Circuit::arrays(l, gt, i0, i1); }
+        std::vector<const uint64_t*> ptrs;
+        for (auto& t : ev.tables) ptrs.push_back(t->u64());
+        std::vector<Fr> sums(nl), wb(nl), wc(nl), w0(2);
+        std::vector<uint32_t> n_rounds(nl), lens((size_t)nl * stride);
+        std::vector<uint64_t> rps((size_t)nl * stride * 7 * 8);
+        int st = zkhip_gkr_prove(ctx(), nl, n_gates.data(), gt.data(), i0.data(), i1.data(), ptrs.data(), ev.lens.data(), sums[0].l, n_rounds.data(),
+                                 lens.data(), rps.data(), wb[0].l, wc[0].l, w0[0].l);
+        if (st == ZKHIP_ERR_SHAPE) throw Panic("Number of evaluations must be a power of 2");
+        check(st, "gkr_prove");
+        GKRProof proof;
+        for (uint32_t k = 0; k < nl; ++k) {
+            MultiComposedSumcheckProof sp;
+            sp.sum = sums[k];
+            for (uint32_t r = 0; r < n_rounds[k]; ++r) {
+                SparseUnivariatePolynomial poly;
+                for (uint32_t m = 0; m < lens[(size_t)k * stride + r]; ++m) {
+                    UnivariateMonomial mono;
+                    std::memcpy(mono.coeff.l, &rps[(((size_t)k * stride + r) * 7 + m) * 8], 32);
+                    std::memcpy(mono.pow.l, &rps[(((size_t)k * stride + r) * 7 + m) * 8 + 4], 32);
+                    poly.monomial.push_back(mono);
+                }
+                sp.round_polys.push_back(poly);
+            }
+            proof.sumcheck_proofs.push_back(sp);
+        }
+        proof.wb_s = wb; proof.wc_s = wc; proof.w_0_mle = w0;
+        return proof;
+    }
 };
 
 // ---- polynomial::univariate::{Domain, UnivariateEval} -------------------------------------------------------------------

@@ -198,6 +198,64 @@ TEST(test_kzg_random_2_10) {
     ora_g1_mul_bigint(&want, &g, canon, 4);          // commit == p(tau) * G
     EXPECT(same_point(commit, want));
 }
+// ---- circuit / GKR ------------------------------------------------------------------------------------------------------
+static Circuit make_circuit(const std::vector<std::vector<std::array<int, 3>>>& layers) {   // {type (0 add, 1 mul), in0, in1}
+    std::vector<CircuitLayer> ls;
+    for (auto& l : layers) {
+        CircuitLayer cl;
+        for (auto& g : l) cl.layer.push_back(Gate{g[0] ? GateType::Mul : GateType::Add, {(size_t)g[1], (size_t)g[2]}});
+        ls.push_back(cl);
+    }
+    return Circuit(ls);
+}
+static void gkr_case(const Circuit& circuit, const std::vector<Fr>& input, int64_t expected_output) {
+    auto ev = circuit.evaluation(input);
+    EXPECT(ev.layer(0)[0] == Fr::from(expected_output));
+    GKRProof proof = GKRProtocol::prove(circuit, ev);
+    // the oracle's restatement of the same circuit: identical proof, accepted by the restated verifier
+    std::vector<size_t> n_gates; std::vector<uint8_t> gt; std::vector<uint32_t> i0, i1;
+    for (auto& l : circuit.layers) { n_gates.push_back(l.layer.size()); Circuit::arrays(l, gt, i0, i1); }
+    size_t total = 0;
+    for (auto n : ev.lens) total += n;
+    std::vector<Fr> flat(total);
+    std::vector<size_t> lens(ev.lens.size());
+    EXPECT(ora_circuit_evaluation(circuit.layers.size(), n_gates.data(), gt.data(), i0.data(), i1.data(), O(input), input.size(), (fr_t*)flat.data(), lens.data()) == 0);
+    auto want = std::make_unique<ora_gkr_proof_t>();
+    EXPECT(ora_gkr_prove(circuit.layers.size(), n_gates.data(), gt.data(), i0.data(), i1.data(), (const fr_t*)flat.data(), lens.data(), want.get()) == 0);
+    EXPECT(want->n_proofs == proof.sumcheck_proofs.size());
+    auto got = std::make_unique<ora_gkr_proof_t>();
+    std::memset(got.get(), 0, sizeof(ora_gkr_proof_t));
+    got->n_proofs = proof.sumcheck_proofs.size();
+    for (size_t k = 0; k < proof.sumcheck_proofs.size(); ++k) {
+        auto& sp = proof.sumcheck_proofs[k];
+        std::memcpy(&got->sums[k], sp.sum.l, 32);
+        got->n_rounds[k] = sp.round_polys.size();
+        for (size_t r = 0; r < sp.round_polys.size(); ++r) {
+            got->round_polys[k][r].len = sp.round_polys[r].monomial.size();
+            for (size_t m = 0; m < sp.round_polys[r].monomial.size(); ++m) {
+                std::memcpy(&got->round_polys[k][r].coeff[m], sp.round_polys[r].monomial[m].coeff.l, 32);
+                std::memcpy(&got->round_polys[k][r].pow[m], sp.round_polys[r].monomial[m].pow.l, 32);
+            }
+            EXPECT(want->round_polys[k][r].len == got->round_polys[k][r].len &&
+                   std::memcmp(want->round_polys[k][r].coeff, got->round_polys[k][r].coeff, 32 * got->round_polys[k][r].len) == 0);
+        }
+        std::memcpy(&got->wb[k], proof.wb_s[k].l, 32);
+        std::memcpy(&got->wc[k], proof.wc_s[k].l, 32);
+        EXPECT(std::memcmp(&want->wb[k], &got->wb[k], 32) == 0 && std::memcmp(&want->wc[k], &got->wc[k], 32) == 0);
+    }
+    std::memcpy(got->w0, proof.w_0_mle[0].l, 64);
+    EXPECT(ora_gkr_verify(circuit.layers.size(), n_gates.data(), gt.data(), i0.data(), i1.data(), O(input), input.size(), got.get()) == 1);
+}
+TEST(test_gkr_protocol_1) {   // gkr/src/protocol.rs:209-232
+    gkr_case(make_circuit({{{1, 0, 1}}, {{0, 0, 1}, {1, 2, 3}}}), F({2, 3, 4, 5}), 100);
+}
+TEST(test_gkr_protocol_2) {   // gkr/src/protocol.rs:234-286
+    gkr_case(make_circuit({{{0, 0, 1}},
+                           {{1, 0, 1}, {0, 2, 3}},
+                           {{0, 0, 1}, {1, 2, 3}, {1, 4, 5}, {1, 6, 7}},
+                           {{1, 0, 1}, {1, 2, 3}, {1, 4, 5}, {0, 6, 7}, {1, 8, 9}, {0, 10, 11}, {1, 12, 13}, {1, 14, 15}}}),
+             F({2, 1, 3, 1, 4, 1, 2, 2, 3, 3, 4, 4, 2, 3, 3, 4}), 224);
+}
 // ---- domain / NTT ---------------------------------------------------------------------------------------------------------
 TEST(test_domain_new) {   // domain.rs:154-168 (the decimal strings are checked through the oracle's KAT-pinned root)
     Domain d(10);

@@ -66,6 +66,9 @@ def _check_against_oracle(zk, ora, layers, inp):
     want_ev = ora.circuit_evaluation(layers, inp)
     assert all(np.array_equal(_host(a), b) for a, b in zip(ev, want_ev))
     proof = zk.GKRProtocol.prove(circuit, ev)
+    step = zk.GKRProtocol.prove_stepwise(circuit, ev)          # same prover, one mirror call per reference line
+    assert [sp.to_bytes() for sp in step.sumcheck_proofs] == [sp.to_bytes() for sp in proof.sumcheck_proofs]
+    assert all(np.array_equal(a, b) for a, b in zip(step.wb_s + step.wc_s, proof.wb_s + proof.wc_s))
     want = ora.gkr_prove(layers, want_ev)
     assert len(proof.sumcheck_proofs) == want.n_proofs == len(layers)
     for k, sp in enumerate(proof.sumcheck_proofs):
@@ -88,6 +91,12 @@ def test_gkr_protocol_2(zk, ora):   # protocol.rs:234-286
     proof = _check_against_oracle(zk, ora, GKR_2["layers"], zk.Fr.from_ints(GKR_2["input"]))
     bad = list(GKR_2["input"]); bad[3] += 1
     assert not ora.gkr_verify(GKR_2["layers"], zk.Fr.from_ints(bad), _to_oracle_proof(zk, ora, proof))
+
+
+def test_gkr_shape_panics(zk):
+    circuit = zk.Circuit.from_tuples(CIRCUIT_2["layers"])       # two output gates: w_0 would have 3 entries
+    with pytest.raises(AssertionError):
+        zk.GKRProtocol.prove(circuit, circuit.evaluation(zk.Fr.from_ints(CIRCUIT_2["input"])))
 
 
 @pytest.mark.parametrize("depth", [3, 6])

@@ -131,6 +131,42 @@ struct Sha256 {
         while (n >= 64) { compress(d); d += 64; n -= 64; }
         if (n) memcpy(buf, d, n);
     }
+    void finish(uint8_t out[32]) {   // digest of everything absorbed; the object is consumed (reset() to reuse)
+        const uint64_t bits = len * 8;
+        uint8_t pad[72] = {0x80};
+        const size_t fill = (size_t)(len % 64), padlen = (fill < 56 ? 56 : 120) - fill;
+        update(pad, padlen);
+        uint8_t lb[8];
+        for (int i = 0; i < 8; ++i) lb[i] = (uint8_t)(bits >> (56 - 8 * i));
+        update(lb, 8);
+        for (int i = 0; i < 8; ++i) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
+    }
+};
+
+// FiatShamirTranscript on the host (transcripts/fiat-shamir/src/fiat_shamir.rs:10-40): the GKR outer transcript
+struct Transcript {
+    Sha256 hasher;
+    void commit(const uint8_t* d, size_t n) { hasher.update(d, n); }
+    void challenge(uint8_t out[32]) {            // finalize_reset + update(digest)  :21-25
+        hasher.finish(out);
+        hasher.reset();
+        hasher.update(out, 32);
+    }
+    Fr challenge_fr() {                           // from_be_bytes_mod_order(digest)  :27-29, Montgomery form
+        uint8_t d[32];
+        challenge(d);
+        uint64_t t[4];
+        for (int i = 0; i < 4; ++i) {
+            uint64_t w = 0;
+            for (int j = 0; j < 8; ++j) w = (w << 8) | d[8 * (3 - i) + j];
+            t[i] = w;
+        }
+        while (fr_geq_p(t)) fr_sub_p(t);          // 2^256 < 3 p: at most two subtractions
+        Fr c, r2;
+        memcpy(c.l, t, 32);
+        memcpy(r2.l, FR_R2, 32);
+        return fr_mul(c, r2);
+    }
 };
 
 }  // namespace zkhost

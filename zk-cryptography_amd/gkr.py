@@ -161,7 +161,42 @@ class GKRProtocol:
 
     @staticmethod
     def prove(circuit, circuit_evaluation):
-        """GKRProtocol::prove (protocol.rs:21-117); circuit_evaluation as returned by Circuit.evaluation"""
+        """GKRProtocol::prove (protocol.rs:21-117) through the single C-ABI entry point zkhip_gkr_prove;
+        circuit_evaluation as returned by Circuit.evaluation (device tables)."""
+        from zk_cryptography_amd.composed import MAX_MONO, MultiComposedSumcheckProof, SparseUnivariatePolynomial
+        nl = len(circuit.layers)
+        assert len(circuit_evaluation) == nl + 1
+        arrays = [layer._arrays() for layer in circuit.layers]
+        gt = np.concatenate([a[0] for a in arrays])
+        i0 = np.concatenate([a[1] for a in arrays])
+        i1 = np.concatenate([a[2] for a in arrays])
+        n_gates = (C.c_size_t * nl)(*[len(layer.layer) for layer in circuit.layers])
+        tables = [t.contiguous() for t in circuit_evaluation]
+        ptrs = (C.c_void_p * (nl + 1))(*[t.data_ptr() for t in tables])
+        lens = (C.c_size_t * (nl + 1))(*[t.shape[0] for t in tables])
+        stride = 2 * nl
+        sums = np.zeros((nl, 4), dtype=np.uint64)
+        n_rounds = np.zeros(nl, dtype=np.uint32)
+        rp_lens = np.zeros((nl, stride), dtype=np.uint32)
+        rps = np.zeros((nl, stride, MAX_MONO, 2, 4), dtype=np.uint64)
+        wb, wc = np.zeros((nl, 4), dtype=np.uint64), np.zeros((nl, 4), dtype=np.uint64)
+        w0 = np.zeros((2, 4), dtype=np.uint64)
+        ctx = N.Context.get(tables[0].device.index)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        st = N.lib().zkhip_gkr_prove(ctx.handle, C.c_uint32(nl), n_gates, p(gt), p(i0), p(i1), ptrs, lens, p(sums), p(n_rounds),
+                                     p(rp_lens), p(rps), p(wb), p(wc), p(w0))
+        N.check(st, "gkr_prove: every layer must hold a power-of-two number of values, 2^l gates in layer l")
+        proofs = []
+        for k in range(nl):
+            polys = [SparseUnivariatePolynomial(rps[k, r, : rp_lens[k, r], 0].copy(), rps[k, r, : rp_lens[k, r], 1].copy())
+                     for r in range(n_rounds[k])]
+            proofs.append(MultiComposedSumcheckProof(polys, sums[k].copy()))
+        return GKRProof(proofs, [wb[k].copy() for k in range(nl)], [wc[k].copy() for k in range(nl)], Multilinear(w0))
+
+    @staticmethod
+    def prove_stepwise(circuit, circuit_evaluation):
+        """The same prover spelled out call by call over the mirror's types, line for line with protocol.rs:21-117
+        (kept as a cross-check of zkhip_gkr_prove and as the reading order of the reference)."""
         import torch
         transcript = FiatShamirTranscript()
         ev0 = circuit_evaluation[0]
