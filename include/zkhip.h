@@ -91,6 +91,11 @@ int zkhip_mle_mul_distinct(zkhip_ctx *ctx, const uint64_t *d_a, size_t na, const
 /* Add / Sub / Mul<F> (:178-251): op 0 add, 1 sub (d_b: n elements), 2 scale (h_scalar[4]) */
 int zkhip_mle_elementwise(zkhip_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b,
                           const uint64_t *h_scalar, size_t n, uint64_t *d_out);
+/* add_to_front (:86-96): d_out[n * 2 * 2^variable_length] = the table repeated; add_to_back (:98-110):
+ * d_out[n * 2^variable_length] = every entry repeated 2^variable_length times (new variables the polynomial does not
+ * depend on, before / after its own). */
+int zkhip_mle_add_to_front(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, uint32_t variable_length, uint64_t *d_out);
+int zkhip_mle_add_to_back(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, uint32_t variable_length, uint64_t *d_out);
 /* Multilinear::to_bytes (:54-62): 32 big-endian canonical bytes per element into d_out_bytes[32 n] */
 int zkhip_mle_to_bytes(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, uint8_t *d_out_bytes);
 
@@ -114,11 +119,13 @@ int zkhip_circuit_add_mult_mle(zkhip_ctx *ctx, const uint8_t *h_gate_type, const
  *                non-power-of-two layer, mismatching table sizes) -> ZKHIP_ERR_SHAPE.
  * Outputs (host), one ComposedSumcheckProof per layer k < n_layers, R = 2 * n_layers rounds reserved per proof:
  *   h_sums[k*4]; h_n_rounds[k]; h_round_poly_lens[k*R + r]; h_round_polys[(k*R + r)*7*8] (coeff[4], pow[4] pairs as
- *   zkhip_multi_composed_prove); h_wb[k*4], h_wc[k*4] (GKRProof::wb_s / wc_s); h_w0[8] = w_0_mle = [output, 0]. */
+ *   zkhip_multi_composed_prove); h_wb[k*4], h_wc[k*4] (GKRProof::wb_s / wc_s); h_w0[8] = w_0_mle = [output, 0];
+ *   h_challenges (nullable) [(k*R + r)*4]: the sumcheck challenges of every layer (b = first half, c = second half;
+ *   SuccintGKRProtocol::prove opens the input layer at the last layer's b and c, succint_protocol.rs:133-152). */
 int zkhip_gkr_prove(zkhip_ctx *ctx, uint32_t n_layers, const size_t *h_n_gates, const uint8_t *h_gate_type,
                     const uint32_t *h_in0, const uint32_t *h_in1, const uint64_t *const *h_layer_ptrs,
                     const size_t *h_layer_len, uint64_t *h_sums, uint32_t *h_n_rounds, uint32_t *h_round_poly_lens,
-                    uint64_t *h_round_polys, uint64_t *h_wb, uint64_t *h_wc, uint64_t *h_w0);
+                    uint64_t *h_round_polys, uint64_t *h_wb, uint64_t *h_wc, uint64_t *h_w0, uint64_t *h_challenges);
 
 /* ---- basic sumcheck prover (sumcheck/src/sumcheck.rs:25-61) -------------------------- */
 /* Block sums of a table: d_out[(2^log_blocks + 1) * 4] = the sums of its 2^log_blocks equal consecutive blocks

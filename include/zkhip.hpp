@@ -417,7 +417,7 @@ struct GKRProtocol {
         std::vector<uint32_t> n_rounds(nl), lens((size_t)nl * stride);
         std::vector<uint64_t> rps((size_t)nl * stride * 7 * 8);
         int st = zkhip_gkr_prove(ctx(), nl, n_gates.data(), gt.data(), i0.data(), i1.data(), ptrs.data(), ev.lens.data(), sums[0].l, n_rounds.data(),
-                                 lens.data(), rps.data(), wb[0].l, wc[0].l, w0[0].l);
+                                 lens.data(), rps.data(), wb[0].l, wc[0].l, w0[0].l, nullptr);
         if (st == ZKHIP_ERR_SHAPE) throw Panic("Number of evaluations must be a power of 2");
         check(st, "gkr_prove");
         GKRProof proof;

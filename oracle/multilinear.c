@@ -121,3 +121,16 @@ void ora_mle_mul_distinct(fr_t *out, const fr_t *a, size_t na, const fr_t *b, si
 void ora_mle_to_bytes(uint8_t *out, const fr_t *in, size_t n) {
     for (size_t i = 0; i < n; ++i) ora_fr_to_bytes_be(out + 32 * i, &in[i]);
 }
+
+/* add_to_front (evaluation_form.rs:86-96): the table followed by itself, 2^variable_length times over:
+ * out has n * 2 * 2^variable_length entries. */
+void ora_mle_add_to_front(fr_t *out, const fr_t *in, size_t n, size_t variable_length) {
+    const size_t copies = (size_t)2 << variable_length;
+    for (size_t r = 0; r < copies; ++r) memcpy(out + r * n, in, n * sizeof(fr_t));
+}
+/* add_to_back (evaluation_form.rs:98-110): every entry repeated 2^variable_length times in place */
+void ora_mle_add_to_back(fr_t *out, const fr_t *in, size_t n, size_t variable_length) {
+    const size_t reps = (size_t)1 << variable_length;
+    for (size_t i = 0; i < n; ++i)
+        for (size_t r = 0; r < reps; ++r) out[i * reps + r] = in[i];
+}

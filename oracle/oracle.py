@@ -245,6 +245,20 @@ def mle_sum(evals):
     return o
 
 
+def mle_add_to_front(evals, variable_length):
+    evals = _fr(evals).reshape(-1, 4)
+    o = np.empty((evals.shape[0] * 2 * (1 << variable_length), 4), dtype=np.uint64)
+    lib().ora_mle_add_to_front(_p(o), _p(evals), C.c_size_t(evals.shape[0]), C.c_size_t(variable_length))
+    return o
+
+
+def mle_add_to_back(evals, variable_length):
+    evals = _fr(evals).reshape(-1, 4)
+    o = np.empty((evals.shape[0] << variable_length, 4), dtype=np.uint64)
+    lib().ora_mle_add_to_back(_p(o), _p(evals), C.c_size_t(evals.shape[0]), C.c_size_t(variable_length))
+    return o
+
+
 def mle_add_distinct(a, b):
     a, b = _fr(a), _fr(b)
     o = np.empty((a.shape[0] * b.shape[0], 4), dtype=np.uint64)

@@ -91,6 +91,9 @@ void ora_mle_sum(fr_t *out, const fr_t *in, size_t n);
 void ora_mle_add_distinct(fr_t *out, const fr_t *a, size_t na, const fr_t *b, size_t nb);
 void ora_mle_mul_distinct(fr_t *out, const fr_t *a, size_t na, const fr_t *b, size_t nb);
 void ora_mle_to_bytes(uint8_t *out, const fr_t *in, size_t n);
+/* add_to_front (:86-96): out[n * 2 * 2^k]; add_to_back (:98-110): out[n * 2^k] */
+void ora_mle_add_to_front(fr_t *out, const fr_t *in, size_t n, size_t variable_length);
+void ora_mle_add_to_back(fr_t *out, const fr_t *in, size_t n, size_t variable_length);
 /* fast variant used ONLY as an all-cores CPU baseline (same arithmetic, OpenMP) */
 int  ora_mle_partial_evaluation_mt(fr_t *out, const fr_t *in, size_t n, const fr_t *r, size_t var_index);
 

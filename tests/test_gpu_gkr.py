@@ -102,3 +102,33 @@ def test_gkr_shape_panics(zk):
 @pytest.mark.parametrize("depth", [3, 6])
 def test_gkr_random_circuit(zk, ora, depth):   # Circuit::random (circuit.rs:99-122), gkr/benches
     _check_against_oracle(zk, ora, random_circuit(depth), ora.random_fr(2 ** depth, 40 + depth))
+
+
+@pytest.mark.parametrize("layers,inp,tau", [
+    (GKR_1["layers"], GKR_1["input"], [54, 90]),                       # succint_protocol.rs:282-306 (test_succint_gkr_protocol_1)
+    (random_circuit(3), [4, 3, 7, 6, 6, 1, 2, 5], [5, 6, 7, 8, 9]),    # SRS larger than the input layer: add_to_back blow-up
+])
+def test_succint_gkr_prove(zk, ora, layers, inp, tau):
+    """SuccintGKRProtocol::prove: GKR proof + commitment to the input layer (blown up to the SRS size) + openings at
+    the last layer's b and c.  The pairing verifier is out of scope; the commitment and both openings are compared with
+    the oracle's naive restatements, the opened values with w_b / w_c, and the sumcheck part with the oracle's verifier."""
+    circuit = zk.Circuit.from_tuples(layers)
+    inp_f, tau_f = zk.Fr.from_ints(inp), zk.Fr.from_ints(tau)
+    ev = circuit.evaluation(inp_f)
+    srs = zk.TrustedSetup.setup(tau_f)
+    commitment, proof = zk.SuccintGKRProtocol.prove(circuit, ev, srs)
+    assert ora.gkr_verify(layers, inp_f, _to_oracle_proof(zk, ora, proof))
+    blow = len(tau) - (len(inp).bit_length() - 1)
+    poly = ora.mle_add_to_back(inp_f, blow)
+    osrs = ora.kzg_multilinear_srs_g1(tau_f)
+    want_c = ora.g1_to_affine(ora.kzg_commitment(poly, osrs, True))
+    assert np.array_equal(commitment.xy, want_c[:12]) and commitment.infinity == bool(want_c[12])
+    ch = proof._challenges[-1]
+    half = len(ch) // 2
+    for pts, opening, w_val in ((ch[:half], proof.proof_wb_opening, proof.wb_s[-1]), (ch[half:], proof.proof_wc_opening, proof.wc_s[-1])):
+        z = np.concatenate([pts, np.zeros((len(tau) - len(pts), 4), dtype=np.uint64)])
+        want_ev, want_proofs = ora.kzg_open(poly, z, osrs)
+        assert np.array_equal(opening.evaluation, want_ev) and np.array_equal(opening.evaluation, w_val)
+        for got, want in zip(opening.proofs, want_proofs):
+            a = ora.g1_to_affine(want)
+            assert got.infinity == bool(a[12]) and (got.infinity or np.array_equal(got.xy, a[:12]))

@@ -179,3 +179,21 @@ def test_back_to_back_calls_with_different_points_do_not_race(zk, ora):
         assert np.array_equal(outs[i].to_numpy(), ora.mle_partial_evaluation(a, rs[i], 0))
         want = [x * y % zk.Fr.MODULUS for x, y in zip(zk.Fr.to_ints(a[:4]), zk.Fr.to_ints(rs[i:i + 1]) * 4)]
         assert zk.Fr.to_ints(scaled[i].to_numpy()[:4]) == want
+
+
+def test_add_to_front_and_back(zk):   # evaluation_form.rs:465-507, :548-556
+    F = zk.Fr.from_ints
+    ints = lambda m: zk.Fr.to_ints(m.to_numpy())   # noqa: E731
+    assert ints(zk.Multilinear(F([0, 0, 4, 4])).add_to_front(0)) == [0, 0, 4, 4, 0, 0, 4, 4]
+    assert ints(zk.Multilinear(F([0, 4])).add_to_front(1)) == [0, 4, 0, 4, 0, 4, 0, 4]
+    assert ints(zk.Multilinear(F([0, 0, 4, 4])).add_to_back(1)) == [0, 0, 0, 0, 4, 4, 4, 4]
+    assert ints(zk.Multilinear(F([1, 2])).add_to_back(0)) == [1, 2]
+    assert ints(zk.Multilinear.duplicate_evaluation(F([11]))) == [11, 11]
+    assert ints(zk.Multilinear.additive_identity(2)) == [0, 0, 0, 0]
+
+
+def test_add_to_back_front_match_oracle_random(zk, ora):
+    v = ora.random_fr(64, 5)
+    import numpy as np
+    assert np.array_equal(zk.Multilinear(v).add_to_back(3).to_numpy(), ora.mle_add_to_back(v, 3))
+    assert np.array_equal(zk.Multilinear(v).add_to_front(2).to_numpy(), ora.mle_add_to_front(v, 2))

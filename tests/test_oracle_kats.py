@@ -394,6 +394,12 @@ def test_srs_with_identity_points(ora):
         ora.g1_affine_ints(ora.g1_to_affine(c))
 
 
+def test_add_to_front_and_back(ora):   # evaluation_form.rs:465-507
+    eq(ora, ora.mle_add_to_front(F(ora, [0, 0, 4, 4]), 0), [0, 0, 4, 4, 0, 0, 4, 4])
+    eq(ora, ora.mle_add_to_front(F(ora, [0, 4]), 1), [0, 4, 0, 4, 0, 4, 0, 4])
+    eq(ora, ora.mle_add_to_back(F(ora, [0, 0, 4, 4]), 1), [0, 0, 0, 0, 4, 4, 4, 4])
+
+
 # ---- MultilinearKZG::open, multilinear_kzg.rs:50-88 (test data :131-197) ------------------------------------
 def _mle_eval_ints(vals, pts):
     vals = [v % R for v in vals]

@@ -19,7 +19,7 @@ namespace {
 constexpr int GKR_MONO = 7;   // monomials per round polynomial in zkhip_multi_composed_prove's output
 
 struct LayerOut {
-    uint64_t *sums, *round_polys, *wb, *wc;
+    uint64_t *sums, *round_polys, *wb, *wc, *challenges;
     uint32_t *n_rounds, *lens;
     uint32_t stride;   // rounds reserved per proof
 };
@@ -61,6 +61,7 @@ int layer_sumcheck(zkhip_ctx* c, const uint64_t* d_add, const uint64_t* d_mul, c
     uint64_t* polys = out.round_polys + (size_t)k * out.stride * GKR_MONO * 8;
     uint32_t* lens = out.lens + (size_t)k * out.stride;
     ZK_TRY(zkhip_multi_composed_prove(c, tables, sizes, 2, n, claimed.l, 1, lens, polys, challenges.data()));
+    if (out.challenges) std::memcpy(out.challenges + (size_t)k * out.stride * 4, challenges.data(), 32 * (size_t)nv);
     std::memcpy(out.sums + 4 * (size_t)k, claimed.l, 32);
     out.n_rounds[k] = nv;
     absorb_proof(tr, polys, lens, nv);                                     // transcript.commit(&sumcheck_proof.to_bytes())
@@ -85,7 +86,7 @@ int layer_sumcheck(zkhip_ctx* c, const uint64_t* d_add, const uint64_t* d_mul, c
 extern "C" int zkhip_gkr_prove(zkhip_ctx* c, uint32_t n_layers, const size_t* h_n_gates, const uint8_t* h_gate_type,
                                const uint32_t* h_in0, const uint32_t* h_in1, const uint64_t* const* h_layer_ptrs,
                                const size_t* h_layer_len, uint64_t* h_sums, uint32_t* h_n_rounds, uint32_t* h_round_poly_lens,
-                               uint64_t* h_round_polys, uint64_t* h_wb, uint64_t* h_wc, uint64_t* h_w0) {
+                               uint64_t* h_round_polys, uint64_t* h_wb, uint64_t* h_wc, uint64_t* h_w0, uint64_t* h_challenges) {
     if (!c || !h_n_gates || !h_gate_type || !h_in0 || !h_in1 || !h_layer_ptrs || !h_layer_len || !h_sums || !h_n_rounds ||
         !h_round_poly_lens || !h_round_polys || !h_wb || !h_wc || !h_w0)
         return ZKHIP_ERR_ARG;
@@ -113,7 +114,7 @@ extern "C" int zkhip_gkr_prove(zkhip_ctx* c, uint32_t n_layers, const size_t* h_
     uint64_t* d_f[4] = {(uint64_t*)(aux + o_f0), (uint64_t*)(aux + o_f0 + fsz), (uint64_t*)(aux + o_f0 + 2 * fsz), (uint64_t*)(aux + o_f0 + 3 * fsz)};
     uint64_t* d_sum = (uint64_t*)(aux + o_sum);
     uint64_t* d_prod = (uint64_t*)(aux + o_prod);
-    LayerOut out = {h_sums, h_round_polys, h_wb, h_wc, h_n_rounds, h_round_poly_lens, 2 * n_layers};
+    LayerOut out = {h_sums, h_round_polys, h_wb, h_wc, h_challenges, h_n_rounds, h_round_poly_lens, 2 * n_layers};
 
     // w_0 = circuit_evaluation[0] padded with a zero (protocol.rs:30-33); commit its bytes, draw n_r
     zkhost::Transcript tr;

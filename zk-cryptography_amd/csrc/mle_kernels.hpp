@@ -227,6 +227,13 @@ static __global__ __launch_bounds__(MLE_BLOCK) void open_step_kernel(const uint6
     }
 }
 
+// add_to_front / add_to_back (evaluation_form.rs:86-110): out[i] = in[i mod n_in] (shift = 0) or in[i >> shift]
+static __global__ __launch_bounds__(MLE_BLOCK) void repeat_kernel(const uint64_t* __restrict__ in, size_t n_in, uint32_t shift, size_t n_out,
+                                                           uint64_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    for (size_t i = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; i < n_out; i += stride)
+        store_fr(out, i, load_fr(in, shift ? (i >> shift) : (i & (n_in - 1))));
+}
 // Circuit::evaluation, one layer (circuit/src/circuit.rs:41-50): gate = (type u8 | in0 u32 | in1 u32) packed as 3 words
 static __global__ __launch_bounds__(MLE_BLOCK) void circuit_layer_kernel(const uint64_t* __restrict__ in, const uint32_t* __restrict__ gates,
                                                                   size_t n_gates, uint64_t* __restrict__ out) {

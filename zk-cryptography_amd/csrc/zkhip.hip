@@ -328,6 +328,29 @@ extern "C" int zkhip_mle_to_bytes(zkhip_ctx* c, const uint64_t* d_evals, size_t 
     return ZKHIP_OK;
 }
 
+extern "C" int zkhip_mle_add_to_front(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint32_t variable_length, uint64_t* d_out) {
+    if (!c || !d_evals || !d_out) return ZKHIP_ERR_ARG;
+    if (!is_pow2(n) || variable_length > 40) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    const size_t n_out = n * ((size_t)2 << variable_length);
+    hipLaunchKernelGGL(repeat_kernel, dim3(mle_grid(n_out)), dim3(MLE_BLOCK), 0, c->stream, d_evals, n, 0u, n_out, d_out);
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_mle_add_to_back(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint32_t variable_length, uint64_t* d_out) {
+    if (!c || !d_evals || !d_out) return ZKHIP_ERR_ARG;
+    if (!is_pow2(n) || variable_length > 40) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    if (variable_length == 0) {
+        ZK_HIP(c, hipMemcpyAsync(d_out, d_evals, 32 * n, hipMemcpyDeviceToDevice, c->stream));
+        return ZKHIP_OK;
+    }
+    const size_t n_out = n << variable_length;
+    hipLaunchKernelGGL(repeat_kernel, dim3(mle_grid(n_out)), dim3(MLE_BLOCK), 0, c->stream, d_evals, n, variable_length, n_out, d_out);
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // layered circuit (GKR table builders)
 // ---------------------------------------------------------------------------------------

@@ -183,15 +183,18 @@ class GKRProtocol:
         w0 = np.zeros((2, 4), dtype=np.uint64)
         ctx = N.Context.get(tables[0].device.index)
         p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        chal = np.zeros((nl, stride, 4), dtype=np.uint64)
         st = N.lib().zkhip_gkr_prove(ctx.handle, C.c_uint32(nl), n_gates, p(gt), p(i0), p(i1), ptrs, lens, p(sums), p(n_rounds),
-                                     p(rp_lens), p(rps), p(wb), p(wc), p(w0))
+                                     p(rp_lens), p(rps), p(wb), p(wc), p(w0), p(chal))
         N.check(st, "gkr_prove: every layer must hold a power-of-two number of values, 2^l gates in layer l")
         proofs = []
         for k in range(nl):
             polys = [SparseUnivariatePolynomial(rps[k, r, : rp_lens[k, r], 0].copy(), rps[k, r, : rp_lens[k, r], 1].copy())
                      for r in range(n_rounds[k])]
             proofs.append(MultiComposedSumcheckProof(polys, sums[k].copy()))
-        return GKRProof(proofs, [wb[k].copy() for k in range(nl)], [wc[k].copy() for k in range(nl)], Multilinear(w0))
+        proof = GKRProof(proofs, [wb[k].copy() for k in range(nl)], [wc[k].copy() for k in range(nl)], Multilinear(w0))
+        proof._challenges = [chal[k, : n_rounds[k]].copy() for k in range(nl)]   # not part of the reference's struct
+        return proof
 
     @staticmethod
     def prove_stepwise(circuit, circuit_evaluation):
@@ -227,3 +230,37 @@ class GKRProtocol:
             claimed_sum, alpha, beta, r_b, r_c = GKRProtocol._layer_sumcheck(add_alpha_beta, mul_alpha_beta, w_i_mle, claimed_sum,
                                                                             transcript, proof)
         return proof
+
+
+class SuccintGKRProof(GKRProof):
+    """gkr/src/succint_protocol.rs:21-29: GKRProof + the two KZG openings of the (blown-up) input layer"""
+
+    def __init__(self, base, proof_wb_opening, proof_wc_opening):
+        super().__init__(base.sumcheck_proofs, base.wb_s, base.wc_s, base.w_0_mle)
+        self._challenges = base._challenges
+        self.proof_wb_opening = proof_wb_opening
+        self.proof_wc_opening = proof_wc_opening
+
+
+class SuccintGKRProtocol:
+    @staticmethod
+    def prove(circuit, circuit_evaluation, tau):
+        """SuccintGKRProtocol::prove (succint_protocol.rs:36-167) -> (commitment, proof).  The sumcheck part is
+        GKRProtocol::prove verbatim (:38-131 repeat protocol.rs:21-108); at the input layer the values are blown up
+        to the SRS size (add_to_back, :134-137), committed (:148) and opened at b || 0.. and c || 0.. (:139-151)."""
+        from zk_cryptography_amd.kzg import MultilinearKZG
+        assert len(circuit_evaluation) >= 3, "the commitment is made inside `for layer_index in 2..len` (:82-152)"
+        base = GKRProtocol.prove(circuit, circuit_evaluation)
+        w_i_mle = Multilinear(circuit_evaluation[-1])
+        srs_vars = (len(tau)).bit_length() - 1
+        assert 1 << srs_vars == len(tau), "Value is not a power of 2"        # gkr/src/utils.rs:100-111 exponent()
+        blow_up = srs_vars - w_i_mle.n_vars                                   # usize underflow panics in the reference
+        assert blow_up >= 0
+        poly = w_i_mle.add_to_back(blow_up)
+        ch = base._challenges[-1]
+        half = len(ch) // 2
+        zeros = np.zeros((poly.n_vars - half, 4), dtype=np.uint64)
+        b_clone = np.concatenate([ch[:half], zeros])
+        c_clone = np.concatenate([ch[half:], np.zeros((poly.n_vars - (len(ch) - half), 4), dtype=np.uint64)])
+        commitment = MultilinearKZG.commitment(poly, tau)
+        return commitment, SuccintGKRProof(base, MultilinearKZG.open(poly, b_clone, tau), MultilinearKZG.open(poly, c_clone, tau))

@@ -128,6 +128,31 @@ class Multilinear:
         N.check(st, "distinct")
         return Multilinear._wrap(out)
 
+    def add_to_front(self, variable_length):
+        """evaluation_form.rs:86-96: the table repeated 2 * 2^variable_length times"""
+        out = self._new_like(len(self) * 2 * (1 << variable_length))
+        N.check(N.lib().zkhip_mle_add_to_front(self._ctx.handle, N.ptr(self.evaluations), C.c_size_t(len(self)),
+                                               C.c_uint32(variable_length), N.ptr(out)), "add_to_front")
+        return Multilinear._wrap(out)
+
+    def add_to_back(self, variable_length):
+        """evaluation_form.rs:98-110: every entry repeated 2^variable_length times"""
+        out = self._new_like(len(self) << variable_length)
+        N.check(N.lib().zkhip_mle_add_to_back(self._ctx.handle, N.ptr(self.evaluations), C.c_size_t(len(self)),
+                                              C.c_uint32(variable_length), N.ptr(out)), "add_to_back")
+        return Multilinear._wrap(out)
+
+    @staticmethod
+    def duplicate_evaluation(value):
+        """evaluation_form.rs:112-119: value ++ value"""
+        v = _fr_host(value)
+        return Multilinear(np.concatenate([v, v]))
+
+    @staticmethod
+    def additive_identity(num_vars):
+        """evaluation_form.rs:64-66"""
+        return Multilinear(np.zeros((1 << num_vars, 4), dtype=np.uint64))
+
     def add_distinct(self, rhs):
         """evaluation_form.rs:28-39"""
         return self._distinct(rhs, N.lib().zkhip_mle_add_distinct)
