@@ -140,7 +140,7 @@ def main():
             sc.poly_sum()
             return sc.prove()
         # N > 1: ONE prover over the world * 2^log_n-entry table whose rank-interleaved shard is `table`
-        # (per-round 64-byte all-gather over RCCL/xGMI + replicated transcript)
+        # (stage form: one all-gather of 2^k partial block sums per k rounds over RCCL/xGMI + replicated transcript)
         return D.ShardedSumcheck(D.HipSumcheckEngine(table), world, None, dist).prove()
 
     def barrier():
@@ -226,7 +226,7 @@ def main():
             "config": {"field": "BLS12-381 Fr (255-bit Montgomery, 8 x u32 limbs); G1 over Fq (381-bit)",
                        "workload": "24-var multilinear sumcheck prover (poly_sum + prove), BLS12-381 Fr" if args.log_n == 24
                        else "%d-var multilinear sumcheck prover" % args.log_n,
-                       "evals_per_gpu": n, "sharding": ("one %d-entry table sharded by low index bits over %d GPUs, 64 B all-gather per round" % (n * world, world))
+                       "evals_per_gpu": n, "sharding": ("one %d-entry table sharded by low index bits over %d GPUs; per stage of k rounds one RCCL all-gather of the 2^k partial block sums, local k-variable fold, replicated transcript" % (n * world, world))
                        if world > 1 else "single GPU"},
             "roofline": roofline,
             "cpu_baseline": cpu,
