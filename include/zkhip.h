@@ -250,6 +250,14 @@ int zkhip_kzg_open(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint
                    const uint64_t *d_points_xy, const uint8_t *d_points_inf, size_t n_points,
                    const uint64_t *d_folded_xy, const uint8_t *d_folded_inf, uint64_t *h_evaluation,
                    uint64_t *h_proofs_xy, uint8_t *h_proofs_inf);
+/* UnivariateKZGInterface::open (kzg/src/univariate_kzg.rs:60-81): evaluation = poly(z) (dense_univariate.rs:184-196),
+ * proof = commitment to the quotient of (poly - z) / (x - z) (divide_with_q_and_r, dense_univariate.rs:88-124) against
+ * the first n_coeffs - 1 SRS points.  Evaluation and quotient come from one Horner suffix scan on the device.
+ * n_coeffs - 1 > n_points is the index panic at :75 -> ZKHIP_ERR_INDEX (checked on the coefficient count as given;
+ * the reference would first drop zero leading coefficients).  Outputs (host): h_evaluation[4], h_proof_xy[12], *h_proof_inf. */
+int zkhip_univariate_kzg_open(zkhip_ctx *ctx, const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *h_z,
+                              const uint64_t *d_points_xy, const uint8_t *d_points_inf, size_t n_points,
+                              uint64_t *h_evaluation, uint64_t *h_proof_xy, uint8_t *h_proof_inf);
 /* Sum of n affine points given on the host (combining per-GPU partial commitments after an all-gather). */
 int zkhip_g1_sum_affine(const uint64_t *h_points_xy, const uint8_t *h_points_inf, size_t n, uint64_t *h_out_xy,
                         uint8_t *h_out_inf);

@@ -355,7 +355,21 @@ struct MultilinearKZG {
         return pr;
     }
 };
+struct UnivariateKZGProof {                                                                    // univariate_kzg.rs:11-15
+    Fr evaluation;
+    G1Affine proof;
+};
 struct UnivariateKZG {
+    static UnivariateKZGProof open(const DenseUnivariatePolynomial& poly, const Fr& evaluation_point, const TrustedSetup& srs) {   // :60-81
+        UnivariateKZGProof pr;
+        uint8_t inf = 0;
+        int st = zkhip_univariate_kzg_open(ctx(), poly.n ? poly.dev->u64() : nullptr, poly.n, evaluation_point.l, srs.points(), srs.inf(), srs.len(),
+                                           pr.evaluation.l, pr.proof.xy, &inf);
+        if (st == ZKHIP_ERR_INDEX) throw std::out_of_range("index out of bounds: the len of powers_of_tau_in_g1 is smaller than the quotient");
+        check(st, "univariate_kzg_open");
+        pr.proof.infinity = inf != 0;
+        return pr;
+    }
     static TrustedSetup generate_srs(const Fr& tau, size_t max_degree) {                       // univariate_kzg.rs:18-35
         TrustedSetup s(max_degree + 1);
         check(zkhip_srs_univariate_g1(ctx(), tau.l, max_degree, s.pts_->u64(), s.inf_->u8()), "generate_srs");

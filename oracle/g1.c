@@ -309,6 +309,27 @@ int ora_kzg_open(fr_t *evaluation, g1_jac_t *proofs, const fr_t *evals, size_t n
     return rc;
 }
 
+/* UnivariateKZG::open (univariate_kzg.rs:60-81): evaluation = poly(z); numerator = poly - z (sic: the evaluation POINT is
+ * subtracted, dense_univariate.rs:332-346 -- the quotient does not depend on that constant); quotient = numerator /
+ * (x - z); proof = sum_i srs[i] * quotient[i].  Returns -2 when the quotient is longer than the srs (index panic). */
+int ora_univariate_kzg_open(fr_t *evaluation, g1_jac_t *proof, const fr_t *coeffs, size_t n, const fr_t *z,
+                            const g1_jac_t *srs, size_t n_srs) {
+    ora_dense_evaluate(evaluation, coeffs, n, z);
+    fr_t den[2];
+    ora_fr_neg(&den[0], z);
+    ora_fr_one(&den[1]);
+    fr_t *num = (fr_t *)malloc((n + 1) * sizeof(fr_t));
+    size_t nn = n;
+    if (n == 0) { num[0] = *z; nn = 1; }                            /* Sub<F> on the zero polynomial returns [other] (:337-339) */
+    else { memcpy(num, coeffs, n * sizeof(fr_t)); ora_fr_sub(&num[0], &num[0], z); }
+    fr_t *q = (fr_t *)malloc((nn + 1) * sizeof(fr_t)), *r = (fr_t *)malloc((nn + 1) * sizeof(fr_t));
+    size_t nq = 0, nr = 0;
+    int rc = ora_dense_divide(q, &nq, r, &nr, num, nn, den, 2);
+    if (rc == 0) rc = ora_kzg_commitment(proof, q, nq, srs, n_srs, 0);
+    free(num); free(q); free(r);
+    return rc;
+}
+
 /* CPU bucket-method MSM: NOT the reference's algorithm (the reference is the naive
  * sum above); provided so that large-size GPU results can be cross-checked in
  * seconds and as a context number.  Unsigned windows of c bits. */

@@ -122,3 +122,34 @@ void ora_dense_evaluate(fr_t *o, const fr_t *coeffs, size_t n, const fr_t *x) {
     }
     *o = acc;
 }
+
+/* divide_with_q_and_r (dense_univariate.rs:88-124): quotient and remainder of a / b, coefficient vectors low degree
+ * first; `degree` ignores zero leading coefficients (:199-207), `is_zero` means an EMPTY vector (:41-43).
+ * q must hold na entries, r na entries; returns 0 and the lengths, -1 for "Dividing by zero polynomial". */
+int ora_dense_divide(fr_t *q, size_t *nq, fr_t *r, size_t *nr, const fr_t *a, size_t na, const fr_t *b, size_t nb) {
+    if (na == 0) { *nq = 0; *nr = 0; return 0; }
+    if (nb == 0) return -1;
+    const size_t da = dense_degree(a, na), db = dense_degree(b, nb);
+    if (da < db) { *nq = 0; memcpy(r, a, na * sizeof(fr_t)); *nr = na; return 0; }
+    const size_t lq = da - db + 1;
+    for (size_t i = 0; i < lq; ++i) ora_fr_zero(&q[i]);
+    memcpy(r, a, na * sizeof(fr_t));
+    size_t lr = na;
+    fr_t inv;
+    if (!ora_fr_inv(&inv, &b[nb - 1])) return -1;                 /* leading_coefficient().inverse().unwrap() */
+    while (lr != 0 && dense_degree(r, lr) >= db) {
+        fr_t cur;
+        ora_fr_mul(&cur, &r[lr - 1], &inv);                        /* remainder.coefficients.last() * divisor_leading_inv */
+        const size_t cur_deg = dense_degree(r, lr) - db;
+        q[cur_deg] = cur;
+        for (size_t i = 0; i < nb; ++i) {
+            fr_t t;
+            ora_fr_mul(&t, &cur, &b[i]);
+            ora_fr_sub(&r[cur_deg + i], &r[cur_deg + i], &t);
+        }
+        while (lr != 0 && ora_fr_is_zero(&r[lr - 1])) --lr;       /* pop zero leading coefficients */
+    }
+    *nq = lq;
+    *nr = lr;
+    return 0;
+}

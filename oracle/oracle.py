@@ -501,6 +501,29 @@ def kzg_open(evals, points, srs_jac):
     return ev, proofs[: points.shape[0]]
 
 
+def univariate_kzg_open(coeffs, z, srs_jac):
+    """UnivariateKZG::open (univariate_kzg.rs:60-81) -> (evaluation [4], proof [18] Jacobian)"""
+    coeffs, z = _fr(coeffs).reshape(-1, 4), _fr(z).reshape(4)
+    srs = np.ascontiguousarray(srs_jac, dtype=np.uint64).reshape(-1, 18)
+    ev, proof = np.empty(4, dtype=np.uint64), np.empty(18, dtype=np.uint64)
+    rc = lib().ora_univariate_kzg_open(_p(ev), _p(proof), _p(coeffs), C.c_size_t(coeffs.shape[0]), _p(z), _p(srs), C.c_size_t(srs.shape[0]))
+    if rc == -2:
+        raise IndexError("index out of bounds: srs shorter than the quotient")
+    assert rc == 0
+    return ev, proof
+
+
+def dense_divide(a, b):
+    """divide_with_q_and_r (dense_univariate.rs:88-124) -> (quotient, remainder)"""
+    a, b = _fr(a).reshape(-1, 4), _fr(b).reshape(-1, 4)
+    q, r = np.empty((max(a.shape[0], 1), 4), dtype=np.uint64), np.empty((max(a.shape[0], 1), 4), dtype=np.uint64)
+    nq, nr = C.c_size_t(0), C.c_size_t(0)
+    rc = lib().ora_dense_divide(_p(q), C.byref(nq), _p(r), C.byref(nr), _p(a), C.c_size_t(a.shape[0]), _p(b), C.c_size_t(b.shape[0]))
+    if rc != 0:
+        raise ZeroDivisionError("Dividing by zero polynomial")
+    return q[: nq.value], r[: nr.value]
+
+
 def msm_pippenger(scalars, pts_affine):
     scalars = _fr(scalars).reshape(-1, 4)
     pts = np.ascontiguousarray(pts_affine, dtype=np.uint64).reshape(-1, 13)

@@ -169,6 +169,9 @@ int  ora_kzg_commitment(g1_jac_t *out, const fr_t *coeffs, size_t n_coeffs, cons
 /* MultilinearKZG::open (multilinear_kzg.rs:50-88), naive as the reference; proofs[n_vars] Jacobian */
 int  ora_kzg_open(fr_t *evaluation, g1_jac_t *proofs, const fr_t *evals, size_t n, const fr_t *points, size_t n_points,
                   const g1_jac_t *srs, size_t n_srs);
+/* UnivariateKZG::open (univariate_kzg.rs:60-81) */
+int  ora_univariate_kzg_open(fr_t *evaluation, g1_jac_t *proof, const fr_t *coeffs, size_t n, const fr_t *z,
+                             const g1_jac_t *srs, size_t n_srs);
 void ora_msm_pippenger(g1_jac_t *out, const fr_t *scalars, const g1_affine_t *pts, size_t n);
 
 /* ---- NTT / Domain / multiply (utils.rs:281-324, domain.rs, evaluation.rs) -- */
@@ -180,6 +183,8 @@ int  ora_univariate_multiply(fr_t *out, const fr_t *a, size_t na, const fr_t *b,
 /* DenseUnivariatePolynomial Mul (schoolbook, dense_univariate.rs:210-233) ; returns out length */
 size_t ora_dense_mul(fr_t *out, const fr_t *a, size_t na, const fr_t *b, size_t nb);
 void ora_dense_evaluate(fr_t *o, const fr_t *coeffs, size_t n, const fr_t *x);
+/* divide_with_q_and_r (dense_univariate.rs:88-124); q, r: na entries each */
+int  ora_dense_divide(fr_t *q, size_t *nq, fr_t *r, size_t *nr, const fr_t *a, size_t na, const fr_t *b, size_t nb);
 
 #ifdef __cplusplus
 }

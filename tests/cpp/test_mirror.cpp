@@ -186,6 +186,18 @@ TEST(test_univariate_kzg) {   // univariate_kzg.rs:111-129 (commitment half)
     EXPECT(same_point(commit, want));
     EXPECT(panics([&] { UnivariateKZG::commitment(DenseUnivariatePolynomial(F({1, 2, 3, 4, 5, 6})), srs); }));   // index out of bounds :53
 }
+TEST(test_univariate_kzg_open) {   // univariate_kzg.rs:111-129 (open half)
+    auto coeffs = F({1, 2, 3, 4, 5});
+    Fr tau = Fr::from(10), z = Fr::from(2);
+    TrustedSetup srs = UnivariateKZG::generate_srs(tau, 4);
+    UnivariateKZGProof proof = UnivariateKZG::open(DenseUnivariatePolynomial(coeffs), z, srs);
+    std::vector<g1_jac_t> osrs(5);
+    ora_kzg_univariate_srs_g1(osrs.data(), (const fr_t*)&tau, 4);
+    Fr ev; g1_jac_t want;
+    EXPECT(ora_univariate_kzg_open((fr_t*)&ev, &want, O(coeffs), 5, (const fr_t*)&z, osrs.data(), 5) == 0);
+    EXPECT(proof.evaluation == ev && proof.evaluation == Fr::from(129) && same_point(proof.proof, want));
+    EXPECT(panics([&] { UnivariateKZG::open(DenseUnivariatePolynomial(F({1, 2, 3, 4, 5, 6, 7})), z, srs); }));
+}
 TEST(test_kzg_random_2_10) {
     auto tau = random_fr(10, 3), sc = random_fr(1 << 10, 4);
     G1Affine commit = MultilinearKZG::commitment(Multilinear(sc), TrustedSetup::setup(tau));

@@ -228,3 +228,49 @@ def test_kzg_open_shape_panics(zk, ora):
     with pytest.raises(AssertionError):    # one variable: `variable_index - 1` underflows in the reference (:73)
         zk.MultilinearKZG.open(zk.Multilinear(zk.Fr.from_ints([3, 4])), zk.Fr.from_ints([5]),
                                zk.TrustedSetup.setup(zk.Fr.from_ints([2])))
+
+
+# ---- UnivariateKZG::open (univariate_kzg.rs:60-81) -----------------------------------------------------------
+def test_univariate_kzg_open_reference_data(zk, ora):   # univariate_kzg.rs:111-129: tau = 10, poly 1..5, opened at 2
+    tau, z, coeffs = zk.Fr.from_int(10), zk.Fr.from_int(2), zk.Fr.from_ints([1, 2, 3, 4, 5])
+    srs = zk.UnivariateKZG.generate_srs(tau, 4)
+    proof = zk.UnivariateKZG.open(zk.DenseUnivariatePolynomial(coeffs), z, srs)
+    want_ev, want_proof = ora.univariate_kzg_open(coeffs, z, ora.kzg_univariate_srs_g1(tau, 4))
+    assert zk.Fr.to_ints(proof.evaluation) == [129] and np.array_equal(proof.evaluation, want_ev)
+    _same(zk, proof.proof, *_aff(ora, want_proof))
+    with pytest.raises(IndexError):   # quotient longer than the SRS (univariate_kzg.rs:75)
+        zk.UnivariateKZG.open(zk.DenseUnivariatePolynomial(zk.Fr.from_ints([1, 2, 3, 4, 5, 6, 7])), z, srs)
+    const = zk.UnivariateKZG.open(zk.DenseUnivariatePolynomial(zk.Fr.from_ints([7])), z, srs)   # degree 0: quotient zero
+    assert zk.Fr.to_ints(const.evaluation) == [7] and const.proof.infinity
+
+
+@pytest.mark.parametrize("n", [2, 9, 64, 300])
+def test_univariate_kzg_open_random_matches_naive_oracle(zk, ora, n):
+    tau, z = ora.random_fr(1, 2100 + n)[0], ora.random_fr(1, 2200 + n)[0]
+    coeffs = ora.random_fr(n, 2300 + n)
+    srs = zk.UnivariateKZG.generate_srs(tau, n - 1)
+    proof = zk.UnivariateKZG.open(zk.DenseUnivariatePolynomial(coeffs), z, srs)
+    want_ev, want_proof = ora.univariate_kzg_open(coeffs, z, ora.kzg_univariate_srs_g1(tau, n - 1))
+    assert np.array_equal(proof.evaluation, want_ev)
+    _same(zk, proof.proof, *_aff(ora, want_proof))
+
+
+@pytest.mark.parametrize("n,z_int", [(5000, None), (1 << 16, None), ((1 << 16) + 123, None), (4097, 0), (4097, 1)])
+def test_univariate_kzg_open_exponent_identity(zk, ora, n, z_int):
+    """Sizes spanning several workgroups of the Horner scan: proof == q(tau) G with q(tau) = (p(tau) - p(z)) / (tau - z),
+    p(.) from the oracle's Horner-free evaluate on the host (python ints)."""
+    tau = ora.random_fr(1, 31)[0]
+    z = ora.random_fr(1, 32)[0] if z_int is None else zk.Fr.from_int(z_int)
+    coeffs = ora.random_fr(n, 33 + n)
+    srs = zk.UnivariateKZG.generate_srs(tau, n - 1)
+    proof = zk.UnivariateKZG.open(zk.DenseUnivariatePolynomial(coeffs), z, srs)
+    ci, t, zi = zk.Fr.to_ints(coeffs), zk.Fr.to_ints(tau)[0], zk.Fr.to_ints(z)[0]
+
+    def horner(x):
+        acc = 0
+        for c in reversed(ci):
+            acc = (acc * x + c) % R
+        return acc
+    assert zk.Fr.to_ints(proof.evaluation) == [horner(zi)]
+    q_tau = (horner(t) - horner(zi)) * pow(t - zi, -1, R) % R
+    _same(zk, proof.proof, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), q_tau)))

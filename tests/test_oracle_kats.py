@@ -496,3 +496,40 @@ def test_gkr_random_circuit_depth_5(ora):   # Circuit::random, gkr/benches
     ev = ora.circuit_evaluation(layers, inp)
     proof = ora.gkr_prove(layers, ev)
     assert ora.gkr_verify(layers, inp, proof)
+
+
+# ---- dense division + UnivariateKZG::open (dense_univariate.rs:88-124, univariate_kzg.rs:60-81) -------------
+def _poly_mul_add(q, b, r):
+    out = [0] * max(len(q) + len(b) - 1 if q and b else 0, len(r))
+    for i, x in enumerate(q):
+        for j, y in enumerate(b):
+            out[i + j] = (out[i + j] + x * y) % R
+    for i, x in enumerate(r):
+        out[i] = (out[i] + x) % R
+    return out
+
+
+@pytest.mark.parametrize("a,b", [([1, 2, 3, 4, 5], [-2, 1]), ([6, 11, 6, 1], [1, 1]), ([5, 0, 0, 7, 0, 0], [3, 0, 2]), ([4, 4], [1, 2, 3])])
+def test_dense_divide_identity(ora, a, b):
+    q, r = ora.dense_divide(F(ora, a), F(ora, b))
+    qi, ri = ints(ora, q) if len(q) else [], ints(ora, r) if len(r) else []
+    full = _poly_mul_add(qi, [x % R for x in b], ri)
+    want = [x % R for x in a]
+    assert full[: len(want)] == want[: len(full)] and not any(full[len(want):]) and not any(want[len(full):])
+    if len(a) >= len(b):
+        assert len(ri) < len(b)          # deg r < deg b
+    if a == [6, 11, 6, 1]:               # (x+1)(x+2)(x+3) / (x+1) = x^2 + 5x + 6
+        assert qi == [6, 5, 1] and ri == []
+
+
+def test_univariate_kzg_open(ora):   # univariate_kzg.rs:111-129 data: tau = 10, poly 1..5, z = 2
+    tau, z, coeffs = 10, 2, [1, 2, 3, 4, 5]
+    srs = ora.kzg_univariate_srs_g1(F(ora, [tau])[0], 4)
+    ev, proof = ora.univariate_kzg_open(F(ora, coeffs), F(ora, [z])[0], srs)
+    p = lambda x: sum(c * x ** i for i, c in enumerate(coeffs)) % R   # noqa: E731
+    assert ints(ora, ev) == [p(z)] == [129]
+    # the verifier's pairing equation in the exponent: p(tau) - p(z) = q(tau) (tau - z), proof = q(tau) G
+    q_tau = (p(tau) - p(z)) * pow(tau - z, -1, R) % R
+    assert ora.g1_affine_ints(ora.g1_to_affine(proof)) == ora.g1_affine_ints(ora.g1_to_affine(ora.g1_mul_int(ora.g1_generator(), q_tau)))
+    with pytest.raises(IndexError):
+        ora.univariate_kzg_open(F(ora, coeffs + [6, 7]), F(ora, [z])[0], srs)

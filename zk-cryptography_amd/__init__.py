@@ -14,7 +14,7 @@ from zk_cryptography_amd.field import Fr  # noqa: F401
 from zk_cryptography_amd.polynomial import Multilinear  # noqa: F401
 from zk_cryptography_amd.sumcheck import Sumcheck, SumcheckProof  # noqa: F401
 from zk_cryptography_amd.kzg import (DenseUnivariatePolynomial, G1Affine, MultilinearKZG, MultilinearKZGProof, TrustedSetup,  # noqa: F401
-                                     UnivariateKZG)
+                                     UnivariateKZG, UnivariateKZGProof)
 from zk_cryptography_amd.composed import (ComposedMultilinear, ComposedSumcheck, ComposedSumcheckProof,  # noqa: F401
                                           MultiComposedSumcheckProof, MultiComposedSumcheckProver,
                                           SparseUnivariatePolynomial)

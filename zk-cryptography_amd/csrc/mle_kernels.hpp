@@ -227,6 +227,94 @@ static __global__ __launch_bounds__(MLE_BLOCK) void open_step_kernel(const uint6
     }
 }
 
+// ---- Horner suffix scan: UnivariateKZG::open ---------------------------------------------------------------
+// V_i = sum_{j >= i} c_j z^(j-i)  (V_i = c_i + z V_{i+1}, V_n = 0).  V_0 = p(z) is DenseUnivariatePolynomial::evaluate
+// (dense_univariate.rs:184-196) and V_1 .. V_{n-1} are the coefficients of the quotient (p(x) - k) / (x - z) for any
+// constant k -- what univariate_kzg.rs:66-69 takes from divide_with_q_and_r (dense_univariate.rs:88-124; the constant only
+// changes the remainder).  The recurrence is a scan: a lane owns HS_L coefficients, a workgroup HS_T lanes; pass 1 leaves
+// every workgroup's value at its base for zero carry-in (block_vals), horner_top_kernel turns those into the carry
+// entering each workgroup, pass 2 (APPLY) redoes the in-workgroup scan with that carry injected at the top lane and
+// writes the quotient / the evaluation.
+constexpr int HS_L = 8;
+constexpr int HS_T = 256;
+template <bool APPLY>
+static __global__ __launch_bounds__(HS_T) void horner_scan_kernel(const uint64_t* __restrict__ coeffs, size_t n, FrArg z_val,
+                                                           uint64_t* __restrict__ block_vals, const uint64_t* __restrict__ carries,
+                                                           uint64_t* __restrict__ quotient, uint64_t* __restrict__ evaluation) {
+    __shared__ Fr a_lds[HS_T];
+    const Fr z = fr_from_arg(z_val);
+    const uint32_t t = threadIdx.x;
+    const size_t s = ((size_t)blockIdx.x * HS_T + t) * HS_L;
+    Fr c[HS_L];
+#pragma unroll
+    for (int j = 0; j < HS_L; ++j) c[j] = (s + j < n) ? load_fr(coeffs, s + j) : Fr::zero();
+    Fr h = c[HS_L - 1];
+#pragma unroll
+    for (int j = HS_L - 2; j >= 0; --j) h = c[j] + z * h;
+    Fr rp = z;                                  // z^HS_L by squaring (HS_L = 8)
+#pragma unroll
+    for (int q = 1; q < HS_L; q <<= 1) rp = rp * rp;
+    Fr carry_in = Fr::zero();
+    if (APPLY) {
+        carry_in = load_fr(carries, blockIdx.x);
+        if (t == HS_T - 1) h = h + rp * carry_in;
+    }
+    a_lds[t] = h;
+    __syncthreads();
+    for (uint32_t d = 1; d < (uint32_t)HS_T; d <<= 1) {      // A_t += (z^L)^d A_{t+d}
+        Fr v = Fr::zero();
+        const bool has = t + d < (uint32_t)HS_T;
+        if (has) v = a_lds[t + d];
+        __syncthreads();
+        if (has) { h = h + rp * v; a_lds[t] = h; }
+        __syncthreads();
+        rp = rp * rp;
+    }
+    if (!APPLY) {
+        if (t == 0) store_fr(block_vals, blockIdx.x, h);
+        return;
+    }
+    Fr v = (t == HS_T - 1) ? carry_in : a_lds[t + 1];        // V at the top of this lane's chunk
+#pragma unroll
+    for (int j = HS_L - 1; j >= 0; --j) {
+        v = c[j] + z * v;                                    // V_{s+j}
+        const size_t i = s + j;
+        if (i == 0) store_fr(evaluation, 0, v);
+        else if (i < n) store_fr(quotient, i - 1, v);
+    }
+}
+// carries[b] = V at the base of workgroup b + 1 (0 for the last): Y_b = H_{b+1} + R Y_{b+1}, R = z^(HS_T HS_L); one workgroup
+static __global__ __launch_bounds__(1024) void horner_top_kernel(const uint64_t* __restrict__ block_vals, uint32_t n_blocks, FrArg z_val,
+                                                          uint64_t* __restrict__ carries) {
+    __shared__ Fr a_lds[1024];
+    const uint32_t t = threadIdx.x;
+    Fr R = fr_from_arg(z_val);
+    for (int q = 1; q < HS_T * HS_L; q <<= 1) R = R * R;
+    const uint32_t per = (n_blocks + 1023) / 1024;
+    const uint32_t lo = t * per, hi = min(lo + per, n_blocks);       // this lane's workgroups [lo, hi)
+    Fr g = Fr::zero();
+    for (uint32_t b = hi; b-- > lo;) g = load_fr(block_vals, b) + R * g;   // value at the base of `lo` for zero carry-in
+    Fr rp = Fr::one();                                               // R^per
+    for (uint32_t q = 0; q < per; ++q) rp = rp * R;
+    a_lds[t] = g;
+    __syncthreads();
+    Fr h = g;
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        Fr v = Fr::zero();
+        const bool has = t + d < 1024;
+        if (has) v = a_lds[t + d];
+        __syncthreads();
+        if (has) { h = h + rp * v; a_lds[t] = h; }
+        __syncthreads();
+        rp = rp * rp;
+    }
+    Fr y = (t == 1023) ? Fr::zero() : a_lds[t + 1];                  // V at the base of workgroup `hi`
+    for (uint32_t b = hi; b-- > lo;) {
+        store_fr(carries, b, y);
+        y = load_fr(block_vals, b) + R * y;
+    }
+}
+
 // add_to_front / add_to_back (evaluation_form.rs:86-110): out[i] = in[i mod n_in] (shift = 0) or in[i >> shift]
 static __global__ __launch_bounds__(MLE_BLOCK) void repeat_kernel(const uint64_t* __restrict__ in, size_t n_in, uint32_t shift, size_t n_out,
                                                            uint64_t* __restrict__ out) {

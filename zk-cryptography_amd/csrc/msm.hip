@@ -258,6 +258,49 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
     return ZKHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// UnivariateKZG::open
+// ---------------------------------------------------------------------------------------
+extern "C" int zkhip_univariate_kzg_open(zkhip_ctx* c, const uint64_t* d_coeffs, size_t n, const uint64_t* h_z,
+                                         const uint64_t* d_points_xy, const uint8_t* d_points_inf, size_t n_points,
+                                         uint64_t* h_evaluation, uint64_t* h_proof_xy, uint8_t* h_proof_inf) {
+    if (!c || !h_z || !h_evaluation || !h_proof_xy || !h_proof_inf || (n && !d_coeffs)) return ZKHIP_ERR_ARG;
+    std::memset(h_proof_xy, 0, 96);
+    if (n == 0) {                                   // the zero polynomial: evaluate() = 0; numerator [z] has degree 0 < 1 -> quotient zero
+        std::memset(h_evaluation, 0, 32);
+        *h_proof_inf = 1;
+        return ZKHIP_OK;
+    }
+    if (n - 1 > n_points) return ZKHIP_ERR_INDEX;  // srs.powers_of_tau_in_g1[i] out of bounds (univariate_kzg.rs:75)
+    if (n >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
+    if (n > 1 && !d_points_xy) return ZKHIP_ERR_ARG;
+    ZK_TRY(c->activate());
+    const size_t per_block = (size_t)HS_T * HS_L;
+    const uint32_t n_blocks = (uint32_t)((n + per_block - 1) / per_block);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_q = 0, o_vals = al(32 * n), o_carry = o_vals + al(32 * (size_t)n_blocks), o_eval = o_carry + al(32 * (size_t)n_blocks);
+    ZK_TRY(c->reserve_aux(o_eval + 256));
+    char* aux = (char*)c->d_aux;
+    uint64_t* d_q = (uint64_t*)(aux + o_q);
+    uint64_t* d_vals = (uint64_t*)(aux + o_vals);
+    uint64_t* d_carry = (uint64_t*)(aux + o_carry);
+    uint64_t* d_eval = (uint64_t*)(aux + o_eval);
+    FrArg z = {};
+    std::memcpy(z.v, h_z, 32);
+    {
+        ProfScope ps(c, "horner_scan", 96.0 * (double)n);
+        hipLaunchKernelGGL(horner_scan_kernel<false>, dim3(n_blocks), dim3(HS_T), 0, c->stream, d_coeffs, n, z, d_vals, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(horner_top_kernel, dim3(1), dim3(1024), 0, c->stream, d_vals, n_blocks, z, d_carry);
+        hipLaunchKernelGGL(horner_scan_kernel<true>, dim3(n_blocks), dim3(HS_T), 0, c->stream, d_coeffs, n, z, nullptr, d_carry, d_q, d_eval);
+    }
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_eval, 32, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(h_evaluation, c->pinned_u64(ZK_PIN_RES), 32);
+    if (n == 1) { *h_proof_inf = 1; return ZKHIP_OK; }          // degree 0 < 1: quotient zero, proof = G1::default()
+    return msm_commit(c, d_points_xy, d_points_inf, d_q, n - 1, h_proof_xy, h_proof_inf);
+}
+
 // scalars (device, n x 4) -> affine SRS points
 static int srs_from_scalars(zkhip_ctx* c, const uint64_t* d_scalars, size_t n, uint64_t* d_out_xy, uint8_t* d_out_inf) {
     // workspace layout: [scalars n*32 (owned by caller region)] ... we only need n*192 for XYZZ here

@@ -133,7 +133,29 @@ class MultilinearKZG:
         return MultilinearKZGProof(ev, [G1Affine(pxy[i], pinf[i]) for i in range(nv)])
 
 
+class UnivariateKZGProof:
+    """kzg/src/univariate_kzg.rs:11-15: evaluation (Montgomery limbs uint64 [4]) + the quotient's commitment"""
+
+    def __init__(self, evaluation, proof):
+        self.evaluation = evaluation
+        self.proof = proof
+
+
 class UnivariateKZG:
+    @staticmethod
+    def open(poly, evaluation_point, srs):
+        """UnivariateKZGInterface::open (univariate_kzg.rs:60-81)"""
+        assert isinstance(poly, DenseUnivariatePolynomial)
+        z = _fr_host(evaluation_point).reshape(4)
+        ev, xy, inf = np.empty(4, dtype=np.uint64), np.empty(12, dtype=np.uint64), C.c_uint8(0)
+        ctx = N.Context.get(srs.powers_of_tau_in_g1.device.index)
+        st = N.lib().zkhip_univariate_kzg_open(ctx.handle, N.ptr(poly.coefficients) if len(poly) else None, C.c_size_t(len(poly)),
+                                               z.ctypes.data_as(C.c_void_p), N.ptr(srs.powers_of_tau_in_g1), N.ptr(srs.inf),
+                                               C.c_size_t(len(srs)), ev.ctypes.data_as(C.c_void_p), xy.ctypes.data_as(C.c_void_p),
+                                               C.byref(inf))
+        N.check(st, "univariate open")
+        return UnivariateKZGProof(ev, G1Affine(xy, inf.value))
+
     @staticmethod
     def generate_srs(tau, max_degree):
         """UnivariateKZGInterface::generate_srs (univariate_kzg.rs:18-35), G1 powers"""
