@@ -224,6 +224,13 @@ int zkhip_multi_composed_prove(zkhip_ctx *ctx, const uint64_t *const *h_table_pt
 int zkhip_kzg_commit(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t *d_points_inf, size_t n_points,
                      const uint64_t *d_scalars, size_t n_scalars, int require_equal_len, uint64_t *h_out_xy,
                      uint8_t *h_out_inf);
+/* Several independent commitments in one pass of every kernel: problem j commits d_scalars[h_offsets[j] .. h_offsets[j+1])
+ * against d_points_xy[same range] (n_problems <= 64; no reference counterpart -- the reference commits one polynomial at
+ * a time; MultilinearKZG::open uses this for its small rounds, and a caller that commits many short polynomials should
+ * too: a single small commit is latency bound at ~1 ms).  Outputs: h_out_xy[12 j], h_out_inf[j]. */
+int zkhip_kzg_commit_batch(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t *d_points_inf,
+                           const uint64_t *d_scalars, const size_t *h_offsets, uint32_t n_problems, uint64_t *h_out_xy,
+                           uint8_t *h_out_inf);
 /* SRS generation on the device (G1 side; the G2 powers are only used by the pairing verifier, out of scope).
  *   multilinear: TrustedSetup::generate_powers_of_tau_in_g1 (kzg/src/trusted_setup.rs:25-35):
  *                point i = G * prod_j (bit_j(i) ? tau_j : 1 - tau_j), hypercube bits MSB first; 2^n_vars points.

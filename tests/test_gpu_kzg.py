@@ -274,3 +274,24 @@ def test_univariate_kzg_open_exponent_identity(zk, ora, n, z_int):
     assert zk.Fr.to_ints(proof.evaluation) == [horner(zi)]
     q_tau = (horner(t) - horner(zi)) * pow(t - zi, -1, R) % R
     _same(zk, proof.proof, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), q_tau)))
+
+
+@pytest.mark.parametrize("sizes", [[1, 2, 4, 8], [4096, 2048, 1024, 512, 256, 128, 64, 32, 16, 8, 4, 2, 1], [300, 17, 5000], [16384, 3]])
+def test_commit_batch_matches_single_commits(zk, ora, sizes):
+    """zkhip_kzg_commit_batch (the small rounds of MultilinearKZG::open share one pass): every slice's commitment equals
+    the stand-alone commitment of that slice (itself checked against the oracle above)."""
+    from zk_cryptography_amd.kzg import commit_batch
+    import torch
+    total = sum(sizes)
+    tau = ora.random_fr(1, 3100 + len(sizes))[0]
+    srs = zk.UnivariateKZG.generate_srs(tau, total - 1)
+    sc = torch.from_numpy(ora.random_fr(total, 3200 + total).view(np.int64)).cuda()
+    offsets = [0]
+    for s in sizes:
+        offsets.append(offsets[-1] + s)
+    got = commit_batch(srs.powers_of_tau_in_g1, srs.inf, sc, offsets)
+    for j, s in enumerate(sizes):
+        lo, hi = offsets[j], offsets[j + 1]
+        sub = zk.TrustedSetup(srs.powers_of_tau_in_g1[lo:hi], srs.inf[lo:hi])
+        want = zk.UnivariateKZG.commitment(zk.DenseUnivariatePolynomial(sc[lo:hi]), sub)
+        assert got[j] == want

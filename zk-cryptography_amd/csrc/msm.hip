@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "ctx.hpp"
@@ -21,20 +22,23 @@ using namespace zk;
 // ---------------------------------------------------------------------------------------
 // KZG commit (MSM)
 // ---------------------------------------------------------------------------------------
-static MsmPlan msm_plan(size_t n) {
+static MsmPlan msm_plan(size_t n, uint32_t n_problems = 1) {
     uint32_t lg = 0;
     while (((size_t)1 << lg) < n) ++lg;
     // One lane per bucket: the accumulate pass wants many short lists, so the window is as wide as the sort allows
     // as soon as the bucket reduction is not the larger cost (measured with tools/perf_msm.py, ZKHIP_MSM_C sweep:
     // c = 16 wins from 2^13 points on; below that every c ends at the ~1 ms latency floor of the reduction passes).
     uint32_t c = lg >= 13 ? 16 : lg >= 10 ? 12 : 8;
+    if (n_problems > 1) c = lg >= 11 ? 10 : 8;   // batched: windows x problems x partitions must stay within the sort's 2048 partitions
+    if (n_problems > 1) if (const char* e = std::getenv("ZKHIP_MSM_BATCH_C")) c = (uint32_t)std::atoi(e);
     if (const char* e = std::getenv("ZKHIP_MSM_C")) {   // tuning aid (tools/perf_msm.py); any 4 <= c <= 16 is correct
         const int v = std::atoi(e);
         if (v >= 4 && v <= 16) c = (uint32_t)v;
     }
     MsmPlan pl;
     pl.c = c;
-    pl.n_windows = (256 + c - 1) / c;
+    pl.w_per = (256 + c - 1) / c;
+    pl.n_windows = pl.w_per * n_problems;
     pl.nb = 1u << (c - 1);
     pl.ns = pl.nb / MSM_SEG;
     pl.n_bits = c - 1 - MSM_SEG_LOG;
@@ -45,10 +49,14 @@ static MsmPlan msm_plan(size_t n) {
     return pl;
 }
 
-// sum_i scalars[i] * points[i] over the first n entries -> affine result on the host
-static int msm_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, const uint64_t* d_scalars, size_t n,
-                      uint64_t* h_out_xy, uint8_t* h_out_inf) {
-    const MsmPlan pl = msm_plan(n);
+// Problem j = sum_i scalars[i] * points[i] over the entries [off[j], off[j+1]) of the n given -> affine results on the
+// host (h_out_xy[12 j], h_out_inf[j]).  All problems share one pass of every kernel: the windows of problem j are the
+// "virtual windows" [j * w_per, (j+1) * w_per) of one bucket array.
+static int msm_commit_multi(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, const uint64_t* d_scalars, size_t n,
+                            const MsmProblems& pr, uint64_t* h_out_xy, uint8_t* h_out_inf) {
+    size_t max_n = 0;
+    for (uint32_t j = 0; j < pr.n; ++j) max_n = std::max<size_t>(max_n, pr.off[j + 1] - pr.off[j]);
+    const MsmPlan pl = msm_plan(max_n, pr.n);
     const size_t n_buckets = (size_t)pl.n_windows * pl.nb;
     const size_t n_segments = (size_t)pl.n_windows * pl.ns;
     const size_t n_out = (size_t)pl.n_windows * pl.n_terms;
@@ -60,8 +68,8 @@ static int msm_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* 
     const size_t o_bins = o_order + al(n_buckets * 4);
     const size_t o_sorted = o_bins + al(MSM_COUNT_BINS * 4);
     const size_t n_wgs = (n + SORT_TILE - 1) / SORT_TILE;
-    const size_t o_items = o_sorted + al(n * pl.n_windows * 4);
-    const size_t o_wgc = o_items + al(n * pl.n_windows * 8);
+    const size_t o_items = o_sorted + al(n * pl.w_per * 4);
+    const size_t o_wgc = o_items + al(n * pl.w_per * 8);
     const size_t o_pcnt = o_wgc + al(n_wgs * pl.n_parts * 4);
     const size_t o_poff = o_pcnt + al((pl.n_parts + 1) * 4);
     const size_t o_points = o_poff + al((pl.n_parts + 1) * 4);          // SRS in the internal 28-bit-limb layout
@@ -71,8 +79,8 @@ static int msm_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* 
     const size_t o_terms = o_sega + al(n_segments * 256);
     // heavy buckets (msm_kernels.hpp pass 4b/4c): more than heavy_min points, so at most n W / heavy_min of them;
     // a bucket of k points files ceil(k / 8192) level-0 records and, above one record, a <= 256-way tree over them
-    const uint32_t heavy_min = (uint32_t)std::max<size_t>(32, 4 * ((n + pl.nb - 1) / pl.nb));
-    const size_t items_max = n * pl.n_windows;
+    const uint32_t heavy_min = (uint32_t)std::max<size_t>(32, 4 * ((max_n + pl.nb - 1) / pl.nb));
+    const size_t items_max = n * pl.w_per;
     const size_t rec_cap = items_max / heavy_min + items_max / MSM_HEAVY_REC + 2;
     const size_t slots_cap = 3 * (items_max / MSM_HEAVY_REC) + 8;
     const size_t o_ovf = o_terms + al(n_out * 192);
@@ -107,11 +115,11 @@ static int msm_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* 
     }
     {   // two-level counting sort of the (point, window) pairs by bucket; also yields counts[] and offsets[]
         ProfScope ps(c, "msm_sort", 32.0 * (double)n);
-        hipLaunchKernelGGL(msm_sort_count_kernel, dim3((unsigned)n_wgs), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl, wg_counts);
+        hipLaunchKernelGGL(msm_sort_count_kernel, dim3((unsigned)n_wgs), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl, pr, wg_counts);
         hipLaunchKernelGGL(msm_sort_bases_kernel, dim3((pl.n_parts + MSM_BLOCK - 1) / MSM_BLOCK), dim3(MSM_BLOCK), 0, c->stream, wg_counts,
                            (uint32_t)n_wgs, pl.n_parts, part_count);
         hipLaunchKernelGGL(msm_sort_part_scan_kernel, dim3(1), dim3(1024), 0, c->stream, part_count, pl.n_parts, part_off);
-        hipLaunchKernelGGL(msm_sort_scatter_kernel, dim3((unsigned)n_wgs), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl,
+        hipLaunchKernelGGL(msm_sort_scatter_kernel, dim3((unsigned)n_wgs), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl, pr,
                            wg_counts, part_off, items);
         hipLaunchKernelGGL(msm_sort_local_kernel, dim3(pl.n_parts), dim3(SORT_LOCAL_BLOCK), 0, c->stream, items, part_off, pl, sorted, counts, offsets);
     }
@@ -150,17 +158,37 @@ static int msm_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* 
     std::vector<uint64_t> h_terms(n_out * 24);
     ZK_HIP(c, hipMemcpyAsync(h_terms.data(), terms, n_out * 192, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
-    // host epilogue: sum over (window w, term t) of 2^exp * point
-    std::vector<zkhost::Xyzz> pts(n_out);
-    std::vector<uint32_t> exps(n_out);
-    for (size_t i = 0; i < n_out; ++i) {
-        std::memcpy(&pts[i], &h_terms[24 * i], 192);
-        const uint32_t w = (uint32_t)(i / pl.n_terms), t = (uint32_t)(i % pl.n_terms);
-        exps[i] = w * pl.c + (t == 0 ? 0 : MSM_SEG_LOG + (t - 1));
+    // host epilogue, per problem: sum over (window w, term t) of 2^exp * point
+    const size_t per_problem = (size_t)pl.w_per * pl.n_terms;
+    auto finish = [&](uint32_t j) {
+        std::vector<zkhost::Xyzz> pts(per_problem);
+        std::vector<uint32_t> exps(per_problem);
+        for (size_t i = 0; i < per_problem; ++i) {
+            std::memcpy(&pts[i], &h_terms[24 * (j * per_problem + i)], 192);
+            const uint32_t w = (uint32_t)(i / pl.n_terms), t = (uint32_t)(i % pl.n_terms);
+            exps[i] = w * pl.c + (t == 0 ? 0 : MSM_SEG_LOG + (t - 1));
+        }
+        zkhost::Xyzz res = zkhost::weighted_sum_pow2(pts, exps);
+        h_out_inf[j] = zkhost::xyzz_to_affine(res, h_out_xy + 12 * (size_t)j) ? 0 : 1;
+    };
+    // the chains of different problems are independent (~0.25 ms each): a batch spreads them over host threads
+    const uint32_t n_threads = std::min<uint32_t>(std::min<uint32_t>(pr.n, 8u), std::max(1u, std::thread::hardware_concurrency()));
+    if (n_threads <= 1) {
+        for (uint32_t j = 0; j < pr.n; ++j) finish(j);
+    } else {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < n_threads; ++t)
+            pool.emplace_back([&, t] { for (uint32_t j = t; j < pr.n; j += n_threads) finish(j); });
+        for (auto& th : pool) th.join();
     }
-    zkhost::Xyzz res = zkhost::weighted_sum_pow2(pts, exps);
-    *h_out_inf = zkhost::xyzz_to_affine(res, h_out_xy) ? 0 : 1;
     return ZKHIP_OK;
+}
+static int msm_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, const uint64_t* d_scalars, size_t n,
+                      uint64_t* h_out_xy, uint8_t* h_out_inf) {
+    MsmProblems one = {};
+    one.n = 1;
+    one.off[1] = (uint32_t)n;
+    return msm_commit_multi(c, d_points_xy, d_points_inf, d_scalars, n, one, h_out_xy, h_out_inf);
 }
 
 extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf,
@@ -175,6 +203,29 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     if (n >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
     return msm_commit(c, d_points_xy, d_points_inf, d_scalars, n, h_out_xy, h_out_inf);
+}
+
+extern "C" int zkhip_kzg_commit_batch(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf,
+                                      const uint64_t* d_scalars, const size_t* h_offsets, uint32_t n_problems, uint64_t* h_out_xy,
+                                      uint8_t* h_out_inf) {
+    if (!c || !h_offsets || !h_out_xy || !h_out_inf) return ZKHIP_ERR_ARG;
+    if (n_problems == 0) return ZKHIP_OK;
+    if (n_problems > (uint32_t)MSM_MAX_PROBLEMS) return ZKHIP_ERR_SHAPE;
+    MsmProblems pr = {};
+    pr.n = n_problems;
+    for (uint32_t j = 0; j <= n_problems; ++j) {
+        if (h_offsets[j] >= ((size_t)1 << 31) || (j && h_offsets[j] < h_offsets[j - 1])) return ZKHIP_ERR_SHAPE;
+        pr.off[j] = (uint32_t)(h_offsets[j] - h_offsets[0]);
+    }
+    const size_t n = pr.off[n_problems];
+    if (n == 0) {
+        for (uint32_t j = 0; j < n_problems; ++j) { std::memset(h_out_xy + 12 * (size_t)j, 0, 96); h_out_inf[j] = 1; }
+        return ZKHIP_OK;
+    }
+    if (!d_points_xy || !d_scalars) return ZKHIP_ERR_ARG;
+    ZK_TRY(c->activate());
+    const size_t o = h_offsets[0];
+    return msm_commit_multi(c, d_points_xy + 12 * o, d_points_inf ? d_points_inf + o : nullptr, d_scalars + 4 * o, n, pr, h_out_xy, h_out_inf);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -222,9 +273,10 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
     if (n >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
     if ((d_folded_xy == nullptr) != (d_folded_inf == nullptr)) return ZKHIP_ERR_ARG;
     ZK_TRY(c->activate());
-    // aux layout: quotient (n/2) | remainder ping (n/2) | pong (n/4) | [folded SRS xy, inf]
+    // aux layout: quotients of all rounds (n - 1, laid out like the folded SRS) | remainder ping (n/2) | pong (n/4) |
+    // [folded SRS xy, inf]
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_q = 0, o_ping = o_q + al(n / 2 * 32), o_pong = o_ping + al(n / 2 * 32);
+    const size_t o_q = 0, o_ping = o_q + al(n * 32), o_pong = o_ping + al(n / 2 * 32);
     const size_t o_fxy = o_pong + al((n / 4 + 1) * 32), o_finf = o_fxy + al((n - 1) * 96);
     const bool own_fold = d_folded_xy == nullptr;
     ZK_TRY(c->reserve_aux(own_fold ? o_finf + al(n - 1) : o_fxy));
@@ -237,20 +289,36 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
         d_folded_inf = (const uint8_t*)(aux + o_finf);
     }
     uint64_t* d_q = (uint64_t*)(aux + o_q);
+    // Rounds with more than OPEN_BATCH_MAX quotient entries commit one by one; the remaining (<= 15) small rounds, each
+    // far below the size at which a commit stops being latency bound, share one batched commit.
+    size_t OPEN_BATCH_MAX = (size_t)1 << 14;   // measured: 2^20 open 14.4 ms at 2^12, 11.6 ms at 2^14 (tools/perf_open.py)
+    if (const char* e = std::getenv("ZKHIP_OPEN_BATCH_LOG")) OPEN_BATCH_MAX = (size_t)1 << std::atoi(e);   // tuning aid
     const uint64_t* cur = d_evals;
     size_t cn = n, lvl_off = 0;
+    MsmProblems batch = {};
+    size_t batch_first_off = 0;
+    uint32_t batch_first_round = 0;
     for (uint32_t i = 0; i < n_vars; ++i) {
         FrArg z = {};
         std::memcpy(z.v, h_points + 4 * (size_t)i, 32);
         uint64_t* rem = (uint64_t*)(aux + ((i & 1) ? o_pong : o_ping));
-        hipLaunchKernelGGL(open_step_kernel, dim3(mle_grid(cn / 2)), dim3(MLE_BLOCK), 0, c->stream, cur, cn, z, d_q, rem);
+        hipLaunchKernelGGL(open_step_kernel, dim3(mle_grid(cn / 2)), dim3(MLE_BLOCK), 0, c->stream, cur, cn, z, d_q + 4 * lvl_off, rem);
         ZK_HIP(c, hipGetLastError());
         const size_t h = cn / 2;   // |q_i| = |S_i|
-        ZK_TRY(msm_commit(c, d_folded_xy + 12 * lvl_off, d_folded_inf + lvl_off, d_q, h, h_proofs_xy + 12 * (size_t)i, h_proofs_inf + i));
+        if (h > OPEN_BATCH_MAX) {
+            ZK_TRY(msm_commit(c, d_folded_xy + 12 * lvl_off, d_folded_inf + lvl_off, d_q + 4 * lvl_off, h, h_proofs_xy + 12 * (size_t)i, h_proofs_inf + i));
+        } else {
+            if (batch.n == 0) { batch_first_off = lvl_off; batch_first_round = i; }
+            batch.off[batch.n] = (uint32_t)(lvl_off - batch_first_off);
+            batch.off[++batch.n] = (uint32_t)(lvl_off + h - batch_first_off);
+        }
         lvl_off += h;
         cur = rem;
         cn = h;
     }
+    if (batch.n)
+        ZK_TRY(msm_commit_multi(c, d_folded_xy + 12 * batch_first_off, d_folded_inf + batch_first_off, d_q + 4 * batch_first_off,
+                                lvl_off - batch_first_off, batch, h_proofs_xy + 12 * (size_t)batch_first_round, h_proofs_inf + batch_first_round));
     // the last remainder is poly(z): `evaluation`, and what the reference checks it against (:84-86)
     ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), cur, 32, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));

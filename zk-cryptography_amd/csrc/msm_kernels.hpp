@@ -31,7 +31,8 @@ constexpr int MSM_MAX_WINDOWS = 64;
 
 struct MsmPlan {
     uint32_t c;          // window bits
-    uint32_t n_windows;  // ceil(256 / c)
+    uint32_t n_windows;  // windows in all = w_per * number of batched problems (one problem: ceil(256 / c))
+    uint32_t w_per;      // windows of one scalar = ceil(256 / c)
     uint32_t nb;         // buckets per window = 2^(c-1); bucket i holds digit magnitude i+1
     uint32_t ns;         // segments per window = nb / L
     uint32_t n_bits;     // bits of the segment index = c - 1 - log2 L
@@ -114,13 +115,29 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_order_scatter_kernel(con
 constexpr int SORT_TILE = 2048;          // scalars per workgroup tile (8 per lane)
 constexpr int SORT_MAX_PARTS = 2048;
 
+// Batched commits (several independent (points, scalars) problems laid end to end, e.g. the small levels of
+// MultilinearKZG::open): problem j owns the entries [off[j], off[j+1]) and the windows [j * w_per, (j+1) * w_per).
+constexpr int MSM_MAX_PROBLEMS = 64;
+struct MsmProblems {
+    uint32_t n;
+    uint32_t off[MSM_MAX_PROBLEMS + 1];
+};
+__device__ __forceinline__ uint32_t msm_problem_of(const MsmProblems& pr, uint32_t i) {
+    uint32_t lo = 0, hi = pr.n;            // off[lo] <= i < off[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (i >= pr.off[mid]) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 __device__ __forceinline__ uint32_t msm_partition_of(uint32_t w, uint32_t mag, const MsmPlan& pl) {
     return w * pl.parts_pw + ((mag - 1) >> pl.sub_bits);
 }
 
 static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_count_kernel(const uint64_t* __restrict__ scalars,
                                                                           const uint8_t* __restrict__ inf, size_t n, MsmPlan pl,
-                                                                          uint32_t* __restrict__ wg_counts) {
+                                                                          MsmProblems pr, uint32_t* __restrict__ wg_counts) {
     __shared__ uint32_t local[SORT_MAX_PARTS];
     for (uint32_t i = threadIdx.x; i < pl.n_parts; i += MSM_BLOCK) local[i] = 0;
     __syncthreads();
@@ -129,10 +146,11 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_count_kernel(const 
         const size_t i = base + u * MSM_BLOCK + threadIdx.x;
         if (i >= n || (inf && inf[i])) continue;
         DigitStream ds(load_fr(scalars, i).from_mont());
-        for (uint32_t w = 0; w < pl.n_windows; ++w) {
+        const uint32_t wbase = pr.n > 1 ? msm_problem_of(pr, (uint32_t)i) * pl.w_per : 0u;
+        for (uint32_t w = 0; w < pl.w_per; ++w) {
             const int32_t d = ds.next(pl);
             if (d == 0) continue;
-            atomicAdd(&local[msm_partition_of(w, d < 0 ? (uint32_t)(-d) : (uint32_t)d, pl)], 1u);
+            atomicAdd(&local[msm_partition_of(wbase + w, d < 0 ? (uint32_t)(-d) : (uint32_t)d, pl)], 1u);
         }
     }
     __syncthreads();
@@ -174,7 +192,7 @@ static __global__ __launch_bounds__(1024) void msm_sort_part_scan_kernel(const u
 
 static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_scatter_kernel(const uint64_t* __restrict__ scalars,
                                                                             const uint8_t* __restrict__ inf, size_t n, MsmPlan pl,
-                                                                            const uint32_t* __restrict__ wg_bases,
+                                                                            MsmProblems pr, const uint32_t* __restrict__ wg_bases,
                                                                             const uint32_t* __restrict__ part_off,
                                                                             uint2* __restrict__ items) {
     __shared__ uint32_t cur[SORT_MAX_PARTS];
@@ -187,12 +205,13 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_scatter_kernel(cons
         const size_t i = base + u * MSM_BLOCK + threadIdx.x;
         if (i >= n || (inf && inf[i])) continue;
         DigitStream ds(load_fr(scalars, i).from_mont());
-        for (uint32_t w = 0; w < pl.n_windows; ++w) {
+        const uint32_t wbase = pr.n > 1 ? msm_problem_of(pr, (uint32_t)i) * pl.w_per : 0u;
+        for (uint32_t w = 0; w < pl.w_per; ++w) {
             const int32_t d = ds.next(pl);
             if (d == 0) continue;
             const bool neg = d < 0;
             const uint32_t mag = neg ? (uint32_t)(-d) : (uint32_t)d;
-            const uint32_t pos = atomicAdd(&cur[msm_partition_of(w, mag, pl)], 1u);
+            const uint32_t pos = atomicAdd(&cur[msm_partition_of(wbase + w, mag, pl)], 1u);
             items[pos] = make_uint2((uint32_t)i | (neg ? 0x80000000u : 0u), (mag - 1) & sub_mask);
         }
     }

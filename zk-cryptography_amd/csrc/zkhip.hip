@@ -552,14 +552,17 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
         ZK_TRY(launch_small(c, a, st, d_rp, d_ch));
     }
     // results -> host
+    // one copy of the small-scratch span [state .. round polynomials]: the sum, the challenges and the round
+    // polynomials are a few KiB apart in one allocation, and three small copies cost three launches
     uint64_t* pin = c->pinned_u64(ZK_PIN_PROOF);
-    ZK_HIP(c, hipMemcpyAsync(pin, st->sum, 32, hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(c, hipMemcpyAsync(pin + 4, d_rp, 64 * (size_t)n_vars, hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(c, hipMemcpyAsync(pin + 4 + 8 * ZK_MAX_ROUNDS, d_ch, 32 * (size_t)n_vars, hipMemcpyDeviceToHost, c->stream));
+    const uint64_t* span = c->small_u64(ZK_SMALL_STATE);
+    const size_t span_words = (size_t)(ZK_SMALL_ROUNDPOLYS - ZK_SMALL_STATE) + 8 * (size_t)n_vars;
+    static_assert(ZK_PIN_END - ZK_PIN_PROOF >= (ZK_SMALL_ROUNDPOLYS - ZK_SMALL_STATE) + 8 * ZK_MAX_ROUNDS, "pinned proof area too small");
+    ZK_HIP(c, hipMemcpyAsync(pin, span, 8 * span_words, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
-    std::memcpy(h_sum, pin, 32);
-    std::memcpy(h_round_polys, pin + 4, 64 * (size_t)n_vars);
-    std::memcpy(h_challenges, pin + 4 + 8 * ZK_MAX_ROUNDS, 32 * (size_t)n_vars);
+    std::memcpy(h_sum, pin + ((const uint64_t*)st->sum - span), 32);
+    std::memcpy(h_round_polys, pin + (d_rp - span), 64 * (size_t)n_vars);
+    std::memcpy(h_challenges, pin + (d_ch - span), 32 * (size_t)n_vars);
     return ZKHIP_OK;
 }
 

@@ -94,6 +94,18 @@ def _commit(points, inf, n_points, scalars, n_scalars, require_equal_len):
     return G1Affine(out, oinf.value)
 
 
+def commit_batch(points, inf, scalars, offsets):
+    """zkhip_kzg_commit_batch: commitments of the slices [offsets[j], offsets[j+1]) of (points, scalars), one pass"""
+    nprob = len(offsets) - 1
+    xy = np.zeros((max(nprob, 1), 12), dtype=np.uint64)
+    oinf = np.zeros(max(nprob, 1), dtype=np.uint8)
+    offs = (C.c_size_t * len(offsets))(*[int(o) for o in offsets])
+    ctx = N.Context.get(points.device.index)
+    N.check(N.lib().zkhip_kzg_commit_batch(ctx.handle, N.ptr(points), N.ptr(inf), N.ptr(scalars), offs, C.c_uint32(nprob),
+                                           xy.ctypes.data_as(C.c_void_p), oinf.ctypes.data_as(C.c_void_p)), "commit_batch")
+    return [G1Affine(xy[j], oinf[j]) for j in range(nprob)]
+
+
 class MultilinearKZGProof:
     """kzg/src/multilinear_kzg.rs:17-21: evaluation (Montgomery limbs, uint64 [4]) + one G1 proof per variable"""
 
