@@ -30,6 +30,11 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
     n = 1 << log_n
     tau = zk.Fr.random(log_n, 0x7A0 + rank)
     srs = zk.TrustedSetup.setup(tau)                  # real SRS, generated on the device (not timed)
+    plain_srs = zk.TrustedSetup(srs.powers_of_tau_in_g1, srs.inf)
+    t_tab = time.perf_counter()
+    srs.precompute()                                  # shifted-SRS table (depends on the SRS only; built once, not timed)
+    torch.cuda.synchronize()
+    t_tab = time.perf_counter() - t_tab
     g = torch.Generator(device="cuda").manual_seed(0x5EED1001 + rank)
     poly = zk.Multilinear(torch.randint(0, 2 ** 62, (n, 4), dtype=torch.int64, device="cuda", generator=g))
     steps = max(2, min(args.steps, 10))
@@ -57,6 +62,15 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # the same commitments without the table (16 instead of 13 bucket additions per point, 16 bucket reductions)
+    zk.MultilinearKZG.commitment(poly, plain_srs)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        com_plain = zk.MultilinearKZG.commitment(poly, plain_srs)
+    torch.cuda.synchronize()
+    dt_plain = time.perf_counter() - t1
+    assert world > 1 or com_plain == com, "table and plain commitments differ"
     ctx = N.Context.get()
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 1), "profile_enable")
     zk.MultilinearKZG.commitment(poly, srs)
@@ -66,21 +80,25 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
     out = {"metric": "MSM points/s (KZG commit, 2^%d-point SRS per GPU)" % log_n,
            "value": round(float(n) * world * steps / dt, 1), "unit": "points/s", "ms_per_commit": round(1e3 * dt / steps, 3),
            "steps": steps,
+           "srs_table": {"bytes": int(srs._table.numel()), "build_ms": round(1e3 * t_tab, 1),
+                         "note": "2^(20 w) * point for the 13 windows of a scalar; depends on the SRS only, built once, not timed"},
+           "without_srs_table": {"value": round(float(n) * steps / dt_plain, 1), "unit": "points/s (this rank)",
+                                 "ms_per_commit": round(1e3 * dt_plain / steps, 3)},
            "roofline": {"bound": "integer ALU (not HBM: ~10 Fq products of ~900 instructions per bucket addition)",
                         "kernel": "msm_accumulate_kernel", "achieved": round(by.value / (ms.value * 1e-3) / 1e9, 2),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by.value / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                         "avg_launch_us": round(1e3 * ms.value, 1),
                         "algorithmic_bytes_per_launch": "128 B x points (96 B affine point + 32 B scalar)"}}
     # what actually bounds that kernel: issue of v_mad_u64_u32.  One bucket addition = 10 products in the 14 x 28-bit
-    # representation = 4060 multiply-adds; a launch adds one point per non-zero digit (16 windows x points, all but
-    # 2^-16 of them).  Peak = 1024 SIMDs x 64 lanes / 4.9 cycles per wave-instruction x 2.4 GHz as measured by
+    # representation = 4060 multiply-adds; a launch adds one point per non-zero digit (13 windows x points with the
+    # shifted-SRS table, all but 2^-20 of them).  Peak = 1024 SIMDs x 64 lanes / 4.9 cycles per wave-instruction x 2.4 GHz as measured by
     # tools/ubench.hip (profiles/r01/ubench_alu_gfx950.txt).
-    mads = 4060.0 * 16.0 * n * (1.0 - 2.0 ** -16)
+    mads = 4060.0 * 13.0 * n * (1.0 - 2.0 ** -20)
     peak_tmads = 1024 * 64 / 4.9 * 2.4e9 / 1e12
     out["roofline_alu"] = {"bound": "valu", "kernel": "msm_accumulate_kernel", "achieved": round(mads / (ms.value * 1e-3) / 1e12, 2),
                            "peak": round(peak_tmads, 2), "unit": "T v_mad_u64_u32 lane-ops/s",
                            "frac": round(mads / (ms.value * 1e-3) / 1e12 / peak_tmads, 4),
-                           "ops_per_launch": "4060 multiply-adds x 16 windows x points"}
+                           "ops_per_launch": "4060 multiply-adds x 13 windows x points"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as ora
         m = 1 << 15                                                     # bounded sample of the naive reference algorithm (~7 s)

@@ -224,6 +224,17 @@ int zkhip_multi_composed_prove(zkhip_ctx *ctx, const uint64_t *const *h_table_pt
 int zkhip_kzg_commit(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t *d_points_inf, size_t n_points,
                      const uint64_t *d_scalars, size_t n_scalars, int require_equal_len, uint64_t *h_out_xy,
                      uint8_t *h_out_inf);
+/* Shifted-SRS table: d_table[w * n + i] = 2^(20 w) * point i for the 13 windows w of a 255-bit scalar, in the kernels'
+ * internal layout (zkhip_srs_table_bytes(n) = 13 * 128 * n bytes: 1.6 GiB for 2^20 points -- HBM is what this part has).
+ * With it the digits of all windows fall into ONE set of 2^19 buckets: 13 n bucket additions instead of 16 n and a single
+ * bucket reduction.  The table depends on the SRS only (built once, ~70 ms at 2^20); zkhip_kzg_commit_table then has the
+ * semantics of zkhip_kzg_commit (same group element, same errors).  n * 13 must stay below 2^31. */
+size_t zkhip_srs_table_bytes(size_t n_points);
+int zkhip_srs_precompute(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t *d_points_inf, size_t n_points,
+                         void *d_table);
+int zkhip_kzg_commit_table(zkhip_ctx *ctx, const void *d_table, const uint8_t *d_points_inf, size_t n_points,
+                           const uint64_t *d_scalars, size_t n_scalars, int require_equal_len, uint64_t *h_out_xy,
+                           uint8_t *h_out_inf);
 /* Several independent commitments in one pass of every kernel: problem j commits d_scalars[h_offsets[j] .. h_offsets[j+1])
  * against d_points_xy[same range] (n_problems <= 64; no reference counterpart -- the reference commits one polynomial at
  * a time; MultilinearKZG::open uses this for its small rounds, and a caller that commits many short polynomials should

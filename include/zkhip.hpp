@@ -315,16 +315,26 @@ class TrustedSetup {                                                            
         return s;
     }
     size_t len() const { return n_; }
+    // shifted-SRS table (zkhip_srs_precompute): built once per SRS, then every commitment uses it
+    TrustedSetup& precompute() {
+        if (!table_) {
+            table_ = std::make_shared<DeviceBuffer>(zkhip_srs_table_bytes(n_));
+            check(zkhip_srs_precompute(ctx(), points(), inf(), n_, table_->u8()), "srs_precompute");
+        }
+        return *this;
+    }
+    const void* table() const { return table_ ? table_->u8() : nullptr; }
     const uint64_t* points() const { return pts_->u64(); }
     const uint8_t* inf() const { return inf_->u8(); }
     explicit TrustedSetup(size_t n) : pts_(std::make_shared<DeviceBuffer>(96 * n)), inf_(std::make_shared<DeviceBuffer>(n)), n_(n) {}
-    std::shared_ptr<DeviceBuffer> pts_, inf_;
+    std::shared_ptr<DeviceBuffer> pts_, inf_, table_;
   private:
     size_t n_;
 };
 inline G1Affine commit_impl(const TrustedSetup& srs, const uint64_t* d_scalars, size_t n, int require_equal) {
     G1Affine g; uint8_t inf = 0;
-    int st = zkhip_kzg_commit(ctx(), srs.points(), srs.inf(), srs.len(), d_scalars, n, require_equal, g.xy, &inf);
+    int st = srs.table() ? zkhip_kzg_commit_table(ctx(), srs.table(), srs.inf(), srs.len(), d_scalars, n, require_equal, g.xy, &inf)
+                         : zkhip_kzg_commit(ctx(), srs.points(), srs.inf(), srs.len(), d_scalars, n, require_equal, g.xy, &inf);
     if (st == ZKHIP_ERR_SHAPE) throw Panic("The length of powers_of_tau_in_g1 and the length of the evaluations of the polynomial should tally!");
     if (st == ZKHIP_ERR_INDEX) throw std::out_of_range("index out of bounds: the len of powers_of_tau_in_g1 is smaller than the polynomial");
     check(st, "kzg_commit");

@@ -209,6 +209,8 @@ TEST(test_kzg_random_2_10) {
     ora_g1_generator(&g);
     ora_g1_mul_bigint(&want, &g, canon, 4);          // commit == p(tau) * G
     EXPECT(same_point(commit, want));
+    TrustedSetup with_table = TrustedSetup::setup(tau);
+    EXPECT(same_point(MultilinearKZG::commitment(Multilinear(sc), with_table.precompute()), want));   // shifted-SRS table path
 }
 // ---- circuit / GKR ------------------------------------------------------------------------------------------------------
 static Circuit make_circuit(const std::vector<std::vector<std::array<int, 3>>>& layers) {   // {type (0 add, 1 mul), in0, in1}

@@ -295,3 +295,48 @@ def test_commit_batch_matches_single_commits(zk, ora, sizes):
         sub = zk.TrustedSetup(srs.powers_of_tau_in_g1[lo:hi], srs.inf[lo:hi])
         want = zk.UnivariateKZG.commitment(zk.DenseUnivariatePolynomial(sc[lo:hi]), sub)
         assert got[j] == want
+
+
+# ---- shifted-SRS table (zkhip_srs_precompute / zkhip_kzg_commit_table): same commitments, fewer bucket additions ----
+def test_commit_table_reference_data(zk, ora):   # multilinear_kzg.rs:133-148 data through the table path
+    vals = [0, 7, 0, 5, 0, 7, 4, 9]
+    srs = zk.TrustedSetup.setup(zk.Fr.from_ints([2, 3, 4])).precompute()
+    com = zk.MultilinearKZG.commitment(zk.Multilinear(zk.Fr.from_ints(vals)), srs)
+    x, y = com.coords()
+    assert x == 0x16ad11e5d15f77c1143b1697344911b9c590110fdd8dd09df2e58bfd757269169deefe8be3544d4e049fb3776fb0bcfb
+    assert y == 0x0f5c8be5f27fc19eee337785e43d18414a8ff04995230f04509800252164cf47887a4a1864f18288652196af6272e7f6
+    with pytest.raises(AssertionError):
+        zk.MultilinearKZG.commitment(zk.Multilinear(zk.Fr.from_ints([1, 2, 3, 4])), srs)
+
+
+@pytest.mark.parametrize("log_n,kind", [(4, "uniform"), (10, "uniform"), (13, "bytes"), (16, "uniform"), (16, "ones"), (17, "uniform")])
+def test_commit_table_matches_plain_commit(zk, ora, log_n, kind):
+    n = 1 << log_n
+    tau = ora.random_fr(log_n, 4100 + log_n)
+    plain = zk.TrustedSetup.setup(tau)
+    table = zk.TrustedSetup(plain.powers_of_tau_in_g1, plain.inf).precompute()
+    rng = np.random.default_rng(log_n)
+    if kind == "uniform":
+        sc = ora.random_fr(n, 4200 + log_n)
+    elif kind == "ones":
+        sc = zk.Fr.from_ints([1] * n)
+    else:
+        sc = zk.Fr.from_ints([int(v) for v in rng.integers(0, 256, n)])
+    poly = zk.Multilinear(sc)
+    a, b = zk.MultilinearKZG.commitment(poly, plain), zk.MultilinearKZG.commitment(poly, table)
+    assert a == b
+    if log_n <= 10:   # and both equal p(tau) G
+        p_tau = ora.fr_to_ints(ora.mle_evaluation(sc, tau))[0]
+        _same(zk, b, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), p_tau)))
+
+
+def test_commit_table_with_identity_points_and_short_polynomial(zk, ora):
+    tau = zk.Fr.from_ints([0, 1, 2, 3])     # SRS with points at infinity (kzg benches' tau)
+    plain = zk.TrustedSetup.setup(tau)
+    table = zk.TrustedSetup(plain.powers_of_tau_in_g1, plain.inf).precompute()
+    vals = zk.Fr.from_ints([0, 5, 0, 0, 7, 0, 1, R - 1, 2, 3, 0, 0, 9, 9, 9, 1])
+    assert zk.MultilinearKZG.commitment(zk.Multilinear(vals), plain) == zk.MultilinearKZG.commitment(zk.Multilinear(vals), table)
+    usrs = zk.UnivariateKZG.generate_srs(zk.Fr.from_int(10), 40)
+    utab = zk.TrustedSetup(usrs.powers_of_tau_in_g1, usrs.inf).precompute()
+    coeffs = zk.DenseUnivariatePolynomial(ora.random_fr(17, 5))     # shorter than the SRS: table stride != n_scalars
+    assert zk.UnivariateKZG.commitment(coeffs, usrs) == zk.UnivariateKZG.commitment(coeffs, utab)

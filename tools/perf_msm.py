@@ -37,6 +37,9 @@ for log_n in range(lo, hi + 1):
         sc[:, 0] &= 255
         sc = (zk.Multilinear(sc) * zk.Fr.from_int(pow(2, 256, R_MOD))).evaluations
     poly = zk.Multilinear(sc)
+    if os.environ.get("TABLE"):
+        t0 = time.perf_counter(); srs.precompute(); torch.cuda.synchronize()
+        print("    table built in %.1f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
     c = zk.MultilinearKZG.commitment(poly, srs)
     torch.cuda.synchronize()
     reps = 5 if log_n <= 22 else 2

@@ -35,7 +35,7 @@ static MsmPlan msm_plan(size_t n, uint32_t n_problems = 1) {
         const int v = std::atoi(e);
         if (v >= 4 && v <= 16) c = (uint32_t)v;
     }
-    MsmPlan pl;
+    MsmPlan pl = {};
     pl.c = c;
     pl.w_per = (256 + c - 1) / c;
     pl.n_windows = pl.w_per * n_problems;
@@ -52,11 +52,35 @@ static MsmPlan msm_plan(size_t n, uint32_t n_problems = 1) {
 // Problem j = sum_i scalars[i] * points[i] over the entries [off[j], off[j+1]) of the n given -> affine results on the
 // host (h_out_xy[12 j], h_out_inf[j]).  All problems share one pass of every kernel: the windows of problem j are the
 // "virtual windows" [j * w_per, (j+1) * w_per) of one bucket array.
+// The window width of the shifted-SRS table (zkhip_srs_precompute): 255-bit scalars are twelve full 20-bit windows and a
+// 15-bit top window, so no window is sparse; 2^19 buckets in all.
+constexpr uint32_t MSM_TABLE_C = 20;
+constexpr uint32_t MSM_TABLE_WINDOWS = (256 + MSM_TABLE_C - 1) / MSM_TABLE_C;   // 13
+static MsmPlan msm_plan_table(size_t stride) {
+    MsmPlan pl = {};
+    pl.c = MSM_TABLE_C;
+    pl.w_per = MSM_TABLE_WINDOWS;
+    pl.n_windows = 1;                              // one bucket set for the digits of all windows
+    pl.shared = 1;
+    pl.stride = (uint32_t)stride;
+    pl.nb = 1u << (pl.c - 1);
+    pl.ns = pl.nb / MSM_SEG;
+    pl.n_bits = pl.c - 1 - MSM_SEG_LOG;
+    pl.n_terms = 1 + pl.n_bits;
+    pl.sub_bits = 8;
+    pl.parts_pw = pl.nb >> pl.sub_bits;            // 2048
+    pl.n_parts = pl.parts_pw;
+    return pl;
+}
+
+// d_table (nullable): shifted-SRS table in the internal layout, entry w * table_stride + i = 2^(20 w) * point i; then
+// d_points_xy is not read and there is exactly one problem.
 static int msm_commit_multi(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, const uint64_t* d_scalars, size_t n,
-                            const MsmProblems& pr, uint64_t* h_out_xy, uint8_t* h_out_inf) {
+                            const MsmProblems& pr, uint64_t* h_out_xy, uint8_t* h_out_inf, const uint32_t* d_table = nullptr,
+                            size_t table_stride = 0) {
     size_t max_n = 0;
     for (uint32_t j = 0; j < pr.n; ++j) max_n = std::max<size_t>(max_n, pr.off[j + 1] - pr.off[j]);
-    const MsmPlan pl = msm_plan(max_n, pr.n);
+    const MsmPlan pl = d_table ? msm_plan_table(table_stride) : msm_plan(max_n, pr.n);
     const size_t n_buckets = (size_t)pl.n_windows * pl.nb;
     const size_t n_segments = (size_t)pl.n_windows * pl.ns;
     const size_t n_out = (size_t)pl.n_windows * pl.n_terms;
@@ -73,17 +97,31 @@ static int msm_commit_multi(zkhip_ctx* c, const uint64_t* d_points_xy, const uin
     const size_t o_pcnt = o_wgc + al(n_wgs * pl.n_parts * 4);
     const size_t o_poff = o_pcnt + al((pl.n_parts + 1) * 4);
     const size_t o_points = o_poff + al((pl.n_parts + 1) * 4);          // SRS in the internal 28-bit-limb layout
-    const size_t o_buckets = o_points + al(n * 128);
+    const size_t o_buckets = o_points + al(d_table ? 0 : n * 128);
     const size_t o_segs = o_buckets + al(n_buckets * 256);
     const size_t o_sega = o_segs + al(n_segments * 256);
     const size_t o_terms = o_sega + al(n_segments * 256);
     // heavy buckets (msm_kernels.hpp pass 4b/4c): more than heavy_min points, so at most n W / heavy_min of them;
     // a bucket of k points files ceil(k / 8192) level-0 records and, above one record, a <= 256-way tree over them
-    const uint32_t heavy_min = (uint32_t)std::max<size_t>(32, 4 * ((max_n + pl.nb - 1) / pl.nb));
+    const uint32_t heavy_min = (uint32_t)std::max<size_t>(32, 4 * ((max_n * (pl.shared ? pl.w_per : 1) + pl.nb - 1) / pl.nb));
     const size_t items_max = n * pl.w_per;
     const size_t rec_cap = items_max / heavy_min + items_max / MSM_HEAVY_REC + 2;
     const size_t slots_cap = 3 * (items_max / MSM_HEAVY_REC) + 8;
-    const size_t o_ovf = o_terms + al(n_out * 192);
+    // two-level pass 6 when a window has more than 4096 segments: `term_sel` selected segments per workgroup, chosen so
+    // that the launch has about two workgroups per CU (see msm_terms_part_kernel)
+    const bool wide_terms = pl.ns > 4096;
+    uint32_t term_block = MSM_BLOCK;
+    if (const char* e = std::getenv("ZKHIP_TERMS_BLOCK")) term_block = (uint32_t)std::atoi(e);   // tuning aid
+    uint32_t term_sel = term_block;
+    {
+        const size_t selected = (size_t)pl.n_windows * ((size_t)pl.ns + (size_t)pl.n_bits * (pl.ns / 2));
+        size_t cap = 464;   // measured best of 58..2000 (tools/perf_msm.py with TABLE=1): 0.6 ms at 2^16 segments
+        if (const char* e = std::getenv("ZKHIP_TERMS_CAP")) cap = (size_t)std::atoi(e);   // tuning aid
+        while ((selected + term_sel - 1) / term_sel > cap) term_sel += term_block;
+    }
+    const uint32_t term_chunks = (pl.ns + term_sel - 1) / term_sel;   // chunks of term 0 (the longest row)
+    const size_t o_tparts = o_terms + al(n_out * 192);
+    const size_t o_ovf = o_tparts + al(wide_terms ? n_out * term_chunks * 256 : 0);
     const size_t o_rec = o_ovf + al(sizeof(MsmOverflow));
     const size_t o_part = o_rec + al(MSM_HEAVY_LEVELS * rec_cap * sizeof(MsmHeavyRec));
     const size_t total = o_part + al(slots_cap * 256);
@@ -94,7 +132,8 @@ static int msm_commit_multi(zkhip_ctx* c, const uint64_t* d_points_xy, const uin
     uint32_t* sorted = (uint32_t*)(ws + o_sorted);
     uint32_t* order = (uint32_t*)(ws + o_order);
     uint32_t* bins = (uint32_t*)(ws + o_bins);
-    uint32_t* points_u = (uint32_t*)(ws + o_points);
+    const uint32_t* points_u = d_table ? d_table : (const uint32_t*)(ws + o_points);
+    uint32_t* tparts = (uint32_t*)(ws + o_tparts);
     uint2* items = (uint2*)(ws + o_items);
     uint32_t* wg_counts = (uint32_t*)(ws + o_wgc);
     uint32_t* part_count = (uint32_t*)(ws + o_pcnt);
@@ -109,9 +148,9 @@ static int msm_commit_multi(zkhip_ctx* c, const uint64_t* d_points_xy, const uin
 
     if (pl.n_parts > (uint32_t)SORT_MAX_PARTS) return ZKHIP_ERR_SHAPE;
     const int grid_n = (int)std::min<size_t>((n + MSM_BLOCK - 1) / MSM_BLOCK, 256 * 8);
-    {
+    if (!d_table) {
         ProfScope ps(c, "msm_convert_points", 224.0 * (double)n);
-        hipLaunchKernelGGL(msm_convert_points_kernel, dim3(grid_n), dim3(MSM_BLOCK), 0, c->stream, d_points_xy, n, points_u);
+        hipLaunchKernelGGL(msm_convert_points_kernel, dim3(grid_n), dim3(MSM_BLOCK), 0, c->stream, d_points_xy, n, (uint32_t*)(ws + o_points));
     }
     {   // two-level counting sort of the (point, window) pairs by bucket; also yields counts[] and offsets[]
         ProfScope ps(c, "msm_sort", 32.0 * (double)n);
@@ -152,14 +191,20 @@ static int msm_commit_multi(zkhip_ctx* c, const uint64_t* d_points_xy, const uin
     }
     {
         ProfScope ps(c, "msm_terms", 0.0);
-        hipLaunchKernelGGL(msm_terms_kernel, dim3((unsigned)n_out), dim3(MSM_BLOCK), MSM_BLOCK * 256, c->stream, segs, sega, pl, terms);
+        if (wide_terms) {
+            ZK_TRY(c->allow_big_lds((const void*)msm_terms_part_kernel, MSM_TERMS_LDS));
+            hipLaunchKernelGGL(msm_terms_part_kernel, dim3((unsigned)n_out, term_chunks), dim3(term_block), term_block == (uint32_t)MSM_BLOCK ? MSM_TERMS_LDS : term_block * 256, c->stream, segs, sega, pl, term_sel, tparts);
+            hipLaunchKernelGGL(msm_terms_final_kernel, dim3((unsigned)n_out), dim3(MSM_BLOCK), MSM_BLOCK * 256, c->stream, tparts, term_chunks, pl, term_sel, terms);
+        } else {
+            hipLaunchKernelGGL(msm_terms_kernel, dim3((unsigned)n_out), dim3(MSM_BLOCK), MSM_BLOCK * 256, c->stream, segs, sega, pl, terms);
+        }
     }
     ZK_HIP(c, hipGetLastError());
     std::vector<uint64_t> h_terms(n_out * 24);
     ZK_HIP(c, hipMemcpyAsync(h_terms.data(), terms, n_out * 192, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     // host epilogue, per problem: sum over (window w, term t) of 2^exp * point
-    const size_t per_problem = (size_t)pl.w_per * pl.n_terms;
+    const size_t per_problem = (size_t)(pl.shared ? 1 : pl.w_per) * pl.n_terms;
     auto finish = [&](uint32_t j) {
         std::vector<zkhost::Xyzz> pts(per_problem);
         std::vector<uint32_t> exps(per_problem);
@@ -203,6 +248,60 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     if (n >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
     return msm_commit(c, d_points_xy, d_points_inf, d_scalars, n, h_out_xy, h_out_inf);
+}
+
+// ---------------------------------------------------------------------------------------
+// shifted-SRS table: commitments with one bucket set for all windows
+// ---------------------------------------------------------------------------------------
+extern "C" size_t zkhip_srs_table_bytes(size_t n_points) { return n_points * MSM_TABLE_WINDOWS * 128; }
+
+extern "C" int zkhip_srs_precompute(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, size_t n,
+                                    void* d_table) {
+    if (!c || !d_points_xy || !d_table) return ZKHIP_ERR_ARG;
+    if (n == 0) return ZKHIP_OK;
+    if (n * MSM_TABLE_WINDOWS >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;   // entry index + sign bit in 32 bits
+    ZK_TRY(c->activate());
+    // workspace: XYZZ of one window (192 n) | affine (96 n) | infinity flags (n)
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_xyzz = 0, o_aff = al(192 * n), o_inf = o_aff + al(96 * n);
+    ZK_TRY(c->reserve_ws(o_inf + al(n)));
+    char* ws = (char*)c->d_ws;
+    uint32_t* table = (uint32_t*)d_table;
+    const unsigned grid = (unsigned)((n + MSM_BLOCK - 1) / MSM_BLOCK);
+    hipLaunchKernelGGL(msm_convert_points_kernel, dim3(std::min<unsigned>(grid, 256 * 8)), dim3(MSM_BLOCK), 0, c->stream, d_points_xy, n, table);
+    if (d_points_inf) {   // entries of points at infinity: all-zero coordinates (their scalars are skipped by the sort anyway)
+        hipLaunchKernelGGL(msm_clear_inf_kernel, dim3(grid), dim3(MSM_BLOCK), 0, c->stream, d_points_inf, n, table);
+    }
+    const size_t n_threads = (n + SRS_CHUNK - 1) / SRS_CHUNK;
+    for (uint32_t w = 1; w < MSM_TABLE_WINDOWS; ++w) {
+        const uint32_t* prev = table + (size_t)(w - 1) * n * 32;
+        uint32_t* cur = table + (size_t)w * n * 32;
+        hipLaunchKernelGGL(msm_shift_points_kernel, dim3(grid), dim3(MSM_BLOCK), 0, c->stream, prev, n, MSM_TABLE_C, (uint64_t*)(ws + o_xyzz));
+        hipLaunchKernelGGL(srs_batch_affine_kernel, dim3((unsigned)((n_threads + SRS_BLOCK - 1) / SRS_BLOCK)), dim3(SRS_BLOCK), 0, c->stream,
+                           (const uint64_t*)(ws + o_xyzz), n, (uint64_t*)(ws + o_aff), (uint8_t*)(ws + o_inf));
+        hipLaunchKernelGGL(msm_convert_points_kernel, dim3(std::min<unsigned>(grid, 256 * 8)), dim3(MSM_BLOCK), 0, c->stream,
+                           (const uint64_t*)(ws + o_aff), n, cur);
+    }
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipStreamSynchronize(c->stream));   // the workspace is reused by the next call
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_kzg_commit_table(zkhip_ctx* c, const void* d_table, const uint8_t* d_points_inf, size_t n_points,
+                                      const uint64_t* d_scalars, size_t n_scalars, int require_equal_len, uint64_t* h_out_xy,
+                                      uint8_t* h_out_inf) {
+    if (!c || !h_out_xy || !h_out_inf) return ZKHIP_ERR_ARG;
+    if (require_equal_len && n_points != n_scalars) return ZKHIP_ERR_SHAPE;   // multilinear_kzg.rs:36-41
+    if (n_scalars > n_points) return ZKHIP_ERR_INDEX;                          // univariate_kzg.rs:53
+    const size_t n = n_scalars;
+    if (n == 0) { std::memset(h_out_xy, 0, 96); *h_out_inf = 1; return ZKHIP_OK; }
+    if (!d_table || !d_scalars) return ZKHIP_ERR_ARG;
+    if (n_points * MSM_TABLE_WINDOWS >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    MsmProblems one = {};
+    one.n = 1;
+    one.off[1] = (uint32_t)n;
+    return msm_commit_multi(c, nullptr, d_points_inf, d_scalars, n, one, h_out_xy, h_out_inf, (const uint32_t*)d_table, n_points);
 }
 
 extern "C" int zkhip_kzg_commit_batch(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf,

@@ -33,6 +33,9 @@ struct MsmPlan {
     uint32_t c;          // window bits
     uint32_t n_windows;  // windows in all = w_per * number of batched problems (one problem: ceil(256 / c))
     uint32_t w_per;      // windows of one scalar = ceil(256 / c)
+    uint32_t shared;     // 1: the points come from a table holding 2^(c w) P for every window w, so the digits of all
+                         //    windows share ONE bucket set (n_windows = 1) and an item names table entry w * stride + i
+    uint32_t stride;     // shared: entries per window in the table
     uint32_t nb;         // buckets per window = 2^(c-1); bucket i holds digit magnitude i+1
     uint32_t ns;         // segments per window = nb / L
     uint32_t n_bits;     // bits of the segment index = c - 1 - log2 L
@@ -150,7 +153,7 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_count_kernel(const 
         for (uint32_t w = 0; w < pl.w_per; ++w) {
             const int32_t d = ds.next(pl);
             if (d == 0) continue;
-            atomicAdd(&local[msm_partition_of(wbase + w, d < 0 ? (uint32_t)(-d) : (uint32_t)d, pl)], 1u);
+            atomicAdd(&local[msm_partition_of(pl.shared ? 0u : wbase + w, d < 0 ? (uint32_t)(-d) : (uint32_t)d, pl)], 1u);
         }
     }
     __syncthreads();
@@ -211,8 +214,9 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_scatter_kernel(cons
             if (d == 0) continue;
             const bool neg = d < 0;
             const uint32_t mag = neg ? (uint32_t)(-d) : (uint32_t)d;
-            const uint32_t pos = atomicAdd(&cur[msm_partition_of(wbase + w, mag, pl)], 1u);
-            items[pos] = make_uint2((uint32_t)i | (neg ? 0x80000000u : 0u), (mag - 1) & sub_mask);
+            const uint32_t pos = atomicAdd(&cur[msm_partition_of(pl.shared ? 0u : wbase + w, mag, pl)], 1u);
+            const uint32_t entry = pl.shared ? w * pl.stride + (uint32_t)i : (uint32_t)i;
+            items[pos] = make_uint2(entry | (neg ? 0x80000000u : 0u), (mag - 1) & sub_mask);
         }
     }
 }
@@ -480,6 +484,90 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_terms_kernel(const uint3
         }
         __syncthreads();
     }
+    if (threadIdx.x == 0) {
+        uint64_t* o = terms + 24 * (size_t)blockIdx.x;
+        store_fq(o, fqu_to_ark(acc.x));
+        store_fq(o + 6, fqu_to_ark(acc.y));
+        store_fq(o + 12, fqu_to_ark(acc.zz));
+        store_fq(o + 18, fqu_to_ark(acc.zzz));
+    }
+}
+
+// ---- shifted-SRS table (zkhip_srs_precompute) -------------------------------------------------------------
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_clear_inf_kernel(const uint8_t* __restrict__ inf, size_t n, uint32_t* __restrict__ table) {
+    const size_t i = (size_t)blockIdx.x * MSM_BLOCK + threadIdx.x;
+    if (i >= n || !inf[i]) return;
+    store_fqu(table + 32 * i, FqU::zero());
+    store_fqu(table + 32 * i + 16, FqU::zero());
+}
+// out[i] = 2^c * in[i] as XYZZ in the arkworks limb layout (for the batched affine conversion): c doublings of a
+// table entry (internal affine layout; all-zero coordinates = the identity of an SRS point at infinity).
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_shift_points_kernel(const uint32_t* __restrict__ in, size_t n, uint32_t c,
+                                                                     uint64_t* __restrict__ out_xyzz) {
+    const size_t i = (size_t)blockIdx.x * MSM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const G1AffineU p = load_affine_u(in, i);
+    uint64_t* o = out_xyzz + 24 * i;
+    if (p.x.all_zero() && p.y.all_zero()) {
+        const Fq z = Fq::zero();
+        store_fq(o, z); store_fq(o + 6, z); store_fq(o + 12, z); store_fq(o + 18, z);
+        return;
+    }
+    G1XyzzU acc = g1u_double_affine(p);
+    for (uint32_t k = 1; k < c; ++k) acc = g1u_double(acc);
+    store_fq(o, fqu_to_ark(acc.x));
+    store_fq(o + 6, fqu_to_ark(acc.y));
+    store_fq(o + 12, fqu_to_ark(acc.zz));
+    store_fq(o + 18, fqu_to_ark(acc.zzz));
+}
+
+// pass 6 for windows with many segments (one shared bucket set has 2^16 of them): first every workgroup sums `sel`
+// SELECTED segments of its (window, term) (blockIdx.x), chunk blockIdx.y -- term 0 selects every segment, term 1+k the
+// segments whose index has bit k set (the j-th of them is j with a one inserted at bit k), so every lane adds the same
+// number of points whatever the term.  These kernels are chains of ~7 k-instruction additions: a wave alone on a SIMD
+// issues nearly as fast as the SIMD can, so what counts is the length of the chain (serial additions + tree levels) and
+// that waves do not pile up on one SIMD; the launch asks for more than half of a CU's LDS so that two workgroups never
+// share a CU at the same time.
+constexpr uint32_t MSM_TERMS_LDS = 96 * 1024;
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_terms_part_kernel(const uint32_t* __restrict__ seg_s,
+                                                                   const uint32_t* __restrict__ seg_a, MsmPlan pl, uint32_t sel,
+                                                                   uint32_t* __restrict__ parts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
+    uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);
+    const uint32_t w = blockIdx.x / pl.n_terms, t = blockIdx.x % pl.n_terms;
+    const uint32_t n_sel = t == 0 ? pl.ns : pl.ns >> 1;                    // selected segments of this term
+    const uint32_t first = blockIdx.y * sel;
+    if (first >= n_sel) return;
+    const uint32_t* src = (t == 0 ? seg_a : seg_s) + (size_t)w * pl.ns * 64;
+    G1XyzzU acc = G1XyzzU::identity();
+    for (uint32_t j = first + threadIdx.x; j < first + sel && j < n_sel; j += blockDim.x) {
+        uint32_t s = j;
+        if (t != 0) {
+            const uint32_t k = t - 1, low = j & ((1u << k) - 1);
+            s = ((j >> k) << (k + 1)) | (1u << k) | low;
+        }
+        G1XyzzU v = load_xyzz_u(src, s);
+        g1u_add(acc, v);
+    }
+    msm_block_tree_sum(acc, blockDim.x, lds);
+    if (threadIdx.x == 0) store_xyzz_u(parts, (size_t)blockIdx.x * gridDim.y + blockIdx.y, acc);
+}
+// ... then one workgroup per (window, term) sums the chunk sums and converts to the arkworks layout for the host
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_terms_final_kernel(const uint32_t* __restrict__ parts, uint32_t row, MsmPlan pl,
+                                                                    uint32_t sel, uint64_t* __restrict__ terms) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
+    uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);
+    const uint32_t t = blockIdx.x % pl.n_terms;
+    const uint32_t n_sel = t == 0 ? pl.ns : pl.ns >> 1;
+    const uint32_t n_chunks = (n_sel + sel - 1) / sel;
+    G1XyzzU acc = G1XyzzU::identity();
+    for (uint32_t k = threadIdx.x; k < n_chunks; k += MSM_BLOCK) {
+        G1XyzzU v = load_xyzz_u(parts, (size_t)blockIdx.x * row + k);
+        g1u_add(acc, v);
+    }
+    uint32_t width = 1;
+    while (width < n_chunks && width < (uint32_t)MSM_BLOCK) width <<= 1;
+    msm_block_tree_sum(acc, width, lds);
     if (threadIdx.x == 0) {
         uint64_t* o = terms + 24 * (size_t)blockIdx.x;
         store_fq(o, fqu_to_ark(acc.x));
