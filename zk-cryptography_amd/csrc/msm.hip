@@ -30,7 +30,6 @@ static MsmPlan msm_plan(size_t n, uint32_t n_problems = 1) {
     // c = 16 wins from 2^13 points on; below that every c ends at the ~1 ms latency floor of the reduction passes).
     uint32_t c = lg >= 13 ? 16 : lg >= 10 ? 12 : 8;
     if (n_problems > 1) c = lg >= 11 ? 10 : 8;   // batched: windows x problems x partitions must stay within the sort's 2048 partitions
-    if (n_problems > 1) if (const char* e = std::getenv("ZKHIP_MSM_BATCH_C")) c = (uint32_t)std::atoi(e);
     if (const char* e = std::getenv("ZKHIP_MSM_C")) {   // tuning aid (tools/perf_msm.py); any 4 <= c <= 16 is correct
         const int v = std::atoi(e);
         if (v >= 4 && v <= 16) c = (uint32_t)v;
@@ -110,13 +109,11 @@ static int msm_commit_multi(zkhip_ctx* c, const uint64_t* d_points_xy, const uin
     // two-level pass 6 when a window has more than 4096 segments: `term_sel` selected segments per workgroup, chosen so
     // that the launch has about two workgroups per CU (see msm_terms_part_kernel)
     const bool wide_terms = pl.ns > 4096;
-    uint32_t term_block = MSM_BLOCK;
-    if (const char* e = std::getenv("ZKHIP_TERMS_BLOCK")) term_block = (uint32_t)std::atoi(e);   // tuning aid
+    const uint32_t term_block = MSM_BLOCK;
     uint32_t term_sel = term_block;
     {
         const size_t selected = (size_t)pl.n_windows * ((size_t)pl.ns + (size_t)pl.n_bits * (pl.ns / 2));
-        size_t cap = 464;   // measured best of 58..2000 (tools/perf_msm.py with TABLE=1): 0.6 ms at 2^16 segments
-        if (const char* e = std::getenv("ZKHIP_TERMS_CAP")) cap = (size_t)std::atoi(e);   // tuning aid
+        const size_t cap = 464;   // measured best of 58..2000 workgroups (tools/perf_msm.py with TABLE=1): 0.6 ms at 2^16 segments
         while ((selected + term_sel - 1) / term_sel > cap) term_sel += term_block;
     }
     const uint32_t term_chunks = (pl.ns + term_sel - 1) / term_sel;   // chunks of term 0 (the longest row)
@@ -390,8 +387,7 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
     uint64_t* d_q = (uint64_t*)(aux + o_q);
     // Rounds with more than OPEN_BATCH_MAX quotient entries commit one by one; the remaining (<= 15) small rounds, each
     // far below the size at which a commit stops being latency bound, share one batched commit.
-    size_t OPEN_BATCH_MAX = (size_t)1 << 14;   // measured: 2^20 open 14.4 ms at 2^12, 11.6 ms at 2^14 (tools/perf_open.py)
-    if (const char* e = std::getenv("ZKHIP_OPEN_BATCH_LOG")) OPEN_BATCH_MAX = (size_t)1 << std::atoi(e);   // tuning aid
+    const size_t OPEN_BATCH_MAX = (size_t)1 << 14;   // measured: 2^20 open 14.4 ms at 2^12, 11.6 ms at 2^14 (tools/perf_open.py)
     const uint64_t* cur = d_evals;
     size_t cn = n, lvl_off = 0;
     MsmProblems batch = {};
