@@ -195,10 +195,10 @@ def test_kzg_open_random_matches_naive_oracle(zk, ora, n_vars):
         _same(zk, got, *_aff(ora, want))
 
 
-def test_kzg_open_2_14_exponent_identity(zk, ora):
+@pytest.mark.parametrize("n_vars", [14, 20])   # 20 = BASELINE config 3's SRS size
+def test_kzg_open_exponent_identity(zk, ora, n_vars):
     """Beyond what the naive oracle can do in seconds: proof_i == Q_i(tau) * G, Q_i the round's quotient evaluated at
     the remaining tau (through the independently verified GPU folds), and the verifier's equation in the exponent."""
-    n_vars = 14
     tau, z = ora.random_fr(n_vars, 71), ora.random_fr(n_vars, 72)
     vals = ora.random_fr(1 << n_vars, 73)
     srs = zk.TrustedSetup.setup(tau)
