@@ -152,7 +152,7 @@ static int msm_commit_multi(zkhip_ctx* c, const uint64_t* d_points_xy, const uin
     {   // two-level counting sort of the (point, window) pairs by bucket; also yields counts[] and offsets[]
         ProfScope ps(c, "msm_sort", 32.0 * (double)n);
         hipLaunchKernelGGL(msm_sort_count_kernel, dim3((unsigned)n_wgs), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl, pr, wg_counts);
-        hipLaunchKernelGGL(msm_sort_bases_kernel, dim3((pl.n_parts + MSM_BLOCK - 1) / MSM_BLOCK), dim3(MSM_BLOCK), 0, c->stream, wg_counts,
+        hipLaunchKernelGGL(msm_sort_bases_kernel, dim3((pl.n_parts + MSM_BLOCK / 64 - 1) / (MSM_BLOCK / 64)), dim3(MSM_BLOCK), 0, c->stream, wg_counts,
                            (uint32_t)n_wgs, pl.n_parts, part_count);
         hipLaunchKernelGGL(msm_sort_part_scan_kernel, dim3(1), dim3(1024), 0, c->stream, part_count, pl.n_parts, part_off);
         hipLaunchKernelGGL(msm_sort_scatter_kernel, dim3((unsigned)n_wgs), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl, pr,

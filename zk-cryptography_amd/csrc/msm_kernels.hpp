@@ -160,18 +160,31 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_count_kernel(const 
     for (uint32_t i = threadIdx.x; i < pl.n_parts; i += MSM_BLOCK) wg_counts[(size_t)blockIdx.x * pl.n_parts + i] = local[i];
 }
 
-// per partition: exclusive scan of the workgroups' counts (in place) and the partition total
+// per partition: exclusive scan of the workgroups' counts (in place) and the partition total.  One WAVE per partition:
+// lane l owns the workgroups [l * per, (l + 1) * per), the lanes' sums are scanned with shuffles (a single lane walking
+// all the workgroups of a partition is a chain of dependent strided loads: 120 us at 2^20 points).
 static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_bases_kernel(uint32_t* __restrict__ wg_counts, uint32_t n_wgs,
                                                                           uint32_t n_parts, uint32_t* __restrict__ part_count) {
-    const uint32_t p = blockIdx.x * MSM_BLOCK + threadIdx.x;
+    const uint32_t p = blockIdx.x * (MSM_BLOCK / 64) + (threadIdx.x >> 6);
     if (p >= n_parts) return;
-    uint32_t run = 0;
-    for (uint32_t g = 0; g < n_wgs; ++g) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t per = (n_wgs + 63) / 64;
+    const uint32_t lo = lane * per, hi = min(lo + per, n_wgs);
+    uint32_t sum = 0;
+    for (uint32_t g = lo; g < hi; ++g) sum += wg_counts[(size_t)g * n_parts + p];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += v;
+    }
+    uint32_t run = incl - sum;
+    for (uint32_t g = lo; g < hi; ++g) {
         const uint32_t c = wg_counts[(size_t)g * n_parts + p];
         wg_counts[(size_t)g * n_parts + p] = run;
         run += c;
     }
-    part_count[p] = run;
+    if (lane == 63) part_count[p] = incl;
 }
 // exclusive scan of <= 2048 partition totals by one workgroup; part_off[n_parts] = grand total
 static __global__ __launch_bounds__(1024) void msm_sort_part_scan_kernel(const uint32_t* __restrict__ part_count, uint32_t n_parts,
