@@ -137,11 +137,57 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
     }
     if (threadIdx.x < 2 && a.log_n >= 2) e_sh[threadIdx.x] = (tree0[6 + threadIdx.x] - tree0[4 + threadIdx.x]).to_mont();
     __syncthreads();
-    const bool wave0 = threadIdx.x < 64;
-    Transcript tr;
-    if (wave0 && !a.first) tr.load(&st->transcript);
+    // ---- rounds.  Every round hashes the same two-block message from the initial hash value:
+    //   block 1 = prefix (the previous challenge's digest; in the first round of a proof the claimed sum) || lo
+    //   block 2 = hi || 0x80 padding || length (96 bytes)
+    // (commit(lo), commit(hi), challenge() of fiat_shamir.rs:17-25 after a challenge() has re-seeded the hasher).
+    // Wave 0 runs the rounds of the two compressions; wave 1 prepares the schedule of block 1, wave 2 that of block 2
+    // (sha256_schedule_to_lds), both from their own copy of lo / hi, one round ahead of the hash.
+    const uint32_t wave = threadIdx.x >> 6;
+    const bool wave0 = wave == 0;
+    uint32_t* kw1 = reinterpret_cast<uint32_t*>(r_sh + 2);      // 64 words
+    uint32_t* kw2 = kw1 + 64;                                   // 64 words
+    uint32_t* dig_sh = kw2 + 64;                                // 2 x 8: raw digest of the last challenge, double-buffered
+    uint32_t* flags = dig_sh + 16;                              // [0]: kw1 progress, [1]: kw2 progress
+    if (threadIdx.x == 0) {
+        flags[0] = 0; flags[1] = 0;
+        // prefix of the first round run here
+        uint32_t pre[8];
+        if (a.first) {
+            const Fr sum_c = (a.first == 2) ? fr_from_mont_outlined(fr_from_arg(a.claimed))
+                           : (a.first == 3) ? fr_from_mont_outlined(load_fr(a.d_claimed, 0)) : tree0[2] + tree0[3];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pre[i] = sum_c.l[7 - i];
+        } else {   // a kernel always stops after a challenge(): initial hash value, the digest pending
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pre[i] = st->transcript.buf[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dig_sh[8 + i] = pre[i];     // slot (it - 1) & 1 for it = 0
+    }
+    __syncthreads();
     Fr lo = tree0[2], hi = tree0[3];     // canonical
     uint32_t depth = a.log_n, round = a.round0, n_w = 1;
+    // schedules of round 0 (waves 1 and 2)
+    auto schedule_block1 = [&](const uint32_t* prefix, const Fr& lo_c, uint32_t it) {
+        uint32_t w[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { w[i] = prefix[i]; w[8 + i] = lo_c.l[7 - i]; }
+        sha256_schedule_to_lds(w, kw1, flags, 4 * it, 1);
+    };
+    auto schedule_block2 = [&](const Fr& hi_c, uint32_t it) {
+        uint32_t w[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { w[i] = hi_c.l[7 - i]; w[8 + i] = 0; }
+        w[8] = 0x80000000u;
+        w[15] = 96 * 8;
+        sha256_schedule_to_lds(w, kw2, flags + 1, 4 * it, 0);
+    };
+    if (a.n_rounds) {
+        if (wave == 1) schedule_block1(dig_sh + 8, lo, 0);
+        if (wave == 2) schedule_block2(hi, 0);
+    }
+    uint32_t digest[8];
     for (uint32_t it = 0; it < a.n_rounds; ++it) {
         Fr* told = (it & 1) ? tree1 : tree0;
         Fr* tnew = (it & 1) ? tree0 : tree1;
@@ -151,18 +197,27 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
         Fr* enew = e_sh + 2 * ((it & 1) ^ 1);
         const bool absorb_sum = a.first && it == 0;
         if (wave0) {
-            if (absorb_sum) {
-                Fr sum_c = (a.first == 2) ? fr_from_mont_outlined(fr_from_arg(a.claimed))
-                         : (a.first == 3) ? fr_from_mont_outlined(load_fr(a.d_claimed, 0)) : lo + hi;
-                tr.init();
-                tr.commit_canonical(sum_c);
+            uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+            uint32_t blk[16];
+            const uint32_t* pre = dig_sh + 8 * ((it + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { blk[i] = pre[i]; blk[8 + i] = lo.l[7 - i]; }
+            sha256_compress_kw(h, blk, kw1, flags, 4 * it);          // uni_poly.to_bytes()  sumcheck.rs:42
+            sha256_compress_kw(h, nullptr, kw2, flags + 1, 4 * it);  // challenge()  :46
+#pragma unroll
+            for (int i = 0; i < 8; ++i) digest[i] = h[i];
+            Fr c;                                                    // from_be_bytes_mod_order, still canonical
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c.l[i] = h[7 - i];
+            c.reduce_once();
+            c.reduce_once();
+            if (threadIdx.x == 0) {
+                r_sh[it & 1] = c;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dig_sh[8 * (it & 1) + i] = h[i];
             }
-            tr.commit_canonical(lo);     // uni_poly.to_bytes()  sumcheck.rs:42
-            tr.commit_canonical(hi);
-            Fr c = tr.challenge_canonical();   // :46, still canonical
-            if (threadIdx.x == 0) r_sh[it & 1] = c;
         }
-        __syncthreads();   // challenge published; tree `told` and `eold` complete
+        __syncthreads();   // challenge and digest published; tree `told` and `eold` complete
         const Fr c = r_sh[it & 1];
         if (wave0) {
             if (depth >= 2) {   // next round polynomial straight from level 2 of the old tree: lo' = t[4] + c * (t[6] - t[4])
@@ -172,6 +227,13 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
                 hi = shfl_fr(v, 1);
             }
         } else {
+            // schedules of the NEXT round first (its hash is already waiting for them), then this round's folding
+            if (it + 1 < a.n_rounds && depth >= 2 && wave <= 2) {
+                const uint32_t q = wave - 1;                         // wave 1: lo', wave 2: hi'
+                const Fr v = told[4 + q] + fr_mul_outlined(c, eold[q]);
+                if (wave == 1) schedule_block1(dig_sh + 8 * (it & 1), v, it + 1);
+                else schedule_block2(v, it + 1);
+            }
             const Fr r = fr_to_mont_outlined(c);       // every helper wave converts for itself (no extra sync)
             const uint32_t helper = threadIdx.x - 64, n_helpers = MLE_BLOCK - 64;
             if (helper == 0) {   // outputs of this round, in Montgomery form as the reference holds them
@@ -185,14 +247,14 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
                 store_fr(challenges, round, r);
             }
             const uint32_t nodes = 1u << (depth - 1);   // the new tree has nodes 1 .. 2*nodes - 1
-            if (helper >= 62 && helper < 64 && depth >= 3) {
-                // lanes 62, 63 of helper wave 0: new level 2 pair (q, q+2) and the product wave 0 will need next round
-                const uint32_t q = 4 + (helper - 62);
+            if (helper >= 190 && helper < 192 && depth >= 3) {
+                // the last two lanes of the last helper wave: new level 2 pair (q, q+2) and the product wave 0 will need next round
+                const uint32_t q = 4 + (helper - 190);
                 Fr va = told[q + 4] + r * (told[q + 8] - told[q + 4]);           // new[q],   p = 4
                 Fr vb = told[q + 6] + r * (told[q + 10] - told[q + 6]);          // new[q+2], p = 4
                 tnew[q] = va;
                 tnew[q + 2] = vb;
-                enew[helper - 62] = (vb - va).to_mont();
+                enew[helper - 190] = (vb - va).to_mont();
             }
             for (uint32_t q = 1 + helper; q < 2 * nodes; q += n_helpers) {
                 if (depth >= 3 && q >= 4 && q < 8) continue;                     // done above
@@ -212,7 +274,13 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
         ++round;
     }
     __syncthreads();
-    if (threadIdx.x == 0) tr.store(&st->transcript);
+    if (threadIdx.x == 0 && a.n_rounds) {   // what FiatShamirTranscript holds after a challenge(): fresh hasher + the digest
+        Transcript tr;
+        tr.init();
+        tr.commit_words8(digest);
+        tr.store(&st->transcript);
+    }
+
     if (a.weights_out) {
         Fr* w = (a.n_rounds & 1) ? w1 : w0;
         for (uint32_t b = threadIdx.x; b < n_w; b += MLE_BLOCK) store_fr(a.weights_out, b, w[b]);
@@ -224,7 +292,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
     }
 }
 __host__ __device__ constexpr size_t small_lds_bytes(uint32_t log_n) {
-    return ((size_t)4 * ((size_t)1 << log_n) + 2 * (1u << MF_MAX_LOGK) + MLE_BLOCK + 4 + 2) * 32;
+    return ((size_t)4 * ((size_t)1 << log_n) + 2 * (1u << MF_MAX_LOGK) + MLE_BLOCK + 4 + 2) * 32 + (64 + 64 + 16 + 2) * 4;
 }
 
 // Fold weights of k known points (MultilinearTrait::evaluation folds variable 0 repeatedly, evaluation_form.rs:162-175):

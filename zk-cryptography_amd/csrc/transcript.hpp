@@ -82,11 +82,91 @@ __device__ __noinline__ void sha256_compress(uint32_t (&h)[8], const uint32_t (&
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
 
+// ---- split compression: the message schedule on another wave ---------------------------------------------------
+// A compression is 64 rounds of ~14 instructions on the working state plus 48 schedule steps of ~10 -- and the
+// schedule does not depend on the state.  In the serial prover kernel a helper wave computes kw[t] = K[t] + W[t] into
+// LDS while the transcript wave runs the rounds; chunks of 16 words are handed over through a counter that only
+// grows (round r uses the values 4 r + 1 .. 4 r + 4), written after the data by the same wave (LDS operations of
+// one wave complete in order).
+__device__ __forceinline__ void sha256_wait_flag(volatile uint32_t* flag, uint32_t want) {
+    while (*flag < want) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// producer: w[0..15] = the block; publishes kw[first_chunk*16 .. 63] chunk by chunk
+__device__ __forceinline__ void sha256_schedule_to_lds(uint32_t (&w)[16], uint32_t* __restrict__ kw, volatile uint32_t* flag,
+                                                    uint32_t flag_base, uint32_t first_chunk) {
+    const bool writer = (threadIdx.x & 63) == 0;
+    if (first_chunk == 0) {
+        if (writer) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) kw[j] = SHA256_K[j] + w[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the data before the counter
+            *flag = flag_base + 1;
+        }
+    }
+#pragma unroll 1
+    for (int base = 16; base < 64; base += 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            uint32_t w15 = w[(j + 1) & 15], w2 = w[(j + 14) & 15];
+            uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+            uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
+            w[j] = w[j] + s0 + w[(j + 9) & 15] + s1;
+        }
+        if (writer) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) kw[base + j] = SHA256_K[base + j] + w[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            *flag = flag_base + 1 + base / 16;
+        }
+    }
+}
+#define ZK_SHA_8ROUNDS_KW(KW)                                  \
+    ZK_SHA_ROUND(a, b, c, d, e, f, g, hh, KW[0])               \
+    ZK_SHA_ROUND(hh, a, b, c, d, e, f, g, KW[1])               \
+    ZK_SHA_ROUND(g, hh, a, b, c, d, e, f, KW[2])               \
+    ZK_SHA_ROUND(f, g, hh, a, b, c, d, e, KW[3])               \
+    ZK_SHA_ROUND(e, f, g, hh, a, b, c, d, KW[4])               \
+    ZK_SHA_ROUND(d, e, f, g, hh, a, b, c, KW[5])               \
+    ZK_SHA_ROUND(c, d, e, f, g, hh, a, b, KW[6])               \
+    ZK_SHA_ROUND(b, c, d, e, f, g, hh, a, KW[7])
+// consumer: rounds 0..15 from `blk` when given (else from kw chunk 0), rounds 16..63 from the kw chunks as they arrive
+__device__ __forceinline__ void sha256_compress_kw(uint32_t (&h)[8], const uint32_t* blk /* 16 words or nullptr */,
+                                                const uint32_t* __restrict__ kw, volatile uint32_t* flag, uint32_t flag_base) {
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    uint32_t v[16];
+    if (blk) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = SHA256_K[j] + blk[j];
+    } else {
+        sha256_wait_flag(flag, flag_base + 1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = kw[j];
+    }
+    {
+        const uint32_t* KW = v;
+        ZK_SHA_8ROUNDS_KW(KW)
+        KW = v + 8;
+        ZK_SHA_8ROUNDS_KW(KW)
+    }
+#pragma unroll 1
+    for (int base = 16; base < 64; base += 16) {
+        sha256_wait_flag(flag, flag_base + 1 + base / 16);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = kw[base + j];
+        const uint32_t* KW = v;
+        ZK_SHA_8ROUNDS_KW(KW)
+        KW = v + 8;
+        ZK_SHA_8ROUNDS_KW(KW)
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
 // Out-of-line Montgomery product for the single-wave control paths (keeps those kernels small).
-__device__ __noinline__ Fr fr_mul_outlined(const Fr& a, const Fr& b) { return a * b; }
+__device__ __noinline__ Fr fr_mul_outlined(Fr a, Fr b) { return a * b; }   // by value: arguments travel in registers, not through scratch
 // Montgomery form -> canonical integer (into_bigint): the reduction half of a product only (x * 1 has no
 // multiplication part): 8 words of word-serial REDC, 64 mads instead of 128.
-__device__ __noinline__ Fr fr_from_mont_outlined(const Fr& a) {
+__device__ __noinline__ Fr fr_from_mont_outlined(Fr a) {
     uint32_t x[9];
 #pragma unroll
     for (int i = 0; i < 8; ++i) x[i] = a.l[i];
