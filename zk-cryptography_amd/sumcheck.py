@@ -29,6 +29,7 @@ class Sumcheck:
         self.poly = poly if isinstance(poly, Multilinear) else Multilinear(poly)
         self._sum_host = np.zeros(4, dtype=np.uint64)   # Default::default()
         self._sum_dev = None                       # poly_sum() leaves the sum on the device until someone reads it
+        self._sum_ptr = None                       # its device address (no tensor view per call: host time is GPU idle time)
         self._block_sums = None                    # device tensor kept by poly_sum() for prove()
         self._log_blocks = 0
 
@@ -36,7 +37,7 @@ class Sumcheck:
     def sum(self):
         """`self.sum` (private in the reference, sumcheck.rs:7-10): fetched from the device on first read."""
         if self._sum_dev is not None:
-            self._sum_host = self._sum_dev.cpu().numpy().view(np.uint64).reshape(4).copy()
+            self._sum_host = self._sum_dev[-1].cpu().numpy().view(np.uint64).reshape(4).copy()
             self._sum_dev = None
         return self._sum_host
 
@@ -54,12 +55,17 @@ class Sumcheck:
         if n == 1:
             self.sum = self.poly.to_numpy()[0].copy()
             return
-        lb = N.lib().zkhip_sumcheck_plan_log_blocks(C.c_size_t(n))
-        buf = torch.empty(((1 << lb) + 1, 4), dtype=torch.int64, device=self.poly.evaluations.device)
-        N.check(N.lib().zkhip_mle_block_sums(self.poly._ctx.handle, N.ptr(self.poly.evaluations), C.c_size_t(n),
-                                             C.c_uint32(lb), N.ptr(buf), None), "block_sums")
+        cached = getattr(self.poly, "_block_sum_buf", None)     # (lb, buffer): reused by every Sumcheck over this table
+        if cached is None:
+            lb = N.lib().zkhip_sumcheck_plan_log_blocks(C.c_size_t(n))
+            cached = (lb, torch.empty(((1 << lb) + 1, 4), dtype=torch.int64, device=self.poly.evaluations.device))
+            self.poly._block_sum_buf = cached
+        lb, buf = cached
+        N.check(N.lib().zkhip_mle_block_sums(self.poly._ctx.handle, C.c_void_p(self.poly.evaluations.data_ptr()), C.c_size_t(n),
+                                             C.c_uint32(lb), C.c_void_p(buf.data_ptr()), None), "block_sums")
         self._block_sums, self._log_blocks = (buf, lb) if lb else (None, 0)
-        self._sum_dev = buf[1 << lb]
+        self._sum_dev = buf
+        self._sum_ptr = buf.data_ptr() + 32 * (1 << lb)
 
     def prove(self):
         """sumcheck.rs:29-61 -> (SumcheckProof, challenges uint64 [n_vars, 4]).
@@ -73,8 +79,8 @@ class Sumcheck:
         st = N.lib().zkhip_sumcheck_prove(self.poly._ctx.handle, N.ptr(self.poly.evaluations),
                                           C.c_size_t(len(self.poly)),
                                           None if self._sum_dev is not None else self._sum_host.ctypes.data_as(C.c_void_p),
-                                          N.ptr(self._sum_dev) if self._sum_dev is not None else None,
-                                          N.ptr(self._block_sums) if self._block_sums is not None else None,
+                                          C.c_void_p(self._sum_ptr) if self._sum_dev is not None else None,
+                                          C.c_void_p(self._block_sums.data_ptr()) if self._block_sums is not None else None,
                                           C.c_uint32(self._log_blocks), s.ctypes.data_as(C.c_void_p),
                                           rp.ctypes.data_as(C.c_void_p), ch.ctypes.data_as(C.c_void_p))
         N.check(st, "sumcheck_prove")
