@@ -21,6 +21,7 @@ constexpr int CMP_MAX_K = 5;        // tables per product term (K <= 
 constexpr int CMP_MAX_TERMS = 4;    // product terms (GKR uses 2)
 constexpr int CMP_MAX_REC = 16;     // sums per workgroup record, sum_p (K_p + 1)
 constexpr int CMP_MAX_MONO = 7;     // monomials of a round polynomial (degree <= 6)
+constexpr int CMP_MAX_BLOCKS = 9;   // SHA-256 blocks of one round: <= 15 pending words + sum (8) + 7 x 16 + padding
 
 struct TablePtrs {
     const uint64_t* in[CMP_MAX_K];
@@ -68,6 +69,10 @@ struct CloseShared {                   // LDS scratch of close_round
     uint32_t pow_of[CMP_MAX_MONO];
     uint32_t n_items;
     Fr challenge;                      // Montgomery form, for the caller
+    Fr sum_canon;                      // canonical claimed sum (absorbed in the first round of a multi-composed proof)
+    uint32_t msg[16 * CMP_MAX_BLOCKS]; // the padded message of the round: pending bytes || items || padding
+    uint32_t kw[64 * CMP_MAX_BLOCKS];  // K + W of every block
+    uint32_t n_blocks;
 };
 
 // Closes a round with the whole workgroup (>= 64 threads; every thread must call): sh.evals hold the sums.
@@ -129,23 +134,61 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
             if (tid == 0) { sh.n_items = (uint32_t)__popcll(mask); out[0] = (uint64_t)__popcll(mask); }
         }
     }
+    if (meta.multi && first && tid == 64) sh.sum_canon = fr_from_mont_outlined(load_fr(st->sum, 0));   // multi_composed_sumcheck.rs:70
     __syncthreads();
-    if (tid == 0) {
-        Transcript tr;
-        if (first == 1) tr.init(); else tr.load(tr_state);
-        if (meta.multi && first) tr.commit_fr(load_fr(st->sum, 0));   // multi_composed_sumcheck.rs:70
+    // ---- the round's message, padded (FiatShamirTranscript: commit ... then challenge = finalize, fiat_shamir.rs:17-25):
+    // what the hasher still holds || [claimed sum] || items || 0x80 00.. || bit length.  Every word is written by one lane.
+    {
+        const uint32_t pending = (first == 1) ? 0u : (tr_state->fill >> 2);        // words
+        const uint64_t len_prev = (first == 1) ? 0u : tr_state->len;               // bytes, pending included
+        const uint32_t sum_words = (meta.multi && first) ? 8u : 0u;
+        const uint32_t item_words = meta.multi ? 16u : 8u;
         const uint32_t n_items = sh.n_items;
-        for (uint32_t i = 0; i < n_items; ++i) {
-            tr.commit_canonical(sh.canon[i]);
-            if (meta.multi) {   // coeff || pow, 32 bytes big-endian each (sparse_univariate.rs:27-34)
-                uint32_t pw[8] = {0, 0, 0, 0, 0, 0, 0, sh.pow_of[i]};
-                tr.commit_words8(pw);
-            }
+        const uint32_t body = pending + sum_words + n_items * item_words;
+        const uint32_t n_blocks = (body + 3 + 15) / 16;                             // + 0x80 word + 64-bit length
+        const uint64_t bits = (len_prev + 4ull * (sum_words + n_items * item_words)) * 8ull;
+        for (uint32_t w = tid; w < 16 * n_blocks; w += blockDim.x) {
+            uint32_t v = 0;
+            if (w < pending) v = tr_state->buf[w];
+            else if (w < pending + sum_words) v = sh.sum_canon.l[7 - (w - pending)];
+            else if (w < body) {
+                const uint32_t q = w - pending - sum_words, i = q / item_words, o = q % item_words;
+                v = o < 8 ? sh.canon[i].l[7 - o] : (o == 15 ? sh.pow_of[i] : 0u);   // coeff || pow, big-endian (sparse_univariate.rs:27-34)
+            } else if (w == body) v = 0x80000000u;
+            else if (w == 16 * n_blocks - 2) v = (uint32_t)(bits >> 32);
+            else if (w == 16 * n_blocks - 1) v = (uint32_t)bits;
+            sh.msg[w] = v;
         }
-        const Fr r = tr.challenge_fr();
-        tr.store(tr_state);
-        store_fr(challenges, round, r);
-        sh.challenge = r;
+        if (tid == 0) sh.n_blocks = n_blocks;
+    }
+    __syncthreads();
+    {   // schedules: wave w takes the blocks w, w + #waves, ...
+        const uint32_t wave = tid >> 6, n_waves = blockDim.x >> 6;
+        for (uint32_t b = wave; b < sh.n_blocks; b += n_waves) sha256_schedule_block(sh.msg + 16 * b, sh.kw + 64 * b);
+    }
+    __syncthreads();
+    if (tid < 64) {   // wave 0: the state rounds of every block, then the challenge
+        uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+        if (first != 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] = tr_state->h[i];
+        }
+        const uint32_t n_blocks = sh.n_blocks;
+        for (uint32_t b = 0; b < n_blocks; ++b) sha256_rounds_block(h, sh.kw + 64 * b);
+        Fr c;                                                   // from_be_bytes_mod_order (fiat_shamir.rs:27-29)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c.l[i] = h[7 - i];
+        c.reduce_once();
+        c.reduce_once();
+        const Fr r = fr_to_mont_outlined(c);
+        if (tid == 0) {
+            Transcript tr;                                      // finalize_reset + update(digest)
+            tr.init();
+            tr.commit_words8(h);
+            tr.store(tr_state);
+            store_fr(challenges, round, r);
+            sh.challenge = r;
+        }
     }
     __syncthreads();
 }

@@ -162,6 +162,47 @@ __device__ __forceinline__ void sha256_compress_kw(uint32_t (&h)[8], const uint3
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
 
+// whole-block forms for the composed provers' round closing: every block of the padded message is known before the
+// hash starts, so all schedules are computed side by side (one wave per block) and the hash wave runs state rounds only
+__device__ __forceinline__ void sha256_schedule_block(const uint32_t* __restrict__ blk, uint32_t* __restrict__ kw) {
+    uint32_t w[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w[j] = blk[j];
+    const bool writer = (threadIdx.x & 63) == 0;
+    if (writer) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) kw[j] = SHA256_K[j] + w[j];
+    }
+#pragma unroll 1
+    for (int base = 16; base < 64; base += 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            uint32_t w15 = w[(j + 1) & 15], w2 = w[(j + 14) & 15];
+            uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+            uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
+            w[j] = w[j] + s0 + w[(j + 9) & 15] + s1;
+        }
+        if (writer) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) kw[base + j] = SHA256_K[base + j] + w[j];
+        }
+    }
+}
+__device__ __forceinline__ void sha256_rounds_block(uint32_t (&h)[8], const uint32_t* __restrict__ kw) {
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll 1
+    for (int base = 0; base < 64; base += 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = kw[base + j];
+        const uint32_t* KW = v;
+        ZK_SHA_8ROUNDS_KW(KW)
+        KW = v + 8;
+        ZK_SHA_8ROUNDS_KW(KW)
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
 // Out-of-line Montgomery product for the single-wave control paths (keeps those kernels small).
 __device__ __noinline__ Fr fr_mul_outlined(Fr a, Fr b) { return a * b; }   // by value: arguments travel in registers, not through scratch
 // Montgomery form -> canonical integer (into_bigint): the reduction half of a product only (x * 1 has no
