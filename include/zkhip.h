@@ -276,6 +276,10 @@ int zkhip_kzg_open(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint
 int zkhip_univariate_kzg_open(zkhip_ctx *ctx, const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *h_z,
                               const uint64_t *d_points_xy, const uint8_t *d_points_inf, size_t n_points,
                               uint64_t *h_evaluation, uint64_t *h_proof_xy, uint8_t *h_proof_inf);
+/* DenseUnivariatePolynomial::evaluate (dense_univariate.rs:184-196: sum c_i z^i; here the Horner suffix scan's V_0) and
+ * ::degree (:199-207: index of the last non-zero coefficient, 0 for none or an empty vector) of device coefficients. */
+int zkhip_dense_evaluate(zkhip_ctx *ctx, const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *h_z, uint64_t *h_out);
+int zkhip_dense_degree(zkhip_ctx *ctx, const uint64_t *d_coeffs, size_t n_coeffs, size_t *h_degree);
 /* Sum of n affine points given on the host (combining per-GPU partial commitments after an all-gather). */
 int zkhip_g1_sum_affine(const uint64_t *h_points_xy, const uint8_t *h_points_inf, size_t n, uint64_t *h_out_xy,
                         uint8_t *h_out_inf);

@@ -89,3 +89,32 @@ def test_multiply_2_20_evaluation_identity(zk, ora):
     d = zk.Domain(2 * n)
     x = torch.cat([a, b])
     assert torch.equal(d.ifft(d.fft(x)), x)
+
+
+# ---- DenseUnivariatePolynomial::{evaluate, degree, Mul} on device coefficients (dense_univariate.rs) --------------
+def test_dense_polynomial_evaluation_degree_multiplication(ora):
+    import zk_cryptography_amd as zk
+    F = zk.Fr.from_ints
+    D = zk.DenseUnivariatePolynomial
+    ints = lambda p: zk.Fr.to_ints(p.coefficients.cpu().numpy().view(np.uint64)) if len(p) else []   # noqa: E731
+    assert zk.Fr.to_ints(D(F([5, 2, 4])).evaluate(zk.Fr.from_int(2))) == [25]                  # :425-433
+    assert zk.Fr.to_ints(D(F([5, 2, 0, 0, 0, 0, 4])).evaluate(zk.Fr.from_int(2))) == [265]     # :185-188
+    assert D(F([1, 3, 2])).degree() == 2 and D(F([1, 3, 0, 0])).degree() == 1 and D(F([0, 0])).degree() == 0
+    assert ints(D(F([1, 3, 2])) * D(F([3, 2]))) == [3, 11, 12, 4]                               # :464-477
+    assert ints(D(F([6, 5, 3])) * D(F([5, 4, 2]))) == [30, 49, 47, 22, 6]                       # :479-497
+    assert ints(D(F([1, 3, 2])) * D(F([3]))) == [3, 9, 6]                                        # :500-509
+    assert ints(D(F([1, 3, 2, 0, 0])) * D(F([3, 2, 0]))) == [3, 11, 12, 4]                       # degree() ignores zero leading coefficients
+    assert ints(D(F([1, 3, 2])) * zk.Fr.from_int(3)) == [3, 9, 6] and ints(D(F([1, 3, 2])) * zk.Fr.from_int(0)) == []
+
+
+@pytest.mark.parametrize("n", [1, 7, 2048, 2049, 100000])
+def test_dense_evaluate_matches_oracle(ora, n):
+    import zk_cryptography_amd as zk
+    coeffs, z = ora.random_fr(n, 900 + n), ora.random_fr(1, 901 + n)[0]
+    got = zk.DenseUnivariatePolynomial(coeffs).evaluate(z)
+    ci, zi, acc = zk.Fr.to_ints(coeffs), zk.Fr.to_ints(z)[0], 0
+    for c in reversed(ci):
+        acc = (acc * zi + c) % zk.Fr.MODULUS
+    assert zk.Fr.to_ints(got) == [acc]
+    if n <= 2049:
+        assert np.array_equal(got, ora.dense_evaluate(coeffs, z))

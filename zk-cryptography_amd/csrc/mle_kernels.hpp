@@ -285,7 +285,7 @@ static __global__ __launch_bounds__(HS_T) void horner_scan_kernel(const uint64_t
 }
 // carries[b] = V at the base of workgroup b + 1 (0 for the last): Y_b = H_{b+1} + R Y_{b+1}, R = z^(HS_T HS_L); one workgroup
 static __global__ __launch_bounds__(1024) void horner_top_kernel(const uint64_t* __restrict__ block_vals, uint32_t n_blocks, FrArg z_val,
-                                                          uint64_t* __restrict__ carries) {
+                                                          uint64_t* __restrict__ carries, uint64_t* __restrict__ v0_out) {
     __shared__ Fr a_lds[1024];
     const uint32_t t = threadIdx.x;
     Fr R = fr_from_arg(z_val);
@@ -313,6 +313,21 @@ static __global__ __launch_bounds__(1024) void horner_top_kernel(const uint64_t*
         store_fr(carries, b, y);
         y = load_fr(block_vals, b) + R * y;
     }
+    if (t == 0 && v0_out) store_fr(v0_out, 0, y);   // V at the base of workgroup 0 = p(z)
+}
+// DenseUnivariatePolynomial::degree (dense_univariate.rs:199-207): index of the last non-zero coefficient, 0 if none;
+// *out must be zeroed first
+static __global__ __launch_bounds__(MLE_BLOCK) void dense_degree_kernel(const uint64_t* __restrict__ coeffs, size_t n,
+                                                                 unsigned long long* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    unsigned long long best = 0;
+    for (size_t i = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; i < n; i += stride)
+        if (!load_fr(coeffs, i).is_zero()) best = i;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_down(best, d, 64);
+        best = best > o ? best : o;
+    }
+    if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
 }
 
 // add_to_front / add_to_back (evaluation_form.rs:86-110): out[i] = in[i mod n_in] (shift = 0) or in[i >> shift]

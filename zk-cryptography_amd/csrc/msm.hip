@@ -453,7 +453,7 @@ extern "C" int zkhip_univariate_kzg_open(zkhip_ctx* c, const uint64_t* d_coeffs,
     {
         ProfScope ps(c, "horner_scan", 96.0 * (double)n);
         hipLaunchKernelGGL(horner_scan_kernel<false>, dim3(n_blocks), dim3(HS_T), 0, c->stream, d_coeffs, n, z, d_vals, nullptr, nullptr, nullptr);
-        hipLaunchKernelGGL(horner_top_kernel, dim3(1), dim3(1024), 0, c->stream, d_vals, n_blocks, z, d_carry);
+        hipLaunchKernelGGL(horner_top_kernel, dim3(1), dim3(1024), 0, c->stream, d_vals, n_blocks, z, d_carry, (uint64_t*)nullptr);
         hipLaunchKernelGGL(horner_scan_kernel<true>, dim3(n_blocks), dim3(HS_T), 0, c->stream, d_coeffs, n, z, nullptr, d_carry, d_q, d_eval);
     }
     ZK_HIP(c, hipGetLastError());
@@ -462,6 +462,42 @@ extern "C" int zkhip_univariate_kzg_open(zkhip_ctx* c, const uint64_t* d_coeffs,
     std::memcpy(h_evaluation, c->pinned_u64(ZK_PIN_RES), 32);
     if (n == 1) { *h_proof_inf = 1; return ZKHIP_OK; }          // degree 0 < 1: quotient zero, proof = G1::default()
     return msm_commit(c, d_points_xy, d_points_inf, d_q, n - 1, h_proof_xy, h_proof_inf);
+}
+
+// DenseUnivariatePolynomial::evaluate (dense_univariate.rs:184-196) and ::degree (:199-207) on a device coefficient vector
+extern "C" int zkhip_dense_evaluate(zkhip_ctx* c, const uint64_t* d_coeffs, size_t n, const uint64_t* h_z, uint64_t* h_out) {
+    if (!c || !h_z || !h_out || (n && !d_coeffs)) return ZKHIP_ERR_ARG;
+    if (n == 0) { std::memset(h_out, 0, 32); return ZKHIP_OK; }
+    ZK_TRY(c->activate());
+    const size_t per_block = (size_t)HS_T * HS_L;
+    const uint32_t n_blocks = (uint32_t)((n + per_block - 1) / per_block);
+    ZK_TRY(c->reserve_aux(64 * (size_t)n_blocks + 512));
+    uint64_t* d_vals = (uint64_t*)c->d_aux;
+    uint64_t* d_carry = d_vals + 4 * (size_t)n_blocks;
+    uint64_t* d_eval = d_carry + 4 * (size_t)n_blocks;
+    FrArg z = {};
+    std::memcpy(z.v, h_z, 32);
+    hipLaunchKernelGGL(horner_scan_kernel<false>, dim3(n_blocks), dim3(HS_T), 0, c->stream, d_coeffs, n, z, d_vals, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(horner_top_kernel, dim3(1), dim3(1024), 0, c->stream, d_vals, n_blocks, z, d_carry, d_eval);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_eval, 32, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(h_out, c->pinned_u64(ZK_PIN_RES), 32);
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_dense_degree(zkhip_ctx* c, const uint64_t* d_coeffs, size_t n, size_t* h_degree) {
+    if (!c || !h_degree || (n && !d_coeffs)) return ZKHIP_ERR_ARG;
+    *h_degree = 0;
+    if (n == 0) return ZKHIP_OK;
+    ZK_TRY(c->activate());
+    unsigned long long* d_out = (unsigned long long*)c->small_u64(ZK_SMALL_RES);
+    ZK_HIP(c, hipMemsetAsync(d_out, 0, 8, c->stream));
+    hipLaunchKernelGGL(dense_degree_kernel, dim3(mle_grid(n)), dim3(MLE_BLOCK), 0, c->stream, d_coeffs, n, d_out);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_out, 8, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *h_degree = (size_t)c->pinned_u64(ZK_PIN_RES)[0];
+    return ZKHIP_OK;
 }
 
 // scalars (device, n x 4) -> affine SRS points

@@ -39,6 +39,44 @@ class DenseUnivariatePolynomial:
     def __len__(self):
         return self.coefficients.shape[0]
 
+    def is_zero(self):
+        """dense_univariate.rs:41-43: an EMPTY coefficient vector"""
+        return len(self) == 0
+
+    def degree(self):
+        """dense_univariate.rs:199-207: zero leading coefficients do not count; 0 for the zero polynomial"""
+        d = C.c_size_t(0)
+        if len(self):
+            ctx = N.Context.get(self.coefficients.device.index)
+            N.check(N.lib().zkhip_dense_degree(ctx.handle, N.ptr(self.coefficients), C.c_size_t(len(self)), C.byref(d)), "degree")
+        return d.value
+
+    def evaluate(self, point):
+        """dense_univariate.rs:184-196 -> uint64[4] (Montgomery)"""
+        out = np.zeros(4, dtype=np.uint64)
+        if len(self):
+            z = _fr_host(point).reshape(4)
+            ctx = N.Context.get(self.coefficients.device.index)
+            N.check(N.lib().zkhip_dense_evaluate(ctx.handle, N.ptr(self.coefficients), C.c_size_t(len(self)),
+                                                 z.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), "evaluate")
+        return out
+
+    def __mul__(self, other):
+        """Mul (dense_univariate.rs:210-233): schoolbook product of the first degree()+1 coefficients in the reference,
+        the same coefficients through three NTTs here; Mul<F> (:235-251) for a field element."""
+        import torch
+        if isinstance(other, DenseUnivariatePolynomial):
+            if self.is_zero() or other.is_zero():
+                return DenseUnivariatePolynomial(torch.empty((0, 4), dtype=torch.int64, device="cuda"))
+            from zk_cryptography_amd.univariate import UnivariateEval
+            a = DenseUnivariatePolynomial(self.coefficients[: self.degree() + 1])
+            b = DenseUnivariatePolynomial(other.coefficients[: other.degree() + 1])
+            return UnivariateEval.multiply(a, b)
+        scalar = _fr_host(other).reshape(4)
+        if self.is_zero() or not scalar.any():
+            return DenseUnivariatePolynomial(torch.empty((0, 4), dtype=torch.int64, device="cuda"))
+        return DenseUnivariatePolynomial((Multilinear._wrap(self.coefficients) * scalar).evaluations)
+
 
 class TrustedSetup:
     """kzg/src/trusted_setup.rs:9-13, G1 side only, stored affine in HBM: points int64 [n, 12], inf uint8 [n]."""
