@@ -99,7 +99,7 @@ def test_gkr_shape_panics(zk):
         zk.GKRProtocol.prove(circuit, circuit.evaluation(zk.Fr.from_ints(CIRCUIT_2["input"])))
 
 
-@pytest.mark.parametrize("depth", [3, 6])
+@pytest.mark.parametrize("depth", [3, 6, 8])   # 8: wiring tables of 2^23 entries, the largest the dense representation allows in practice
 def test_gkr_random_circuit(zk, ora, depth):   # Circuit::random (circuit.rs:99-122), gkr/benches
     _check_against_oracle(zk, ora, random_circuit(depth), ora.random_fr(2 ** depth, 40 + depth))
 
