@@ -795,10 +795,17 @@ extern "C" int zkhip_sc_finish(zkhip_sc_state* st, uint64_t* h_sum, uint64_t* h_
     zkhip_ctx* c = st->c;
     int rc = ZKHIP_OK;
     if (c->activate() != ZKHIP_OK) rc = ZKHIP_ERR_HIP;
-    if (rc == ZKHIP_OK && h_sum && hipMemcpyAsync(h_sum, st->dev()->sum, 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
-    if (rc == ZKHIP_OK && h_rp && st->round && hipMemcpyAsync(h_rp, st->rp(), 64 * (size_t)st->round, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
-    if (rc == ZKHIP_OK && h_ch && st->round && hipMemcpyAsync(h_ch, st->ch(), 32 * (size_t)st->round, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
+    // one copy of [state | round polynomials | challenges] (contiguous in `small`) into pinned memory
+    const size_t span = 64 + 12 * (size_t)ZK_MAX_ROUNDS;
+    static_assert(ZK_PIN_END - ZK_PIN_PROOF >= 64 + 12 * ZK_MAX_ROUNDS, "pinned proof area too small");
+    uint64_t* pin = c->pinned_u64(ZK_PIN_PROOF);
+    if (rc == ZKHIP_OK && hipMemcpyAsync(pin, st->small, 8 * span, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
+    if (rc == ZKHIP_OK) {
+        if (h_sum) std::memcpy(h_sum, pin + ((const uint64_t*)st->dev()->sum - st->small), 32);
+        if (h_rp && st->round) std::memcpy(h_rp, pin + 64, 64 * (size_t)st->round);
+        if (h_ch && st->round) std::memcpy(h_ch, pin + 64 + 8 * ZK_MAX_ROUNDS, 32 * (size_t)st->round);
+    }
     if (n_rounds) *n_rounds = st->round;
     if (st->A && st->owns_tables) hipFree(st->A);
     if (st->A && !st->owns_tables) c->ws_lent = false;

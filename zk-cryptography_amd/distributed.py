@@ -4,10 +4,11 @@ Only the hot path's two sharding schemes live here:
 
 * ShardedSumcheck -- the evaluation table of N = n_local * world entries is partitioned by the LOW index
   bits (rank g holds entry j*world + g at local index j).  Sumcheck rounds fold variable 0 = the most
-  significant index bit, so every fold is local; per round the ranks exchange 64 bytes each (their partial
-  half sums) with one all-gather and add them locally (modular addition is not an RCCL reduction).
-  The transcript is replicated deterministically.  The last log2(world) rounds run replicated on the
-  all-gathered `world` remaining values.
+  significant index bit, so every fold is local.  Stage form (default): per k rounds the ranks all-gather
+  their 2^k partial block sums (8 KiB for k = 8; modular addition is not an RCCL reduction, so the payload is
+  gathered and added locally), run the k rounds on the summed block sums with a replicated transcript, and
+  fold their shard by k variables locally; once the remaining table fits one workgroup's LDS it is gathered
+  and the last rounds run replicated.  Round form (kept as a fallback): one 64-byte exchange per round.
 * sharded_commit -- (scalars, SRS points) are split the same way; each rank runs a full sub-MSM and the
   `world` partial commitments (104 bytes each) are all-gathered and summed.
 
