@@ -82,7 +82,7 @@ def test_orchestration_over_nccl_world_1(zk, ora):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,log_n", [(2, 14), (4, 13), (8, 20), (2, 22), (8, 12), (4, 5)])
+@pytest.mark.parametrize("world,log_n", [(2, 14), (4, 13), (8, 20), (2, 22), (8, 12), (4, 5), (2, 19)])   # (2, 19): one 9-variable stage
 def test_stage_form_shards_in_lockstep_match_full_prover(zk, ora, world, log_n):
     """Stage form (one exchange per k rounds) with `world` shards driven in lockstep on one GPU."""
     import torch
@@ -125,3 +125,46 @@ def test_stage_form_shards_in_lockstep_match_full_prover(zk, ora, world, log_n):
     for s, rp, ch in outs:
         assert np.array_equal(s, ws) and np.array_equal(rp, wrp) and np.array_equal(ch, wch)
     assert n_exchanges <= 3
+
+
+def test_stage_form_2_27_over_8_shards_matches_single_gpu_prover(zk):
+    """The 8-GPU bench shape (2^24 entries per rank): 9 + 8 variables in two stages, then the gathered 2^10-entry tail --
+    three exchanges.  Eight shards driven in lockstep on one GPU against the single-GPU prover on the full table
+    (itself checked against the oracle up to 2^24)."""
+    import torch
+    from zk_cryptography_amd import distributed as D
+    world, log_n = 8, 27
+    g = torch.Generator(device="cuda").manual_seed(27)
+    full = torch.randint(0, 2 ** 62, (1 << log_n, 4), dtype=torch.int64, device="cuda", generator=g)
+    sc = zk.Sumcheck(zk.Multilinear(full))
+    sc.poly_sum()
+    want, want_ch = sc.prove()
+    engines = [D.HipSumcheckEngine(full[r::world].contiguous()) for r in range(world)]
+    n_local, ks = (1 << log_n) // world, []
+    while True:
+        k = engines[0].stage_plan(world)
+        assert all(e.stage_plan(world) == k for e in engines[1:])
+        if k == 0:
+            break
+        mine = []
+        for e in engines:
+            b = e.new_buffer(1 << k, 4)
+            e.stage_block_sums(b)
+            mine.append(b)
+        gathered = torch.stack(mine).contiguous()
+        for e in engines:
+            e.stage_absorb(gathered, world)
+            e.stage_fold()
+        n_local >>= k
+        ks.append(k)
+    assert ks == [9, 8] and n_local * world == 1024
+    tabs = []
+    for e in engines:
+        t = e.new_buffer(n_local, 4)
+        e.local_table(t)
+        tabs.append(t)
+    rest = torch.stack(tabs).transpose(0, 1).contiguous().view(n_local * world, 4)
+    for e in engines:
+        e.tail(rest, n_local * world)
+        s, rp, ch = e.finish(log_n)
+        assert np.array_equal(s, want.sum) and np.array_equal(rp, want.univariate_poly) and np.array_equal(ch, want_ch)

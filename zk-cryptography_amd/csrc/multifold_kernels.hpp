@@ -21,7 +21,8 @@
 
 namespace zk {
 
-constexpr int MF_MAX_LOGK = 8;
+constexpr int MF_MAX_LOGK = 8;   // variables per fold in the single-GPU plan
+constexpr int MF_CAP_LOGK = 9;   // what the kernels can take; the sharded plan uses 9 where it saves an exchange (2^27 over 8 GPUs)
 
 // per-workgroup sum of a contiguous chunk of `chunk` entries (chunk a power of two, >= MLE_BLOCK)
 static __global__ __launch_bounds__(MLE_BLOCK) void chunk_sums_kernel(const uint64_t* __restrict__ in, uint32_t chunk,
@@ -91,9 +92,10 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
     const uint32_t n = 1u << a.log_n;
     Fr* tree0 = reinterpret_cast<Fr*>(zk_dyn_lds);      // 2n nodes each, canonical values
     Fr* tree1 = tree0 + 2 * n;
+    const uint32_t w_cap = a.weights_out ? (1u << MF_CAP_LOGK) : 0u;   // no weights region when none are asked for
     Fr* w0 = tree1 + 2 * n;                             // weights (Montgomery), ping / pong
-    Fr* w1 = w0 + (1u << MF_MAX_LOGK);
-    Fr* scratch = w1 + (1u << MF_MAX_LOGK);             // MLE_BLOCK
+    Fr* w1 = w0 + w_cap;
+    Fr* scratch = w1 + w_cap;                           // MLE_BLOCK
     Fr* e_sh = scratch + MLE_BLOCK;                     // 2 x 2: to_mont(level-2 differences) of tree0 / tree1
     Fr* r_sh = e_sh + 4;                                // 2: canonical challenge, double-buffered
     // ---- leaves (sums are taken in Montgomery form, then converted once)
@@ -291,8 +293,8 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
         for (uint32_t j = threadIdx.x; j < cnt; j += MLE_BLOCK) store_fr(a.final_out, j, t[cnt + j].to_mont());
     }
 }
-__host__ __device__ constexpr size_t small_lds_bytes(uint32_t log_n) {
-    return ((size_t)4 * ((size_t)1 << log_n) + 2 * (1u << MF_MAX_LOGK) + MLE_BLOCK + 4 + 2) * 32 + (64 + 64 + 16 + 2) * 4;
+__host__ __device__ constexpr size_t small_lds_bytes(uint32_t log_n, bool with_weights) {
+    return ((size_t)4 * ((size_t)1 << log_n) + (with_weights ? 2 * (1u << MF_CAP_LOGK) : 0u) + MLE_BLOCK + 4 + 2) * 32 + (64 + 64 + 16 + 2) * 4;
 }
 
 // Fold weights of k known points (MultilinearTrait::evaluation folds variable 0 repeatedly, evaluation_form.rs:162-175):
@@ -391,7 +393,8 @@ static __global__ __launch_bounds__(1024) void multifold_kernel(const uint64_t* 
                                                                 uint64_t* __restrict__ out,
                                                                 uint64_t* __restrict__ partials) {
     constexpr int TG = 64 / G;                                // term groups inside a wave
-    __shared__ Fr w_lds[1 << MF_MAX_LOGK];
+    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];   // 2^k weights: 32 << k bytes (LDS decides
+    Fr* w_lds = reinterpret_cast<Fr*>(zk_dyn_lds);                                // how many workgroups share a CU: keep it exact)
     __shared__ Fr part[16 * G];
     const uint32_t n_terms = 1u << k;
     for (uint32_t b = threadIdx.x; b < n_terms; b += blockDim.x) w_lds[b] = load_fr(weights, b);

@@ -202,12 +202,12 @@ static int fold_chain(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uin
             hipLaunchKernelGGL(eq_weights_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, pa, (uint32_t)p0, k, d_w);
             if (m >= 8192) {
                 ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m);
-                hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), 0, c->stream, cur, m, k, d_w, dst, d_dummy);
+                hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), (size_t)32 << k, c->stream, cur, m, k, d_w, dst, d_dummy);
             } else {
                 uint32_t waves = 16;
                 while (waves * 4 > (1u << k)) waves >>= 1;
                 ProfScope ps(c, "multifold_small", 32.0 * (double)cn + 32.0 * (double)m);
-                hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), 0, c->stream, cur, m, k, d_w, dst, d_dummy);
+                hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), (size_t)32 << k, c->stream, cur, m, k, d_w, dst, d_dummy);
             }
             ZK_HIP(c, hipGetLastError());
             cur = dst; cn = m; p0 += k; ++stage;
@@ -424,8 +424,10 @@ static inline uint32_t stage_k(size_t cur_n) {
 extern "C" int zkhip_sumcheck_plan_log_blocks(size_t n) { return is_pow2(n) ? (int)stage_k(n) : 0; }
 
 static int launch_small(zkhip_ctx* c, const SmallArgs& a, SumcheckDev* st, uint64_t* d_rp, uint64_t* d_ch) {
-    const size_t lds = small_lds_bytes(a.log_n);
-    ZK_TRY(c->allow_big_lds((const void*)sumcheck_small_kernel, small_lds_bytes(TREE_MAX_LOG)));
+    if (a.weights_out && a.log_n > (uint32_t)MF_CAP_LOGK) return ZKHIP_ERR_SHAPE;
+    const size_t lds = small_lds_bytes(a.log_n, a.weights_out != nullptr);
+    ZK_TRY(c->allow_big_lds((const void*)sumcheck_small_kernel,
+                            std::max(small_lds_bytes(TREE_MAX_LOG, false), small_lds_bytes(MF_CAP_LOGK, true))));
     ProfScope ps(c, "sumcheck_small", 0.0);
     hipLaunchKernelGGL(sumcheck_small_kernel, dim3(1), dim3(MLE_BLOCK), lds, c->stream, a, st, d_rp, d_ch);
     ZK_HIP(c, hipGetLastError());
@@ -436,7 +438,7 @@ static int launch_small(zkhip_ctx* c, const SmallArgs& a, SumcheckDev* st, uint6
 extern "C" int zkhip_mle_block_sums(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint32_t log_blocks,
                                     uint64_t* d_out, uint64_t* h_total) {
     if (!c || !d_evals || !d_out) return ZKHIP_ERR_ARG;
-    if (!is_pow2(n) || log_blocks > MF_MAX_LOGK || ((size_t)1 << log_blocks) > n) return ZKHIP_ERR_SHAPE;
+    if (!is_pow2(n) || log_blocks > MF_CAP_LOGK || ((size_t)1 << log_blocks) > n) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
     const size_t m = n >> log_blocks;
     const uint32_t chunk = (uint32_t)std::min<size_t>(m, 4096);
@@ -481,7 +483,7 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
     // workspace: stage tables (n/4 + n/16 + ...), partial sums, fold weights
     const size_t tab_entries = n / 4 + n / 16 + 64;
     const size_t part_entries = std::max<size_t>(n / 4096, n / 256) + 1024;   // chunk sums of stage 0, per-workgroup sums of stage outputs
-    const size_t w_entries = (size_t)1 << MF_MAX_LOGK;
+    const size_t w_entries = (size_t)1 << MF_CAP_LOGK;
     ZK_TRY(c->reserve_ws((tab_entries + 2 * part_entries + w_entries) * 32));
     uint64_t* tabA = (uint64_t*)c->d_ws;
     uint64_t* tabB = tabA + 4 * (n / 4 + 32);
@@ -530,13 +532,13 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
         if (m >= 8192) {          // streaming shape: 64 outputs per workgroup, 4 waves split the terms
             out_per_wg = 64;
             ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m);
-            hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), 0, c->stream, cur, m, k, d_w, dst, pdst);
+            hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), (size_t)32 << k, c->stream, cur, m, k, d_w, dst, pdst);
         } else {                  // few outputs left: 16 per workgroup, up to 64 lanes share one output
             out_per_wg = 16;
             uint32_t waves = 16;
             while (waves * 4 > (1u << k)) waves >>= 1;   // at least one term per lane group (k >= 3 here)
             ProfScope ps(c, "multifold_small", 32.0 * (double)cn + 32.0 * (double)m);
-            hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), 0, c->stream, cur, m, k, d_w, dst, pdst);
+            hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), (size_t)32 << k, c->stream, cur, m, k, d_w, dst, pdst);
         }
         parts = pdst;
         n_parts = (uint32_t)(m / out_per_wg);
@@ -580,12 +582,12 @@ struct zkhip_sc_state {
     bool owns_tables;        // false: A/B live in the context workspace (the common, single-state case)
     bool uses_cache;         // small + stage buffers borrowed from the context
     // stage form
-    uint64_t* stage_buf;     // [weights 4*256][partials X 4*P][partials Y 4*P][block sums 4*257]
+    uint64_t* stage_buf;     // [weights 4*512][partials X 4*P][partials Y 4*P][block sums 4*513]
     size_t stage_parts_cap;
     uint32_t stage_k_cur, stage_world, stage_idx, n_parts;
     const uint64_t* parts;
     uint64_t* sw() { return stage_buf; }
-    uint64_t* spx() { return stage_buf + 4 * 256; }
+    uint64_t* spx() { return stage_buf + 4 * ((size_t)1 << MF_CAP_LOGK); }
     uint64_t* spy() { return spx() + 4 * stage_parts_cap; }
     uint64_t* sbs() { return spy() + 4 * stage_parts_cap; }
     SumcheckDev* dev() { return (SumcheckDev*)small; }
@@ -614,7 +616,7 @@ extern "C" int zkhip_sc_begin(zkhip_ctx* c, const uint64_t* d_local, size_t n_lo
     } else {
         if (hipMalloc(&st->small, small_u64 * 8) != hipSuccess) { delete st; return ZKHIP_ERR_NOMEM; }
         st->stage_buf = nullptr;
-        if (hipMalloc(&st->stage_buf, (256 + 2 * st->stage_parts_cap + 257 + 8) * 32) != hipSuccess) {
+        if (hipMalloc(&st->stage_buf, (((size_t)1 << MF_CAP_LOGK) + 2 * st->stage_parts_cap + ((size_t)1 << MF_CAP_LOGK) + 1 + 8) * 32) != hipSuccess) {
             hipFree(st->small); delete st; return ZKHIP_ERR_NOMEM;
         }
     }
@@ -640,7 +642,20 @@ extern "C" int zkhip_sc_begin(zkhip_ctx* c, const uint64_t* d_local, size_t n_lo
 // ---- stage form -------------------------------------------------------------------------------------
 extern "C" int zkhip_sc_stage_plan(zkhip_sc_state* st, uint32_t world, uint32_t* k_out) {
     if (!st || !k_out || !is_pow2(world)) return ZKHIP_ERR_ARG;
-    uint32_t k = stage_k(st->cn * world);
+    uint32_t k;
+    if (world == 1) {
+        k = stage_k(st->cn);                    // the single-GPU plan
+    } else {
+        // Every stage costs an exchange: use as few as the kernels allow (<= MF_CAP_LOGK variables per stage, the
+        // gathered tail takes 2^TREE_MAX_LOG entries) and spread the variables evenly over them.
+        const uint32_t lg = log2_exact(st->cn * world);
+        if (lg <= (uint32_t)TREE_MAX_LOG) k = 0;
+        else {
+            const uint32_t need = lg - TREE_MAX_LOG;
+            const uint32_t stages = (need + MF_CAP_LOGK - 1) / MF_CAP_LOGK;
+            k = std::max<uint32_t>((need + stages - 1) / stages, 3);   // a stage folds at least 3 variables (overshooting the tail size is fine)
+        }
+    }
     while (k && (st->cn >> k) < 16) --k;       // the local k-variable fold needs >= 16 outputs per workgroup
     if (k < 3) k = 0;                           // too little left: gather the tables and finish replicated
     st->stage_k_cur = k;
@@ -697,13 +712,13 @@ extern "C" int zkhip_sc_stage_fold(zkhip_sc_state* st) {
     if (m >= 8192) {
         out_per_wg = 64;
         ProfScope ps(c, "multifold", 32.0 * (double)st->cn + 32.0 * (double)m);
-        hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), 0, c->stream, st->cur, m, k, st->sw(), dst, pdst);
+        hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), (size_t)32 << k, c->stream, st->cur, m, k, st->sw(), dst, pdst);
     } else {
         out_per_wg = 16;
         uint32_t waves = 16;
         while (waves * 4 > (1u << k)) waves >>= 1;
         ProfScope ps(c, "multifold_small", 32.0 * (double)st->cn + 32.0 * (double)m);
-        hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), 0, c->stream, st->cur, m, k, st->sw(), dst, pdst);
+        hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), (size_t)32 << k, c->stream, st->cur, m, k, st->sw(), dst, pdst);
     }
     ZK_HIP(c, hipGetLastError());
     st->parts = pdst;

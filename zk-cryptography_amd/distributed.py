@@ -140,11 +140,12 @@ class ShardedSumcheck:
                 absorbed = True
                 e.stage_fold()
                 n_local >>= k
-        else:
-            # round form: one 64-byte exchange per round
+        # round form: one 64-byte exchange per round -- the whole protocol for engines without stages, and the way down
+        # to the tail size where a stage no longer fits (shards of a few entries on many ranks)
+        cap = e.tail_capacity()
+        if n_local * world > cap and n_local > 1:
             send = e.new_buffer(2, 4)
             recv = e.new_buffer(world, 2, 4)
-            cap = e.tail_capacity()
             while n_local * world > cap and n_local > 1:
                 e.local_half_sums(send)
                 _all_gather(self.dist, self.group, recv, send, world)
