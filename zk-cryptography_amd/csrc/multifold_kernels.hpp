@@ -393,9 +393,11 @@ static __global__ __launch_bounds__(1024) void multifold_kernel(const uint64_t* 
                                                                 uint64_t* __restrict__ out,
                                                                 uint64_t* __restrict__ partials) {
     constexpr int TG = 64 / G;                                // term groups inside a wave
-    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];   // 2^k weights: 32 << k bytes (LDS decides
-    Fr* w_lds = reinterpret_cast<Fr*>(zk_dyn_lds);                                // how many workgroups share a CU: keep it exact)
-    __shared__ Fr part[16 * G];
+    // dynamic LDS: 2^k weights, then the (waves - 1) x G partial outputs -- (32 << k) + 32 (waves - 1) G bytes.  LDS decides
+    // how many workgroups share a CU, so it is sized exactly (a fixed 16 KiB for the weights cost the streaming fold 30 %).
+    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
+    Fr* w_lds = reinterpret_cast<Fr*>(zk_dyn_lds);
+    Fr* part = w_lds + (1u << k);
     const uint32_t n_terms = 1u << k;
     for (uint32_t b = threadIdx.x; b < n_terms; b += blockDim.x) w_lds[b] = load_fr(weights, b);
     __syncthreads();

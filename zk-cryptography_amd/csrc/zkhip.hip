@@ -202,12 +202,12 @@ static int fold_chain(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uin
             hipLaunchKernelGGL(eq_weights_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, pa, (uint32_t)p0, k, d_w);
             if (m >= 8192) {
                 ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m);
-                hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), (size_t)32 << k, c->stream, cur, m, k, d_w, dst, d_dummy);
+                hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), ((size_t)32 << k) + 32 * 3 * 64, c->stream, cur, m, k, d_w, dst, d_dummy);
             } else {
                 uint32_t waves = 16;
                 while (waves * 4 > (1u << k)) waves >>= 1;
                 ProfScope ps(c, "multifold_small", 32.0 * (double)cn + 32.0 * (double)m);
-                hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), (size_t)32 << k, c->stream, cur, m, k, d_w, dst, d_dummy);
+                hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), ((size_t)32 << k) + 32 * (size_t)(waves - 1) * 16, c->stream, cur, m, k, d_w, dst, d_dummy);
             }
             ZK_HIP(c, hipGetLastError());
             cur = dst; cn = m; p0 += k; ++stage;
@@ -532,13 +532,13 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
         if (m >= 8192) {          // streaming shape: 64 outputs per workgroup, 4 waves split the terms
             out_per_wg = 64;
             ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m);
-            hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), (size_t)32 << k, c->stream, cur, m, k, d_w, dst, pdst);
+            hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), ((size_t)32 << k) + 32 * 3 * 64, c->stream, cur, m, k, d_w, dst, pdst);
         } else {                  // few outputs left: 16 per workgroup, up to 64 lanes share one output
             out_per_wg = 16;
             uint32_t waves = 16;
             while (waves * 4 > (1u << k)) waves >>= 1;   // at least one term per lane group (k >= 3 here)
             ProfScope ps(c, "multifold_small", 32.0 * (double)cn + 32.0 * (double)m);
-            hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), (size_t)32 << k, c->stream, cur, m, k, d_w, dst, pdst);
+            hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), ((size_t)32 << k) + 32 * (size_t)(waves - 1) * 16, c->stream, cur, m, k, d_w, dst, pdst);
         }
         parts = pdst;
         n_parts = (uint32_t)(m / out_per_wg);
@@ -712,13 +712,13 @@ extern "C" int zkhip_sc_stage_fold(zkhip_sc_state* st) {
     if (m >= 8192) {
         out_per_wg = 64;
         ProfScope ps(c, "multifold", 32.0 * (double)st->cn + 32.0 * (double)m);
-        hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), (size_t)32 << k, c->stream, st->cur, m, k, st->sw(), dst, pdst);
+        hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), ((size_t)32 << k) + 32 * 3 * 64, c->stream, st->cur, m, k, st->sw(), dst, pdst);
     } else {
         out_per_wg = 16;
         uint32_t waves = 16;
         while (waves * 4 > (1u << k)) waves >>= 1;
         ProfScope ps(c, "multifold_small", 32.0 * (double)st->cn + 32.0 * (double)m);
-        hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), (size_t)32 << k, c->stream, st->cur, m, k, st->sw(), dst, pdst);
+        hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), ((size_t)32 << k) + 32 * (size_t)(waves - 1) * 16, c->stream, st->cur, m, k, st->sw(), dst, pdst);
     }
     ZK_HIP(c, hipGetLastError());
     st->parts = pdst;
