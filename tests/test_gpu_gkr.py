@@ -132,3 +132,24 @@ def test_succint_gkr_prove(zk, ora, layers, inp, tau):
         for got, want in zip(opening.proofs, want_proofs):
             a = ora.g1_to_affine(want)
             assert got.infinity == bool(a[12]) and (got.infinity or np.array_equal(got.xy, a[:12]))
+
+
+@pytest.mark.parametrize("depth", [10, 11])
+def test_gkr_beyond_the_dense_wiring_tables(zk, ora, depth):
+    """zkhip_gkr_prove never builds the dense 2^(3l+2)-entry wiring tables (a depth-11 circuit would need two of 2^32
+    entries): layers beyond what the reference's representation holds are provable.  No dense prover exists to compare
+    with at this depth; the proof must pass the restated verifier (whose own checks of the wiring stop at layer one, as
+    in gkr/src/protocol.rs:119-196) and a wrong input must fail it."""
+    layers = random_circuit(depth)
+    inp = ora.random_fr(2 ** depth, 60 + depth)
+    circuit = zk.Circuit.from_tuples(layers)
+    ev = circuit.evaluation(inp)
+    want_ev = ora.circuit_evaluation(layers, inp)
+    assert all(np.array_equal(_host(a), b) for a, b in zip(ev, want_ev))
+    proof = zk.GKRProtocol.prove(circuit, ev)
+    assert len(proof.sumcheck_proofs) == depth and len(proof.sumcheck_proofs[-1].round_polys) == 2 * depth
+    op = _to_oracle_proof(zk, ora, proof)
+    assert ora.gkr_verify(layers, inp, op)
+    bad = inp.copy()
+    bad[5, 0] ^= np.uint64(1)
+    assert not ora.gkr_verify(layers, bad, op)
