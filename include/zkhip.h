@@ -112,7 +112,10 @@ int zkhip_circuit_layer_eval(zkhip_ctx *ctx, const uint64_t *d_in, size_t n_in, 
 int zkhip_circuit_add_mult_mle(zkhip_ctx *ctx, const uint8_t *h_gate_type, const uint32_t *h_in0, const uint32_t *h_in1,
                                size_t n_gates, uint32_t layer_index, uint64_t *d_add, uint64_t *d_mul);
 
-/* GKRProtocol::prove (gkr/src/protocol.rs:21-117 with gkr/src/utils.rs:8-56) in one call, every table in HBM.
+/* GKRProtocol::prove (gkr/src/protocol.rs:21-117 with gkr/src/utils.rs:8-56) in one call, every table in HBM.  The dense
+ * wiring tables of Circuit::add_mult_mle are not built: their fold over the gate variables is written directly as the
+ * (b, c) tables the layer's sumcheck runs on (same values), so n_layers <= 14 is bounded by those 2^(2 n_layers)-entry
+ * tables rather than by 2^(3 l + 2)-entry ones.
  *   circuit    : n_layers layers, layer l with h_n_gates[l] gates (layer 0 = output); gate arrays concatenated
  *   evaluation : h_layer_ptrs[k], k = 0..n_layers, DEVICE tables as Circuit::evaluation returns them (output first,
  *                input last), h_layer_len[k] entries each.  The reference's shape panics (Multilinear::new on a
