@@ -60,6 +60,19 @@ struct zkhip_ctx {
     size_t ws_bytes = 0;
     void* d_aux = nullptr;      // second grow-only buffer for entry points that call others which own d_ws (kzg_open)
     size_t aux_bytes = 0;
+    // two pinned result buffers + events for commits whose host epilogue is deferred (msm_enqueue / msm_finish)
+    void* msm_pin[2] = {nullptr, nullptr};
+    size_t msm_pin_bytes[2] = {0, 0};
+    hipEvent_t msm_ev[2] = {nullptr, nullptr};
+    int reserve_msm_pin(int slot, size_t bytes) {
+        if (!msm_ev[slot] && hipEventCreateWithFlags(&msm_ev[slot], hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
+        if (bytes <= msm_pin_bytes[slot]) return ZKHIP_OK;
+        if (msm_pin[slot]) hipHostFree(msm_pin[slot]);
+        msm_pin[slot] = nullptr; msm_pin_bytes[slot] = 0;
+        if (hipHostMalloc(&msm_pin[slot], bytes, hipHostMallocDefault) != hipSuccess) return ZKHIP_ERR_NOMEM;
+        msm_pin_bytes[slot] = bytes;
+        return ZKHIP_OK;
+    }
     bool ws_lent = false;       // the workspace currently backs a split-phase prover state
     // one cached set of small split-phase buffers, so that a steady stream of sharded proves never allocates
     void* sc_small = nullptr; void* sc_stage = nullptr; size_t sc_stage_cap = 0; bool sc_lent = false;

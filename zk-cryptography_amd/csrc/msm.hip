@@ -74,9 +74,19 @@ static MsmPlan msm_plan_table(size_t stride) {
 
 // d_table (nullable): shifted-SRS table in the internal layout, entry w * table_stride + i = 2^(20 w) * point i; then
 // d_points_xy is not read and there is exactly one problem.
-static int msm_commit_multi(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, const uint64_t* d_scalars, size_t n,
-                            const MsmProblems& pr, uint64_t* h_out_xy, uint8_t* h_out_inf, const uint32_t* d_table = nullptr,
-                            size_t table_stride = 0) {
+// A commit in two halves, so that a caller with several commits in a row (MultilinearKZG::open) can run the host epilogue
+// of one while the GPU works on the next: msm_enqueue launches everything and the copy of the (window, term) points into
+// pinned slot `slot` (workspace from byte offset ws_off; *ws_used = what it occupies), msm_finish waits for that copy
+// and runs the epilogue.
+struct MsmPending {
+    MsmPlan pl;
+    MsmProblems pr;
+    size_t n_out = 0;
+    int slot = 0;
+};
+static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, const uint64_t* d_scalars, size_t n,
+                       const MsmProblems& pr, const uint32_t* d_table, size_t table_stride, size_t ws_off, int slot, MsmPending* pend,
+                       size_t* ws_used) {
     size_t max_n = 0;
     for (uint32_t j = 0; j < pr.n; ++j) max_n = std::max<size_t>(max_n, pr.off[j + 1] - pr.off[j]);
     const MsmPlan pl = d_table ? msm_plan_table(table_stride) : msm_plan(max_n, pr.n);
@@ -122,8 +132,9 @@ static int msm_commit_multi(zkhip_ctx* c, const uint64_t* d_points_xy, const uin
     const size_t o_rec = o_ovf + al(sizeof(MsmOverflow));
     const size_t o_part = o_rec + al(MSM_HEAVY_LEVELS * rec_cap * sizeof(MsmHeavyRec));
     const size_t total = o_part + al(slots_cap * 256);
-    ZK_TRY(c->reserve_ws(total));
-    char* ws = (char*)c->d_ws;
+    if (ws_used) *ws_used = total;
+    ZK_TRY(c->reserve_ws(ws_off + total));
+    char* ws = (char*)c->d_ws + ws_off;
     uint32_t* counts = (uint32_t*)(ws + o_counts);
     uint32_t* offsets = (uint32_t*)(ws + o_offsets);
     uint32_t* sorted = (uint32_t*)(ws + o_sorted);
@@ -197,9 +208,20 @@ static int msm_commit_multi(zkhip_ctx* c, const uint64_t* d_points_xy, const uin
         }
     }
     ZK_HIP(c, hipGetLastError());
-    std::vector<uint64_t> h_terms(n_out * 24);
-    ZK_HIP(c, hipMemcpyAsync(h_terms.data(), terms, n_out * 192, hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    ZK_TRY(c->reserve_msm_pin(slot, n_out * 192));
+    ZK_HIP(c, hipMemcpyAsync(c->msm_pin[slot], terms, n_out * 192, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipEventRecord(c->msm_ev[slot], c->stream));
+    pend->pl = pl;
+    pend->pr = pr;
+    pend->n_out = n_out;
+    pend->slot = slot;
+    return ZKHIP_OK;
+}
+static int msm_finish(zkhip_ctx* c, const MsmPending& pend, uint64_t* h_out_xy, uint8_t* h_out_inf) {
+    ZK_HIP(c, hipEventSynchronize(c->msm_ev[pend.slot]));
+    const MsmPlan& pl = pend.pl;
+    const MsmProblems& pr = pend.pr;
+    const uint64_t* h_terms = (const uint64_t*)c->msm_pin[pend.slot];
     // host epilogue, per problem: sum over (window w, term t) of 2^exp * point
     const size_t per_problem = (size_t)(pl.shared ? 1 : pl.w_per) * pl.n_terms;
     auto finish = [&](uint32_t j) {
@@ -224,6 +246,13 @@ static int msm_commit_multi(zkhip_ctx* c, const uint64_t* d_points_xy, const uin
         for (auto& th : pool) th.join();
     }
     return ZKHIP_OK;
+}
+static int msm_commit_multi(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, const uint64_t* d_scalars, size_t n,
+                            const MsmProblems& pr, uint64_t* h_out_xy, uint8_t* h_out_inf, const uint32_t* d_table = nullptr,
+                            size_t table_stride = 0) {
+    MsmPending pend;
+    ZK_TRY(msm_enqueue(c, d_points_xy, d_points_inf, d_scalars, n, pr, d_table, table_stride, 0, 0, &pend, nullptr));
+    return msm_finish(c, pend, h_out_xy, h_out_inf);
 }
 static int msm_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, const uint64_t* d_scalars, size_t n,
                       uint64_t* h_out_xy, uint8_t* h_out_inf) {
@@ -393,6 +422,18 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
     MsmProblems batch = {};
     size_t batch_first_off = 0;
     uint32_t batch_first_round = 0;
+    // The large rounds alternate between two halves of the workspace and two pinned result slots: the host epilogue of
+    // round i - 1 (~0.25 ms of serial point arithmetic) runs while the GPU works on round i.
+    MsmPending pend[2];
+    int pend_round[2] = {-1, -1};
+    size_t slot_bytes = 0;
+    uint32_t n_enq = 0;
+    auto finish_slot = [&](int sl) -> int {
+        if (pend_round[sl] < 0) return ZKHIP_OK;
+        const int r = pend_round[sl];
+        pend_round[sl] = -1;
+        return msm_finish(c, pend[sl], h_proofs_xy + 12 * (size_t)r, h_proofs_inf + r);
+    };
     for (uint32_t i = 0; i < n_vars; ++i) {
         FrArg z = {};
         std::memcpy(z.v, h_points + 4 * (size_t)i, 32);
@@ -401,7 +442,18 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
         ZK_HIP(c, hipGetLastError());
         const size_t h = cn / 2;   // |q_i| = |S_i|
         if (h > OPEN_BATCH_MAX) {
-            ZK_TRY(msm_commit(c, d_folded_xy + 12 * lvl_off, d_folded_inf + lvl_off, d_q + 4 * lvl_off, h, h_proofs_xy + 12 * (size_t)i, h_proofs_inf + i));
+            const int sl = (int)(n_enq & 1);
+            ZK_TRY(finish_slot(sl));                       // round i - 2 used this half of the workspace
+            MsmProblems one = {};
+            one.n = 1;
+            one.off[1] = (uint32_t)h;
+            size_t used = 0;
+            ZK_TRY(msm_enqueue(c, d_folded_xy + 12 * lvl_off, d_folded_inf + lvl_off, d_q + 4 * lvl_off, h, one, nullptr, 0,
+                               sl ? slot_bytes : 0, sl, &pend[sl], &used));
+            if (n_enq == 0) slot_bytes = (used + 4095) & ~(size_t)4095;   // the first round is the largest: later ones fit behind it
+            pend_round[sl] = (int)i;
+            ++n_enq;
+            ZK_TRY(finish_slot(sl ^ 1));                   // the previous round's epilogue, overlapped with this round's kernels
         } else {
             if (batch.n == 0) { batch_first_off = lvl_off; batch_first_round = i; }
             batch.off[batch.n] = (uint32_t)(lvl_off - batch_first_off);
@@ -411,9 +463,18 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
         cur = rem;
         cn = h;
     }
-    if (batch.n)
-        ZK_TRY(msm_commit_multi(c, d_folded_xy + 12 * batch_first_off, d_folded_inf + batch_first_off, d_q + 4 * batch_first_off,
-                                lvl_off - batch_first_off, batch, h_proofs_xy + 12 * (size_t)batch_first_round, h_proofs_inf + batch_first_round));
+    if (batch.n) {
+        const int sl = (int)(n_enq & 1);
+        ZK_TRY(finish_slot(sl));
+        MsmPending bp;
+        // its own region behind the two halves: the other half may still be in use by the last large round
+        ZK_TRY(msm_enqueue(c, d_folded_xy + 12 * batch_first_off, d_folded_inf + batch_first_off, d_q + 4 * batch_first_off,
+                           lvl_off - batch_first_off, batch, nullptr, 0, 2 * slot_bytes, sl, &bp, nullptr));
+        ZK_TRY(finish_slot(sl ^ 1));
+        ZK_TRY(msm_finish(c, bp, h_proofs_xy + 12 * (size_t)batch_first_round, h_proofs_inf + batch_first_round));
+    }
+    ZK_TRY(finish_slot(0));
+    ZK_TRY(finish_slot(1));
     // the last remainder is poly(z): `evaluation`, and what the reference checks it against (:84-86)
     ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), cur, 32, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
