@@ -17,7 +17,11 @@
 //                by workgroup tree reductions.  The window total is sum_s A_s + L * sum_k 2^k T_k.
 //   7. the (#windows x #terms) points, each tagged with its power-of-two weight, go to the host, which runs
 //      the final 255-step double-and-add chain (inherently serial; a few hundred group operations).
-// MSM is integer-ALU bound (about 10 Fq products of ~900 instructions per added point), not HBM bound.
+// Variants of the same passes: several independent problems in one pass (MsmProblems: problem j owns its own
+// "virtual windows" of the bucket array -- the small rounds of MultilinearKZG::open), and the shifted-SRS table
+// (MsmPlan::shared: the points 2^(c w) P are read from a table built once per SRS, so the digits of all windows share
+// ONE bucket set and one bucket reduction).
+// MSM is integer-ALU bound (10 Fq products of ~500 instructions per added point, VALU issue saturated), not HBM bound.
 #pragma once
 #include "g1.hpp"
 #include "g1u.hpp"
