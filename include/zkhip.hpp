@@ -140,6 +140,21 @@ class Multilinear {
     }
     Multilinear add_distinct(const Multilinear& rhs) const { return distinct(rhs, false); }   // :28-39
     Multilinear mul_distinct(const Multilinear& rhs) const { return distinct(rhs, true); }    // :41-52
+    Multilinear add_to_front(size_t variable_length) const {                                  // :86-96
+        Multilinear out(n_ * ((size_t)2 << variable_length), n_vars + variable_length + 1);
+        check(zkhip_mle_add_to_front(ctx(), device(), n_, (uint32_t)variable_length, out.dev_->u64()), "add_to_front");
+        return out;
+    }
+    Multilinear add_to_back(size_t variable_length) const {                                   // :98-110
+        Multilinear out(n_ << variable_length, n_vars + variable_length);
+        check(zkhip_mle_add_to_back(ctx(), device(), n_, (uint32_t)variable_length, out.dev_->u64()), "add_to_back");
+        return out;
+    }
+    static Multilinear duplicate_evaluation(const std::vector<Fr>& value) {                   // :112-119
+        std::vector<Fr> v(value);
+        v.insert(v.end(), value.begin(), value.end());
+        return Multilinear(v);
+    }
     std::vector<uint8_t> to_bytes() const {   // :54-62
         DeviceBuffer b(32 * n_);
         check(zkhip_mle_to_bytes(ctx(), device(), n_, b.u8()), "to_bytes");
@@ -304,6 +319,16 @@ struct DenseUnivariatePolynomial {                                              
     explicit DenseUnivariatePolynomial(const std::vector<Fr>& c) : n(c.size()), dev(std::make_shared<DeviceBuffer>(32 * (c.size() ? c.size() : 1))) { if (n) dev->upload(c.data(), 32 * n); }
     DenseUnivariatePolynomial(size_t n_, std::shared_ptr<DeviceBuffer> d) : n(n_), dev(std::move(d)) {}
     std::vector<Fr> coefficients() const { std::vector<Fr> v(n); if (n) dev->download(v.data(), 32 * n); return v; }
+    Fr evaluate(const Fr& point) const {                                                       // :184-196
+        Fr out;
+        check(zkhip_dense_evaluate(ctx(), n ? dev->u64() : nullptr, n, point.l, out.l), "dense_evaluate");
+        return out;
+    }
+    size_t degree() const {                                                                    // :199-207
+        size_t d = 0;
+        check(zkhip_dense_degree(ctx(), n ? dev->u64() : nullptr, n, &d), "dense_degree");
+        return d;
+    }
     size_t n;
     std::shared_ptr<DeviceBuffer> dev;
 };

@@ -58,6 +58,16 @@ TEST(test_split_poly_into_two_and_sum_each_part) {
     EXPECT(Multilinear(F({0, 0, 2, 7, 3, 3, 6, 11})).split_poly_into_two_and_sum_each_part() == Multilinear(F({9, 23})));
 }
 TEST(test_sum_over_boolean_hypercube) { EXPECT(Multilinear(F({1, 2, 3, 4, 5, 6, 7, 8})).sum_over_the_boolean_hypercube() == Fr::from(36)); }
+TEST(test_add_to_front_and_back) {   // evaluation_form.rs:465-507, :548-556
+    EXPECT(Multilinear(F({0, 0, 4, 4})).add_to_front(0) == Multilinear(F({0, 0, 4, 4, 0, 0, 4, 4})));
+    EXPECT(Multilinear(F({0, 4})).add_to_front(1) == Multilinear(F({0, 4, 0, 4, 0, 4, 0, 4})));
+    EXPECT(Multilinear(F({0, 0, 4, 4})).add_to_back(1) == Multilinear(F({0, 0, 0, 0, 4, 4, 4, 4})));
+    EXPECT(Multilinear::duplicate_evaluation(F({11})) == Multilinear(F({11, 11})));
+}
+TEST(test_dense_polynomial_evaluation) {   // dense_univariate.rs:425-433, :199-207
+    EXPECT(DenseUnivariatePolynomial(F({5, 2, 4})).evaluate(Fr::from(2)) == Fr::from(25));
+    EXPECT(DenseUnivariatePolynomial(F({1, 3, 0, 0})).degree() == 1 && DenseUnivariatePolynomial(F({0, 0})).degree() == 0);
+}
 TEST(test_poly_subtraction) {
     EXPECT(Multilinear(F({0, 0, 0, 5, 4, 4, 7, 12})) - Multilinear(F({0, 0, 0, 2, 0, 0, 1, 3})) == Multilinear(F({0, 0, 0, 3, 4, 4, 6, 9})));
 }
