@@ -25,10 +25,19 @@ static void launch_product_sum(zkhip_ctx* c, const TablePtrs& tp, size_t n, int 
 template <int K>
 static void launch_round(zkhip_ctx* c, bool fold, const TablePtrs& tp, size_t n, const uint64_t* r, uint32_t rec,
                          uint32_t rec_off, uint64_t* partials, int grid) {
+    if (tp.lin_in) {   // term = product + additive table: instantiated for the shapes that occur (K <= 2, gkr.hip)
+        if constexpr (K <= 2) {
+            if (fold)
+                hipLaunchKernelGGL((composed_round_kernel<K, true, true>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
+            else
+                hipLaunchKernelGGL((composed_round_kernel<K, false, true>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
+        }
+        return;
+    }
     if (fold)
-        hipLaunchKernelGGL((composed_round_kernel<K, true>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
+        hipLaunchKernelGGL((composed_round_kernel<K, true, false>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
     else
-        hipLaunchKernelGGL((composed_round_kernel<K, false>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
+        hipLaunchKernelGGL((composed_round_kernel<K, false, false>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
 }
 #define ZK_DISPATCH_K(k, CALL)                 \
     switch (k) {                               \
@@ -74,16 +83,20 @@ extern "C" int zkhip_multi_composed_sum(zkhip_ctx* c, const uint64_t* const* ptr
 }
 
 // shared driver.  multi = 0: ComposedSumcheck (one term).  first_mode: see close_round.
+// lin_ptrs (nullable): per term an optional additive table (term = product + table; K <= 2).  cont: continue the
+// transcript the previous call left in the context (its rounds are the next rounds of the same sumcheck) instead of
+// starting one; every call leaves its final transcript state there.
 static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes, uint32_t n_terms,
                                size_t n, int multi, const uint64_t* h_sum, int partial, uint32_t* h_lens,
-                               uint64_t* h_round_polys, uint64_t* h_challenges) {
+                               uint64_t* h_round_polys, uint64_t* h_challenges, const uint64_t* const* lin_ptrs = nullptr,
+                               int cont = 0) {
     if (!c || !ptrs || !term_sizes) return ZKHIP_ERR_ARG;
     if (n_terms == 0 || n_terms > CMP_MAX_TERMS) return ZKHIP_ERR_ARG;
     if (!is_pow2(n)) return ZKHIP_ERR_SHAPE;
     const uint32_t n_vars = log2_exact(n);
     if (n_vars > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
     if (n_vars == 0) return ZKHIP_OK;   // `for _ in 0..n_vars` never runs
-    if (!h_round_polys || !h_challenges || (multi && (!h_sum || !h_lens))) return ZKHIP_ERR_ARG;
+    if (!h_round_polys || !h_challenges || (multi && ((!h_sum && !cont) || !h_lens))) return ZKHIP_ERR_ARG;
     ZK_TRY(c->activate());
     ComposedMeta meta = {};
     meta.n_terms = n_terms;
@@ -98,9 +111,21 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
     }
     meta.rec = rec;
     if (rec > CMP_MAX_REC) return ZKHIP_ERR_ARG;
+    // additive tables: numbered after the product tables
+    uint32_t n_lin = 0;
+    std::vector<const uint64_t*> lin_cur(n_terms, nullptr);
+    for (uint32_t p = 0; p < n_terms; ++p) {
+        meta.lin_tab[p] = ~0u;
+        if (lin_ptrs && lin_ptrs[p]) {
+            if (term_sizes[p] > 2) return ZKHIP_ERR_ARG;
+            lin_cur[p] = lin_ptrs[p];
+            meta.lin_tab[p] = total + n_lin++;
+        }
+    }
+    const uint32_t total_all = total + n_lin;
     // workspace: per table a ping (n/2) and a pong (n/4) buffer, then the state
     const size_t per_table = (n / 2 + n / 4 + 2) * 32;
-    const size_t state_off = (total * per_table + 255) & ~(size_t)255;
+    const size_t state_off = (total_all * per_table + 255) & ~(size_t)255;
     const size_t bytes_off = state_off + ((sizeof(ComposedDev) + 255) & ~(size_t)255);
     ZK_TRY(c->reserve_ws(bytes_off + (multi && !partial ? 32 * n : 0)));
     char* ws = (char*)c->d_ws;
@@ -110,6 +135,11 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
     uint64_t* d_ch = c->small_u64(ZK_SMALL_CHALLENGES);
 
     uint32_t first = 1;
+    Sha256State* saved = (Sha256State*)c->small_u64(ZK_SMALL_STATE);   // transcript handed from call to call (cont)
+    if (cont) {
+        ZK_HIP(c, hipMemcpyAsync(&st->transcript, saved, sizeof(Sha256State), hipMemcpyDeviceToDevice, c->stream));
+        first = 0;
+    }
     if (multi) {
         // interpolation matrices for the degrees in use
         std::vector<uint64_t> mats((CMP_MAX_K + 1) * (CMP_MAX_K + 1) * (CMP_MAX_K + 1) * 4, 0);
@@ -119,8 +149,8 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
             std::memcpy(&mats[(size_t)d * (CMP_MAX_K + 1) * (CMP_MAX_K + 1) * 4], m.data(), m.size() * 32);
         }
         ZK_HIP(c, hipMemcpyAsync(st->interp, mats.data(), mats.size() * 8, hipMemcpyHostToDevice, c->stream));
-        ZK_HIP(c, hipMemcpyAsync(st->sum, h_sum, 32, hipMemcpyHostToDevice, c->stream));
-        if (!partial) {
+        if (h_sum) ZK_HIP(c, hipMemcpyAsync(st->sum, h_sum, 32, hipMemcpyHostToDevice, c->stream));
+        if (!partial && !cont) {
             // prove(): transcript.commit(&composed_poly_to_bytes(&poly)) first (multi_composed_sumcheck.rs:51-53).
             // The GPU produces the canonical big-endian bytes, the host hashes the (inherently sequential) stream.
             uint8_t* d_bytes = (uint8_t*)(ws + bytes_off);
@@ -150,7 +180,7 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
     // Rounds on tables too large for one workgroup's LDS: one launch per term (fold at the previous challenge + the
     // round's sums) and one that closes the round.  From the round whose tables fit the LDS on, one launch finishes
     // the proof.
-    const uint32_t tail_len = composed_tail_len(total);
+    const uint32_t tail_len = composed_tail_len(total_all);
     std::vector<const uint64_t*> cur(ptrs, ptrs + total);
     size_t cn = n;   // entries of the tables `cur` points to
     for (uint32_t round = 0; round < n_vars; ++round) {
@@ -161,9 +191,10 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
         if (after <= tail_len) {
             TailTables tt = {};
             for (uint32_t q = 0; q < total; ++q) tt.in[q] = cur[q];
+            for (uint32_t p = 0; p < n_terms; ++p) if (lin_cur[p]) tt.in[meta.lin_tab[p]] = lin_cur[p];
             ZK_TRY(c->allow_big_lds((const void*)composed_tail_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
             ProfScope ps(c, "composed_tail", 0.0);
-            hipLaunchKernelGGL(composed_tail_kernel, dim3(1), dim3(CMP_TAIL_BLOCK), total * after * 32, c->stream, tt, total, (uint32_t)after,
+            hipLaunchKernelGGL(composed_tail_kernel, dim3(1), dim3(CMP_TAIL_BLOCK), total_all * after * 32, c->stream, tt, total_all, (uint32_t)after,
                                fold ? 1u : 0u, fold ? d_ch + 4 * (round - 1) : nullptr, ca, n_vars - round);
             break;
         }
@@ -179,11 +210,17 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
                 char* base = ws + (size_t)(off + q) * per_table;
                 tp.out[q] = (uint64_t*)((round & 1) ? base : base + (n / 2 + 1) * 32);
             }
+            if (lin_cur[p]) {
+                tp.lin_in = lin_cur[p];
+                char* base = ws + (size_t)meta.lin_tab[p] * per_table;
+                tp.lin_out = (uint64_t*)((round & 1) ? base : base + (n / 2 + 1) * 32);
+            }
             ProfScope ps(c, "composed_round", 0.0);
 #define CALL(KK) launch_round<KK>(c, fold, tp, cn, fold ? d_ch + 4 * (round - 1) : nullptr, meta.rec, meta.rec_off[p], d_partials, grid)
             ZK_DISPATCH_K(term_sizes[p], CALL)
 #undef CALL
             if (fold) for (uint32_t q = 0; q < term_sizes[p]; ++q) cur[off + q] = tp.out[q];
+            if (fold && lin_cur[p]) lin_cur[p] = tp.lin_out;
             off += term_sizes[p];
         }
         if (fold) cn /= 2;
@@ -191,6 +228,7 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
         first = 0;
     }
     ZK_HIP(c, hipGetLastError());
+    if (multi) ZK_HIP(c, hipMemcpyAsync(saved, &st->transcript, sizeof(Sha256State), hipMemcpyDeviceToDevice, c->stream));
     std::vector<uint64_t> h_rp(64 * (size_t)n_vars);
     ZK_HIP(c, hipMemcpyAsync(h_rp.data(), d_rp, 64 * 8 * (size_t)n_vars, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipMemcpyAsync(h_challenges, d_ch, 32 * (size_t)n_vars, hipMemcpyDeviceToHost, c->stream));
@@ -204,6 +242,13 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
         }
     }
     return ZKHIP_OK;
+}
+
+// internal entry for gkr.hip (same shared object; not part of the C ABI)
+int zk_multi_composed_prove_ex(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes, const uint64_t* const* lin_ptrs,
+                               uint32_t n_terms, size_t n, const uint64_t* h_sum, int cont, uint32_t* h_lens, uint64_t* h_round_polys,
+                               uint64_t* h_challenges) {
+    return composed_prove_impl(c, ptrs, term_sizes, n_terms, n, 1, h_sum, 1, h_lens, h_round_polys, h_challenges, lin_ptrs, cont);
 }
 
 extern "C" int zkhip_composed_prove(zkhip_ctx* c, const uint64_t* const* ptrs, uint32_t k, size_t n, uint64_t* h_round_polys,

@@ -26,7 +26,22 @@ constexpr int CMP_MAX_BLOCKS = 9;   // SHA-256 blocks of one round: <= 15 pendin
 struct TablePtrs {
     const uint64_t* in[CMP_MAX_K];
     uint64_t* out[CMP_MAX_K];
+    // optional additive table of the term (term = prod_k table_k + lin): not a reference shape by itself -- the GKR layer
+    // prover sums its c variables out first, which leaves terms of this form over the b variables (gkr.hip)
+    const uint64_t* lin_in;
+    uint64_t* lin_out;
 };
+// evaluations at t = 0..K of lo + t (hi - lo), added into sums[0..K]
+template <int K>
+__device__ __forceinline__ void accumulate_linear_evals(const Fr& lo, const Fr& hi, Fr (&sums)[K + 1]) {
+    Fr v = lo;
+    const Fr d = hi - lo;
+#pragma unroll
+    for (int t = 0; t <= K; ++t) {
+        sums[t] = sums[t] + v;
+        if (t < K) v = v + d;
+    }
+}
 
 // evaluations at t = 0..K of prod_k (lo_k + t*(hi_k - lo_k)), added into sums[0..K]
 template <int K>
@@ -53,6 +68,7 @@ struct ComposedMeta {
     uint32_t k[CMP_MAX_TERMS];         // tables per term (= degree of the term's round polynomial)
     uint32_t rec_off[CMP_MAX_TERMS];   // offset of the term's K+1 sums inside a workgroup record
     uint32_t rec;                      // sums per record
+    uint32_t lin_tab[CMP_MAX_TERMS];   // tail kernel: index of the term's additive table among the LDS tables, or ~0u
     uint32_t multi;                    // 0: ComposedSumcheck transcript (raw evaluations), 1: multi-composed (sparse coefficients)
 };
 // Device-resident state.  interp[d] is the (d+1)x(d+1) matrix taking evaluations at x = 0..d to coefficients
@@ -200,7 +216,7 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
 // Per workgroup, the K+1 sums go to partials[(block * rec + rec_off + t)]; composed_close_kernel sums the records
 // and closes the round.  (Closing inside this kernel by the last workgroup to finish was measured and dropped: on
 // eight XCDs with private L2s the agent-scope release every workgroup then needs costs more than a launch.)
-template <int K, bool FOLD>
+template <int K, bool FOLD, bool LIN>
 static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TablePtrs tp, size_t n, const uint64_t* __restrict__ r_ptr,
                                                                    uint32_t rec, uint32_t rec_off,
                                                                    uint64_t* __restrict__ partials) {
@@ -216,6 +232,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TableP
             if (blockIdx.x == 0 && threadIdx.x == 0) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) store_fr(tp.out[k], 0, fold_pair(load_fr(tp.in[k], 0), load_fr(tp.in[k], 1), r));
+                if (LIN) store_fr(tp.lin_out, 0, fold_pair(load_fr(tp.lin_in, 0), load_fr(tp.lin_in, 1), r));
             }
         }
         for (size_t j = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; j < q; j += stride) {
@@ -230,6 +247,13 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TableP
                 store_fr(tp.out[k], j + q, hi[k]);
             }
             accumulate_round_evals<K>(lo, hi, sums);
+            if (LIN) {
+                const Fr llo = fold_pair(load_fr(tp.lin_in, j), load_fr(tp.lin_in, j + h), r);
+                const Fr lhi = fold_pair(load_fr(tp.lin_in, j + q), load_fr(tp.lin_in, j + h + q), r);
+                store_fr(tp.lin_out, j, llo);
+                store_fr(tp.lin_out, j + q, lhi);
+                accumulate_linear_evals<K>(llo, lhi, sums);
+            }
         }
     } else {
         const size_t h = n >> 1;
@@ -238,6 +262,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TableP
 #pragma unroll
             for (int k = 0; k < K; ++k) { lo[k] = load_fr(tp.in[k], j); hi[k] = load_fr(tp.in[k], j + h); }
             accumulate_round_evals<K>(lo, hi, sums);
+            if (LIN) accumulate_linear_evals<K>(load_fr(tp.lin_in, j), load_fr(tp.lin_in, j + h), sums);
         }
     }
 #pragma unroll
@@ -301,7 +326,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void finish_sum_kernel(const uint
 constexpr int CMP_TAIL_BLOCK = 512;
 constexpr uint32_t CMP_TAIL_ENTRIES = 4096;
 struct TailTables {
-    const uint64_t* in[CMP_MAX_TERMS * CMP_MAX_K];
+    const uint64_t* in[CMP_MAX_TERMS * (CMP_MAX_K + 1)];   // the terms' product tables, then the additive tables
 };
 inline uint32_t composed_tail_len(uint32_t total_tables) {   // entries per table the tail can hold
     uint32_t m = 1;
@@ -323,8 +348,8 @@ __device__ __forceinline__ void lds_store_fr(uint32_t* base, uint32_t idx, const
 }
 // one term: per-wave sums of the K+1 evaluations over the pairs (j, j + cn/2) of its K tables (table k at tab + k * m)
 template <int K>
-__device__ __forceinline__ void tail_term_sums(const uint32_t* tab, uint32_t m, uint32_t cn, Fr* wave_part /* [rec] of this wave */,
-                                               uint32_t rec_off) {
+__device__ __forceinline__ void tail_term_sums(const uint32_t* tab, const uint32_t* lin /* the term's additive table or nullptr */,
+                                               uint32_t m, uint32_t cn, Fr* wave_part /* [rec] of this wave */, uint32_t rec_off) {
     Fr sums[K + 1];
 #pragma unroll
     for (int t = 0; t <= K; ++t) sums[t] = Fr::zero();
@@ -335,6 +360,7 @@ __device__ __forceinline__ void tail_term_sums(const uint32_t* tab, uint32_t m, 
 #pragma unroll
             for (int k = 0; k < K; ++k) { lo[k] = lds_load_fr(tab, k * m + j); hi[k] = lds_load_fr(tab, k * m + j + half); }
             accumulate_round_evals<K>(lo, hi, sums);
+            if (lin) accumulate_linear_evals<K>(lds_load_fr(lin, j), lds_load_fr(lin, j + half), sums);
         }
 #pragma unroll
         for (int t = 0; t <= K; ++t) sums[t] = wave_reduce_fr(sums[t]);
@@ -372,12 +398,13 @@ static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(Ta
         uint32_t q0 = 0;
         for (uint32_t p = 0; p < ca.meta.n_terms; ++p) {
             const uint32_t* base = tab + 8 * (size_t)q0 * m;
+            const uint32_t* lin = ca.meta.lin_tab[p] != ~0u ? tab + 8 * (size_t)ca.meta.lin_tab[p] * m : nullptr;
             switch (ca.meta.k[p]) {
-                case 1: tail_term_sums<1>(base, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
-                case 2: tail_term_sums<2>(base, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
-                case 3: tail_term_sums<3>(base, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
-                case 4: tail_term_sums<4>(base, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
-                default: tail_term_sums<5>(base, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
+                case 1: tail_term_sums<1>(base, lin, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
+                case 2: tail_term_sums<2>(base, lin, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
+                case 3: tail_term_sums<3>(base, lin, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
+                case 4: tail_term_sums<4>(base, lin, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
+                default: tail_term_sums<5>(base, lin, m, cn, wave_part[wave], ca.meta.rec_off[p]); break;
             }
             q0 += ca.meta.k[p];
         }
