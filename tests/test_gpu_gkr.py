@@ -134,12 +134,12 @@ def test_succint_gkr_prove(zk, ora, layers, inp, tau):
             assert got.infinity == bool(a[12]) and (got.infinity or np.array_equal(got.xy, a[:12]))
 
 
-@pytest.mark.parametrize("depth", [10, 11])
-def test_gkr_beyond_the_dense_wiring_tables(zk, ora, depth):
-    """zkhip_gkr_prove never builds the dense 2^(3l+2)-entry wiring tables (a depth-11 circuit would need two of 2^32
-    entries): layers beyond what the reference's representation holds are provable.  No dense prover exists to compare
-    with at this depth; the proof must pass the restated verifier (whose own checks of the wiring stop at layer one, as
-    in gkr/src/protocol.rs:119-196) and a wrong input must fail it."""
+@pytest.mark.parametrize("depth", [10, 11, 16])
+def test_gkr_beyond_the_dense_tables(zk, ora, depth):
+    """zkhip_gkr_prove builds neither the dense 2^(3l+2)-entry wiring tables nor the dense 2^(2l+2)-entry (b, c) tables of
+    the layer sumchecks (depth 16: 2^47 and 2^32 entries): every table is as wide as the layer.  No dense prover exists to
+    compare with at these depths (depth <= 8 is compared bit for bit above); the proof must pass the restated verifier
+    (whose own checks of the wiring stop at layer one, as in gkr/src/protocol.rs:119-196) and a wrong input must fail it."""
     layers = random_circuit(depth)
     inp = ora.random_fr(2 ** depth, 60 + depth)
     circuit = zk.Circuit.from_tuples(layers)

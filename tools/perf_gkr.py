@@ -16,5 +16,5 @@ for depth in [int(a) for a in sys.argv[1:]] or [4, 6, 8]:
         proof = zk.GKRProtocol.prove(circuit, ev)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / reps
-    print("GKR prove depth %d (widest dense wiring table would be 2^%d, widest sumcheck 2^%d): %.2f ms, %d sumcheck proofs"
+    print("GKR prove depth %d (dense wiring table would be 2^%d, dense (b, c) tables 2^%d entries): %.2f ms, %d sumcheck proofs"
           % (depth, 3 * depth - 1, 2 * depth, dt * 1e3, len(proof.sumcheck_proofs)), flush=True)

@@ -428,6 +428,10 @@ static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(Ta
         __syncthreads();
         cn = half;
     }
+    // hand the transcript back (a later call may continue this sumcheck's rounds: composed.hip `cont`)
+    __syncthreads();
+    if (threadIdx.x < sizeof(Sha256State) / 4)
+        reinterpret_cast<uint32_t*>(&ca.st->transcript)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&trs)[threadIdx.x];
 }
 
 }  // namespace zk

@@ -15,43 +15,92 @@
 #include "host_fr.hpp"
 #include "mle_kernels.hpp"
 
-// ---- wiring tables folded at the gate variables, without the dense table ------------------------------------------
-// The reference builds add_i / mul_i as dense 0/1 tables over (a, b, c) -- 2^(3l+2) entries, one 1 per gate
-// (circuit.rs:59-97) -- folds them at r_b and at r_c over the l gate variables and combines the two with alpha, beta
-// (protocol.rs:67-87).  A fold over `a` of a table that is 1 at (g, b_g, c_g) and 0 elsewhere is
-//     T'[b, c] = sum over the gates g with inputs (b, c) of eq_g(r),   eq_g(r) = prod_j (bit_j(g) ? r_j : 1 - r_j),
-// the same field element (the arithmetic is exact), so the (b, c) tables are written directly: one lane per distinct
-// (type, b, c), summing alpha eq_g(r_b) + beta eq_g(r_c) over its gates (the host groups the gates).  2^(2l+2) entries
-// of output instead of 2^(3l+2) of input: the 2^23-entry tables of an 8-layer circuit never exist, and deeper circuits
-// than the dense representation can hold become provable.
+// ---- a layer's sumcheck in time linear in its width -------------------------------------------------------------
+// The reference proves, per layer,   sum_{b,c} add~(b,c) (V(b) + V(c)) + mul~(b,c) V(b) V(c)   with the multi-composed
+// prover over DENSE tables of all (b, c): 2^(2s) entries for a layer of 2^s values (and builds add~ / mul~ from dense
+// 0/1 tables over (a, b, c), 2^(3l+2) entries, folded over the gate variables: protocol.rs:67-87, circuit.rs:59-97).
+// Both are sums over the GATES in disguise.  With w_g the gate's weight (its eq factor at r_b / r_c, times alpha / beta):
+//   * rounds over b (the first s variables): summing c out first leaves   V(b) Ha0(b) + Ha1(b)   and   V(b) Hm(b)   with
+//       Ha0(b) = sum_{add gates g, in0 = b} w_g,  Ha1(b) = sum_{add, in0 = b} w_g V(in1),  Hm(b) = sum_{mul, in0 = b} w_g V(in1);
+//     the round polynomials of the dense prover are those of these two terms over s variables (folding commutes with
+//     the sum over c), term by term -- which matters because each term's zero coefficients are dropped separately;
+//   * rounds over c, b fixed at the challenges u:   Aa(c) (V(u) + V(c))   and   Am(c) (V(u) V(c))   with
+//       Aa(c) = sum_{add, in1 = c} w_g eq_{in0}(u),  Am(c) likewise: again two product terms, over s variables.
+// Every table has 2^s entries and is built by one pass over the gates (grouped by in0 / in1 on the host), field
+// arithmetic is exact, so sums, round polynomials, challenges and w_b, w_c are those of the dense prover, bit for bit --
+// and a layer of 2^20 values (dense: 2^40 entries) is a few dozen launches over 32 MiB tables.
 namespace zk {
-static __global__ __launch_bounds__(MLE_BLOCK) void gkr_wiring_kernel(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_out,
-                                                               const uint32_t* __restrict__ gate_ids, uint32_t n_segs, uint32_t n_gate_vars,
-                                                               PtsArg r_b, PtsArg r_c, FrArg alpha_v, FrArg beta_v, uint32_t two_points,
-                                                               uint64_t* __restrict__ add_bc, uint64_t* __restrict__ mul_bc) {
-    const uint32_t sidx = blockIdx.x * MLE_BLOCK + threadIdx.x;
-    if (sidx >= n_segs) return;
+// gate weights: w_g = eq_g(r_b) (one point) or alpha eq_g(r_b) + beta eq_g(r_c); eq over the n_gate_vars index bits, MSB first
+static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_weights_kernel(uint32_t n_gates, uint32_t n_gate_vars, PtsArg r_b, PtsArg r_c,
+                                                                     FrArg alpha_v, FrArg beta_v, uint32_t two_points,
+                                                                     uint64_t* __restrict__ wg) {
+    const uint32_t g = blockIdx.x * MLE_BLOCK + threadIdx.x;
+    if (g >= n_gates) return;
     const Fr one = Fr::one();
-    const Fr alpha = fr_from_arg(alpha_v), beta = fr_from_arg(beta_v);
-    Fr acc = Fr::zero();
-    for (uint32_t q = seg_off[sidx]; q < seg_off[sidx + 1]; ++q) {
-        const uint32_t g = gate_ids[q];
-        Fr eb = one, ec = one;
-        for (uint32_t j = 0; j < n_gate_vars; ++j) {
-            const bool bit = (g >> (n_gate_vars - 1 - j)) & 1;
-            const Fr tb = fr_from_pts(r_b, j);
-            eb = eb * (bit ? tb : one - tb);
-            if (two_points) {
-                const Fr tc = fr_from_pts(r_c, j);
-                ec = ec * (bit ? tc : one - tc);
-            }
+    Fr eb = one, ec = one;
+    for (uint32_t j = 0; j < n_gate_vars; ++j) {
+        const bool bit = (g >> (n_gate_vars - 1 - j)) & 1;
+        const Fr tb = fr_from_pts(r_b, j);
+        eb = eb * (bit ? tb : one - tb);
+        if (two_points) {
+            const Fr tc = fr_from_pts(r_c, j);
+            ec = ec * (bit ? tc : one - tc);
         }
-        acc = acc + (two_points ? alpha * eb + beta * ec : eb);
     }
-    const uint32_t o = seg_out[sidx];
-    store_fr((o >> 31) ? mul_bc : add_bc, o & 0x7fffffffu, acc);
+    store_fr(wg, g, two_points ? fr_from_arg(alpha_v) * eb + fr_from_arg(beta_v) * ec : eb);
+}
+// rows of a CSR grouping of the gates by one of their inputs: row_off[x] .. row_off[x+1] index `ids` (gate numbers).
+// phase 1 (rows = in0):  add_out[x] = sum_{add} w_g (Ha0),  lin_out[x] = sum_{add} w_g V[in1] (Ha1),  mul_out[x] = sum_{mul} w_g V[in1] (Hm)
+// phase 2 (rows = in1):  add_out[x] = sum_{add} w_g eq_u[in0] (Aa),  mul_out[x] = sum_{mul} w_g eq_u[in0] (Am);  lin_out unused
+static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_rows_kernel(const uint32_t* __restrict__ row_off, const uint32_t* __restrict__ ids,
+                                                                  const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ other_in,
+                                                                  const uint64_t* __restrict__ wg, const uint64_t* __restrict__ factor,
+                                                                  uint32_t n_rows, uint32_t phase, uint64_t* __restrict__ add_out,
+                                                                  uint64_t* __restrict__ lin_out, uint64_t* __restrict__ mul_out) {
+    const uint32_t x = blockIdx.x * MLE_BLOCK + threadIdx.x;
+    if (x >= n_rows) return;
+    Fr a = Fr::zero(), l = Fr::zero(), m = Fr::zero();
+    for (uint32_t q = row_off[x]; q < row_off[x + 1]; ++q) {
+        const uint32_t g = ids[q];
+        const Fr w = load_fr(wg, g);
+        const Fr wf = w * load_fr(factor, other_in[g]);     // phase 1: w_g V[in1];  phase 2: w_g eq_u[in0]
+        if (gate_type[g]) m = m + wf;
+        else if (phase == 1) { a = a + w; l = l + wf; }
+        else a = a + wf;
+    }
+    store_fr(add_out, x, a);
+    if (phase == 1) store_fr(lin_out, x, l);
+    store_fr(mul_out, x, m);
+}
+// eq_x(u) over n_vars index bits, MSB first (the b side of the wiring at the phase-1 challenges)
+static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_table_kernel(PtsArg u, uint32_t n_vars, uint64_t* __restrict__ out) {
+    const size_t n = (size_t)1 << n_vars, stride = (size_t)gridDim.x * MLE_BLOCK;
+    const Fr one = Fr::one();
+    for (size_t i = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; i < n; i += stride) {
+        Fr acc = one;
+        for (uint32_t j = 0; j < n_vars; ++j) {
+            const Fr t = fr_from_pts(u, j);
+            acc = acc * (((i >> (n_vars - 1 - j)) & 1) ? t : one - t);
+        }
+        store_fr(out, i, acc);
+    }
+}
+// t1[c] = V(u) + V[c]  (wb_add_wc with b at u),  t2[c] = V(u) V[c]  (wb_mul_wc with b at u)
+static __global__ __launch_bounds__(MLE_BLOCK) void gkr_vu_tables_kernel(const uint64_t* __restrict__ v, size_t n, FrArg vu_v,
+                                                                  uint64_t* __restrict__ t1, uint64_t* __restrict__ t2) {
+    const Fr vu = fr_from_arg(vu_v);
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    for (size_t i = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; i < n; i += stride) {
+        const Fr x = load_fr(v, i);
+        store_fr(t1, i, vu + x);
+        store_fr(t2, i, vu * x);
+    }
 }
 }  // namespace zk
+
+int zk_multi_composed_prove_ex(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes, const uint64_t* const* lin_ptrs,
+                               uint32_t n_terms, size_t n, const uint64_t* h_sum, int cont, uint32_t* h_lens, uint64_t* h_round_polys,
+                               uint64_t* h_challenges);   // composed.hip
 
 namespace {
 
@@ -83,85 +132,103 @@ void absorb_proof(zkhost::Transcript& tr, const uint64_t* polys, const uint32_t*
     }
 }
 
-// The shared tail of generate_layer_one_prove_sumcheck (gkr/src/utils.rs:27-55) and of the loop body of
-// GKRProtocol::prove (protocol.rs:78-107).  d_add / d_mul: the wiring tables reduced to (b, c), n = w_len^2 entries.
-// d_sum / d_prod: scratch of n entries each.
-int layer_sumcheck(zkhip_ctx* c, const uint64_t* d_add, const uint64_t* d_mul, const uint64_t* d_w, size_t w_len, uint64_t* d_sum,
-                   uint64_t* d_prod, zkhost::Fr& claimed, zkhost::Transcript& tr, const LayerOut& out, uint32_t k, zkhost::Fr& alpha,
-                   zkhost::Fr& beta, std::vector<zkhost::Fr>& r_b, std::vector<zkhost::Fr>& r_c) {
-    const size_t n = w_len * w_len;
-    const uint32_t nv = log2_exact(n);
-    if (nv > out.stride) return ZKHIP_ERR_SHAPE;
-    ZK_TRY(zkhip_mle_add_distinct(c, d_w, w_len, d_w, w_len, d_sum));     // wb.add_distinct(&wc)
-    ZK_TRY(zkhip_mle_mul_distinct(c, d_w, w_len, d_w, w_len, d_prod));    // wb.mul_distinct(&wc)
-    const uint64_t* tables[4] = {d_add, d_sum, d_mul, d_prod};            // [add, wb + wc], [mul, wb * wc]
-    const uint32_t sizes[2] = {2, 2};
-    std::vector<uint64_t> challenges(4 * (size_t)nv);
+// CSR grouping of gates by key[g] in [0, n_rows): row offsets + gate ids (counting sort; stable, so sums run in gate order)
+static void group_gates(const uint32_t* key, size_t n_gates, size_t n_rows, std::vector<uint32_t>& csr /* row_off (n_rows+1) | ids */) {
+    csr.assign(n_rows + 1 + n_gates, 0);
+    for (size_t g = 0; g < n_gates; ++g) csr[key[g] + 1]++;
+    for (size_t x = 0; x < n_rows; ++x) csr[x + 1] += csr[x];
+    std::vector<uint32_t> cur(csr.begin(), csr.begin() + n_rows);
+    for (size_t g = 0; g < n_gates; ++g) csr[n_rows + 1 + cur[key[g]]++] = (uint32_t)g;
+}
+
+// device scratch of one layer (carved from the context's aux buffer)
+struct LayerScratch {
+    uint64_t *wg, *ha0, *ha1, *hm, *equ, *aa, *am, *t1, *t2;
+    uint32_t *csr0, *csr1, *in0, *in1;
+    uint8_t* type;
+};
+
+// One layer: the sumcheck of generate_layer_one_prove_sumcheck (gkr/src/utils.rs:27-55) / the loop body of
+// GKRProtocol::prove (protocol.rs:64-107) in the linear-time form described above, then w_b, w_c, alpha, beta, the next claim.
+int layer_prove(zkhip_ctx* c, const uint8_t* gate_type, const uint32_t* in0, const uint32_t* in1, size_t n_gates, uint32_t l,
+                const uint64_t* d_w, size_t w_len, const LayerScratch& sc, zkhost::Fr& claimed, zkhost::Transcript& tr, const LayerOut& out,
+                uint32_t k, zkhost::Fr& alpha, zkhost::Fr& beta, std::vector<zkhost::Fr>& r_b, std::vector<zkhost::Fr>& r_c, bool two_points) {
+    using namespace zk;
+    const uint32_t s = log2_exact(w_len);                  // variables of b (and of c)
+    const uint32_t n_gate_vars = l == 0 ? 1u : l;          // binary_string(a, layer_index) has at least one bit (circuit/src/utils.rs:27-33)
+    if (s != l + 1 || 2 * s > out.stride || s < 1) return ZKHIP_ERR_SHAPE;   // the wiring index has l + 1 bits for b and for c
+    if (r_b.size() != n_gate_vars || (two_points && r_c.size() != n_gate_vars)) return ZKHIP_ERR_SHAPE;
+    for (size_t g = 0; g < n_gates; ++g)
+        if (in0[g] >= w_len || in1[g] >= w_len || (g >> n_gate_vars)) return ZKHIP_ERR_INDEX;   // add_evaluations[gate_decimal] out of bounds
+    // gates and their two groupings -> device
+    std::vector<uint32_t> csr0, csr1;
+    group_gates(in0, n_gates, w_len, csr0);
+    group_gates(in1, n_gates, w_len, csr1);
+    ZK_HIP(c, hipMemcpyAsync(sc.csr0, csr0.data(), 4 * csr0.size(), hipMemcpyHostToDevice, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(sc.csr1, csr1.data(), 4 * csr1.size(), hipMemcpyHostToDevice, c->stream));
+    if (n_gates) {
+        ZK_HIP(c, hipMemcpyAsync(sc.in0, in0, 4 * n_gates, hipMemcpyHostToDevice, c->stream));
+        ZK_HIP(c, hipMemcpyAsync(sc.in1, in1, 4 * n_gates, hipMemcpyHostToDevice, c->stream));
+        ZK_HIP(c, hipMemcpyAsync(sc.type, gate_type, n_gates, hipMemcpyHostToDevice, c->stream));
+    }
+    PtsArg pb = {}, pc = {};
+    std::memcpy(pb.v, r_b[0].l, 32 * r_b.size());
+    if (two_points) std::memcpy(pc.v, r_c[0].l, 32 * r_c.size());
+    FrArg av = {}, bv = {};
+    std::memcpy(av.v, alpha.l, 32);
+    std::memcpy(bv.v, beta.l, 32);
+    const unsigned gg = (unsigned)((n_gates + MLE_BLOCK - 1) / MLE_BLOCK), gw = (unsigned)((w_len + MLE_BLOCK - 1) / MLE_BLOCK);
+    if (n_gates)
+        hipLaunchKernelGGL(gkr_gate_weights_kernel, dim3(gg), dim3(MLE_BLOCK), 0, c->stream, (uint32_t)n_gates, n_gate_vars, pb, pc, av, bv,
+                           two_points ? 1u : 0u, sc.wg);
+    // ---- rounds over b
+    hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, sc.csr0, sc.csr0 + w_len + 1, sc.type, sc.in1, sc.wg, d_w,
+                       (uint32_t)w_len, 1u, sc.ha0, sc.ha1, sc.hm);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipStreamSynchronize(c->stream));            // csr0 / csr1 are host temporaries; the prover below reuses the workspace
+    const uint32_t nv = 2 * s;
     uint64_t* polys = out.round_polys + (size_t)k * out.stride * GKR_MONO * 8;
     uint32_t* lens = out.lens + (size_t)k * out.stride;
-    ZK_TRY(zkhip_multi_composed_prove(c, tables, sizes, 2, n, claimed.l, 1, lens, polys, challenges.data()));
+    std::vector<uint64_t> challenges(4 * (size_t)nv);
+    const uint32_t sizes[2] = {2, 2};
+    {
+        const uint64_t* tables[4] = {sc.ha0, d_w, sc.hm, d_w};          // [Ha0, V] + Ha1,  [Hm, V]
+        const uint64_t* lin[2] = {sc.ha1, nullptr};
+        ZK_TRY(zk_multi_composed_prove_ex(c, tables, sizes, lin, 2, w_len, claimed.l, 0, lens, polys, challenges.data()));
+    }
+    // ---- rounds over c, b at u
+    std::vector<zkhost::Fr> u(s);
+    std::memcpy(u.data(), challenges.data(), 32 * (size_t)s);
+    zkhost::Fr eval_wb;                                     // V(u): the factor of the second phase and w_b of the proof
+    ZK_TRY(zkhip_mle_evaluation(c, d_w, w_len, u[0].l, s, eval_wb.l));
+    PtsArg pu = {};
+    std::memcpy(pu.v, u[0].l, 32 * (size_t)s);
+    FrArg vu = {};
+    std::memcpy(vu.v, eval_wb.l, 32);
+    hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid(w_len)), dim3(MLE_BLOCK), 0, c->stream, pu, s, sc.equ);
+    hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, sc.csr1, sc.csr1 + w_len + 1, sc.type, sc.in0, sc.wg, sc.equ,
+                       (uint32_t)w_len, 2u, sc.aa, (uint64_t*)nullptr, sc.am);
+    hipLaunchKernelGGL(gkr_vu_tables_kernel, dim3(mle_grid(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_w, w_len, vu, sc.t1, sc.t2);
+    ZK_HIP(c, hipGetLastError());
+    {
+        const uint64_t* tables[4] = {sc.aa, sc.t1, sc.am, sc.t2};        // [add~(u, c), V(u) + V(c)],  [mul~(u, c), V(u) V(c)]
+        ZK_TRY(zk_multi_composed_prove_ex(c, tables, sizes, nullptr, 2, w_len, nullptr, 1, lens + s, polys + (size_t)s * GKR_MONO * 8,
+                                          challenges.data() + 4 * (size_t)s));
+    }
     if (out.challenges) std::memcpy(out.challenges + (size_t)k * out.stride * 4, challenges.data(), 32 * (size_t)nv);
     std::memcpy(out.sums + 4 * (size_t)k, claimed.l, 32);
     out.n_rounds[k] = nv;
     absorb_proof(tr, polys, lens, nv);                                     // transcript.commit(&sumcheck_proof.to_bytes())
-    const uint32_t half = nv / 2;                                          // challenges.split_at(len / 2)
-    r_b.assign(half, zkhost::fr_zero());
-    r_c.assign(nv - half, zkhost::fr_zero());
-    std::memcpy(r_b.data(), challenges.data(), 32 * (size_t)half);
-    std::memcpy(r_c.data(), challenges.data() + 4 * (size_t)half, 32 * (size_t)(nv - half));
-    zkhost::Fr eval_wb, eval_wc;
-    ZK_TRY(zkhip_mle_evaluation(c, d_w, w_len, r_b.empty() ? nullptr : r_b[0].l, r_b.size(), eval_wb.l));
-    ZK_TRY(zkhip_mle_evaluation(c, d_w, w_len, r_c.empty() ? nullptr : r_c[0].l, r_c.size(), eval_wc.l));
+    r_b = u;                                                               // challenges.split_at(len / 2)
+    r_c.assign(s, zkhost::fr_zero());
+    std::memcpy(r_c.data(), challenges.data() + 4 * (size_t)s, 32 * (size_t)s);
+    zkhost::Fr eval_wc;
+    ZK_TRY(zkhip_mle_evaluation(c, d_w, w_len, r_c[0].l, s, eval_wc.l));
     std::memcpy(out.wb + 4 * (size_t)k, eval_wb.l, 32);
     std::memcpy(out.wc + 4 * (size_t)k, eval_wc.l, 32);
     alpha = tr.challenge_fr();
     beta = tr.challenge_fr();
     claimed = zkhost::fr_add(zkhost::fr_mul(alpha, eval_wb), zkhost::fr_mul(beta, eval_wc));
-    return ZKHIP_OK;
-}
-
-// add_bc / mul_bc (bc entries each) for layer l's gates, folded at r_b (and r_c, weighted alpha / beta, when given)
-int wiring_tables(zkhip_ctx* c, const uint8_t* gate_type, const uint32_t* in0, const uint32_t* in1, size_t n_gates, uint32_t l,
-                  const std::vector<zkhost::Fr>& r_b, const std::vector<zkhost::Fr>* r_c, const zkhost::Fr& alpha, const zkhost::Fr& beta,
-                  size_t bc, uint64_t* d_add, uint64_t* d_mul) {
-    const uint32_t shift = l + 1;                       // bits of b and of c
-    const uint32_t n_gate_vars = l == 0 ? 1u : l;       // binary_string(a, layer_index) has at least one bit (circuit/src/utils.rs:27-33)
-    if (r_b.size() != n_gate_vars || (r_c && r_c->size() != n_gate_vars) || 2 * shift > 30) return ZKHIP_ERR_SHAPE;
-    if (bc != ((size_t)1 << (2 * shift))) return ZKHIP_ERR_SHAPE;
-    std::vector<uint64_t> keys(n_gates);                // (type, b, c, gate)
-    for (size_t g = 0; g < n_gates; ++g) {
-        if (in0[g] >> shift || in1[g] >> shift || (g >> n_gate_vars)) return ZKHIP_ERR_INDEX;   // add_evaluations[gate_decimal] out of bounds
-        const uint64_t o = ((uint64_t)(gate_type[g] ? 1 : 0) << 31) | ((uint64_t)in0[g] << shift) | in1[g];
-        keys[g] = (o << 32) | (uint32_t)g;
-    }
-    std::sort(keys.begin(), keys.end());
-    std::vector<uint32_t> host;                          // [seg_off (n_segs + 1)] [seg_out (n_segs)] [gate_ids (n_gates)]
-    std::vector<uint32_t> seg_off, seg_out, ids(n_gates);
-    for (size_t q = 0; q < n_gates; ++q) {
-        ids[q] = (uint32_t)keys[q];
-        if (q == 0 || (keys[q] >> 32) != (keys[q - 1] >> 32)) { seg_off.push_back((uint32_t)q); seg_out.push_back((uint32_t)(keys[q] >> 32)); }
-    }
-    const uint32_t n_segs = (uint32_t)seg_out.size();
-    seg_off.push_back((uint32_t)n_gates);
-    host.insert(host.end(), seg_off.begin(), seg_off.end());
-    host.insert(host.end(), seg_out.begin(), seg_out.end());
-    host.insert(host.end(), ids.begin(), ids.end());
-    ZK_HIP(c, hipMemsetAsync(d_add, 0, 32 * bc, c->stream));   // F::zero() is all-zero limbs
-    ZK_HIP(c, hipMemsetAsync(d_mul, 0, 32 * bc, c->stream));
-    if (n_segs == 0) return ZKHIP_OK;
-    ZK_TRY(c->reserve_ws(4 * host.size() + 256));
-    ZK_HIP(c, hipMemcpyAsync(c->d_ws, host.data(), 4 * host.size(), hipMemcpyHostToDevice, c->stream));
-    zk::PtsArg pb = {}, pc = {};
-    std::memcpy(pb.v, r_b[0].l, 32 * r_b.size());
-    if (r_c) std::memcpy(pc.v, (*r_c)[0].l, 32 * r_c->size());
-    zk::FrArg a = {}, b = {};
-    std::memcpy(a.v, alpha.l, 32);
-    std::memcpy(b.v, beta.l, 32);
-    const uint32_t* d = (const uint32_t*)c->d_ws;
-    hipLaunchKernelGGL(zk::gkr_wiring_kernel, dim3((n_segs + zk::MLE_BLOCK - 1) / zk::MLE_BLOCK), dim3(zk::MLE_BLOCK), 0, c->stream, d, d + n_segs + 1,
-                       d + 2 * n_segs + 1, n_segs, n_gate_vars, pb, pc, a, b, r_c ? 1u : 0u, d_add, d_mul);
-    ZK_HIP(c, hipGetLastError());
-    ZK_HIP(c, hipStreamSynchronize(c->stream));   // `host` is a temporary and the staging lives in the shared workspace
     return ZKHIP_OK;
 }
 
@@ -174,23 +241,28 @@ extern "C" int zkhip_gkr_prove(zkhip_ctx* c, uint32_t n_layers, const size_t* h_
     if (!c || !h_n_gates || !h_gate_type || !h_in0 || !h_in1 || !h_layer_ptrs || !h_layer_len || !h_sums || !h_n_rounds ||
         !h_round_poly_lens || !h_round_polys || !h_wb || !h_wc || !h_w0)
         return ZKHIP_ERR_ARG;
-    if (n_layers < 1 || n_layers > 14) return ZKHIP_ERR_SHAPE;   // (b, c) tables of 2^(2 n_layers) entries
+    if (n_layers < 1 || 2 * n_layers > (uint32_t)ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;   // 2 (l + 1) rounds for layer l
     if (h_layer_len[0] != 1) return ZKHIP_ERR_SHAPE;              // w_0 = [output.., 0] must have 2^k entries; the wiring of layer 0 has one gate bit
     for (uint32_t k = 1; k <= n_layers; ++k)
         if (!is_pow2(h_layer_len[k])) return ZKHIP_ERR_SHAPE;  // Multilinear::new (evaluation_form.rs:16-20)
     ZK_TRY(c->activate());
-    // aux layout: w_0 (2) | the two wiring tables over (b, c) | wb + wc, wb * wc  (all of the layer's (b, c) size)
-    size_t max_bc = 0;
-    for (uint32_t l = 0; l < n_layers; ++l) max_bc = std::max(max_bc, h_layer_len[l + 1] * h_layer_len[l + 1]);
+    // aux layout: w_0 (2) | nine tables of the widest layer | gate weights | gate arrays and their two groupings
+    size_t max_w = 0, max_g = 0;
+    for (uint32_t l = 0; l < n_layers; ++l) { max_w = std::max(max_w, h_layer_len[l + 1]); max_g = std::max(max_g, h_n_gates[l]); }
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_w0 = 0, o_add = al(64), o_mul = o_add + al(32 * max_bc), o_sum = o_mul + al(32 * max_bc), o_prod = o_sum + al(32 * max_bc);
-    ZK_TRY(c->reserve_aux(o_prod + al(32 * max_bc)));
+    const size_t tb = al(32 * max_w);
+    const size_t o_w0 = 0, o_tab = al(64), o_wg = o_tab + 8 * tb, o_csr0 = o_wg + al(32 * max_g), o_csr1 = o_csr0 + al(4 * (max_w + 1 + max_g));
+    const size_t o_in0 = o_csr1 + al(4 * (max_w + 1 + max_g)), o_in1 = o_in0 + al(4 * max_g), o_type = o_in1 + al(4 * max_g);
+    ZK_TRY(c->reserve_aux(o_type + al(max_g)));
     char* aux = (char*)c->d_aux;
     uint64_t* d_w0 = (uint64_t*)(aux + o_w0);
-    uint64_t* d_add = (uint64_t*)(aux + o_add);
-    uint64_t* d_mul = (uint64_t*)(aux + o_mul);
-    uint64_t* d_sum = (uint64_t*)(aux + o_sum);
-    uint64_t* d_prod = (uint64_t*)(aux + o_prod);
+    LayerScratch sc;
+    sc.ha0 = (uint64_t*)(aux + o_tab); sc.ha1 = (uint64_t*)(aux + o_tab + tb); sc.hm = (uint64_t*)(aux + o_tab + 2 * tb);
+    sc.equ = (uint64_t*)(aux + o_tab + 3 * tb); sc.aa = (uint64_t*)(aux + o_tab + 4 * tb); sc.am = (uint64_t*)(aux + o_tab + 5 * tb);
+    sc.t1 = (uint64_t*)(aux + o_tab + 6 * tb); sc.t2 = (uint64_t*)(aux + o_tab + 7 * tb);
+    sc.wg = (uint64_t*)(aux + o_wg);
+    sc.csr0 = (uint32_t*)(aux + o_csr0); sc.csr1 = (uint32_t*)(aux + o_csr1);
+    sc.in0 = (uint32_t*)(aux + o_in0); sc.in1 = (uint32_t*)(aux + o_in1); sc.type = (uint8_t*)(aux + o_type);
     LayerOut out = {h_sums, h_round_polys, h_wb, h_wc, h_challenges, h_n_rounds, h_round_poly_lens, 2 * n_layers};
 
     // w_0 = circuit_evaluation[0] padded with a zero (protocol.rs:30-33); commit its bytes, draw n_r
@@ -219,18 +291,14 @@ extern "C" int zkhip_gkr_prove(zkhip_ctx* c, uint32_t n_layers, const size_t* h_
     zkhost::Fr alpha = zkhost::fr_one(), beta = zkhost::fr_zero();
     std::vector<zkhost::Fr> r_b, r_c;
     size_t g_off = 0;
-    {   // layer one (gkr/src/utils.rs:12-56): the wiring of layer 0 with its gate variable fixed at n_r
-        const size_t bc = h_layer_len[1] * h_layer_len[1];
-        ZK_TRY(wiring_tables(c, h_gate_type, h_in0, h_in1, h_n_gates[0], 0, n_r, nullptr, alpha, beta, bc, d_add, d_mul));
-        ZK_TRY(layer_sumcheck(c, d_add, d_mul, h_layer_ptrs[1], h_layer_len[1], d_sum, d_prod, claimed, tr, out, 0, alpha, beta, r_b, r_c));
-        g_off += h_n_gates[0];
-    }
+    // layer one (gkr/src/utils.rs:12-56): the wiring of layer 0 with its gate variable fixed at n_r
+    ZK_TRY(layer_prove(c, h_gate_type, h_in0, h_in1, h_n_gates[0], 0, h_layer_ptrs[1], h_layer_len[1], sc, claimed, tr, out, 0, alpha, beta, n_r, r_c, false));
+    r_b = n_r;   // layer_prove left (b, c) of layer one in (n_r, r_c)
+    g_off += h_n_gates[0];
     for (uint32_t li = 2; li <= n_layers; ++li) {                    // protocol.rs:64-108
         const uint32_t l = li - 1;
-        const size_t bc = h_layer_len[li] * h_layer_len[li];
-        // alpha * add(r_b, b, c) + beta * add(r_c, b, c); the same for mul  (:67-87)
-        ZK_TRY(wiring_tables(c, h_gate_type + g_off, h_in0 + g_off, h_in1 + g_off, h_n_gates[l], l, r_b, &r_c, alpha, beta, bc, d_add, d_mul));
-        ZK_TRY(layer_sumcheck(c, d_add, d_mul, h_layer_ptrs[li], h_layer_len[li], d_sum, d_prod, claimed, tr, out, li - 1, alpha, beta, r_b, r_c));
+        ZK_TRY(layer_prove(c, h_gate_type + g_off, h_in0 + g_off, h_in1 + g_off, h_n_gates[l], l, h_layer_ptrs[li], h_layer_len[li], sc, claimed,
+                           tr, out, li - 1, alpha, beta, r_b, r_c, true));
         g_off += h_n_gates[l];
     }
     return ZKHIP_OK;
