@@ -113,9 +113,10 @@ int zkhip_circuit_add_mult_mle(zkhip_ctx *ctx, const uint8_t *h_gate_type, const
                                size_t n_gates, uint32_t layer_index, uint64_t *d_add, uint64_t *d_mul);
 
 /* GKRProtocol::prove (gkr/src/protocol.rs:21-117 with gkr/src/utils.rs:8-56) in one call, every table in HBM.  The dense
- * wiring tables of Circuit::add_mult_mle are not built: their fold over the gate variables is written directly as the
- * (b, c) tables the layer's sumcheck runs on (same values), so n_layers <= 14 is bounded by those 2^(2 n_layers)-entry
- * tables rather than by 2^(3 l + 2)-entry ones.
+ * wiring tables of Circuit::add_mult_mle (2^(3 l + 2) entries) and the dense (b, c) tables of a layer's sumcheck
+ * (2^(2 l + 2) entries) are not built: the layer prover sums over the gates and works on tables as wide as the layer
+ * (rounds over b, then over c), giving the proof of the dense prover bit for bit.  2 * n_layers <= 40
+ * rounds per layer proof, i.e. circuits up to depth 20 / width 2^20.
  *   circuit    : n_layers layers, layer l with h_n_gates[l] gates (layer 0 = output); gate arrays concatenated
  *   evaluation : h_layer_ptrs[k], k = 0..n_layers, DEVICE tables as Circuit::evaluation returns them (output first,
  *                input last), h_layer_len[k] entries each.  The reference's shape panics (Multilinear::new on a
@@ -213,6 +214,37 @@ int zkhip_multi_composed_sum(zkhip_ctx *ctx, const uint64_t *const *h_table_ptrs
 int zkhip_multi_composed_prove(zkhip_ctx *ctx, const uint64_t *const *h_table_ptrs, const uint32_t *h_term_sizes,
                                uint32_t n_terms, size_t n, const uint64_t *h_sum, int partial,
                                uint32_t *h_round_poly_lens, uint64_t *h_round_polys, uint64_t *h_challenges);
+
+/* The same provers over tables SHARDED across `world` ranks (rank g holds entry j*world + g of every table at
+ * local index j; the rounds fold the most significant variable, so folds are local).  ComposedSumcheck::prove (multi = 0,
+ * one term) and MultiComposedSumcheckProver::prove_partial (multi = 1, h_sum = the claimed sum of the WHOLE tables).  Per
+ * round every rank contributes one record of its partial sums -- term p's evaluations at t = 0..K_p, term after term,
+ * zkhip_mc_record_len field elements (<= 24, i.e. <= 768 bytes) -- the host all-gathers the records (RCCL over xGMI) and
+ * every rank closes the round on the gathered records (sum, interpolation, transcript, challenge), replicated.  A product of
+ * tables does not commute with block sums, so there is no stage form here: one exchange per round.  Once the remaining
+ * tables of all ranks fit one workgroup's LDS together they are gathered and the last rounds run replicated in one launch.
+ *   begin -> { round_sums -> [all-gather] -> absorb } while local_len * world > tail_capacity
+ *         -> local_tables -> [all-gather + interleave] -> tail -> finish
+ * One session per context at a time (its buffers live in the context's workspace). */
+typedef struct zkhip_mc_state zkhip_mc_state;
+int zkhip_mc_begin(zkhip_ctx *ctx, const uint64_t *const *h_local_table_ptrs, const uint32_t *h_term_sizes, uint32_t n_terms,
+                   size_t n_local, uint32_t world, int multi, const uint64_t *h_sum, zkhip_mc_state **out);
+int zkhip_mc_record_len(zkhip_mc_state *st, uint32_t *rec, uint32_t *n_tables);
+/* entries per local table the next round's sums run over (n_local, then n_local/2, ...) */
+int zkhip_mc_local_len(zkhip_mc_state *st, size_t *n_now);
+int zkhip_mc_tail_capacity(zkhip_mc_state *st, uint32_t *entries_per_table);
+/* folds the local tables at the previous challenge (rounds > 0) and writes this rank's record d_out[rec][4] */
+int zkhip_mc_round_sums(zkhip_mc_state *st, uint64_t *d_out);
+/* d_gathered[world][rec][4]: every rank's record in rank order */
+int zkhip_mc_absorb(zkhip_mc_state *st, const uint64_t *d_gathered, uint32_t world);
+/* the local tables as the next round would see them, d_out[n_tables][local_len][4] */
+int zkhip_mc_local_tables(zkhip_mc_state *st, uint64_t *d_out);
+/* d_tables[n_tables][m][4]: the whole remaining tables in natural order (entry j*world + g = rank g's local entry j),
+ * m = local_len * world <= tail_capacity; runs ALL remaining log2(m) rounds */
+int zkhip_mc_tail(zkhip_mc_state *st, const uint64_t *d_tables, uint32_t m);
+/* copies out the proof in the layouts of zkhip_composed_prove / zkhip_multi_composed_prove (log2(n_local * world) rounds)
+ * and releases the state; all-NULL outputs just release it */
+int zkhip_mc_finish(zkhip_mc_state *st, uint32_t *h_round_poly_lens, uint64_t *h_round_polys, uint64_t *h_challenges);
 
 /* ---- KZG commit = multi-scalar multiplication over G1 -------------------------------------- */
 /* MultilinearKZG::commitment (kzg/src/multilinear_kzg.rs:33-48; require_equal_len = 1 reproduces its

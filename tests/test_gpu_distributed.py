@@ -168,3 +168,82 @@ def test_stage_form_2_27_over_8_shards_matches_single_gpu_prover(zk):
         e.tail(rest, n_local * world)
         s, rp, ch = e.finish(log_n)
         assert np.array_equal(s, want.sum) and np.array_equal(rp, want.univariate_poly) and np.array_equal(ch, want_ch)
+
+
+def _drive_composed_shards(D, torch, engines, world, n_local):
+    """What ShardedComposedSumcheck.prove does, with the all-gather done by stacking the shards' buffers."""
+    cap, rec, nt = engines[0].tail_capacity(), engines[0].record_len(), engines[0].table_count()
+    sends = [e.new_buffer(rec, 4) for e in engines]
+    n_exchanges = 0
+    while n_local * world > cap and n_local > 1:
+        for e, s in zip(engines, sends):
+            e.round_sums(s)
+        gathered = torch.stack(sends).contiguous()
+        for e in engines:
+            e.absorb(gathered, world)
+        n_local //= 2
+        n_exchanges += 1
+    tabs = []
+    for e in engines:
+        assert e.local_len() == n_local
+        t = e.new_buffer(nt, n_local, 4)
+        e.local_tables(t)
+        tabs.append(t)
+    full = torch.stack(tabs).permute(1, 2, 0, 3).contiguous().view(nt, n_local * world, 4)
+    total_rounds = (n_local * world).bit_length() - 1 + n_exchanges
+    for e in engines:
+        e.tail(full, n_local * world)
+    return [e.finish(total_rounds) for e in engines]
+
+
+@pytest.mark.parametrize("world,k,log_n", [(2, 2, 14), (4, 3, 13), (8, 5, 12), (2, 1, 11), (8, 2, 4), (2, 2, 1), (4, 2, 18)])
+def test_sharded_composed_sumcheck_matches_full_prover(zk, ora, world, k, log_n):
+    """ComposedSumcheck::prove with every table split over `world` shards driven in lockstep on one GPU: round polynomials
+    and challenges must be those of the oracle (and so of the single-GPU prover) on the whole tables."""
+    import torch
+    from zk_cryptography_amd import distributed as D
+    from zk_cryptography_amd import _native as N
+    full = np.stack([ora.random_fr(1 << log_n, 300 + 7 * q + log_n) for q in range(k)])
+    engines = []
+    for g in range(world):
+        shard = [torch.from_numpy(np.ascontiguousarray(D.shard_interleaved(full[q], g, world)).view(np.int64)).cuda() for q in range(k)]
+        engines.append(D.HipComposedEngine([shard], world, multi=False, ctx=N.Context(0)))
+    outs = _drive_composed_shards(D, torch, engines, world, (1 << log_n) // world)
+    wrp, wch = ora.composed_prove(full)
+    for rp, ch in outs:
+        assert np.array_equal(rp, wrp) and np.array_equal(ch, wch)
+
+
+@pytest.mark.parametrize("world,sizes,log_n", [(2, [2, 2], 12), (8, [2, 3], 13), (4, [1, 5], 10), (2, [2, 2, 1, 1], 7), (4, [3], 16)])
+def test_sharded_multi_composed_prove_partial_matches_full_prover(zk, ora, world, sizes, log_n):
+    """MultiComposedSumcheckProver::prove_partial (what GKR calls per layer) over sharded tables."""
+    import torch
+    from zk_cryptography_amd import distributed as D
+    from zk_cryptography_amd import _native as N
+    flat = np.stack([ora.random_fr(1 << log_n, 500 + 3 * q + log_n) for q in range(sum(sizes))])
+    s = ora.multi_composed_sum(flat, sizes)
+    engines = []
+    for g in range(world):
+        terms, q = [], 0
+        for k in sizes:
+            terms.append([torch.from_numpy(np.ascontiguousarray(D.shard_interleaved(flat[q + i], g, world)).view(np.int64)).cuda()
+                          for i in range(k)])
+            q += k
+        engines.append(D.HipComposedEngine(terms, world, multi=True, claimed_sum=s, ctx=N.Context(0)))
+    outs = _drive_composed_shards(D, torch, engines, world, (1 << log_n) // world)
+    orps, och = ora.multi_composed_prove(flat, sizes, s, partial=True)
+    want = [o.monomials() for o in orps]
+    for rps, ch in outs:
+        got = [zk.SparseUnivariatePolynomial(c, p).monomials() for c, p in rps]
+        assert got == want and np.array_equal(ch, och)
+
+
+def test_sharded_composed_orchestration_world_1(zk, ora):
+    """ShardedComposedSumcheck end to end with one rank (no process group needed: the gather is a copy)."""
+    import torch
+    from zk_cryptography_amd import distributed as D
+    full = np.stack([ora.random_fr(1 << 15, 900 + q) for q in range(3)])
+    shard = [torch.from_numpy(full[q].view(np.int64)).cuda() for q in range(3)]
+    rp, ch = D.ShardedComposedSumcheck(D.HipComposedEngine([shard], 1, multi=False), 1).prove()
+    wrp, wch = ora.composed_prove(full)
+    assert np.array_equal(rp, wrp) and np.array_equal(ch, wch)

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "ctx.hpp"
@@ -82,69 +83,77 @@ extern "C" int zkhip_multi_composed_sum(zkhip_ctx* c, const uint64_t* const* ptr
     return product_sums(c, ptrs, term_sizes, n_terms, n, h_sum);
 }
 
-// shared driver.  multi = 0: ComposedSumcheck (one term).  first_mode: see close_round.
+// One composed / multi-composed sumcheck in progress: the state shared by the one-call provers below and by the
+// split-phase session (zkhip_mc_*, tables sharded over several GPUs).  multi = 0: ComposedSumcheck (one term).
 // lin_ptrs (nullable): per term an optional additive table (term = product + table; K <= 2).  cont: continue the
 // transcript the previous call left in the context (its rounds are the next rounds of the same sumcheck) instead of
-// starting one; every call leaves its final transcript state there.
-static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes, uint32_t n_terms,
-                               size_t n, int multi, const uint64_t* h_sum, int partial, uint32_t* h_lens,
-                               uint64_t* h_round_polys, uint64_t* h_challenges, const uint64_t* const* lin_ptrs = nullptr,
-                               int cont = 0) {
-    if (!c || !ptrs || !term_sizes) return ZKHIP_ERR_ARG;
-    if (n_terms == 0 || n_terms > CMP_MAX_TERMS) return ZKHIP_ERR_ARG;
-    if (!is_pow2(n)) return ZKHIP_ERR_SHAPE;
-    const uint32_t n_vars = log2_exact(n);
-    if (n_vars > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
-    if (n_vars == 0) return ZKHIP_OK;   // `for _ in 0..n_vars` never runs
-    if (!h_round_polys || !h_challenges || (multi && ((!h_sum && !cont) || !h_lens))) return ZKHIP_ERR_ARG;
-    ZK_TRY(c->activate());
+// starting one; every one-call prove leaves its final transcript state there.
+struct ComposedRun {
+    zkhip_ctx* c = nullptr;
     ComposedMeta meta = {};
-    meta.n_terms = n_terms;
-    meta.multi = (uint32_t)multi;
-    uint32_t total = 0, rec = 0;
-    for (uint32_t p = 0; p < n_terms; ++p) {
-        if (term_sizes[p] < 1 || term_sizes[p] > CMP_MAX_K) return ZKHIP_ERR_ARG;
-        meta.k[p] = term_sizes[p];
-        meta.rec_off[p] = rec;
-        rec += term_sizes[p] + 1;
-        total += term_sizes[p];
-    }
-    meta.rec = rec;
-    if (rec > CMP_MAX_REC) return ZKHIP_ERR_ARG;
-    // additive tables: numbered after the product tables
-    uint32_t n_lin = 0;
-    std::vector<const uint64_t*> lin_cur(n_terms, nullptr);
-    for (uint32_t p = 0; p < n_terms; ++p) {
-        meta.lin_tab[p] = ~0u;
-        if (lin_ptrs && lin_ptrs[p]) {
-            if (term_sizes[p] > 2) return ZKHIP_ERR_ARG;
-            lin_cur[p] = lin_ptrs[p];
-            meta.lin_tab[p] = total + n_lin++;
-        }
-    }
-    const uint32_t total_all = total + n_lin;
-    // workspace: per table a ping (n/2) and a pong (n/4) buffer, then the state
-    const size_t per_table = (n / 2 + n / 4 + 2) * 32;
-    const size_t state_off = (total_all * per_table + 255) & ~(size_t)255;
-    const size_t bytes_off = state_off + ((sizeof(ComposedDev) + 255) & ~(size_t)255);
-    ZK_TRY(c->reserve_ws(bytes_off + (multi && !partial ? 32 * n : 0)));
-    char* ws = (char*)c->d_ws;
-    ComposedDev* st = (ComposedDev*)(ws + state_off);
-    uint64_t* d_partials = c->small_u64(ZK_SMALL_PARTIALS);
-    uint64_t* d_rp = c->small_u64(ZK_SMALL_ROUNDPOLYS);
-    uint64_t* d_ch = c->small_u64(ZK_SMALL_CHALLENGES);
+    uint32_t n_terms = 0, total = 0, total_all = 0, n_rounds = 0;
+    uint32_t term_sizes[CMP_MAX_TERMS] = {};
+    int multi = 0;
+    size_t n = 0, cn = 0, per_table = 0;
+    char* ws = nullptr;
+    ComposedDev* st = nullptr;
+    uint64_t *d_partials = nullptr, *d_rp = nullptr, *d_ch = nullptr;
+    std::vector<const uint64_t*> cur, lin_cur;
+    uint32_t round = 0, first = 1, tail_len = 0;
 
-    uint32_t first = 1;
-    Sha256State* saved = (Sha256State*)c->small_u64(ZK_SMALL_STATE);   // transcript handed from call to call (cont)
-    if (cont) {
-        ZK_HIP(c, hipMemcpyAsync(&st->transcript, saved, sizeof(Sha256State), hipMemcpyDeviceToDevice, c->stream));
-        first = 0;
-    }
-    if (multi) {
+    // n = entries per table held here, n_rounds = rounds of the whole sumcheck (log2 n, more when other ranks hold shards)
+    int setup(zkhip_ctx* ctx, const uint64_t* const* ptrs, const uint32_t* sizes, uint32_t nt, size_t n_entries, uint32_t rounds,
+              int is_multi, const uint64_t* h_sum, int partial, const uint64_t* const* lin_ptrs, int cont) {
+        c = ctx;
+        n_terms = nt; n = cn = n_entries; n_rounds = rounds; multi = is_multi;
+        meta.n_terms = n_terms;
+        meta.multi = (uint32_t)multi;
+        uint32_t rec = 0;
+        total = 0;
+        for (uint32_t p = 0; p < n_terms; ++p) {
+            if (sizes[p] < 1 || sizes[p] > CMP_MAX_K) return ZKHIP_ERR_ARG;
+            term_sizes[p] = meta.k[p] = sizes[p];
+            meta.rec_off[p] = rec;
+            rec += sizes[p] + 1;
+            total += sizes[p];
+        }
+        meta.rec = rec;
+        if (rec > CMP_MAX_REC) return ZKHIP_ERR_ARG;
+        // additive tables: numbered after the product tables
+        uint32_t n_lin = 0;
+        lin_cur.assign(n_terms, nullptr);
+        for (uint32_t p = 0; p < n_terms; ++p) {
+            meta.lin_tab[p] = ~0u;
+            if (lin_ptrs && lin_ptrs[p]) {
+                if (sizes[p] > 2) return ZKHIP_ERR_ARG;
+                lin_cur[p] = lin_ptrs[p];
+                meta.lin_tab[p] = total + n_lin++;
+            }
+        }
+        total_all = total + n_lin;
+        tail_len = composed_tail_len(total_all);
+        cur.assign(ptrs, ptrs + total);
+        // workspace: per table a ping (n/2) and a pong (n/4) buffer, then the state
+        per_table = (n / 2 + n / 4 + 2) * 32;
+        const size_t state_off = (total_all * per_table + 255) & ~(size_t)255;
+        const size_t bytes_off = state_off + ((sizeof(ComposedDev) + 255) & ~(size_t)255);
+        ZK_TRY(c->reserve_ws(bytes_off + (multi && !partial ? 32 * n : 0)));
+        ws = (char*)c->d_ws;
+        st = (ComposedDev*)(ws + state_off);
+        d_partials = c->small_u64(ZK_SMALL_PARTIALS);
+        d_rp = c->small_u64(ZK_SMALL_ROUNDPOLYS);
+        d_ch = c->small_u64(ZK_SMALL_CHALLENGES);
+        first = 1;
+        round = 0;
+        if (cont) {
+            ZK_HIP(c, hipMemcpyAsync(&st->transcript, saved_transcript(), sizeof(Sha256State), hipMemcpyDeviceToDevice, c->stream));
+            first = 0;
+        }
+        if (!multi) return ZKHIP_OK;
         // interpolation matrices for the degrees in use
         std::vector<uint64_t> mats((CMP_MAX_K + 1) * (CMP_MAX_K + 1) * (CMP_MAX_K + 1) * 4, 0);
         for (uint32_t p = 0; p < n_terms; ++p) {
-            const int d = (int)term_sizes[p];
+            const int d = (int)sizes[p];
             std::vector<zkhost::Fr> m = zkhost::interpolation_matrix(d);
             std::memcpy(&mats[(size_t)d * (CMP_MAX_K + 1) * (CMP_MAX_K + 1) * 4], m.data(), m.size() * 32);
         }
@@ -170,34 +179,23 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
             hs.fill = fill;
             hs.len = sha.len;
             ZK_HIP(c, hipMemcpyAsync(&st->transcript, &hs, sizeof(hs), hipMemcpyHostToDevice, c->stream));
-            ZK_HIP(c, hipStreamSynchronize(c->stream));   // hs / mats are stack/heap temporaries
             first = 2;
-        } else {
-            ZK_HIP(c, hipStreamSynchronize(c->stream));
         }
+        ZK_HIP(c, hipStreamSynchronize(c->stream));   // hs / mats are stack/heap temporaries
+        return ZKHIP_OK;
     }
-
-    // Rounds on tables too large for one workgroup's LDS: one launch per term (fold at the previous challenge + the
-    // round's sums) and one that closes the round.  From the round whose tables fit the LDS on, one launch finishes
-    // the proof.
-    const uint32_t tail_len = composed_tail_len(total_all);
-    std::vector<const uint64_t*> cur(ptrs, ptrs + total);
-    size_t cn = n;   // entries of the tables `cur` points to
-    for (uint32_t round = 0; round < n_vars; ++round) {
-        const bool fold = round > 0;
-        const size_t after = fold ? cn / 2 : cn;   // entries the round's sums run over
+    Sha256State* saved_transcript() const { return (Sha256State*)c->small_u64(ZK_SMALL_STATE); }   // handed from call to call (cont)
+    bool folds() const { return round > 0; }
+    size_t after() const { return folds() ? cn / 2 : cn; }   // entries the current round's sums run over
+    CloseArgs close_args() const {
         CloseArgs ca = {};
         ca.meta = meta; ca.st = st; ca.round = round; ca.first = first; ca.round_out = d_rp; ca.challenges = d_ch;
-        if (after <= tail_len) {
-            TailTables tt = {};
-            for (uint32_t q = 0; q < total; ++q) tt.in[q] = cur[q];
-            for (uint32_t p = 0; p < n_terms; ++p) if (lin_cur[p]) tt.in[meta.lin_tab[p]] = lin_cur[p];
-            ZK_TRY(c->allow_big_lds((const void*)composed_tail_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
-            ProfScope ps(c, "composed_tail", 0.0);
-            hipLaunchKernelGGL(composed_tail_kernel, dim3(1), dim3(CMP_TAIL_BLOCK), total_all * after * 32, c->stream, tt, total_all, (uint32_t)after,
-                               fold ? 1u : 0u, fold ? d_ch + 4 * (round - 1) : nullptr, ca, n_vars - round);
-            break;
-        }
+        return ca;
+    }
+    // The round on tables too large for one workgroup's LDS, first part: one launch per term (fold at the previous
+    // challenge + the round's sums, one record per workgroup in d_partials).  Returns the number of records.
+    int round_sums(int* n_records) {
+        const bool fold = folds();
         const size_t work = fold ? cn / 4 : cn / 2;
         const int grid = mle_grid(work ? work : 1);
         uint32_t off = 0;
@@ -224,24 +222,76 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
             off += term_sizes[p];
         }
         if (fold) cn /= 2;
-        hipLaunchKernelGGL(composed_close_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_partials, (uint32_t)grid, ca);
+        *n_records = grid;
+        return ZKHIP_OK;
+    }
+    // second part: sum the records (the workgroups' here, the ranks' in the sharded protocol) and close the round
+    void close(const uint64_t* records, uint32_t n_records) {
+        hipLaunchKernelGGL(composed_close_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, records, n_records, close_args());
         first = 0;
+        ++round;
     }
-    ZK_HIP(c, hipGetLastError());
-    if (multi) ZK_HIP(c, hipMemcpyAsync(saved, &st->transcript, sizeof(Sha256State), hipMemcpyDeviceToDevice, c->stream));
-    std::vector<uint64_t> h_rp(64 * (size_t)n_vars);
-    ZK_HIP(c, hipMemcpyAsync(h_rp.data(), d_rp, 64 * 8 * (size_t)n_vars, hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(c, hipMemcpyAsync(h_challenges, d_ch, 32 * (size_t)n_vars, hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(c, hipStreamSynchronize(c->stream));
-    for (uint32_t r = 0; r < n_vars; ++r) {
-        if (!multi) {
-            std::memcpy(h_round_polys + (size_t)r * (term_sizes[0] + 1) * 4, &h_rp[64 * r], (term_sizes[0] + 1) * 32);
-        } else {
-            h_lens[r] = (uint32_t)h_rp[64 * r];
-            std::memcpy(h_round_polys + (size_t)r * CMP_MAX_MONO * 8, &h_rp[64 * r + 8], CMP_MAX_MONO * 64);
+    // all remaining rounds in one launch, on tables of m = after() entries that fit the LDS (fold: they are still to be
+    // folded at the previous challenge while loading)
+    int tail(const TailTables& tt, uint32_t m, bool fold) {
+        ZK_TRY(c->allow_big_lds((const void*)composed_tail_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
+        ProfScope ps(c, "composed_tail", 0.0);
+        hipLaunchKernelGGL(composed_tail_kernel, dim3(1), dim3(CMP_TAIL_BLOCK), (size_t)total_all * m * 32, c->stream, tt, total_all, m,
+                           fold ? 1u : 0u, fold ? d_ch + 4 * (round - 1) : nullptr, close_args(), n_rounds - round);
+        round = n_rounds;
+        return ZKHIP_OK;
+    }
+    TailTables current_tables() const {
+        TailTables tt = {};
+        for (uint32_t q = 0; q < total; ++q) tt.in[q] = cur[q];
+        for (uint32_t p = 0; p < n_terms; ++p) if (lin_cur[p]) tt.in[meta.lin_tab[p]] = lin_cur[p];
+        return tt;
+    }
+    // round polynomials and challenges to the host, in the layouts of the C ABI
+    int collect(uint32_t* h_lens, uint64_t* h_round_polys, uint64_t* h_challenges) {
+        ZK_HIP(c, hipGetLastError());
+        if (multi) ZK_HIP(c, hipMemcpyAsync(saved_transcript(), &st->transcript, sizeof(Sha256State), hipMemcpyDeviceToDevice, c->stream));
+        std::vector<uint64_t> h_rp(64 * (size_t)n_rounds);
+        ZK_HIP(c, hipMemcpyAsync(h_rp.data(), d_rp, 64 * 8 * (size_t)n_rounds, hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(c, hipMemcpyAsync(h_challenges, d_ch, 32 * (size_t)n_rounds, hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(c, hipStreamSynchronize(c->stream));
+        for (uint32_t r = 0; r < n_rounds; ++r) {
+            if (!multi) {
+                std::memcpy(h_round_polys + (size_t)r * (term_sizes[0] + 1) * 4, &h_rp[64 * r], (term_sizes[0] + 1) * 32);
+            } else {
+                h_lens[r] = (uint32_t)h_rp[64 * r];
+                std::memcpy(h_round_polys + (size_t)r * CMP_MAX_MONO * 8, &h_rp[64 * r + 8], CMP_MAX_MONO * 64);
+            }
         }
+        return ZKHIP_OK;
     }
-    return ZKHIP_OK;
+};
+
+static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes, uint32_t n_terms,
+                               size_t n, int multi, const uint64_t* h_sum, int partial, uint32_t* h_lens,
+                               uint64_t* h_round_polys, uint64_t* h_challenges, const uint64_t* const* lin_ptrs = nullptr,
+                               int cont = 0) {
+    if (!c || !ptrs || !term_sizes) return ZKHIP_ERR_ARG;
+    if (n_terms == 0 || n_terms > CMP_MAX_TERMS) return ZKHIP_ERR_ARG;
+    if (!is_pow2(n)) return ZKHIP_ERR_SHAPE;
+    const uint32_t n_vars = log2_exact(n);
+    if (n_vars > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
+    if (n_vars == 0) return ZKHIP_OK;   // `for _ in 0..n_vars` never runs
+    if (!h_round_polys || !h_challenges || (multi && ((!h_sum && !cont) || !h_lens))) return ZKHIP_ERR_ARG;
+    ZK_TRY(c->activate());
+    ComposedRun run;
+    ZK_TRY(run.setup(c, ptrs, term_sizes, n_terms, n, n_vars, multi, h_sum, partial, lin_ptrs, cont));
+    // From the round whose tables fit the LDS on, one launch finishes the proof.
+    while (run.round < n_vars) {
+        if (run.after() <= run.tail_len) {
+            ZK_TRY(run.tail(run.current_tables(), (uint32_t)run.after(), run.folds()));
+            break;
+        }
+        int grid = 0;
+        ZK_TRY(run.round_sums(&grid));
+        run.close(run.d_partials, (uint32_t)grid);
+    }
+    return run.collect(h_lens, h_round_polys, h_challenges);
 }
 
 // internal entry for gkr.hip (same shared object; not part of the C ABI)
@@ -261,3 +311,111 @@ extern "C" int zkhip_multi_composed_prove(zkhip_ctx* c, const uint64_t* const* p
     return composed_prove_impl(c, ptrs, term_sizes, n_terms, n, 1, h_sum, partial, h_lens, h_round_polys, h_challenges);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// split-phase session: the same prover with its tables sharded over several GPUs (include/zkhip.h, zkhip_mc_*)
+// ---------------------------------------------------------------------------------------
+struct zkhip_mc_state {
+    ComposedRun run;
+    uint32_t world = 1;
+    bool sums_pending = false;   // round_sums done, absorb not yet
+};
+
+extern "C" int zkhip_mc_begin(zkhip_ctx* c, const uint64_t* const* d_local_tables, const uint32_t* term_sizes, uint32_t n_terms,
+                              size_t n_local, uint32_t world, int multi, const uint64_t* h_sum, zkhip_mc_state** out) {
+    if (!c || !d_local_tables || !term_sizes || !out) return ZKHIP_ERR_ARG;
+    if (n_terms == 0 || n_terms > CMP_MAX_TERMS || (!multi && n_terms != 1) || (multi && !h_sum)) return ZKHIP_ERR_ARG;
+    if (!is_pow2(n_local) || world == 0 || !is_pow2(world)) return ZKHIP_ERR_SHAPE;
+    const uint32_t rounds = log2_exact(n_local) + log2_exact(world);
+    if (rounds == 0 || rounds > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    zkhip_mc_state* s = new (std::nothrow) zkhip_mc_state();
+    if (!s) return ZKHIP_ERR_NOMEM;
+    s->world = world;
+    const int rc = s->run.setup(c, d_local_tables, term_sizes, n_terms, n_local, rounds, multi, h_sum, 1, nullptr, 0);
+    if (rc != ZKHIP_OK) {
+        delete s;
+        return rc;
+    }
+    if (world > s->run.tail_len) {   // shards of one entry per table must fit the replicated tail when gathered
+        delete s;
+        return ZKHIP_ERR_SHAPE;
+    }
+    *out = s;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_mc_record_len(zkhip_mc_state* s, uint32_t* rec, uint32_t* n_tables) {
+    if (!s || !rec) return ZKHIP_ERR_ARG;
+    *rec = s->run.meta.rec;
+    if (n_tables) *n_tables = s->run.total_all;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_mc_local_len(zkhip_mc_state* s, size_t* n_now) {
+    if (!s || !n_now) return ZKHIP_ERR_ARG;
+    *n_now = s->run.after();
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_mc_tail_capacity(zkhip_mc_state* s, uint32_t* cap) {
+    if (!s || !cap) return ZKHIP_ERR_ARG;
+    *cap = s->run.tail_len;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_mc_round_sums(zkhip_mc_state* s, uint64_t* d_out) {
+    if (!s || !d_out) return ZKHIP_ERR_ARG;
+    ComposedRun& run = s->run;
+    if (s->sums_pending || run.round >= run.n_rounds || run.after() < 2) return ZKHIP_ERR_ARG;
+    ZK_TRY(run.c->activate());
+    int grid = 0;
+    ZK_TRY(run.round_sums(&grid));
+    hipLaunchKernelGGL(composed_reduce_kernel, dim3(1), dim3(MLE_BLOCK), 0, run.c->stream, run.d_partials, (uint32_t)grid, run.meta.rec, d_out);
+    ZK_HIP(run.c, hipGetLastError());
+    s->sums_pending = true;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_mc_absorb(zkhip_mc_state* s, const uint64_t* d_gathered, uint32_t world) {
+    if (!s || !d_gathered || world != s->world || !s->sums_pending) return ZKHIP_ERR_ARG;
+    ZK_TRY(s->run.c->activate());
+    s->run.close(d_gathered, world);
+    ZK_HIP(s->run.c, hipGetLastError());
+    s->sums_pending = false;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_mc_local_tables(zkhip_mc_state* s, uint64_t* d_out) {
+    if (!s || !d_out || s->sums_pending) return ZKHIP_ERR_ARG;
+    ComposedRun& run = s->run;
+    ZK_TRY(run.c->activate());
+    const size_t m = run.after();
+    const TailTables tt = run.current_tables();
+    for (uint32_t q = 0; q < run.total_all; ++q) {
+        uint64_t* dst = d_out + (size_t)q * m * 4;
+        if (run.folds()) {   // the fold at the last challenge is still pending (the next round's kernel would have done it)
+            hipLaunchKernelGGL(fold_kernel<false>, dim3(mle_grid(m)), dim3(MLE_BLOCK), 0, run.c->stream, tt.in[q], dst, m, log2_exact(m),
+                               run.d_ch + 4 * (run.round - 1), FrArg{}, (uint64_t*)nullptr);
+        } else {
+            ZK_HIP(run.c, hipMemcpyAsync(dst, tt.in[q], m * 32, hipMemcpyDeviceToDevice, run.c->stream));
+        }
+    }
+    ZK_HIP(run.c, hipGetLastError());
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_mc_tail(zkhip_mc_state* s, const uint64_t* d_tables, uint32_t m) {
+    if (!s || !d_tables || s->sums_pending) return ZKHIP_ERR_ARG;
+    ComposedRun& run = s->run;
+    if (!is_pow2(m) || m > run.tail_len || m != run.after() * s->world || run.round + log2_exact(m) != run.n_rounds) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(run.c->activate());
+    TailTables tt = {};
+    for (uint32_t q = 0; q < run.total_all; ++q) tt.in[q] = d_tables + (size_t)q * m * 4;
+    ZK_TRY(run.tail(tt, m, false));
+    ZK_HIP(run.c, hipGetLastError());
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_mc_finish(zkhip_mc_state* s, uint32_t* h_lens, uint64_t* h_round_polys, uint64_t* h_challenges) {
+    if (!s) return ZKHIP_ERR_ARG;
+    int rc = ZKHIP_OK;
+    if (h_round_polys || h_challenges) {
+        if (!h_round_polys || !h_challenges || (s->run.multi && !h_lens) || s->run.round != s->run.n_rounds) rc = ZKHIP_ERR_ARG;
+        else if ((rc = s->run.c->activate()) == ZKHIP_OK) rc = s->run.collect(h_lens, h_round_polys, h_challenges);
+    }
+    delete s;
+    return rc;
+}

@@ -294,6 +294,18 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_close_kernel(const 
     close_round(sh, ca.meta, ca.st, &ca.st->transcript, ca.round, ca.first, ca.round_out, ca.challenges);
 }
 
+// the records of a round summed into one (what a rank contributes to the exchange of the sharded protocol)
+static __global__ __launch_bounds__(MLE_BLOCK) void composed_reduce_kernel(const uint64_t* __restrict__ partials, uint32_t n_partials,
+                                                                    uint32_t rec, uint64_t* __restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t v = wave; v < rec; v += MLE_BLOCK / 64) {
+        Fr s = Fr::zero();
+        for (uint32_t b = lane; b < n_partials; b += 64) s = s + load_fr(partials, (size_t)b * rec + v);
+        s = wave_reduce_fr(s);
+        if (lane == 0) store_fr(out, v, s);
+    }
+}
+
 // sum_j prod_k table_k[j]  (ComposedSumcheck::calculate_poly_sum composed_sumcheck.rs:28-30): one partial per workgroup
 template <int K>
 static __global__ __launch_bounds__(MLE_BLOCK) void product_sum_kernel(TablePtrs tp, size_t n, uint64_t* __restrict__ partials) {

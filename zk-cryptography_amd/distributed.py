@@ -164,6 +164,123 @@ class ShardedSumcheck:
         return e.finish(total_rounds)
 
 
+class HipComposedEngine:
+    """Split-phase composed / multi-composed prover state on this rank's GPU (zkhip_mc_* in include/zkhip.h).
+
+    terms: list of lists of int64 [n_local, 4] CUDA tensors (this rank's shard of every table, term after term);
+    multi = False: ComposedSumcheck (one term);  multi = True: MultiComposedSumcheckProver::prove_partial with the
+    claimed sum of the whole tables."""
+
+    def __init__(self, terms, world, multi, claimed_sum=None, ctx=None):
+        import torch
+        self.torch = torch
+        self.tables = [t for term in terms for t in term]      # kept alive for the duration
+        self.sizes = [len(term) for term in terms]
+        self.multi = bool(multi)
+        self.device = self.tables[0].device
+        self.ctx = ctx or N.Context.get(self.device.index)     # one session per context at a time
+        self.st = C.c_void_p()
+        cs = np.ascontiguousarray(claimed_sum, dtype=np.uint64).reshape(4) if claimed_sum is not None else None
+        self.sum = cs
+        ptrs = (C.c_void_p * len(self.tables))(*[t.data_ptr() for t in self.tables])
+        N.check(N.lib().zkhip_mc_begin(self.ctx.handle, ptrs, (C.c_uint32 * len(self.sizes))(*self.sizes),
+                                       C.c_uint32(len(self.sizes)), C.c_size_t(self.tables[0].shape[0]), C.c_uint32(world),
+                                       C.c_int(1 if multi else 0), cs.ctypes.data_as(C.c_void_p) if cs is not None else None,
+                                       C.byref(self.st)), "mc_begin")
+        rec, nt = C.c_uint32(0), C.c_uint32(0)
+        N.check(N.lib().zkhip_mc_record_len(self.st, C.byref(rec), C.byref(nt)), "mc_record_len")
+        self.rec, self.n_tables = rec.value, nt.value
+
+    def new_buffer(self, *shape):
+        return self.torch.empty(shape, dtype=self.torch.int64, device=self.device)
+
+    def record_len(self):
+        return self.rec
+
+    def table_count(self):
+        return self.n_tables
+
+    def local_len(self):
+        n = C.c_size_t(0)
+        N.check(N.lib().zkhip_mc_local_len(self.st, C.byref(n)), "mc_local_len")
+        return n.value
+
+    def tail_capacity(self):
+        cap = C.c_uint32(0)
+        N.check(N.lib().zkhip_mc_tail_capacity(self.st, C.byref(cap)), "mc_tail_capacity")
+        return cap.value
+
+    def round_sums(self, out):
+        N.check(N.lib().zkhip_mc_round_sums(self.st, N.ptr(out)), "mc_round_sums")
+
+    def absorb(self, gathered, world):
+        N.check(N.lib().zkhip_mc_absorb(self.st, N.ptr(gathered), C.c_uint32(world)), "mc_absorb")
+
+    def local_tables(self, out):
+        N.check(N.lib().zkhip_mc_local_tables(self.st, N.ptr(out)), "mc_local_tables")
+
+    def tail(self, tables, m):
+        N.check(N.lib().zkhip_mc_tail(self.st, N.ptr(tables), C.c_uint32(m)), "mc_tail")
+
+    def finish(self, n_rounds):
+        """-> (round polynomials, challenges [n_rounds, 4]); round polynomials are uint64 [n_rounds, K+1, 4] evaluations
+        (ComposedSumcheck) or a list of (coeffs [m, 4], pows [m, 4]) pairs (multi-composed)."""
+        ch = np.empty((n_rounds, 4), dtype=np.uint64)
+        if not self.multi:
+            rp = np.empty((n_rounds, self.sizes[0] + 1, 4), dtype=np.uint64)
+            lens = None
+        else:
+            rp = np.zeros((n_rounds, 7, 2, 4), dtype=np.uint64)
+            lens = np.zeros(n_rounds, dtype=np.uint32)
+        N.check(N.lib().zkhip_mc_finish(self.st, lens.ctypes.data_as(C.c_void_p) if lens is not None else None,
+                                        rp.ctypes.data_as(C.c_void_p), ch.ctypes.data_as(C.c_void_p)), "mc_finish")
+        self.st = None
+        if not self.multi:
+            return rp, ch
+        return [(rp[r, : lens[r], 0].copy(), rp[r, : lens[r], 1].copy()) for r in range(n_rounds)], ch
+
+
+class ShardedComposedSumcheck:
+    """ComposedSumcheck::prove (composed_sumcheck.rs:32-67) / MultiComposedSumcheckProver::prove_partial
+    (multi_composed_sumcheck.rs:56-121) over tables sharded by low index bits ("GKR tables").
+
+    One exchange per round: a record of (K_p + 1) partial sums per term (a product of tables does not commute with block
+    sums, so the stage form of the basic prover does not apply).  Every rank returns what engine.finish yields -- the
+    round polynomials and challenges a single-GPU / reference prover produces on the whole tables."""
+
+    def __init__(self, engine, world=1, group=None, dist=None):
+        self.e = engine
+        self.world = world
+        self.group = group
+        self.dist = dist
+        if world & (world - 1):
+            raise AssertionError("world size must be a power of two (the tables have 2^n entries)")
+
+    def prove(self):
+        e, world = self.e, self.world
+        n_local = e.local_len()
+        total_rounds = (n_local * world).bit_length() - 1
+        cap = e.tail_capacity()
+        rec = e.record_len()
+        if n_local * world > cap and n_local > 1:
+            send = e.new_buffer(rec, 4)
+            recv = e.new_buffer(world, rec, 4)
+            while n_local * world > cap and n_local > 1:
+                e.round_sums(send)                                            # fold at the previous challenge + partial sums
+                _all_gather(self.dist, self.group, recv, send, world)         # RCCL all-gather over xGMI, <= 768 B per rank
+                e.absorb(recv, world)                                         # local modular add + transcript -> challenge
+                n_local //= 2
+        if n_local * world > 1:
+            nt = e.table_count()
+            mine = e.new_buffer(nt, n_local, 4)
+            e.local_tables(mine)
+            gathered = e.new_buffer(world, nt, n_local, 4)
+            _all_gather(self.dist, self.group, gathered, mine, world)
+            full = gathered.permute(1, 2, 0, 3).contiguous()                  # entry j*world + g <- rank g, local j
+            e.tail(full.view(nt, n_local * world, 4), n_local * world)
+        return e.finish(total_rounds)
+
+
 def sharded_commit(local_commit, sum_affine, world=1, group=None, dist=None, device=None):
     """KZG commit over (scalars, SRS) sharded across ranks.
 
