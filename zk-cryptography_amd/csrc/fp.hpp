@@ -35,6 +35,66 @@ __device__ __forceinline__ void mac96_s(uint64_t& lo, uint32_t& hi, uint32_t s_c
         : "vcc");
 }
 
+
+// ---- carry chains of 8 limbs (Fr), one asm statement each so that VCC links the whole chain ------------------------
+// (The same loops written with 64-bit C arithmetic compile to ~100 instructions per modular addition -- v_lshl_add_u64 plus
+// moves that rebuild the carries -- instead of these 8 + 8 + 8.)
+// r += b   (no carry out of the top limb by construction: the moduli leave spare bits)
+__device__ __forceinline__ void add_chain8(uint32_t (&r)[8], const uint32_t (&b)[8]) {
+    asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %10, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %11, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %4, %12, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %14, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %7, %15, vcc"
+        : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+        : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7])
+        : "vcc");
+}
+// r = (r >= p) ? r - p : r      (p in VGPRs: a carry-in from VCC already takes the instruction's one scalar operand)
+__device__ __forceinline__ void cond_sub_chain8(uint32_t (&r)[8], const uint32_t (&p)[8]) {
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+    asm("v_sub_co_u32 %8, vcc, %0, %16\n\t"
+        "v_subb_co_u32 %9, vcc, %1, %17, vcc\n\t"
+        "v_subb_co_u32 %10, vcc, %2, %18, vcc\n\t"
+        "v_subb_co_u32 %11, vcc, %3, %19, vcc\n\t"
+        "v_subb_co_u32 %12, vcc, %4, %20, vcc\n\t"
+        "v_subb_co_u32 %13, vcc, %5, %21, vcc\n\t"
+        "v_subb_co_u32 %14, vcc, %6, %22, vcc\n\t"
+        "v_subb_co_u32 %15, vcc, %7, %23, vcc\n\t"
+        "v_cndmask_b32 %0, %8, %0, vcc\n\t"
+        "v_cndmask_b32 %1, %9, %1, vcc\n\t"
+        "v_cndmask_b32 %2, %10, %2, vcc\n\t"
+        "v_cndmask_b32 %3, %11, %3, vcc\n\t"
+        "v_cndmask_b32 %4, %12, %4, vcc\n\t"
+        "v_cndmask_b32 %5, %13, %5, vcc\n\t"
+        "v_cndmask_b32 %6, %14, %6, vcc\n\t"
+        "v_cndmask_b32 %7, %15, %7, vcc"
+        : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+        : "vcc");
+}
+// r -= b, returns the borrow as a mask (all ones when r < b)
+__device__ __forceinline__ uint32_t sub_chain8(uint32_t (&r)[8], const uint32_t (&b)[8]) {
+    uint32_t mask;
+    asm("v_sub_co_u32 %0, vcc, %0, %9\n\t"
+        "v_subb_co_u32 %1, vcc, %1, %10, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %2, %11, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %3, %12, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %4, %13, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %5, %14, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %6, %15, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %7, %16, vcc\n\t"
+        "v_cndmask_b32 %8, 0, -1, vcc"
+        : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "=&v"(mask)
+        : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7])
+        : "vcc");
+    return mask;
+}
+
 }  // namespace zk
 #include "fp_mul_gen.hpp"
 namespace zk {
@@ -71,6 +131,13 @@ struct Fp {
 
     // r = a - p if a >= p (a < 2p)
     __device__ __forceinline__ void reduce_once() {
+        if constexpr (N == 8) {
+            uint32_t p[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p[i] = P::p(i);
+            cond_sub_chain8(l, p);
+            return;
+        }
         uint32_t t[N];
         uint64_t borrow = 0;
 #pragma unroll
@@ -86,6 +153,12 @@ struct Fp {
     }
 
     __device__ __forceinline__ friend Fp operator+(const Fp& a, const Fp& b) {
+        if constexpr (N == 8) {
+            Fp r = a;
+            add_chain8(r.l, b.l);
+            r.reduce_once();
+            return r;
+        }
         Fp r;
         uint64_t c = 0;
 #pragma unroll
@@ -99,6 +172,15 @@ struct Fp {
         return r;
     }
     __device__ __forceinline__ friend Fp operator-(const Fp& a, const Fp& b) {
+        if constexpr (N == 8) {
+            Fp r = a;
+            const uint32_t mask = sub_chain8(r.l, b.l);
+            uint32_t pm[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pm[i] = P::p(i) & mask;   // add p back when a < b
+            add_chain8(r.l, pm);
+            return r;
+        }
         Fp r;
         uint64_t borrow = 0;
 #pragma unroll
