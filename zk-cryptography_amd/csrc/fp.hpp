@@ -95,6 +95,72 @@ __device__ __forceinline__ uint32_t sub_chain8(uint32_t (&r)[8], const uint32_t 
     return mask;
 }
 
+// ---- the same for 12 limbs (Fq) ----
+__device__ __forceinline__ void add_chain12(uint32_t (&r)[12], const uint32_t (&b)[12]) {
+    asm("v_add_co_u32 %0, vcc, %0, %12\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %13, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %14, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %15, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %4, %16, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %5, %17, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %18, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %7, %19, vcc\n\t"
+        "v_addc_co_u32 %8, vcc, %8, %20, vcc\n\t"
+        "v_addc_co_u32 %9, vcc, %9, %21, vcc\n\t"
+        "v_addc_co_u32 %10, vcc, %10, %22, vcc\n\t"
+        "v_addc_co_u32 %11, vcc, %11, %23, vcc"
+        : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11])
+        : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]), "v"(b[9]), "v"(b[10]), "v"(b[11])
+        : "vcc");
+}
+__device__ __forceinline__ uint32_t sub_chain12(uint32_t (&r)[12], const uint32_t (&b)[12]) {
+    uint32_t mask;
+    asm("v_sub_co_u32 %0, vcc, %0, %13\n\t"
+        "v_subb_co_u32 %1, vcc, %1, %14, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %2, %15, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %3, %16, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %4, %17, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %5, %18, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %6, %19, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %7, %20, vcc\n\t"
+        "v_subb_co_u32 %8, vcc, %8, %21, vcc\n\t"
+        "v_subb_co_u32 %9, vcc, %9, %22, vcc\n\t"
+        "v_subb_co_u32 %10, vcc, %10, %23, vcc\n\t"
+        "v_subb_co_u32 %11, vcc, %11, %24, vcc\n\t"
+        "v_cndmask_b32 %12, 0, -1, vcc"
+        : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "=&v"(mask)
+        : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]), "v"(b[9]), "v"(b[10]), "v"(b[11])
+        : "vcc");
+    return mask;
+}
+// t = r - p in two statements of 6 limbs (36 operands do not fit one), the borrow handed over in a VGPR; returns the
+// final borrow as a mask (all ones when r < p)
+__device__ __forceinline__ uint32_t sub_to_chain12(uint32_t (&t)[12], const uint32_t (&r)[12], const uint32_t (&p)[12]) {
+    uint32_t bor, mask;
+    asm("v_sub_co_u32 %0, vcc, %7, %13\n\t"
+        "v_subb_co_u32 %1, vcc, %8, %14, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %9, %15, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %10, %16, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %11, %17, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %12, %18, vcc\n\t"
+        "v_cndmask_b32 %6, 0, 1, vcc"
+        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(bor)
+        : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5])
+        : "vcc");
+    asm("v_cmp_ne_u32 vcc, 0, %7\n\t"
+        "v_subb_co_u32 %0, vcc, %8, %14, vcc\n\t"
+        "v_subb_co_u32 %1, vcc, %9, %15, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %10, %16, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %11, %17, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %12, %18, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %13, %19, vcc\n\t"
+        "v_cndmask_b32 %6, 0, -1, vcc"
+        : "=&v"(t[6]), "=&v"(t[7]), "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]), "=&v"(mask)
+        : "v"(bor), "v"(r[6]), "v"(r[7]), "v"(r[8]), "v"(r[9]), "v"(r[10]), "v"(r[11]), "v"(p[6]), "v"(p[7]), "v"(p[8]), "v"(p[9]), "v"(p[10]), "v"(p[11])
+        : "vcc");
+    return mask;
+}
+
 }  // namespace zk
 #include "fp_mul_gen.hpp"
 namespace zk {
@@ -137,6 +203,14 @@ struct Fp {
             for (int i = 0; i < 8; ++i) p[i] = P::p(i);
             cond_sub_chain8(l, p);
             return;
+        } else if constexpr (N == 12) {
+            uint32_t p[12], t[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) p[i] = P::p(i);
+            const uint32_t keep = sub_to_chain12(t, l, p);   // all ones: l < p, keep l
+#pragma unroll
+            for (int i = 0; i < 12; ++i) l[i] = keep ? l[i] : t[i];
+            return;
         }
         uint32_t t[N];
         uint64_t borrow = 0;
@@ -156,6 +230,11 @@ struct Fp {
         if constexpr (N == 8) {
             Fp r = a;
             add_chain8(r.l, b.l);
+            r.reduce_once();
+            return r;
+        } else if constexpr (N == 12) {
+            Fp r = a;
+            add_chain12(r.l, b.l);
             r.reduce_once();
             return r;
         }
@@ -179,6 +258,14 @@ struct Fp {
 #pragma unroll
             for (int i = 0; i < 8; ++i) pm[i] = P::p(i) & mask;   // add p back when a < b
             add_chain8(r.l, pm);
+            return r;
+        } else if constexpr (N == 12) {
+            Fp r = a;
+            const uint32_t mask = sub_chain12(r.l, b.l);
+            uint32_t pm[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) pm[i] = P::p(i) & mask;
+            add_chain12(r.l, pm);
             return r;
         }
         Fp r;
