@@ -131,6 +131,20 @@ int zkhip_gkr_prove(zkhip_ctx *ctx, uint32_t n_layers, const size_t *h_n_gates, 
                     const size_t *h_layer_len, uint64_t *h_sums, uint32_t *h_n_rounds, uint32_t *h_round_poly_lens,
                     uint64_t *h_round_polys, uint64_t *h_wb, uint64_t *h_wc, uint64_t *h_w0, uint64_t *h_challenges);
 
+/* Device-resident circuit: the gate arrays and their groupings by first / second input (what the layer prover reads) are
+ * validated, built and uploaded once; a prover that proves many inputs on one circuit then pays no per-proof host work
+ * (zkhip_gkr_prove spends about half of a depth-20 proof there).  Layer l holds h_n_gates[l] <= 2^l gates (2 at l = 0) whose
+ * inputs label the 2^(l+1) values below it (circuit/src/circuit.rs:59-97); a label out of range is reported as ZKHIP_ERR_INDEX by
+ * the prover when it reaches that layer (where the reference panics), after the shape checks of the layers before it.
+ * zkhip_gkr_prove_circuit = zkhip_gkr_prove on that circuit (same outputs, same errors for the tables). */
+typedef struct zkhip_circuit zkhip_circuit;
+int zkhip_circuit_create(zkhip_ctx *ctx, uint32_t n_layers, const size_t *h_n_gates, const uint8_t *h_gate_type,
+                         const uint32_t *h_in0, const uint32_t *h_in1, zkhip_circuit **out);
+void zkhip_circuit_destroy(zkhip_circuit *circuit);
+int zkhip_gkr_prove_circuit(zkhip_circuit *circuit, const uint64_t *const *h_layer_ptrs, const size_t *h_layer_len,
+                            uint64_t *h_sums, uint32_t *h_n_rounds, uint32_t *h_round_poly_lens, uint64_t *h_round_polys,
+                            uint64_t *h_wb, uint64_t *h_wc, uint64_t *h_w0, uint64_t *h_challenges);
+
 /* ---- basic sumcheck prover (sumcheck/src/sumcheck.rs:25-61) -------------------------- */
 /* Block sums of a table: d_out[(2^log_blocks + 1) * 4] = the sums of its 2^log_blocks equal consecutive blocks
  * followed by the total (= Sumcheck::poly_sum, sumcheck.rs:25-27, which also goes to h_total[4] if non-NULL).

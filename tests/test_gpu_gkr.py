@@ -153,3 +153,31 @@ def test_gkr_beyond_the_dense_tables(zk, ora, depth):
     bad = inp.copy()
     bad[5, 0] ^= np.uint64(1)
     assert not ora.gkr_verify(layers, bad, op)
+
+
+def test_gkr_device_circuit_reused_across_inputs(zk, ora):
+    """One Circuit, several inputs: the device-resident circuit (zkhip_circuit_create) is built on the first proof and reused;
+    every proof must still be the oracle's for its input.  A bad gate label surfaces when the prover reaches its layer."""
+    layers = random_circuit(6)
+    circuit = zk.Circuit.from_tuples(layers)
+    handles = []
+    for seed in (1, 2, 3):
+        inp = ora.random_fr(2 ** 6, 700 + seed)
+        ev = circuit.evaluation(inp)
+        proof = zk.GKRProtocol.prove(circuit, ev)
+        handles.append(circuit._device.handle.value)
+        want = ora.gkr_prove(layers, ora.circuit_evaluation(layers, inp))
+        for k, sp in enumerate(proof.sumcheck_proofs):
+            w_sum, w_rps, w_wb, w_wc = want.layer(k)
+            assert np.array_equal(sp.sum, w_sum) and sp.to_bytes() == ora.multi_composed_proof_bytes(w_rps)
+            assert np.array_equal(proof.wb_s[k], w_wb) and np.array_equal(proof.wc_s[k], w_wc)
+        assert ora.gkr_verify(layers, inp, _to_oracle_proof(zk, ora, proof))
+    assert len(set(handles)) == 1
+    # an out-of-range label in layer 2 (inputs of layer 2 label 8 values): the reference indexes out of bounds there
+    bad = [list(layer) for layer in random_circuit(3)]
+    g = bad[2][1]
+    bad[2][1] = (g[0], 8, g[2])
+    ok = zk.Circuit.from_tuples(random_circuit(3))
+    ev = ok.evaluation(ora.random_fr(8, 9))
+    with pytest.raises(IndexError):
+        zk.GKRProtocol.prove(zk.Circuit.from_tuples(bad), ev)

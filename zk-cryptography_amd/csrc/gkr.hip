@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "ctx.hpp"
@@ -144,33 +145,27 @@ static void group_gates(const uint32_t* key, size_t n_gates, size_t n_rows, std:
 // device scratch of one layer (carved from the context's aux buffer)
 struct LayerScratch {
     uint64_t *wg, *ha0, *ha1, *hm, *equ, *aa, *am, *t1, *t2;
+};
+// one layer of a device-resident circuit: the gate arrays and their two CSR groupings (by in0 and by in1)
+struct LayerDev {
+    size_t n_gates, w_len;   // w_len = 2^(l + 1) entries of the layer's input table
+    bool bad_label;          // a gate label out of range: reported when the prover reaches the layer, as the reference panics there
     uint32_t *csr0, *csr1, *in0, *in1;
     uint8_t* type;
 };
 
 // One layer: the sumcheck of generate_layer_one_prove_sumcheck (gkr/src/utils.rs:27-55) / the loop body of
 // GKRProtocol::prove (protocol.rs:64-107) in the linear-time form described above, then w_b, w_c, alpha, beta, the next claim.
-int layer_prove(zkhip_ctx* c, const uint8_t* gate_type, const uint32_t* in0, const uint32_t* in1, size_t n_gates, uint32_t l,
-                const uint64_t* d_w, size_t w_len, const LayerScratch& sc, zkhost::Fr& claimed, zkhost::Transcript& tr, const LayerOut& out,
+int layer_prove(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_w, size_t w_len, const LayerScratch& sc,
+                zkhost::Fr& claimed, zkhost::Transcript& tr, const LayerOut& out,
                 uint32_t k, zkhost::Fr& alpha, zkhost::Fr& beta, std::vector<zkhost::Fr>& r_b, std::vector<zkhost::Fr>& r_c, bool two_points) {
     using namespace zk;
+    const size_t n_gates = ld.n_gates;
     const uint32_t s = log2_exact(w_len);                  // variables of b (and of c)
     const uint32_t n_gate_vars = l == 0 ? 1u : l;          // binary_string(a, layer_index) has at least one bit (circuit/src/utils.rs:27-33)
-    if (s != l + 1 || 2 * s > out.stride || s < 1) return ZKHIP_ERR_SHAPE;   // the wiring index has l + 1 bits for b and for c
+    if (s != l + 1 || w_len != ld.w_len || 2 * s > out.stride || s < 1) return ZKHIP_ERR_SHAPE;   // the wiring index has l + 1 bits for b and for c
     if (r_b.size() != n_gate_vars || (two_points && r_c.size() != n_gate_vars)) return ZKHIP_ERR_SHAPE;
-    for (size_t g = 0; g < n_gates; ++g)
-        if (in0[g] >= w_len || in1[g] >= w_len || (g >> n_gate_vars)) return ZKHIP_ERR_INDEX;   // add_evaluations[gate_decimal] out of bounds
-    // gates and their two groupings -> device
-    std::vector<uint32_t> csr0, csr1;
-    group_gates(in0, n_gates, w_len, csr0);
-    group_gates(in1, n_gates, w_len, csr1);
-    ZK_HIP(c, hipMemcpyAsync(sc.csr0, csr0.data(), 4 * csr0.size(), hipMemcpyHostToDevice, c->stream));
-    ZK_HIP(c, hipMemcpyAsync(sc.csr1, csr1.data(), 4 * csr1.size(), hipMemcpyHostToDevice, c->stream));
-    if (n_gates) {
-        ZK_HIP(c, hipMemcpyAsync(sc.in0, in0, 4 * n_gates, hipMemcpyHostToDevice, c->stream));
-        ZK_HIP(c, hipMemcpyAsync(sc.in1, in1, 4 * n_gates, hipMemcpyHostToDevice, c->stream));
-        ZK_HIP(c, hipMemcpyAsync(sc.type, gate_type, n_gates, hipMemcpyHostToDevice, c->stream));
-    }
+    if (ld.bad_label) return ZKHIP_ERR_INDEX;              // add_evaluations[gate_decimal] out of bounds (circuit.rs:73-93)
     PtsArg pb = {}, pc = {};
     std::memcpy(pb.v, r_b[0].l, 32 * r_b.size());
     if (two_points) std::memcpy(pc.v, r_c[0].l, 32 * r_c.size());
@@ -182,10 +177,9 @@ int layer_prove(zkhip_ctx* c, const uint8_t* gate_type, const uint32_t* in0, con
         hipLaunchKernelGGL(gkr_gate_weights_kernel, dim3(gg), dim3(MLE_BLOCK), 0, c->stream, (uint32_t)n_gates, n_gate_vars, pb, pc, av, bv,
                            two_points ? 1u : 0u, sc.wg);
     // ---- rounds over b
-    hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, sc.csr0, sc.csr0 + w_len + 1, sc.type, sc.in1, sc.wg, d_w,
+    hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr0, ld.csr0 + w_len + 1, ld.type, ld.in1, sc.wg, d_w,
                        (uint32_t)w_len, 1u, sc.ha0, sc.ha1, sc.hm);
     ZK_HIP(c, hipGetLastError());
-    ZK_HIP(c, hipStreamSynchronize(c->stream));            // csr0 / csr1 are host temporaries; the prover below reuses the workspace
     const uint32_t nv = 2 * s;
     uint64_t* polys = out.round_polys + (size_t)k * out.stride * GKR_MONO * 8;
     uint32_t* lens = out.lens + (size_t)k * out.stride;
@@ -206,7 +200,7 @@ int layer_prove(zkhip_ctx* c, const uint8_t* gate_type, const uint32_t* in0, con
     FrArg vu = {};
     std::memcpy(vu.v, eval_wb.l, 32);
     hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid(w_len)), dim3(MLE_BLOCK), 0, c->stream, pu, s, sc.equ);
-    hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, sc.csr1, sc.csr1 + w_len + 1, sc.type, sc.in0, sc.wg, sc.equ,
+    hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr1, ld.csr1 + w_len + 1, ld.type, ld.in0, sc.wg, sc.equ,
                        (uint32_t)w_len, 2u, sc.aa, (uint64_t*)nullptr, sc.am);
     hipLaunchKernelGGL(gkr_vu_tables_kernel, dim3(mle_grid(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_w, w_len, vu, sc.t1, sc.t2);
     ZK_HIP(c, hipGetLastError());
@@ -234,26 +228,103 @@ int layer_prove(zkhip_ctx* c, const uint8_t* gate_type, const uint32_t* in0, con
 
 }  // namespace
 
-extern "C" int zkhip_gkr_prove(zkhip_ctx* c, uint32_t n_layers, const size_t* h_n_gates, const uint8_t* h_gate_type,
-                               const uint32_t* h_in0, const uint32_t* h_in1, const uint64_t* const* h_layer_ptrs,
-                               const size_t* h_layer_len, uint64_t* h_sums, uint32_t* h_n_rounds, uint32_t* h_round_poly_lens,
-                               uint64_t* h_round_polys, uint64_t* h_wb, uint64_t* h_wc, uint64_t* h_w0, uint64_t* h_challenges) {
-    if (!c || !h_n_gates || !h_gate_type || !h_in0 || !h_in1 || !h_layer_ptrs || !h_layer_len || !h_sums || !h_n_rounds ||
-        !h_round_poly_lens || !h_round_polys || !h_wb || !h_wc || !h_w0)
+// ---- device-resident circuit ---------------------------------------------------------------------------------------
+struct zkhip_circuit {
+    zkhip_ctx* c = nullptr;
+    uint32_t n_layers = 0;
+    std::vector<LayerDev> layers;
+    void* d_mem = nullptr;
+};
+
+extern "C" void zkhip_circuit_destroy(zkhip_circuit* cir) {
+    if (!cir) return;
+    if (cir->d_mem && cir->c && cir->c->activate() == ZKHIP_OK) (void)hipFree(cir->d_mem);
+    delete cir;
+}
+
+extern "C" int zkhip_circuit_create(zkhip_ctx* c, uint32_t n_layers, const size_t* h_n_gates, const uint8_t* h_gate_type,
+                                    const uint32_t* h_in0, const uint32_t* h_in1, zkhip_circuit** out) {
+    if (!c || !h_n_gates || !h_gate_type || !h_in0 || !h_in1 || !out) return ZKHIP_ERR_ARG;
+    if (n_layers < 1 || 2 * n_layers > (uint32_t)ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;   // 2 (l + 1) sumcheck rounds for layer l
+    ZK_TRY(c->activate());
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // layer l: 2^l gate slots (one bit at l = 0), inputs are labels of the 2^(l + 1)-entry table below it
+    size_t total = 0, g_off = 0;
+    std::vector<char> bad(n_layers, 0);
+    for (uint32_t l = 0; l < n_layers; ++l) {
+        const size_t w_len = (size_t)2 << l, ng = h_n_gates[l];
+        const uint32_t n_gate_vars = l == 0 ? 1u : l;
+        for (size_t g = 0; g < ng && !bad[l]; ++g)
+            if (h_in0[g_off + g] >= w_len || h_in1[g_off + g] >= w_len || (g >> n_gate_vars)) bad[l] = 1;
+        total += 2 * al(4 * (w_len + 1 + ng)) + 2 * al(4 * ng) + al(ng);
+        g_off += ng;
+    }
+    zkhip_circuit* cir = new (std::nothrow) zkhip_circuit();
+    if (!cir) return ZKHIP_ERR_NOMEM;
+    cir->c = c;
+    cir->n_layers = n_layers;
+    if (hipMalloc(&cir->d_mem, total ? total : 256) != hipSuccess) {
+        delete cir;
+        return ZKHIP_ERR_NOMEM;
+    }
+    // stage everything in one host buffer, one upload
+    std::vector<char> host(total);
+    std::vector<uint32_t> csr;
+    size_t off = 0;
+    g_off = 0;
+    for (uint32_t l = 0; l < n_layers; ++l) {
+        const size_t w_len = (size_t)2 << l, ng = h_n_gates[l];
+        LayerDev ld = {};
+        ld.n_gates = ng;
+        ld.w_len = w_len;
+        ld.bad_label = bad[l] != 0;
+        char* base = (char*)cir->d_mem;
+        if (!bad[l]) {
+            group_gates(h_in0 + g_off, ng, w_len, csr);
+            std::memcpy(host.data() + off, csr.data(), 4 * csr.size());
+        }
+        ld.csr0 = (uint32_t*)(base + off); off += al(4 * (w_len + 1 + ng));
+        if (!bad[l]) {
+            group_gates(h_in1 + g_off, ng, w_len, csr);
+            std::memcpy(host.data() + off, csr.data(), 4 * csr.size());
+        }
+        ld.csr1 = (uint32_t*)(base + off); off += al(4 * (w_len + 1 + ng));
+        if (ng) std::memcpy(host.data() + off, h_in0 + g_off, 4 * ng);
+        ld.in0 = (uint32_t*)(base + off); off += al(4 * ng);
+        if (ng) std::memcpy(host.data() + off, h_in1 + g_off, 4 * ng);
+        ld.in1 = (uint32_t*)(base + off); off += al(4 * ng);
+        if (ng) std::memcpy(host.data() + off, h_gate_type + g_off, ng);
+        ld.type = (uint8_t*)(base + off); off += al(ng);
+        cir->layers.push_back(ld);
+        g_off += ng;
+    }
+    if (total && (hipMemcpyAsync(cir->d_mem, host.data(), total, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                  hipStreamSynchronize(c->stream) != hipSuccess)) {
+        zkhip_circuit_destroy(cir);
+        return ZKHIP_ERR_HIP;
+    }
+    *out = cir;
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const* h_layer_ptrs, const size_t* h_layer_len, uint64_t* h_sums,
+                                       uint32_t* h_n_rounds, uint32_t* h_round_poly_lens, uint64_t* h_round_polys, uint64_t* h_wb,
+                                       uint64_t* h_wc, uint64_t* h_w0, uint64_t* h_challenges) {
+    if (!cir || !h_layer_ptrs || !h_layer_len || !h_sums || !h_n_rounds || !h_round_poly_lens || !h_round_polys || !h_wb || !h_wc || !h_w0)
         return ZKHIP_ERR_ARG;
-    if (n_layers < 1 || 2 * n_layers > (uint32_t)ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;   // 2 (l + 1) rounds for layer l
+    zkhip_ctx* c = cir->c;
+    const uint32_t n_layers = cir->n_layers;
     if (h_layer_len[0] != 1) return ZKHIP_ERR_SHAPE;              // w_0 = [output.., 0] must have 2^k entries; the wiring of layer 0 has one gate bit
     for (uint32_t k = 1; k <= n_layers; ++k)
         if (!is_pow2(h_layer_len[k])) return ZKHIP_ERR_SHAPE;  // Multilinear::new (evaluation_form.rs:16-20)
     ZK_TRY(c->activate());
-    // aux layout: w_0 (2) | nine tables of the widest layer | gate weights | gate arrays and their two groupings
+    // aux layout: w_0 (2) | eight tables of the widest layer | gate weights
     size_t max_w = 0, max_g = 0;
-    for (uint32_t l = 0; l < n_layers; ++l) { max_w = std::max(max_w, h_layer_len[l + 1]); max_g = std::max(max_g, h_n_gates[l]); }
+    for (uint32_t l = 0; l < n_layers; ++l) { max_w = std::max(max_w, h_layer_len[l + 1]); max_g = std::max(max_g, cir->layers[l].n_gates); }
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t tb = al(32 * max_w);
-    const size_t o_w0 = 0, o_tab = al(64), o_wg = o_tab + 8 * tb, o_csr0 = o_wg + al(32 * max_g), o_csr1 = o_csr0 + al(4 * (max_w + 1 + max_g));
-    const size_t o_in0 = o_csr1 + al(4 * (max_w + 1 + max_g)), o_in1 = o_in0 + al(4 * max_g), o_type = o_in1 + al(4 * max_g);
-    ZK_TRY(c->reserve_aux(o_type + al(max_g)));
+    const size_t o_w0 = 0, o_tab = al(64), o_wg = o_tab + 8 * tb;
+    ZK_TRY(c->reserve_aux(o_wg + al(32 * max_g)));
     char* aux = (char*)c->d_aux;
     uint64_t* d_w0 = (uint64_t*)(aux + o_w0);
     LayerScratch sc;
@@ -261,8 +332,6 @@ extern "C" int zkhip_gkr_prove(zkhip_ctx* c, uint32_t n_layers, const size_t* h_
     sc.equ = (uint64_t*)(aux + o_tab + 3 * tb); sc.aa = (uint64_t*)(aux + o_tab + 4 * tb); sc.am = (uint64_t*)(aux + o_tab + 5 * tb);
     sc.t1 = (uint64_t*)(aux + o_tab + 6 * tb); sc.t2 = (uint64_t*)(aux + o_tab + 7 * tb);
     sc.wg = (uint64_t*)(aux + o_wg);
-    sc.csr0 = (uint32_t*)(aux + o_csr0); sc.csr1 = (uint32_t*)(aux + o_csr1);
-    sc.in0 = (uint32_t*)(aux + o_in0); sc.in1 = (uint32_t*)(aux + o_in1); sc.type = (uint8_t*)(aux + o_type);
     LayerOut out = {h_sums, h_round_polys, h_wb, h_wc, h_challenges, h_n_rounds, h_round_poly_lens, 2 * n_layers};
 
     // w_0 = circuit_evaluation[0] padded with a zero (protocol.rs:30-33); commit its bytes, draw n_r
@@ -290,16 +359,32 @@ extern "C" int zkhip_gkr_prove(zkhip_ctx* c, uint32_t n_layers, const size_t* h_
 
     zkhost::Fr alpha = zkhost::fr_one(), beta = zkhost::fr_zero();
     std::vector<zkhost::Fr> r_b, r_c;
-    size_t g_off = 0;
     // layer one (gkr/src/utils.rs:12-56): the wiring of layer 0 with its gate variable fixed at n_r
-    ZK_TRY(layer_prove(c, h_gate_type, h_in0, h_in1, h_n_gates[0], 0, h_layer_ptrs[1], h_layer_len[1], sc, claimed, tr, out, 0, alpha, beta, n_r, r_c, false));
+    ZK_TRY(layer_prove(c, cir->layers[0], 0, h_layer_ptrs[1], h_layer_len[1], sc, claimed, tr, out, 0, alpha, beta, n_r, r_c, false));
     r_b = n_r;   // layer_prove left (b, c) of layer one in (n_r, r_c)
-    g_off += h_n_gates[0];
     for (uint32_t li = 2; li <= n_layers; ++li) {                    // protocol.rs:64-108
         const uint32_t l = li - 1;
-        ZK_TRY(layer_prove(c, h_gate_type + g_off, h_in0 + g_off, h_in1 + g_off, h_n_gates[l], l, h_layer_ptrs[li], h_layer_len[li], sc, claimed,
-                           tr, out, li - 1, alpha, beta, r_b, r_c, true));
-        g_off += h_n_gates[l];
+        ZK_TRY(layer_prove(c, cir->layers[l], l, h_layer_ptrs[li], h_layer_len[li], sc, claimed, tr, out, li - 1, alpha, beta, r_b, r_c, true));
     }
     return ZKHIP_OK;
+}
+
+// one-shot form: the circuit is grouped and uploaded for this proof only
+extern "C" int zkhip_gkr_prove(zkhip_ctx* c, uint32_t n_layers, const size_t* h_n_gates, const uint8_t* h_gate_type,
+                               const uint32_t* h_in0, const uint32_t* h_in1, const uint64_t* const* h_layer_ptrs,
+                               const size_t* h_layer_len, uint64_t* h_sums, uint32_t* h_n_rounds, uint32_t* h_round_poly_lens,
+                               uint64_t* h_round_polys, uint64_t* h_wb, uint64_t* h_wc, uint64_t* h_w0, uint64_t* h_challenges) {
+    if (!c || !h_n_gates || !h_gate_type || !h_in0 || !h_in1 || !h_layer_ptrs || !h_layer_len || !h_sums || !h_n_rounds ||
+        !h_round_poly_lens || !h_round_polys || !h_wb || !h_wc || !h_w0)
+        return ZKHIP_ERR_ARG;
+    if (n_layers < 1 || 2 * n_layers > (uint32_t)ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
+    if (h_layer_len[0] != 1) return ZKHIP_ERR_SHAPE;
+    for (uint32_t k = 1; k <= n_layers; ++k)
+        if (!is_pow2(h_layer_len[k]) || h_layer_len[k] != ((size_t)2 << (k - 1))) return ZKHIP_ERR_SHAPE;   // shapes before labels, as the reference panics
+    zkhip_circuit* cir = nullptr;
+    ZK_TRY(zkhip_circuit_create(c, n_layers, h_n_gates, h_gate_type, h_in0, h_in1, &cir));
+    const int rc = zkhip_gkr_prove_circuit(cir, h_layer_ptrs, h_layer_len, h_sums, h_n_rounds, h_round_poly_lens, h_round_polys, h_wb, h_wc,
+                                           h_w0, h_challenges);
+    zkhip_circuit_destroy(cir);
+    return rc;
 }

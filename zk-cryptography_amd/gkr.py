@@ -140,6 +140,30 @@ def _fadd(a, b):
     return Fr.from_int((Fr.to_ints(a)[0] + Fr.to_ints(b)[0]) % R_MOD)
 
 
+class _DeviceCircuit:
+    """zkhip_circuit handle (include/zkhip.h): the circuit's gate arrays and CSR groupings resident in HBM."""
+
+    def __init__(self, ctx, circuit, shape):
+        arrays = [layer._arrays() for layer in circuit.layers]
+        gt = np.concatenate([a[0] for a in arrays])
+        i0 = np.concatenate([a[1] for a in arrays])
+        i1 = np.concatenate([a[2] for a in arrays])
+        self.ctx, self.shape = ctx, shape
+        self.handle = C.c_void_p()
+        p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        st = N.lib().zkhip_circuit_create(ctx.handle, C.c_uint32(len(shape)), (C.c_size_t * len(shape))(*shape), p(gt), p(i0), p(i1),
+                                          C.byref(self.handle))
+        N.check(st, "circuit_create")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                N.lib().zkhip_circuit_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 class GKRProtocol:
     @staticmethod
     def _layer_sumcheck(add_bc, mul_bc, w_mle, claimed_sum, transcript, proof):
@@ -169,14 +193,7 @@ class GKRProtocol:
         from zk_cryptography_amd.composed import MAX_MONO, MultiComposedSumcheckProof, SparseUnivariatePolynomial
         nl = len(circuit.layers)
         assert len(circuit_evaluation) == nl + 1
-        flat = getattr(circuit, "_flat", None)
-        if flat is None or flat[3] != [len(layer.layer) for layer in circuit.layers]:
-            arrays = [layer._arrays() for layer in circuit.layers]
-            flat = (np.concatenate([a[0] for a in arrays]), np.concatenate([a[1] for a in arrays]),
-                    np.concatenate([a[2] for a in arrays]), [len(layer.layer) for layer in circuit.layers])
-            circuit._flat = flat
-        gt, i0, i1 = flat[0], flat[1], flat[2]
-        n_gates = (C.c_size_t * nl)(*[len(layer.layer) for layer in circuit.layers])
+        shape = [len(layer.layer) for layer in circuit.layers]
         tables = [t.contiguous() for t in circuit_evaluation]
         ptrs = (C.c_void_p * (nl + 1))(*[t.data_ptr() for t in tables])
         lens = (C.c_size_t * (nl + 1))(*[t.shape[0] for t in tables])
@@ -190,8 +207,11 @@ class GKRProtocol:
         ctx = N.Context.get(tables[0].device.index)
         p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
         chal = np.zeros((nl, stride, 4), dtype=np.uint64)
-        st = N.lib().zkhip_gkr_prove(ctx.handle, C.c_uint32(nl), n_gates, p(gt), p(i0), p(i1), ptrs, lens, p(sums), p(n_rounds),
-                                     p(rp_lens), p(rps), p(wb), p(wc), p(w0), p(chal))
+        # the circuit lives on the device: gate arrays and their groupings are validated, built and uploaded once per Circuit
+        dev = getattr(circuit, "_device", None)
+        if dev is None or dev.shape != shape or dev.ctx is not ctx:
+            dev = circuit._device = _DeviceCircuit(ctx, circuit, shape)
+        st = N.lib().zkhip_gkr_prove_circuit(dev.handle, ptrs, lens, p(sums), p(n_rounds), p(rp_lens), p(rps), p(wb), p(wc), p(w0), p(chal))
         N.check(st, "gkr_prove: every layer must hold a power-of-two number of values, 2^l gates in layer l")
         proofs = []
         for k in range(nl):
