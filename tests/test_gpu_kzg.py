@@ -81,6 +81,19 @@ def test_srs_univariate_matches_oracle(zk, ora):
     assert np.array_equal(srs.powers_of_tau_in_g1.cpu().numpy().view(np.uint64), want[:, :12])
 
 
+@pytest.mark.parametrize("tau", [2, R - 1, 256])
+def test_srs_window_table_single_digit_scalars(zk, ora, tau):
+    """SRS points come from a table of the generator's multiples indexed by the scalar's bytes: powers of two (one non-zero
+    digit, every window and every bit of a window), powers of 256 (digit 1 per window, reduced mod r beyond 2^255) and +-1
+    (r - 1: every digit non-zero) against the oracle's double-and-add."""
+    t = zk.Fr.from_ints([tau])[0]
+    deg = 254 if tau == 2 else 40
+    srs = zk.UnivariateKZG.generate_srs(t, deg)
+    want = ora.g1_batch_to_affine(ora.kzg_univariate_srs_g1(t, deg))
+    assert np.array_equal(srs.powers_of_tau_in_g1.cpu().numpy().view(np.uint64), want[:, :12])
+    assert not srs.inf.any()
+
+
 def test_srs_with_identity_points_and_zero_scalars(zk, ora):
     # kzg/benches/multilinear_kzg_benchmark.rs:17-22: tau = (0,1,2,...) => eq-scalars that are 0 => G*0 = identity
     tau = zk.Fr.from_ints([0, 1, 2, 3])

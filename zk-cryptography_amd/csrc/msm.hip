@@ -561,12 +561,34 @@ extern "C" int zkhip_dense_degree(zkhip_ctx* c, const uint64_t* d_coeffs, size_t
     return ZKHIP_OK;
 }
 
+// the generator's window table of this context (built once: 32 chains of 255 additions, ~10 ms)
+static int srs_gen_table(zkhip_ctx* c, const uint64_t** table_xy) {
+    const size_t n_tab = (size_t)SRS_WINDOWS * SRS_DIGITS;
+    if (!c->d_gen_table) {
+        void* mem = nullptr;
+        if (hipMalloc(&mem, n_tab * 97 + 256 + n_tab * 192) != hipSuccess) return ZKHIP_ERR_NOMEM;
+        uint64_t* xy = (uint64_t*)mem;
+        uint8_t* inf = (uint8_t*)mem + n_tab * 96;                 // never set: no multiple d * 2^(8w) * G with d < 256 is the identity
+        uint64_t* xyzz = (uint64_t*)((char*)mem + ((n_tab * 97 + 255) & ~(size_t)255));
+        hipLaunchKernelGGL(srs_gen_table_kernel, dim3(1), dim3(64), 0, c->stream, xyzz);
+        const size_t n_threads = (n_tab + SRS_CHUNK - 1) / SRS_CHUNK;
+        hipLaunchKernelGGL(srs_batch_affine_kernel, dim3((unsigned)((n_threads + SRS_BLOCK - 1) / SRS_BLOCK)), dim3(SRS_BLOCK), 0,
+                           c->stream, xyzz, n_tab, xy, inf);
+        if (hipGetLastError() != hipSuccess) { (void)hipFree(mem); return ZKHIP_ERR_HIP; }
+        c->d_gen_table = mem;
+    }
+    *table_xy = (const uint64_t*)c->d_gen_table;
+    return ZKHIP_OK;
+}
+
 // scalars (device, n x 4) -> affine SRS points
 static int srs_from_scalars(zkhip_ctx* c, const uint64_t* d_scalars, size_t n, uint64_t* d_out_xy, uint8_t* d_out_inf) {
     // workspace layout: [scalars n*32 (owned by caller region)] ... we only need n*192 for XYZZ here
     uint64_t* xyzz = (uint64_t*)((char*)c->d_ws + ((n * 32 + 255) & ~(size_t)255));
-    hipLaunchKernelGGL(srs_fixed_base_kernel, dim3((unsigned)((n + SRS_BLOCK - 1) / SRS_BLOCK)), dim3(SRS_BLOCK), 0, c->stream,
-                       d_scalars, n, xyzz);
+    const uint64_t* table = nullptr;
+    ZK_TRY(srs_gen_table(c, &table));
+    hipLaunchKernelGGL(srs_fixed_base_window_kernel, dim3((unsigned)((n + SRS_BLOCK - 1) / SRS_BLOCK)), dim3(SRS_BLOCK), 0, c->stream,
+                       d_scalars, n, table, xyzz);
     const size_t n_threads = (n + SRS_CHUNK - 1) / SRS_CHUNK;
     hipLaunchKernelGGL(srs_batch_affine_kernel, dim3((unsigned)((n_threads + SRS_BLOCK - 1) / SRS_BLOCK)), dim3(SRS_BLOCK), 0,
                        c->stream, xyzz, n, d_out_xy, d_out_inf);

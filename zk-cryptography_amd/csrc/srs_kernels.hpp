@@ -3,7 +3,7 @@
 // Replaces TrustedSetup::generate_powers_of_tau_in_g1 (kzg/src/trusted_setup.rs:25-35, with
 // check_for_zero_and_one / generate_array_of_points kzg/src/utils.rs:19-40 over boolean_hypercube
 // polynomial/src/utils.rs:141-157) and UnivariateKZG::generate_srs (kzg/src/univariate_kzg.rs:18-35):
-// N independent fixed-base scalar multiplications G * s_i, then one batched conversion to affine
+// N independent fixed-base scalar multiplications G * s_i (byte-wide windows over a table of the generator's multiples), then one batched conversion to affine
 // (the SRS is stored affine in HBM so that the commit path can use mixed additions).
 #pragma once
 #include "g1.hpp"
@@ -57,22 +57,37 @@ __device__ __forceinline__ G1Affine g1_generator() {
     return g;
 }
 
-// out[i] = G * scalars[i]  (Group::mul_bigint(point.into_bigint()) trusted_setup.rs:33): MSB-first double-and-add
-static __global__ __launch_bounds__(SRS_BLOCK) void srs_fixed_base_kernel(const uint64_t* __restrict__ scalars, size_t n,
-                                                                   uint64_t* __restrict__ out_xyzz) {
+// ---- windowed fixed base: 32 byte-wide windows of the scalar, table[w * 255 + d - 1] = d * 2^(8 w) * G -------------------
+// 32 mixed additions per point instead of 255 doublings + ~127 additions.  The table depends on G only: one lane per window
+// builds its 255 multiples by a chain of additions (XYZZ), srs_batch_affine_kernel turns them into affine points.
+constexpr int SRS_WINDOWS = 32, SRS_DIGITS = 255;
+static __global__ __launch_bounds__(64) void srs_gen_table_kernel(uint64_t* __restrict__ out_xyzz) {
+    const uint32_t w = blockIdx.x * 64 + threadIdx.x;
+    if (w >= SRS_WINDOWS) return;
+    G1Xyzz base = G1Xyzz::identity();
+    g1_madd(base, g1_generator(), false);
+    for (uint32_t i = 0; i < 8 * w; ++i) base = g1_double(base);          // 2^(8 w) * G
+    G1Xyzz acc = base;
+    store_xyzz(out_xyzz, (size_t)w * SRS_DIGITS, acc);
+    for (uint32_t d = 2; d <= SRS_DIGITS; ++d) {
+        g1_add(acc, base);
+        store_xyzz(out_xyzz, (size_t)w * SRS_DIGITS + d - 1, acc);
+    }
+}
+// out[i] = G * scalars[i]  (Group::mul_bigint(point.into_bigint()) trusted_setup.rs:33) from the window table
+static __global__ __launch_bounds__(SRS_BLOCK) void srs_fixed_base_window_kernel(const uint64_t* __restrict__ scalars, size_t n,
+                                                                          const uint64_t* __restrict__ table_xy,
+                                                                          uint64_t* __restrict__ out_xyzz) {
     const size_t i = (size_t)blockIdx.x * SRS_BLOCK + threadIdx.x;
     if (i >= n) return;
     const Fr k = load_fr(scalars, i).from_mont();
-    const G1Affine g = g1_generator();
     G1Xyzz acc = G1Xyzz::identity();
-    for (int w = 7; w >= 0; --w) {
-        uint32_t word = k.l[7];
+    for (int w = 0; w < SRS_WINDOWS; ++w) {
+        uint32_t word = k.l[0];
 #pragma unroll
-        for (int q = 7; q >= 0; --q) if (q == w) word = k.l[q];
-        for (int b = 31; b >= 0; --b) {
-            acc = g1_double(acc);
-            if ((word >> b) & 1) g1_madd(acc, g, false);
-        }
+        for (int q = 1; q < 8; ++q) if (q == (w >> 2)) word = k.l[q];
+        const uint32_t d = (word >> (8 * (w & 3))) & 255u;
+        if (d) g1_madd(acc, load_affine(table_xy, (size_t)w * SRS_DIGITS + d - 1), false);
     }
     store_xyzz(out_xyzz, i, acc);
 }

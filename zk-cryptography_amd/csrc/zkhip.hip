@@ -60,6 +60,7 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     for (auto& e : c->prof_events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
     if (c->d_ws) hipFree(c->d_ws);
     if (c->d_aux) hipFree(c->d_aux);
+    if (c->d_gen_table) hipFree(c->d_gen_table);
     for (int i = 0; i < 2; ++i) { if (c->msm_pin[i]) hipHostFree(c->msm_pin[i]); if (c->msm_ev[i]) hipEventDestroy(c->msm_ev[i]); }
     if (c->d_small) hipFree(c->d_small);
     if (c->sc_small) hipFree(c->sc_small);
