@@ -454,20 +454,31 @@ struct GKRProof {                                                               
     std::vector<Fr> wb_s, wc_s;
     std::vector<Fr> w_0_mle;
 };
-struct GKRProtocol {
-    static GKRProof prove(const Circuit& circuit, const Circuit::Evaluation& ev) {             // protocol.rs:21-117
-        const uint32_t nl = (uint32_t)circuit.layers.size(), stride = 2 * nl;
+// A circuit resident in HBM (zkhip_circuit): gate arrays and their groupings validated, built and uploaded once, for provers
+// that prove many inputs on one circuit.  GKRProtocol::prove builds one for the call.
+class DeviceCircuit {
+  public:
+    explicit DeviceCircuit(const Circuit& circuit) : n_layers_((uint32_t)circuit.layers.size()) {
         std::vector<size_t> n_gates;
         std::vector<uint8_t> gt; std::vector<uint32_t> i0, i1;
         for (auto& l : circuit.layers) { n_gates.push_back(l.layer.size()); Circuit::arrays(l, gt, i0, i1); }
+        check(zkhip_circuit_create(ctx(), n_layers_, n_gates.data(), gt.data(), i0.data(), i1.data(), &handle_), "circuit_create");
+    }
+    ~DeviceCircuit() { zkhip_circuit_destroy(handle_); }
+    DeviceCircuit(const DeviceCircuit&) = delete;
+    DeviceCircuit& operator=(const DeviceCircuit&) = delete;
+    GKRProof prove(const Circuit::Evaluation& ev) const {                                        // protocol.rs:21-117
+        const uint32_t nl = n_layers_, stride = 2 * nl;
+        if (ev.tables.size() != (size_t)nl + 1) throw Panic("circuit evaluation does not match the circuit");
         std::vector<const uint64_t*> ptrs;
         for (auto& t : ev.tables) ptrs.push_back(t->u64());
         std::vector<Fr> sums(nl), wb(nl), wc(nl), w0(2);
         std::vector<uint32_t> n_rounds(nl), lens((size_t)nl * stride);
         std::vector<uint64_t> rps((size_t)nl * stride * 7 * 8);
-        int st = zkhip_gkr_prove(ctx(), nl, n_gates.data(), gt.data(), i0.data(), i1.data(), ptrs.data(), ev.lens.data(), sums[0].l, n_rounds.data(),
-                                 lens.data(), rps.data(), wb[0].l, wc[0].l, w0[0].l, nullptr);
+        int st = zkhip_gkr_prove_circuit(handle_, ptrs.data(), ev.lens.data(), sums[0].l, n_rounds.data(), lens.data(), rps.data(), wb[0].l,
+                                         wc[0].l, w0[0].l, nullptr);
         if (st == ZKHIP_ERR_SHAPE) throw Panic("Number of evaluations must be a power of 2");
+        if (st == ZKHIP_ERR_INDEX) throw std::out_of_range("index out of bounds: gate input");
         check(st, "gkr_prove");
         GKRProof proof;
         for (uint32_t k = 0; k < nl; ++k) {
@@ -487,6 +498,14 @@ struct GKRProtocol {
         }
         proof.wb_s = wb; proof.wc_s = wc; proof.w_0_mle = w0;
         return proof;
+    }
+  private:
+    uint32_t n_layers_;
+    zkhip_circuit* handle_ = nullptr;
+};
+struct GKRProtocol {
+    static GKRProof prove(const Circuit& circuit, const Circuit::Evaluation& ev) {             // protocol.rs:21-117
+        return DeviceCircuit(circuit).prove(ev);
     }
 };
 

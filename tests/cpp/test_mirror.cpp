@@ -280,6 +280,16 @@ TEST(test_gkr_protocol_2) {   // gkr/src/protocol.rs:234-286
                            {{1, 0, 1}, {1, 2, 3}, {1, 4, 5}, {0, 6, 7}, {1, 8, 9}, {0, 10, 11}, {1, 12, 13}, {1, 14, 15}}}),
              F({2, 1, 3, 1, 4, 1, 2, 2, 3, 3, 4, 4, 2, 3, 3, 4}), 224);
 }
+TEST(test_gkr_device_circuit_reused) {   // one resident circuit, two inputs: each proof equals the one-shot prover's
+    Circuit c = make_circuit({{{0, 0, 1}}, {{1, 0, 1}, {0, 2, 3}}, {{0, 0, 1}, {1, 2, 3}, {1, 4, 5}, {1, 6, 7}}});
+    DeviceCircuit dc(c);
+    for (uint64_t seed : {11, 12}) {
+        auto ev = c.evaluation(random_fr(8, seed));
+        GKRProof a = dc.prove(ev), b = GKRProtocol::prove(c, ev);
+        EXPECT(a.wb_s == b.wb_s && a.wc_s == b.wc_s && a.w_0_mle == b.w_0_mle && a.sumcheck_proofs.size() == b.sumcheck_proofs.size());
+        for (size_t k = 0; k < a.sumcheck_proofs.size(); ++k) EXPECT(a.sumcheck_proofs[k].to_bytes() == b.sumcheck_proofs[k].to_bytes());
+    }
+}
 // ---- domain / NTT ---------------------------------------------------------------------------------------------------------
 TEST(test_domain_new) {   // domain.rs:154-168 (the decimal strings are checked through the oracle's KAT-pinned root)
     Domain d(10);
