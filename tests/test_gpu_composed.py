@@ -51,7 +51,8 @@ def test_sum_check_proof(zk, ora, tables):   # composed_sumcheck.rs:143-241
     assert ora.composed_verify(t, ora.composed_sum(t), proof.round_polys)
 
 
-@pytest.mark.parametrize("k,log_n", [(1, 1), (2, 5), (2, 12), (3, 9), (5, 8), (5, 13), (4, 10)])
+@pytest.mark.parametrize("k,log_n", [(1, 1), (2, 5), (2, 12), (3, 9), (5, 8), (5, 13), (4, 10),
+                                     (2, 20), (3, 18), (2, 22)])   # the last three: grids above the workgroup cap (grid-stride rounds)
 def test_composed_prove_random(zk, ora, k, log_n):   # benches: 2 and 5 tables (composed_sumcheck_benchmark.rs)
     t = np.stack([ora.random_fr(1 << log_n, 900 + 10 * k + q) for q in range(k)])
     poly = zk.ComposedMultilinear(list(t))
@@ -100,7 +101,7 @@ def test_multi_composed_sumcheck_proof(zk, ora, case, partial):   # multi_compos
         assert ora.multi_composed_verify(flat, sizes, s, orps) == 1
 
 
-@pytest.mark.parametrize("sizes,log_n", [([2, 3], 8), ([2, 2], 12), ([1, 5], 6), ([3], 10), ([2, 2, 1, 1], 7)])
+@pytest.mark.parametrize("sizes,log_n", [([2, 3], 8), ([2, 2], 12), ([1, 5], 6), ([3], 10), ([2, 2, 1, 1], 7), ([2, 2], 20)])
 @pytest.mark.parametrize("partial", [False, True])
 def test_multi_composed_random(zk, ora, sizes, log_n, partial):   # bench shape: 2 + 3 tables x 2^8
     terms, seed = [], 1000
