@@ -23,7 +23,7 @@ def test_domain_new(zk):   # domain.rs:154-168
     assert zk.Fr.to_ints(d.group_size_inverse) == [pow(16, -1, zk.Fr.MODULUS)]
 
 
-@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 9, 10, 11, 12, 14, 16])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 9, 10, 11, 12, 14, 16, 18, 21])   # 21 = the transform size of a 2^20 x 2^20 product
 def test_fft_ifft_match_oracle(zk, ora, log_n):
     n = 1 << log_n
     x = ora.random_fr(n, 70 + log_n)
