@@ -61,10 +61,20 @@ struct zkhip_ctx {
     void* d_gen_table = nullptr;   // SRS generation: d * 2^(8w) * G for 32 windows x 255 digits, affine (+ infinity flags); built on first use
     void* d_aux = nullptr;      // second grow-only buffer for entry points that call others which own d_ws (kzg_open)
     size_t aux_bytes = 0;
-    // two pinned result buffers + events for commits whose host epilogue is deferred (msm_enqueue / msm_finish)
-    void* msm_pin[2] = {nullptr, nullptr};
-    size_t msm_pin_bytes[2] = {0, 0};
-    hipEvent_t msm_ev[2] = {nullptr, nullptr};
+    // pinned result buffers + events for commits whose host epilogue is deferred (msm_enqueue / msm_finish), and the side
+    // streams on which MultilinearKZG::open runs its per-round commits next to each other
+    static constexpr int MSM_SLOTS = 6;
+    void* msm_pin[MSM_SLOTS] = {};
+    size_t msm_pin_bytes[MSM_SLOTS] = {};
+    hipEvent_t msm_ev[MSM_SLOTS] = {};
+    hipStream_t side[MSM_SLOTS] = {};
+    hipEvent_t fork_ev = nullptr;
+    int ensure_side_streams() {
+        for (int i = 0; i < MSM_SLOTS; ++i)
+            if (!side[i] && hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) return ZKHIP_ERR_HIP;
+        if (!fork_ev && hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
+        return ZKHIP_OK;
+    }
     int reserve_msm_pin(int slot, size_t bytes) {
         if (!msm_ev[slot] && hipEventCreateWithFlags(&msm_ev[slot], hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
         if (bytes <= msm_pin_bytes[slot]) return ZKHIP_OK;

@@ -133,6 +133,7 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     const size_t o_part = o_rec + al(MSM_HEAVY_LEVELS * rec_cap * sizeof(MsmHeavyRec));
     const size_t total = o_part + al(slots_cap * 256);
     if (ws_used) *ws_used = total;
+    if (!pend) return ZKHIP_OK;                     // size query only
     ZK_TRY(c->reserve_ws(ws_off + total));
     char* ws = (char*)c->d_ws + ws_off;
     uint32_t* counts = (uint32_t*)(ws + o_counts);
@@ -414,46 +415,29 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
         d_folded_inf = (const uint8_t*)(aux + o_finf);
     }
     uint64_t* d_q = (uint64_t*)(aux + o_q);
-    // Rounds with more than OPEN_BATCH_MAX quotient entries commit one by one; the remaining (<= 15) small rounds, each
-    // far below the size at which a commit stops being latency bound, share one batched commit.
+    // All quotients first (a chain of n_vars small kernels on the caller's stream; none of them depends on a commit).
+    // Then the commits: rounds with more than OPEN_BATCH_MAX quotient entries one by one, the remaining (<= 15) small rounds,
+    // each far below the size at which a commit stops being latency bound, in one batched commit -- every one of them on
+    // its own side stream, workspace region and pinned result slot.  A commit is a throughput-bound accumulate pass followed
+    // by latency-bound reduction passes that leave the chip mostly idle; next to each other, the reductions of one round
+    // hide behind the accumulate pass of the next, and the host epilogues (~0.25 ms of serial point arithmetic each) behind both.
     const size_t OPEN_BATCH_MAX = (size_t)1 << 14;   // measured: 2^20 open 14.4 ms at 2^12, 11.6 ms at 2^14 (tools/perf_open.py)
+    constexpr int NSLOT = zkhip_ctx::MSM_SLOTS - 1;  // large rounds in flight; the last slot is the batch's
     const uint64_t* cur = d_evals;
     size_t cn = n, lvl_off = 0;
     MsmProblems batch = {};
     size_t batch_first_off = 0;
     uint32_t batch_first_round = 0;
-    // The large rounds alternate between two halves of the workspace and two pinned result slots: the host epilogue of
-    // round i - 1 (~0.25 ms of serial point arithmetic) runs while the GPU works on round i.
-    MsmPending pend[2];
-    int pend_round[2] = {-1, -1};
-    size_t slot_bytes = 0;
-    uint32_t n_enq = 0;
-    auto finish_slot = [&](int sl) -> int {
-        if (pend_round[sl] < 0) return ZKHIP_OK;
-        const int r = pend_round[sl];
-        pend_round[sl] = -1;
-        return msm_finish(c, pend[sl], h_proofs_xy + 12 * (size_t)r, h_proofs_inf + r);
-    };
+    struct Large { uint32_t round; size_t off, h; };
+    std::vector<Large> large;
     for (uint32_t i = 0; i < n_vars; ++i) {
         FrArg z = {};
         std::memcpy(z.v, h_points + 4 * (size_t)i, 32);
         uint64_t* rem = (uint64_t*)(aux + ((i & 1) ? o_pong : o_ping));
         hipLaunchKernelGGL(open_step_kernel, dim3(mle_grid(cn / 2)), dim3(MLE_BLOCK), 0, c->stream, cur, cn, z, d_q + 4 * lvl_off, rem);
-        ZK_HIP(c, hipGetLastError());
         const size_t h = cn / 2;   // |q_i| = |S_i|
         if (h > OPEN_BATCH_MAX) {
-            const int sl = (int)(n_enq & 1);
-            ZK_TRY(finish_slot(sl));                       // round i - 2 used this half of the workspace
-            MsmProblems one = {};
-            one.n = 1;
-            one.off[1] = (uint32_t)h;
-            size_t used = 0;
-            ZK_TRY(msm_enqueue(c, d_folded_xy + 12 * lvl_off, d_folded_inf + lvl_off, d_q + 4 * lvl_off, h, one, nullptr, 0,
-                               sl ? slot_bytes : 0, sl, &pend[sl], &used));
-            if (n_enq == 0) slot_bytes = (used + 4095) & ~(size_t)4095;   // the first round is the largest: later ones fit behind it
-            pend_round[sl] = (int)i;
-            ++n_enq;
-            ZK_TRY(finish_slot(sl ^ 1));                   // the previous round's epilogue, overlapped with this round's kernels
+            large.push_back({i, lvl_off, h});
         } else {
             if (batch.n == 0) { batch_first_off = lvl_off; batch_first_round = i; }
             batch.off[batch.n] = (uint32_t)(lvl_off - batch_first_off);
@@ -463,18 +447,72 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
         cur = rem;
         cn = h;
     }
-    if (batch.n) {
-        const int sl = (int)(n_enq & 1);
-        ZK_TRY(finish_slot(sl));
-        MsmPending bp;
-        // its own region behind the two halves: the other half may still be in use by the last large round
-        ZK_TRY(msm_enqueue(c, d_folded_xy + 12 * batch_first_off, d_folded_inf + batch_first_off, d_q + 4 * batch_first_off,
-                           lvl_off - batch_first_off, batch, nullptr, 0, 2 * slot_bytes, sl, &bp, nullptr));
-        ZK_TRY(finish_slot(sl ^ 1));
-        ZK_TRY(msm_finish(c, bp, h_proofs_xy + 12 * (size_t)batch_first_round, h_proofs_inf + batch_first_round));
+    ZK_HIP(c, hipGetLastError());
+    // workspace: region k (k < NSLOT) is sized for the k-th large round and reused by rounds k + NSLOT, k + 2 NSLOT, ... (each
+    // half the size of its predecessor in the region or less); the batch has its own region.  Reserved once, up front: a
+    // commit that grew the workspace later would move it under the commits in flight.
+    size_t region_off[zkhip_ctx::MSM_SLOTS + 1] = {};
+    for (int k = 0; k < NSLOT; ++k) {
+        size_t used = 0;
+        if ((size_t)k < large.size()) {
+            MsmProblems one = {};
+            one.n = 1;
+            one.off[1] = (uint32_t)large[k].h;
+            ZK_TRY(msm_enqueue(c, nullptr, nullptr, nullptr, large[k].h, one, nullptr, 0, 0, 0, nullptr, &used));
+        }
+        region_off[k + 1] = region_off[k] + ((used + 4095) & ~(size_t)4095);
     }
-    ZK_TRY(finish_slot(0));
-    ZK_TRY(finish_slot(1));
+    {
+        size_t used = 0;
+        if (batch.n) ZK_TRY(msm_enqueue(c, nullptr, nullptr, nullptr, lvl_off - batch_first_off, batch, nullptr, 0, 0, 0, nullptr, &used));
+        region_off[NSLOT + 1] = region_off[NSLOT] + used;
+    }
+    ZK_TRY(c->reserve_ws(region_off[NSLOT + 1]));
+    ZK_TRY(c->ensure_side_streams());
+    ZK_HIP(c, hipEventRecord(c->fork_ev, c->stream));
+    MsmPending pend[zkhip_ctx::MSM_SLOTS];
+    int pend_round[zkhip_ctx::MSM_SLOTS];
+    for (int k = 0; k < zkhip_ctx::MSM_SLOTS; ++k) pend_round[k] = -1;
+    auto finish_slot = [&](int sl) -> int {
+        if (pend_round[sl] < 0) return ZKHIP_OK;
+        const int r = pend_round[sl];
+        pend_round[sl] = -1;
+        return msm_finish(c, pend[sl], h_proofs_xy + 12 * (size_t)r, h_proofs_inf + r);
+    };
+    hipStream_t const main_stream = c->stream;
+    int rc = ZKHIP_OK;
+    for (size_t j = 0; j < large.size() && rc == ZKHIP_OK; ++j) {
+        const int sl = (int)(j % NSLOT);
+        if ((rc = finish_slot(sl)) != ZKHIP_OK) break;     // round j - NSLOT used this region, stream and result slot
+        MsmProblems one = {};
+        one.n = 1;
+        one.off[1] = (uint32_t)large[j].h;
+        if (hipStreamWaitEvent(c->side[sl], c->fork_ev, 0) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
+        c->stream = c->side[sl];                           // msm_enqueue launches on the context's stream
+        rc = msm_enqueue(c, d_folded_xy + 12 * large[j].off, d_folded_inf + large[j].off, d_q + 4 * large[j].off, large[j].h, one, nullptr, 0,
+                         region_off[sl], sl, &pend[sl], nullptr);
+        c->stream = main_stream;
+        if (rc == ZKHIP_OK) pend_round[sl] = (int)large[j].round;
+    }
+    if (batch.n && rc == ZKHIP_OK) {
+        const int sl = NSLOT;
+        if (hipStreamWaitEvent(c->side[sl], c->fork_ev, 0) != hipSuccess) rc = ZKHIP_ERR_HIP;
+        if (rc == ZKHIP_OK) {
+            c->stream = c->side[sl];
+            rc = msm_enqueue(c, d_folded_xy + 12 * batch_first_off, d_folded_inf + batch_first_off, d_q + 4 * batch_first_off,
+                             lvl_off - batch_first_off, batch, nullptr, 0, region_off[sl], sl, &pend[sl], nullptr);
+            c->stream = main_stream;
+            if (rc == ZKHIP_OK) pend_round[sl] = (int)batch_first_round;
+        }
+    }
+    // the remaining epilogues; every slot is drained even after an error, so that nothing is left running on a side stream
+    for (int pass = 0; pass < 2; ++pass)
+        for (int k = 0; k < zkhip_ctx::MSM_SLOTS; ++k) {
+            if (pend_round[k] < 0) continue;
+            const int r2 = finish_slot(k);
+            if (rc == ZKHIP_OK) rc = r2;
+        }
+    if (rc != ZKHIP_OK) return rc;
     // the last remainder is poly(z): `evaluation`, and what the reference checks it against (:84-86)
     ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), cur, 32, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));

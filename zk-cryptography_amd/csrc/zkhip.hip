@@ -61,7 +61,12 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     if (c->d_ws) hipFree(c->d_ws);
     if (c->d_aux) hipFree(c->d_aux);
     if (c->d_gen_table) hipFree(c->d_gen_table);
-    for (int i = 0; i < 2; ++i) { if (c->msm_pin[i]) hipHostFree(c->msm_pin[i]); if (c->msm_ev[i]) hipEventDestroy(c->msm_ev[i]); }
+    for (int i = 0; i < zkhip_ctx::MSM_SLOTS; ++i) {
+        if (c->msm_pin[i]) hipHostFree(c->msm_pin[i]);
+        if (c->msm_ev[i]) hipEventDestroy(c->msm_ev[i]);
+        if (c->side[i]) hipStreamDestroy(c->side[i]);
+    }
+    if (c->fork_ev) hipEventDestroy(c->fork_ev);
     if (c->d_small) hipFree(c->d_small);
     if (c->sc_small) hipFree(c->sc_small);
     if (c->sc_stage) hipFree(c->sc_stage);
