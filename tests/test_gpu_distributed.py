@@ -247,3 +247,38 @@ def test_sharded_composed_orchestration_world_1(zk, ora):
     rp, ch = D.ShardedComposedSumcheck(D.HipComposedEngine([shard], 1, multi=False), 1).prove()
     wrp, wch = ora.composed_prove(full)
     assert np.array_equal(rp, wrp) and np.array_equal(ch, wch)
+
+
+def test_sharded_composed_session_misuse_is_refused(zk, ora):
+    """The split-phase session checks its call order and shapes (include/zkhip.h, zkhip_mc_*)."""
+    import ctypes as C
+    import torch
+    from zk_cryptography_amd import _native as N
+    from zk_cryptography_amd import distributed as D
+    t = [torch.from_numpy(ora.random_fr(1 << 13, 1 + q).view(np.int64)).cuda() for q in range(2)]
+    with pytest.raises(AssertionError):                       # world must be a power of two
+        D.HipComposedEngine([t], 3, multi=False)
+    with pytest.raises(N.ZkhipError):                         # a multi-composed claim needs its sum
+        D.HipComposedEngine([t], 2, multi=True)
+    with pytest.raises(N.ZkhipError):                         # ComposedSumcheck is one term
+        D.HipComposedEngine([t, t], 2, multi=False)
+    e = D.HipComposedEngine([t], 2, multi=False)
+    rec = e.new_buffer(e.record_len(), 4)
+    gathered = e.new_buffer(2, e.record_len(), 4)
+    with pytest.raises(N.ZkhipError):                         # nothing to absorb yet
+        e.absorb(gathered, 2)
+    e.round_sums(rec)
+    with pytest.raises(N.ZkhipError):                         # the round is still open
+        e.round_sums(rec)
+    with pytest.raises(N.ZkhipError):                         # other world size than at begin
+        e.absorb(e.new_buffer(4, e.record_len(), 4), 4)
+    with pytest.raises(N.ZkhipError):                         # tables are gathered between rounds only
+        e.local_tables(e.new_buffer(e.table_count(), e.local_len(), 4))
+    gathered.zero_()
+    gathered[0] = rec
+    e.absorb(gathered, 2)
+    with pytest.raises(AssertionError):                       # the remaining tables do not fit the replicated tail yet
+        e.tail(e.new_buffer(e.table_count(), 1 << 13, 4), 1 << 13)
+    # release without collecting a proof
+    N.check(N.lib().zkhip_mc_finish(e.st, None, None, None), "mc_finish")
+    e.st = None
