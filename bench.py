@@ -23,6 +23,38 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 
 
+_CHILD = """
+import sys, time
+sys.path.insert(0, %r)
+from oracle import oracle as ora
+ev = ora.random_fr(1 << 22, 7)
+ora.sumcheck_prove(ev)
+t = time.perf_counter()
+for _ in range(%d):
+    ora.sumcheck_prove(ev)
+print(time.perf_counter() - t)
+"""
+
+
+def cpu_all_cores(reps=2):
+    """The C oracle's poly_sum + prove on all host cores at once: one child process per core (children never touch the GPU)."""
+    import subprocess
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    kids = [subprocess.Popen([sys.executable, "-c", _CHILD % (ROOT, reps)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+            for _ in range(cores)]
+    times = []
+    for k in kids:
+        out, _ = k.communicate(timeout=240)
+        if k.returncode != 0:
+            raise RuntimeError("oracle child exited with %d" % k.returncode)
+        times.append(float(out.decode().strip().splitlines()[-1]))
+    slowest = max(times)
+    return {"value": round(cores * reps * (1 << 22) / slowest, 1), "unit": "field-evals/s", "cores": cores, "kind": "port",
+            "sample": "%d processes x %d runs of the same C port on a 2^22-entry table each, slowest process %.1f s (%.1f s with start-up)"
+                      % (cores, reps, slowest, time.perf_counter() - t0)}
+
+
 def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
     """KZG commit (MultilinearKZG::commitment) on a 2^msm_log_n-point SRS per GPU, SRS + scalars resident."""
     import ctypes as C
@@ -263,6 +295,13 @@ def main():
                "sample": "%d runs of the C oracle's Sumcheck poly_sum+prove (2 Montgomery muls per fold output, as "
                          "evaluation_form.rs:133; single-threaded like the reference) on the same 2^%d-entry table, "
                          "%.1f s in total" % (reps, cpu_log, cdt)}
+
+        # the same port on every host core at once (the reference is single-threaded; this is the box's CPU ceiling for
+        # independent provers): one child process per core, each proving its own 2^22-entry table
+        try:
+            cpu["all_cores"] = cpu_all_cores()
+        except Exception as e:
+            cpu["all_cores"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- second half of BASELINE's metric: MSM points/s of the KZG commit on a 2^20-point SRS per GPU
     msm = None
