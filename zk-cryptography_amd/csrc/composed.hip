@@ -137,7 +137,8 @@ struct ComposedRun {
         per_table = (n / 2 + n / 4 + 2) * 32;
         const size_t state_off = (total_all * per_table + 255) & ~(size_t)255;
         const size_t bytes_off = state_off + ((sizeof(ComposedDev) + 255) & ~(size_t)255);
-        ZK_TRY(c->reserve_ws(bytes_off + (multi && !partial ? 32 * n : 0)));
+        const size_t chunk = std::min<size_t>(n, (size_t)1 << 18);   // entries per staging buffer of prove()'s table-bytes pass
+        ZK_TRY(c->reserve_ws(bytes_off + (multi && !partial ? 64 * chunk : 0)));
         ws = (char*)c->d_ws;
         st = (ComposedDev*)(ws + state_off);
         d_partials = c->small_u64(ZK_SMALL_PARTIALS);
@@ -162,14 +163,28 @@ struct ComposedRun {
         if (!partial && !cont) {
             // prove(): transcript.commit(&composed_poly_to_bytes(&poly)) first (multi_composed_sumcheck.rs:51-53).
             // The GPU produces the canonical big-endian bytes, the host hashes the (inherently sequential) stream.
+            // Chunks of 2^18 entries (8 MiB of bytes) through two device staging buffers and two pinned buffers: the
+            // conversion + copy of chunk k + 1 runs while the host hashes chunk k (SHA extensions where the CPU has them).
             uint8_t* d_bytes = (uint8_t*)(ws + bytes_off);
-            std::vector<uint8_t> h_bytes(32 * n);
+            const size_t per_table = (n + chunk - 1) / chunk, n_chunks = per_table * total;
+            ZK_TRY(c->reserve_msm_pin(0, 32 * chunk));
+            ZK_TRY(c->reserve_msm_pin(1, 32 * chunk));
             zkhost::Sha256 sha;
-            for (uint32_t q = 0; q < total; ++q) {
-                hipLaunchKernelGGL(to_bytes_kernel, dim3(mle_grid(n)), dim3(MLE_BLOCK), 0, c->stream, ptrs[q], n, (uint32_t*)d_bytes);
-                ZK_HIP(c, hipMemcpyAsync(h_bytes.data(), d_bytes, 32 * n, hipMemcpyDeviceToHost, c->stream));
-                ZK_HIP(c, hipStreamSynchronize(c->stream));
-                sha.update(h_bytes.data(), 32 * n);
+            auto chunk_len = [&](size_t k) { const size_t off = (k % per_table) * chunk; return std::min(chunk, n - off); };
+            auto issue = [&](size_t k) -> int {
+                const size_t q = k / per_table, off = (k % per_table) * chunk, len = chunk_len(k);
+                const int sl = (int)(k & 1);
+                uint8_t* stage = d_bytes + (size_t)sl * 32 * chunk;
+                hipLaunchKernelGGL(to_bytes_kernel, dim3(mle_grid(len)), dim3(MLE_BLOCK), 0, c->stream, ptrs[q] + 4 * off, len, (uint32_t*)stage);
+                ZK_HIP(c, hipMemcpyAsync(c->msm_pin[sl], stage, 32 * len, hipMemcpyDeviceToHost, c->stream));
+                ZK_HIP(c, hipEventRecord(c->msm_ev[sl], c->stream));
+                return ZKHIP_OK;
+            };
+            ZK_TRY(issue(0));
+            for (size_t k = 0; k < n_chunks; ++k) {
+                if (k + 1 < n_chunks) ZK_TRY(issue(k + 1));            // its buffers held chunk k - 1, hashed in the last iteration
+                ZK_HIP(c, hipEventSynchronize(c->msm_ev[k & 1]));
+                sha.update((const uint8_t*)c->msm_pin[k & 1], 32 * chunk_len(k));
             }
             Sha256State hs = {};
             std::memcpy(hs.h, sha.h, 32);
