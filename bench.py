@@ -23,6 +23,31 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 
 
+class _HostStagedCollectives:
+    """torch.distributed stand-in for the ZKHIP_BENCH_ONE_GPU dry run: the same calls, CUDA tensors staged through the host."""
+
+    def __init__(self, dist, torch):
+        self._d, self._torch = dist, torch
+        self.ReduceOp = dist.ReduceOp
+
+    def all_gather_into_tensor(self, out, inp, group=None):
+        o = out.cpu()
+        self._d.all_gather_into_tensor(o, inp.cpu(), group=group)
+        out.copy_(o)
+
+    def all_reduce(self, t, op=None):
+        h = t.cpu()
+        self._d.all_reduce(h, op=op)
+        t.copy_(h)
+
+    def barrier(self):
+        self._torch.cuda.synchronize()
+        self._d.barrier()
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
+
+
 _CHILD = """
 import sys, time
 sys.path.insert(0, %r)
@@ -213,9 +238,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    # diagnostic: ZKHIP_BENCH_ONE_GPU=1 runs the N > 1 code path with every rank on GPU 0 and the exchange over gloo (RCCL
+    # refuses two ranks on one device) -- a dry run of the multi-rank protocol on a 1-GPU box, never a measurement
+    one_gpu = world > 1 and os.environ.get("ZKHIP_BENCH_ONE_GPU") == "1"
+    torch.cuda.set_device(0 if one_gpu else local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+            dist = _HostStagedCollectives(dist, torch)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import zk_cryptography_amd as zk
     from zk_cryptography_amd import _native as N
@@ -329,6 +361,7 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True,
             "scaling": "weak",
+            **({"dry_run": "ZKHIP_BENCH_ONE_GPU: all ranks on one GPU, exchange over gloo -- not a measurement"} if one_gpu else {}),
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",

@@ -1,0 +1,32 @@
+"""bench.py's multi-rank code path (torchrun, one process per rank, sharded prover / commit / composed prover, max-over-ranks
+timing, rank 0 prints the JSON line) exercised on the test box's single GPU: ZKHIP_BENCH_ONE_GPU=1 puts every rank on GPU 0 and
+carries the exchange over gloo.  A dry run of the protocol and of the output contract, not a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_dry_run(world):
+    env = dict(os.environ, ZKHIP_BENCH_ONE_GPU="1")
+    port = 29800 + (os.getpid() % 1000) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+           "--log-n", "22", "--msm-log-n", "12", "--composed-log-n", "15", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 only, one line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["value"] > 0 and d["unit"] == "field-evals/s" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["launches"] > 0
+    assert d["msm"]["value"] > 0
+    assert d["composed"]["transcript_replicated_on_all_ranks"] is True and d["composed"]["rounds"] == 15 + (world.bit_length() - 1)
+    assert "dry_run" in d
