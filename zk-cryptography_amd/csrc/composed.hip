@@ -175,7 +175,7 @@ struct ComposedRun {
                 const size_t q = k / per_table, off = (k % per_table) * chunk, len = chunk_len(k);
                 const int sl = (int)(k & 1);
                 uint8_t* stage = d_bytes + (size_t)sl * 32 * chunk;
-                hipLaunchKernelGGL(to_bytes_kernel, dim3(mle_grid(len)), dim3(MLE_BLOCK), 0, c->stream, ptrs[q] + 4 * off, len, (uint32_t*)stage);
+                hipLaunchKernelGGL(to_bytes_kernel, dim3(mle_grid_stream(len)), dim3(MLE_BLOCK), 0, c->stream, ptrs[q] + 4 * off, len, (uint32_t*)stage);
                 ZK_HIP(c, hipMemcpyAsync(c->msm_pin[sl], stage, 32 * len, hipMemcpyDeviceToHost, c->stream));
                 ZK_HIP(c, hipEventRecord(c->msm_ev[sl], c->stream));
                 return ZKHIP_OK;
@@ -404,7 +404,7 @@ extern "C" int zkhip_mc_local_tables(zkhip_mc_state* s, uint64_t* d_out) {
     for (uint32_t q = 0; q < run.total_all; ++q) {
         uint64_t* dst = d_out + (size_t)q * m * 4;
         if (run.folds()) {   // the fold at the last challenge is still pending (the next round's kernel would have done it)
-            hipLaunchKernelGGL(fold_kernel<false>, dim3(mle_grid(m)), dim3(MLE_BLOCK), 0, run.c->stream, tt.in[q], dst, m, log2_exact(m),
+            hipLaunchKernelGGL(fold_kernel<false>, dim3(mle_grid_stream((m + 1) / 2)), dim3(MLE_BLOCK), 0, run.c->stream, tt.in[q], dst, m, log2_exact(m),
                                run.d_ch + 4 * (run.round - 1), FrArg{}, (uint64_t*)nullptr);
         } else {
             ZK_HIP(run.c, hipMemcpyAsync(dst, tt.in[q], m * 32, hipMemcpyDeviceToDevice, run.c->stream));

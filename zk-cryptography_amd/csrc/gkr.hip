@@ -199,10 +199,10 @@ int layer_prove(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_
     std::memcpy(pu.v, u[0].l, 32 * (size_t)s);
     FrArg vu = {};
     std::memcpy(vu.v, eval_wb.l, 32);
-    hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid(w_len)), dim3(MLE_BLOCK), 0, c->stream, pu, s, sc.equ);
+    hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, pu, s, sc.equ);
     hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr1, ld.csr1 + w_len + 1, ld.type, ld.in0, sc.wg, sc.equ,
                        (uint32_t)w_len, 2u, sc.aa, (uint64_t*)nullptr, sc.am);
-    hipLaunchKernelGGL(gkr_vu_tables_kernel, dim3(mle_grid(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_w, w_len, vu, sc.t1, sc.t2);
+    hipLaunchKernelGGL(gkr_vu_tables_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_w, w_len, vu, sc.t1, sc.t2);
     ZK_HIP(c, hipGetLastError());
     {
         const uint64_t* tables[4] = {sc.aa, sc.t1, sc.am, sc.t2};        // [add~(u, c), V(u) + V(c)],  [mul~(u, c), V(u) V(c)]

@@ -434,7 +434,7 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
         FrArg z = {};
         std::memcpy(z.v, h_points + 4 * (size_t)i, 32);
         uint64_t* rem = (uint64_t*)(aux + ((i & 1) ? o_pong : o_ping));
-        hipLaunchKernelGGL(open_step_kernel, dim3(mle_grid(cn / 2)), dim3(MLE_BLOCK), 0, c->stream, cur, cn, z, d_q + 4 * lvl_off, rem);
+        hipLaunchKernelGGL(open_step_kernel, dim3(mle_grid_stream(cn / 2)), dim3(MLE_BLOCK), 0, c->stream, cur, cn, z, d_q + 4 * lvl_off, rem);
         const size_t h = cn / 2;   // |q_i| = |S_i|
         if (h > OPEN_BATCH_MAX) {
             large.push_back({i, lvl_off, h});

@@ -100,7 +100,7 @@ static int ntt_inplace(zkhip_ctx* c, uint64_t* d_data, uint32_t log_n, int inver
         zkhost::Fr ni = zkhost::fr_inv(zkhost::fr_from_u64((uint64_t)n));
         FrArg sc;
         std::memcpy(sc.v, ni.l, 32);
-        hipLaunchKernelGGL(elementwise_kernel<2>, dim3(mle_grid(n)), dim3(MLE_BLOCK), 0, c->stream, d_scratch,
+        hipLaunchKernelGGL(elementwise_kernel<2>, dim3(mle_grid_stream(n)), dim3(MLE_BLOCK), 0, c->stream, d_scratch,
                            (const uint64_t*)nullptr, sc, n, d_data);
     } else {
         ZK_HIP(c, hipMemcpyAsync(d_data, d_scratch, n * 32, hipMemcpyDeviceToDevice, c->stream));
@@ -121,7 +121,7 @@ extern "C" int zkhip_ntt(zkhip_ctx* c, uint64_t* d_data, uint32_t log_n, int inv
 extern "C" int zkhip_pointwise_mul(zkhip_ctx* c, const uint64_t* d_a, const uint64_t* d_b, size_t n, uint64_t* d_out) {
     if (!c || !d_a || !d_b || !d_out) return ZKHIP_ERR_ARG;
     ZK_TRY(c->activate());
-    hipLaunchKernelGGL(pointwise_mul_kernel, dim3(mle_grid(n)), dim3(MLE_BLOCK), 0, c->stream, d_a, d_b, n, d_out);
+    hipLaunchKernelGGL(pointwise_mul_kernel, dim3(mle_grid_stream(n)), dim3(MLE_BLOCK), 0, c->stream, d_a, d_b, n, d_out);
     ZK_HIP(c, hipGetLastError());
     return ZKHIP_OK;
 }
@@ -145,7 +145,7 @@ extern "C" int zkhip_univariate_multiply(zkhip_ctx* c, const uint64_t* d_a, size
     ZK_HIP(c, hipMemcpyAsync(eb, d_b, nb * 32, hipMemcpyDeviceToDevice, c->stream));
     ZK_TRY(ntt_inplace(c, ea, log_n, 0, scratch));                                                   // domain.fft :76-77
     ZK_TRY(ntt_inplace(c, eb, log_n, 0, scratch));
-    hipLaunchKernelGGL(pointwise_mul_kernel, dim3(mle_grid(n)), dim3(MLE_BLOCK), 0, c->stream, ea, eb, n, ea);   // :79-82
+    hipLaunchKernelGGL(pointwise_mul_kernel, dim3(mle_grid_stream(n)), dim3(MLE_BLOCK), 0, c->stream, ea, eb, n, ea);   // :79-82
     ZK_TRY(ntt_inplace(c, ea, log_n, 1, scratch));                                                   // domain.ifft :84
     ZK_HIP(c, hipMemcpyAsync(d_out, ea, unscaled * 32, hipMemcpyDeviceToDevice, c->stream));         // truncate :85
     return ZKHIP_OK;

@@ -150,7 +150,7 @@ static int launch_fold(zkhip_ctx* c, const uint64_t* d_in, size_t n, const uint6
     if (h_r) std::memcpy(rv.v, h_r, 32);
     const size_t n_out = n / 2;
     const uint32_t log_half = log2_exact(n) - 1 - var_index;
-    const int grid = mle_grid((n_out + 1) / 2);
+    const int grid = with_sums ? mle_grid((n_out + 1) / 2) : mle_grid_stream((n_out + 1) / 2);   // with sums: one record per workgroup
     ProfScope ps(c, with_sums ? "fold_sums" : "fold", 48.0 * (double)n);
     if (with_sums)
         hipLaunchKernelGGL(fold_kernel<true>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_in, d_out, n_out, log_half,
@@ -294,7 +294,7 @@ static int distinct(zkhip_ctx* c, bool mul, const uint64_t* d_a, size_t na, cons
     if (!is_pow2(na * nb)) return ZKHIP_ERR_SHAPE;   // Self::new(new_evaluations) asserts a power of two
     ZK_TRY(c->activate());
     const size_t n_out = na * nb;
-    const int grid = mle_grid(n_out);
+    const int grid = mle_grid_stream(n_out);
     if (mul)
         hipLaunchKernelGGL(distinct_kernel<true>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_a, d_b, nb, n_out, d_out);
     else
@@ -312,7 +312,7 @@ extern "C" int zkhip_mle_elementwise(zkhip_ctx* c, int op, const uint64_t* d_a, 
     if (!c || !d_a || !d_out || op < 0 || op > 2) return ZKHIP_ERR_ARG;
     if (op == 2 ? !h_scalar : !d_b) return ZKHIP_ERR_ARG;
     ZK_TRY(c->activate());
-    const int grid = mle_grid(n);
+    const int grid = mle_grid_stream(n);
     FrArg sc = {};
     if (op == 2) {
         std::memcpy(sc.v, h_scalar, 32);
@@ -329,7 +329,7 @@ extern "C" int zkhip_mle_elementwise(zkhip_ctx* c, int op, const uint64_t* d_a, 
 extern "C" int zkhip_mle_to_bytes(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint8_t* d_out_bytes) {
     if (!c || !d_evals || !d_out_bytes) return ZKHIP_ERR_ARG;
     ZK_TRY(c->activate());
-    hipLaunchKernelGGL(to_bytes_kernel, dim3(mle_grid(n)), dim3(MLE_BLOCK), 0, c->stream, d_evals, n,
+    hipLaunchKernelGGL(to_bytes_kernel, dim3(mle_grid_stream(n)), dim3(MLE_BLOCK), 0, c->stream, d_evals, n,
                        (uint32_t*)d_out_bytes);
     ZK_HIP(c, hipGetLastError());
     return ZKHIP_OK;
@@ -340,7 +340,7 @@ extern "C" int zkhip_mle_add_to_front(zkhip_ctx* c, const uint64_t* d_evals, siz
     if (!is_pow2(n) || variable_length > 40) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
     const size_t n_out = n * ((size_t)2 << variable_length);
-    hipLaunchKernelGGL(repeat_kernel, dim3(mle_grid(n_out)), dim3(MLE_BLOCK), 0, c->stream, d_evals, n, 0u, n_out, d_out);
+    hipLaunchKernelGGL(repeat_kernel, dim3(mle_grid_stream(n_out)), dim3(MLE_BLOCK), 0, c->stream, d_evals, n, 0u, n_out, d_out);
     ZK_HIP(c, hipGetLastError());
     return ZKHIP_OK;
 }
@@ -353,7 +353,7 @@ extern "C" int zkhip_mle_add_to_back(zkhip_ctx* c, const uint64_t* d_evals, size
         return ZKHIP_OK;
     }
     const size_t n_out = n << variable_length;
-    hipLaunchKernelGGL(repeat_kernel, dim3(mle_grid(n_out)), dim3(MLE_BLOCK), 0, c->stream, d_evals, n, variable_length, n_out, d_out);
+    hipLaunchKernelGGL(repeat_kernel, dim3(mle_grid_stream(n_out)), dim3(MLE_BLOCK), 0, c->stream, d_evals, n, variable_length, n_out, d_out);
     ZK_HIP(c, hipGetLastError());
     return ZKHIP_OK;
 }
