@@ -1,0 +1,134 @@
+"""Randomised parity stress against the CPU oracle (test infrastructure): random shapes and sizes for a given time budget.
+Usage: python tools/stress_parity.py [seconds] [seed].  Prints one line per failure and a summary; exit code = #failures."""
+import sys, os, time, random
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import zk_cryptography_amd as zk
+from oracle import oracle as ora
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+fails, counts = 0, {}
+dev = lambda t: t.cpu().numpy().view(np.uint64)
+
+
+def case_sumcheck():
+    log_n = rng.randint(0, 19)
+    t = ora.random_fr(1 << log_n, rng.randrange(1 << 30))
+    sc = zk.Sumcheck(zk.Multilinear(t))
+    if rng.random() < 0.8: sc.poly_sum()
+    proof, ch = sc.prove()
+    if sc._sum_dev is None and not np.any(sc.sum):
+        return "skip"   # prove() without poly_sum absorbs a zero sum; the oracle call below assumes the true sum
+    ws, wrp, wch = ora.sumcheck_prove(t)
+    return np.array_equal(proof.sum, ws) and np.array_equal(proof.univariate_poly, wrp) and np.array_equal(ch, wch), ("sumcheck", log_n)
+
+
+def case_fold_eval():
+    log_n = rng.randint(1, 18)
+    t = ora.random_fr(1 << log_n, rng.randrange(1 << 30))
+    k = rng.randrange(log_n)
+    r = ora.random_fr(1, rng.randrange(1 << 30))[0]
+    p = zk.Multilinear(t)
+    ok = np.array_equal(dev(p.partial_evaluation(r, k).evaluations), ora.mle_partial_evaluation(t, r, k))
+    pts = ora.random_fr(log_n, rng.randrange(1 << 30))
+    ok = ok and np.array_equal(p.evaluation(pts), ora.mle_evaluation(t, pts))
+    return ok, ("fold/eval", log_n, k)
+
+
+def case_composed():
+    k, log_n = rng.randint(1, 5), rng.randint(1, 14)
+    t = np.stack([ora.random_fr(1 << log_n, rng.randrange(1 << 30)) for _ in range(k)])
+    proof, ch = zk.ComposedSumcheck(zk.ComposedMultilinear(list(t))).prove()
+    rp, och = ora.composed_prove(t)
+    return np.array_equal(proof.round_polys, rp) and np.array_equal(ch, och), ("composed", k, log_n)
+
+
+def case_multi():
+    n_terms = rng.randint(1, 4)
+    sizes = [rng.randint(1, 5) for _ in range(n_terms)]
+    while sum(s + 1 for s in sizes) > 16: sizes.pop()
+    log_n = rng.randint(1, 12)
+    flat = np.stack([ora.random_fr(1 << log_n, rng.randrange(1 << 30)) for _ in range(sum(sizes))])
+    if rng.random() < 0.3: flat[rng.randrange(len(flat))][:] = 0          # a zero table: zero coefficients dropped per term
+    terms, q = [], 0
+    for k in sizes:
+        terms.append(zk.ComposedMultilinear([zk.Multilinear(flat[q + i]) for i in range(k)])); q += k
+    s = zk.MultiComposedSumcheckProver.calculate_poly_sum(terms)
+    partial = rng.random() < 0.5
+    fn = zk.MultiComposedSumcheckProver.prove_partial if partial else zk.MultiComposedSumcheckProver.prove
+    proof, ch = fn(terms, s)
+    orps, och = ora.multi_composed_prove(flat, sizes, s, partial=partial)
+    return (np.array_equal(s, ora.multi_composed_sum(flat, sizes)) and proof.to_bytes() == ora.multi_composed_proof_bytes(orps)
+            and np.array_equal(ch, och)), ("multi", sizes, log_n, partial)
+
+
+_srs = {}
+def case_commit():
+    nv = rng.randint(1, 10)
+    if nv not in _srs:
+        tau = ora.random_fr(nv, 1000 + nv)
+        _srs[nv] = (zk.TrustedSetup.setup(tau), ora.kzg_multilinear_srs_g1(tau))
+    srs, osrs = _srs[nv]
+    kind = rng.choice(["uniform", "small", "sparse", "same"])
+    n = 1 << nv
+    if kind == "uniform": v = ora.random_fr(n, rng.randrange(1 << 30))
+    elif kind == "small": v = zk.Fr.from_ints([rng.randrange(0, 300) for _ in range(n)])
+    elif kind == "sparse": v = zk.Fr.from_ints([rng.randrange(1 << 200) if rng.random() < 0.1 else 0 for _ in range(n)])
+    else: v = zk.Fr.from_ints([zk.Fr.MODULUS - 1] * n)
+    com = zk.MultilinearKZG.commitment(zk.Multilinear(v), srs)
+    want = ora.g1_to_affine(ora.kzg_commitment(v, osrs, True))
+    return (bool(want[12]) == com.infinity) and (com.infinity or np.array_equal(com.xy, want[:12])), ("commit", nv, kind)
+
+
+def case_ntt():
+    log_n = rng.randint(0, 15)
+    x = ora.random_fr(1 << log_n, rng.randrange(1 << 30))
+    d = zk.Domain(1 << log_n)
+    ok = np.array_equal(dev(d.fft(x)), ora.domain_fft(x, 1 << log_n)) and np.array_equal(dev(d.ifft(x)), ora.domain_ifft(x, 1 << log_n))
+    na, nb = rng.randint(1, 3000), rng.randint(1, 3000)
+    a, b = ora.random_fr(na, rng.randrange(1 << 30)), ora.random_fr(nb, rng.randrange(1 << 30))
+    got = dev(zk.UnivariateEval.multiply(zk.DenseUnivariatePolynomial(a), zk.DenseUnivariatePolynomial(b)).coefficients)
+    return ok and np.array_equal(got, ora.univariate_multiply(a, b)), ("ntt", log_n, na, nb)
+
+
+def case_gkr():
+    from gkr_cases import A, M
+    depth = rng.randint(1, 6)
+    layers = []
+    for li in range(depth):
+        n_in = 2 ** (li + 1)
+        layers.append([(rng.choice((A, M)), rng.randrange(n_in), rng.randrange(n_in)) for _ in range(2 ** li)])
+    if depth >= 1: layers[0] = layers[0][:1]
+    inp = ora.random_fr(2 ** depth, rng.randrange(1 << 30))
+    circuit = zk.Circuit.from_tuples(layers)
+    ev = circuit.evaluation(inp)
+    proof = zk.GKRProtocol.prove(circuit, ev)
+    want = ora.gkr_prove(layers, ora.circuit_evaluation(layers, inp))
+    ok = True
+    for k, sp in enumerate(proof.sumcheck_proofs):
+        w_sum, w_rps, w_wb, w_wc = want.layer(k)
+        ok = ok and np.array_equal(sp.sum, w_sum) and sp.to_bytes() == ora.multi_composed_proof_bytes(w_rps)
+        ok = ok and np.array_equal(proof.wb_s[k], w_wb) and np.array_equal(proof.wc_s[k], w_wc)
+    return ok, ("gkr", depth)
+
+
+cases = [case_sumcheck, case_fold_eval, case_composed, case_multi, case_commit, case_ntt, case_gkr]
+if len(sys.argv) > 3:
+    cases = [c for c in cases if c.__name__ in sys.argv[3:]]
+t0 = time.time()
+while time.time() - t0 < budget:
+    fn = rng.choice(cases)
+    try:
+        res = fn()
+    except Exception as e:   # an exception is a failure too
+        res = (False, (fn.__name__, "EXCEPTION %s: %s" % (type(e).__name__, e)))
+    if res == "skip": continue
+    ok, what = res
+    counts[fn.__name__] = counts.get(fn.__name__, 0) + 1
+    if not ok:
+        fails += 1
+        print("FAIL", what, flush=True)
+print("cases:", counts, "failures:", fails)
+sys.exit(min(fails, 100))
