@@ -114,7 +114,54 @@ def case_gkr():
     return ok, ("gkr", depth)
 
 
-cases = [case_sumcheck, case_fold_eval, case_composed, case_multi, case_commit, case_ntt, case_gkr]
+def case_open():
+    nv = rng.randint(2, 5)
+    if nv not in _srs:
+        tau = ora.random_fr(nv, 1000 + nv)
+        _srs[nv] = (zk.TrustedSetup.setup(tau), ora.kzg_multilinear_srs_g1(tau))
+    srs, osrs = _srs[nv]
+    v, z = ora.random_fr(1 << nv, rng.randrange(1 << 30)), ora.random_fr(nv, rng.randrange(1 << 30))
+    proof = zk.MultilinearKZG.open(zk.Multilinear(v), z, srs, cache_folded_srs=rng.random() < 0.5)
+    want_ev, want_proofs = ora.kzg_open(v, z, osrs)
+    ok = np.array_equal(proof.evaluation, want_ev)
+    for got, w in zip(proof.proofs, want_proofs):
+        a = ora.g1_to_affine(w)
+        ok = ok and (bool(a[12]) == got.infinity) and (got.infinity or np.array_equal(got.xy, a[:12]))
+    return ok, ("open", nv)
+
+
+_usrs = {}
+def case_uni_open():
+    n = rng.randint(1, 200)
+    if "s" not in _usrs:
+        tau = ora.random_fr(1, 555)[0]
+        _usrs["s"] = (zk.UnivariateKZG.generate_srs(tau, 200), ora.kzg_univariate_srs_g1(tau, 200))
+    srs, osrs = _usrs["s"]
+    c, z = ora.random_fr(n, rng.randrange(1 << 30)), ora.random_fr(1, rng.randrange(1 << 30))[0]
+    proof = zk.UnivariateKZG.open(zk.DenseUnivariatePolynomial(c), z, srs)
+    want_ev, want_proof = ora.univariate_kzg_open(c, z, osrs)
+    a = ora.g1_to_affine(want_proof)
+    ok = np.array_equal(proof.evaluation, want_ev) and (bool(a[12]) == proof.proof.infinity) and (proof.proof.infinity or np.array_equal(proof.proof.xy, a[:12]))
+    com = zk.UnivariateKZG.commitment(zk.DenseUnivariatePolynomial(c), srs)
+    w = ora.g1_to_affine(ora.kzg_commitment(c, osrs, False))
+    return ok and np.array_equal(com.xy, w[:12]), ("uni_open", n)
+
+
+def case_table_ops():
+    la, lb = rng.randint(0, 7), rng.randint(0, 7)
+    a, b = ora.random_fr(1 << la, rng.randrange(1 << 30)), ora.random_fr(1 << lb, rng.randrange(1 << 30))
+    pa, pb = zk.Multilinear(a), zk.Multilinear(b)
+    ok = np.array_equal(dev(pa.add_distinct(pb).evaluations), ora.mle_add_distinct(a, b))
+    ok = ok and np.array_equal(dev(pa.mul_distinct(pb).evaluations), ora.mle_mul_distinct(a, b))
+    k = rng.randint(0, 5)
+    ok = ok and np.array_equal(dev(pa.add_to_front(k).evaluations), ora.mle_add_to_front(a, k))
+    ok = ok and np.array_equal(dev(pa.add_to_back(k).evaluations), ora.mle_add_to_back(a, k))
+    ok = ok and pa.to_bytes() == ora.mle_to_bytes(a)
+    hs = ora.mle_half_sums(a) if la > 0 else None
+    return ok, ("table_ops", la, lb, k)
+
+
+cases = [case_open, case_uni_open, case_table_ops, case_sumcheck, case_fold_eval, case_composed, case_multi, case_commit, case_ntt, case_gkr]
 if len(sys.argv) > 3:
     cases = [c for c in cases if c.__name__ in sys.argv[3:]]
 t0 = time.time()
