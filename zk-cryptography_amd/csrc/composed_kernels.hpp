@@ -407,6 +407,54 @@ static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(Ta
     uint32_t cn = m, first = ca.first;
     const uint32_t wave = threadIdx.x >> 6;
     for (uint32_t round = ca.round; round < ca.round + n_rounds; ++round) {
+        // Late rounds (all pairs fit one wave): wave w computes evaluation w of the record -- one point t of one term -- for
+        // every pair and reduces it, so the critical path is K - 1 products and ONE wave reduction instead of all (K + 1) points
+        // of all terms one after another on the same lanes.  Field arithmetic is exact: same sums.
+        if ((cn >> 1) <= 64 && ca.meta.rec <= CMP_TAIL_BLOCK / 64) {
+            const uint32_t half = cn >> 1, lane = threadIdx.x & 63;
+            if (wave < ca.meta.rec) {
+                uint32_t p = 0, q0w = 0;
+                while (p + 1 < ca.meta.n_terms && wave >= ca.meta.rec_off[p + 1]) { q0w += ca.meta.k[p]; ++p; }
+                const uint32_t t = wave - ca.meta.rec_off[p], K = ca.meta.k[p];
+                Fr s = Fr::zero();
+                if (lane < half) {
+                    for (uint32_t k = 0; k < K; ++k) {
+                        const Fr lo = lds_load_fr(tab, (q0w + k) * m + lane), hi = lds_load_fr(tab, (q0w + k) * m + lane + half);
+                        Fr v = t == 0 ? lo : hi;
+                        if (t >= 2) {
+                            const Fr d = hi - lo;
+                            for (uint32_t i = 1; i < t; ++i) v = v + d;
+                        }
+                        s = k == 0 ? v : fr_mul_outlined(s, v);
+                    }
+                    if (ca.meta.lin_tab[p] != ~0u) {
+                        const uint32_t lq = ca.meta.lin_tab[p];
+                        const Fr lo = lds_load_fr(tab, lq * m + lane), hi = lds_load_fr(tab, lq * m + lane + half);
+                        Fr v = t == 0 ? lo : hi;
+                        if (t >= 2) {
+                            const Fr d = hi - lo;
+                            for (uint32_t i = 1; i < t; ++i) v = v + d;
+                        }
+                        s = s + v;
+                    }
+                }
+                s = wave_reduce_fr(s);
+                if (lane == 0) sh.evals[wave] = s;
+            }
+            __syncthreads();
+            close_round(sh, ca.meta, ca.st, &trs, round, first, ca.round_out, ca.challenges);
+            first = 0;
+            if (cn == 2) break;
+            const Fr r = sh.challenge;
+            for (uint32_t idx = threadIdx.x; idx < total * half; idx += CMP_TAIL_BLOCK) {
+                const uint32_t q = idx / half, j = idx % half;
+                const Fr lo = lds_load_fr(tab, q * m + j), hi = lds_load_fr(tab, q * m + j + half);
+                lds_store_fr(tab, q * m + j, fold_pair(lo, hi, r));
+            }
+            __syncthreads();
+            cn = half;
+            continue;
+        }
         uint32_t q0 = 0;
         for (uint32_t p = 0; p < ca.meta.n_terms; ++p) {
             const uint32_t* base = tab + 8 * (size_t)q0 * m;
