@@ -80,6 +80,7 @@ struct ComposedDev {
 };
 struct CloseShared {                   // LDS scratch of close_round
     Fr evals[CMP_MAX_REC];             // the round's sums: term p's evaluations at t = 0..K_p from rec_off[p]
+    Fr prod[CMP_MAX_REC * (CMP_MAX_K + 1)];   // interpolation products, (record entry, i)
     Fr term_coeff[CMP_MAX_TERMS][CMP_MAX_MONO];
     Fr canon[CMP_MAX_MONO];            // canonical integers of what the transcript absorbs, in order
     uint32_t pow_of[CMP_MAX_MONO];
@@ -117,13 +118,24 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
     } else {
         // round_poly = sum over terms of interpolation(evals at x = 0..K)  (:79-95); coefficients that are zero
         // are dropped per term (sparse_univariate.rs:55) but a zero produced by the sum is kept (:159-203).
+        // coefficient k of term p = sum_i interp[d][k][i] * eval_i: one lane per product (p, k, i) -- at most 4 * 36 of them --
+        // then one lane per coefficient adds its d + 1 products; a chain of d + 1 products per lane cost 2.6 us per round
+        {
+            uint32_t p = 0, base = 0;
+            while (p < meta.n_terms && tid >= base + (meta.k[p] + 1) * (meta.k[p] + 1)) { base += (meta.k[p] + 1) * (meta.k[p] + 1); ++p; }
+            if (p < meta.n_terms) {
+                const uint32_t d = meta.k[p], e = tid - base, k = e / (d + 1), i = e % (d + 1);
+                sh.prod[(meta.rec_off[p] + k) * (CMP_MAX_K + 1) + i] =
+                    fr_mul_outlined(load_fr(&st->interp[d][k * (d + 1) + i][0], 0), sh.evals[meta.rec_off[p] + i]);
+            }
+        }
+        __syncthreads();
         if (tid < meta.rec) {
             uint32_t p = 0;
             while (p + 1 < meta.n_terms && tid >= meta.rec_off[p + 1]) ++p;
             const uint32_t d = meta.k[p], k = tid - meta.rec_off[p];
-            Fr c = Fr::zero();
-            for (uint32_t i = 0; i <= d; ++i)
-                c = c + fr_mul_outlined(load_fr(&st->interp[d][k * (d + 1) + i][0], 0), sh.evals[meta.rec_off[p] + i]);
+            Fr c = sh.prod[tid * (CMP_MAX_K + 1)];
+            for (uint32_t i = 1; i <= d; ++i) c = c + sh.prod[tid * (CMP_MAX_K + 1) + i];
             sh.term_coeff[p][k] = c;
         }
         __syncthreads();
@@ -143,9 +155,9 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
                 sh.canon[at] = fr_from_mont_outlined(coeff);
                 sh.pow_of[at] = tid;
                 store_fr(out + 8, 2 * at, coeff);
-                Fr powm = Fr::zero();
-                powm.l[0] = tid;
-                store_fr(out + 8, 2 * at + 1, fr_to_mont_outlined(powm));
+                Fr powm = Fr::zero();                        // Fr::from(tid): tid <= 5 additions of one instead of a product
+                for (uint32_t i = 0; i < tid; ++i) powm = powm + Fr::one();
+                store_fr(out + 8, 2 * at + 1, powm);
             }
             if (tid == 0) { sh.n_items = (uint32_t)__popcll(mask); out[0] = (uint64_t)__popcll(mask); }
         }
