@@ -100,6 +100,7 @@ struct ComposedRun {
     uint64_t *d_partials = nullptr, *d_rp = nullptr, *d_ch = nullptr;
     std::vector<const uint64_t*> cur, lin_cur;
     uint32_t round = 0, first = 1, tail_len = 0;
+    uint32_t out_base = 0;   // rounds already recorded in d_rp / d_ch by an earlier call of the same sumcheck (cont): this call appends
 
     // n = entries per table held here, n_rounds = rounds of the whole sumcheck (log2 n, more when other ranks hold shards)
     int setup(zkhip_ctx* ctx, const uint64_t* const* ptrs, const uint32_t* sizes, uint32_t nt, size_t n_entries, uint32_t rounds,
@@ -151,15 +152,25 @@ struct ComposedRun {
             first = 0;
         }
         if (!multi) return ZKHIP_OK;
-        // interpolation matrices for the degrees in use
-        std::vector<uint64_t> mats((CMP_MAX_K + 1) * (CMP_MAX_K + 1) * (CMP_MAX_K + 1) * 4, 0);
-        for (uint32_t p = 0; p < n_terms; ++p) {
-            const int d = (int)sizes[p];
-            std::vector<zkhost::Fr> m = zkhost::interpolation_matrix(d);
-            std::memcpy(&mats[(size_t)d * (CMP_MAX_K + 1) * (CMP_MAX_K + 1) * 4], m.data(), m.size() * 32);
+        // interpolation matrices of every degree: they depend on nothing, so the context uploads them once and every prove
+        // copies them device to device (no host temporary, hence no synchronisation before the first round)
+        constexpr size_t interp_u64 = (size_t)(CMP_MAX_K + 1) * (CMP_MAX_K + 1) * (CMP_MAX_K + 1) * 4;
+        if (!c->d_interp) {
+            std::vector<uint64_t> mats(interp_u64, 0);
+            for (int d = 1; d <= CMP_MAX_K; ++d) {
+                std::vector<zkhost::Fr> m = zkhost::interpolation_matrix(d);
+                std::memcpy(&mats[(size_t)d * (CMP_MAX_K + 1) * (CMP_MAX_K + 1) * 4], m.data(), m.size() * 32);
+            }
+            void* mem = nullptr;
+            if (hipMalloc(&mem, interp_u64 * 8) != hipSuccess) return ZKHIP_ERR_NOMEM;
+            if (hipMemcpy(mem, mats.data(), interp_u64 * 8, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(mem); return ZKHIP_ERR_HIP; }
+            c->d_interp = mem;
         }
-        ZK_HIP(c, hipMemcpyAsync(st->interp, mats.data(), mats.size() * 8, hipMemcpyHostToDevice, c->stream));
-        if (h_sum) ZK_HIP(c, hipMemcpyAsync(st->sum, h_sum, 32, hipMemcpyHostToDevice, c->stream));
+        ZK_HIP(c, hipMemcpyAsync(st->interp, c->d_interp, interp_u64 * 8, hipMemcpyDeviceToDevice, c->stream));
+        if (h_sum) {   // through the pinned scratch: the caller's buffer need not outlive the call (the previous prove's collect() synchronised)
+            std::memcpy(c->pinned_u64(ZK_PIN_R), h_sum, 32);
+            ZK_HIP(c, hipMemcpyAsync(st->sum, c->pinned_u64(ZK_PIN_R), 32, hipMemcpyHostToDevice, c->stream));
+        }
         if (!partial && !cont) {
             // prove(): transcript.commit(&composed_poly_to_bytes(&poly)) first (multi_composed_sumcheck.rs:51-53).
             // The GPU produces the canonical big-endian bytes, the host hashes the (inherently sequential) stream.
@@ -194,17 +205,18 @@ struct ComposedRun {
             hs.fill = fill;
             hs.len = sha.len;
             ZK_HIP(c, hipMemcpyAsync(&st->transcript, &hs, sizeof(hs), hipMemcpyHostToDevice, c->stream));
+            ZK_HIP(c, hipStreamSynchronize(c->stream));   // hs is a stack temporary
             first = 2;
         }
-        ZK_HIP(c, hipStreamSynchronize(c->stream));   // hs / mats are stack/heap temporaries
         return ZKHIP_OK;
     }
     Sha256State* saved_transcript() const { return (Sha256State*)c->small_u64(ZK_SMALL_STATE); }   // handed from call to call (cont)
     bool folds() const { return round > 0; }
+    const uint64_t* prev_challenge() const { return d_ch + 4 * (size_t)(out_base + round - 1); }   // valid when folds()
     size_t after() const { return folds() ? cn / 2 : cn; }   // entries the current round's sums run over
     CloseArgs close_args() const {
         CloseArgs ca = {};
-        ca.meta = meta; ca.st = st; ca.round = round; ca.first = first; ca.round_out = d_rp; ca.challenges = d_ch;
+        ca.meta = meta; ca.st = st; ca.round = out_base + round; ca.first = first; ca.round_out = d_rp; ca.challenges = d_ch;
         return ca;
     }
     // The round on tables too large for one workgroup's LDS, first part: one launch per term (fold at the previous
@@ -229,7 +241,7 @@ struct ComposedRun {
                 tp.lin_out = (uint64_t*)((round & 1) ? base : base + (n / 2 + 1) * 32);
             }
             ProfScope ps(c, "composed_round", 0.0);
-#define CALL(KK) launch_round<KK>(c, fold, tp, cn, fold ? d_ch + 4 * (round - 1) : nullptr, meta.rec, meta.rec_off[p], d_partials, grid)
+#define CALL(KK) launch_round<KK>(c, fold, tp, cn, fold ? prev_challenge() : nullptr, meta.rec, meta.rec_off[p], d_partials, grid)
             ZK_DISPATCH_K(term_sizes[p], CALL)
 #undef CALL
             if (fold) for (uint32_t q = 0; q < term_sizes[p]; ++q) cur[off + q] = tp.out[q];
@@ -252,7 +264,7 @@ struct ComposedRun {
         ZK_TRY(c->allow_big_lds((const void*)composed_tail_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
         ProfScope ps(c, "composed_tail", 0.0);
         hipLaunchKernelGGL(composed_tail_kernel, dim3(1), dim3(CMP_TAIL_BLOCK), (size_t)total_all * m * 32, c->stream, tt, total_all, m,
-                           fold ? 1u : 0u, fold ? d_ch + 4 * (round - 1) : nullptr, close_args(), n_rounds - round);
+                           fold ? 1u : 0u, fold ? prev_challenge() : nullptr, close_args(), n_rounds - round);
         round = n_rounds;
         return ZKHIP_OK;
     }
@@ -263,9 +275,22 @@ struct ComposedRun {
         return tt;
     }
     // round polynomials and challenges to the host, in the layouts of the C ABI
-    int collect(uint32_t* h_lens, uint64_t* h_round_polys, uint64_t* h_challenges) {
+    // leaves the transcript where a continuation (cont) picks it up
+    int save_transcript() {
         ZK_HIP(c, hipGetLastError());
         if (multi) ZK_HIP(c, hipMemcpyAsync(saved_transcript(), &st->transcript, sizeof(Sha256State), hipMemcpyDeviceToDevice, c->stream));
+        return ZKHIP_OK;
+    }
+    int collect(uint32_t* h_lens, uint64_t* h_round_polys, uint64_t* h_challenges) {
+        ZK_TRY(save_transcript());
+        return collect_rounds(c, multi, term_sizes[0], out_base + n_rounds, h_lens, h_round_polys, h_challenges);
+    }
+    // the first `rounds` recorded rounds (of this call and the calls it continued) to the host
+    static int collect_rounds(zkhip_ctx* c, int multi, uint32_t k0, uint32_t n_rounds, uint32_t* h_lens, uint64_t* h_round_polys,
+                              uint64_t* h_challenges) {
+        const uint64_t* d_rp = c->small_u64(ZK_SMALL_ROUNDPOLYS);
+        const uint64_t* d_ch = c->small_u64(ZK_SMALL_CHALLENGES);
+        const uint32_t term_sizes[1] = {k0};
         std::vector<uint64_t> h_rp(64 * (size_t)n_rounds);
         ZK_HIP(c, hipMemcpyAsync(h_rp.data(), d_rp, 64 * 8 * (size_t)n_rounds, hipMemcpyDeviceToHost, c->stream));
         ZK_HIP(c, hipMemcpyAsync(h_challenges, d_ch, 32 * (size_t)n_rounds, hipMemcpyDeviceToHost, c->stream));
@@ -309,12 +334,35 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
     return run.collect(h_lens, h_round_polys, h_challenges);
 }
 
-// internal entry for gkr.hip (same shared object; not part of the C ABI)
-int zk_multi_composed_prove_ex(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes, const uint64_t* const* lin_ptrs,
-                               uint32_t n_terms, size_t n, const uint64_t* h_sum, int cont, uint32_t* h_lens, uint64_t* h_round_polys,
-                               uint64_t* h_challenges) {
-    return composed_prove_impl(c, ptrs, term_sizes, n_terms, n, 1, h_sum, 1, h_lens, h_round_polys, h_challenges, lin_ptrs, cont);
+// Internal entries for gkr.hip (same shared object; not part of the C ABI): the two halves of prove_partial.  A caller chains the
+// calls of ONE sumcheck on the device -- `cont` continues the transcript, `out_base` appends to the rounds already recorded --
+// and reads all rounds back once (zk_multi_composed_collect), so nothing between the calls waits for the host.
+int zk_multi_composed_enqueue(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes, const uint64_t* const* lin_ptrs,
+                              uint32_t n_terms, size_t n, const uint64_t* h_sum, int cont, uint32_t out_base) {
+    if (!c || !ptrs || !term_sizes || n_terms == 0 || n_terms > CMP_MAX_TERMS || (!h_sum && !cont)) return ZKHIP_ERR_ARG;
+    if (!is_pow2(n) || n < 2) return ZKHIP_ERR_SHAPE;
+    const uint32_t n_vars = log2_exact(n);
+    if (out_base + n_vars > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    ComposedRun run;
+    ZK_TRY(run.setup(c, ptrs, term_sizes, n_terms, n, n_vars, 1, h_sum, 1, lin_ptrs, cont));
+    run.out_base = out_base;
+    while (run.round < n_vars) {
+        if (run.after() <= run.tail_len) {
+            ZK_TRY(run.tail(run.current_tables(), (uint32_t)run.after(), run.folds()));
+            break;
+        }
+        int grid = 0;
+        ZK_TRY(run.round_sums(&grid));
+        run.close(run.d_partials, (uint32_t)grid);
+    }
+    return run.save_transcript();
 }
+int zk_multi_composed_collect(zkhip_ctx* c, uint32_t n_rounds, uint32_t* h_lens, uint64_t* h_round_polys, uint64_t* h_challenges) {
+    return ComposedRun::collect_rounds(c, 1, 0, n_rounds, h_lens, h_round_polys, h_challenges);
+}
+// device addresses of the recorded challenges (4 u64 per round), for kernels that consume them without a host round trip
+const uint64_t* zk_composed_challenges_dev(zkhip_ctx* c) { return c->small_u64(ZK_SMALL_CHALLENGES); }
 
 extern "C" int zkhip_composed_prove(zkhip_ctx* c, const uint64_t* const* ptrs, uint32_t k, size_t n, uint64_t* h_round_polys,
                                     uint64_t* h_challenges) {
@@ -405,7 +453,7 @@ extern "C" int zkhip_mc_local_tables(zkhip_mc_state* s, uint64_t* d_out) {
         uint64_t* dst = d_out + (size_t)q * m * 4;
         if (run.folds()) {   // the fold at the last challenge is still pending (the next round's kernel would have done it)
             hipLaunchKernelGGL(fold_kernel<false>, dim3(mle_grid_stream((m + 1) / 2)), dim3(MLE_BLOCK), 0, run.c->stream, tt.in[q], dst, m, log2_exact(m),
-                               run.d_ch + 4 * (run.round - 1), FrArg{}, (uint64_t*)nullptr);
+                               run.prev_challenge(), FrArg{}, (uint64_t*)nullptr);
         } else {
             ZK_HIP(run.c, hipMemcpyAsync(dst, tt.in[q], m * 32, hipMemcpyDeviceToDevice, run.c->stream));
         }

@@ -73,23 +73,24 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_rows_kernel(const u
     if (phase == 1) store_fr(lin_out, x, l);
     store_fr(mul_out, x, m);
 }
-// eq_x(u) over n_vars index bits, MSB first (the b side of the wiring at the phase-1 challenges)
-static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_table_kernel(PtsArg u, uint32_t n_vars, uint64_t* __restrict__ out) {
+// eq_x(u) over n_vars index bits, MSB first (the b side of the wiring at the phase-1 challenges).  The points are read from
+// DEVICE memory -- where the sumcheck that produced them left them -- so the host never waits for them.
+static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_table_kernel(const uint64_t* __restrict__ u, uint32_t n_vars, uint64_t* __restrict__ out) {
     const size_t n = (size_t)1 << n_vars, stride = (size_t)gridDim.x * MLE_BLOCK;
     const Fr one = Fr::one();
     for (size_t i = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; i < n; i += stride) {
         Fr acc = one;
         for (uint32_t j = 0; j < n_vars; ++j) {
-            const Fr t = fr_from_pts(u, j);
+            const Fr t = load_fr(u, j);
             acc = acc * (((i >> (n_vars - 1 - j)) & 1) ? t : one - t);
         }
         store_fr(out, i, acc);
     }
 }
 // t1[c] = V(u) + V[c]  (wb_add_wc with b at u),  t2[c] = V(u) V[c]  (wb_mul_wc with b at u)
-static __global__ __launch_bounds__(MLE_BLOCK) void gkr_vu_tables_kernel(const uint64_t* __restrict__ v, size_t n, FrArg vu_v,
+static __global__ __launch_bounds__(MLE_BLOCK) void gkr_vu_tables_kernel(const uint64_t* __restrict__ v, size_t n, const uint64_t* __restrict__ vu_ptr,
                                                                   uint64_t* __restrict__ t1, uint64_t* __restrict__ t2) {
-    const Fr vu = fr_from_arg(vu_v);
+    const Fr vu = load_fr(vu_ptr, 0);                      // V(u), left on the device by gkr_dot_* below
     const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
     for (size_t i = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; i < n; i += stride) {
         const Fr x = load_fr(v, i);
@@ -97,11 +98,31 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_vu_tables_kernel(const u
         store_fr(t2, i, vu * x);
     }
 }
+// V(point) = sum_x eq_x(point) V[x]: the same field element as MultilinearTrait::evaluation's chain of folds (exact arithmetic).
+// One partial per workgroup, then one workgroup adds them; the result stays on the device.
+static __global__ __launch_bounds__(MLE_BLOCK) void gkr_dot_kernel(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, size_t n,
+                                                            uint64_t* __restrict__ partials) {
+    __shared__ Fr red[MLE_BLOCK / 64];
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    Fr s = Fr::zero();
+    for (size_t i = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; i < n; i += stride) s = s + load_fr(a, i) * load_fr(b, i);
+    s = block_reduce_fr(s, red);
+    if (threadIdx.x == 0) store_fr(partials, blockIdx.x, s);
+}
+static __global__ __launch_bounds__(MLE_BLOCK) void gkr_dot_finish_kernel(const uint64_t* __restrict__ partials, uint32_t n_partials,
+                                                                   uint64_t* __restrict__ out) {
+    __shared__ Fr red[MLE_BLOCK / 64];
+    Fr s = Fr::zero();
+    for (uint32_t i = threadIdx.x; i < n_partials; i += MLE_BLOCK) s = s + load_fr(partials, i);
+    s = block_reduce_fr(s, red);
+    if (threadIdx.x == 0) store_fr(out, 0, s);
+}
 }  // namespace zk
 
-int zk_multi_composed_prove_ex(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes, const uint64_t* const* lin_ptrs,
-                               uint32_t n_terms, size_t n, const uint64_t* h_sum, int cont, uint32_t* h_lens, uint64_t* h_round_polys,
-                               uint64_t* h_challenges);   // composed.hip
+int zk_multi_composed_enqueue(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes, const uint64_t* const* lin_ptrs,
+                              uint32_t n_terms, size_t n, const uint64_t* h_sum, int cont, uint32_t out_base);   // composed.hip
+int zk_multi_composed_collect(zkhip_ctx* c, uint32_t n_rounds, uint32_t* h_lens, uint64_t* h_round_polys, uint64_t* h_challenges);
+const uint64_t* zk_composed_challenges_dev(zkhip_ctx* c);
 
 namespace {
 
@@ -145,6 +166,7 @@ static void group_gates(const uint32_t* key, size_t n_gates, size_t n_rows, std:
 // device scratch of one layer (carved from the context's aux buffer)
 struct LayerScratch {
     uint64_t *wg, *ha0, *ha1, *hm, *equ, *aa, *am, *t1, *t2;
+    uint64_t *dot_partials, *evals;   // workgroup partials of gkr_dot_kernel; evals[0..4) = V(u) = w_b, evals[4..8) = V(r_c) = w_c
 };
 // one layer of a device-resident circuit: the gate arrays and their two CSR groupings (by in0 and by in1)
 struct LayerDev {
@@ -180,44 +202,51 @@ int layer_prove(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_
     hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr0, ld.csr0 + w_len + 1, ld.type, ld.in1, sc.wg, d_w,
                        (uint32_t)w_len, 1u, sc.ha0, sc.ha1, sc.hm);
     ZK_HIP(c, hipGetLastError());
+    // Everything up to the end of the layer's sumcheck is enqueued without waiting for the host: the rounds over c read the
+    // challenges of the rounds over b, V(u) and the eq table from device memory, the two composed-prover calls append to one
+    // array of recorded rounds, and the host reads rounds, challenges, w_b and w_c back once.
     const uint32_t nv = 2 * s;
     uint64_t* polys = out.round_polys + (size_t)k * out.stride * GKR_MONO * 8;
     uint32_t* lens = out.lens + (size_t)k * out.stride;
     std::vector<uint64_t> challenges(4 * (size_t)nv);
     const uint32_t sizes[2] = {2, 2};
+    const uint64_t* d_ch = zk_composed_challenges_dev(c);
+    const int dot_grid = mle_grid(w_len);
     {
         const uint64_t* tables[4] = {sc.ha0, d_w, sc.hm, d_w};          // [Ha0, V] + Ha1,  [Hm, V]
         const uint64_t* lin[2] = {sc.ha1, nullptr};
-        ZK_TRY(zk_multi_composed_prove_ex(c, tables, sizes, lin, 2, w_len, claimed.l, 0, lens, polys, challenges.data()));
+        ZK_TRY(zk_multi_composed_enqueue(c, tables, sizes, lin, 2, w_len, claimed.l, 0, 0));
     }
-    // ---- rounds over c, b at u
-    std::vector<zkhost::Fr> u(s);
-    std::memcpy(u.data(), challenges.data(), 32 * (size_t)s);
-    zkhost::Fr eval_wb;                                     // V(u): the factor of the second phase and w_b of the proof
-    ZK_TRY(zkhip_mle_evaluation(c, d_w, w_len, u[0].l, s, eval_wb.l));
-    PtsArg pu = {};
-    std::memcpy(pu.v, u[0].l, 32 * (size_t)s);
-    FrArg vu = {};
-    std::memcpy(vu.v, eval_wb.l, 32);
-    hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, pu, s, sc.equ);
+    // ---- rounds over c, b at u = the challenges just recorded
+    hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_ch, s, sc.equ);
+    hipLaunchKernelGGL(gkr_dot_kernel, dim3(dot_grid), dim3(MLE_BLOCK), 0, c->stream, sc.equ, d_w, w_len, sc.dot_partials);
+    hipLaunchKernelGGL(gkr_dot_finish_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, sc.dot_partials, (uint32_t)dot_grid, sc.evals);   // V(u): w_b and the factor of the second phase
     hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr1, ld.csr1 + w_len + 1, ld.type, ld.in0, sc.wg, sc.equ,
                        (uint32_t)w_len, 2u, sc.aa, (uint64_t*)nullptr, sc.am);
-    hipLaunchKernelGGL(gkr_vu_tables_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_w, w_len, vu, sc.t1, sc.t2);
+    hipLaunchKernelGGL(gkr_vu_tables_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_w, w_len, sc.evals, sc.t1, sc.t2);
     ZK_HIP(c, hipGetLastError());
     {
         const uint64_t* tables[4] = {sc.aa, sc.t1, sc.am, sc.t2};        // [add~(u, c), V(u) + V(c)],  [mul~(u, c), V(u) V(c)]
-        ZK_TRY(zk_multi_composed_prove_ex(c, tables, sizes, nullptr, 2, w_len, nullptr, 1, lens + s, polys + (size_t)s * GKR_MONO * 8,
-                                          challenges.data() + 4 * (size_t)s));
+        ZK_TRY(zk_multi_composed_enqueue(c, tables, sizes, nullptr, 2, w_len, nullptr, 1, s));
     }
+    // w_c = V(r_c), r_c = the second half of the challenges
+    hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_ch + 4 * (size_t)s, s, sc.equ);
+    hipLaunchKernelGGL(gkr_dot_kernel, dim3(dot_grid), dim3(MLE_BLOCK), 0, c->stream, sc.equ, d_w, w_len, sc.dot_partials);
+    hipLaunchKernelGGL(gkr_dot_finish_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, sc.dot_partials, (uint32_t)dot_grid, sc.evals + 4);
+    ZK_HIP(c, hipGetLastError());
+    zkhost::Fr eval_wb, eval_wc;
+    ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), sc.evals, 64, hipMemcpyDeviceToHost, c->stream));
+    ZK_TRY(zk_multi_composed_collect(c, nv, lens, polys, challenges.data()));   // synchronises the stream
+    std::memcpy(eval_wb.l, c->pinned_u64(ZK_PIN_RES), 32);
+    std::memcpy(eval_wc.l, c->pinned_u64(ZK_PIN_RES) + 4, 32);
     if (out.challenges) std::memcpy(out.challenges + (size_t)k * out.stride * 4, challenges.data(), 32 * (size_t)nv);
     std::memcpy(out.sums + 4 * (size_t)k, claimed.l, 32);
     out.n_rounds[k] = nv;
     absorb_proof(tr, polys, lens, nv);                                     // transcript.commit(&sumcheck_proof.to_bytes())
-    r_b = u;                                                               // challenges.split_at(len / 2)
+    r_b.assign(s, zkhost::fr_zero());                                      // challenges.split_at(len / 2)
+    std::memcpy(r_b.data(), challenges.data(), 32 * (size_t)s);
     r_c.assign(s, zkhost::fr_zero());
     std::memcpy(r_c.data(), challenges.data() + 4 * (size_t)s, 32 * (size_t)s);
-    zkhost::Fr eval_wc;
-    ZK_TRY(zkhip_mle_evaluation(c, d_w, w_len, r_c[0].l, s, eval_wc.l));
     std::memcpy(out.wb + 4 * (size_t)k, eval_wb.l, 32);
     std::memcpy(out.wc + 4 * (size_t)k, eval_wc.l, 32);
     alpha = tr.challenge_fr();
@@ -323,8 +352,8 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
     for (uint32_t l = 0; l < n_layers; ++l) { max_w = std::max(max_w, h_layer_len[l + 1]); max_g = std::max(max_g, cir->layers[l].n_gates); }
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t tb = al(32 * max_w);
-    const size_t o_w0 = 0, o_tab = al(64), o_wg = o_tab + 8 * tb;
-    ZK_TRY(c->reserve_aux(o_wg + al(32 * max_g)));
+    const size_t o_w0 = 0, o_tab = al(64), o_wg = o_tab + 8 * tb, o_dot = o_wg + al(32 * max_g), o_ev = o_dot + al(32 * (size_t)zk::MLE_MAX_GRID);
+    ZK_TRY(c->reserve_aux(o_ev + 256));
     char* aux = (char*)c->d_aux;
     uint64_t* d_w0 = (uint64_t*)(aux + o_w0);
     LayerScratch sc;
@@ -332,6 +361,7 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
     sc.equ = (uint64_t*)(aux + o_tab + 3 * tb); sc.aa = (uint64_t*)(aux + o_tab + 4 * tb); sc.am = (uint64_t*)(aux + o_tab + 5 * tb);
     sc.t1 = (uint64_t*)(aux + o_tab + 6 * tb); sc.t2 = (uint64_t*)(aux + o_tab + 7 * tb);
     sc.wg = (uint64_t*)(aux + o_wg);
+    sc.dot_partials = (uint64_t*)(aux + o_dot); sc.evals = (uint64_t*)(aux + o_ev);
     LayerOut out = {h_sums, h_round_polys, h_wb, h_wc, h_challenges, h_n_rounds, h_round_poly_lens, 2 * n_layers};
 
     // w_0 = circuit_evaluation[0] padded with a zero (protocol.rs:30-33); commit its bytes, draw n_r
