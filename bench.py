@@ -9,7 +9,9 @@ with the table already resident in HBM.  value = (tables' entries consumed by al
 
 Extra objects on the JSON line: `roofline` for the dominant kernel (the fused fold) from HIP
 events on the launch stream, and `cpu_baseline`: the CPU oracle (a C port of the reference
-algorithm, single-threaded like the reference) timed on rank 0 at N=1.
+algorithm, single-threaded like the reference) timed on rank 0 at N=1 (plus the same port on all host cores at once).
+Informational objects that never enter `value`: `msm` (the second half of BASELINE's metric: KZG commit points/s with its own
+roofline and CPU baseline), `composed` (ComposedSumcheck::prove over sharded tables) and `gkr` (GKRProtocol::prove, replicas).
 """
 import argparse
 import json
@@ -217,6 +219,30 @@ def bench_composed(args, zk, N, rank, world, barrier, dist, torch, np):
             "sharding": "tables sharded by low index bits, one 96-byte record per rank all-gathered per round" if world > 1 else "single GPU"}
 
 
+def bench_gkr(args, zk, rank, world, barrier, dist, torch, np):
+    """GKRProtocol::prove (gkr/src/protocol.rs:21-117) on Circuit::random(depth) -- the reference's gkr bench shape at depth 8,
+    BASELINE configs[3]'s width 2^20 at depth 20.  Replicas only: every rank proves its own circuit."""
+    out = {"workload": "GKRProtocol::prove on Circuit::random(depth), evaluation resident in HBM, circuit resident (zkhip_circuit)",
+           "replicas": world, "ms_per_proof": {}}
+    for depth in (8, 20):
+        circuit = zk.Circuit.random(depth)
+        ev = circuit.evaluation(zk.Fr.random(2 ** depth, 0x2001 + rank))
+        zk.GKRProtocol.prove(circuit, ev)
+        barrier()
+        reps = 5 if depth <= 8 else 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            zk.GKRProtocol.prove(circuit, ev)
+        barrier()
+        dt = (time.perf_counter() - t0) / reps
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        out["ms_per_proof"]["depth_%d" % depth] = round(1e3 * dt, 3)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,6 +254,7 @@ def main():
     ap.add_argument("--no-msm", action="store_true")
     ap.add_argument("--composed-log-n", type=int, default=22, help="log2 of the per-GPU table size of the composed-sumcheck leg")
     ap.add_argument("--no-composed", action="store_true")
+    ap.add_argument("--no-gkr", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="diagnostic: run the sharded prover protocol even on one GPU")
     args = ap.parse_args()
 
@@ -348,6 +375,13 @@ def main():
         except Exception as e:   # reported, not hidden: the headline legs above are already measured
             composed = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    gkr = None
+    if not args.no_gkr:
+        try:
+            gkr = bench_gkr(args, zk, rank, world, barrier, dist, torch, np)
+        except Exception as e:
+            gkr = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         total_evals = float(n) * world * args.steps
         out = {
@@ -374,6 +408,7 @@ def main():
             "cpu_baseline": cpu,
             "msm": msm,
             "composed": composed,
+            "gkr": gkr,
         }
         print(json.dumps(out))
     if world > 1:

@@ -18,7 +18,7 @@ def test_bench_multi_rank_dry_run(world):
     port = 29800 + (os.getpid() % 1000) + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
-           "--log-n", "22", "--msm-log-n", "12", "--composed-log-n", "15", "--no-cpu-baseline"]
+           "--log-n", "22", "--msm-log-n", "12", "--composed-log-n", "15", "--no-cpu-baseline"]   # the gkr leg runs too (replicas)
     out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
