@@ -100,7 +100,8 @@ struct ComposedRun {
     uint64_t *d_partials = nullptr, *d_rp = nullptr, *d_ch = nullptr;
     std::vector<const uint64_t*> cur, lin_cur;
     uint32_t round = 0, first = 1, tail_len = 0;
-    uint32_t out_base = 0;   // rounds already recorded in d_rp / d_ch by an earlier call of the same sumcheck (cont): this call appends
+    uint32_t out_base = 0;
+    FrArg sum_arg = {};      // the claimed sum, passed to the closing kernels by value   // rounds already recorded in d_rp / d_ch by an earlier call of the same sumcheck (cont): this call appends
 
     // n = entries per table held here, n_rounds = rounds of the whole sumcheck (log2 n, more when other ranks hold shards)
     int setup(zkhip_ctx* ctx, const uint64_t* const* ptrs, const uint32_t* sizes, uint32_t nt, size_t n_entries, uint32_t rounds,
@@ -136,41 +137,33 @@ struct ComposedRun {
         cur.assign(ptrs, ptrs + total);
         // workspace: per table a ping (n/2) and a pong (n/4) buffer, then the state
         per_table = (n / 2 + n / 4 + 2) * 32;
-        const size_t state_off = (total_all * per_table + 255) & ~(size_t)255;
-        const size_t bytes_off = state_off + ((sizeof(ComposedDev) + 255) & ~(size_t)255);
+        const size_t bytes_off = (total_all * per_table + 255) & ~(size_t)255;
         const size_t chunk = std::min<size_t>(n, (size_t)1 << 18);   // entries per staging buffer of prove()'s table-bytes pass
         ZK_TRY(c->reserve_ws(bytes_off + (multi && !partial ? 64 * chunk : 0)));
         ws = (char*)c->d_ws;
-        st = (ComposedDev*)(ws + state_off);
-        d_partials = c->small_u64(ZK_SMALL_PARTIALS);
-        d_rp = c->small_u64(ZK_SMALL_ROUNDPOLYS);
-        d_ch = c->small_u64(ZK_SMALL_CHALLENGES);
-        first = 1;
-        round = 0;
-        if (cont) {
-            ZK_HIP(c, hipMemcpyAsync(&st->transcript, saved_transcript(), sizeof(Sha256State), hipMemcpyDeviceToDevice, c->stream));
-            first = 0;
-        }
-        if (!multi) return ZKHIP_OK;
-        // interpolation matrices of every degree: they depend on nothing, so the context uploads them once and every prove
-        // copies them device to device (no host temporary, hence no synchronisation before the first round)
-        constexpr size_t interp_u64 = (size_t)(CMP_MAX_K + 1) * (CMP_MAX_K + 1) * (CMP_MAX_K + 1) * 4;
-        if (!c->d_interp) {
-            std::vector<uint64_t> mats(interp_u64, 0);
+        // the device-resident state (transcript, interpolation matrices of every degree) belongs to the context: uploaded once,
+        // and a continuation (cont) finds the transcript where the previous call's kernels left it -- no copies, no waiting
+        if (!c->d_composed) {
+            std::vector<uint64_t> img(sizeof(ComposedDev) / 8, 0);
+            uint64_t* mats = img.data() + offsetof(ComposedDev, interp) / 8;
             for (int d = 1; d <= CMP_MAX_K; ++d) {
                 std::vector<zkhost::Fr> m = zkhost::interpolation_matrix(d);
                 std::memcpy(&mats[(size_t)d * (CMP_MAX_K + 1) * (CMP_MAX_K + 1) * 4], m.data(), m.size() * 32);
             }
             void* mem = nullptr;
-            if (hipMalloc(&mem, interp_u64 * 8) != hipSuccess) return ZKHIP_ERR_NOMEM;
-            if (hipMemcpy(mem, mats.data(), interp_u64 * 8, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(mem); return ZKHIP_ERR_HIP; }
-            c->d_interp = mem;
+            if (hipMalloc(&mem, sizeof(ComposedDev)) != hipSuccess) return ZKHIP_ERR_NOMEM;
+            if (hipMemcpy(mem, img.data(), sizeof(ComposedDev), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(mem); return ZKHIP_ERR_HIP; }
+            c->d_composed = mem;
         }
-        ZK_HIP(c, hipMemcpyAsync(st->interp, c->d_interp, interp_u64 * 8, hipMemcpyDeviceToDevice, c->stream));
-        if (h_sum) {   // through the pinned scratch: the caller's buffer need not outlive the call (the previous prove's collect() synchronised)
-            std::memcpy(c->pinned_u64(ZK_PIN_R), h_sum, 32);
-            ZK_HIP(c, hipMemcpyAsync(st->sum, c->pinned_u64(ZK_PIN_R), 32, hipMemcpyHostToDevice, c->stream));
-        }
+        st = (ComposedDev*)c->d_composed;
+        d_partials = c->small_u64(ZK_SMALL_PARTIALS);
+        d_rp = c->small_u64(ZK_SMALL_ROUNDPOLYS);
+        d_ch = c->small_u64(ZK_SMALL_CHALLENGES);
+        first = 1;
+        round = 0;
+        if (cont) first = 0;                                   // st->transcript is the previous call's
+        if (!multi) return ZKHIP_OK;
+        if (h_sum) std::memcpy(sum_arg.v, h_sum, 32);
         if (!partial && !cont) {
             // prove(): transcript.commit(&composed_poly_to_bytes(&poly)) first (multi_composed_sumcheck.rs:51-53).
             // The GPU produces the canonical big-endian bytes, the host hashes the (inherently sequential) stream.
@@ -210,13 +203,12 @@ struct ComposedRun {
         }
         return ZKHIP_OK;
     }
-    Sha256State* saved_transcript() const { return (Sha256State*)c->small_u64(ZK_SMALL_STATE); }   // handed from call to call (cont)
     bool folds() const { return round > 0; }
     const uint64_t* prev_challenge() const { return d_ch + 4 * (size_t)(out_base + round - 1); }   // valid when folds()
     size_t after() const { return folds() ? cn / 2 : cn; }   // entries the current round's sums run over
     CloseArgs close_args() const {
         CloseArgs ca = {};
-        ca.meta = meta; ca.st = st; ca.round = out_base + round; ca.first = first; ca.round_out = d_rp; ca.challenges = d_ch;
+        ca.meta = meta; ca.st = st; ca.round = out_base + round; ca.first = first; ca.round_out = d_rp; ca.challenges = d_ch; ca.sum = sum_arg;
         return ca;
     }
     // The round on tables too large for one workgroup's LDS, first part: one launch per term (fold at the previous
@@ -278,8 +270,7 @@ struct ComposedRun {
     // leaves the transcript where a continuation (cont) picks it up
     int save_transcript() {
         ZK_HIP(c, hipGetLastError());
-        if (multi) ZK_HIP(c, hipMemcpyAsync(saved_transcript(), &st->transcript, sizeof(Sha256State), hipMemcpyDeviceToDevice, c->stream));
-        return ZKHIP_OK;
+        return ZKHIP_OK;                                       // the transcript already lives in the context's persistent state
     }
     int collect(uint32_t* h_lens, uint64_t* h_round_polys, uint64_t* h_challenges) {
         ZK_TRY(save_transcript());

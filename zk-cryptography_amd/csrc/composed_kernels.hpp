@@ -73,9 +73,8 @@ struct ComposedMeta {
 };
 // Device-resident state.  interp[d] is the (d+1)x(d+1) matrix taking evaluations at x = 0..d to coefficients
 // (Montgomery form), uploaded by the host once per prove.
-struct ComposedDev {
+struct ComposedDev {                   // one per context, persistent: a continuation finds the transcript where the last call left it
     Sha256State transcript;
-    uint64_t sum[4];
     uint64_t interp[CMP_MAX_K + 1][(CMP_MAX_K + 1) * (CMP_MAX_K + 1)][4];
 };
 struct CloseShared {                   // LDS scratch of close_round
@@ -102,7 +101,7 @@ struct CloseShared {                   // LDS scratch of close_round
 // Output per round (round_out + 64 * round, in u64):
 //   multi == 0: K+1 evaluations (4 u64 each);  multi == 1: [0] = #monomials, then (coeff, pow) pairs of 8 u64 from [8].
 // Only the hash chain is serial (thread 0); interpolation products and Montgomery conversions run one per lane.
-__device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta& meta, ComposedDev* st, Sha256State* tr_state,
+__device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta& meta, ComposedDev* st, const FrArg& claimed_sum, Sha256State* tr_state,
                                             uint32_t round, uint32_t first, uint64_t* __restrict__ round_out,
                                             uint64_t* __restrict__ challenges) {
     uint64_t* out = round_out + 64 * (size_t)round;
@@ -162,7 +161,7 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
             if (tid == 0) { sh.n_items = (uint32_t)__popcll(mask); out[0] = (uint64_t)__popcll(mask); }
         }
     }
-    if (meta.multi && first && tid == 64) sh.sum_canon = fr_from_mont_outlined(load_fr(st->sum, 0));   // multi_composed_sumcheck.rs:70
+    if (meta.multi && first && tid == 64) sh.sum_canon = fr_from_mont_outlined(fr_from_arg(claimed_sum));   // multi_composed_sumcheck.rs:70
     __syncthreads();
     // ---- the round's message, padded (FiatShamirTranscript: commit ... then challenge = finalize, fiat_shamir.rs:17-25):
     // what the hasher still holds || [claimed sum] || items || 0x80 00.. || bit length.  Every word is written by one lane.
@@ -287,6 +286,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TableP
 struct CloseArgs {
     ComposedMeta meta;
     ComposedDev* st;
+    FrArg sum;                          // the claimed sum (absorbed in the first round of a multi-composed proof)
     uint32_t round, first;
     uint64_t* round_out;
     uint64_t* challenges;
@@ -303,7 +303,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_close_kernel(const 
         if (lane == 0) sh.evals[v] = s;
     }
     __syncthreads();
-    close_round(sh, ca.meta, ca.st, &ca.st->transcript, ca.round, ca.first, ca.round_out, ca.challenges);
+    close_round(sh, ca.meta, ca.st, ca.sum, &ca.st->transcript, ca.round, ca.first, ca.round_out, ca.challenges);
 }
 
 // the records of a round summed into one (what a rank contributes to the exchange of the sharded protocol)
@@ -454,7 +454,7 @@ static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(Ta
                 if (lane == 0) sh.evals[wave] = s;
             }
             __syncthreads();
-            close_round(sh, ca.meta, ca.st, &trs, round, first, ca.round_out, ca.challenges);
+            close_round(sh, ca.meta, ca.st, ca.sum, &trs, round, first, ca.round_out, ca.challenges);
             first = 0;
             if (cn == 2) break;
             const Fr r = sh.challenge;
@@ -487,7 +487,7 @@ static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(Ta
             sh.evals[threadIdx.x] = s;
         }
         __syncthreads();
-        close_round(sh, ca.meta, ca.st, &trs, round, first, ca.round_out, ca.challenges);
+        close_round(sh, ca.meta, ca.st, ca.sum, &trs, round, first, ca.round_out, ca.challenges);
         first = 0;
         if (cn == 2) break;   // the fold after the last round has no consumer
         const Fr r = sh.challenge;

@@ -58,7 +58,7 @@ struct zkhip_ctx {
     int last_hip = 0;
     void* d_ws = nullptr;       // large workspace (ping-pong tables, MSM buckets, ...)
     size_t ws_bytes = 0;
-    void* d_interp = nullptr;      // composed provers: interpolation matrices of every degree 1..5 (ComposedDev::interp), uploaded once
+    void* d_composed = nullptr;      // composed provers: ComposedDev (transcript + interpolation matrices of every degree), uploaded once
     void* d_gen_table = nullptr;   // SRS generation: d * 2^(8w) * G for 32 windows x 255 digits, affine (+ infinity flags); built on first use
     void* d_aux = nullptr;      // second grow-only buffer for entry points that call others which own d_ws (kzg_open)
     size_t aux_bytes = 0;

@@ -61,7 +61,7 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     if (c->d_ws) hipFree(c->d_ws);
     if (c->d_aux) hipFree(c->d_aux);
     if (c->d_gen_table) hipFree(c->d_gen_table);
-    if (c->d_interp) hipFree(c->d_interp);
+    if (c->d_composed) hipFree(c->d_composed);
     for (int i = 0; i < zkhip_ctx::MSM_SLOTS; ++i) {
         if (c->msm_pin[i]) hipHostFree(c->msm_pin[i]);
         if (c->msm_ev[i]) hipEventDestroy(c->msm_ev[i]);
