@@ -87,7 +87,7 @@ extern "C" int zkhip_multi_composed_sum(zkhip_ctx* c, const uint64_t* const* ptr
 // split-phase session (zkhip_mc_*, tables sharded over several GPUs).  multi = 0: ComposedSumcheck (one term).
 // lin_ptrs (nullable): per term an optional additive table (term = product + table; K <= 2).  cont: continue the
 // transcript the previous call left in the context (its rounds are the next rounds of the same sumcheck) instead of
-// starting one; every one-call prove leaves its final transcript state there.
+// starting one (the transcript lives in the context's ComposedDev, where every call's kernels leave it).
 struct ComposedRun {
     zkhip_ctx* c = nullptr;
     ComposedMeta meta = {};
@@ -100,8 +100,8 @@ struct ComposedRun {
     uint64_t *d_partials = nullptr, *d_rp = nullptr, *d_ch = nullptr;
     std::vector<const uint64_t*> cur, lin_cur;
     uint32_t round = 0, first = 1, tail_len = 0;
-    uint32_t out_base = 0;
-    FrArg sum_arg = {};      // the claimed sum, passed to the closing kernels by value   // rounds already recorded in d_rp / d_ch by an earlier call of the same sumcheck (cont): this call appends
+    uint32_t out_base = 0;   // rounds already recorded in d_rp / d_ch by an earlier call of the same sumcheck (cont): this call appends
+    FrArg sum_arg = {};      // the claimed sum, passed to the closing kernels by value
 
     // n = entries per table held here, n_rounds = rounds of the whole sumcheck (log2 n, more when other ranks hold shards)
     int setup(zkhip_ctx* ctx, const uint64_t* const* ptrs, const uint32_t* sizes, uint32_t nt, size_t n_entries, uint32_t rounds,
@@ -267,13 +267,14 @@ struct ComposedRun {
         return tt;
     }
     // round polynomials and challenges to the host, in the layouts of the C ABI
-    // leaves the transcript where a continuation (cont) picks it up
-    int save_transcript() {
+    // launch errors of everything enqueued so far (the transcript already lives in the context's persistent state, where a
+    // continuation picks it up)
+    int check_launches() {
         ZK_HIP(c, hipGetLastError());
-        return ZKHIP_OK;                                       // the transcript already lives in the context's persistent state
+        return ZKHIP_OK;
     }
     int collect(uint32_t* h_lens, uint64_t* h_round_polys, uint64_t* h_challenges) {
-        ZK_TRY(save_transcript());
+        ZK_TRY(check_launches());
         return collect_rounds(c, multi, term_sizes[0], out_base + n_rounds, h_lens, h_round_polys, h_challenges);
     }
     // the first `rounds` recorded rounds (of this call and the calls it continued) to the host
@@ -347,7 +348,7 @@ int zk_multi_composed_enqueue(zkhip_ctx* c, const uint64_t* const* ptrs, const u
         ZK_TRY(run.round_sums(&grid));
         run.close(run.d_partials, (uint32_t)grid);
     }
-    return run.save_transcript();
+    return run.check_launches();
 }
 int zk_multi_composed_collect(zkhip_ctx* c, uint32_t n_rounds, uint32_t* h_lens, uint64_t* h_round_polys, uint64_t* h_challenges) {
     return ComposedRun::collect_rounds(c, 1, 0, n_rounds, h_lens, h_round_polys, h_challenges);
