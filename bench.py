@@ -339,7 +339,28 @@ def main():
                 "launches": int(cnt.value), "avg_launch_us": round(1e3 * ms.value / max(1, cnt.value), 2),
                 "algorithmic_bytes_per_launch": "32 B x (table entries read + folded entries written), k variables per launch"}
 
-    # ---- CPU baseline: the oracle's single-threaded restatement of poly_sum + prove, rank 0 only
+    # ---- second half of BASELINE's metric: MSM points/s of the KZG commit on a 2^20-point SRS per GPU
+    msm = None
+    if not args.no_msm:
+        msm = bench_msm(args, zk, N, rank, world, barrier, dist, torch, np)
+
+    # ---- the composed prover (GKR's sumcheck shape) on sharded tables; informational, never part of `value`
+    composed = None
+    if not args.no_composed:
+        try:
+            composed = bench_composed(args, zk, N, rank, world, barrier, dist, torch, np)
+        except Exception as e:   # reported, not hidden: the headline legs above are already measured
+            composed = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    gkr = None
+    if not args.no_gkr:
+        try:
+            gkr = bench_gkr(args, zk, rank, world, barrier, dist, torch, np)
+        except Exception as e:
+            gkr = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # ---- CPU baseline: the oracle's single-threaded restatement of poly_sum + prove, rank 0 only.  Last: the all-cores leg
+    # loads every host core, which would disturb the host-side share of the GPU legs above if it ran before them
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as ora
@@ -361,26 +382,6 @@ def main():
             cpu["all_cores"] = cpu_all_cores()
         except Exception as e:
             cpu["all_cores"] = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    # ---- second half of BASELINE's metric: MSM points/s of the KZG commit on a 2^20-point SRS per GPU
-    msm = None
-    if not args.no_msm:
-        msm = bench_msm(args, zk, N, rank, world, barrier, dist, torch, np)
-
-    # ---- the composed prover (GKR's sumcheck shape) on sharded tables; informational, never part of `value`
-    composed = None
-    if not args.no_composed:
-        try:
-            composed = bench_composed(args, zk, N, rank, world, barrier, dist, torch, np)
-        except Exception as e:   # reported, not hidden: the headline legs above are already measured
-            composed = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    gkr = None
-    if not args.no_gkr:
-        try:
-            gkr = bench_gkr(args, zk, rank, world, barrier, dist, torch, np)
-        except Exception as e:
-            gkr = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         total_evals = float(n) * world * args.steps
