@@ -10,11 +10,12 @@ from oracle import oracle as ora
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 fails, counts = 0, {}
+BIG = 4 if os.environ.get("STRESS_BIG") else 0   # STRESS_BIG=1: table sizes up to 16x larger (fewer, slower cases)
 dev = lambda t: t.cpu().numpy().view(np.uint64)
 
 
 def case_sumcheck():
-    log_n = rng.randint(0, 19)
+    log_n = rng.randint(0, 19 + BIG)
     t = ora.random_fr(1 << log_n, rng.randrange(1 << 30))
     sc = zk.Sumcheck(zk.Multilinear(t))
     if rng.random() < 0.8: sc.poly_sum()
@@ -26,7 +27,7 @@ def case_sumcheck():
 
 
 def case_fold_eval():
-    log_n = rng.randint(1, 18)
+    log_n = rng.randint(1, 18 + BIG)
     t = ora.random_fr(1 << log_n, rng.randrange(1 << 30))
     k = rng.randrange(log_n)
     r = ora.random_fr(1, rng.randrange(1 << 30))[0]
@@ -38,7 +39,7 @@ def case_fold_eval():
 
 
 def case_composed():
-    k, log_n = rng.randint(1, 5), rng.randint(1, 14)
+    k, log_n = rng.randint(1, 5), rng.randint(1, 14 + BIG)
     t = np.stack([ora.random_fr(1 << log_n, rng.randrange(1 << 30)) for _ in range(k)])
     proof, ch = zk.ComposedSumcheck(zk.ComposedMultilinear(list(t))).prove()
     rp, och = ora.composed_prove(t)
@@ -49,7 +50,7 @@ def case_multi():
     n_terms = rng.randint(1, 4)
     sizes = [rng.randint(1, 5) for _ in range(n_terms)]
     while sum(s + 1 for s in sizes) > 16: sizes.pop()
-    log_n = rng.randint(1, 12)
+    log_n = rng.randint(1, 12 + BIG)
     flat = np.stack([ora.random_fr(1 << log_n, rng.randrange(1 << 30)) for _ in range(sum(sizes))])
     if rng.random() < 0.3: flat[rng.randrange(len(flat))][:] = 0          # a zero table: zero coefficients dropped per term
     terms, q = [], 0
@@ -83,7 +84,7 @@ def case_commit():
 
 
 def case_ntt():
-    log_n = rng.randint(0, 15)
+    log_n = rng.randint(0, 15 + BIG)
     x = ora.random_fr(1 << log_n, rng.randrange(1 << 30))
     d = zk.Domain(1 << log_n)
     ok = np.array_equal(dev(d.fft(x)), ora.domain_fft(x, 1 << log_n)) and np.array_equal(dev(d.ifft(x)), ora.domain_ifft(x, 1 << log_n))
@@ -95,7 +96,7 @@ def case_ntt():
 
 def case_gkr():
     from gkr_cases import A, M
-    depth = rng.randint(1, 6)
+    depth = rng.randint(1, 6 + BIG // 2)
     layers = []
     for li in range(depth):
         n_in = 2 ** (li + 1)
