@@ -421,7 +421,11 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
     // its own side stream, workspace region and pinned result slot.  A commit is a throughput-bound accumulate pass followed
     // by latency-bound reduction passes that leave the chip mostly idle; next to each other, the reductions of one round
     // hide behind the accumulate pass of the next, and the host epilogues (~0.25 ms of serial point arithmetic each) behind both.
-    const size_t OPEN_BATCH_MAX = (size_t)1 << 14;   // measured: 2^20 open 14.4 ms at 2^12, 11.6 ms at 2^14 (tools/perf_open.py)
+    size_t OPEN_BATCH_MAX = (size_t)1 << 14;   // measured with the rounds on side streams (2^20 / 2^22 open): 2^12 9.9 / 20.0 ms, 2^13 10.4 / 19.1, 2^14 8.1 / 19.6, 2^15 9.5 / 20.2, 2^16 10.0 / 19.5, 2^17 13.1 / 23.2
+    if (const char* e = std::getenv("ZKHIP_OPEN_BATCH_LOG")) {   // tuning aid (tools/perf_open.py)
+        const int v = std::atoi(e);
+        if (v >= 8 && v <= 20) OPEN_BATCH_MAX = (size_t)1 << v;
+    }
     constexpr int NSLOT = zkhip_ctx::MSM_SLOTS - 1;  // large rounds in flight; the last slot is the batch's
     const uint64_t* cur = d_evals;
     size_t cn = n, lvl_off = 0;
