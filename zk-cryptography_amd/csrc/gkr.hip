@@ -1,6 +1,7 @@
 // gkr.hip -- GKRProtocol::prove as one C-ABI call: the host orchestration of the reference's prover over the
 // device-resident tables.  Every table operation below is one of libzkhip's own entry points (HIP kernels);
-// the outer Fiat-Shamir transcript absorbs a few hundred bytes per layer and runs on the host.
+// the outer Fiat-Shamir transcript absorbs the layer's proof bytes and runs on the host -- the ONE point per layer where the
+// host waits for the GPU; everything else of a layer (both halves of its sumcheck, eq tables, V(u), w_b, w_c) is enqueued ahead.
 // gfx950 only.  No CPU fallback: the tables never leave HBM.
 #include "../../include/zkhip.h"
 
