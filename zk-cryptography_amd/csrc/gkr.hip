@@ -213,6 +213,14 @@ int layer_prove(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_
     const uint32_t sizes[2] = {2, 2};
     const uint64_t* d_ch = zk_composed_challenges_dev(c);
     const int dot_grid = mle_grid(w_len);
+    auto dot = [&](uint64_t* d_out) {                       // <eq table, V> -> d_out; one workgroup's partial IS the result
+        if (dot_grid == 1) {
+            hipLaunchKernelGGL(gkr_dot_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, sc.equ, d_w, w_len, d_out);
+        } else {
+            hipLaunchKernelGGL(gkr_dot_kernel, dim3(dot_grid), dim3(MLE_BLOCK), 0, c->stream, sc.equ, d_w, w_len, sc.dot_partials);
+            hipLaunchKernelGGL(gkr_dot_finish_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, sc.dot_partials, (uint32_t)dot_grid, d_out);
+        }
+    };
     {
         const uint64_t* tables[4] = {sc.ha0, d_w, sc.hm, d_w};          // [Ha0, V] + Ha1,  [Hm, V]
         const uint64_t* lin[2] = {sc.ha1, nullptr};
@@ -220,8 +228,7 @@ int layer_prove(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_
     }
     // ---- rounds over c, b at u = the challenges just recorded
     hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_ch, s, sc.equ);
-    hipLaunchKernelGGL(gkr_dot_kernel, dim3(dot_grid), dim3(MLE_BLOCK), 0, c->stream, sc.equ, d_w, w_len, sc.dot_partials);
-    hipLaunchKernelGGL(gkr_dot_finish_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, sc.dot_partials, (uint32_t)dot_grid, sc.evals);   // V(u): w_b and the factor of the second phase
+    dot(sc.evals);                                         // V(u): w_b and the factor of the second phase
     hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr1, ld.csr1 + w_len + 1, ld.type, ld.in0, sc.wg, sc.equ,
                        (uint32_t)w_len, 2u, sc.aa, (uint64_t*)nullptr, sc.am);
     hipLaunchKernelGGL(gkr_vu_tables_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_w, w_len, sc.evals, sc.t1, sc.t2);
@@ -232,8 +239,7 @@ int layer_prove(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_
     }
     // w_c = V(r_c), r_c = the second half of the challenges
     hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_ch + 4 * (size_t)s, s, sc.equ);
-    hipLaunchKernelGGL(gkr_dot_kernel, dim3(dot_grid), dim3(MLE_BLOCK), 0, c->stream, sc.equ, d_w, w_len, sc.dot_partials);
-    hipLaunchKernelGGL(gkr_dot_finish_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, sc.dot_partials, (uint32_t)dot_grid, sc.evals + 4);
+    dot(sc.evals + 4);
     ZK_HIP(c, hipGetLastError());
     zkhost::Fr eval_wb, eval_wc;
     ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), sc.evals, 64, hipMemcpyDeviceToHost, c->stream));
