@@ -450,7 +450,8 @@ static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(Ta
                         s = s + v;
                     }
                 }
-                s = wave_reduce_fr(s);
+                // lanes >= half hold zero: log2(half) shuffle steps instead of six
+                for (uint32_t dd = half > 1 ? (1u << (31 - __builtin_clz(half - 1))) : 0; dd >= 1; dd >>= 1) s = s + shfl_down_fr(s, (int)dd);
                 if (lane == 0) sh.evals[wave] = s;
             }
             __syncthreads();
