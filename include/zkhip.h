@@ -19,6 +19,9 @@
  *   - Return value: 0 on success, negative zkhip_status otherwise.  Shape errors that the
  *     reference raises as assert!/panic! come back as ZKHIP_ERR_SHAPE / ZKHIP_ERR_INDEX.
  *   - One context per host thread (or external locking); contexts are independent.
+ *   - While a split-phase session (zkhip_sc_begin / zkhip_mc_begin .. finish / abort) is alive its tables live in the
+ *     context's workspace: every other entry point that needs that workspace returns ZKHIP_ERR_BUSY until the session
+ *     ends (a second zkhip_sc_begin gets an allocation of its own instead).
  */
 #ifndef ZKHIP_H
 #define ZKHIP_H
@@ -35,7 +38,9 @@ typedef enum {
     ZKHIP_ERR_SHAPE = -2,    /* assert!/assert_eq! on sizes in the reference */
     ZKHIP_ERR_INDEX = -3,    /* out-of-bounds index panic in the reference */
     ZKHIP_ERR_ARG = -4,      /* null pointer / unsupported argument */
-    ZKHIP_ERR_NOMEM = -5
+    ZKHIP_ERR_NOMEM = -5,
+    ZKHIP_ERR_BUSY = -6      /* the context's workspace backs a live split-phase session (zkhip_sc_* / zkhip_mc_*):
+                                finish or abort it first, or use another context */
 } zkhip_status;
 
 typedef struct zkhip_ctx zkhip_ctx;
@@ -88,9 +93,11 @@ int zkhip_mle_add_distinct(zkhip_ctx *ctx, const uint64_t *d_a, size_t na, const
                            uint64_t *d_out);
 int zkhip_mle_mul_distinct(zkhip_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb,
                            uint64_t *d_out);
-/* Add / Sub / Mul<F> (:178-251): op 0 add, 1 sub (d_b: n elements), 2 scale (h_scalar[4]) */
+/* Add / Sub / Mul<F> (:178-251): op 0 add, 1 sub (d_b: nb elements), 2 scale (h_scalar[4]; nb ignored).  The reference
+ * walks the left operand and indexes the right one (rhs.evaluations[i], :185,215): a longer rhs is read up to n, a shorter
+ * one is the index panic -> ZKHIP_ERR_INDEX. */
 int zkhip_mle_elementwise(zkhip_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b,
-                          const uint64_t *h_scalar, size_t n, uint64_t *d_out);
+                          const uint64_t *h_scalar, size_t n, size_t nb, uint64_t *d_out);
 /* add_to_front (:86-96): d_out[n * 2 * 2^variable_length] = the table repeated; add_to_back (:98-110):
  * d_out[n * 2^variable_length] = every entry repeated 2^variable_length times (new variables the polynomial does not
  * depend on, before / after its own). */
@@ -206,12 +213,21 @@ int zkhip_sc_stage_fold(zkhip_sc_state *st);
 /* copies out the proof (as zkhip_sumcheck_prove; *n_rounds rounds were recorded) and releases the state */
 int zkhip_sc_finish(zkhip_sc_state *st, uint64_t *h_sum, uint64_t *h_round_polys, uint64_t *h_challenges,
                     uint32_t *n_rounds);
+/* releases the state without reading anything back (error paths: a failed collective, an exception in the host loop) */
+int zkhip_sc_abort(zkhip_sc_state *st);
 
 /* ---- composed sumcheck provers (sumcheck/src/composed/) --------------------------------------- */
 /* A product term is K tables (ComposedMultilinear, polynomial/src/composed/composed_multilinear.rs:8-18) of n
  * entries each, given as a HOST array of K DEVICE pointers.  K <= 5; at most 4 terms. */
 /* ComposedSumcheck::calculate_poly_sum (composed_sumcheck.rs:28-30): sum_x prod_k f_k(x) -> h_sum[4] */
 int zkhip_composed_sum(zkhip_ctx *ctx, const uint64_t *const *h_table_ptrs, uint32_t k, size_t n, uint64_t *h_sum);
+/* ComposedMultilinearTrait::element_wise_product (op 0) / element_wise_add (op 1) as materialised vectors
+ * (polynomial/src/composed/composed_multilinear.rs:105-119; trait at polynomial/src/interface.rs:15-19; caller
+ * sumcheck/src/utils.rs:46): d_out[i] = prod_k / sum_k table_k[i], i < n = the FIRST table's length (the reference indexes
+ * every table up to polys[0].len()).  Any k >= 1 (not limited to 5); k == 0 is the `self.polys[0]` index panic ->
+ * ZKHIP_ERR_INDEX. */
+int zkhip_composed_element_wise(zkhip_ctx *ctx, int op, const uint64_t *const *h_table_ptrs, uint32_t k, size_t n,
+                                uint64_t *d_out);
 /* ComposedSumcheck::prove (composed_sumcheck.rs:32-67): h_round_polys[n_vars*(k+1)*4] (evaluations at
  * 0..=k per round), h_challenges[n_vars*4]. */
 int zkhip_composed_prove(zkhip_ctx *ctx, const uint64_t *const *h_table_ptrs, uint32_t k, size_t n,
@@ -259,6 +275,7 @@ int zkhip_mc_tail(zkhip_mc_state *st, const uint64_t *d_tables, uint32_t m);
 /* copies out the proof in the layouts of zkhip_composed_prove / zkhip_multi_composed_prove (log2(n_local * world) rounds)
  * and releases the state; all-NULL outputs just release it */
 int zkhip_mc_finish(zkhip_mc_state *st, uint32_t *h_round_poly_lens, uint64_t *h_round_polys, uint64_t *h_challenges);
+int zkhip_mc_abort(zkhip_mc_state *st);
 
 /* ---- KZG commit = multi-scalar multiplication over G1 -------------------------------------- */
 /* MultilinearKZG::commitment (kzg/src/multilinear_kzg.rs:33-48; require_equal_len = 1 reproduces its

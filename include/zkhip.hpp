@@ -175,7 +175,7 @@ class Multilinear {
     }
     Multilinear elementwise(int op, const Multilinear* o, const Fr* s) const {
         Multilinear out(n_, n_vars);
-        check(zkhip_mle_elementwise(ctx(), op, device(), o ? o->device() : nullptr, s ? s->l : nullptr, n_, out.dev_->u64()), "elementwise");
+        check(zkhip_mle_elementwise(ctx(), op, device(), o ? o->device() : nullptr, s ? s->l : nullptr, n_, o ? o->n_ : 0, out.dev_->u64()), "elementwise");
         return out;
     }
     size_t n_ = 0;
@@ -230,6 +230,21 @@ class ComposedMultilinear {
         return acc;
     }
     std::vector<const uint64_t*> ptrs() const { std::vector<const uint64_t*> v; for (auto& p : polys) v.push_back(p.device()); return v; }
+    // ComposedMultilinearTrait (interface.rs:15-19): the materialised vectors of composed_multilinear.rs:105-119
+    std::vector<Fr> element_wise_product() const { return element_wise(0); }
+    std::vector<Fr> element_wise_add() const { return element_wise(1); }
+  private:
+    std::vector<Fr> element_wise(int op) const {
+        if (polys.empty()) throw Panic("index out of bounds: the len is 0 but the index is 0");
+        const size_t n = polys[0].len();
+        for (auto& p : polys) if (p.len() < n) throw Panic("index out of bounds");
+        DeviceBuffer out(32 * n);
+        auto pv = ptrs();
+        check(zkhip_composed_element_wise(ctx(), op, pv.data(), (uint32_t)pv.size(), n, out.u64()), "element_wise");
+        std::vector<Fr> v(n);
+        out.download(v.data(), 32 * n);
+        return v;
+    }
 };
 
 struct ComposedSumcheckProof { std::vector<std::vector<Fr>> round_polys; };   // composed_sumcheck.rs:15-18 (poly omitted: caller holds it)

@@ -114,6 +114,14 @@ TEST(test_composed_sum_calculation) {
     EXPECT(ComposedSumcheck::calculate_poly_sum(ComposedMultilinear({Multilinear(F({0, 1, 2, 3}))})) == Fr::from(6));
     EXPECT(ComposedMultilinear({Multilinear(F({0, 1, 2, 3})), Multilinear(F({0, 0, 0, 1}))}).evaluation(F({2, 3})) == Fr::from(42));
 }
+TEST(test_element_wise_product) {   // composed_multilinear.rs:159-170
+    ComposedMultilinear polys({Multilinear(F({0, 1, 2, 3})), Multilinear(F({0, 0, 0, 1}))});
+    EXPECT(polys.element_wise_product() == F({0, 0, 0, 3}));
+}
+TEST(test_element_wise_add) {       // composed_multilinear.rs:172-184
+    ComposedMultilinear polys({Multilinear(F({0, 1, 2, 3})), Multilinear(F({0, 0, 0, 1}))});
+    EXPECT(polys.element_wise_add() == F({0, 1, 2, 4}));
+}
 TEST(test_composed_sum_check_proof) {
     std::vector<std::vector<Fr>> tabs = {F({3, 3, 5, 5}), F({0, 0, 0, 1})};
     ComposedSumcheck sc(ComposedMultilinear({Multilinear(tabs[0]), Multilinear(tabs[1])}));

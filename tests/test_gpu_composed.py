@@ -23,6 +23,35 @@ def test_composed_multilinear_evaluation(zk):   # composed_multilinear.rs:134-15
     assert polys.n_vars() == 2 and polys.max_degree() == 2
 
 
+def _host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def test_element_wise_product_and_add(zk):   # composed_multilinear.rs:159-184
+    polys = zk.ComposedMultilinear([F(zk, [0, 1, 2, 3]), F(zk, [0, 0, 0, 1])])
+    assert zk.Fr.to_ints(_host(polys.element_wise_product())) == [0, 0, 0, 3]
+    assert zk.Fr.to_ints(_host(polys.element_wise_add())) == [0, 1, 2, 4]
+
+
+@pytest.mark.parametrize("k,log_n", [(1, 0), (2, 3), (3, 12), (5, 16), (11, 10)])
+def test_element_wise_random_matches_host_arithmetic(zk, ora, k, log_n):
+    """Any number of tables (the reference's fold over `polys` has no cap): 11 tables take two launches."""
+    n = 1 << log_n
+    tabs = [ora.random_fr(n, 6100 + 17 * k + q) for q in range(k)]
+    polys = zk.ComposedMultilinear(tabs)
+    R = zk.Fr.MODULUS
+    ints = [zk.Fr.to_ints(t) for t in tabs]            # python integers: an independent check of the kernels' field arithmetic
+    prod, add = list(ints[0]), list(ints[0])
+    for t in ints[1:]:
+        prod = [a * b % R for a, b in zip(prod, t)]
+        add = [(a + b) % R for a, b in zip(add, t)]
+    assert zk.Fr.to_ints(_host(polys.element_wise_product())) == prod
+    assert zk.Fr.to_ints(_host(polys.element_wise_add())) == add
+    # sum_over_boolean_hypercube (sumcheck/src/utils.rs:45-51) = the sum of the product vector
+    if k <= 5:
+        assert zk.Fr.to_ints(zk.ComposedSumcheck.calculate_poly_sum(polys))[0] == sum(prod) % R
+
+
 def test_sum_calculation(zk):   # composed_sumcheck.rs:108-140, multi_composed_sumcheck.rs:195-214
     cs = zk.ComposedSumcheck.calculate_poly_sum
     assert zk.Fr.to_ints(cs(zk.ComposedMultilinear([F(zk, [0, 1, 2, 3]), F(zk, [0, 0, 0, 1])]))) == [3]

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libzkhip.so")
 
-ZKHIP_OK, ERR_HIP, ERR_SHAPE, ERR_INDEX, ERR_ARG, ERR_NOMEM = 0, -1, -2, -3, -4, -5
+ZKHIP_OK, ERR_HIP, ERR_SHAPE, ERR_INDEX, ERR_ARG, ERR_NOMEM, ERR_BUSY = 0, -1, -2, -3, -4, -5, -6
 
 
 class ZkhipError(RuntimeError):

@@ -44,6 +44,27 @@ class ComposedMultilinear:
         """composed_multilinear.rs:40-48"""
         return b"".join(p.to_bytes() for p in self.polys)
 
+    def _element_wise(self, op):
+        if not self.polys:
+            raise IndexError("element_wise on an empty ComposedMultilinear")      # self.polys[0] panics
+        first = self.polys[0]
+        if any(len(p) < len(first) for p in self.polys):
+            raise IndexError("a table is shorter than the first one")             # v.evaluations[i] panics
+        out = first._new_like(len(first))
+        N.check(N.lib().zkhip_composed_element_wise(first._ctx.handle, C.c_int(op), _ptr_array(self._ptrs()),
+                                                    C.c_uint32(len(self.polys)), C.c_size_t(len(first)), N.ptr(out)),
+                "composed_element_wise")
+        return out
+
+    def element_wise_product(self):
+        """ComposedMultilinearTrait::element_wise_product (composed_multilinear.rs:105-111) -> device tensor int64 [n, 4]
+        (the reference's Vec<F>)"""
+        return self._element_wise(0)
+
+    def element_wise_add(self):
+        """ComposedMultilinearTrait::element_wise_add (composed_multilinear.rs:113-119)"""
+        return self._element_wise(1)
+
     def _ptrs(self):
         return [p.evaluations.data_ptr() for p in self.polys]
 

@@ -356,6 +356,27 @@ int zk_multi_composed_collect(zkhip_ctx* c, uint32_t n_rounds, uint32_t* h_lens,
 // device addresses of the recorded challenges (4 u64 per round), for kernels that consume them without a host round trip
 const uint64_t* zk_composed_challenges_dev(zkhip_ctx* c) { return c->small_u64(ZK_SMALL_CHALLENGES); }
 
+// ComposedMultilinearTrait::element_wise_product (op 0) / element_wise_add (op 1), composed_multilinear.rs:105-119
+extern "C" int zkhip_composed_element_wise(zkhip_ctx* c, int op, const uint64_t* const* ptrs, uint32_t k, size_t n, uint64_t* d_out) {
+    if (!c || !ptrs || !d_out || op < 0 || op > 1) return ZKHIP_ERR_ARG;
+    if (k == 0) return ZKHIP_ERR_INDEX;                    // self.polys[0] on an empty vector
+    for (uint32_t q = 0; q < k; ++q) if (!ptrs[q]) return ZKHIP_ERR_ARG;
+    if (n == 0) return ZKHIP_OK;
+    ZK_TRY(c->activate());
+    const int grid = mle_grid_stream(n);
+    for (uint32_t q0 = 0; q0 < k; q0 += 8) {
+        ElementwisePtrs t = {};
+        const uint32_t cnt = std::min<uint32_t>(8, k - q0);
+        for (uint32_t q = 0; q < cnt; ++q) t.in[q] = ptrs[q0 + q];
+        if (op == 0)
+            hipLaunchKernelGGL(composed_elementwise_kernel<true>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, t, cnt, n, q0 ? 1u : 0u, d_out);
+        else
+            hipLaunchKernelGGL(composed_elementwise_kernel<false>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, t, cnt, n, q0 ? 1u : 0u, d_out);
+    }
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+
 extern "C" int zkhip_composed_prove(zkhip_ctx* c, const uint64_t* const* ptrs, uint32_t k, size_t n, uint64_t* h_round_polys,
                                     uint64_t* h_challenges) {
     return composed_prove_impl(c, ptrs, &k, 1, n, 0, nullptr, 1, nullptr, h_round_polys, h_challenges);
@@ -384,6 +405,7 @@ extern "C" int zkhip_mc_begin(zkhip_ctx* c, const uint64_t* const* d_local_table
     const uint32_t rounds = log2_exact(n_local) + log2_exact(world);
     if (rounds == 0 || rounds > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
+    if (c->ws_lent) return ZKHIP_ERR_BUSY;      // one session per context: its tables live in the context's workspace
     zkhip_mc_state* s = new (std::nothrow) zkhip_mc_state();
     if (!s) return ZKHIP_ERR_NOMEM;
     s->world = world;
@@ -396,6 +418,7 @@ extern "C" int zkhip_mc_begin(zkhip_ctx* c, const uint64_t* const* d_local_table
         delete s;
         return ZKHIP_ERR_SHAPE;
     }
+    c->ws_lent = true;              // until finish / abort: every other user of the workspace gets ZKHIP_ERR_BUSY
     *out = s;
     return ZKHIP_OK;
 }
@@ -471,6 +494,16 @@ extern "C" int zkhip_mc_finish(zkhip_mc_state* s, uint32_t* h_lens, uint64_t* h_
         if (!h_round_polys || !h_challenges || (s->run.multi && !h_lens) || s->run.round != s->run.n_rounds) rc = ZKHIP_ERR_ARG;
         else if ((rc = s->run.c->activate()) == ZKHIP_OK) rc = s->run.collect(h_lens, h_round_polys, h_challenges);
     }
+    s->run.c->ws_lent = false;
+    delete s;
+    return rc;
+}
+extern "C" int zkhip_mc_abort(zkhip_mc_state* s) {
+    if (!s) return ZKHIP_ERR_ARG;
+    zkhip_ctx* c = s->run.c;
+    int rc = ZKHIP_OK;
+    if (c->activate() != ZKHIP_OK || hipStreamSynchronize(c->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
+    c->ws_lent = false;
     delete s;
     return rc;
 }

@@ -62,6 +62,27 @@ __device__ __forceinline__ void accumulate_round_evals(const Fr (&lo)[K], const 
     }
 }
 
+// ComposedMultilinearTrait::element_wise_product / element_wise_add as materialised vectors
+// (polynomial/src/composed/composed_multilinear.rs:105-119): out[i] = prod_k / sum_k table_k[i].  Up to 8 tables per launch;
+// ACC continues a longer product from `out` itself.
+struct ElementwisePtrs { const uint64_t* in[8]; };
+template <bool PRODUCT>
+static __global__ __launch_bounds__(MLE_BLOCK) void composed_elementwise_kernel(ElementwisePtrs t, uint32_t k, size_t n, uint32_t acc,
+                                                                          uint64_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    for (size_t i = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; i < n; i += stride) {
+        Fr v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if ((uint32_t)q < k) v[q] = load_fr(t.in[q], i);
+        Fr r = acc ? load_fr(out, i) : v[0];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if ((uint32_t)q < k && (acc || q > 0)) r = PRODUCT ? r * v[q] : r + v[q];
+        }
+        store_fr(out, i, r);
+    }
+}
+
 // ---- closing a round ------------------------------------------------------------------------------------
 struct ComposedMeta {
     uint32_t n_terms;

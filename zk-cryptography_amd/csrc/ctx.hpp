@@ -69,11 +69,32 @@ struct zkhip_ctx {
     size_t msm_pin_bytes[MSM_SLOTS] = {};
     hipEvent_t msm_ev[MSM_SLOTS] = {};
     hipStream_t side[MSM_SLOTS] = {};
-    hipEvent_t fork_ev = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     int ensure_side_streams() {
         for (int i = 0; i < MSM_SLOTS; ++i)
             if (!side[i] && hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) return ZKHIP_ERR_HIP;
         if (!fork_ev && hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
+        if (!join_ev && hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
+        return ZKHIP_OK;
+    }
+    // The basic prover's streaming fold runs on a LOW-priority stream of its own next to the serial transcript kernel
+    // (the dispatcher prefers the serial kernel's single workgroup whenever both are ready).  Measured alternatives
+    // (DESIGN.md section 5): a CU-masked fold stream that leaves one CU to the serial kernel -- such streams can only be
+    // created "blocking", and the implicit synchronisation with the NULL stream (PyTorch's default) cost 30-60 us per
+    // fork / join; sharing a CU with fold waves -- the transcript wave runs at half speed.
+    hipStream_t fold_stream = nullptr;
+    int ensure_fold_stream() {
+        if (fold_stream) return ensure_side_streams();
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return ZKHIP_ERR_HIP;
+        if (hipStreamCreateWithPriority(&fold_stream, hipStreamNonBlocking, least) != hipSuccess) return ZKHIP_ERR_HIP;
+        return ensure_side_streams();
+    }
+    // coarse block sums left by zkhip_mle_block_sums for the prover's first rounds (valid for the fine-sum buffer coarse_of)
+    void* d_coarse = nullptr;
+    const void* coarse_of = nullptr; size_t coarse_n = 0; uint32_t coarse_k1 = 0;
+    int ensure_coarse() {
+        if (!d_coarse && hipMalloc(&d_coarse, 1024 * 32) != hipSuccess) return ZKHIP_ERR_NOMEM;
         return ZKHIP_OK;
     }
     int reserve_msm_pin(int slot, size_t bytes) {
@@ -109,6 +130,21 @@ struct zkhip_ctx {
         big_lds_done.insert(fn);
         return ZKHIP_OK;
     }
+    // Host wait for the stream's work so far: polls an event for up to ~2 ms (a prover call is a few hundred
+    // microseconds; a blocking wait's wake-up costs 10-20 us of idle GPU before the next call), then blocks.
+    hipEvent_t done_ev = nullptr;
+    int wait_stream() {
+        if (!done_ev && hipEventCreateWithFlags(&done_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
+        if (hipEventRecord(done_ev, stream) != hipSuccess) return ZKHIP_ERR_HIP;
+        for (int spin = 0; spin < 200000; ++spin) {
+            const hipError_t e = hipEventQuery(done_ev);
+            if (e == hipSuccess) return ZKHIP_OK;
+            if (e != hipErrorNotReady) { last_hip = (int)e; return ZKHIP_ERR_HIP; }
+        }
+        const hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { last_hip = (int)e; return ZKHIP_ERR_HIP; }
+        return ZKHIP_OK;
+    }
     uint64_t* small_u64(size_t off) { return (uint64_t*)d_small + off; }
     uint64_t* pinned_u64(size_t off) { return (uint64_t*)h_pinned + off; }
     // grow-only workspace; growth synchronises (never inside a steady-state timed loop)
@@ -125,6 +161,7 @@ struct zkhip_ctx {
         return ZKHIP_OK;
     }
     int reserve_ws(size_t bytes) {
+        if (ws_lent) return ZKHIP_ERR_BUSY;     // a live split-phase session owns it: neither overwrite nor free it
         if (bytes <= ws_bytes) return ZKHIP_OK;
         hipError_t e = hipStreamSynchronize(stream);
         if (e != hipSuccess) { last_hip = (int)e; return ZKHIP_ERR_HIP; }
@@ -143,7 +180,9 @@ struct ProfScope {
     zkhip_ctx* c;
     size_t idx = 0;
     bool on;
-    ProfScope(zkhip_ctx* ctx, const char* name, double bytes) : c(ctx), on(ctx->profiling) {
+    hipStream_t s;
+    ProfScope(zkhip_ctx* ctx, const char* name, double bytes, hipStream_t on_stream = nullptr)
+        : c(ctx), on(ctx->profiling), s(on_stream ? on_stream : ctx->stream) {
         if (!on) return;
         if (c->prof_used == c->prof_events.size()) {
             ZkProfEvent ev;
@@ -152,10 +191,10 @@ struct ProfScope {
             c->prof_events.push_back(ev);
         }
         idx = c->prof_used++;
-        hipEventRecord(c->prof_events[idx].start, c->stream);
+        hipEventRecord(c->prof_events[idx].start, s);
         c->prof_records.push_back({name, idx, bytes});
     }
     ~ProfScope() {
-        if (on) hipEventRecord(c->prof_events[idx].stop, c->stream);
+        if (on) hipEventRecord(c->prof_events[idx].stop, s);
     }
 };

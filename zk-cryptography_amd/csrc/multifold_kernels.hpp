@@ -56,6 +56,53 @@ static __global__ __launch_bounds__(MLE_BLOCK) void group_sums_kernel(const uint
     if (threadIdx.x == 0) store_fr(out, n_blocks, tot);
 }
 
+// ---- fine block sums for the overlapped plan -------------------------------------------------------------
+// sums[c] = sum of the c-th run of FINE_CHUNK consecutive entries.  A wave owns two runs at a time (8 loads of 2 KiB in
+// flight per wave); no loop, the grid covers the table (n / (8 FINE_CHUNK) workgroups).
+constexpr int FINE_CHUNK = 256;
+static __global__ __launch_bounds__(MLE_BLOCK) void fine_sums_kernel(const uint64_t* __restrict__ in, size_t n_chunks,
+                                                                     uint64_t* __restrict__ sums) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t c0 = ((size_t)blockIdx.x * (MLE_BLOCK / 64) + wave) * 2;
+    if (c0 >= n_chunks) return;
+    const bool two = c0 + 1 < n_chunks;
+    const uint64_t* base = in + 4 * (c0 * FINE_CHUNK);
+    Fr v[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = load_fr(base, lane + 64 * u);
+#pragma unroll
+    for (int u = 4; u < 8; ++u) v[u] = two ? load_fr(base, lane + 64 * u) : Fr::zero();
+    Fr a = (v[0] + v[1]) + (v[2] + v[3]);
+    Fr b = (v[4] + v[5]) + (v[6] + v[7]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        Fr ta = shfl_down_fr(a, d), tb = shfl_down_fr(b, d);
+        a = a + ta;
+        b = b + tb;
+    }
+    if (lane == 0) {
+        store_fr(sums, c0, a);
+        if (two) store_fr(sums, c0 + 1, b);
+    }
+}
+
+// out[b] = sum of in[b*group .. (b+1)*group), one workgroup per output (the coarse block sums from the fine ones)
+static __global__ __launch_bounds__(MLE_BLOCK) void group_sums_wg_kernel(const uint64_t* __restrict__ in, uint32_t group,
+                                                                         uint64_t* __restrict__ out) {
+    __shared__ Fr red[MLE_BLOCK / 64];
+    const uint64_t* base = in + 4 * (size_t)blockIdx.x * group;
+    Fr s = Fr::zero();
+    for (uint32_t j = threadIdx.x; j < group; j += 4 * MLE_BLOCK) {
+        Fr v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (j + u * MLE_BLOCK < group) ? load_fr(base, j + u * MLE_BLOCK) : Fr::zero();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s = s + v[u];
+    }
+    s = block_reduce_fr(s, red);
+    if (threadIdx.x == 0) store_fr(out, blockIdx.x, s);
+}
+
 constexpr int TREE_MAX_LOG = 10;   // the serial kernel keeps tables of up to 2^10 entries (and their sum trees) in LDS
 
 struct SmallArgs {
@@ -89,13 +136,16 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
                                                                           uint64_t* __restrict__ round_polys,
                                                                           uint64_t* __restrict__ challenges) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
+    __builtin_amdgcn_s_setprio(3);                      // the chip's critical path: win every issue arbitration
     const uint32_t n = 1u << a.log_n;
-    Fr* tree0 = reinterpret_cast<Fr*>(zk_dyn_lds);      // 2n nodes each, canonical values
-    Fr* tree1 = tree0 + 2 * n;
-    const uint32_t w_cap = a.weights_out ? (1u << MF_CAP_LOGK) : 0u;   // no weights region when none are asked for
-    Fr* w0 = tree1 + 2 * n;                             // weights (Montgomery), ping / pong
-    Fr* w1 = w0 + w_cap;
-    Fr* scratch = w1 + w_cap;                           // MLE_BLOCK
+    Fr* tree0 = reinterpret_cast<Fr*>(zk_dyn_lds);      // 2n nodes, canonical values
+    Fr* tree1 = tree0 + 2 * n;                          // n nodes: the first tree built here is already a folded one
+    // weights (Montgomery), ping / pong: 2^(it+1) of them after round it, so the array that receives the last round's
+    // holds 2^n_rounds and the other one half of that; no region at all when none are asked for
+    const uint32_t w_all = a.weights_out ? (1u << a.n_rounds) : 0u;
+    Fr* w0 = tree1 + n;
+    Fr* w1 = w0 + ((a.n_rounds & 1) ? w_all / 2 : w_all);
+    Fr* scratch = w0 + w_all + w_all / 2;               // MLE_BLOCK
     Fr* e_sh = scratch + MLE_BLOCK;                     // 2 x 2: to_mont(level-2 differences) of tree0 / tree1
     Fr* r_sh = e_sh + 4;                                // 2: canonical challenge, double-buffered
     // ---- leaves (sums are taken in Montgomery form, then converted once)
@@ -104,7 +154,13 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
     } else if (a.stride != 0) {   // all-gathered per-rank block sums: add the ranks' contributions in rank order
         for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) {
             Fr s = load_fr(a.src, j);
-            for (uint32_t g = 1; g < a.group; ++g) s = s + load_fr(a.src, (size_t)g * a.stride + j);
+            for (uint32_t g = 1; g < a.group; g += 8) {      // up to 8 loads in flight (the serial kernel's prologue is latency)
+                Fr v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (g + u < a.group) v[u] = load_fr(a.src, (size_t)(g + u) * a.stride + j);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (g + u < a.group) s = s + v[u];
+            }
             tree0[n + j] = s.from_mont();
         }
     } else {
@@ -293,8 +349,9 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
         for (uint32_t j = threadIdx.x; j < cnt; j += MLE_BLOCK) store_fr(a.final_out, j, t[cnt + j].to_mont());
     }
 }
-__host__ __device__ constexpr size_t small_lds_bytes(uint32_t log_n, bool with_weights) {
-    return ((size_t)4 * ((size_t)1 << log_n) + (with_weights ? 2 * (1u << MF_CAP_LOGK) : 0u) + MLE_BLOCK + 4 + 2) * 32 + (64 + 64 + 16 + 2) * 4;
+// dynamic LDS of the kernel above: trees (3 x 2^log_n), weights (1.5 x 2^weight_rounds; weight_rounds < 0: none), scratch
+__host__ __device__ constexpr size_t small_lds_bytes(uint32_t log_n, int weight_rounds) {
+    return ((size_t)3 * ((size_t)1 << log_n) + (weight_rounds >= 0 ? 3 * ((size_t)1 << weight_rounds) / 2 + 1 : 0u) + MLE_BLOCK + 4 + 2) * 32 + (64 + 64 + 16 + 2) * 4;
 }
 
 // Fold weights of k known points (MultilinearTrait::evaluation folds variable 0 repeatedly, evaluation_form.rs:162-175):
@@ -434,6 +491,37 @@ static __global__ __launch_bounds__(1024) void multifold_kernel(const uint64_t* 
         }
         Fr s = wave_reduce_fr(o);
         if (lane == 0) store_fr(partials, blockIdx.x, s);
+    }
+}
+
+// ---- k-variable fold of a SMALL table (<= 2^17 entries), spread over the chip -----------------------------------------
+// partial[y*m + c] = sum over the term range y of w[b] * in[b*m + c].  multifold_kernel<16> gives such a table to m/16
+// workgroups (16 at m = 256: ~16 us of one-wave-per-SIMD latency); here a workgroup takes OW outputs x (256/OW) term slices
+// of <= 4 terms each and the term ranges go to blockIdx.y, so 2^16 entries are 64 workgroups of 4 products per lane.  The
+// serial kernel adds the gridDim.y partial tables (SmallArgs::stride).
+static __global__ __launch_bounds__(MLE_BLOCK) void blockfold_kernel(const uint64_t* __restrict__ in, uint32_t m, uint32_t log_ow,
+                                                                     uint32_t per, const uint64_t* __restrict__ weights,
+                                                                     uint64_t* __restrict__ partial) {
+    __shared__ Fr part[MLE_BLOCK];
+    const uint32_t ow = 1u << log_ow, sl_cnt = MLE_BLOCK >> log_ow;
+    const uint32_t o = threadIdx.x & (ow - 1), sl = threadIdx.x >> log_ow;
+    const uint32_t c = blockIdx.x * ow + o;
+    const uint32_t b0 = (blockIdx.y * sl_cnt + sl) * per;
+    WideAcc acc;
+    acc.clear();
+    Fr v[4], w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if ((uint32_t)u < per) { v[u] = load_fr(in, (size_t)(b0 + u) * m + c); w[u] = load_fr(weights, b0 + u); }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if ((uint32_t)u < per) acc.mac(w[u], v[u]);
+    part[threadIdx.x] = wide_reduce(acc.lo, acc.hi);
+    __syncthreads();
+    if (sl == 0) {
+        Fr s = part[o];
+        for (uint32_t q = 1; q < sl_cnt; ++q) s = s + part[(q << log_ow) + o];
+        store_fr(partial, (size_t)blockIdx.y * m + c, s);
     }
 }
 

@@ -33,6 +33,7 @@ extern "C" const char* zkhip_status_string(int s) {
         case ZKHIP_ERR_INDEX: return "index out of bounds";
         case ZKHIP_ERR_ARG: return "invalid argument";
         case ZKHIP_ERR_NOMEM: return "out of memory";
+        case ZKHIP_ERR_BUSY: return "workspace lent to a live split-phase session";
         default: return "unknown";
     }
 }
@@ -68,6 +69,10 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
         if (c->side[i]) hipStreamDestroy(c->side[i]);
     }
     if (c->fork_ev) hipEventDestroy(c->fork_ev);
+    if (c->join_ev) hipEventDestroy(c->join_ev);
+    if (c->done_ev) hipEventDestroy(c->done_ev);
+    if (c->fold_stream) hipStreamDestroy(c->fold_stream);
+    if (c->d_coarse) hipFree(c->d_coarse);
     if (c->d_small) hipFree(c->d_small);
     if (c->sc_small) hipFree(c->sc_small);
     if (c->sc_stage) hipFree(c->sc_stage);
@@ -79,6 +84,13 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
 
 extern "C" int zkhip_ctx_set_stream(zkhip_ctx* c, void* stream) {
     if (!c) return ZKHIP_ERR_ARG;
+    if ((hipStream_t)stream == c->stream) return ZKHIP_OK;
+    // Several entry points return before their kernels have run, and they share the context's scratch buffers: work
+    // enqueued on the new stream must come after what is still queued on the old one.
+    ZK_TRY(c->activate());
+    ZK_TRY(c->ensure_side_streams());
+    ZK_HIP(c, hipEventRecord(c->fork_ev, c->stream));
+    ZK_HIP(c, hipStreamWaitEvent((hipStream_t)stream, c->fork_ev, 0));
     c->stream = (hipStream_t)stream;
     return ZKHIP_OK;
 }
@@ -309,9 +321,11 @@ extern "C" int zkhip_mle_mul_distinct(zkhip_ctx* c, const uint64_t* d_a, size_t 
                                       uint64_t* d_out) { return distinct(c, true, d_a, na, d_b, nb, d_out); }
 
 extern "C" int zkhip_mle_elementwise(zkhip_ctx* c, int op, const uint64_t* d_a, const uint64_t* d_b,
-                                     const uint64_t* h_scalar, size_t n, uint64_t* d_out) {
+                                     const uint64_t* h_scalar, size_t n, size_t nb, uint64_t* d_out) {
     if (!c || !d_a || !d_out || op < 0 || op > 2) return ZKHIP_ERR_ARG;
     if (op == 2 ? !h_scalar : !d_b) return ZKHIP_ERR_ARG;
+    if (op != 2 && nb < n) return ZKHIP_ERR_INDEX;      // rhs.evaluations[i] out of bounds (evaluation_form.rs:185,215)
+    if (n == 0) return ZKHIP_OK;
     ZK_TRY(c->activate());
     const int grid = mle_grid_stream(n);
     FrArg sc = {};
@@ -429,15 +443,83 @@ static inline uint32_t stage_k(size_t cur_n) {
     if (k > MF_MAX_LOGK) k = MF_MAX_LOGK;
     return k;                                                  // >= 3 here
 }
-extern "C" int zkhip_sumcheck_plan_log_blocks(size_t n) { return is_pow2(n) ? (int)stage_k(n) : 0; }
+// Overlapped plan (tables of 2^19 .. 2^24 entries).  Identity (1) of multifold_kernels.hpp applied twice: with FINE block
+// sums B_g (2^g blocks of 256 entries, g = lg - 8) the first k1 rounds run on B_k1 (grouped B_g) and the next k2 = g - k1
+// rounds on fold_k1(B_g; r_1..r_k1) -- a table of 2^k2 <= 1024 entries -- so rounds k1+1 .. g need the first k1 challenges
+// but NOT the folded big table.  The streaming k1-variable fold of the big table therefore runs on a side stream next to
+// the serial kernel of those rounds and is joined before the fold by the next k2 variables.  k2 is as large as the serial
+// kernel takes (10), so that the fold starts as early as possible: 2^24 = 6 rounds | fold (100 us) next to 10 rounds | 8
+// rounds.  Same values as the round-by-round loop, bit for bit.
+static inline bool overlapped_plan(size_t n) { return is_pow2(n) && n >= ((size_t)1 << 19) && n <= ((size_t)1 << 24); }
+static inline uint32_t overlapped_k2(size_t n) { return std::min<uint32_t>(TREE_MAX_LOG, log2_exact(n) - 8 - 3); }
+extern "C" int zkhip_sumcheck_plan_log_blocks(size_t n) {
+    if (!is_pow2(n)) return 0;
+    return overlapped_plan(n) ? (int)(log2_exact(n) - 8) : (int)stage_k(n);
+}
 
-static int launch_small(zkhip_ctx* c, const SmallArgs& a, SumcheckDev* st, uint64_t* d_rp, uint64_t* d_ch) {
-    if (a.weights_out && a.log_n > (uint32_t)MF_CAP_LOGK) return ZKHIP_ERR_SHAPE;
-    const size_t lds = small_lds_bytes(a.log_n, a.weights_out != nullptr);
-    ZK_TRY(c->allow_big_lds((const void*)sumcheck_small_kernel,
-                            std::max(small_lds_bytes(TREE_MAX_LOG, false), small_lds_bytes(MF_CAP_LOGK, true))));
-    ProfScope ps(c, "sumcheck_small", 0.0);
-    hipLaunchKernelGGL(sumcheck_small_kernel, dim3(1), dim3(MLE_BLOCK), lds, c->stream, a, st, d_rp, d_ch);
+// min_lds: pads the dynamic LDS request.  The serial kernel that runs next to the streaming fold asks for (nearly) a whole
+// CU's LDS so that no workgroup of the fold shares its CU: beside 8+ fold waves per SIMD the transcript wave ran at half speed.
+static int launch_small(zkhip_ctx* c, const SmallArgs& a, SumcheckDev* st, uint64_t* d_rp, uint64_t* d_ch, size_t min_lds = 0,
+                        hipStream_t stream = nullptr) {
+    if (!stream) stream = c->stream;
+    if (a.log_n > (uint32_t)TREE_MAX_LOG || a.n_rounds > a.log_n) return ZKHIP_ERR_SHAPE;
+    const size_t lds = std::max(small_lds_bytes(a.log_n, a.weights_out ? (int)a.n_rounds : -1), min_lds);
+    ZK_TRY(c->allow_big_lds((const void*)sumcheck_small_kernel, 160 * 1024));
+    ProfScope ps(c, "sumcheck_small", 0.0, stream);
+    hipLaunchKernelGGL(sumcheck_small_kernel, dim3(1), dim3(MLE_BLOCK), lds, stream, a, st, d_rp, d_ch);
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+// the k-variable fold of a cn-entry table in the shape that suits its output size; returns the per-workgroup sums' count
+static int launch_multifold(zkhip_ctx* c, hipStream_t stream, const uint64_t* cur, size_t cn, uint32_t k, const uint64_t* d_w,
+                            uint64_t* dst, uint64_t* pdst, uint32_t* n_parts) {
+    const size_t m = cn >> k;
+    uint32_t out_per_wg;
+    if (m >= 8192) {          // streaming shape: 64 outputs per workgroup, its waves split the terms
+        out_per_wg = 64;
+        // >= 64 terms per lane: every lane pays one 9-word reduction (~a product), which at 16 terms per lane made the
+        // 6-variable fold of the overlapped plan 12 % slower than the 8-variable one
+        const uint32_t waves = k >= 8 ? 4 : k == 7 ? 2 : 1;
+        ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m, stream);
+        hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(64 * waves), ((size_t)32 << k) + 32 * (size_t)(waves - 1) * 64, stream, cur, m, k, d_w, dst, pdst);
+    } else {                  // few outputs left: 16 per workgroup, up to 64 lanes share one output
+        out_per_wg = 16;
+        uint32_t waves = 16;
+        while (waves * 4 > (1u << k)) waves >>= 1;   // at least one term per lane group (k >= 3 here)
+        ProfScope ps(c, "multifold_small", 32.0 * (double)cn + 32.0 * (double)m, stream);
+        hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), ((size_t)32 << k) + 32 * (size_t)(waves - 1) * 16, stream, cur, m, k, d_w, dst, pdst);
+    }
+    ZK_HIP(c, hipGetLastError());
+    if (n_parts) *n_parts = (uint32_t)(m / out_per_wg);
+    return ZKHIP_OK;
+}
+// k-variable fold of a small table spread over the chip: partial tables P[y][m], y < *n_slices (blockfold_kernel)
+static int launch_blockfold(zkhip_ctx* c, hipStream_t stream, const uint64_t* in, uint32_t m, uint32_t k, const uint64_t* d_w,
+                            uint64_t* d_partial, uint32_t* n_slices) {
+    const uint32_t log_ow = std::min<uint32_t>(log2_exact(m), 5);
+    const uint32_t sl_cnt = (uint32_t)MLE_BLOCK >> log_ow;
+    const uint32_t terms = 1u << k;
+    if (terms < sl_cnt) return ZKHIP_ERR_SHAPE;
+    const uint32_t per = std::min<uint32_t>(4, terms / sl_cnt);
+    const uint32_t ny = terms / (per * sl_cnt);
+    ProfScope ps(c, "blockfold", 32.0 * (double)m * terms, stream);
+    hipLaunchKernelGGL(blockfold_kernel, dim3(m >> log_ow, ny), dim3(MLE_BLOCK), 0, stream, in, m, log_ow, per, d_w, d_partial);
+    ZK_HIP(c, hipGetLastError());
+    *n_slices = ny;
+    return ZKHIP_OK;
+}
+// fine block sums: d_fine[2^lb] = sums of the 2^lb equal consecutive blocks of the table (each >= FINE_CHUNK entries);
+// d_chunk (n / FINE_CHUNK entries of scratch) is only touched when a block is longer than FINE_CHUNK
+static int launch_fine_sums(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint32_t lb, uint64_t* d_fine, uint64_t* d_chunk) {
+    const size_t blk = n >> lb, n_chunks = n / FINE_CHUNK;
+    uint64_t* first = blk == (size_t)FINE_CHUNK ? d_fine : d_chunk;
+    {
+        ProfScope ps(c, "chunk_sums", 32.0 * (double)n);
+        hipLaunchKernelGGL(fine_sums_kernel, dim3((unsigned)((n_chunks + 7) / 8)), dim3(MLE_BLOCK), 0, c->stream, d_evals, n_chunks, first);
+    }
+    if (first != d_fine)
+        hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << lb), dim3(MLE_BLOCK), 0, c->stream, first, (uint32_t)(blk / FINE_CHUNK), d_fine);
     ZK_HIP(c, hipGetLastError());
     return ZKHIP_OK;
 }
@@ -446,21 +528,34 @@ static int launch_small(zkhip_ctx* c, const SmallArgs& a, SumcheckDev* st, uint6
 extern "C" int zkhip_mle_block_sums(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint32_t log_blocks,
                                     uint64_t* d_out, uint64_t* h_total) {
     if (!c || !d_evals || !d_out) return ZKHIP_ERR_ARG;
-    if (!is_pow2(n) || log_blocks > MF_CAP_LOGK || ((size_t)1 << log_blocks) > n) return ZKHIP_ERR_SHAPE;
+    if (!is_pow2(n) || log_blocks > 16 || ((size_t)1 << log_blocks) > n) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
     const size_t m = n >> log_blocks;
-    const uint32_t chunk = (uint32_t)std::min<size_t>(m, 4096);
-    const size_t n_chunks = n / chunk;
-    uint64_t* d_partials;
-    if (n_chunks <= 8 * (size_t)ZK_MAX_PARTIALS) d_partials = c->small_u64(ZK_SMALL_PARTIALS);
-    else { ZK_TRY(c->reserve_ws(n_chunks * 32)); d_partials = (uint64_t*)c->d_ws; }
-    if (chunk >= (uint32_t)MLE_BLOCK) {
-        ProfScope ps(c, "chunk_sums", 32.0 * (double)n);
-        hipLaunchKernelGGL(chunk_sums_kernel, dim3((unsigned)n_chunks), dim3(MLE_BLOCK), 0, c->stream, d_evals, chunk, d_partials);
-        hipLaunchKernelGGL(group_sums_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_partials, (uint32_t)(m / chunk),
-                           1u << log_blocks, d_out);
-    } else {   // tiny table: every entry is its own partial
-        hipLaunchKernelGGL(group_sums_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_evals, (uint32_t)m, 1u << log_blocks, d_out);
+    if (log_blocks > (uint32_t)MF_CAP_LOGK) {      // fine sums (the overlapped prover's granularity)
+        if (m < (size_t)FINE_CHUNK) return ZKHIP_ERR_SHAPE;
+        uint64_t* d_chunk = nullptr;
+        if (m > (size_t)FINE_CHUNK) { ZK_TRY(c->reserve_ws((n / FINE_CHUNK) * 32)); d_chunk = (uint64_t*)c->d_ws; }
+        ZK_TRY(launch_fine_sums(c, d_evals, n, log_blocks, d_out, d_chunk));
+        // coarse sums at the granularity the prover's first rounds want (kept for it: zkhip_ctx::coarse), then the total
+        const uint32_t k1 = overlapped_plan(n) && log_blocks == log2_exact(n) - 8 ? log_blocks - overlapped_k2(n) : 8;
+        ZK_TRY(c->ensure_coarse());
+        hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, c->stream, d_out, 1u << (log_blocks - k1), (uint64_t*)c->d_coarse);
+        hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, (uint64_t*)c->d_coarse, 1u << k1, d_out + 4 * ((size_t)1 << log_blocks));
+        c->coarse_of = d_out; c->coarse_n = n; c->coarse_k1 = k1;
+    } else {
+        const uint32_t chunk = (uint32_t)std::min<size_t>(m, 4096);
+        const size_t n_chunks = n / chunk;
+        uint64_t* d_partials;
+        if (n_chunks <= 8 * (size_t)ZK_MAX_PARTIALS) d_partials = c->small_u64(ZK_SMALL_PARTIALS);
+        else { ZK_TRY(c->reserve_ws(n_chunks * 32)); d_partials = (uint64_t*)c->d_ws; }
+        if (chunk >= (uint32_t)MLE_BLOCK) {
+            ProfScope ps(c, "chunk_sums", 32.0 * (double)n);
+            hipLaunchKernelGGL(chunk_sums_kernel, dim3((unsigned)n_chunks), dim3(MLE_BLOCK), 0, c->stream, d_evals, chunk, d_partials);
+            hipLaunchKernelGGL(group_sums_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_partials, (uint32_t)(m / chunk),
+                               1u << log_blocks, d_out);
+        } else {   // tiny table: every entry is its own partial
+            hipLaunchKernelGGL(group_sums_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_evals, (uint32_t)m, 1u << log_blocks, d_out);
+        }
     }
     ZK_HIP(c, hipGetLastError());
     if (h_total) {
@@ -488,16 +583,24 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
         std::memcpy(h_sum, c->pinned_u64(ZK_PIN_RES), 32);
         return ZKHIP_OK;
     }
-    // workspace: stage tables (n/4 + n/16 + ...), partial sums, fold weights
-    const size_t tab_entries = n / 4 + n / 16 + 64;
+    const bool overlap = overlapped_plan(n);
+    // workspace: stage tables (n/4 + n/16 + ...; overlapped: n / 2^k1 <= n/8), partial sums, fold weights, and for the
+    // overlapped plan the fine sums (n/256 <= 2^16) and two sets of partial tables (<= 2 x 1024 and 32 x 256)
+    const size_t tab_entries = overlap ? n / 8 + 64 : n / 4 + n / 16 + 64;
+    const size_t tabA_entries = overlap ? n / 8 + 32 : n / 4 + 32;
     const size_t part_entries = std::max<size_t>(n / 4096, n / 256) + 1024;   // chunk sums of stage 0, per-workgroup sums of stage outputs
-    const size_t w_entries = (size_t)1 << MF_CAP_LOGK;
-    ZK_TRY(c->reserve_ws((tab_entries + 2 * part_entries + w_entries) * 32));
+    const size_t w_entries = (size_t)1 << TREE_MAX_LOG;
+    const size_t fine_entries = overlap ? 65536 + 2 * 1024 + 32 * 256 : 0;
+    ZK_TRY(c->reserve_ws((tab_entries + 2 * part_entries + 2 * w_entries + fine_entries) * 32));
     uint64_t* tabA = (uint64_t*)c->d_ws;
-    uint64_t* tabB = tabA + 4 * (n / 4 + 32);
+    uint64_t* tabB = tabA + 4 * tabA_entries;
     uint64_t* partA = (uint64_t*)c->d_ws + 4 * tab_entries;
     uint64_t* partB = partA + 4 * part_entries;
     uint64_t* d_w = partB + 4 * part_entries;
+    uint64_t* d_w2 = d_w + 4 * w_entries;
+    uint64_t* d_fine = d_w2 + 4 * w_entries;           // overlapped plan only from here on
+    uint64_t* d_p1 = d_fine + 4 * 65536;
+    uint64_t* d_p2 = d_p1 + 4 * 2 * 1024;
     SumcheckDev* st = (SumcheckDev*)c->small_u64(ZK_SMALL_STATE);
     uint64_t* d_rp = c->small_u64(ZK_SMALL_ROUNDPOLYS);
     uint64_t* d_ch = c->small_u64(ZK_SMALL_CHALLENGES);
@@ -513,11 +616,52 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
     uint32_t round = 0, stage = 0;
     const uint64_t* parts = nullptr;   // partial sums of `cur`, `group` consecutive ones per block of this stage
     uint32_t n_parts = 0;
-    while (stage_k(cn) != 0) {
+    bool done = false;
+    if (overlap) {
+        const uint32_t g = n_vars - 8, k2 = overlapped_k2(n), k1 = g - k2;
+        ZK_TRY(c->ensure_fold_stream());
+        ZK_TRY(c->ensure_coarse());
+        const uint64_t* fine = d_block_sums;
+        bool have_coarse = fine && log_blocks == g && c->coarse_of == fine && c->coarse_n == n && c->coarse_k1 == k1;
+        if (!fine || log_blocks != g) {             // poly_sum() was not called (or with another granularity)
+            ZK_TRY(launch_fine_sums(c, d_evals, n, g, d_fine, nullptr));
+            fine = d_fine;
+        }
+        if (!have_coarse)
+            hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, c->stream, fine, 1u << k2, (uint64_t*)c->d_coarse);
+        c->coarse_of = nullptr;                     // d_coarse belongs to this call from here on
+        SmallArgs a = {};
+        a.src = (const uint64_t*)c->d_coarse; a.group = 0; a.log_n = k1; a.n_rounds = k1; a.round0 = 0; a.first = first; a.claimed = claimed;
+        a.d_claimed = d_claimed_sum; a.weights_out = d_w; a.final_out = nullptr;
+        ZK_TRY(launch_small(c, a, st, d_rp, d_ch));
+        first = 0;
+        // fork: the big fold on the fold stream next to rounds k1+1 .. g.  The serial kernel of those rounds asks for
+        // (nearly) a whole CU's LDS, so no fold workgroup shares its CU (beside 8+ fold waves per SIMD the transcript
+        // wave ran at half speed)
+        ZK_HIP(c, hipEventRecord(c->fork_ev, c->stream));
+        ZK_HIP(c, hipStreamWaitEvent(c->fold_stream, c->fork_ev, 0));
+        uint32_t ny = 0;
+        ZK_TRY(launch_blockfold(c, c->stream, fine, 1u << k2, k1, d_w, d_p1, &ny));
+        ZK_TRY(launch_multifold(c, c->fold_stream, d_evals, n, k1, d_w, tabA, partA, &n_parts));
+        ZK_HIP(c, hipEventRecord(c->join_ev, c->fold_stream));
+        SmallArgs b = {};
+        b.src = d_p1; b.group = ny; b.stride = 1u << k2; b.log_n = k2; b.n_rounds = k2; b.round0 = k1; b.first = 0;
+        b.weights_out = d_w2; b.final_out = nullptr;
+        ZK_TRY(launch_small(c, b, st, d_rp, d_ch, 156 * 1024));
+        ZK_HIP(c, hipStreamWaitEvent(c->stream, c->join_ev, 0));
+        round = g;
+        ZK_TRY(launch_blockfold(c, c->stream, tabA, 256, k2, d_w2, d_p2, &ny));       // 2^(8 + k2) entries -> 2^8, the last 8 rounds
+        SmallArgs t = {};
+        t.src = d_p2; t.group = ny; t.stride = 256; t.log_n = 8; t.n_rounds = 8; t.round0 = round; t.first = 0;
+        t.weights_out = nullptr; t.final_out = d_fin;
+        ZK_TRY(launch_small(c, t, st, d_rp, d_ch));
+        done = true;
+    }
+    while (!done && stage_k(cn) != 0) {
         const uint32_t k = stage_k(cn);
         const size_t m = cn >> k;
         SmallArgs a = {};
-        if (stage == 0 && d_block_sums && log_blocks >= k) {            // poly_sum() already streamed the table once
+        if (stage == 0 && d_block_sums && log_blocks >= k && log_blocks <= (uint32_t)MF_CAP_LOGK) {   // poly_sum() already streamed the table once
             a.src = d_block_sums;
             a.group = 1u << (log_blocks - k);
         } else if (stage == 0) {
@@ -536,26 +680,14 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
         first = 0;
         uint64_t* dst = (stage & 1) ? tabB : tabA;
         uint64_t* pdst = (stage & 1) ? partB : partA;
-        uint32_t out_per_wg;
-        if (m >= 8192) {          // streaming shape: 64 outputs per workgroup, 4 waves split the terms
-            out_per_wg = 64;
-            ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m);
-            hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), ((size_t)32 << k) + 32 * 3 * 64, c->stream, cur, m, k, d_w, dst, pdst);
-        } else {                  // few outputs left: 16 per workgroup, up to 64 lanes share one output
-            out_per_wg = 16;
-            uint32_t waves = 16;
-            while (waves * 4 > (1u << k)) waves >>= 1;   // at least one term per lane group (k >= 3 here)
-            ProfScope ps(c, "multifold_small", 32.0 * (double)cn + 32.0 * (double)m);
-            hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), ((size_t)32 << k) + 32 * (size_t)(waves - 1) * 16, c->stream, cur, m, k, d_w, dst, pdst);
-        }
+        ZK_TRY(launch_multifold(c, c->stream, cur, cn, k, d_w, dst, pdst, &n_parts));
         parts = pdst;
-        n_parts = (uint32_t)(m / out_per_wg);
         cur = dst;
         cn = m;
         round += k;
         ++stage;
     }
-    {
+    if (!done) {
         SmallArgs a = {};
         a.src = cur; a.group = 0; a.log_n = log2_exact(cn); a.n_rounds = a.log_n; a.round0 = round; a.first = first;
         a.claimed = claimed; a.d_claimed = d_claimed_sum; a.weights_out = nullptr; a.final_out = d_fin;
@@ -569,7 +701,7 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
     const size_t span_words = (size_t)(ZK_SMALL_ROUNDPOLYS - ZK_SMALL_STATE) + 8 * (size_t)n_vars;
     static_assert(ZK_PIN_END - ZK_PIN_PROOF >= (ZK_SMALL_ROUNDPOLYS - ZK_SMALL_STATE) + 8 * ZK_MAX_ROUNDS, "pinned proof area too small");
     ZK_HIP(c, hipMemcpyAsync(pin, span, 8 * span_words, hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    ZK_TRY(c->wait_stream());
     std::memcpy(h_sum, pin + ((const uint64_t*)st->sum - span), 32);
     std::memcpy(h_round_polys, pin + (d_rp - span), 64 * (size_t)n_vars);
     std::memcpy(h_challenges, pin + (d_ch - span), 32 * (size_t)n_vars);
@@ -813,6 +945,21 @@ extern "C" int zkhip_sc_tail(zkhip_sc_state* st, const uint64_t* d_values, uint3
     st->round += a.log_n;
     return ZKHIP_OK;
 }
+// releases a state's buffers and the context's loan flags
+static void sc_release(zkhip_sc_state* st) {
+    zkhip_ctx* c = st->c;
+    if (st->A && st->owns_tables) hipFree(st->A);
+    if (st->A && !st->owns_tables) c->ws_lent = false;
+    if (st->uses_cache) {
+        c->sc_lent = false;
+    } else if (!c->sc_small) {           // keep this set for the next prove instead of freeing it
+        c->sc_small = st->small; c->sc_stage = st->stage_buf; c->sc_stage_cap = st->stage_parts_cap;
+    } else {
+        hipFree(st->small);
+        if (st->stage_buf) hipFree(st->stage_buf);
+    }
+    delete st;
+}
 extern "C" int zkhip_sc_finish(zkhip_sc_state* st, uint64_t* h_sum, uint64_t* h_rp, uint64_t* h_ch, uint32_t* n_rounds) {
     if (!st) return ZKHIP_ERR_ARG;
     zkhip_ctx* c = st->c;
@@ -830,17 +977,15 @@ extern "C" int zkhip_sc_finish(zkhip_sc_state* st, uint64_t* h_sum, uint64_t* h_
         if (h_ch && st->round) std::memcpy(h_ch, pin + 64 + 8 * ZK_MAX_ROUNDS, 32 * (size_t)st->round);
     }
     if (n_rounds) *n_rounds = st->round;
-    if (st->A && st->owns_tables) hipFree(st->A);
-    if (st->A && !st->owns_tables) c->ws_lent = false;
-    if (st->uses_cache) {
-        c->sc_lent = false;
-    } else if (!c->sc_small) {           // keep this set for the next prove instead of freeing it
-        c->sc_small = st->small; c->sc_stage = st->stage_buf; c->sc_stage_cap = st->stage_parts_cap;
-    } else {
-        hipFree(st->small);
-        if (st->stage_buf) hipFree(st->stage_buf);
-    }
-    delete st;
+    sc_release(st);
+    return rc;
+}
+extern "C" int zkhip_sc_abort(zkhip_sc_state* st) {
+    if (!st) return ZKHIP_ERR_ARG;
+    zkhip_ctx* c = st->c;
+    int rc = ZKHIP_OK;
+    if (c->activate() != ZKHIP_OK || hipStreamSynchronize(c->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;   // kernels may still read the buffers
+    sc_release(st);
     return rc;
 }
 

@@ -39,6 +39,17 @@ class HipSumcheckEngine:
         N.check(N.lib().zkhip_sc_begin(self.ctx.handle, N.ptr(local_table), C.c_size_t(local_table.shape[0]),
                                        C.byref(self.st)), "sc_begin")
 
+    def abort(self):
+        """Releases the device state without a result (zkhip_sc_abort): error paths and dropped engines."""
+        if getattr(self, "st", None):
+            st, self.st = self.st, None
+            try:
+                N.lib().zkhip_sc_abort(st)
+            except Exception:       # interpreter shutdown: the library may already be gone
+                pass
+
+    __del__ = abort
+
     def new_buffer(self, *shape):
         return self.torch.empty(shape, dtype=self.torch.int64, device=self.table.device)
 
@@ -93,9 +104,9 @@ class HipSumcheckEngine:
         rp = np.empty((max(n_rounds, 1), 2, 4), dtype=np.uint64)
         ch = np.empty((max(n_rounds, 1), 4), dtype=np.uint64)
         got = C.c_uint32(0)
-        N.check(N.lib().zkhip_sc_finish(self.st, s.ctypes.data_as(C.c_void_p), rp.ctypes.data_as(C.c_void_p),
+        st, self.st = self.st, None            # zkhip_sc_finish releases the state whatever it returns
+        N.check(N.lib().zkhip_sc_finish(st, s.ctypes.data_as(C.c_void_p), rp.ctypes.data_as(C.c_void_p),
                                         ch.ctypes.data_as(C.c_void_p), C.byref(got)), "sc_finish")
-        self.st = None
         assert got.value == n_rounds
         return s, rp[:n_rounds], ch[:n_rounds]
 
@@ -122,6 +133,14 @@ class ShardedSumcheck:
             raise AssertionError("world size must be a power of two (the table has 2^n entries)")
 
     def prove(self, claimed_sum=None):
+        try:
+            return self._prove(claimed_sum)
+        except BaseException:
+            if hasattr(self.e, "abort"):
+                self.e.abort()              # a failed collective / assert must not leave the context's workspace lent
+            raise
+
+    def _prove(self, claimed_sum=None):
         e, world = self.e, self.world
         n_local = e.local_len()
         total_rounds = (n_local * world).bit_length() - 1
@@ -191,6 +210,17 @@ class HipComposedEngine:
         N.check(N.lib().zkhip_mc_record_len(self.st, C.byref(rec), C.byref(nt)), "mc_record_len")
         self.rec, self.n_tables = rec.value, nt.value
 
+    def abort(self):
+        """Releases the device state without a result (zkhip_mc_abort): error paths and dropped engines."""
+        if getattr(self, "st", None):
+            st, self.st = self.st, None
+            try:
+                N.lib().zkhip_mc_abort(st)
+            except Exception:       # interpreter shutdown: the library may already be gone
+                pass
+
+    __del__ = abort
+
     def new_buffer(self, *shape):
         return self.torch.empty(shape, dtype=self.torch.int64, device=self.device)
 
@@ -232,9 +262,9 @@ class HipComposedEngine:
         else:
             rp = np.zeros((n_rounds, 7, 2, 4), dtype=np.uint64)
             lens = np.zeros(n_rounds, dtype=np.uint32)
-        N.check(N.lib().zkhip_mc_finish(self.st, lens.ctypes.data_as(C.c_void_p) if lens is not None else None,
+        st, self.st = self.st, None            # zkhip_mc_finish releases the state whatever it returns
+        N.check(N.lib().zkhip_mc_finish(st, lens.ctypes.data_as(C.c_void_p) if lens is not None else None,
                                         rp.ctypes.data_as(C.c_void_p), ch.ctypes.data_as(C.c_void_p)), "mc_finish")
-        self.st = None
         if not self.multi:
             return rp, ch
         return [(rp[r, : lens[r], 0].copy(), rp[r, : lens[r], 1].copy()) for r in range(n_rounds)], ch
@@ -257,6 +287,14 @@ class ShardedComposedSumcheck:
             raise AssertionError("world size must be a power of two (the tables have 2^n entries)")
 
     def prove(self):
+        try:
+            return self._prove()
+        except BaseException:
+            if hasattr(self.e, "abort"):
+                self.e.abort()
+            raise
+
+    def _prove(self):
         e, world = self.e, self.world
         n_local = e.local_len()
         total_rounds = (n_local * world).bit_length() - 1

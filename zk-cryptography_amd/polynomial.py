@@ -175,8 +175,8 @@ class Multilinear:
         st = N.lib().zkhip_mle_elementwise(self._ctx.handle, C.c_int(op), N.ptr(self.evaluations),
                                            N.ptr(other.evaluations) if other is not None else None,
                                            sc.ctypes.data_as(C.c_void_p) if sc is not None else None,
-                                           C.c_size_t(len(self)), N.ptr(out))
-        N.check(st, "elementwise")
+                                           C.c_size_t(len(self)), C.c_size_t(len(other) if other is not None else 0), N.ptr(out))
+        N.check(st, "elementwise")     # a shorter rhs is the reference's index panic (evaluation_form.rs:185) -> IndexError
         return Multilinear._wrap(out)
 
     def __add__(self, rhs):   # evaluation_form.rs:178-194
