@@ -64,6 +64,11 @@ int zkhip_memcpy_d2h(zkhip_ctx *ctx, void *h_dst, const void *d_src, size_t byte
  * when enabled, every fold launch is bracketed by HIP events on the context's stream. */
 int zkhip_profile_enable(zkhip_ctx *ctx, int enable);
 int zkhip_profile_read(zkhip_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches, double *bytes);
+/* every bracketed launch since zkhip_profile_enable(ctx, 1) in issue order: names[32 * i] (NUL-terminated), start / stop in
+ * microseconds relative to the first launch's start -- the stream-ordered timeline of a call, gaps included, without a
+ * profiler attached (tools/timeline.py) */
+int zkhip_profile_timeline(zkhip_ctx *ctx, uint32_t max_records, char *names, double *start_us, double *stop_us,
+                           uint32_t *count);
 
 /* ---- host-side Fr helpers (what `Fr::from(..)`, `into_bigint()` and the field operators are to a Rust caller) --- */
 int zkhip_fr_from_i64(int64_t v, uint64_t *h_out);                       /* Fr::from(v): Montgomery limbs of v mod r */
@@ -357,6 +362,10 @@ int zkhip_domain_params(uint64_t size, uint64_t *h_generator, uint64_t *h_genera
 /* Domain::fft_internal / ifft_internal (domain.rs:120-133) = serial_fft (polynomial/src/utils.rs:281-315) with
  * omega, resp. omega^-1 followed by the scaling with size^-1; in place on d_data[2^log_n], natural order in/out. */
 int zkhip_ntt(zkhip_ctx *ctx, uint64_t *d_data, uint32_t log_n, int inverse);
+/* Domain::fft / ifft as the reference calls them (domain.rs:108-118: clone the input, resize it to the domain size with
+ * zeros, transform): d_src holds n_src <= 2^log_n values and is not modified, d_dst receives the 2^log_n results.  The zero
+ * padding happens inside the first pass (no staging copy). */
+int zkhip_domain_transform(zkhip_ctx *ctx, const uint64_t *d_src, size_t n_src, uint64_t *d_dst, uint32_t log_n, int inverse);
 int zkhip_pointwise_mul(zkhip_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, size_t n, uint64_t *d_out);
 /* UnivariateEval::multiply (evaluation.rs:59-86): d_out[na + nb - 1] = coefficients of a * b via three transforms. */
 int zkhip_univariate_multiply(zkhip_ctx *ctx, const uint64_t *d_a, size_t na, const uint64_t *d_b, size_t nb,

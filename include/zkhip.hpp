@@ -538,12 +538,12 @@ class Domain {
     std::vector<Fr> ifft(const std::vector<Fr>& evals) const { return transform(evals, 1); }    // :114-118
   private:
     std::vector<Fr> transform(const std::vector<Fr>& v, int inverse) const {
-        std::vector<Fr> buf(size, Fr::zero());
-        for (size_t i = 0; i < v.size() && i < size; ++i) buf[i] = v[i];
-        DeviceBuffer d(32 * size);
-        d.upload(buf.data(), 32 * size);
+        const size_t n_src = v.size() < size ? v.size() : (size_t)size;
+        DeviceBuffer src(32 * (n_src ? n_src : 1)), d(32 * size);
+        if (n_src) src.upload(v.data(), 32 * n_src);
         uint32_t lg = 0; while (((uint64_t)1 << lg) < size) ++lg;
-        check(zkhip_ntt(ctx(), d.u64(), lg, inverse), "ntt");
+        check(zkhip_domain_transform(ctx(), src.u64(), n_src, d.u64(), lg, inverse), "domain_transform");   // resize(size, zero) inside
+        std::vector<Fr> buf(size);
         d.download(buf.data(), 32 * size);
         return buf;
     }

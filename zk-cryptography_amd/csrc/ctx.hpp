@@ -69,12 +69,13 @@ struct zkhip_ctx {
     size_t msm_pin_bytes[MSM_SLOTS] = {};
     hipEvent_t msm_ev[MSM_SLOTS] = {};
     hipStream_t side[MSM_SLOTS] = {};
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr, serial_ev = nullptr;
     int ensure_side_streams() {
         for (int i = 0; i < MSM_SLOTS; ++i)
             if (!side[i] && hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) return ZKHIP_ERR_HIP;
         if (!fork_ev && hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
         if (!join_ev && hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
+        if (!serial_ev && hipEventCreateWithFlags(&serial_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
         return ZKHIP_OK;
     }
     // The basic prover's streaming fold runs on a LOW-priority stream of its own next to the serial transcript kernel
@@ -94,7 +95,7 @@ struct zkhip_ctx {
     void* d_coarse = nullptr;
     const void* coarse_of = nullptr; size_t coarse_n = 0; uint32_t coarse_k1 = 0;
     int ensure_coarse() {
-        if (!d_coarse && hipMalloc(&d_coarse, 1024 * 32) != hipSuccess) return ZKHIP_ERR_NOMEM;
+        if (!d_coarse && hipMalloc(&d_coarse, 2 * 1024 * 32) != hipSuccess) return ZKHIP_ERR_NOMEM;   // canonical, then Montgomery
         return ZKHIP_OK;
     }
     int reserve_msm_pin(int slot, size_t bytes) {
@@ -130,18 +131,20 @@ struct zkhip_ctx {
         big_lds_done.insert(fn);
         return ZKHIP_OK;
     }
-    // Host wait for the stream's work so far: polls an event for up to ~2 ms (a prover call is a few hundred
+    // Host wait for a stream's work so far: polls an event for up to ~2 ms (a prover call is a few hundred
     // microseconds; a blocking wait's wake-up costs 10-20 us of idle GPU before the next call), then blocks.
     hipEvent_t done_ev = nullptr;
-    int wait_stream() {
+    int wait_stream(hipStream_t s = nullptr) {
+        if (!s) s = stream;
         if (!done_ev && hipEventCreateWithFlags(&done_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
-        if (hipEventRecord(done_ev, stream) != hipSuccess) return ZKHIP_ERR_HIP;
+        if (hipEventRecord(done_ev, s) != hipSuccess) return ZKHIP_ERR_HIP;
+        if (s != stream && hipStreamWaitEvent(stream, done_ev, 0) != hipSuccess) return ZKHIP_ERR_HIP;   // the caller's stream stays ordered behind it
         for (int spin = 0; spin < 200000; ++spin) {
             const hipError_t e = hipEventQuery(done_ev);
             if (e == hipSuccess) return ZKHIP_OK;
             if (e != hipErrorNotReady) { last_hip = (int)e; return ZKHIP_ERR_HIP; }
         }
-        const hipError_t e = hipStreamSynchronize(stream);
+        const hipError_t e = hipStreamSynchronize(s);
         if (e != hipSuccess) { last_hip = (int)e; return ZKHIP_ERR_HIP; }
         return ZKHIP_OK;
     }

@@ -86,9 +86,11 @@ static __global__ __launch_bounds__(MLE_BLOCK) void fine_sums_kernel(const uint6
     }
 }
 
-// out[b] = sum of in[b*group .. (b+1)*group), one workgroup per output (the coarse block sums from the fine ones)
+// One workgroup per output b: the sum of in[b*group .. (b+1)*group) (the coarse block sums from the fine ones), written as
+// a Montgomery residue to out_mont[b] and / or as a canonical integer -- what the serial kernel's sum tree holds -- to
+// out_canon[b] (either may be null)
 static __global__ __launch_bounds__(MLE_BLOCK) void group_sums_wg_kernel(const uint64_t* __restrict__ in, uint32_t group,
-                                                                         uint64_t* __restrict__ out) {
+                                                                         uint64_t* __restrict__ out_mont, uint64_t* __restrict__ out_canon) {
     __shared__ Fr red[MLE_BLOCK / 64];
     const uint64_t* base = in + 4 * (size_t)blockIdx.x * group;
     Fr s = Fr::zero();
@@ -100,7 +102,10 @@ static __global__ __launch_bounds__(MLE_BLOCK) void group_sums_wg_kernel(const u
         for (int u = 0; u < 4; ++u) s = s + v[u];
     }
     s = block_reduce_fr(s, red);
-    if (threadIdx.x == 0) store_fr(out, blockIdx.x, s);
+    if (threadIdx.x == 0) {
+        if (out_mont) store_fr(out_mont, blockIdx.x, s);
+        if (out_canon) store_fr(out_canon, blockIdx.x, fr_from_mont_outlined(s));
+    }
 }
 
 constexpr int TREE_MAX_LOG = 10;   // the serial kernel keeps tables of up to 2^10 entries (and their sum trees) in LDS
@@ -109,6 +114,7 @@ struct SmallArgs {
     const uint64_t* src;    // mode 0: the table itself (2^log_n entries); mode 1: partial sums, `group` per entry
     uint32_t group;         // mode 1: partials per table entry (0 = mode 0)
     uint32_t stride;        // mode 1: 0 = entry j owns partials j*group .. +group; else partial g of entry j is src[g*stride + j]
+    uint32_t canon;         // the source values are canonical integers already (blockfold_kernel / group_sums_wg_kernel<true>)
     uint32_t log_n;         // working table has 2^log_n entries (<= 2^TREE_MAX_LOG)
     uint32_t n_rounds;      // rounds to run, <= log_n
     uint32_t round0;        // index of the first round run here
@@ -118,6 +124,8 @@ struct SmallArgs {
     uint64_t* weights_out;  // nullable: 2^n_rounds fold weights eq_b(r) * 2^32 (Montgomery form)
     uint64_t* final_out;    // nullable: the table left after n_rounds folds
 };
+
+constexpr int SMALL_BLOCK = 512;   // 8 waves: the transcript wave, two schedule waves, five waves for the trees and weights
 
 // n_rounds sumcheck rounds (half sums -> transcript -> challenge -> fold, sumcheck.rs:40-51) of a small table.
 //
@@ -129,14 +137,17 @@ struct SmallArgs {
 // The tree is kept in CANONICAL (non-Montgomery) form: the transcript absorbs canonical bytes, so (lo, hi) need no
 // conversion, and a product of a Montgomery-form challenge with a canonical difference is again canonical.
 // Wave 0 runs nothing but the transcript chain plus ONE product per round (challenge_canonical * E, where
-// E = to_mont(hi' - lo') was prepared a round earlier); waves 1-3 convert the challenge, fold the rest of the tree
-// and the k-variable fold weights, and write the outputs (Montgomery form) behind it.  One barrier per round; the
-// trees, E and the challenge slot are double-buffered.
-static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallArgs a, SumcheckDev* st,
-                                                                          uint64_t* __restrict__ round_polys,
-                                                                          uint64_t* __restrict__ challenges) {
+// E = to_mont(hi' - lo') was prepared a round earlier); waves 1 and 2 prepare the message schedules of the next round's
+// two SHA-256 blocks and nothing else (with tree work on top they were the last to reach the barrier); waves 3-7 convert
+// the challenge, fold the rest of the tree and the k-variable fold weights, and write the outputs (Montgomery form).
+// One barrier per round; the trees, E and the challenge slot are double-buffered.  (Stamps of a 2^24 prove,
+// tools/diag_small.py: a round = 2 x 2.1 us of state rounds + 0.9 us for the product + 0.3 us to publish.)
+static __global__ __launch_bounds__(SMALL_BLOCK) void sumcheck_small_kernel(SmallArgs a, SumcheckDev* st,
+                                                                            uint64_t* __restrict__ round_polys,
+                                                                            uint64_t* __restrict__ challenges) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
     __builtin_amdgcn_s_setprio(3);                      // the chip's critical path: win every issue arbitration
+    ZK_STAMP_AT(0, 40 + a.round0, 0);                   // diagnostics: kernel entry
     const uint32_t n = 1u << a.log_n;
     Fr* tree0 = reinterpret_cast<Fr*>(zk_dyn_lds);      // 2n nodes, canonical values
     Fr* tree1 = tree0 + 2 * n;                          // n nodes: the first tree built here is already a folded one
@@ -145,14 +156,18 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
     const uint32_t w_all = a.weights_out ? (1u << a.n_rounds) : 0u;
     Fr* w0 = tree1 + n;
     Fr* w1 = w0 + ((a.n_rounds & 1) ? w_all / 2 : w_all);
-    Fr* scratch = w0 + w_all + w_all / 2;               // MLE_BLOCK
-    Fr* e_sh = scratch + MLE_BLOCK;                     // 2 x 2: to_mont(level-2 differences) of tree0 / tree1
+    const bool grouped = a.group != 0 && a.stride == 0;
+    Fr* scratch = w0 + w_all + w_all / 2 + 1;           // SMALL_BLOCK entries, only in the grouped mode
+    Fr* e_sh = scratch + (grouped ? SMALL_BLOCK : 0);   // 2 x 2: to_mont(level-2 differences) of tree0 / tree1
     Fr* r_sh = e_sh + 4;                                // 2: canonical challenge, double-buffered
-    // ---- leaves (sums are taken in Montgomery form, then converted once)
+    // ---- leaves (sums are taken as they come -- the conversion to canonical integers is linear -- then converted once)
     if (a.group == 0) {
-        for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) tree0[n + j] = load_fr(a.src, j).from_mont();
-    } else if (a.stride != 0) {   // all-gathered per-rank block sums: add the ranks' contributions in rank order
-        for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) {
+        for (uint32_t j = threadIdx.x; j < n; j += SMALL_BLOCK) {
+            const Fr v = load_fr(a.src, j);
+            tree0[n + j] = a.canon ? v : fr_from_mont_outlined(v);
+        }
+    } else if (a.stride != 0) {   // partial tables (blockfold_kernel's term ranges, or all-gathered per-rank block sums in rank order)
+        for (uint32_t j = threadIdx.x; j < n; j += SMALL_BLOCK) {
             Fr s = load_fr(a.src, j);
             for (uint32_t g = 1; g < a.group; g += 8) {      // up to 8 loads in flight (the serial kernel's prologue is latency)
                 Fr v[8];
@@ -161,22 +176,22 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (g + u < a.group) s = s + v[u];
             }
-            tree0[n + j] = s.from_mont();
+            tree0[n + j] = a.canon ? s : fr_from_mont_outlined(s);
         }
     } else {
         const uint32_t total = n * a.group;
-        const uint32_t run = total > (uint32_t)MLE_BLOCK ? total / MLE_BLOCK : 1;   // consecutive partials per thread
+        const uint32_t run = total > (uint32_t)SMALL_BLOCK ? total / SMALL_BLOCK : 1;   // consecutive partials per thread
         if (threadIdx.x * run < total) {
             Fr s = Fr::zero();
             for (uint32_t g = 0; g < run; ++g) s = s + load_fr(a.src, (size_t)threadIdx.x * run + g);
             scratch[threadIdx.x] = s;
         }
         __syncthreads();
-        const uint32_t tpe = a.group / run;   // scratch slots per entry (run <= group because n <= MLE_BLOCK in this mode)
-        for (uint32_t j = threadIdx.x; j < n; j += MLE_BLOCK) {
+        const uint32_t tpe = a.group / run;   // scratch slots per entry (run <= group because n <= SMALL_BLOCK in this mode)
+        for (uint32_t j = threadIdx.x; j < n; j += SMALL_BLOCK) {
             Fr s = scratch[j * tpe];
             for (uint32_t g = 1; g < tpe; ++g) s = s + scratch[j * tpe + g];
-            tree0[n + j] = s.from_mont();
+            tree0[n + j] = a.canon ? s : fr_from_mont_outlined(s);
         }
     }
     if (threadIdx.x == 0 && a.weights_out) {
@@ -187,14 +202,32 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
         w0[0] = one32;
     }
     __syncthreads();
-    // ---- inner levels, bottom up
-    for (uint32_t lvl = a.log_n; lvl-- > 1;) {
-        const uint32_t cnt = 1u << lvl;
-        for (uint32_t b = threadIdx.x; b < cnt; b += MLE_BLOCK) tree0[cnt + b] = tree0[2 * cnt + 2 * b] + tree0[2 * cnt + 2 * b + 1];
+    // ---- inner levels, bottom up, three levels per barrier: a lane sums the subtree under 8 nodes of the level below
+    for (uint32_t lvl = a.log_n; lvl > 1;) {
+        const uint32_t step = lvl - 1 < 3 ? lvl - 1 : 3;
+        const uint32_t groups = 1u << (lvl - step);
+        for (uint32_t g = threadIdx.x; g < groups; g += SMALL_BLOCK) {
+            Fr v[8];
+            const uint32_t cnt0 = 1u << step;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if ((uint32_t)i < cnt0) v[i] = tree0[(1u << lvl) + g * cnt0 + i];
+#pragma unroll
+            for (int sft = 1; sft <= 3; ++sft) {
+                if ((uint32_t)sft <= step) {
+                    const uint32_t cnt = cnt0 >> sft;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if ((uint32_t)i < cnt) {
+                            v[i] = v[2 * i] + v[2 * i + 1];
+                            tree0[(1u << (lvl - sft)) + g * cnt + i] = v[i];
+                        }
+                    }
+                }
+            }
+        }
         __syncthreads();
+        lvl -= step;
     }
-    if (threadIdx.x < 2 && a.log_n >= 2) e_sh[threadIdx.x] = (tree0[6 + threadIdx.x] - tree0[4 + threadIdx.x]).to_mont();
-    __syncthreads();
     // ---- rounds.  Every round hashes the same two-block message from the initial hash value:
     //   block 1 = prefix (the previous challenge's digest; in the first round of a proof the claimed sum) || lo
     //   block 2 = hi || 0x80 padding || length (96 bytes)
@@ -207,6 +240,8 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
     uint32_t* kw2 = kw1 + 64;                                   // 64 words
     uint32_t* dig_sh = kw2 + 64;                                // 2 x 8: raw digest of the last challenge, double-buffered
     uint32_t* flags = dig_sh + 16;                              // [0]: kw1 progress, [1]: kw2 progress
+    if (threadIdx.x >= 64 && threadIdx.x < 66 && a.log_n >= 2)
+        e_sh[threadIdx.x - 64] = (tree0[6 + threadIdx.x - 64] - tree0[4 + threadIdx.x - 64]).to_mont();
     if (threadIdx.x == 0) {
         flags[0] = 0; flags[1] = 0;
         // prefix of the first round run here
@@ -226,6 +261,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
     __syncthreads();
     Fr lo = tree0[2], hi = tree0[3];     // canonical
     uint32_t depth = a.log_n, round = a.round0, n_w = 1;
+    ZK_STAMP_AT(0, 40 + a.round0, 1);                   // prologue done
     // schedules of round 0 (waves 1 and 2)
     auto schedule_block1 = [&](const uint32_t* prefix, const Fr& lo_c, uint32_t it) {
         uint32_t w[16];
@@ -246,6 +282,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
         if (wave == 2) schedule_block2(hi, 0);
     }
     uint32_t digest[8];
+    constexpr uint32_t FIRST_HELPER = 192, N_HELPERS = SMALL_BLOCK - FIRST_HELPER;
     for (uint32_t it = 0; it < a.n_rounds; ++it) {
         Fr* told = (it & 1) ? tree1 : tree0;
         Fr* tnew = (it & 1) ? tree0 : tree1;
@@ -255,13 +292,16 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
         Fr* enew = e_sh + 2 * ((it & 1) ^ 1);
         const bool absorb_sum = a.first && it == 0;
         if (wave0) {
+            ZK_STAMP_AT(0, round, 0);
             uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
             uint32_t blk[16];
             const uint32_t* pre = dig_sh + 8 * ((it + 1) & 1);
 #pragma unroll
             for (int i = 0; i < 8; ++i) { blk[i] = pre[i]; blk[8 + i] = lo.l[7 - i]; }
             sha256_compress_kw(h, blk, kw1, flags, 4 * it);          // uni_poly.to_bytes()  sumcheck.rs:42
+            ZK_STAMP_AT(0, round, 1);
             sha256_compress_kw(h, nullptr, kw2, flags + 1, 4 * it);  // challenge()  :46
+            ZK_STAMP_AT(0, round, 2);
 #pragma unroll
             for (int i = 0; i < 8; ++i) digest[i] = h[i];
             Fr c;                                                    // from_be_bytes_mod_order, still canonical
@@ -275,7 +315,11 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
                 for (int i = 0; i < 8; ++i) dig_sh[8 * (it & 1) + i] = h[i];
             }
         }
+        ZK_STAMP_AT(0, round, 3);
+        ZK_STAMP_AT(SMALL_BLOCK - 1, round, 6);      // the last helper arrives at the barrier
+        ZK_STAMP_AT(64, round, 7);                   // the first schedule wave arrives
         __syncthreads();   // challenge and digest published; tree `told` and `eold` complete
+        ZK_STAMP_AT(0, round, 4);
         const Fr c = r_sh[it & 1];
         if (wave0) {
             if (depth >= 2) {   // next round polynomial straight from level 2 of the old tree: lo' = t[4] + c * (t[6] - t[4])
@@ -284,16 +328,18 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
                 lo = shfl_fr(v, 0);
                 hi = shfl_fr(v, 1);
             }
-        } else {
-            // schedules of the NEXT round first (its hash is already waiting for them), then this round's folding
-            if (it + 1 < a.n_rounds && depth >= 2 && wave <= 2) {
+            ZK_STAMP_AT(0, round, 5);
+        } else if (wave <= 2) {
+            // schedules of the NEXT round (its hash is already waiting for them)
+            if (it + 1 < a.n_rounds && depth >= 2) {
                 const uint32_t q = wave - 1;                         // wave 1: lo', wave 2: hi'
                 const Fr v = told[4 + q] + fr_mul_outlined(c, eold[q]);
                 if (wave == 1) schedule_block1(dig_sh + 8 * (it & 1), v, it + 1);
                 else schedule_block2(v, it + 1);
             }
+        } else {
             const Fr r = fr_to_mont_outlined(c);       // every helper wave converts for itself (no extra sync)
-            const uint32_t helper = threadIdx.x - 64, n_helpers = MLE_BLOCK - 64;
+            const uint32_t helper = threadIdx.x - FIRST_HELPER;
             if (helper == 0) {   // outputs of this round, in Montgomery form as the reference holds them
                 Fr lo_m = told[2].to_mont(), hi_m = told[3].to_mont();
                 if (absorb_sum) {
@@ -305,22 +351,22 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
                 store_fr(challenges, round, r);
             }
             const uint32_t nodes = 1u << (depth - 1);   // the new tree has nodes 1 .. 2*nodes - 1
-            if (helper >= 190 && helper < 192 && depth >= 3) {
+            if (helper >= N_HELPERS - 2 && depth >= 3) {
                 // the last two lanes of the last helper wave: new level 2 pair (q, q+2) and the product wave 0 will need next round
-                const uint32_t q = 4 + (helper - 190);
+                const uint32_t q = 4 + (helper - (N_HELPERS - 2));
                 Fr va = told[q + 4] + r * (told[q + 8] - told[q + 4]);           // new[q],   p = 4
                 Fr vb = told[q + 6] + r * (told[q + 10] - told[q + 6]);          // new[q+2], p = 4
                 tnew[q] = va;
                 tnew[q + 2] = vb;
-                enew[helper - 190] = (vb - va).to_mont();
+                enew[helper - (N_HELPERS - 2)] = (vb - va).to_mont();
             }
-            for (uint32_t q = 1 + helper; q < 2 * nodes; q += n_helpers) {
+            for (uint32_t q = 1 + helper; q < 2 * nodes; q += N_HELPERS) {
                 if (depth >= 3 && q >= 4 && q < 8) continue;                     // done above
                 const uint32_t p = 1u << (31 - __builtin_clz(q));
                 tnew[q] = told[q + p] + r * (told[q + 2 * p] - told[q + p]);
             }
             if (a.weights_out) {   // eq weights: the index gains the new variable as its least significant bit
-                for (uint32_t b = helper; b < n_w; b += n_helpers) {
+                for (uint32_t b = helper; b < n_w; b += N_HELPERS) {
                     Fr w1v = wold[b] * r;
                     wnew[2 * b + 1] = w1v;
                     wnew[2 * b] = wold[b] - w1v;
@@ -331,6 +377,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
         --depth;
         ++round;
     }
+    ZK_STAMP_AT(0, 40 + a.round0, 2);                   // rounds done
     __syncthreads();
     if (threadIdx.x == 0 && a.n_rounds) {   // what FiatShamirTranscript holds after a challenge(): fresh hasher + the digest
         Transcript tr;
@@ -341,17 +388,19 @@ static __global__ __launch_bounds__(MLE_BLOCK) void sumcheck_small_kernel(SmallA
 
     if (a.weights_out) {
         Fr* w = (a.n_rounds & 1) ? w1 : w0;
-        for (uint32_t b = threadIdx.x; b < n_w; b += MLE_BLOCK) store_fr(a.weights_out, b, w[b]);
+        for (uint32_t b = threadIdx.x; b < n_w; b += SMALL_BLOCK) store_fr(a.weights_out, b, w[b]);
     }
     if (a.final_out) {
         Fr* t = (a.n_rounds & 1) ? tree1 : tree0;
         const uint32_t cnt = 1u << depth;
-        for (uint32_t j = threadIdx.x; j < cnt; j += MLE_BLOCK) store_fr(a.final_out, j, t[cnt + j].to_mont());
+        for (uint32_t j = threadIdx.x; j < cnt; j += SMALL_BLOCK) store_fr(a.final_out, j, t[cnt + j].to_mont());
     }
 }
-// dynamic LDS of the kernel above: trees (3 x 2^log_n), weights (1.5 x 2^weight_rounds; weight_rounds < 0: none), scratch
-__host__ __device__ constexpr size_t small_lds_bytes(uint32_t log_n, int weight_rounds) {
-    return ((size_t)3 * ((size_t)1 << log_n) + (weight_rounds >= 0 ? 3 * ((size_t)1 << weight_rounds) / 2 + 1 : 0u) + MLE_BLOCK + 4 + 2) * 32 + (64 + 64 + 16 + 2) * 4;
+// dynamic LDS of the kernel above: trees (3 x 2^log_n), weights (1.5 x 2^weight_rounds; weight_rounds < 0: none), the
+// grouped mode's scratch, the small shared slots
+__host__ __device__ constexpr size_t small_lds_bytes(uint32_t log_n, int weight_rounds, bool grouped) {
+    return ((size_t)3 * ((size_t)1 << log_n) + (weight_rounds >= 0 ? 3 * ((size_t)1 << weight_rounds) / 2 : 0u) + 1 +
+            (grouped ? SMALL_BLOCK : 0) + 4 + 2) * 32 + (64 + 64 + 16 + 2) * 4;
 }
 
 // Fold weights of k known points (MultilinearTrait::evaluation folds variable 0 repeatedly, evaluation_form.rs:162-175):
@@ -444,7 +493,17 @@ __device__ __forceinline__ Fr wide_reduce(const uint64_t (&lo)[15], const uint32
 // groups of a wave combine by shuffles, the waves through LDS.  G = 64 streams big tables (2 KiB per wave-load);
 // G = 16 keeps the chip busy when only a few hundred outputs are left.
 // Also writes the workgroup's sum of outputs to partials[blockIdx.x] (block sums of the output table).
-template <int G>
+// once-read streaming load of a table entry (nt: no reuse to keep in the caches)
+__device__ __forceinline__ Fr load_fr_nt(const uint64_t* __restrict__ base) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* p = reinterpret_cast<const u32x4*>(base);
+    const u32x4 a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 1);
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+template <int G, int DEPTH = 4, bool NT = false>
 static __global__ __launch_bounds__(1024) void multifold_kernel(const uint64_t* __restrict__ in, size_t m, uint32_t k,
                                                                 const uint64_t* __restrict__ weights,
                                                                 uint64_t* __restrict__ out,
@@ -470,12 +529,12 @@ static __global__ __launch_bounds__(1024) void multifold_kernel(const uint64_t* 
     const uint32_t b0 = slice * per;
     const uint64_t* p = in + 4 * ((size_t)b0 * m + j);
     const size_t row = 4 * m;
-    for (uint32_t t = 0; t < per; t += 4) {
-        Fr v[4];
+    for (uint32_t t = 0; t < per; t += DEPTH) {
+        Fr v[DEPTH];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (t + u < per) v[u] = load_fr(p + (size_t)(t + u) * row, 0);
+        for (int u = 0; u < DEPTH; ++u) if (t + u < per) v[u] = NT ? load_fr_nt(p + (size_t)(t + u) * row) : load_fr(p + (size_t)(t + u) * row, 0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (t + u < per) acc.mac(w_lds[b0 + t + u], v[u]);
+        for (int u = 0; u < DEPTH; ++u) if (t + u < per) acc.mac(w_lds[b0 + t + u], v[u]);
     }
     Fr o = wide_reduce(acc.lo, acc.hi);
 #pragma unroll
@@ -494,35 +553,38 @@ static __global__ __launch_bounds__(1024) void multifold_kernel(const uint64_t* 
     }
 }
 
-// ---- k-variable fold of a SMALL table (<= 2^17 entries), spread over the chip -----------------------------------------
-// partial[y*m + c] = sum over the term range y of w[b] * in[b*m + c].  multifold_kernel<16> gives such a table to m/16
-// workgroups (16 at m = 256: ~16 us of one-wave-per-SIMD latency); here a workgroup takes OW outputs x (256/OW) term slices
-// of <= 4 terms each and the term ranges go to blockIdx.y, so 2^16 entries are 64 workgroups of 4 products per lane.  The
-// serial kernel adds the gridDim.y partial tables (SmallArgs::stride).
-static __global__ __launch_bounds__(MLE_BLOCK) void blockfold_kernel(const uint64_t* __restrict__ in, uint32_t m, uint32_t log_ow,
-                                                                     uint32_t per, const uint64_t* __restrict__ weights,
-                                                                     uint64_t* __restrict__ partial) {
-    __shared__ Fr part[MLE_BLOCK];
-    const uint32_t ow = 1u << log_ow, sl_cnt = MLE_BLOCK >> log_ow;
+// ---- k-variable fold of a SMALL table (<= 2^18 entries), spread over the chip -----------------------------------------
+// partial[y*m + c] = sum over the term range y of w[b] * in[b*m + c], as CANONICAL integers (the serial kernel's form; the
+// conversion is linear, so partial tables still add up).  multifold_kernel<16> gives such a table to m/16 workgroups (16 at
+// m = 256: ~16 us of one-wave-per-SIMD latency); here a workgroup of 1024 lanes takes OW outputs x (1024/OW) term slices
+// of <= 4 terms each, sums the slices in LDS, and the term ranges go to blockIdx.y: 2^18 entries are 64 workgroups of
+// 4 products per lane.  The serial kernel adds the gridDim.y (<= 8) partial tables (SmallArgs::stride).
+constexpr int BF_BLOCK = 1024;
+static __global__ __launch_bounds__(BF_BLOCK) void blockfold_kernel(const uint64_t* __restrict__ in, uint32_t m, uint32_t log_ow,
+                                                                    uint32_t per, const uint64_t* __restrict__ weights,
+                                                                    uint64_t* __restrict__ partial) {
+    __shared__ Fr part[BF_BLOCK];
+    const uint32_t ow = 1u << log_ow, sl_cnt = BF_BLOCK >> log_ow;
     const uint32_t o = threadIdx.x & (ow - 1), sl = threadIdx.x >> log_ow;
     const uint32_t c = blockIdx.x * ow + o;
     const uint32_t b0 = (blockIdx.y * sl_cnt + sl) * per;
     WideAcc acc;
     acc.clear();
-    Fr v[4], w[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if ((uint32_t)u < per) { v[u] = load_fr(in, (size_t)(b0 + u) * m + c); w[u] = load_fr(weights, b0 + u); }
+    for (uint32_t u = 0; u < per; u += 2) {
+        Fr v0 = load_fr(in, (size_t)(b0 + u) * m + c), w0 = load_fr(weights, b0 + u);
+        Fr v1 = v0, w1 = w0;
+        const bool two = u + 1 < per;
+        if (two) { v1 = load_fr(in, (size_t)(b0 + u + 1) * m + c); w1 = load_fr(weights, b0 + u + 1); }
+        acc.mac(w0, v0);
+        if (two) acc.mac(w1, v1);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) if ((uint32_t)u < per) acc.mac(w[u], v[u]);
     part[threadIdx.x] = wide_reduce(acc.lo, acc.hi);
     __syncthreads();
-    if (sl == 0) {
-        Fr s = part[o];
-        for (uint32_t q = 1; q < sl_cnt; ++q) s = s + part[(q << log_ow) + o];
-        store_fr(partial, (size_t)blockIdx.y * m + c, s);
+    for (uint32_t half = sl_cnt >> 1; half >= 1; half >>= 1) {       // tree over the slices
+        if (sl < half) part[threadIdx.x] = part[threadIdx.x] + part[threadIdx.x + (half << log_ow)];
+        __syncthreads();
     }
+    if (sl == 0) store_fr(partial, (size_t)blockIdx.y * m + c, fr_from_mont_outlined(part[o]));
 }
 
 }  // namespace zk

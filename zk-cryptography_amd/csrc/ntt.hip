@@ -76,10 +76,78 @@ static int get_twiddles(zkhip_ctx* c, uint32_t log_n, int inverse, uint64_t** ou
     return ZKHIP_OK;
 }
 
+// ---- transforms of >= 2^12 points (ntt_kernels.hpp, second half) ------------------------------------------------------------
+struct NttPass { uint32_t s0, T; uint64_t* table; };
+struct NttPlan { uint64_t* tw1 = nullptr; std::vector<NttPass> passes; zkhost::Fr n_inv; };
+static std::map<TwiddleKey, NttPlan> g_plans;        // device tables, kept for the life of the process
+
+static int get_plan(zkhip_ctx* c, uint32_t log_n, int inverse, NttPlan** out) {
+    TwiddleKey key{c, log_n, inverse};
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) { *out = &it->second; return ZKHIP_OK; }
+    uint64_t* W = nullptr;
+    ZK_TRY(get_twiddles(c, log_n, inverse, &W));
+    NttPlan plan;
+    plan.n_inv = zkhost::fr_inv(zkhost::fr_from_u64((uint64_t)1 << log_n));
+    ZK_HIP(c, hipMalloc(&plan.tw1, 256 * 32));
+    hipLaunchKernelGGL(ntt_first_table_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, W, log_n, plan.tw1);
+    // the stages after the first eight, in passes of <= 7 spread evenly
+    const uint32_t rest = log_n - NTT_FIRST_STAGES;
+    const uint32_t n_pass = (rest + 6) / 7;
+    uint32_t s0 = NTT_FIRST_STAGES;
+    for (uint32_t p = 0; p < n_pass; ++p) {
+        const uint32_t T = (rest - (s0 - NTT_FIRST_STAGES) + (n_pass - p) - 1) / (n_pass - p);
+        NttPass ps{s0, T, nullptr};
+        const size_t entries = (((size_t)1 << T) - 1) << s0;
+        ZK_HIP(c, hipMalloc(&ps.table, entries * 32));
+        FrArg sc = {};
+        const bool scaled = inverse && p + 1 == n_pass;
+        if (scaled) std::memcpy(sc.v, plan.n_inv.l, 32);
+        hipLaunchKernelGGL(ntt_pass_table_kernel, dim3(mle_grid_stream(entries)), dim3(MLE_BLOCK), 0, c->stream, W, log_n, s0, T, sc,
+                           scaled ? 1u : 0u, ps.table);
+        plan.passes.push_back(ps);
+        s0 += T;
+    }
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *out = &(g_plans[key] = plan);
+    return ZKHIP_OK;
+}
+
+// src (n_src <= n elements, zero-padded; times src2 element-wise when given) -> dst (the first n_dst <= n outputs), which may
+// be src itself; d_scratch: n elements.  The last pass writes dst, every earlier one d_scratch.
+static int ntt_big(zkhip_ctx* c, const uint64_t* d_src, size_t n_src, const uint64_t* d_src2, uint64_t* d_dst, size_t n_dst,
+                   uint32_t log_n, int inverse, uint64_t* d_scratch) {
+    const size_t n = (size_t)1 << log_n;
+    NttPlan* plan = nullptr;
+    ZK_TRY(get_plan(c, log_n, inverse, &plan));
+    const size_t lds = (size_t)NTT_BIG_TILE * 32;
+    const unsigned grid = (unsigned)(n >> NTT_BIG_TILE_LOG);
+    {
+        ProfScope ps(c, "ntt_first8", 32.0 * (double)(n_src + n) + (d_src2 ? 32.0 * (double)n : 0.0));
+        hipLaunchKernelGGL(ntt_first8_kernel, dim3(grid), dim3(NTT_BIG_BLOCK), lds, c->stream, d_src, n_src, d_src2, d_scratch, log_n, plan->tw1);
+    }
+    FrArg sc = {};
+    std::memcpy(sc.v, plan->n_inv.l, 32);
+    for (size_t p = 0; p < plan->passes.size(); ++p) {
+        const NttPass& ps = plan->passes[p];
+        const bool last = p + 1 == plan->passes.size();
+        ProfScope pr(c, "ntt_pass", 32.0 * (double)(n + (last ? n_dst : n)) + 32.0 * (double)((((size_t)1 << ps.T) - 1) << ps.s0));
+        if (last && inverse)
+            hipLaunchKernelGGL(ntt_pass_kernel<true>, dim3(grid), dim3(NTT_BIG_BLOCK), lds, c->stream, d_scratch, d_dst, ps.s0, ps.T, ps.table, sc, n_dst);
+        else
+            hipLaunchKernelGGL(ntt_pass_kernel<false>, dim3(grid), dim3(NTT_BIG_BLOCK), lds, c->stream, d_scratch, last ? d_dst : d_scratch, ps.s0, ps.T,
+                               ps.table, sc, last ? n_dst : n);
+    }
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+
 // d_data (n = 2^log_n, in place).  Forward: serial_fft with omega; inverse: omega^-1 then scale by n^-1.
 static int ntt_inplace(zkhip_ctx* c, uint64_t* d_data, uint32_t log_n, int inverse, uint64_t* d_scratch) {
     const size_t n = (size_t)1 << log_n;
     if (log_n == 0) return ZKHIP_OK;
+    if (log_n >= 12) return ntt_big(c, d_data, n, nullptr, d_data, n, log_n, inverse, d_scratch);
     uint64_t* tw = nullptr;
     ZK_TRY(get_twiddles(c, log_n, inverse, &tw));
     const uint32_t tile = (uint32_t)std::min<size_t>(NTT_TILE, n);
@@ -118,6 +186,24 @@ extern "C" int zkhip_ntt(zkhip_ctx* c, uint64_t* d_data, uint32_t log_n, int inv
     return ntt_inplace(c, d_data, log_n, inverse, (uint64_t*)c->d_ws);
 }
 
+// Domain::fft / ifft as the reference calls them (domain.rs:108-118: clone, resize to the domain size with zeros, transform):
+// d_src holds n_src <= 2^log_n values, d_dst receives the 2^log_n results; d_src is not modified (d_dst == d_src is allowed
+// when n_src == 2^log_n).
+extern "C" int zkhip_domain_transform(zkhip_ctx* c, const uint64_t* d_src, size_t n_src, uint64_t* d_dst, uint32_t log_n, int inverse) {
+    if (!c || !d_dst || (n_src && !d_src)) return ZKHIP_ERR_ARG;
+    if (log_n > 30) return ZKHIP_ERR_SHAPE;
+    const size_t n = (size_t)1 << log_n;
+    if (n_src > n) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    ZK_TRY(c->reserve_ws(n * 32));
+    if (log_n >= 12) return ntt_big(c, d_src, n_src, nullptr, d_dst, n, log_n, inverse, (uint64_t*)c->d_ws);
+    if (d_dst != d_src) {
+        if (n_src < n) ZK_HIP(c, hipMemsetAsync(d_dst + 4 * n_src, 0, (n - n_src) * 32, c->stream));
+        if (n_src) ZK_HIP(c, hipMemcpyAsync(d_dst, d_src, n_src * 32, hipMemcpyDeviceToDevice, c->stream));
+    } else if (n_src != n) return ZKHIP_ERR_ARG;
+    return ntt_inplace(c, d_dst, log_n, inverse, (uint64_t*)c->d_ws);
+}
+
 extern "C" int zkhip_pointwise_mul(zkhip_ctx* c, const uint64_t* d_a, const uint64_t* d_b, size_t n, uint64_t* d_out) {
     if (!c || !d_a || !d_b || !d_out) return ZKHIP_ERR_ARG;
     ZK_TRY(c->activate());
@@ -140,6 +226,13 @@ extern "C" int zkhip_univariate_multiply(zkhip_ctx* c, const uint64_t* d_a, size
     uint64_t* scratch = (uint64_t*)c->d_ws;
     uint64_t* ea = scratch + 4 * n;
     uint64_t* eb = ea + 4 * n;
+    if (log_n >= 12) {
+        // three transforms and nothing else: the zero padding (resize, :73-74) happens in the forward transforms' gather, the
+        // evaluation-form product (:79-82) in the inverse transform's gather, the truncation (:85) in its last pass
+        ZK_TRY(ntt_big(c, d_a, na, nullptr, ea, n, log_n, 0, scratch));                              // domain.fft :76-77
+        ZK_TRY(ntt_big(c, d_b, nb, nullptr, eb, n, log_n, 0, scratch));
+        return ntt_big(c, ea, n, eb, d_out, unscaled, log_n, 1, scratch);                            // domain.ifft :84
+    }
     ZK_HIP(c, hipMemsetAsync(ea, 0, 2 * n * 32, c->stream));                                        // resize(.., F::ZERO) :73-74
     ZK_HIP(c, hipMemcpyAsync(ea, d_a, na * 32, hipMemcpyDeviceToDevice, c->stream));
     ZK_HIP(c, hipMemcpyAsync(eb, d_b, nb * 32, hipMemcpyDeviceToDevice, c->stream));

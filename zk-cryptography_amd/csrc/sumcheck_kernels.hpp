@@ -20,8 +20,18 @@ __device__ unsigned long long g_zk_stamps[64 * 8];
             g_zk_stamps[(round & 63) * 8 + (slot)] = _t;                                            \
         }                                                                                           \
     } while (0)
+// the same from any one thread, filed under an explicit row (the serial kernel: row = round, rows 40.. = per-kernel marks)
+#define ZK_STAMP_AT(tid, row, slot)                                                                 \
+    do {                                                                                            \
+        if (threadIdx.x == (tid)) {                                                                 \
+            unsigned long long _t;                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");              \
+            g_zk_stamps[((row) & 63) * 8 + (slot)] = _t;                                            \
+        }                                                                                           \
+    } while (0)
 #else
 #define ZK_STAMP(slot) do { } while (0)
+#define ZK_STAMP_AT(tid, row, slot) do { } while (0)
 #endif
 
 // Device-resident prover bookkeeping (one per context).

@@ -70,6 +70,7 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     }
     if (c->fork_ev) hipEventDestroy(c->fork_ev);
     if (c->join_ev) hipEventDestroy(c->join_ev);
+    if (c->serial_ev) hipEventDestroy(c->serial_ev);
     if (c->done_ev) hipEventDestroy(c->done_ev);
     if (c->fold_stream) hipStreamDestroy(c->fold_stream);
     if (c->d_coarse) hipFree(c->d_coarse);
@@ -149,6 +150,25 @@ extern "C" int zkhip_profile_read(zkhip_ctx* c, const char* kernel, double* tota
     if (total_ms) *total_ms = ms;
     if (launches) *launches = cnt;
     if (bytes) *bytes = by;
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_profile_timeline(zkhip_ctx* c, uint32_t max_records, char* names, double* start_us, double* stop_us,
+                                      uint32_t* count) {
+    if (!c || !names || !start_us || !stop_us || !count) return ZKHIP_ERR_ARG;
+    ZK_HIP(c, hipDeviceSynchronize());
+    uint32_t n = 0;
+    for (auto& r : c->prof_records) {
+        if (n == max_records) break;
+        float a = 0, b = 0;
+        ZK_HIP(c, hipEventElapsedTime(&a, c->prof_events[c->prof_records[0].event].start, c->prof_events[r.event].start));
+        ZK_HIP(c, hipEventElapsedTime(&b, c->prof_events[c->prof_records[0].event].start, c->prof_events[r.event].stop));
+        std::snprintf(names + 32 * (size_t)n, 32, "%s", r.name);
+        start_us[n] = 1e3 * a;
+        stop_us[n] = 1e3 * b;
+        ++n;
+    }
+    *count = n;
     return ZKHIP_OK;
 }
 
@@ -463,10 +483,11 @@ static int launch_small(zkhip_ctx* c, const SmallArgs& a, SumcheckDev* st, uint6
                         hipStream_t stream = nullptr) {
     if (!stream) stream = c->stream;
     if (a.log_n > (uint32_t)TREE_MAX_LOG || a.n_rounds > a.log_n) return ZKHIP_ERR_SHAPE;
-    const size_t lds = std::max(small_lds_bytes(a.log_n, a.weights_out ? (int)a.n_rounds : -1), min_lds);
+    const size_t lds = std::max(small_lds_bytes(a.log_n, a.weights_out ? (int)a.n_rounds : -1, a.group != 0 && a.stride == 0), min_lds);
+    if (lds > 160 * 1024) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->allow_big_lds((const void*)sumcheck_small_kernel, 160 * 1024));
     ProfScope ps(c, "sumcheck_small", 0.0, stream);
-    hipLaunchKernelGGL(sumcheck_small_kernel, dim3(1), dim3(MLE_BLOCK), lds, stream, a, st, d_rp, d_ch);
+    hipLaunchKernelGGL(sumcheck_small_kernel, dim3(1), dim3(SMALL_BLOCK), lds, stream, a, st, d_rp, d_ch);
     ZK_HIP(c, hipGetLastError());
     return ZKHIP_OK;
 }
@@ -482,7 +503,8 @@ static int launch_multifold(zkhip_ctx* c, hipStream_t stream, const uint64_t* cu
         // 6-variable fold of the overlapped plan 12 % slower than the 8-variable one
         const uint32_t waves = k >= 8 ? 4 : k == 7 ? 2 : 1;
         ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m, stream);
-        hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(64 * waves), ((size_t)32 << k) + 32 * (size_t)(waves - 1) * 64, stream, cur, m, k, d_w, dst, pdst);
+        hipLaunchKernelGGL((multifold_kernel<64, 4, true>), dim3((unsigned)(m / 64)), dim3(64 * waves), ((size_t)32 << k) + 32 * (size_t)(waves - 1) * 64,
+                           stream, cur, m, k, d_w, dst, pdst);
     } else {                  // few outputs left: 16 per workgroup, up to 64 lanes share one output
         out_per_wg = 16;
         uint32_t waves = 16;
@@ -497,14 +519,16 @@ static int launch_multifold(zkhip_ctx* c, hipStream_t stream, const uint64_t* cu
 // k-variable fold of a small table spread over the chip: partial tables P[y][m], y < *n_slices (blockfold_kernel)
 static int launch_blockfold(zkhip_ctx* c, hipStream_t stream, const uint64_t* in, uint32_t m, uint32_t k, const uint64_t* d_w,
                             uint64_t* d_partial, uint32_t* n_slices) {
-    const uint32_t log_ow = std::min<uint32_t>(log2_exact(m), 5);
-    const uint32_t sl_cnt = (uint32_t)MLE_BLOCK >> log_ow;
+    // OW outputs x (1024 / OW) term slices per workgroup; at least one term per slice
+    const uint32_t log_m = log2_exact(m);
+    const uint32_t log_ow = std::max<uint32_t>(std::min<uint32_t>(log_m, 5), k < 10 ? 10 - k : 0);
+    if (log_ow > log_m) return ZKHIP_ERR_SHAPE;
+    const uint32_t sl_cnt = (uint32_t)BF_BLOCK >> log_ow;
     const uint32_t terms = 1u << k;
-    if (terms < sl_cnt) return ZKHIP_ERR_SHAPE;
     const uint32_t per = std::min<uint32_t>(4, terms / sl_cnt);
     const uint32_t ny = terms / (per * sl_cnt);
     ProfScope ps(c, "blockfold", 32.0 * (double)m * terms, stream);
-    hipLaunchKernelGGL(blockfold_kernel, dim3(m >> log_ow, ny), dim3(MLE_BLOCK), 0, stream, in, m, log_ow, per, d_w, d_partial);
+    hipLaunchKernelGGL(blockfold_kernel, dim3(m >> log_ow, ny), dim3(BF_BLOCK), 0, stream, in, m, log_ow, per, d_w, d_partial);
     ZK_HIP(c, hipGetLastError());
     *n_slices = ny;
     return ZKHIP_OK;
@@ -519,7 +543,7 @@ static int launch_fine_sums(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uin
         hipLaunchKernelGGL(fine_sums_kernel, dim3((unsigned)((n_chunks + 7) / 8)), dim3(MLE_BLOCK), 0, c->stream, d_evals, n_chunks, first);
     }
     if (first != d_fine)
-        hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << lb), dim3(MLE_BLOCK), 0, c->stream, first, (uint32_t)(blk / FINE_CHUNK), d_fine);
+        hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << lb), dim3(MLE_BLOCK), 0, c->stream, first, (uint32_t)(blk / FINE_CHUNK), d_fine, (uint64_t*)nullptr);
     ZK_HIP(c, hipGetLastError());
     return ZKHIP_OK;
 }
@@ -539,8 +563,15 @@ extern "C" int zkhip_mle_block_sums(zkhip_ctx* c, const uint64_t* d_evals, size_
         // coarse sums at the granularity the prover's first rounds want (kept for it: zkhip_ctx::coarse), then the total
         const uint32_t k1 = overlapped_plan(n) && log_blocks == log2_exact(n) - 8 ? log_blocks - overlapped_k2(n) : 8;
         ZK_TRY(c->ensure_coarse());
-        hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, c->stream, d_out, 1u << (log_blocks - k1), (uint64_t*)c->d_coarse);
-        hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, (uint64_t*)c->d_coarse, 1u << k1, d_out + 4 * ((size_t)1 << log_blocks));
+        uint64_t* coarse_canon = (uint64_t*)c->d_coarse, *coarse_mont = coarse_canon + 4 * 1024;
+        {
+            ProfScope ps(c, "coarse_sums", 0.0);
+            hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, c->stream, d_out, 1u << (log_blocks - k1), coarse_mont, coarse_canon);
+        }
+        {
+            ProfScope ps(c, "total_sum", 0.0);
+            hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, coarse_mont, 1u << k1, d_out + 4 * ((size_t)1 << log_blocks), (uint64_t*)nullptr);
+        }
         c->coarse_of = d_out; c->coarse_n = n; c->coarse_k1 = k1;
     } else {
         const uint32_t chunk = (uint32_t)std::min<size_t>(m, 4096);
@@ -617,6 +648,7 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
     const uint64_t* parts = nullptr;   // partial sums of `cur`, `group` consecutive ones per block of this stage
     uint32_t n_parts = 0;
     bool done = false;
+    hipStream_t tail_stream = c->stream;      // where the last kernels of the proof run (the overlapped plan ends on its fold stream)
     if (overlap) {
         const uint32_t g = n_vars - 8, k2 = overlapped_k2(n), k1 = g - k2;
         ZK_TRY(c->ensure_fold_stream());
@@ -628,33 +660,40 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
             fine = d_fine;
         }
         if (!have_coarse)
-            hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, c->stream, fine, 1u << k2, (uint64_t*)c->d_coarse);
+            hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, c->stream, fine, 1u << k2, (uint64_t*)nullptr, (uint64_t*)c->d_coarse);
         c->coarse_of = nullptr;                     // d_coarse belongs to this call from here on
         SmallArgs a = {};
-        a.src = (const uint64_t*)c->d_coarse; a.group = 0; a.log_n = k1; a.n_rounds = k1; a.round0 = 0; a.first = first; a.claimed = claimed;
+        a.src = (const uint64_t*)c->d_coarse; a.group = 0; a.canon = 1; a.log_n = k1; a.n_rounds = k1; a.round0 = 0; a.first = first; a.claimed = claimed;
         a.d_claimed = d_claimed_sum; a.weights_out = d_w; a.final_out = nullptr;
         ZK_TRY(launch_small(c, a, st, d_rp, d_ch));
         first = 0;
         // fork: the big fold on the fold stream next to rounds k1+1 .. g.  The serial kernel of those rounds asks for
         // (nearly) a whole CU's LDS, so no fold workgroup shares its CU (beside 8+ fold waves per SIMD the transcript
         // wave ran at half speed)
-        ZK_HIP(c, hipEventRecord(c->fork_ev, c->stream));
-        ZK_HIP(c, hipStreamWaitEvent(c->fold_stream, c->fork_ev, 0));
+        // The fork comes BEHIND the small fold: the serial kernel (next in this queue) and the big fold (another queue, behind
+        // an event) then become ready together and the serial kernel's single workgroup is placed first.  Forked before
+        // the small fold, the big fold filled every CU first and the serial kernel waited for one to drain (~60 us).
         uint32_t ny = 0;
         ZK_TRY(launch_blockfold(c, c->stream, fine, 1u << k2, k1, d_w, d_p1, &ny));
+        ZK_HIP(c, hipEventRecord(c->fork_ev, c->stream));
+        ZK_HIP(c, hipStreamWaitEvent(c->fold_stream, c->fork_ev, 0));
         ZK_TRY(launch_multifold(c, c->fold_stream, d_evals, n, k1, d_w, tabA, partA, &n_parts));
-        ZK_HIP(c, hipEventRecord(c->join_ev, c->fold_stream));
         SmallArgs b = {};
-        b.src = d_p1; b.group = ny; b.stride = 1u << k2; b.log_n = k2; b.n_rounds = k2; b.round0 = k1; b.first = 0;
+        b.src = d_p1; b.group = ny; b.stride = 1u << k2; b.canon = 1; b.log_n = k2; b.n_rounds = k2; b.round0 = k1; b.first = 0;
         b.weights_out = d_w2; b.final_out = nullptr;
         ZK_TRY(launch_small(c, b, st, d_rp, d_ch, 156 * 1024));
-        ZK_HIP(c, hipStreamWaitEvent(c->stream, c->join_ev, 0));
+        // join ON THE FOLD STREAM: the serial kernel ends well before the big fold, so its event is long set when the fold
+        // ends and the last stage follows the fold in stream order (joining on the caller's stream left the chip idle for the
+        // ~13 us a cross-stream dependency takes to resolve); the proof is copied from there too
+        ZK_HIP(c, hipEventRecord(c->serial_ev, c->stream));
+        ZK_HIP(c, hipStreamWaitEvent(c->fold_stream, c->serial_ev, 0));
+        tail_stream = c->fold_stream;
         round = g;
-        ZK_TRY(launch_blockfold(c, c->stream, tabA, 256, k2, d_w2, d_p2, &ny));       // 2^(8 + k2) entries -> 2^8, the last 8 rounds
+        ZK_TRY(launch_blockfold(c, tail_stream, tabA, 256, k2, d_w2, d_p2, &ny));       // 2^(8 + k2) entries -> 2^8, the last 8 rounds
         SmallArgs t = {};
-        t.src = d_p2; t.group = ny; t.stride = 256; t.log_n = 8; t.n_rounds = 8; t.round0 = round; t.first = 0;
+        t.src = d_p2; t.group = ny; t.stride = 256; t.canon = 1; t.log_n = 8; t.n_rounds = 8; t.round0 = round; t.first = 0;
         t.weights_out = nullptr; t.final_out = d_fin;
-        ZK_TRY(launch_small(c, t, st, d_rp, d_ch));
+        ZK_TRY(launch_small(c, t, st, d_rp, d_ch, 0, tail_stream));
         done = true;
     }
     while (!done && stage_k(cn) != 0) {
@@ -700,8 +739,11 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
     const uint64_t* span = c->small_u64(ZK_SMALL_STATE);
     const size_t span_words = (size_t)(ZK_SMALL_ROUNDPOLYS - ZK_SMALL_STATE) + 8 * (size_t)n_vars;
     static_assert(ZK_PIN_END - ZK_PIN_PROOF >= (ZK_SMALL_ROUNDPOLYS - ZK_SMALL_STATE) + 8 * ZK_MAX_ROUNDS, "pinned proof area too small");
-    ZK_HIP(c, hipMemcpyAsync(pin, span, 8 * span_words, hipMemcpyDeviceToHost, c->stream));
-    ZK_TRY(c->wait_stream());
+    {
+        ProfScope ps(c, "proof_copy", 0.0, tail_stream);
+        ZK_HIP(c, hipMemcpyAsync(pin, span, 8 * span_words, hipMemcpyDeviceToHost, tail_stream));
+    }
+    ZK_TRY(c->wait_stream(tail_stream));
     std::memcpy(h_sum, pin + ((const uint64_t*)st->sum - span), 32);
     std::memcpy(h_round_polys, pin + (d_rp - span), 64 * (size_t)n_vars);
     std::memcpy(h_challenges, pin + (d_ch - span), 32 * (size_t)n_vars);

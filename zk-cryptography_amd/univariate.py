@@ -30,10 +30,11 @@ class Domain:
         t = _to_device(values)
         if t.shape[0] > self.size:
             raise AssertionError("more values than the domain holds")
-        buf = torch.zeros((self.size, 4), dtype=torch.int64, device=t.device)   # coeffs.resize(size, F::zero())
-        buf[: t.shape[0]] = t
+        buf = torch.empty((self.size, 4), dtype=torch.int64, device=t.device)
         ctx = N.Context.get(buf.device.index)
-        N.check(N.lib().zkhip_ntt(ctx.handle, N.ptr(buf), C.c_uint32(self.size.bit_length() - 1), C.c_int(inverse)), "ntt")
+        # coeffs.resize(size, F::zero()) happens inside the transform's first pass
+        N.check(N.lib().zkhip_domain_transform(ctx.handle, N.ptr(t), C.c_size_t(t.shape[0]), N.ptr(buf),
+                                               C.c_uint32(self.size.bit_length() - 1), C.c_int(inverse)), "domain_transform")
         return buf
 
     def fft(self, coeffs):
