@@ -83,8 +83,13 @@ int zkhip_fr_mul(const uint64_t *h_a, const uint64_t *h_b, uint64_t *h_out);
  * device (d_r, e.g. a challenge produced by the transcript); exactly one is non-NULL. */
 int zkhip_mle_partial_evaluation(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint64_t *h_r,
                                  const uint64_t *d_r, uint32_t var_index, uint64_t *d_out);
+/* Entries the call above writes: n/2, or 0 when 2^var_index >= n -- the reference's pair list is empty there
+ * (polynomial/src/utils.rs:37-50) and it returns an EMPTY table with n_vars - 1; the call then succeeds without touching d_out.
+ * (0 as well for the shapes the reference panics on.) */
+size_t zkhip_mle_partial_evaluation_len(size_t n, uint32_t var_index);
 /* MultilinearTrait::partial_evaluations (evaluation_form.rs:143-159): successive folds; d_out must hold
- * n >> n_pts elements.  h_pts: n_pts x 4. */
+ * n >> n_pts elements.  h_pts: n_pts x 4.  A LAST fold whose 2^index >= the current length leaves the reference's empty
+ * table (nothing is written); any fold after that is its panic -> ZKHIP_ERR_SHAPE. */
 int zkhip_mle_partial_evaluations(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint64_t *h_pts,
                                   const uint32_t *h_var_indices, size_t n_pts, uint64_t *d_out);
 /* MultilinearTrait::evaluation (evaluation_form.rs:162-175): h_out[4]. n_pts must equal log2(n). */

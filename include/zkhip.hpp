@@ -104,7 +104,8 @@ class Multilinear {
     Multilinear partial_evaluation(const Fr& eval_point, size_t variable_index) const {   // evaluation_form.rs:123-141
         if (n_ % 2 != 0) throw Panic("n must be even");                                     // utils.rs:30
         if (!(variable_index < n_ / 2)) throw Panic("variable_index must be less than n/2"); // utils.rs:31-34
-        Multilinear out(n_ / 2, n_vars - 1);
+        // 2^variable_index >= n: the reference's pair list is empty (utils.rs:37-50) -> an empty table with n_vars - 1
+        Multilinear out(zkhip_mle_partial_evaluation_len(n_, (uint32_t)variable_index), n_vars - 1);
         check(zkhip_mle_partial_evaluation(ctx(), device(), n_, eval_point.l, nullptr, (uint32_t)variable_index, out.dev_->u64()),
               "variable_index must be less than n/2");
         return out;

@@ -37,6 +37,22 @@ def test_kzg_1_commitment(zk, ora):   # multilinear_kzg.rs:133-148 data; commit 
     assert y == 0x0f5c8be5f27fc19eee337785e43d18414a8ff04995230f04509800252164cf47887a4a1864f18288652196af6272e7f6
 
 
+def test_commit_public_g1_multiples(zk, ora):
+    """commit([k], SRS) = k * (G * tau^0) = k G: the MSM path against the PUBLISHED compressed encodings of G, 2G, 3G
+    (tests/test_oracle_kats.py::PUBLIC_G1_MULTIPLES -- vectors from outside this repository), plain and table paths."""
+    from test_oracle_kats import PUBLIC_G1_MULTIPLES, g1_compress
+    srs = zk.UnivariateKZG.generate_srs(zk.Fr.from_int(7), 3)
+    table = zk.TrustedSetup(srs.powers_of_tau_in_g1, srs.inf).precompute()
+    for k, want in PUBLIC_G1_MULTIPLES.items():
+        for s in (srs, table):
+            com = zk.UnivariateKZG.commitment(zk.DenseUnivariatePolynomial(zk.Fr.from_ints([k])), s)
+            assert g1_compress(*com.coords()) == want
+    # and the device-generated SRS itself: tau = 2 -> G, 2G, 4G = 2(2G)
+    pts = zk.UnivariateKZG.generate_srs(zk.Fr.from_int(2), 1)
+    x, y = zk.G1Affine(pts.powers_of_tau_in_g1[1].cpu().numpy().view(np.uint64), False).coords()
+    assert g1_compress(x, y) == PUBLIC_G1_MULTIPLES[2]
+
+
 def test_kzg_2_commitment(zk, ora):   # multilinear_kzg.rs:151-197 data
     vals = [0, 0, 0, 2, 0, 0, 10, 12, 0, -12, 4, -6, 0, -12, 14, 4]
     tau = zk.Fr.from_ints([12, 9, 28, 40])

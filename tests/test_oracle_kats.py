@@ -334,6 +334,36 @@ def test_g1_group_law(ora):
         ora.g1_affine_ints(ora.g1_to_affine(a))
 
 
+# Published BLS12-381 G1 vectors: the compressed (ZCash format: 48-byte big-endian x, flag bits 0x80 compressed / 0x20 "y is the
+# larger root") encodings of G, 2G, 3G -- the public keys of the secret keys 1, 2, 3 in every BLS12-381 signature library's test
+# suite (Ethereum consensus specs, py_ecc, blst).  They pin the curve constants, the generator and the group law of the oracle
+# against values that were produced by neither this repository nor its survey.
+PUBLIC_G1_MULTIPLES = {
+    1: "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb",
+    2: "a572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e",
+    3: "89ece308f9d1f0131765212deca99697b112d61f9be9a5f1f3780a51335b3ff981747a0b2ca2179b96d2c0c9024e5224",
+}
+FQ_MODULUS = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+
+
+def g1_compress(x, y):
+    b = bytearray(x.to_bytes(48, "big"))
+    b[0] |= 0x80
+    if y > FQ_MODULUS - y:
+        b[0] |= 0x20
+    return bytes(b).hex()
+
+
+def test_g1_public_multiples_of_the_generator(ora):
+    g = ora.g1_generator()
+    acc = ora.g1_identity()
+    for k in (1, 2, 3):
+        acc = ora.g1_add(acc, g)                                        # repeated addition (mixed add, then doubling inside)
+        for point in (acc, ora.g1_mul_int(g, k)):                       # and double-and-add (mul_bigint)
+            x, y = ora.g1_affine_ints(ora.g1_to_affine(point))[:2]
+            assert g1_compress(x, y) == PUBLIC_G1_MULTIPLES[k]
+
+
 def test_multilinear_kzg_commit_identity(ora):
     # multilinear_kzg.rs:133-148 data: commit == p(tau) * G ; SURVEY 8c restatement vector (28 * G)
     vals = [0, 7, 0, 5, 0, 7, 4, 9]

@@ -204,7 +204,7 @@ extern "C" int zkhip_mle_partial_evaluation(zkhip_ctx* c, const uint64_t* d_eval
     if (!c || !d_evals || !d_out || (!h_r == !d_r)) return ZKHIP_ERR_ARG;
     if (!is_pow2(n) || n < 2) return ZKHIP_ERR_SHAPE;                 // utils.rs:30  (and Multilinear::new :16-20)
     if (!((size_t)var_index < n / 2)) return ZKHIP_ERR_SHAPE;          // utils.rs:31-34
-    if (var_index >= log2_exact(n)) return ZKHIP_ERR_SHAPE;            // reference would return an empty table
+    if (var_index >= log2_exact(n)) return ZKHIP_OK;                   // 2^k >= n: the pair list is empty (utils.rs:37-50), so is the table
     ZK_TRY(c->activate());
     return launch_fold(c, d_evals, n, d_r, h_r, var_index, d_out, false, nullptr, nullptr);
 }
@@ -256,7 +256,8 @@ static int fold_chain(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uin
     }
     for (size_t p = p0; p < n_pts; ++p) {
         const uint32_t k = var_indices ? var_indices[p] : 0;
-        if (cn < 2 || !((size_t)k < cn / 2) || k >= log2_exact(cn)) return ZKHIP_ERR_SHAPE;
+        if (cn < 2 || !((size_t)k < cn / 2)) return ZKHIP_ERR_SHAPE;
+        if (k >= log2_exact(cn)) return p + 1 == n_pts ? ZKHIP_OK : ZKHIP_ERR_SHAPE;   // empty table (utils.rs:37-50); a further fold of it panics
         const bool all_zero_tail = !var_indices || [&] {
             for (size_t q = p; q < n_pts; ++q) if (var_indices[q]) return false;
             return true;
@@ -277,6 +278,11 @@ static int fold_chain(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uin
         cn /= 2;
     }
     return ZKHIP_OK;
+}
+
+extern "C" size_t zkhip_mle_partial_evaluation_len(size_t n, uint32_t var_index) {
+    if (!is_pow2(n) || n < 2 || !((size_t)var_index < n / 2)) return 0;
+    return var_index >= log2_exact(n) ? 0 : n / 2;
 }
 
 extern "C" int zkhip_mle_partial_evaluations(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_pts,

@@ -58,10 +58,10 @@ class Multilinear:
         return torch.empty((n, 4), dtype=torch.int64, device=self.evaluations.device)
 
     @classmethod
-    def _wrap(cls, t):
+    def _wrap(cls, t, n_vars=None):
         m = cls.__new__(cls)
         m.evaluations = t
-        m.n_vars = t.shape[0].bit_length() - 1
+        m.n_vars = t.shape[0].bit_length() - 1 if n_vars is None else n_vars
         return m
 
     # -- MultilinearTrait ------------------------------------------------------------------
@@ -74,6 +74,9 @@ class Multilinear:
                                                   r.ctypes.data_as(C.c_void_p), None, C.c_uint32(variable_index),
                                                   N.ptr(out))
         N.check(st, "partial_evaluation")
+        if n >= 2 and (1 << variable_index) >= n:
+            # the reference's pair list is empty here (utils.rs:37-50): an EMPTY table with n_vars - 1 (struct literal, :137-140)
+            return Multilinear._wrap(out[:0], self.n_vars - 1)
         return Multilinear._wrap(out[: n // 2])
 
     def partial_evaluations(self, points, variable_indices):
