@@ -4,14 +4,20 @@
 Metric (BASELINE.json): field-evals/s of the sumcheck prover over a 24-variable multilinear
 (2^24 BLS12-381 Fr evaluations) per GPU.  A "step" is one full pass of the hot path over one
 table: Sumcheck::poly_sum + Sumcheck::prove (sumcheck/benches/sumcheck_benchmark.rs:13-22 minus
-the verifier) -- fused half-sums + fold kernels with the Fiat-Shamir transcript on the device --
+the verifier) -- block sums, k-variable folds and the Fiat-Shamir transcript on the device --
 with the table already resident in HBM.  value = (tables' entries consumed by all ranks) / time.
 
-Extra objects on the JSON line: `roofline` for the dominant kernel (the fused fold) from HIP
-events on the launch stream, and `cpu_baseline`: the CPU oracle (a C port of the reference
+Extra objects on the JSON line: `roofline` for the dominant kernel (the streaming k-variable fold) from HIP
+events on its launch stream, and `cpu_baseline`: the CPU oracle (a C port of the reference
 algorithm, single-threaded like the reference) timed on rank 0 at N=1 (plus the same port on all host cores at once).
-Informational objects that never enter `value`: `msm` (the second half of BASELINE's metric: KZG commit points/s with its own
-roofline and CPU baseline), `composed` (ComposedSumcheck::prove over sharded tables) and `gkr` (GKRProtocol::prove, replicas).
+Informational objects that never enter `value`: `fold` (the single-variable fold of SURVEY 8d's 48 n row, with its own
+roofline), `msm` (the second half of BASELINE's metric: KZG commit points/s with its roofline and CPU baselines), `ntt`
+(the 2^21-point transform and the 2^20 x 2^20 product), `composed` (ComposedSumcheck::prove over sharded tables) and
+`gkr` (GKRProtocol::prove, replicas).
+
+Synthetic inputs follow SURVEY 8d: uniform field elements from splitmix64-seeded xoshiro256** streams
+(zkhip_synthetic_fr): table t of rank g seed 0x5EED000000000001 + t + 16 g, commit scalars 0x5EED000000001001 + g, GKR inputs
+0x5EED000000002001 + g.
 """
 import argparse
 import json
@@ -23,6 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+VALU_PEAK = 1024 * 2.4e9 / 4.9   # wave-instructions per second: 1024 SIMDs, one v_mad_u64_u32 per 4.9 cycles (tools/ubench.hip)
+SEED_TABLE, SEED_SCALARS, SEED_GKR = 0x5EED000000000001, 0x5EED000000001001, 0x5EED000000002001
 
 
 class _HostStagedCollectives:
@@ -40,6 +48,11 @@ class _HostStagedCollectives:
     def all_reduce(self, t, op=None):
         h = t.cpu()
         self._d.all_reduce(h, op=op)
+        t.copy_(h)
+
+    def broadcast(self, t, src=0):
+        h = t.cpu()
+        self._d.broadcast(h, src=src)
         t.copy_(h)
 
     def barrier(self):
@@ -62,40 +75,148 @@ for _ in range(%d):
 print(time.perf_counter() - t)
 """
 
+_CHILD_MSM = """
+import sys, time
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import oracle as ora
+m = %d
+g = ora.g1_generator()
+jac = np.tile(g, (m, 1))                       # the naive commit's cost does not depend on which points it multiplies
+sc = ora.random_fr(m, 11)
+t = time.perf_counter()
+ora.kzg_commitment(sc, jac, True)
+print(time.perf_counter() - t)
+"""
 
-def cpu_all_cores(reps=2):
-    """The C oracle's poly_sum + prove on all host cores at once: one child process per core (children never touch the GPU)."""
+
+def _all_cores(child_src, work_per_child, unit, what):
+    """One oracle child process per host core at once (children never touch the GPU); value = total work / slowest child."""
     import subprocess
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     t0 = time.perf_counter()
-    kids = [subprocess.Popen([sys.executable, "-c", _CHILD % (ROOT, reps)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-            for _ in range(cores)]
+    kids = [subprocess.Popen([sys.executable, "-c", child_src], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(cores)]
     times = []
     for k in kids:
-        out, _ = k.communicate(timeout=240)
+        out, _ = k.communicate(timeout=300)
         if k.returncode != 0:
             raise RuntimeError("oracle child exited with %d" % k.returncode)
         times.append(float(out.decode().strip().splitlines()[-1]))
     slowest = max(times)
-    return {"value": round(cores * reps * (1 << 22) / slowest, 1), "unit": "field-evals/s", "cores": cores, "kind": "port",
-            "sample": "%d processes x %d runs of the same C port on a 2^22-entry table each, slowest process %.1f s (%.1f s with start-up)"
-                      % (cores, reps, slowest, time.perf_counter() - t0)}
+    return {"value": round(cores * work_per_child / slowest, 1), "unit": unit, "cores": cores, "kind": "port",
+            "sample": "%d processes x %s, slowest process %.1f s (%.1f s with start-up)" % (cores, what, slowest, time.perf_counter() - t0)}
+
+
+def _profile(N, ctx, name):
+    import ctypes as C
+    ms, cnt, by = C.c_double(), C.c_uint64(), C.c_double()
+    N.check(N.lib().zkhip_profile_read(ctx.handle, name, C.byref(ms), C.byref(cnt), C.byref(by)), "profile_read")
+    return ms.value, int(cnt.value), by.value
+
+
+def _synthetic(zk, torch, n, seed):
+    import numpy as np
+    return torch.from_numpy(zk.Fr.synthetic(n, seed).view(np.int64)).cuda()
+
+
+def _same_on_all_ranks(dist, torch, np, arr):
+    """every rank holds the bytes rank 0 holds?"""
+    mine = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1).view(np.int64).copy()).cuda()
+    ref = mine.clone()
+    dist.broadcast(ref, src=0)
+    ok = torch.tensor([1 if torch.equal(ref, mine) else 0], dtype=torch.int64, device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return bool(ok.item())
+
+
+def bench_fold(args, zk, N, poly, torch):
+    """MultilinearTrait::partial_evaluation (evaluation_form.rs:123-141) of the 2^log_n table at variable 0: SURVEY 8d's 48 n row."""
+    n = len(poly)
+    r = zk.Fr.synthetic(1, SEED_TABLE + 0x777)[0]
+    ctx = N.Context.get()
+    for _ in range(2):
+        poly.partial_evaluation(r, 0)
+    torch.cuda.synchronize()
+    reps = max(3, min(args.steps, 10))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        poly.partial_evaluation(r, 0)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    N.check(N.lib().zkhip_profile_enable(ctx.handle, 1), "profile_enable")
+    for _ in range(reps):
+        poly.partial_evaluation(r, 0)
+    ms, cnt, by = _profile(N, ctx, b"fold")
+    N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
+    ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"workload": "partial_evaluation of the 2^%d table at variable 0 (one product per output)" % args.log_n,
+            "value": round(n / wall, 1), "unit": "field-evals/s", "ms_per_fold": round(1e3 * wall, 4),
+            "roofline": {"bound": "hbm", "kernel": "fold_kernel<false>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "launches": cnt, "avg_launch_us": round(1e3 * ms / max(1, cnt), 2),
+                         "algorithmic_bytes_per_launch": "48 B x table entries (32 n read + 16 n written)"}}
+
+
+def bench_ntt(args, zk, N, torch):
+    """Domain::fft / ifft (domain.rs:108-118) at 2^21 points -- the transform size of a 2^20 x 2^20 product -- and
+    UnivariateEval::multiply (evaluation.rs:59-86).  Bound by field products, not HBM: both figures are reported."""
+    log_n = args.ntt_log_n
+    n = 1 << log_n
+    x = _synthetic(zk, torch, n, SEED_TABLE + 0x100)
+    d = zk.Domain(n)
+    ctx = N.Context.get()
+    out = {"workload": "Domain::fft / ifft at 2^%d points; UnivariateEval::multiply 2^%d x 2^%d coefficients" % (log_n, log_n - 1, log_n - 1)}
+    reps = max(3, min(args.steps, 10))
+    for name, fn in (("fft", lambda: d.fft(x)), ("ifft", lambda: d.ifft(x))):
+        fn(); fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        out["ms_per_" + name] = round(1e3 * (time.perf_counter() - t0) / reps, 4)
+    N.check(N.lib().zkhip_profile_enable(ctx.handle, 1), "profile_enable")
+    for _ in range(reps):
+        d.fft(x)
+    ms1, c1, b1 = _profile(N, ctx, b"ntt_first8")
+    ms2, c2, b2 = _profile(N, ctx, b"ntt_pass")
+    N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
+    kernel_ms = (ms1 + ms2) / max(1, c1)
+    ach = (b1 + b2) / ((ms1 + ms2) * 1e-3) / 1e9 if ms1 + ms2 > 0 else 0.0
+    butterflies = n / 2 * log_n
+    valu = butterflies * 380 / 64 / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
+    out["value"] = round(n / (out["ms_per_fft"] * 1e-3), 1)
+    out["unit"] = "points/s (forward transform)"
+    out["roofline"] = {"bound": "hbm", "kernel": "ntt_first8_kernel + ntt_pass_kernel (%d passes)" % (1 + c2 // max(1, c1)),
+                       "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                       "kernel_us_per_transform": round(1e3 * kernel_ms, 2),
+                       "algorithmic_bytes_per_launch": "64 B x points per pass (read + write) + 32 B per twiddle of the pass's table"}
+    out["roofline_alu"] = {"bound": "valu", "achieved": round(valu / 1e9, 1), "peak": round(VALU_PEAK / 1e9, 1),
+                           "unit": "G wave-instructions/s", "frac": round(valu / VALU_PEAK, 4),
+                           "ops_per_launch": "n/2 log2 n butterflies x 380 VALU instructions (one Montgomery product + add + sub; counted in the ISA)"}
+    a = zk.DenseUnivariatePolynomial(_synthetic(zk, torch, n // 2, SEED_TABLE + 0x101))
+    b = zk.DenseUnivariatePolynomial(_synthetic(zk, torch, n // 2, SEED_TABLE + 0x102))
+    zk.UnivariateEval.multiply(a, b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        zk.UnivariateEval.multiply(a, b)
+    torch.cuda.synchronize()
+    out["ms_per_multiply"] = round(1e3 * (time.perf_counter() - t0) / reps, 4)
+    return out
 
 
 def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
     """KZG commit (MultilinearKZG::commitment) on a 2^msm_log_n-point SRS per GPU, SRS + scalars resident."""
-    import ctypes as C
     log_n = args.msm_log_n
     n = 1 << log_n
-    tau = zk.Fr.random(log_n, 0x7A0 + rank)
+    tau = zk.Fr.synthetic(log_n, SEED_SCALARS + 0x100 + rank)
     srs = zk.TrustedSetup.setup(tau)                  # real SRS, generated on the device (not timed)
     plain_srs = zk.TrustedSetup(srs.powers_of_tau_in_g1, srs.inf)
     t_tab = time.perf_counter()
     srs.precompute()                                  # shifted-SRS table (depends on the SRS only; built once, not timed)
     torch.cuda.synchronize()
     t_tab = time.perf_counter() - t_tab
-    g = torch.Generator(device="cuda").manual_seed(0x5EED1001 + rank)
-    poly = zk.Multilinear(torch.randint(0, 2 ** 62, (n, 4), dtype=torch.int64, device="cuda", generator=g))
+    poly = zk.Multilinear(_synthetic(zk, torch, n, SEED_SCALARS + rank))
     steps = max(2, min(args.steps, 10))
     from zk_cryptography_amd import distributed as D
 
@@ -103,7 +224,7 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
         if world == 1:
             return zk.MultilinearKZG.commitment(poly, srs)
         # N > 1: this rank's (scalars, SRS) are one shard of a world * 2^log_n commit; partial commitments
-        # (104 B per rank) are all-gathered and summed on every rank
+        # (104 B per rank) are all-gathered on the device and summed on every rank
         def local():
             c = zk.MultilinearKZG.commitment(poly, srs)
             return c.xy, c.infinity
@@ -117,10 +238,27 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
         com = commit()
     barrier()
     dt = time.perf_counter() - t0
+    same = True
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        same = _same_on_all_ranks(dist, torch, np, np.concatenate([np.asarray(com[0], dtype=np.uint64), np.array([1 if com[1] else 0], dtype=np.uint64)]))
+        assert same, "rank %d: the sharded commitment differs from rank 0's" % rank
+    # the same commitments two in flight (zkhip_kzg_commit_begin / _end): the latency-bound reductions and the host epilogue
+    # of one commit hide behind the bucket accumulation of the next -- what a prover with several polynomials to commit sees
+    pipelined = None
+    if world == 1:
+        pend = [zk.MultilinearKZG.commitment_begin(poly, srs)]
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(steps):
+            pend.append(zk.MultilinearKZG.commitment_begin(poly, srs))
+            last = pend.pop(0).wait()
+        dt_pipe = time.perf_counter() - tp
+        assert pend.pop(0).wait() == com and last == com, "commitments in flight differ from the synchronous ones"
+        pipelined = {"value": round(float(n) * steps / dt_pipe, 1), "unit": "points/s", "ms_per_commit": round(1e3 * dt_pipe / steps, 3),
+                     "in_flight": 2, "note": "zkhip_kzg_commit_begin / _end: same commitments, issued back to back"}
     # the same commitments without the table (16 instead of 13 bucket additions per point, 16 bucket reductions)
     zk.MultilinearKZG.commitment(poly, plain_srs)
     torch.cuda.synchronize()
@@ -133,20 +271,23 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
     ctx = N.Context.get()
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 1), "profile_enable")
     zk.MultilinearKZG.commitment(poly, srs)
-    ms, cnt, by = C.c_double(), C.c_uint64(), C.c_double()
-    N.check(N.lib().zkhip_profile_read(ctx.handle, b"msm_accumulate", C.byref(ms), C.byref(cnt), C.byref(by)), "profile_read")
+    ms, cnt, by = _profile(N, ctx, b"msm_accumulate")
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
     out = {"metric": "MSM points/s (KZG commit, 2^%d-point SRS per GPU)" % log_n,
            "value": round(float(n) * world * steps / dt, 1), "unit": "points/s", "ms_per_commit": round(1e3 * dt / steps, 3),
            "steps": steps,
+           "sharding": ("(scalars, SRS) of one %d-point commit split over %d GPUs; one all-gather of %d partial commitments (104 B each, "
+                        "device to device over RCCL) per commit, summed on every rank" % (n * world, world, world)) if world > 1 else "single GPU",
+           "points_per_gpu": n, "exchanges_per_commit": 1 if world > 1 else 0, "commitment_replicated_on_all_ranks": same,
            "srs_table": {"bytes": int(srs._table.numel()), "build_ms": round(1e3 * t_tab, 1),
                          "note": "2^(20 w) * point for the 13 windows of a scalar; depends on the SRS only, built once, not timed"},
+           "pipelined": pipelined,
            "without_srs_table": {"value": round(float(n) * steps / dt_plain, 1), "unit": "points/s (this rank)",
                                  "ms_per_commit": round(1e3 * dt_plain / steps, 3)},
            "roofline": {"bound": "integer ALU (not HBM: ~10 Fq products of ~900 instructions per bucket addition)",
-                        "kernel": "msm_accumulate_kernel", "achieved": round(by.value / (ms.value * 1e-3) / 1e9, 2),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by.value / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                        "avg_launch_us": round(1e3 * ms.value, 1),
+                        "kernel": "msm_accumulate_kernel", "achieved": round(by / (ms * 1e-3) / 1e9, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "avg_launch_us": round(1e3 * ms, 1),
                         "algorithmic_bytes_per_launch": "128 B x points (96 B affine point + 32 B scalar)"}}
     # what actually bounds that kernel: issue of v_mad_u64_u32.  One bucket addition = 10 products in the 14 x 28-bit
     # representation = 4060 multiply-adds; a launch adds one point per non-zero digit (13 windows x points with the
@@ -154,13 +295,13 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
     # tools/ubench.hip (profiles/r01/ubench_alu_gfx950.txt).
     mads = 4060.0 * 13.0 * n * (1.0 - 2.0 ** -20)
     peak_tmads = 1024 * 64 / 4.9 * 2.4e9 / 1e12
-    out["roofline_alu"] = {"bound": "valu", "kernel": "msm_accumulate_kernel", "achieved": round(mads / (ms.value * 1e-3) / 1e12, 2),
+    out["roofline_alu"] = {"bound": "valu", "kernel": "msm_accumulate_kernel", "achieved": round(mads / (ms * 1e-3) / 1e12, 2),
                            "peak": round(peak_tmads, 2), "unit": "T v_mad_u64_u32 lane-ops/s",
-                           "frac": round(mads / (ms.value * 1e-3) / 1e12 / peak_tmads, 4),
+                           "frac": round(mads / (ms * 1e-3) / 1e12 / peak_tmads, 4),
                            "ops_per_launch": "4060 multiply-adds x 13 windows x points"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as ora
-        m = 1 << 15                                                     # bounded sample of the naive reference algorithm (~7 s)
+        m = 1 << 14                                                     # bounded sample of the naive reference algorithm (~3.5 s)
         pts = srs.powers_of_tau_in_g1[:m].cpu().numpy().view(np.uint64)
         inf = srs.inf[:m].cpu().numpy()
         jac = np.zeros((m, 18), dtype=np.uint64)
@@ -172,8 +313,27 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
         ora.kzg_commitment(sc, jac, True)
         cdt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": round(m / cdt, 1), "unit": "points/s", "cores": 1, "kind": "port",
-                               "sample": "C oracle's naive sum of mul_bigint (multilinear_kzg.rs:43-47) on the first 2^15 "
+                               "sample": "C oracle's naive sum of mul_bigint (multilinear_kzg.rs:43-47) on the first 2^14 "
                                          "points/scalars of the same input, %.1f s (cost is linear in points)" % cdt}
+        try:   # the same naive port on every host core at once
+            out["cpu_baseline"]["all_cores"] = _all_cores(_CHILD_MSM % (ROOT, 1 << 11), 1 << 11, "points/s",
+                                                          "the naive commit of 2^11 points each")
+        except Exception as e:
+            out["cpu_baseline"]["all_cores"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:   # for context only: what a CPU gets with the bucket method (not the reference's algorithm)
+            mp = 1 << 17
+            aff = np.zeros((mp, 13), dtype=np.uint64)
+            aff[:, :12] = srs.powers_of_tau_in_g1[:mp].cpu().numpy().view(np.uint64)
+            aff[:, 12] = srs.inf[:mp].cpu().numpy()
+            scp = poly.evaluations[:mp].cpu().numpy().view(np.uint64)
+            t1 = time.perf_counter()
+            ora.msm_pippenger(scp, aff)
+            pdt = time.perf_counter() - t1
+            out["cpu_baseline"]["cpu_pippenger_context"] = {
+                "value": round(mp / pdt, 1), "unit": "points/s", "cores": 1, "kind": "port",
+                "sample": "the oracle's bucket-method MSM (NOT the reference's algorithm) on the first 2^17 points, %.1f s" % pdt}
+        except Exception as e:
+            out["cpu_baseline"]["cpu_pippenger_context"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
@@ -183,15 +343,18 @@ def bench_composed(args, zk, N, rank, world, barrier, dist, torch, np):
     partial sums (96 B) all-gathered per round (zk_cryptography_amd.distributed.ShardedComposedSumcheck)."""
     from zk_cryptography_amd import distributed as D
     K, n = 2, 1 << args.composed_log_n
-    g = torch.Generator(device="cuda").manual_seed(0x5EED3001 + rank)
-    tables = [torch.randint(0, 2 ** 62, (n, 4), dtype=torch.int64, device="cuda", generator=g) for _ in range(K)]
+    tables = [_synthetic(zk, torch, n, SEED_TABLE + 16 * rank + 1 + k) for k in range(K)]
     poly = zk.ComposedMultilinear([zk.Multilinear(t) for t in tables])
+    exch = [0]
 
     def prove():
         if world == 1:
             proof, ch = zk.ComposedSumcheck(poly).prove()
             return proof.round_polys, ch
-        return D.ShardedComposedSumcheck(D.HipComposedEngine([tables], world, multi=False), world, None, dist).prove()
+        sh = D.ShardedComposedSumcheck(D.HipComposedEngine([tables], world, multi=False), world, None, dist)
+        res = sh.prove()
+        exch[0] = sh.exchanges
+        return res
 
     steps = max(2, min(args.steps, 10))
     for _ in range(2):
@@ -207,14 +370,11 @@ def bench_composed(args, zk, N, rank, world, barrier, dist, torch, np):
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        mine = torch.from_numpy(np.ascontiguousarray(ch[-1]).view(np.int64)).cuda()   # the last challenge depends on every round
-        lo, hi = mine.clone(), mine.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        same = bool(torch.equal(lo, hi))
+        same = _same_on_all_ranks(dist, torch, np, np.concatenate([np.asarray(rp, dtype=np.uint64).reshape(-1), np.asarray(ch, dtype=np.uint64).reshape(-1)]))
     return {"workload": "ComposedSumcheck::prove, product of %d tables, 2^%d entries per table per GPU" % (K, args.composed_log_n),
             "value": round(K * n * world * steps / dt, 1), "unit": "field-evals/s (table entries consumed)",
             "ms_per_prove": round(1e3 * dt / steps, 4), "rounds": int(len(ch)), "steps": steps,
+            "entries_per_table_per_gpu": n, "exchanges_per_prove": exch[0] if world > 1 else 0,
             "transcript_replicated_on_all_ranks": same,
             "sharding": "tables sharded by low index bits, one 96-byte record per rank all-gathered per round" if world > 1 else "single GPU"}
 
@@ -226,7 +386,7 @@ def bench_gkr(args, zk, rank, world, barrier, dist, torch, np):
            "replicas": world, "ms_per_proof": {}}
     for depth in (8, 20):
         circuit = zk.Circuit.random(depth)
-        ev = circuit.evaluation(zk.Fr.random(2 ** depth, 0x2001 + rank))
+        ev = circuit.evaluation(zk.Fr.synthetic(2 ** depth, SEED_GKR + rank))
         zk.GKRProtocol.prove(circuit, ev)
         barrier()
         reps = 5 if depth <= 8 else 3
@@ -255,14 +415,29 @@ def main():
     ap.add_argument("--composed-log-n", type=int, default=22, help="log2 of the per-GPU table size of the composed-sumcheck leg")
     ap.add_argument("--no-composed", action="store_true")
     ap.add_argument("--no-gkr", action="store_true")
+    ap.add_argument("--ntt-log-n", type=int, default=21, help="log2 of the transform size of the NTT leg")
+    ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--no-fold", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="diagnostic: run the sharded prover protocol even on one GPU")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        # plain `python bench.py --gpus N`: become the launcher (nothing has touched the GPU yet) -- one process per GPU
+        import subprocess
+        port = 29500 + os.getpid() % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d -- launch one rank per GPU (python -m torch.distributed.run --nproc-per-node %d "
+                 "bench.py --gpus %d ...)" % (args.gpus, world, args.gpus, args.gpus))
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # diagnostic: ZKHIP_BENCH_ONE_GPU=1 runs the N > 1 code path with every rank on GPU 0 and the exchange over gloo (RCCL
@@ -280,12 +455,11 @@ def main():
     from zk_cryptography_amd import _native as N
 
     n = 1 << args.log_n
-    g = torch.Generator(device="cuda").manual_seed(0x5EED + rank)
-    # synthetic random field elements: four limbs each < 2^62, i.e. uniform residues below 2^254 < r
-    table = torch.randint(0, 2 ** 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    table = _synthetic(zk, torch, n, SEED_TABLE + 16 * rank)      # uniform field elements
     poly = zk.Multilinear(table)
 
     from zk_cryptography_amd import distributed as D
+    exchanges = [0]
 
     def step():
         if world == 1 and not args.force_sharded:
@@ -294,70 +468,81 @@ def main():
             return sc.prove()
         # N > 1: ONE prover over the world * 2^log_n-entry table whose rank-interleaved shard is `table`
         # (stage form: one all-gather of 2^k partial block sums per k rounds over RCCL/xGMI + replicated transcript)
-        return D.ShardedSumcheck(D.HipSumcheckEngine(table), world, None, dist).prove()
+        sh = D.ShardedSumcheck(D.HipSumcheckEngine(table), world, None, dist)
+        res = sh.prove()
+        exchanges[0] = sh.exchanges
+        return res
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    res = None
     for _ in range(args.warmup):
-        step()
+        res = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        res = step()
     barrier()
     dt = time.perf_counter() - t0
+    transcript_same = True
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        s_, rp_, ch_ = res
+        transcript_same = _same_on_all_ranks(dist, torch, np, np.concatenate([np.asarray(s_, dtype=np.uint64).reshape(-1),
+                                                                                  np.asarray(rp_, dtype=np.uint64).reshape(-1),
+                                                                                  np.asarray(ch_, dtype=np.uint64).reshape(-1)]))
+        assert transcript_same, "rank %d: the sharded proof differs from rank 0's" % rank
 
     # ---- roofline of the dominant kernel: HIP events around every fold launch on the launch stream
     ctx = N.Context.get()
-    import ctypes as C
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 1), "profile_enable")
     prof_steps = max(1, min(args.steps, 5))
     for _ in range(prof_steps):
         step()
-    ms, cnt, by = C.c_double(), C.c_uint64(), C.c_double()
-    N.check(N.lib().zkhip_profile_read(ctx.handle, b"multifold", C.byref(ms), C.byref(cnt), C.byref(by)), "profile_read")
+    ms, cnt, by = _profile(N, ctx, b"multifold")
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
-    achieved = by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0
-    # HBM bytes of that launch from the PMC counters (separate rocprofv3 --pmc passes; profiles/r01/pmc_traffic.json)
-    traffic = None
+    achieved = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    # HBM bytes of that launch from the PMC counters: separate rocprofv3 --pmc passes of this command, committed under
+    # profiles/ (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); a file constant, labelled as such
+    traffic, traffic_source = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
-        if args.log_n == 24:
-            traffic = pmc["kernels"]["zk::multifold_kernel grid=262144"]["hbm_bytes_per_launch"]
+        src = os.path.join("profiles", "r02", "pmc_traffic.json")
+        pmc = json.load(open(os.path.join(ROOT, src)))
+        if args.log_n == 24 and world == 1:
+            traffic = pmc["multifold"]["hbm_bytes_per_launch"]
+            traffic_source = src + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not collected in this run)"
     except Exception:
         traffic = None
-    roofline = {"bound": "hbm", "kernel": "multifold_kernel<64> (8-variable fold of the 2^24 table + block sums of its output)",
+    roofline = {"bound": "hbm", "kernel": "multifold_kernel<64> (k-variable fold of the 2^%d table next to the serial rounds; k = 6 at 2^24 on one GPU)" % args.log_n,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "launches": int(cnt.value), "avg_launch_us": round(1e3 * ms.value / max(1, cnt.value), 2),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "launches": cnt, "avg_launch_us": round(1e3 * ms / max(1, cnt), 2),
                 "algorithmic_bytes_per_launch": "32 B x (table entries read + folded entries written), k variables per launch"}
 
+    def leg(skip, fn, *a):
+        if skip:
+            return None
+        try:
+            return fn(*a)
+        except Exception as e:   # reported, not hidden: the headline legs above are already measured
+            return {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # ---- the single-variable fold (48 n bytes), rank-local
+    fold = leg(args.no_fold, bench_fold, args, zk, N, poly, torch)
     # ---- second half of BASELINE's metric: MSM points/s of the KZG commit on a 2^20-point SRS per GPU
     msm = None
     if not args.no_msm:
         msm = bench_msm(args, zk, N, rank, world, barrier, dist, torch, np)
-
+    # ---- NTT / polynomial product (rank-local: replicas)
+    ntt = leg(args.no_ntt, bench_ntt, args, zk, N, torch)
     # ---- the composed prover (GKR's sumcheck shape) on sharded tables; informational, never part of `value`
-    composed = None
-    if not args.no_composed:
-        try:
-            composed = bench_composed(args, zk, N, rank, world, barrier, dist, torch, np)
-        except Exception as e:   # reported, not hidden: the headline legs above are already measured
-            composed = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    gkr = None
-    if not args.no_gkr:
-        try:
-            gkr = bench_gkr(args, zk, rank, world, barrier, dist, torch, np)
-        except Exception as e:
-            gkr = {"error": "%s: %s" % (type(e).__name__, e)}
+    composed = leg(args.no_composed, bench_composed, args, zk, N, rank, world, barrier, dist, torch, np)
+    gkr = leg(args.no_gkr, bench_gkr, args, zk, rank, world, barrier, dist, torch, np)
 
     # ---- CPU baseline: the oracle's single-threaded restatement of poly_sum + prove, rank 0 only.  Last: the all-cores leg
     # loads every host core, which would disturb the host-side share of the GPU legs above if it ran before them
@@ -379,7 +564,7 @@ def main():
         # the same port on every host core at once (the reference is single-threaded; this is the box's CPU ceiling for
         # independent provers): one child process per core, each proving its own 2^22-entry table
         try:
-            cpu["all_cores"] = cpu_all_cores()
+            cpu["all_cores"] = _all_cores(_CHILD % (ROOT, 2), 2 * (1 << 22), "field-evals/s", "2 runs of the same C port on a 2^22-entry table each")
         except Exception as e:
             cpu["all_cores"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -403,11 +588,17 @@ def main():
             "config": {"field": "BLS12-381 Fr (255-bit Montgomery, 8 x u32 limbs); G1 over Fq (381-bit)",
                        "workload": "24-var multilinear sumcheck prover (poly_sum + prove), BLS12-381 Fr" if args.log_n == 24
                        else "%d-var multilinear sumcheck prover" % args.log_n,
-                       "evals_per_gpu": n, "sharding": ("one %d-entry table sharded by low index bits over %d GPUs; per stage of k rounds one RCCL all-gather of the 2^k partial block sums, local k-variable fold, replicated transcript" % (n * world, world))
+                       "evals_per_gpu": n,
+                       "inputs": "uniform field elements, splitmix64-seeded xoshiro256** (SURVEY 8d), table seed 0x5EED000000000001 + 16 rank",
+                       "exchanges_per_prove": exchanges[0] if world > 1 else 0,
+                       "transcript_replicated_on_all_ranks": transcript_same,
+                       "sharding": ("one %d-entry table sharded by low index bits over %d GPUs; per stage of k rounds one RCCL all-gather of the 2^k partial block sums, local k-variable fold, replicated transcript" % (n * world, world))
                        if world > 1 else "single GPU"},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "fold": fold,
             "msm": msm,
+            "ntt": ntt,
             "composed": composed,
             "gkr": gkr,
         }

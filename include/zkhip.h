@@ -71,6 +71,9 @@ int zkhip_profile_timeline(zkhip_ctx *ctx, uint32_t max_records, char *names, do
                            uint32_t *count);
 
 /* ---- host-side Fr helpers (what `Fr::from(..)`, `into_bigint()` and the field operators are to a Rust caller) --- */
+/* Synthetic benchmark / test inputs: n field elements, uniform over Fr, from a splitmix64-seeded xoshiro256**
+ * stream (four draws = 256 bits LE, top bit masked, redrawn while >= r), in Montgomery form.  Deterministic per seed. */
+int zkhip_synthetic_fr(uint64_t seed, size_t n, uint64_t *h_out);
 int zkhip_fr_from_i64(int64_t v, uint64_t *h_out);                       /* Fr::from(v): Montgomery limbs of v mod r */
 int zkhip_fr_to_canonical(const uint64_t *h_in, uint64_t *h_out);         /* into_bigint(): canonical LE limbs */
 int zkhip_fr_add(const uint64_t *h_a, const uint64_t *h_b, uint64_t *h_out);
@@ -311,6 +314,18 @@ int zkhip_srs_precompute(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint
 int zkhip_kzg_commit_table(zkhip_ctx *ctx, const void *d_table, const uint8_t *d_points_inf, size_t n_points,
                            const uint64_t *d_scalars, size_t n_scalars, int require_equal_len, uint64_t *h_out_xy,
                            uint8_t *h_out_inf);
+/* The same commitments, in flight: begin enqueues everything (on a stream of the context's own, ordered behind the caller's
+ * stream) and returns a ticket; end waits for that commit, runs its host epilogue and delivers the result (all-NULL outputs
+ * abandon it).  Up to TWO commits may be in flight: a commit is a throughput-bound bucket accumulation followed by
+ * latency-bound reductions and a host epilogue, and back to back the latter hide behind the next commit's accumulation
+ * (the reference commits one polynomial at a time; a prover with several polynomials to commit -- plonk's wires, every round
+ * of an opening -- issues them this way).  Exactly one of d_points_xy / d_table (zkhip_srs_precompute) is given.  While a
+ * commit is in flight the context's workspace is lent (other entry points that need it return ZKHIP_ERR_BUSY), and so is a
+ * third begin, or a second one larger than the first. */
+int zkhip_kzg_commit_begin(zkhip_ctx *ctx, const uint64_t *d_points_xy, const void *d_table, const uint8_t *d_points_inf,
+                           size_t n_points, const uint64_t *d_scalars, size_t n_scalars, int require_equal_len,
+                           uint32_t *ticket);
+int zkhip_kzg_commit_end(zkhip_ctx *ctx, uint32_t ticket, uint64_t *h_out_xy, uint8_t *h_out_inf);
 /* Several independent commitments in one pass of every kernel: problem j commits d_scalars[h_offsets[j] .. h_offsets[j+1])
  * against d_points_xy[same range] (n_problems <= 64; no reference counterpart -- the reference commits one polynomial at
  * a time; MultilinearKZG::open uses this for its small rounds, and a caller that commits many short polynomials should

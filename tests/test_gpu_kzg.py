@@ -369,3 +369,31 @@ def test_commit_table_with_identity_points_and_short_polynomial(zk, ora):
     utab = zk.TrustedSetup(usrs.powers_of_tau_in_g1, usrs.inf).precompute()
     coeffs = zk.DenseUnivariatePolynomial(ora.random_fr(17, 5))     # shorter than the SRS: table stride != n_scalars
     assert zk.UnivariateKZG.commitment(coeffs, usrs) == zk.UnivariateKZG.commitment(coeffs, utab)
+
+
+# ---- commits in flight (zkhip_kzg_commit_begin / _end) ------------------------------------------------------------------
+@pytest.mark.parametrize("table", [False, True])
+def test_commits_in_flight_match_synchronous_commits(zk, ora, table):
+    from zk_cryptography_amd import _native as N
+    log_n = 14
+    srs = zk.TrustedSetup.setup(ora.random_fr(log_n, 880))
+    if table:
+        srs.precompute()
+    polys = [zk.Multilinear(ora.random_fr(1 << log_n, 890 + i)) for i in range(5)]
+    want = [zk.MultilinearKZG.commitment(p, srs) for p in polys]
+    got, pending = [], []
+    for p in polys:                       # depth-2 pipeline, as bench.py issues them
+        pending.append(zk.MultilinearKZG.commitment_begin(p, srs))
+        if len(pending) == 2:
+            got.append(pending.pop(0).wait())
+    got += [h.wait() for h in pending]
+    assert got == want
+    # two in flight: a third begin, and anything else that needs the workspace, is refused until one has ended
+    a, b = zk.MultilinearKZG.commitment_begin(polys[0], srs), zk.MultilinearKZG.commitment_begin(polys[1], srs)
+    with pytest.raises(N.ZkhipError, match="split-phase|lent"):
+        zk.MultilinearKZG.commitment_begin(polys[2], srs)
+    with pytest.raises(N.ZkhipError, match="split-phase|lent"):
+        zk.MultilinearKZG.commitment(polys[2], srs)
+    assert a.wait() == want[0]
+    del b                                  # an abandoned commitment is drained and its slot released
+    assert zk.MultilinearKZG.commitment(polys[2], srs) == want[2]

@@ -218,6 +218,11 @@ struct ComposedRun {
         const size_t work = fold ? cn / 4 : cn / 2;
         const int grid = mle_grid(work ? work : 1);
         uint32_t off = 0;
+        // every term with the same number of tables (<= 2 when one has an additive table): ONE launch, blockIdx.y = term
+        bool same_k = n_terms > 1;
+        for (uint32_t p = 1; p < n_terms; ++p) same_k = same_k && term_sizes[p] == term_sizes[0];
+        for (uint32_t p = 0; p < n_terms; ++p) if (lin_cur[p] && term_sizes[p] > 2) same_k = false;
+        MultiTablePtrs mp = {};
         for (uint32_t p = 0; p < n_terms; ++p) {
             TablePtrs tp = {};
             // ping-pong: folds happen in rounds 1, 2, ...; round r writes n >> r entries.  Odd rounds use the
@@ -232,13 +237,27 @@ struct ComposedRun {
                 char* base = ws + (size_t)meta.lin_tab[p] * per_table;
                 tp.lin_out = (uint64_t*)((round & 1) ? base : base + (n / 2 + 1) * 32);
             }
-            ProfScope ps(c, "composed_round", 0.0);
+            if (same_k) {
+                mp.t[p] = tp;
+                mp.rec_off[p] = meta.rec_off[p];
+            } else {
+                ProfScope ps(c, "composed_round", 0.0);
 #define CALL(KK) launch_round<KK>(c, fold, tp, cn, fold ? prev_challenge() : nullptr, meta.rec, meta.rec_off[p], d_partials, grid)
-            ZK_DISPATCH_K(term_sizes[p], CALL)
+                ZK_DISPATCH_K(term_sizes[p], CALL)
 #undef CALL
+            }
             if (fold) for (uint32_t q = 0; q < term_sizes[p]; ++q) cur[off + q] = tp.out[q];
             if (fold && lin_cur[p]) lin_cur[p] = tp.lin_out;
             off += term_sizes[p];
+        }
+        if (same_k) {
+            ProfScope ps(c, "composed_round", 0.0);
+            const uint64_t* rp = fold ? prev_challenge() : nullptr;
+#define CALL(KK)                                                                                                                                   \
+            if (fold) hipLaunchKernelGGL((composed_round_multi_kernel<KK, true>), dim3(grid, n_terms), dim3(MLE_BLOCK), 0, c->stream, mp, cn, rp, meta.rec, d_partials); \
+            else hipLaunchKernelGGL((composed_round_multi_kernel<KK, false>), dim3(grid, n_terms), dim3(MLE_BLOCK), 0, c->stream, mp, cn, rp, meta.rec, d_partials)
+            ZK_DISPATCH_K(term_sizes[0], CALL)
+#undef CALL
         }
         if (fold) cn /= 2;
         *n_records = grid;

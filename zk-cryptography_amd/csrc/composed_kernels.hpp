@@ -304,6 +304,71 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TableP
     }
 }
 
+// The same round for ALL terms of a multi-composed claim whose terms have the same number of tables (GKR: two terms of two
+// tables, one of them with an additive table): blockIdx.y is the term, so a round is one launch instead of one per term --
+// the rounds of a layer proof are launch-latency sized (13 us per launch at 2^20 entries and below).
+struct MultiTablePtrs {
+    TablePtrs t[CMP_MAX_TERMS];
+    uint32_t rec_off[CMP_MAX_TERMS];
+};
+template <int K, bool FOLD>
+static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_multi_kernel(MultiTablePtrs mp, size_t n, const uint64_t* __restrict__ r_ptr,
+                                                                          uint32_t rec, uint64_t* __restrict__ partials) {
+    __shared__ Fr red[MLE_BLOCK / 64];
+    const TablePtrs& tp = mp.t[blockIdx.y];
+    const uint32_t rec_off = mp.rec_off[blockIdx.y];
+    const bool lin = tp.lin_in != nullptr;
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    Fr sums[K + 1];
+#pragma unroll
+    for (int t = 0; t <= K; ++t) sums[t] = Fr::zero();
+    if (FOLD) {
+        const Fr r = load_fr(r_ptr, 0);
+        const size_t h = n >> 1, q = n >> 2;
+        if (q == 0) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) store_fr(tp.out[k], 0, fold_pair(load_fr(tp.in[k], 0), load_fr(tp.in[k], 1), r));
+                if (lin) store_fr(tp.lin_out, 0, fold_pair(load_fr(tp.lin_in, 0), load_fr(tp.lin_in, 1), r));
+            }
+        }
+        for (size_t j = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; j < q; j += stride) {
+            Fr lo[K], hi[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                Fr a0 = load_fr(tp.in[k], j), a1 = load_fr(tp.in[k], j + q);
+                Fr b0 = load_fr(tp.in[k], j + h), b1 = load_fr(tp.in[k], j + h + q);
+                lo[k] = fold_pair(a0, b0, r);
+                hi[k] = fold_pair(a1, b1, r);
+                store_fr(tp.out[k], j, lo[k]);
+                store_fr(tp.out[k], j + q, hi[k]);
+            }
+            accumulate_round_evals<K>(lo, hi, sums);
+            if (lin) {
+                const Fr llo = fold_pair(load_fr(tp.lin_in, j), load_fr(tp.lin_in, j + h), r);
+                const Fr lhi = fold_pair(load_fr(tp.lin_in, j + q), load_fr(tp.lin_in, j + h + q), r);
+                store_fr(tp.lin_out, j, llo);
+                store_fr(tp.lin_out, j + q, lhi);
+                accumulate_linear_evals<K>(llo, lhi, sums);
+            }
+        }
+    } else {
+        const size_t h = n >> 1;
+        for (size_t j = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; j < h; j += stride) {
+            Fr lo[K], hi[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { lo[k] = load_fr(tp.in[k], j); hi[k] = load_fr(tp.in[k], j + h); }
+            accumulate_round_evals<K>(lo, hi, sums);
+            if (lin) accumulate_linear_evals<K>(load_fr(tp.lin_in, j), load_fr(tp.lin_in, j + h), sums);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t <= K; ++t) {
+        Fr s = block_reduce_fr(sums[t], red);
+        if (threadIdx.x == 0) store_fr(partials, (size_t)blockIdx.x * rec + rec_off + t, s);
+    }
+}
+
 struct CloseArgs {
     ComposedMeta meta;
     ComposedDev* st;

@@ -107,7 +107,11 @@ struct zkhip_ctx {
         msm_pin_bytes[slot] = bytes;
         return ZKHIP_OK;
     }
-    bool ws_lent = false;       // the workspace currently backs a split-phase prover state
+    bool ws_lent = false;       // the workspace currently backs a split-phase prover state or commits in flight
+    // commits in flight (zkhip_kzg_commit_begin / _end): two slots, each with a region of the workspace, a side stream and a
+    // pinned result buffer of its own; `async_pend` is an MsmPending allocated by msm.hip
+    void* async_pend[2] = {nullptr, nullptr};
+    size_t async_region = 0;
     // one cached set of small split-phase buffers, so that a steady stream of sharded proves never allocates
     void* sc_small = nullptr; void* sc_stage = nullptr; size_t sc_stage_cap = 0; bool sc_lent = false;
     void* d_small = nullptr;    // fixed small scratch, layout above

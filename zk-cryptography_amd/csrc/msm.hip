@@ -128,7 +128,11 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     }
     const uint32_t term_chunks = (pl.ns + term_sel - 1) / term_sel;   // chunks of term 0 (the longest row)
     const size_t o_tparts = o_terms + al(n_out * 192);
-    const size_t o_ovf = o_tparts + al(wide_terms ? n_out * term_chunks * 256 : 0);
+    // rows / columns of the segment sums (msm_rowcol_kernel): per window R row sums of S, R of A, C column sums of S
+    const uint32_t lo_bits = pl.n_bits / 2;
+    const uint32_t rc_C = 1u << lo_bits, rc_R = pl.ns >> lo_bits;
+    (void)wide_terms; (void)term_chunks;
+    const size_t o_ovf = o_tparts + al((size_t)pl.n_windows * (2 * rc_R + rc_C) * 256);
     const size_t o_rec = o_ovf + al(sizeof(MsmOverflow));
     const size_t o_part = o_rec + al(MSM_HEAVY_LEVELS * rec_cap * sizeof(MsmHeavyRec));
     const size_t total = o_part + al(slots_cap * 256);
@@ -200,13 +204,17 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     }
     {
         ProfScope ps(c, "msm_terms", 0.0);
-        if (wide_terms) {
-            ZK_TRY(c->allow_big_lds((const void*)msm_terms_part_kernel, MSM_TERMS_LDS));
-            hipLaunchKernelGGL(msm_terms_part_kernel, dim3((unsigned)n_out, term_chunks), dim3(term_block), term_block == (uint32_t)MSM_BLOCK ? MSM_TERMS_LDS : term_block * 256, c->stream, segs, sega, pl, term_sel, tparts);
-            hipLaunchKernelGGL(msm_terms_final_kernel, dim3((unsigned)n_out), dim3(MSM_BLOCK), MSM_BLOCK * 256, c->stream, tparts, term_chunks, pl, term_sel, terms);
-        } else {
-            hipLaunchKernelGGL(msm_terms_kernel, dim3((unsigned)n_out), dim3(MSM_BLOCK), MSM_BLOCK * 256, c->stream, segs, sega, pl, terms);
-        }
+        uint32_t* row_s = tparts;
+        uint32_t* row_a = row_s + (size_t)pl.n_windows * rc_R * 64;
+        uint32_t* col_s = row_a + (size_t)pl.n_windows * rc_R * 64;
+        // one or two waves per tree, LDS sized to match: all trees of a commit are then resident at once (at 64 KiB per
+        // workgroup two shared a CU and the third waited: the new pass took as long as the old one)
+        const uint32_t rc_max = std::max(rc_R, rc_C);
+        const uint32_t tb = std::min<uint32_t>(128, std::max<uint32_t>(64, rc_max));
+        hipLaunchKernelGGL(msm_rowcol_kernel, dim3(pl.n_windows, 2 * rc_R + rc_C), dim3(tb), tb * 256, c->stream, segs, sega, pl, lo_bits,
+                           row_s, row_a, col_s);
+        hipLaunchKernelGGL(msm_rowcol_terms_kernel, dim3((unsigned)n_out), dim3(tb), tb * 256, c->stream, row_s, row_a, col_s, pl, lo_bits,
+                           terms);
     }
     ZK_HIP(c, hipGetLastError());
     ZK_TRY(c->reserve_msm_pin(slot, n_out * 192));
@@ -275,6 +283,72 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     if (n >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
     return msm_commit(c, d_points_xy, d_points_inf, d_scalars, n, h_out_xy, h_out_inf);
+}
+
+// ---------------------------------------------------------------------------------------
+// commits in flight: a commit is a throughput-bound accumulate pass followed by latency-bound reduction passes (chains of
+// ~25 us point additions on a mostly idle chip) and a host epilogue; a prover that commits several polynomials in a row
+// hides the latter behind the next commit's accumulate pass.  Two slots; same results as the synchronous calls.
+// ---------------------------------------------------------------------------------------
+extern "C" int zkhip_kzg_commit_begin(zkhip_ctx* c, const uint64_t* d_points_xy, const void* d_table, const uint8_t* d_points_inf,
+                                      size_t n_points, const uint64_t* d_scalars, size_t n_scalars, int require_equal_len,
+                                      uint32_t* ticket) {
+    if (!c || !ticket || (!d_points_xy == !d_table)) return ZKHIP_ERR_ARG;
+    if (require_equal_len && n_points != n_scalars) return ZKHIP_ERR_SHAPE;   // multilinear_kzg.rs:36-41
+    if (n_scalars > n_points) return ZKHIP_ERR_INDEX;                          // univariate_kzg.rs:53
+    const size_t n = n_scalars;
+    if (n == 0 || !d_scalars) return ZKHIP_ERR_ARG;                           // nothing to overlap: use the synchronous call
+    if (n >= ((size_t)1 << 31) || (d_table && n_points * MSM_TABLE_WINDOWS >= ((size_t)1 << 31))) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    int slot = -1;
+    for (int k = 0; k < 2; ++k) if (!c->async_pend[k]) { slot = k; break; }
+    if (slot < 0) return ZKHIP_ERR_BUSY;
+    const bool any = c->async_pend[0] || c->async_pend[1];
+    MsmProblems one = {};
+    one.n = 1;
+    one.off[1] = (uint32_t)n;
+    size_t used = 0;
+    ZK_TRY(msm_enqueue(c, nullptr, nullptr, nullptr, n, one, (const uint32_t*)d_table, n_points, 0, 0, nullptr, &used));
+    used = (used + 4095) & ~(size_t)4095;
+    if (!any) {
+        if (c->ws_lent) return ZKHIP_ERR_BUSY;
+        ZK_TRY(c->reserve_ws(2 * used));
+        c->async_region = std::max(used, c->ws_bytes / 2 & ~(size_t)4095);
+    } else if (used > c->async_region) {
+        return ZKHIP_ERR_BUSY;            // a larger commit than the one in flight: end that one first
+    }
+    ZK_TRY(c->ensure_side_streams());
+    MsmPending* pend = new (std::nothrow) MsmPending();
+    if (!pend) return ZKHIP_ERR_NOMEM;
+    hipStream_t const main_stream = c->stream;
+    int rc = ZKHIP_OK;
+    if (hipEventRecord(c->fork_ev, main_stream) != hipSuccess || hipStreamWaitEvent(c->side[slot], c->fork_ev, 0) != hipSuccess) rc = ZKHIP_ERR_HIP;
+    if (rc == ZKHIP_OK) {
+        const bool lent = c->ws_lent;
+        c->ws_lent = false;               // the reservation above covers both regions; msm_enqueue's own reserve is a no-op
+        c->stream = c->side[slot];
+        rc = msm_enqueue(c, d_points_xy, d_points_inf, d_scalars, n, one, (const uint32_t*)d_table, n_points, (size_t)slot * c->async_region, slot,
+                         pend, nullptr);
+        c->stream = main_stream;
+        c->ws_lent = lent;
+    }
+    if (rc != ZKHIP_OK) { delete pend; return rc; }
+    c->async_pend[slot] = pend;
+    c->ws_lent = true;                    // until the last commit in flight has ended
+    *ticket = (uint32_t)slot;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_kzg_commit_end(zkhip_ctx* c, uint32_t ticket, uint64_t* h_out_xy, uint8_t* h_out_inf) {
+    if (!c || ticket > 1 || !c->async_pend[ticket]) return ZKHIP_ERR_ARG;
+    MsmPending* pend = (MsmPending*)c->async_pend[ticket];
+    int rc = c->activate();
+    if (rc == ZKHIP_OK && h_out_xy && h_out_inf) rc = msm_finish(c, *pend, h_out_xy, h_out_inf);
+    else if (hipStreamSynchronize(c->side[ticket]) != hipSuccess) rc = ZKHIP_ERR_HIP;            // abandoned: just drain it
+    if (hipStreamWaitEvent(c->stream, c->msm_ev[ticket], 0) != hipSuccess && rc == ZKHIP_OK) rc = ZKHIP_ERR_HIP;   // workspace reuse stays ordered
+    delete pend;
+    c->async_pend[ticket] = nullptr;
+    if (!c->async_pend[0] && !c->async_pend[1]) c->ws_lent = false;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------

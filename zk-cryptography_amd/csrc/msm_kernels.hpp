@@ -463,6 +463,7 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_heavy_tree_kernel(const 
 static __global__ __launch_bounds__(MSM_BLOCK) void msm_segment_kernel(const uint32_t* __restrict__ buckets,
                                                                 uint32_t n_segments, uint32_t* __restrict__ seg_s,
                                                                 uint32_t* __restrict__ seg_a) {
+    __builtin_amdgcn_s_setprio(2);     // latency-bound chain: beside another commit's accumulate pass (commits in flight) it must win the issue slots
     const uint32_t s = blockIdx.x * MSM_BLOCK + threadIdx.x;
     if (s >= n_segments) return;
     G1XyzzU running = G1XyzzU::identity(), acc = G1XyzzU::identity();
@@ -501,6 +502,81 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_terms_kernel(const uint3
         }
         __syncthreads();
     }
+    if (threadIdx.x == 0) {
+        uint64_t* o = terms + 24 * (size_t)blockIdx.x;
+        store_fq(o, fqu_to_ark(acc.x));
+        store_fq(o + 6, fqu_to_ark(acc.y));
+        store_fq(o + 12, fqu_to_ark(acc.zz));
+        store_fq(o + 18, fqu_to_ark(acc.zzz));
+    }
+}
+
+// pass 6 by rows and columns: write the segment index as s = h C + l (C = 2^lo_bits columns, R = ns / C rows).  Then
+//     T_k = sum_{s: bit k} S_s  =  sum_{l: bit k} colS_l            (k < lo_bits),   colS_l = sum_h S_{h C + l}
+//                               =  sum_{h: bit k - lo_bits} rowS_h  (k >= lo_bits),  rowS_h = sum_l S_{h C + l}
+// and sum_s A_s = sum_h rowA_h: 3 ns additions in R + R + C independent workgroup trees, then n_terms trees over <= max(R, C)
+// values -- instead of ns (1 + n_bits / 2) additions in chains of a dozen and trees of 256 (the shared bucket set of the
+// table path: 2^16 segments, 0.56 ms of mostly idle chip).  Every addition is ~7 k instructions (~15 us on a lone wave), so
+// what counts is the depth: log2 C + log2 R tree levels.
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_rowcol_kernel(const uint32_t* __restrict__ seg_s, const uint32_t* __restrict__ seg_a,
+                                                                    MsmPlan pl, uint32_t lo_bits, uint32_t* __restrict__ row_s,
+                                                                    uint32_t* __restrict__ row_a, uint32_t* __restrict__ col_s) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
+    uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);   // blockDim.x x 64 u32
+    __builtin_amdgcn_s_setprio(2);
+    const uint32_t C = 1u << lo_bits, R = pl.ns >> lo_bits;
+    const uint32_t w = blockIdx.x, b = blockIdx.y;
+    const uint32_t* src;
+    uint32_t first, stride, count;
+    uint32_t* dst;
+    if (b < 2 * R) {                       // a row of S (b < R) or of A
+        const uint32_t h = b < R ? b : b - R;
+        src = (b < R ? seg_s : seg_a) + (size_t)w * pl.ns * 64;
+        first = h * C; stride = 1; count = C;
+        dst = (b < R ? row_s : row_a) + ((size_t)w * R + h) * 64;
+    } else {                               // a column of S
+        const uint32_t l = b - 2 * R;
+        src = seg_s + (size_t)w * pl.ns * 64;
+        first = l; stride = C; count = R;
+        dst = col_s + ((size_t)w * C + l) * 64;
+    }
+    G1XyzzU acc = G1XyzzU::identity();
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+        G1XyzzU v = load_xyzz_u(src, first + (size_t)i * stride);
+        g1u_add(acc, v);
+    }
+    uint32_t width = 1;
+    while (width < count && width < blockDim.x) width <<= 1;
+    msm_block_tree_sum(acc, width, lds);
+    if (threadIdx.x == 0) store_xyzz_u(dst, 0, acc);
+}
+// ... then one workgroup per (window, term); the result leaves in the arkworks layout (XYZZ, 4 x 48 B) for the host epilogue
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_rowcol_terms_kernel(const uint32_t* __restrict__ row_s, const uint32_t* __restrict__ row_a,
+                                                                          const uint32_t* __restrict__ col_s, MsmPlan pl, uint32_t lo_bits,
+                                                                          uint64_t* __restrict__ terms) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
+    uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);
+    __builtin_amdgcn_s_setprio(2);
+    const uint32_t C = 1u << lo_bits, R = pl.ns >> lo_bits;
+    const uint32_t w = blockIdx.x / pl.n_terms, t = blockIdx.x % pl.n_terms;
+    const uint32_t* src;
+    uint32_t count, bit = 0;
+    bool select = t != 0;
+    if (t == 0) { src = row_a + (size_t)w * R * 64; count = R; }
+    else if (t - 1 < lo_bits) { src = col_s + (size_t)w * C * 64; count = C; bit = t - 1; }
+    else { src = row_s + (size_t)w * R * 64; count = R; bit = t - 1 - lo_bits; }
+    G1XyzzU acc = G1XyzzU::identity();
+    // selected entries: every one (term 0), or those with `bit` set -- the j-th of them is j with a one inserted at `bit`
+    const uint32_t n_sel = select ? count >> 1 : count;
+    for (uint32_t j = threadIdx.x; j < n_sel; j += blockDim.x) {
+        uint32_t i = j;
+        if (select) i = ((j >> bit) << (bit + 1)) | (1u << bit) | (j & ((1u << bit) - 1));
+        G1XyzzU v = load_xyzz_u(src, i);
+        g1u_add(acc, v);
+    }
+    uint32_t width = 1;
+    while (width < n_sel && width < blockDim.x) width <<= 1;
+    msm_block_tree_sum(acc, width, lds);
     if (threadIdx.x == 0) {
         uint64_t* o = terms + 24 * (size_t)blockIdx.x;
         store_fq(o, fqu_to_ark(acc.x));

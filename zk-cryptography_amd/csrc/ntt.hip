@@ -273,3 +273,43 @@ extern "C" int zkhip_fr_to_canonical(const uint64_t* h_in, uint64_t* h_out) {
 ZK_FR_BINOP(zkhip_fr_add, fr_add)
 ZK_FR_BINOP(zkhip_fr_sub, fr_sub)
 ZK_FR_BINOP(zkhip_fr_mul, fr_mul)
+
+// Synthetic benchmark inputs: splitmix64-seeded xoshiro256**; an element is four draws taken as a 256-bit
+// little-endian integer with the top bit masked (255 bits), redrawn while >= r -- uniform over the field -- and handed out in
+// the Montgomery form the tables hold.  Host side, deterministic for a seed whatever the machine.
+extern "C" int zkhip_synthetic_fr(uint64_t seed, size_t n, uint64_t* h_out) {
+    if (!h_out && n) return ZKHIP_ERR_ARG;
+    uint64_t st[4];
+    uint64_t x = seed;
+    for (int i = 0; i < 4; ++i) {                      // splitmix64
+        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        st[i] = z ^ (z >> 31);
+    }
+    auto rotl = [](uint64_t v, int k) { return (v << k) | (v >> (64 - k)); };
+    auto next = [&]() {                                // xoshiro256**
+        const uint64_t r = rotl(st[1] * 5, 7) * 9, t = st[1] << 17;
+        st[2] ^= st[0]; st[3] ^= st[1]; st[1] ^= st[2]; st[0] ^= st[3];
+        st[2] ^= t; st[3] = rotl(st[3], 45);
+        return r;
+    };
+    zkhost::Fr r2;                                     // R^2 mod r: canonical -> Montgomery is one product with it
+    std::memcpy(r2.l, zkhost::FR_R2, 32);
+    for (size_t i = 0; i < n; ++i) {
+        zkhost::Fr c;
+        for (;;) {
+            for (int k = 0; k < 4; ++k) c.l[k] = next();
+            c.l[3] &= 0x7FFFFFFFFFFFFFFFull;
+            bool lt = false;                           // c < r ?
+            for (int k = 3; k >= 0; --k) {
+                if (c.l[k] != zkhost::FR_P[k]) { lt = c.l[k] < zkhost::FR_P[k]; break; }
+            }
+            if (lt) break;
+        }
+        const zkhost::Fr m = zkhost::fr_mul(c, r2);    // c * R^2 * R^-1 = c R
+        std::memcpy(h_out + 4 * i, m.l, 32);
+    }
+    return ZKHIP_OK;
+}
+

@@ -145,6 +145,7 @@ class ShardedSumcheck:
         n_local = e.local_len()
         total_rounds = (n_local * world).bit_length() - 1
         absorbed = False
+        self.exchanges = 0                 # collectives of this prove (what a multi-GPU run pays on top of the kernels)
         if getattr(e, "use_stages", True) and hasattr(e, "stage_plan"):
             # stage form: one exchange per k rounds (32 * 2^k bytes per rank), then one local k-variable fold
             while True:
@@ -155,6 +156,7 @@ class ShardedSumcheck:
                 e.stage_block_sums(mine)
                 gathered = e.new_buffer(world, 1 << k, 4)
                 _all_gather(self.dist, self.group, gathered, mine, world)      # C1: RCCL all-gather over xGMI
+                self.exchanges += 1
                 e.stage_absorb(gathered, world, None if absorbed else claimed_sum)
                 absorbed = True
                 e.stage_fold()
@@ -168,6 +170,7 @@ class ShardedSumcheck:
             while n_local * world > cap and n_local > 1:
                 e.local_half_sums(send)
                 _all_gather(self.dist, self.group, recv, send, world)
+                self.exchanges += 1
                 e.absorb(recv, world, None if absorbed else claimed_sum)       # local modular add + transcript -> challenge
                 absorbed = True
                 e.fold()                                                        # local: partners share the low index bits
@@ -178,6 +181,7 @@ class ShardedSumcheck:
             e.local_table(mine)
             gathered = e.new_buffer(world, n_local, 4)
             _all_gather(self.dist, self.group, gathered, mine, world)
+            self.exchanges += 1
             full = gathered.transpose(0, 1).contiguous().view(n_local * world, 4)   # entry j*world + g <- rank g, local j
             e.tail(full, n_local * world, None if absorbed else claimed_sum)
         return e.finish(total_rounds)
@@ -298,6 +302,7 @@ class ShardedComposedSumcheck:
         e, world = self.e, self.world
         n_local = e.local_len()
         total_rounds = (n_local * world).bit_length() - 1
+        self.exchanges = 0
         cap = e.tail_capacity()
         rec = e.record_len()
         if n_local * world > cap and n_local > 1:
@@ -306,6 +311,7 @@ class ShardedComposedSumcheck:
             while n_local * world > cap and n_local > 1:
                 e.round_sums(send)                                            # fold at the previous challenge + partial sums
                 _all_gather(self.dist, self.group, recv, send, world)         # RCCL all-gather over xGMI, <= 768 B per rank
+                self.exchanges += 1
                 e.absorb(recv, world)                                         # local modular add + transcript -> challenge
                 n_local //= 2
         if n_local * world > 1:
@@ -314,25 +320,38 @@ class ShardedComposedSumcheck:
             e.local_tables(mine)
             gathered = e.new_buffer(world, nt, n_local, 4)
             _all_gather(self.dist, self.group, gathered, mine, world)
+            self.exchanges += 1
             full = gathered.permute(1, 2, 0, 3).contiguous()                  # entry j*world + g <- rank g, local j
             e.tail(full.view(nt, n_local * world, 4), n_local * world)
         return e.finish(total_rounds)
+
+
+_COMMIT_BUFS = {}
 
 
 def sharded_commit(local_commit, sum_affine, world=1, group=None, dist=None, device=None):
     """KZG commit over (scalars, SRS) sharded across ranks.
 
     local_commit() -> (xy uint64[12], inf bool): this rank's sub-MSM;  sum_affine(xy [world,12], inf [world]) ->
-    (xy, inf): group sum of the partial commitments.  Returns the full commitment on every rank."""
+    (xy, inf): group sum of the partial commitments.  Returns the full commitment on every rank.  The 104-byte records
+    travel device to device (one pinned staging copy in, one all-gather, one copy out; the buffers are kept)."""
     import torch
     xy, inf = local_commit()
-    rec = torch.zeros(13, dtype=torch.int64, device=device)
-    rec[:12] = torch.from_numpy(np.ascontiguousarray(xy, dtype=np.uint64).view(np.int64)).to(rec.device)
-    rec[12] = 1 if inf else 0
-    out = torch.empty((world, 13), dtype=torch.int64, device=rec.device)
+    key = (str(device), world)
+    bufs = _COMMIT_BUFS.get(key)
+    if bufs is None:
+        pin = torch.empty(13, dtype=torch.int64)
+        if device is not None and str(device).startswith("cuda"):
+            pin = pin.pin_memory()
+        bufs = _COMMIT_BUFS[key] = (pin, torch.empty(13, dtype=torch.int64, device=device), torch.empty((world, 13), dtype=torch.int64, device=device))
+    pin, rec, out = bufs
+    h = pin.numpy()
+    h[:12] = np.ascontiguousarray(xy, dtype=np.uint64).view(np.int64)
+    h[12] = 1 if inf else 0
+    rec.copy_(pin, non_blocking=True)
     _all_gather(dist, group, out, rec, world)                            # C2: 104 bytes per rank
-    h = out.cpu().numpy().view(np.uint64)
-    return sum_affine(np.ascontiguousarray(h[:, :12]), np.ascontiguousarray(h[:, 12].astype(np.uint8)))
+    g = out.cpu().numpy().view(np.uint64)
+    return sum_affine(np.ascontiguousarray(g[:, :12]), np.ascontiguousarray(g[:, 12].astype(np.uint8)))
 
 
 def hip_sum_affine(xy, inf):

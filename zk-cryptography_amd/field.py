@@ -39,3 +39,15 @@ class Fr:
         a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
         a[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
         return a
+
+    @staticmethod
+    def synthetic(n, seed):
+        """SURVEY 8d's synthetic inputs: n uniform field elements from the splitmix64-seeded xoshiro256** stream of `seed`
+        (zkhip_synthetic_fr; e.g. table t: 0x5EED000000000001 + t, commit scalars: 0x5EED000000001001, GKR inputs: ...2001)
+        -> uint64 [n, 4] Montgomery limbs"""
+        import ctypes as C
+        from zk_cryptography_amd import _native as N
+        out = np.empty((n, 4), dtype=np.uint64)
+        N.check(N.lib().zkhip_synthetic_fr(C.c_uint64(seed), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)), "synthetic_fr")
+        return out
+

@@ -152,6 +152,40 @@ def _commit(points, inf, n_points, scalars, n_scalars, require_equal_len, table=
     return G1Affine(out, oinf.value)
 
 
+class PendingCommitment:
+    """A commitment in flight (zkhip_kzg_commit_begin / _end): wait() delivers the G1Affine the synchronous call returns."""
+
+    def __init__(self, ctx, ticket, keep):
+        self._ctx, self._ticket, self._keep = ctx, ticket, keep     # `keep`: the tensors the kernels still read
+
+    def wait(self):
+        if self._ticket is None:
+            raise RuntimeError("commitment already collected")
+        out = np.empty(12, dtype=np.uint64)
+        oinf = C.c_uint8(0)
+        t, self._ticket = self._ticket, None
+        N.check(N.lib().zkhip_kzg_commit_end(self._ctx.handle, C.c_uint32(t), out.ctypes.data_as(C.c_void_p), C.byref(oinf)), "commit_end")
+        self._keep = None
+        return G1Affine(out, oinf.value)
+
+    def __del__(self):
+        if getattr(self, "_ticket", None) is not None:
+            try:
+                N.lib().zkhip_kzg_commit_end(self._ctx.handle, C.c_uint32(self._ticket), None, None)
+            except Exception:
+                pass
+
+
+def _commit_begin(points, inf, n_points, scalars, n_scalars, require_equal_len, table=None):
+    ctx = N.Context.get(points.device.index)
+    ticket = C.c_uint32(0)
+    st = N.lib().zkhip_kzg_commit_begin(ctx.handle, None if table is not None else N.ptr(points), N.ptr(table) if table is not None else None,
+                                        N.ptr(inf), C.c_size_t(n_points), N.ptr(scalars), C.c_size_t(n_scalars),
+                                        C.c_int(1 if require_equal_len else 0), C.byref(ticket))
+    N.check(st, "The length of powers_of_tau_in_g1 and the length of the evaluations of the polynomial should tally!")
+    return PendingCommitment(ctx, ticket.value, (points, inf, scalars, table))
+
+
 def commit_batch(points, inf, scalars, offsets):
     """zkhip_kzg_commit_batch: commitments of the slices [offsets[j], offsets[j+1]) of (points, scalars), one pass"""
     nprob = len(offsets) - 1
@@ -178,6 +212,12 @@ class MultilinearKZG:
         """MultilinearKZGInterface::commitment (multilinear_kzg.rs:33-48)"""
         assert isinstance(poly, Multilinear)
         return _commit(srs.powers_of_tau_in_g1, srs.inf, len(srs), poly.evaluations, len(poly), True, getattr(srs, "_table", None))
+
+    @staticmethod
+    def commitment_begin(poly, srs):
+        """The same commitment, in flight: -> PendingCommitment (at most two at a time); .wait() yields the G1Affine."""
+        assert isinstance(poly, Multilinear)
+        return _commit_begin(srs.powers_of_tau_in_g1, srs.inf, len(srs), poly.evaluations, len(poly), True, getattr(srs, "_table", None))
 
     @staticmethod
     def open(poly, evaluation_points, srs, cache_folded_srs=True):
