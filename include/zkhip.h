@@ -187,6 +187,16 @@ int zkhip_sumcheck_prove(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, cons
                          const uint64_t *d_claimed_sum, const uint64_t *d_block_sums, uint32_t log_blocks, uint64_t *h_sum,
                          uint64_t *h_round_polys, uint64_t *h_challenges);
 
+/* Sumcheck::prove in flight: begin enqueues the whole proof (same inputs as zkhip_sumcheck_prove) and returns a ticket, end
+ * waits for that proof and delivers the same outputs (all-NULL outputs abandon it).  Up to two proofs may be in flight; they
+ * execute in stream order on the device -- what the pair removes is the idle time between a proof's last kernel and the next
+ * proof's first one (host wake-up, return to the caller, the next call's first launch: ~10 % of a 2^24 proof).  While a
+ * proof is in flight zkhip_sumcheck_prove returns ZKHIP_ERR_BUSY (the result slots are taken); zkhip_mle_block_sums for the
+ * next table may be called (it is ordered behind the proof). */
+int zkhip_sumcheck_prove_begin(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint64_t *h_claimed_sum,
+                               const uint64_t *d_claimed_sum, const uint64_t *d_block_sums, uint32_t log_blocks, uint32_t *ticket);
+int zkhip_sumcheck_prove_end(zkhip_ctx *ctx, uint32_t ticket, uint64_t *h_sum, uint64_t *h_round_polys, uint64_t *h_challenges);
+
 /* ---- the same prover, split per phase, for a table SHARDED over several GPUs ---------------------
  * The N = n_local * world entries are partitioned by their low index bits: rank g holds entry i = j*world + g
  * at local index j.  Rounds fold variable 0 (the most significant index bit), so every fold is local; per

@@ -88,3 +88,30 @@ def test_prove_2_24_self_consistency(zk, ora):
         h = hashlib.sha256(d)
         claim = (p0 + r * (p1 - p0)) % R
     assert zk.Fr.to_ints(poly.evaluation(ch)) == [claim]
+
+
+def test_proofs_in_flight_match_synchronous_proofs(zk, ora):
+    """zkhip_sumcheck_prove_begin / _end: two proofs in flight, different tables and sizes, each equal to the oracle's."""
+    from zk_cryptography_amd import _native as N
+    tables = [ora.random_fr(1 << log_n, 5100 + log_n) for log_n in (20, 12, 21, 3, 19)]
+    want = [ora.sumcheck_prove(t) for t in tables]
+    got, pending = [], []
+    for t in tables:
+        sc = zk.Sumcheck(zk.Multilinear(t))
+        sc.poly_sum()
+        pending.append(sc.prove_begin())
+        if len(pending) == 2:
+            got.append(pending.pop(0).wait())
+    got += [h.wait() for h in pending]
+    for (proof, ch), (s, rp, och) in zip(got, want):
+        assert np.array_equal(proof.sum, s) and np.array_equal(proof.univariate_poly, rp) and np.array_equal(ch, och)
+    # a third proof in flight and a synchronous prove are refused while two are pending
+    scs = [zk.Sumcheck(zk.Multilinear(t)) for t in tables[:3]]
+    a, b = scs[0].prove_begin(), scs[1].prove_begin()
+    with pytest.raises(N.ZkhipError):
+        scs[2].prove_begin()
+    with pytest.raises(N.ZkhipError):
+        scs[2].prove()
+    a.wait()
+    del b
+    scs[2].prove()

@@ -7,7 +7,7 @@ for l in sys.stdin:
         continue
     d = json.loads(l)
     g = lambda o, *ks: (g(o.get(ks[0]), *ks[1:]) if len(ks) > 1 else o.get(ks[0])) if isinstance(o, dict) else None
-    print("n_gpus", d["n_gpus"], "ms_per_step", d["ms_per_step"], "value %.3e" % d["value"], "| multifold", g(d, "roofline", "avg_launch_us"), "us frac", g(d, "roofline", "frac"),
+    print("n_gpus", d["n_gpus"], "ms_per_step", d["ms_per_step"], "pipelined", g(d, "pipelined", "ms_per_step"), "value %.3e" % d["value"], "| multifold", g(d, "roofline", "avg_launch_us"), "us frac", g(d, "roofline", "frac"),
           "traffic", g(d, "roofline", "traffic"))
     for k in ("fold", "msm", "ntt", "composed", "gkr", "cpu_baseline"):
         v = d.get(k)

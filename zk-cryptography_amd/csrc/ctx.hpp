@@ -152,6 +152,27 @@ struct zkhip_ctx {
         if (e != hipSuccess) { last_hip = (int)e; return ZKHIP_ERR_HIP; }
         return ZKHIP_OK;
     }
+    int wait_event(hipEvent_t ev) {      // the same for an event already recorded
+        for (int spin = 0; spin < 200000; ++spin) {
+            const hipError_t e = hipEventQuery(ev);
+            if (e == hipSuccess) return ZKHIP_OK;
+            if (e != hipErrorNotReady) { last_hip = (int)e; return ZKHIP_ERR_HIP; }
+        }
+        const hipError_t e = hipEventSynchronize(ev);
+        if (e != hipSuccess) { last_hip = (int)e; return ZKHIP_ERR_HIP; }
+        return ZKHIP_OK;
+    }
+    // result slots of the basic prover: pinned copies of [state .. round polynomials] + the event their copy completes at;
+    // proof_pending[k] = n_vars of the proof in flight in slot k (0: free)
+    void* proof_pin[2] = {nullptr, nullptr};
+    hipEvent_t proof_ev[2] = {nullptr, nullptr};
+    uint32_t proof_pending[2] = {0, 0};
+    int ensure_proof_slot(int k) {
+        if (!proof_ev[k] && hipEventCreateWithFlags(&proof_ev[k], hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
+        if (!proof_pin[k] && hipHostMalloc(&proof_pin[k], ((ZK_SMALL_ROUNDPOLYS - ZK_SMALL_STATE) + 8 * ZK_MAX_ROUNDS) * 8, hipHostMallocDefault) != hipSuccess)
+            return ZKHIP_ERR_NOMEM;
+        return ZKHIP_OK;
+    }
     uint64_t* small_u64(size_t off) { return (uint64_t*)d_small + off; }
     uint64_t* pinned_u64(size_t off) { return (uint64_t*)h_pinned + off; }
     // grow-only workspace; growth synchronises (never inside a steady-state timed loop)

@@ -29,7 +29,7 @@
 namespace zk {
 
 constexpr int MSM_BLOCK = 256;
-constexpr int MSM_SEG_LOG = 3;              // L = 8 buckets per segment (L = 4 measured slower: twice the lanes, longer term sums)
+constexpr int MSM_SEG_LOG = 3;              // L = 8 buckets per segment (L = 4 measured again with the row / column term sums: segment pass 0.30 instead of 0.33 ms, term sums 0.74 instead of 0.47 ms)
 constexpr int MSM_SEG = 1 << MSM_SEG_LOG;
 constexpr int MSM_MAX_WINDOWS = 64;
 

@@ -72,6 +72,7 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     if (c->join_ev) hipEventDestroy(c->join_ev);
     if (c->serial_ev) hipEventDestroy(c->serial_ev);
     if (c->done_ev) hipEventDestroy(c->done_ev);
+    for (int k = 0; k < 2; ++k) { if (c->proof_ev[k]) hipEventDestroy(c->proof_ev[k]); if (c->proof_pin[k]) hipHostFree(c->proof_pin[k]); }
     if (c->fold_stream) hipStreamDestroy(c->fold_stream);
     if (c->d_coarse) hipFree(c->d_coarse);
     if (c->d_small) hipFree(c->d_small);
@@ -603,23 +604,13 @@ extern "C" int zkhip_mle_block_sums(zkhip_ctx* c, const uint64_t* d_evals, size_
     return ZKHIP_OK;
 }
 
-extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_claimed_sum,
-                                    const uint64_t* d_claimed_sum, const uint64_t* d_block_sums, uint32_t log_blocks,
-                                    uint64_t* h_sum,
-                                    uint64_t* h_round_polys, uint64_t* h_challenges) {
-    if (!c || !d_evals || !h_sum) return ZKHIP_ERR_ARG;
-    if (!is_pow2(n)) return ZKHIP_ERR_SHAPE;   // Multilinear::new evaluation_form.rs:16-20
+// The prover in two halves: sumcheck_enqueue launches every kernel and the copy of the proof into pinned slot `slot`,
+// sumcheck_collect waits for that copy (polling its event) and hands the proof out.  A caller with several tables to prove
+// begins the next proof before it collects the previous one (zkhip_sumcheck_prove_begin / _end): the kernels of successive
+// proofs run in stream order, what disappears is the idle time between them (host wake-up, return, next call's first launch).
+static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_claimed_sum,
+                            const uint64_t* d_claimed_sum, const uint64_t* d_block_sums, uint32_t log_blocks, int slot) {
     const uint32_t n_vars = log2_exact(n);
-    if (n_vars > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
-    if (n_vars && (!h_round_polys || !h_challenges)) return ZKHIP_ERR_ARG;
-    ZK_TRY(c->activate());
-    if (n == 1) {   // no rounds: nothing is proven; report the sum the transcript would have absorbed
-        if (h_claimed_sum) { std::memcpy(h_sum, h_claimed_sum, 32); return ZKHIP_OK; }
-        ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_claimed_sum ? d_claimed_sum : d_evals, 32, hipMemcpyDeviceToHost, c->stream));
-        ZK_HIP(c, hipStreamSynchronize(c->stream));
-        std::memcpy(h_sum, c->pinned_u64(ZK_PIN_RES), 32);
-        return ZKHIP_OK;
-    }
     const bool overlap = overlapped_plan(n);
     // workspace: stage tables (n/4 + n/16 + ...; overlapped: n / 2^k1 <= n/8), partial sums, fold weights, and for the
     // overlapped plan the fine sums (n/256 <= 2^16) and two sets of partial tables (<= 2 x 1024 and 32 x 256)
@@ -741,19 +732,82 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
     // results -> host
     // one copy of the small-scratch span [state .. round polynomials]: the sum, the challenges and the round
     // polynomials are a few KiB apart in one allocation, and three small copies cost three launches
-    uint64_t* pin = c->pinned_u64(ZK_PIN_PROOF);
+    ZK_TRY(c->ensure_proof_slot(slot));
+    uint64_t* pin = (uint64_t*)c->proof_pin[slot];
     const uint64_t* span = c->small_u64(ZK_SMALL_STATE);
     const size_t span_words = (size_t)(ZK_SMALL_ROUNDPOLYS - ZK_SMALL_STATE) + 8 * (size_t)n_vars;
-    static_assert(ZK_PIN_END - ZK_PIN_PROOF >= (ZK_SMALL_ROUNDPOLYS - ZK_SMALL_STATE) + 8 * ZK_MAX_ROUNDS, "pinned proof area too small");
     {
         ProfScope ps(c, "proof_copy", 0.0, tail_stream);
         ZK_HIP(c, hipMemcpyAsync(pin, span, 8 * span_words, hipMemcpyDeviceToHost, tail_stream));
     }
-    ZK_TRY(c->wait_stream(tail_stream));
-    std::memcpy(h_sum, pin + ((const uint64_t*)st->sum - span), 32);
-    std::memcpy(h_round_polys, pin + (d_rp - span), 64 * (size_t)n_vars);
-    std::memcpy(h_challenges, pin + (d_ch - span), 32 * (size_t)n_vars);
+    // the event the collector polls; the caller's stream stays ordered behind the proof (the next call reuses the scratch)
+    ZK_HIP(c, hipEventRecord(c->proof_ev[slot], tail_stream));
+    if (tail_stream != c->stream) ZK_HIP(c, hipStreamWaitEvent(c->stream, c->proof_ev[slot], 0));
     return ZKHIP_OK;
+}
+static int sumcheck_collect(zkhip_ctx* c, int slot, uint32_t n_vars, uint64_t* h_sum, uint64_t* h_round_polys, uint64_t* h_challenges) {
+    ZK_TRY(c->wait_event(c->proof_ev[slot]));
+    const uint64_t* pin = (const uint64_t*)c->proof_pin[slot];
+    const uint64_t* span = c->small_u64(ZK_SMALL_STATE);
+    const SumcheckDev* st = (const SumcheckDev*)c->small_u64(ZK_SMALL_STATE);
+    std::memcpy(h_sum, pin + ((const uint64_t*)st->sum - span), 32);
+    std::memcpy(h_round_polys, pin + (c->small_u64(ZK_SMALL_ROUNDPOLYS) - span), 64 * (size_t)n_vars);
+    std::memcpy(h_challenges, pin + (c->small_u64(ZK_SMALL_CHALLENGES) - span), 32 * (size_t)n_vars);
+    return ZKHIP_OK;
+}
+static int sumcheck_check_args(zkhip_ctx* c, const uint64_t* d_evals, size_t n) {
+    if (!c || !d_evals) return ZKHIP_ERR_ARG;
+    if (!is_pow2(n)) return ZKHIP_ERR_SHAPE;   // Multilinear::new evaluation_form.rs:16-20
+    if (log2_exact(n) > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_claimed_sum,
+                                    const uint64_t* d_claimed_sum, const uint64_t* d_block_sums, uint32_t log_blocks,
+                                    uint64_t* h_sum,
+                                    uint64_t* h_round_polys, uint64_t* h_challenges) {
+    ZK_TRY(sumcheck_check_args(c, d_evals, n));
+    if (!h_sum) return ZKHIP_ERR_ARG;
+    const uint32_t n_vars = log2_exact(n);
+    if (n_vars && (!h_round_polys || !h_challenges)) return ZKHIP_ERR_ARG;
+    if (c->proof_pending[0] || c->proof_pending[1]) return ZKHIP_ERR_BUSY;     // proofs in flight own the result slots
+    ZK_TRY(c->activate());
+    if (n == 1) {   // no rounds: nothing is proven; report the sum the transcript would have absorbed
+        if (h_claimed_sum) { std::memcpy(h_sum, h_claimed_sum, 32); return ZKHIP_OK; }
+        ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_claimed_sum ? d_claimed_sum : d_evals, 32, hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(c, hipStreamSynchronize(c->stream));
+        std::memcpy(h_sum, c->pinned_u64(ZK_PIN_RES), 32);
+        return ZKHIP_OK;
+    }
+    ZK_TRY(sumcheck_enqueue(c, d_evals, n, h_claimed_sum, d_claimed_sum, d_block_sums, log_blocks, 0));
+    return sumcheck_collect(c, 0, n_vars, h_sum, h_round_polys, h_challenges);
+}
+// Sumcheck::prove in flight: begin enqueues the whole proof and returns a ticket, end waits for it and delivers the outputs of
+// zkhip_sumcheck_prove.  Up to two proofs of tables with >= 2 entries may be in flight; they execute in stream order.
+extern "C" int zkhip_sumcheck_prove_begin(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_claimed_sum,
+                                          const uint64_t* d_claimed_sum, const uint64_t* d_block_sums, uint32_t log_blocks,
+                                          uint32_t* ticket) {
+    ZK_TRY(sumcheck_check_args(c, d_evals, n));
+    if (!ticket || n < 2) return ZKHIP_ERR_ARG;
+    int slot = -1;
+    for (int k = 0; k < 2; ++k) if (!c->proof_pending[k]) { slot = k; break; }
+    if (slot < 0) return ZKHIP_ERR_BUSY;
+    ZK_TRY(c->activate());
+    ZK_TRY(sumcheck_enqueue(c, d_evals, n, h_claimed_sum, d_claimed_sum, d_block_sums, log_blocks, slot));
+    c->proof_pending[slot] = log2_exact(n);
+    *ticket = (uint32_t)slot;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_sumcheck_prove_end(zkhip_ctx* c, uint32_t ticket, uint64_t* h_sum, uint64_t* h_round_polys, uint64_t* h_challenges) {
+    if (!c || ticket > 1 || !c->proof_pending[ticket]) return ZKHIP_ERR_ARG;
+    const uint32_t n_vars = c->proof_pending[ticket];
+    int rc = c->activate();
+    if (rc == ZKHIP_OK) {
+        if (h_sum && h_round_polys && h_challenges) rc = sumcheck_collect(c, (int)ticket, n_vars, h_sum, h_round_polys, h_challenges);
+        else rc = c->wait_event(c->proof_ev[ticket]);                          // abandoned: just wait it out
+    }
+    c->proof_pending[ticket] = 0;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------

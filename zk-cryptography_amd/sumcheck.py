@@ -23,6 +23,32 @@ class SumcheckProof:
         self.univariate_poly = univariate_poly
 
 
+class PendingProof:
+    """A Sumcheck::prove in flight (zkhip_sumcheck_prove_begin / _end)."""
+
+    def __init__(self, poly, ticket):
+        self._poly, self._ticket = poly, ticket
+
+    def wait(self):
+        if self._ticket is None:
+            raise RuntimeError("proof already collected")
+        nv = self._poly.n_vars
+        s = np.empty(4, dtype=np.uint64)
+        rp = np.empty((nv, 2, 4), dtype=np.uint64)
+        ch = np.empty((nv, 4), dtype=np.uint64)
+        t, self._ticket = self._ticket, None
+        N.check(N.lib().zkhip_sumcheck_prove_end(self._poly._ctx.handle, C.c_uint32(t), s.ctypes.data_as(C.c_void_p),
+                                                 rp.ctypes.data_as(C.c_void_p), ch.ctypes.data_as(C.c_void_p)), "sumcheck_prove_end")
+        return SumcheckProof(self._poly, s, rp), ch
+
+    def __del__(self):
+        if getattr(self, "_ticket", None) is not None:
+            try:
+                N.lib().zkhip_sumcheck_prove_end(self._poly._ctx.handle, C.c_uint32(self._ticket), None, None, None)
+            except Exception:
+                pass
+
+
 class Sumcheck:
     def __init__(self, poly):
         """Sumcheck::new (sumcheck.rs:18-23)"""
@@ -66,6 +92,20 @@ class Sumcheck:
         self._block_sums, self._log_blocks = (buf, lb) if lb else (None, 0)
         self._sum_dev = buf
         self._sum_ptr = buf.data_ptr() + 32 * (1 << lb)
+
+    def prove_begin(self):
+        """The same proof, in flight (zkhip_sumcheck_prove_begin): -> PendingProof; .wait() yields what prove() returns.  At most
+        two per context; a prover with several tables begins the next proof before it collects the previous one."""
+        if len(self.poly) < 2:
+            raise AssertionError("prove_begin needs a table of at least two entries")
+        ticket = C.c_uint32(0)
+        st = N.lib().zkhip_sumcheck_prove_begin(self.poly._ctx.handle, N.ptr(self.poly.evaluations), C.c_size_t(len(self.poly)),
+                                                None if self._sum_dev is not None else self._sum_host.ctypes.data_as(C.c_void_p),
+                                                C.c_void_p(self._sum_ptr) if self._sum_dev is not None else None,
+                                                C.c_void_p(self._block_sums.data_ptr()) if self._block_sums is not None else None,
+                                                C.c_uint32(self._log_blocks), C.byref(ticket))
+        N.check(st, "sumcheck_prove_begin")
+        return PendingProof(self.poly, ticket.value)
 
     def prove(self):
         """sumcheck.rs:29-61 -> (SumcheckProof, challenges uint64 [n_vars, 4]).
