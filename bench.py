@@ -400,6 +400,33 @@ def bench_gkr(args, zk, rank, world, barrier, dist, torch, np):
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         out["ms_per_proof"]["depth_%d" % depth] = round(1e3 * dt, 3)
+    # BASELINE configs[3]: ONE depth-20 proof with every layer's sumcheck sharded over the ranks (GKRProtocol.prove_sharded:
+    # the layer tables are built on every rank, the rounds over b and c run on shards with one record all-gathered per round)
+    # next to the replicated figure above -- whichever is faster is the answer to "should GKR shard at this width"
+    if world > 1 or args.force_sharded:
+        depth = 20
+        circuit = zk.Circuit.random(depth)
+        ev = circuit.evaluation(zk.Fr.synthetic(2 ** depth, SEED_GKR))          # the same input on every rank
+        proof = zk.GKRProtocol.prove_sharded(circuit, ev, world, rank, None, dist if world > 1 else None)
+        barrier()
+        reps = 2
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            proof = zk.GKRProtocol.prove_sharded(circuit, ev, world, rank, None, dist if world > 1 else None)
+        barrier()
+        dt = (time.perf_counter() - t0) / reps
+        same = True
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+            same = _same_on_all_ranks(dist, torch, np, np.concatenate([np.asarray(w, dtype=np.uint64).reshape(-1) for w in proof.wb_s + proof.wc_s]))
+        want = zk.GKRProtocol.prove(circuit, ev)
+        equal = all(a.to_bytes() == b.to_bytes() for a, b in zip(proof.sumcheck_proofs, want.sumcheck_proofs))
+        out["sharded"] = {"workload": "one Circuit::random(20) proof, every layer's sumcheck sharded over %d GPU(s)" % world,
+                          "ms_per_proof": round(1e3 * dt, 3), "exchanges_per_proof": int(proof._exchanges),
+                          "proof_equals_single_gpu_proof": bool(equal), "proof_replicated_on_all_ranks": same,
+                          "compare_with": "ms_per_proof.depth_20 (every rank proving the whole circuit by itself)"}
     return out
 
 

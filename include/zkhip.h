@@ -164,6 +164,19 @@ void zkhip_circuit_destroy(zkhip_circuit *circuit);
 int zkhip_gkr_prove_circuit(zkhip_circuit *circuit, const uint64_t *const *h_layer_ptrs, const size_t *h_layer_len,
                             uint64_t *h_sums, uint32_t *h_n_rounds, uint32_t *h_round_poly_lens, uint64_t *h_round_polys,
                             uint64_t *h_wb, uint64_t *h_wc, uint64_t *h_w0, uint64_t *h_challenges);
+/* The tables of one layer's sumcheck in the linear-time form, for a caller that runs the sumcheck itself --
+ * the sharded prover shards these tables over the ranks (zkhip_mc_begin_ex) instead of calling zkhip_gkr_prove_circuit.
+ * Layer `layer` (0 = output layer) of a device-resident circuit, d_w = the layer's input values (w_len = 2^(layer+1)).
+ *   phase 0 (the rounds over b):  d_out[0] = Ha0, d_out[1] = Ha1, d_out[2] = Hm  (w_len entries each, caller-allocated); the
+ *            claim's terms are [Ha0, W] + Ha1 (additive table) and [Hm, W].  h_rb / h_rc: the points the wiring is bound at
+ *            (n = max(layer, 1) field elements each; h_rc NULL for the first layer proof), h_alpha / h_beta their weights.
+ *   phase 1 (the rounds over c):  reads the s = layer + 1 challenges of phase 0 where the context recorded them;
+ *            d_out[0] = Aa, d_out[1] = W(u) + W, d_out[2] = Am, d_out[3] = W(u) W; h_wu[4] = W(u) (= w_b of the proof).
+ * Every rank of a sharded proof builds the same tables (they are as wide as the layer); the sumcheck rounds are what shards. */
+int zkhip_gkr_layer_tables(zkhip_circuit *circuit, uint32_t layer, const uint64_t *d_w, size_t w_len, const uint64_t *h_rb,
+                           const uint64_t *h_rc, const uint64_t *h_alpha, const uint64_t *h_beta, int phase,
+                           uint64_t *const *d_out, uint64_t *h_wu);
+
 
 /* ---- basic sumcheck prover (sumcheck/src/sumcheck.rs:25-61) -------------------------- */
 /* Block sums of a table: d_out[(2^log_blocks + 1) * 4] = the sums of its 2^log_blocks equal consecutive blocks
@@ -282,6 +295,14 @@ int zkhip_multi_composed_prove(zkhip_ctx *ctx, const uint64_t *const *h_table_pt
 typedef struct zkhip_mc_state zkhip_mc_state;
 int zkhip_mc_begin(zkhip_ctx *ctx, const uint64_t *const *h_local_table_ptrs, const uint32_t *h_term_sizes, uint32_t n_terms,
                    size_t n_local, uint32_t world, int multi, const uint64_t *h_sum, zkhip_mc_state **out);
+/* The general form (what the sharded GKR prover uses): d_local_lin (nullable) names per term an ADDITIVE
+ * table (term = product of its tables + that table; terms of <= 2 tables only); cont = 1 continues the transcript and the
+ * array of recorded rounds of the previous session of this context from round out_base on (h_sum is then not absorbed and may
+ * be NULL) -- a sumcheck over (b, c) runs as a session over b followed by a session over c, and the second session's finish
+ * delivers the rounds of both. */
+int zkhip_mc_begin_ex(zkhip_ctx *ctx, const uint64_t *const *h_local_table_ptrs, const uint32_t *h_term_sizes, uint32_t n_terms,
+                      const uint64_t *const *h_local_lin_ptrs, size_t n_local, uint32_t world, int multi, const uint64_t *h_sum,
+                      int cont, uint32_t out_base, zkhip_mc_state **out);
 int zkhip_mc_record_len(zkhip_mc_state *st, uint32_t *rec, uint32_t *n_tables);
 /* entries per local table the next round's sums run over (n_local, then n_local/2, ...) */
 int zkhip_mc_local_len(zkhip_mc_state *st, size_t *n_now);

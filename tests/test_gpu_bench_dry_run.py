@@ -30,3 +30,7 @@ def test_bench_multi_rank_dry_run(world):
     assert d["msm"]["value"] > 0
     assert d["composed"]["transcript_replicated_on_all_ranks"] is True and d["composed"]["rounds"] == 15 + (world.bit_length() - 1)
     assert "dry_run" in d
+    assert d["config"]["exchanges_per_prove"] >= 1 and d["config"]["transcript_replicated_on_all_ranks"] is True
+    assert d["msm"]["commitment_replicated_on_all_ranks"] is True and d["msm"]["exchanges_per_commit"] == 1
+    sh = d["gkr"]["sharded"]
+    assert sh["proof_equals_single_gpu_proof"] is True and sh["proof_replicated_on_all_ranks"] is True and sh["exchanges_per_proof"] > 0

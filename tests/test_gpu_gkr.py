@@ -181,3 +181,23 @@ def test_gkr_device_circuit_reused_across_inputs(zk, ora):
     ev = ok.evaluation(ora.random_fr(8, 9))
     with pytest.raises(IndexError):
         zk.GKRProtocol.prove(zk.Circuit.from_tuples(bad), ev)
+
+
+@pytest.mark.parametrize("depth", [1, 2, 4, 8, 12])
+def test_gkr_prove_sharded_world_1_matches_prove(zk, ora, depth):
+    """The sharded prover's code path (layer tables from zkhip_gkr_layer_tables, the rounds over b and over c as two zkhip_mc_*
+    sessions with an additive table and a continued transcript) on one rank: the proof must be zkhip_gkr_prove's, bit for bit."""
+    layers = random_circuit(depth)
+    circuit = zk.Circuit.from_tuples(layers)
+    inp = ora.random_fr(2 ** depth, 800 + depth)
+    ev = circuit.evaluation(inp)
+    want = zk.GKRProtocol.prove(circuit, ev)
+    got = zk.GKRProtocol.prove_sharded(circuit, ev)
+    assert len(got.sumcheck_proofs) == depth
+    for a, b in zip(got.sumcheck_proofs, want.sumcheck_proofs):
+        assert np.array_equal(a.sum, b.sum) and a.to_bytes() == b.to_bytes()
+    assert all(np.array_equal(a, b) for a, b in zip(got.wb_s, want.wb_s))
+    assert all(np.array_equal(a, b) for a, b in zip(got.wc_s, want.wc_s))
+    assert np.array_equal(_host(got.w_0_mle.evaluations), _host(want.w_0_mle.evaluations))
+    if 3 <= depth <= 8:
+        assert ora.gkr_verify(layers, inp, _to_oracle_proof(zk, ora, got))

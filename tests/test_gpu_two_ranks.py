@@ -65,6 +65,18 @@ def _worker(rank, world, port, q):
         wproof, wch = zk.MultiComposedSumcheckProver.prove_partial(poly, claimed)
         got = [zk.SparseUnivariatePolynomial(c, p).monomials() for c, p in rps]
         res["multi_composed"] = bool(got == [p.monomials() for p in wproof.round_polys] and np.array_equal(ch, wch))
+        # GKRProtocol::prove with every layer's sumcheck sharded (narrow layers run whole on every rank)
+        for depth in (5, 9):
+            circuit = zk.Circuit.random(depth)
+            ev = circuit.evaluation(zk.Fr.random(2 ** depth, 300 + depth))
+            want = zk.GKRProtocol.prove(circuit, ev)
+            got = zk.GKRProtocol.prove_sharded(circuit, ev, world, rank, None, shim)
+            ok = len(got.sumcheck_proofs) == len(want.sumcheck_proofs) and got._exchanges > 0
+            for a, b in zip(got.sumcheck_proofs, want.sumcheck_proofs):
+                ok = ok and np.array_equal(a.sum, b.sum) and a.to_bytes() == b.to_bytes()
+            ok = ok and all(np.array_equal(a, b) for a, b in zip(got.wb_s, want.wb_s)) and all(np.array_equal(a, b) for a, b in zip(got.wc_s, want.wc_s))
+            ok = ok and all(np.array_equal(a, b) for a, b in zip(got._challenges, want._challenges))
+            res["gkr_depth_%d" % depth] = bool(ok)
         # sharded KZG commit
         tau = zk.Fr.random(12, 7)
         srs = zk.TrustedSetup.setup(tau)

@@ -416,19 +416,22 @@ struct zkhip_mc_state {
     bool sums_pending = false;   // round_sums done, absorb not yet
 };
 
-extern "C" int zkhip_mc_begin(zkhip_ctx* c, const uint64_t* const* d_local_tables, const uint32_t* term_sizes, uint32_t n_terms,
-                              size_t n_local, uint32_t world, int multi, const uint64_t* h_sum, zkhip_mc_state** out) {
+extern "C" int zkhip_mc_begin_ex(zkhip_ctx* c, const uint64_t* const* d_local_tables, const uint32_t* term_sizes, uint32_t n_terms,
+                                 const uint64_t* const* d_local_lin, size_t n_local, uint32_t world, int multi, const uint64_t* h_sum,
+                                 int cont, uint32_t out_base, zkhip_mc_state** out) {
     if (!c || !d_local_tables || !term_sizes || !out) return ZKHIP_ERR_ARG;
-    if (n_terms == 0 || n_terms > CMP_MAX_TERMS || (!multi && n_terms != 1) || (multi && !h_sum)) return ZKHIP_ERR_ARG;
+    if (n_terms == 0 || n_terms > CMP_MAX_TERMS || (!multi && n_terms != 1) || (multi && !h_sum && !cont)) return ZKHIP_ERR_ARG;
+    if ((cont || d_local_lin) && !multi) return ZKHIP_ERR_ARG;
     if (!is_pow2(n_local) || world == 0 || !is_pow2(world)) return ZKHIP_ERR_SHAPE;
     const uint32_t rounds = log2_exact(n_local) + log2_exact(world);
-    if (rounds == 0 || rounds > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
+    if (rounds == 0 || out_base + rounds > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
     if (c->ws_lent) return ZKHIP_ERR_BUSY;      // one session per context: its tables live in the context's workspace
     zkhip_mc_state* s = new (std::nothrow) zkhip_mc_state();
     if (!s) return ZKHIP_ERR_NOMEM;
     s->world = world;
-    const int rc = s->run.setup(c, d_local_tables, term_sizes, n_terms, n_local, rounds, multi, h_sum, 1, nullptr, 0);
+    const int rc = s->run.setup(c, d_local_tables, term_sizes, n_terms, n_local, rounds, multi, h_sum, 1, d_local_lin, cont);
+    s->run.out_base = out_base;
     if (rc != ZKHIP_OK) {
         delete s;
         return rc;
@@ -440,6 +443,10 @@ extern "C" int zkhip_mc_begin(zkhip_ctx* c, const uint64_t* const* d_local_table
     c->ws_lent = true;              // until finish / abort: every other user of the workspace gets ZKHIP_ERR_BUSY
     *out = s;
     return ZKHIP_OK;
+}
+extern "C" int zkhip_mc_begin(zkhip_ctx* c, const uint64_t* const* d_local_tables, const uint32_t* term_sizes, uint32_t n_terms,
+                              size_t n_local, uint32_t world, int multi, const uint64_t* h_sum, zkhip_mc_state** out) {
+    return zkhip_mc_begin_ex(c, d_local_tables, term_sizes, n_terms, nullptr, n_local, world, multi, h_sum, 0, 0, out);
 }
 extern "C" int zkhip_mc_record_len(zkhip_mc_state* s, uint32_t* rec, uint32_t* n_tables) {
     if (!s || !rec) return ZKHIP_ERR_ARG;

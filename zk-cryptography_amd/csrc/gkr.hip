@@ -406,6 +406,64 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
     return ZKHIP_OK;
 }
 
+extern "C" int zkhip_gkr_layer_tables(zkhip_circuit* cir, uint32_t layer, const uint64_t* d_w, size_t w_len, const uint64_t* h_rb,
+                                      const uint64_t* h_rc, const uint64_t* h_alpha, const uint64_t* h_beta, int phase,
+                                      uint64_t* const* d_out, uint64_t* h_wu) {
+    using namespace zk;
+    if (!cir || !d_w || !h_rb || !h_alpha || !h_beta || !d_out || phase < 0 || phase > 1 || layer >= cir->n_layers) return ZKHIP_ERR_ARG;
+    if (phase == 1 && !h_wu) return ZKHIP_ERR_ARG;
+    zkhip_ctx* c = cir->c;
+    const LayerDev& ld = cir->layers[layer];
+    if (!is_pow2(w_len) || w_len != ld.w_len) return ZKHIP_ERR_SHAPE;
+    if (ld.bad_label) return ZKHIP_ERR_INDEX;
+    ZK_TRY(c->activate());
+    const uint32_t s = log2_exact(w_len);
+    const uint32_t n_gate_vars = layer == 0 ? 1u : layer;
+    const bool two_points = h_rc != nullptr;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_wg = 0, o_equ = o_wg + al(32 * std::max<size_t>(ld.n_gates, 1)), o_dot = o_equ + al(32 * w_len),
+                 o_ev = o_dot + al(32 * (size_t)zk::MLE_MAX_GRID);
+    ZK_TRY(c->reserve_aux(o_ev + 256));
+    char* aux = (char*)c->d_aux;
+    uint64_t* wg = (uint64_t*)(aux + o_wg);
+    uint64_t* equ = (uint64_t*)(aux + o_equ);
+    uint64_t* dot_partials = (uint64_t*)(aux + o_dot);
+    uint64_t* evals = (uint64_t*)(aux + o_ev);
+    PtsArg pb = {}, pc = {};
+    std::memcpy(pb.v, h_rb, 32 * (size_t)n_gate_vars);
+    if (two_points) std::memcpy(pc.v, h_rc, 32 * (size_t)n_gate_vars);
+    FrArg av = {}, bv = {};
+    std::memcpy(av.v, h_alpha, 32);
+    std::memcpy(bv.v, h_beta, 32);
+    const unsigned gg = (unsigned)((ld.n_gates + MLE_BLOCK - 1) / MLE_BLOCK), gw = (unsigned)((w_len + MLE_BLOCK - 1) / MLE_BLOCK);
+    if (ld.n_gates)
+        hipLaunchKernelGGL(gkr_gate_weights_kernel, dim3(gg), dim3(MLE_BLOCK), 0, c->stream, (uint32_t)ld.n_gates, n_gate_vars, pb, pc, av, bv,
+                           two_points ? 1u : 0u, wg);
+    if (phase == 0) {
+        hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr0, ld.csr0 + w_len + 1, ld.type, ld.in1, wg, d_w,
+                           (uint32_t)w_len, 1u, d_out[0], d_out[1], d_out[2]);
+        ZK_HIP(c, hipGetLastError());
+        return ZKHIP_OK;
+    }
+    const uint64_t* d_ch = zk_composed_challenges_dev(c);       // the s challenges of the rounds over b
+    hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_ch, s, equ);
+    const int dot_grid = mle_grid(w_len);
+    if (dot_grid == 1) {
+        hipLaunchKernelGGL(gkr_dot_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, equ, d_w, w_len, evals);
+    } else {
+        hipLaunchKernelGGL(gkr_dot_kernel, dim3(dot_grid), dim3(MLE_BLOCK), 0, c->stream, equ, d_w, w_len, dot_partials);
+        hipLaunchKernelGGL(gkr_dot_finish_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, dot_partials, (uint32_t)dot_grid, evals);
+    }
+    hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr1, ld.csr1 + w_len + 1, ld.type, ld.in0, wg, equ,
+                       (uint32_t)w_len, 2u, d_out[0], (uint64_t*)nullptr, d_out[2]);
+    hipLaunchKernelGGL(gkr_vu_tables_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_w, w_len, evals, d_out[1], d_out[3]);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), evals, 32, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(h_wu, c->pinned_u64(ZK_PIN_RES), 32);
+    return ZKHIP_OK;
+}
+
 // one-shot form: the circuit is grouped and uploaded for this proof only
 extern "C" int zkhip_gkr_prove(zkhip_ctx* c, uint32_t n_layers, const size_t* h_n_gates, const uint8_t* h_gate_type,
                                const uint32_t* h_in0, const uint32_t* h_in1, const uint64_t* const* h_layer_ptrs,

@@ -194,10 +194,13 @@ class HipComposedEngine:
     multi = False: ComposedSumcheck (one term);  multi = True: MultiComposedSumcheckProver::prove_partial with the
     claimed sum of the whole tables."""
 
-    def __init__(self, terms, world, multi, claimed_sum=None, ctx=None):
+    def __init__(self, terms, world, multi, claimed_sum=None, ctx=None, lin=None, cont=False, out_base=0):
+        """lin: per term an additive table (or None) -- term = product of its tables + that table; cont / out_base: continue
+        the previous session's transcript and recorded rounds from round out_base on (zkhip_mc_begin_ex)."""
         import torch
         self.torch = torch
         self.tables = [t for term in terms for t in term]      # kept alive for the duration
+        self.lin = list(lin) if lin is not None else None
         self.sizes = [len(term) for term in terms]
         self.multi = bool(multi)
         self.device = self.tables[0].device
@@ -206,10 +209,11 @@ class HipComposedEngine:
         cs = np.ascontiguousarray(claimed_sum, dtype=np.uint64).reshape(4) if claimed_sum is not None else None
         self.sum = cs
         ptrs = (C.c_void_p * len(self.tables))(*[t.data_ptr() for t in self.tables])
-        N.check(N.lib().zkhip_mc_begin(self.ctx.handle, ptrs, (C.c_uint32 * len(self.sizes))(*self.sizes),
-                                       C.c_uint32(len(self.sizes)), C.c_size_t(self.tables[0].shape[0]), C.c_uint32(world),
-                                       C.c_int(1 if multi else 0), cs.ctypes.data_as(C.c_void_p) if cs is not None else None,
-                                       C.byref(self.st)), "mc_begin")
+        lin_ptrs = (C.c_void_p * len(self.sizes))(*[t.data_ptr() if t is not None else None for t in self.lin]) if self.lin else None
+        N.check(N.lib().zkhip_mc_begin_ex(self.ctx.handle, ptrs, (C.c_uint32 * len(self.sizes))(*self.sizes),
+                                          C.c_uint32(len(self.sizes)), lin_ptrs, C.c_size_t(self.tables[0].shape[0]), C.c_uint32(world),
+                                          C.c_int(1 if multi else 0), cs.ctypes.data_as(C.c_void_p) if cs is not None else None,
+                                          C.c_int(1 if cont else 0), C.c_uint32(out_base), C.byref(self.st)), "mc_begin")
         rec, nt = C.c_uint32(0), C.c_uint32(0)
         N.check(N.lib().zkhip_mc_record_len(self.st, C.byref(rec), C.byref(nt)), "mc_record_len")
         self.rec, self.n_tables = rec.value, nt.value
@@ -290,15 +294,18 @@ class ShardedComposedSumcheck:
         if world & (world - 1):
             raise AssertionError("world size must be a power of two (the tables have 2^n entries)")
 
-    def prove(self):
+    def prove(self, collect=True, finish_rounds=None):
+        """collect=False: run the rounds and release the session without reading anything back (a later session that
+        continues it delivers the rounds of both); finish_rounds: how many recorded rounds finish() reads (default: this
+        session's)."""
         try:
-            return self._prove()
+            return self._prove(collect, finish_rounds)
         except BaseException:
             if hasattr(self.e, "abort"):
                 self.e.abort()
             raise
 
-    def _prove(self):
+    def _prove(self, collect=True, finish_rounds=None):
         e, world = self.e, self.world
         n_local = e.local_len()
         total_rounds = (n_local * world).bit_length() - 1
@@ -323,7 +330,10 @@ class ShardedComposedSumcheck:
             self.exchanges += 1
             full = gathered.permute(1, 2, 0, 3).contiguous()                  # entry j*world + g <- rank g, local j
             e.tail(full.view(nt, n_local * world, 4), n_local * world)
-        return e.finish(total_rounds)
+        if not collect:
+            e.abort()
+            return None
+        return e.finish(finish_rounds if finish_rounds is not None else total_rounds)
 
 
 _COMMIT_BUFS = {}

@@ -223,6 +223,82 @@ class GKRProtocol:
         return proof
 
     @staticmethod
+    def prove_sharded(circuit, circuit_evaluation, world=1, rank=0, group=None, dist=None):
+        """GKRProtocol::prove (protocol.rs:21-117) with every layer's sumcheck SHARDED over `world` ranks (SURVEY 8e, "GKR
+        tables"; BASELINE configs[3]).  Every rank holds the evaluation tables and builds the layer's linear-size sumcheck tables
+        (zkhip_gkr_layer_tables: they are as wide as the layer); the rounds over b and over c then run on shards -- rank g folds
+        entries j * world + g -- with one record of partial sums all-gathered per round
+        (distributed.ShardedComposedSumcheck over zkhip_mc_*; the transcript is replicated).  Layers narrower than 2 * world
+        values run unsharded on every rank.  Returns the proof GKRProtocol.prove returns, bit for bit, on every rank; the
+        number of collectives is left in proof._exchanges."""
+        import torch
+        from zk_cryptography_amd import distributed as D
+        from zk_cryptography_amd.composed import MultiComposedSumcheckProof, SparseUnivariatePolynomial
+        nl = len(circuit.layers)
+        assert len(circuit_evaluation) == nl + 1
+        shape = [len(layer.layer) for layer in circuit.layers]
+        tables = [t.contiguous() for t in circuit_evaluation]
+        ctx = N.Context.get(tables[0].device.index)
+        dev = getattr(circuit, "_device", None)
+        if dev is None or dev.shape != shape or dev.ctx is not ctx:
+            dev = circuit._device = _DeviceCircuit(ctx, circuit, shape)
+        transcript = FiatShamirTranscript()
+        pad = torch.zeros((1, 4), dtype=torch.int64, device=tables[0].device)
+        w_0_mle = Multilinear(torch.cat([tables[0], pad]))
+        proof = GKRProof([], [], [], w_0_mle)
+        proof._challenges, proof._exchanges = [], 0
+        transcript.commit(w_0_mle.to_bytes())
+        n_r = transcript.evaluate_n_challenge_into_field(w_0_mle.n_vars)
+        claimed = w_0_mle.evaluation(n_r)
+        alpha, beta = Fr.from_int(1), Fr.from_int(0)
+        r_b, r_c = np.ascontiguousarray(n_r), None
+        p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+
+        def shard(t, w):
+            return t if w == 1 else t.view(-1, w, 4)[:, rank].contiguous()
+
+        for li in range(1, nl + 1):
+            layer, V = li - 1, tables[li]
+            w_len = V.shape[0]
+            s_vars = w_len.bit_length() - 1
+            w = world if w_len >= 2 * world else 1                    # narrow layers: every rank proves them whole
+            grp, dst = (group, dist) if w > 1 else (None, None)
+            out = [torch.empty((w_len, 4), dtype=torch.int64, device=V.device) for _ in range(4)]
+            ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in out])
+            wu = np.zeros(4, dtype=np.uint64)
+            rc_p = p(np.ascontiguousarray(r_c)) if r_c is not None else None
+            rb_a, al_a, be_a = np.ascontiguousarray(r_b), np.ascontiguousarray(alpha), np.ascontiguousarray(beta)
+            N.check(N.lib().zkhip_gkr_layer_tables(dev.handle, C.c_uint32(layer), N.ptr(V), C.c_size_t(w_len), p(rb_a), rc_p, p(al_a), p(be_a),
+                                                   C.c_int(0), ptrs, None), "gkr_layer_tables")
+            ha0, ha1, hm = out[0], out[1], out[2]
+            eng = D.HipComposedEngine([[shard(ha0, w), shard(V, w)], [shard(hm, w), shard(V, w)]], w, multi=True, claimed_sum=claimed, ctx=ctx,
+                                      lin=[shard(ha1, w), None])
+            sh = D.ShardedComposedSumcheck(eng, w, grp, dst)
+            sh.prove(collect=False)                                   # the rounds over b; recorded on the device
+            proof._exchanges += sh.exchanges
+            N.check(N.lib().zkhip_gkr_layer_tables(dev.handle, C.c_uint32(layer), N.ptr(V), C.c_size_t(w_len), p(rb_a), rc_p, p(al_a), p(be_a),
+                                                   C.c_int(1), ptrs, p(wu)), "gkr_layer_tables")
+            eng = D.HipComposedEngine([[shard(out[0], w), shard(out[1], w)], [shard(out[2], w), shard(out[3], w)]], w, multi=True, ctx=ctx,
+                                      cont=True, out_base=s_vars)
+            sh = D.ShardedComposedSumcheck(eng, w, grp, dst)
+            rps, ch = sh.prove(finish_rounds=2 * s_vars)              # the rounds over c; delivers all 2 s rounds
+            proof._exchanges += sh.exchanges
+            sumcheck_proof = MultiComposedSumcheckProof([SparseUnivariatePolynomial(c_, p_) for c_, p_ in rps], np.array(claimed, copy=True))
+            transcript.commit(sumcheck_proof.to_bytes())
+            proof.sumcheck_proofs.append(sumcheck_proof)
+            proof._challenges.append(ch.copy())
+            b, c = ch[:s_vars], ch[s_vars:]
+            eval_wb = wu
+            eval_wc = Multilinear(V).evaluation(c)
+            proof.wb_s.append(eval_wb.copy())
+            proof.wc_s.append(eval_wc)
+            alpha = transcript.evaluate_challenge_into_field()
+            beta = transcript.evaluate_challenge_into_field()
+            claimed = _fadd(_fmul(alpha, eval_wb), _fmul(beta, eval_wc))
+            r_b, r_c = b, c
+        return proof
+
+    @staticmethod
     def prove_stepwise(circuit, circuit_evaluation):
         """The same prover spelled out call by call over the mirror's types, line for line with protocol.rs:21-117
         (kept as a cross-check of zkhip_gkr_prove and as the reading order of the reference)."""
