@@ -1,5 +1,5 @@
-"""Diagnostic only: where a round of the serial prover kernel spends its time (libzkhip_diag.so, -DZK_STAMPS; s_memtime ticks at the 2.4 GHz core clock, printed in microseconds
-of 10 ns).  Rows: one per round (wave 0: hash block 1 / block 2 / publish / barrier wait / product; helpers: when the first and
+"""Diagnostic only: where a round of the serial prover kernel spends its time (libzkhip_diag.so, -DZK_STAMPS; s_memtime ticks at the 2.4 GHz core clock, printed in
+microseconds).  Rows: one per round (wave 0: hash block 1 / block 2 / publish / barrier wait / product; helpers: when the first and
 the last helper wave reach the barrier, relative to wave 0), then one per serial kernel (prologue, rounds)."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
