@@ -494,7 +494,8 @@ def main():
             sc.poly_sum()
             return sc.prove()
         # N > 1: ONE prover over the world * 2^log_n-entry table whose rank-interleaved shard is `table`
-        # (stage form: one all-gather of 2^k partial block sums per k rounds over RCCL/xGMI + replicated transcript)
+        # (overlapped stage: two all-gathers of block sums -- the second one beside the shard's fold -- and one of the 256-entry
+        # local tables, over RCCL/xGMI, replicated transcript)
         sh = D.ShardedSumcheck(D.HipSumcheckEngine(table), world, None, dist)
         res = sh.prove()
         exchanges[0] = sh.exchanges
@@ -638,7 +639,7 @@ def main():
                        "inputs": "uniform field elements, splitmix64-seeded xoshiro256** (SURVEY 8d), table seed 0x5EED000000000001 + 16 rank",
                        "exchanges_per_prove": exchanges[0] if world > 1 else 0,
                        "transcript_replicated_on_all_ranks": transcript_same,
-                       "sharding": ("one %d-entry table sharded by low index bits over %d GPUs; per stage of k rounds one RCCL all-gather of the 2^k partial block sums, local k-variable fold, replicated transcript" % (n * world, world))
+                       "sharding": ("one %d-entry table sharded by low index bits over %d GPUs; overlapped stage: RCCL all-gathers of the coarse block sums, of the folded fine sums (beside the shard's local fold) and of the 256-entry local tables; replicated transcript" % (n * world, world))
                        if world > 1 else "single GPU"},
             "roofline": roofline,
             "cpu_baseline": cpu,

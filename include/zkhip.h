@@ -228,7 +228,8 @@ int zkhip_sc_local_half_sums(zkhip_sc_state *st, uint64_t *d_out /* [2][4] */);
 int zkhip_sc_absorb(zkhip_sc_state *st, const uint64_t *d_gathered, uint32_t world, const uint64_t *h_claimed_sum);
 int zkhip_sc_fold(zkhip_sc_state *st);
 /* copy of the current local table (n_local_now entries) -- gathered by the host once the whole remaining
- * table (n_local_now * world entries) fits one workgroup's LDS (zkhip_sc_tail_capacity entries) */
+ * table (n_local_now * world entries) fits zkhip_sc_tail_capacity() entries (twice what one workgroup's LDS holds:
+ * zkhip_sc_tail runs the first round of a table of that size by itself, which costs less than another exchange) */
 int zkhip_sc_local_table(zkhip_sc_state *st, uint64_t *d_out);
 int zkhip_sc_tail_capacity(void);
 /* d_values[m][4]: the whole remaining table in natural order (entry j*world + g = rank g's local entry j),
@@ -246,6 +247,20 @@ int zkhip_sc_stage_block_sums(zkhip_sc_state *st, uint64_t *d_out /* [2^k][4] */
 /* d_gathered[world][2^k][4] in rank order; h_claimed_sum as in zkhip_sc_absorb (first stage only) */
 int zkhip_sc_stage_absorb(zkhip_sc_state *st, const uint64_t *d_gathered, uint32_t world, const uint64_t *h_claimed_sum);
 int zkhip_sc_stage_fold(zkhip_sc_state *st);
+/* Overlapped stage: the single-GPU plan of 2^19..2^24-entry tables in exchange form, for the shard a rank holds.
+ *   begin -> overlap_plan(k1 > 0) -> overlap_sums -> [all-gather 2^k1 sums] -> overlap_rounds1 -> [all-gather mid_entries sums,
+ *            while the k1-variable fold of the shard runs on the context's fold stream] -> overlap_rounds2
+ *         -> local_table (256 entries) -> [all-gather + interleave] -> tail -> finish
+ * Rounds 1..k1 run on the gathered coarse block sums, rounds k1+1..k1+k2 on the gathered fine sums folded by the first k1
+ * challenges, beside the big fold; three exchanges, as in the stage form.  *k1 == 0: the plan does not apply (shard outside
+ * 2^19..2^24 entries, rounds already absorbed, or 256 * world entries exceed the tail) -- use the stage form. */
+int zkhip_sc_overlap_plan(zkhip_sc_state *st, uint32_t world, uint32_t *k1, uint32_t *k2, uint32_t *mid_entries);
+int zkhip_sc_overlap_sums(zkhip_sc_state *st, uint64_t *d_out /* [2^k1][4] */);
+/* d_gathered[world][2^k1][4] in rank order; d_mid[mid_entries][4] receives what this rank contributes to the second exchange */
+int zkhip_sc_overlap_rounds1(zkhip_sc_state *st, const uint64_t *d_gathered, uint32_t world, const uint64_t *h_claimed_sum,
+                             uint64_t *d_mid);
+/* d_gathered[world][mid_entries][4] in rank order */
+int zkhip_sc_overlap_rounds2(zkhip_sc_state *st, const uint64_t *d_gathered, uint32_t world);
 /* copies out the proof (as zkhip_sumcheck_prove; *n_rounds rounds were recorded) and releases the state */
 int zkhip_sc_finish(zkhip_sc_state *st, uint64_t *h_sum, uint64_t *h_round_polys, uint64_t *h_challenges,
                     uint32_t *n_rounds);

@@ -19,9 +19,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class OracleSumcheckEngine:
     """Same split-phase interface as HipSumcheckEngine, computed by the oracle (test double)."""
 
-    def __init__(self, ora, local_table, use_stages=True):
+    def __init__(self, ora, local_table, use_stages=True, overlap=False):
         self.ora = ora
         self.use_stages = use_stages
+        self.overlap = overlap
         self.cur = np.ascontiguousarray(local_table, dtype=np.uint64)
         self.tr = ora.Transcript()
         self.rps, self.chs, self.sum = [], [], None
@@ -93,6 +94,51 @@ class OracleSumcheckEngine:
         for r in self.stage_rs:
             self.cur = self.ora.mle_partial_evaluation(self.cur, r, 0)
 
+    # ---- overlapped stage: k1 rounds on coarse sums, k2 rounds on the block sums of the table folded by those k1 challenges
+    # (two additive slices per rank, as the HIP engine's partial tables), leaving two local entries
+    def _rounds_on(self, t, k, claimed_sum):
+        rs = []
+        for _ in range(k):
+            hs = self.ora.mle_half_sums(t)
+            r = self._round(hs[0], hs[1], claimed_sum, not self.rps)
+            t = self.ora.mle_partial_evaluation(t, r, 0)
+            rs.append(r)
+        return rs
+
+    def _block_sums(self, tab, blocks):
+        m = tab.shape[0] // blocks
+        return np.stack([self.ora.mle_sum(tab[b * m:(b + 1) * m]) for b in range(blocks)])
+
+    def overlap_plan(self, world):
+        L = self.cur.shape[0].bit_length() - 1
+        if not self.overlap or self.rps or L < 3:
+            return None
+        self.k1 = max(1, (L - 1) // 2)
+        self.k2 = L - 1 - self.k1
+        return self.k1, self.k2, 2 << self.k2
+
+    def overlap_sums(self, out):
+        out.copy_(torch.from_numpy(self._block_sums(self.cur, 1 << self.k1).view(np.int64)))
+
+    def _sum_rows(self, rows):
+        t = rows[0].copy()
+        for r in range(1, rows.shape[0]):
+            t = np.stack([self.ora.fr_add(t[b], rows[r, b]) for b in range(t.shape[0])])
+        return t
+
+    def overlap_rounds1(self, gathered, world, mid_out, claimed_sum=None):
+        for r in self._rounds_on(self._sum_rows(gathered.numpy().view(np.uint64)), self.k1, claimed_sum):
+            self.cur = self.ora.mle_partial_evaluation(self.cur, r, 0)
+        blocks = 1 << self.k2
+        m = self.cur.shape[0] // blocks                      # 2 entries per block: slice y takes entry y of every block
+        mid = np.concatenate([np.stack([self.cur[b * m + y] for b in range(blocks)]) for y in range(2)])
+        mid_out.copy_(torch.from_numpy(np.ascontiguousarray(mid).view(np.int64)))
+
+    def overlap_rounds2(self, gathered, world):
+        g = gathered.numpy().view(np.uint64).reshape(world * 2, 1 << self.k2, 4)
+        for r in self._rounds_on(self._sum_rows(g), self.k2, None):
+            self.cur = self.ora.mle_partial_evaluation(self.cur, r, 0)
+
     def tail_capacity(self):
         return self.cap
 
@@ -120,10 +166,13 @@ def _worker(rank, world, port, log_n, q):
         shard = D.shard_interleaved(full, rank, world)
         ws, wrp, wch = ora.sumcheck_prove(full)
         ok_sc = True
-        for use_stages in (True, False):     # stage form (one exchange per k rounds) and round form
-            eng = OracleSumcheckEngine(ora, shard, use_stages)
-            s, rp, ch = D.ShardedSumcheck(eng, world, None, dist).prove()
+        for use_stages, overlap in ((True, False), (False, False), (True, True)):   # stage form, round form, overlapped stage
+            eng = OracleSumcheckEngine(ora, shard, use_stages, overlap)
+            sh = D.ShardedSumcheck(eng, world, None, dist)
+            s, rp, ch = sh.prove()
             ok_sc = ok_sc and np.array_equal(s, ws) and np.array_equal(rp, wrp) and np.array_equal(ch, wch)
+            if overlap and shard.shape[0] >= 8:
+                ok_sc = ok_sc and sh.exchanges == 3 and eng.k1 + eng.k2 + 1 + (world.bit_length() - 1) == log_n
 
         # sharded KZG commit: SRS and scalars split the same way
         nv = 5

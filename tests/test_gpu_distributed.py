@@ -128,7 +128,7 @@ def test_stage_form_shards_in_lockstep_match_full_prover(zk, ora, world, log_n):
 
 
 def test_stage_form_2_27_over_8_shards_matches_single_gpu_prover(zk):
-    """The 8-GPU bench shape (2^24 entries per rank): 9 + 8 variables in two stages, then the gathered 2^10-entry tail --
+    """The 8-GPU bench shape (2^24 entries per rank): 8 + 8 variables in two stages, then the gathered 2^11-entry tail --
     three exchanges.  Eight shards driven in lockstep on one GPU against the single-GPU prover on the full table
     (itself checked against the oracle up to 2^24)."""
     import torch
@@ -157,7 +157,7 @@ def test_stage_form_2_27_over_8_shards_matches_single_gpu_prover(zk):
             e.stage_fold()
         n_local >>= k
         ks.append(k)
-    assert ks == [9, 8] and n_local * world == 1024
+    assert ks == [8, 8] and n_local * world == 2048
     tabs = []
     for e in engines:
         t = e.new_buffer(n_local, 4)
@@ -167,6 +167,83 @@ def test_stage_form_2_27_over_8_shards_matches_single_gpu_prover(zk):
     for e in engines:
         e.tail(rest, n_local * world)
         s, rp, ch = e.finish(log_n)
+        assert np.array_equal(s, want.sum) and np.array_equal(rp, want.univariate_poly) and np.array_equal(ch, want_ch)
+
+
+def _drive_overlapped(torch, engines, world, log_n):
+    """The overlapped stage with `world` shards in lockstep on one GPU; returns every engine's proof."""
+    plans = [e.overlap_plan(world) for e in engines]
+    assert plans[0] is not None and len(set(plans)) == 1
+    k1, k2, mid = plans[0]
+    mine = []
+    for e in engines:
+        b = e.new_buffer(1 << k1, 4)
+        e.overlap_sums(b)
+        mine.append(b)
+    gathered = torch.stack(mine).contiguous()
+    mids = []
+    for e in engines:
+        b = e.new_buffer(mid, 4)
+        e.overlap_rounds1(gathered, world, b)
+        mids.append(b)
+    gathered = torch.stack(mids).contiguous()
+    for e in engines:
+        e.overlap_rounds2(gathered, world)
+    assert all(e.local_len() == 256 for e in engines) and all(e.stage_plan(world) == 0 for e in engines)
+    assert k1 + k2 + 8 + world.bit_length() - 1 == log_n and 256 * world <= engines[0].tail_capacity()
+    tabs = []
+    for e in engines:
+        t = e.new_buffer(256, 4)
+        e.local_table(t)
+        tabs.append(t)
+    rest = torch.stack(tabs).transpose(0, 1).contiguous().view(256 * world, 4)
+    outs = []
+    for e in engines:
+        e.tail(rest, 256 * world)
+        outs.append(e.finish(log_n))
+    return outs
+
+
+@pytest.mark.parametrize("world,log_n", [(1, 19), (2, 20), (4, 21), (8, 22), (2, 22), (4, 24)])
+def test_overlapped_stage_shards_in_lockstep_match_full_prover(zk, ora, world, log_n):
+    """The overlapped stage (shards of 2^19..2^24 entries: rounds on coarse sums, then on the folded fine sums beside the
+    shard's fold) against the oracle on the full table; (8, 22) ends in the 2048-entry tail."""
+    import torch
+    from zk_cryptography_amd import distributed as D
+    full = ora.random_fr(1 << log_n, 299 + log_n)
+    engines = []
+    for g in range(world):
+        t = torch.from_numpy(np.ascontiguousarray(D.shard_interleaved(full, g, world)).view(np.int64)).cuda()
+        engines.append(D.HipSumcheckEngine(t))
+    outs = _drive_overlapped(torch, engines, world, log_n)
+    ws, wrp, wch = ora.sumcheck_prove(full)
+    for s, rp, ch in outs:
+        assert np.array_equal(s, ws) and np.array_equal(rp, wrp) and np.array_equal(ch, wch)
+    # the protocol driver picks the same path (world 1: the exchange is a copy)
+    if world == 1:
+        sh = D.ShardedSumcheck(D.HipSumcheckEngine(torch.from_numpy(full.view(np.int64)).cuda()), 1, None, None)
+        s, rp, ch = sh.prove()
+        assert sh.exchanges == 3 and np.array_equal(s, ws) and np.array_equal(rp, wrp) and np.array_equal(ch, wch)
+    # shards outside the plan's range fall back to the stage form
+    small = D.HipSumcheckEngine(torch.from_numpy(np.ascontiguousarray(full[: 1 << 12]).view(np.int64)).cuda())
+    assert small.overlap_plan(world) is None
+    small.abort()
+
+
+def test_overlapped_stage_2_27_over_8_shards_matches_single_gpu_prover(zk):
+    """The 8-GPU bench shape (2^24 entries per rank) on the overlapped stage: 6 rounds | 10 rounds beside the 6-variable fold
+    | 2048-entry gathered tail, three exchanges.  Eight shards in lockstep on one GPU against the single-GPU prover."""
+    import torch
+    from zk_cryptography_amd import distributed as D
+    world, log_n = 8, 27
+    g = torch.Generator(device="cuda").manual_seed(2727)
+    full = torch.randint(0, 2 ** 62, (1 << log_n, 4), dtype=torch.int64, device="cuda", generator=g)
+    sc = zk.Sumcheck(zk.Multilinear(full))
+    sc.poly_sum()
+    want, want_ch = sc.prove()
+    engines = [D.HipSumcheckEngine(full[r::world].contiguous()) for r in range(world)]
+    assert engines[0].overlap_plan(world)[:2] == (6, 10)
+    for s, rp, ch in _drive_overlapped(torch, engines, world, log_n):
         assert np.array_equal(s, want.sum) and np.array_equal(rp, want.univariate_poly) and np.array_equal(ch, want_ch)
 
 

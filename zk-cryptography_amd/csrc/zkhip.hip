@@ -524,16 +524,23 @@ static int launch_multifold(zkhip_ctx* c, hipStream_t stream, const uint64_t* cu
     return ZKHIP_OK;
 }
 // k-variable fold of a small table spread over the chip: partial tables P[y][m], y < *n_slices (blockfold_kernel)
+struct BlockfoldShape { uint32_t log_ow, per, ny; };
+// OW outputs x (1024 / OW) term slices per workgroup; at least one term per slice; ny partial tables come out
+static inline bool blockfold_shape(uint32_t m, uint32_t k, BlockfoldShape* sh) {
+    const uint32_t log_m = log2_exact(m);
+    sh->log_ow = std::max<uint32_t>(std::min<uint32_t>(log_m, 5), k < 10 ? 10 - k : 0);
+    if (sh->log_ow > log_m) return false;
+    const uint32_t sl_cnt = (uint32_t)BF_BLOCK >> sh->log_ow;
+    const uint32_t terms = 1u << k;
+    sh->per = std::min<uint32_t>(4, terms / sl_cnt);
+    sh->ny = terms / (sh->per * sl_cnt);
+    return true;
+}
 static int launch_blockfold(zkhip_ctx* c, hipStream_t stream, const uint64_t* in, uint32_t m, uint32_t k, const uint64_t* d_w,
                             uint64_t* d_partial, uint32_t* n_slices) {
-    // OW outputs x (1024 / OW) term slices per workgroup; at least one term per slice
-    const uint32_t log_m = log2_exact(m);
-    const uint32_t log_ow = std::max<uint32_t>(std::min<uint32_t>(log_m, 5), k < 10 ? 10 - k : 0);
-    if (log_ow > log_m) return ZKHIP_ERR_SHAPE;
-    const uint32_t sl_cnt = (uint32_t)BF_BLOCK >> log_ow;
-    const uint32_t terms = 1u << k;
-    const uint32_t per = std::min<uint32_t>(4, terms / sl_cnt);
-    const uint32_t ny = terms / (per * sl_cnt);
+    BlockfoldShape sh;
+    if (!blockfold_shape(m, k, &sh)) return ZKHIP_ERR_SHAPE;
+    const uint32_t log_ow = sh.log_ow, per = sh.per, ny = sh.ny, terms = 1u << k;
     ProfScope ps(c, "blockfold", 32.0 * (double)m * terms, stream);
     hipLaunchKernelGGL(blockfold_kernel, dim3(m >> log_ow, ny), dim3(BF_BLOCK), 0, stream, in, m, log_ow, per, d_w, d_partial);
     ZK_HIP(c, hipGetLastError());
@@ -828,6 +835,13 @@ struct zkhip_sc_state {
     size_t stage_parts_cap;
     uint32_t stage_k_cur, stage_world, stage_idx, n_parts;
     const uint64_t* parts;
+    // overlapped stage (zkhip_sc_overlap_*): scratch inside B -- fine sums, fold weights of both halves, partial tables, local table
+    uint32_t ov_k1 = 0, ov_k2 = 0, ov_ny1 = 0, ov_phase = 0;
+    uint64_t* ov_fine() { return B; }
+    uint64_t* ov_w1() { return B + 4 * (size_t)65536; }
+    uint64_t* ov_w2() { return ov_w1() + 4 * ((size_t)1 << TREE_MAX_LOG); }
+    uint64_t* ov_p2() { return ov_w2() + 4 * ((size_t)1 << TREE_MAX_LOG); }      // <= 32 x 256
+    uint64_t* ov_loc() { return ov_p2() + 4 * (size_t)32 * 256; }                // 256
     uint64_t* sw() { return stage_buf; }
     uint64_t* spx() { return stage_buf + 4 * ((size_t)1 << MF_CAP_LOGK); }
     uint64_t* spy() { return spx() + 4 * stage_parts_cap; }
@@ -889,11 +903,12 @@ extern "C" int zkhip_sc_stage_plan(zkhip_sc_state* st, uint32_t world, uint32_t*
         k = stage_k(st->cn);                    // the single-GPU plan
     } else {
         // Every stage costs an exchange: use as few as the kernels allow (<= MF_CAP_LOGK variables per stage, the
-        // gathered tail takes 2^TREE_MAX_LOG entries) and spread the variables evenly over them.
+        // gathered tail takes zkhip_sc_tail_capacity() entries) and spread the variables evenly over them.
         const uint32_t lg = log2_exact(st->cn * world);
-        if (lg <= (uint32_t)TREE_MAX_LOG) k = 0;
+        const uint32_t tail_log = log2_exact((size_t)zkhip_sc_tail_capacity());
+        if (lg <= tail_log) k = 0;
         else {
-            const uint32_t need = lg - TREE_MAX_LOG;
+            const uint32_t need = lg - tail_log;
             const uint32_t stages = (need + MF_CAP_LOGK - 1) / MF_CAP_LOGK;
             k = std::max<uint32_t>((need + stages - 1) / stages, 3);   // a stage folds at least 3 variables (overshooting the tail size is fine)
         }
@@ -972,6 +987,90 @@ extern "C" int zkhip_sc_stage_fold(zkhip_sc_state* st) {
     st->stage_idx++;
     return ZKHIP_OK;
 }
+// ---- overlapped stage: the single-GPU plan of 2^19..2^24-entry tables (sumcheck_enqueue) in exchange form --------------
+// The local shard is summed once at FINE_CHUNK granularity.  Exchange 1 carries the 2^k1 coarse sums (k1 rounds on them,
+// replicated); the fine sums folded by those k1 variables are the block sums of the next k2 rounds, exchange 2 carries them
+// while the k1-variable fold of the shard runs on the context's fold stream; after the k2 rounds the fold's output is folded
+// by the k2 variables into a 256-entry local table (gathered by the caller for the last rounds).  Three exchanges in all,
+// as in the plain stage form, with the big fold hidden behind the second one and the serial kernel of the k2 rounds.
+extern "C" int zkhip_sc_overlap_plan(zkhip_sc_state* st, uint32_t world, uint32_t* k1, uint32_t* k2, uint32_t* mid_entries) {
+    if (!st || !k1 || !k2 || !mid_entries || !is_pow2(world)) return ZKHIP_ERR_ARG;
+    *k1 = *k2 = *mid_entries = 0;
+    if (st->round != 0 || st->stage_idx != 0 || st->ov_phase != 0 || !overlapped_plan(st->cn)) return ZKHIP_OK;
+    if ((size_t)256 * world > (size_t)zkhip_sc_tail_capacity()) return ZKHIP_OK;      // the gathered 256-entry tables must fit the tail
+    const uint32_t g = log2_exact(st->cn) - 8;
+    st->ov_k2 = overlapped_k2(st->cn);
+    st->ov_k1 = g - st->ov_k2;
+    BlockfoldShape sh;
+    if (!blockfold_shape(1u << st->ov_k2, st->ov_k1, &sh)) return ZKHIP_ERR_SHAPE;
+    st->ov_ny1 = sh.ny;
+    st->stage_world = world;
+    *k1 = st->ov_k1; *k2 = st->ov_k2; *mid_entries = sh.ny << st->ov_k2;
+    return ZKHIP_OK;
+}
+// d_out: the 2^k1 coarse block sums of the local shard (canonical integers; they add up across ranks all the same)
+extern "C" int zkhip_sc_overlap_sums(zkhip_sc_state* st, uint64_t* d_out) {
+    if (!st || !d_out || st->ov_k1 == 0 || st->ov_phase != 0) return ZKHIP_ERR_ARG;
+    zkhip_ctx* c = st->c;
+    ZK_TRY(c->activate());
+    const uint32_t g = st->ov_k1 + st->ov_k2;
+    ZK_TRY(launch_fine_sums(c, st->cur, st->cn, g, st->ov_fine(), nullptr));
+    hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << st->ov_k1), dim3(MLE_BLOCK), 0, c->stream, st->ov_fine(), 1u << st->ov_k2, (uint64_t*)nullptr, d_out);
+    ZK_HIP(c, hipGetLastError());
+    st->ov_phase = 1;
+    return ZKHIP_OK;
+}
+// d_gathered: [world][2^k1] coarse sums in rank order.  Runs rounds 1..k1, starts the k1-variable fold of the shard on the fold
+// stream and leaves this rank's partial block sums of the next k2 rounds in d_mid (mid_entries values).
+extern "C" int zkhip_sc_overlap_rounds1(zkhip_sc_state* st, const uint64_t* d_gathered, uint32_t world, const uint64_t* h_claimed, uint64_t* d_mid) {
+    if (!st || !d_gathered || !d_mid || st->ov_phase != 1 || world != st->stage_world) return ZKHIP_ERR_ARG;
+    zkhip_ctx* c = st->c;
+    ZK_TRY(c->activate());
+    ZK_TRY(c->ensure_fold_stream());
+    const uint32_t k1 = st->ov_k1, k2 = st->ov_k2;
+    SmallArgs a = {};
+    a.src = d_gathered; a.group = world; a.stride = 1u << k1; a.canon = 1; a.log_n = k1; a.n_rounds = k1; a.round0 = 0; a.first = 1;
+    if (h_claimed) { std::memcpy(a.claimed.v, h_claimed, 32); a.first = 2; }
+    a.weights_out = st->ov_w1(); a.final_out = nullptr;
+    ZK_TRY(launch_small(c, a, st->dev(), st->rp(), st->ch()));
+    uint32_t ny = 0, n_parts = 0;
+    ZK_TRY(launch_blockfold(c, c->stream, st->ov_fine(), 1u << k2, k1, st->ov_w1(), d_mid, &ny));
+    if (ny != st->ov_ny1) return ZKHIP_ERR_SHAPE;
+    ZK_HIP(c, hipEventRecord(c->fork_ev, c->stream));
+    ZK_HIP(c, hipStreamWaitEvent(c->fold_stream, c->fork_ev, 0));
+    ZK_TRY(launch_multifold(c, c->fold_stream, st->cur, st->cn, k1, st->ov_w1(), st->A, st->spx(), &n_parts));
+    ZK_HIP(c, hipEventRecord(c->join_ev, c->fold_stream));
+    st->round = k1;
+    st->ov_phase = 2;
+    return ZKHIP_OK;
+}
+// d_gathered: [world][mid_entries].  Runs rounds k1+1..k1+k2 beside the fold, joins it and folds its output by the k2
+// variables: the local table is 256 entries afterwards (zkhip_sc_local_table).
+extern "C" int zkhip_sc_overlap_rounds2(zkhip_sc_state* st, const uint64_t* d_gathered, uint32_t world) {
+    if (!st || !d_gathered || st->ov_phase != 2 || world != st->stage_world) return ZKHIP_ERR_ARG;
+    zkhip_ctx* c = st->c;
+    ZK_TRY(c->activate());
+    const uint32_t k1 = st->ov_k1, k2 = st->ov_k2;
+    SmallArgs b = {};
+    b.src = d_gathered; b.group = world * st->ov_ny1; b.stride = 1u << k2; b.canon = 1; b.log_n = k2; b.n_rounds = k2; b.round0 = k1; b.first = 0;
+    b.weights_out = st->ov_w2(); b.final_out = nullptr;
+    // no exclusive-CU request here (cf. sumcheck_enqueue): the exchange puts this launch tens of microseconds behind the fold's
+    // start, the chip is full by then and a whole free CU only appears when the fold drains
+    ZK_TRY(launch_small(c, b, st->dev(), st->rp(), st->ch()));
+    ZK_HIP(c, hipStreamWaitEvent(c->stream, c->join_ev, 0));
+    uint32_t ny = 0;
+    ZK_TRY(launch_blockfold(c, c->stream, st->A, 256, k2, st->ov_w2(), st->ov_p2(), &ny));
+    if (ny > 32) return ZKHIP_ERR_SHAPE;
+    hipLaunchKernelGGL(slice_sums_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, st->ov_p2(), ny, 256u, st->ov_loc());
+    ZK_HIP(c, hipGetLastError());
+    st->cur = st->ov_loc();
+    st->cn = 256;
+    st->round = k1 + k2;
+    st->partials_valid = false;
+    st->stage_idx++;
+    st->ov_phase = 3;
+    return ZKHIP_OK;
+}
 extern "C" int zkhip_sc_local_len(zkhip_sc_state* st, size_t* n) {
     if (!st || !n) return ZKHIP_ERR_ARG;
     *n = st->cn;
@@ -1031,17 +1130,35 @@ extern "C" int zkhip_sc_local_table(zkhip_sc_state* st, uint64_t* d_out) {
     ZK_HIP(st->c, hipMemcpyAsync(d_out, st->cur, 32 * st->cn, hipMemcpyDeviceToDevice, st->c->stream));
     return ZKHIP_OK;
 }
-extern "C" int zkhip_sc_tail_capacity(void) { return 1 << TREE_MAX_LOG; }
+// The gathered table may be twice what the serial kernel holds: its first round then runs on its own (half sums, transcript,
+// fold: four small launches) -- cheaper than one more round of the exchange protocol.
+extern "C" int zkhip_sc_tail_capacity(void) { return 2 << TREE_MAX_LOG; }
 extern "C" int zkhip_sc_tail(zkhip_sc_state* st, const uint64_t* d_values, uint32_t m, const uint64_t* h_claimed) {
     if (!st || !d_values) return ZKHIP_ERR_ARG;
-    if (!is_pow2(m) || m > (1u << TREE_MAX_LOG)) return ZKHIP_ERR_SHAPE;
+    if (!is_pow2(m) || m > (2u << TREE_MAX_LOG)) return ZKHIP_ERR_SHAPE;
     if (m == 1) return ZKHIP_OK;
     zkhip_ctx* c = st->c;
     ZK_TRY(c->activate());
+    uint32_t first = st->round == 0 ? 1u : 0u;
+    FrArg claimed = {};
+    if (first && h_claimed) { std::memcpy(claimed.v, h_claimed, 32); first = 2; }
+    if (m > (1u << TREE_MAX_LOG)) {
+        if (st->round >= ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
+        FrArg z = {};
+        const int grid = mle_grid((m + 3) / 4);
+        uint64_t* folded = st->partials() + 64;              // m/2 entries behind the two records of half sums
+        hipLaunchKernelGGL(half_sums_kernel, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_values, (size_t)m, st->partials());
+        hipLaunchKernelGGL(sumcheck_round_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, st->partials(), (uint32_t)grid, st->dev(), st->round,
+                           first, claimed, 0u, z, z, st->rp(), st->ch());
+        ZK_TRY(launch_fold(c, d_values, m, st->ch() + 4 * st->round, nullptr, 0, folded, false, nullptr, nullptr));
+        st->round++;
+        first = 0;
+        d_values = folded;
+        m >>= 1;
+    }
     SmallArgs a = {};
     a.src = d_values; a.group = 0; a.stride = 0; a.log_n = log2_exact(m); a.n_rounds = a.log_n; a.round0 = st->round;
-    a.first = st->round == 0 ? 1u : 0u;
-    if (a.first && h_claimed) { std::memcpy(a.claimed.v, h_claimed, 32); a.first = 2; }
+    a.first = first; a.claimed = claimed;
     a.weights_out = nullptr; a.final_out = st->fin();
     ZK_TRY(launch_small(c, a, st->dev(), st->rp(), st->ch()));
     st->round += a.log_n;

@@ -4,11 +4,15 @@ Only the hot path's two sharding schemes live here:
 
 * ShardedSumcheck -- the evaluation table of N = n_local * world entries is partitioned by the LOW index
   bits (rank g holds entry j*world + g at local index j).  Sumcheck rounds fold variable 0 = the most
-  significant index bit, so every fold is local.  Stage form (default): per k rounds the ranks all-gather
-  their 2^k partial block sums (8 KiB for k = 8; modular addition is not an RCCL reduction, so the payload is
-  gathered and added locally), run the k rounds on the summed block sums with a replicated transcript, and
-  fold their shard by k variables locally; once the remaining table fits one workgroup's LDS it is gathered
-  and the last rounds run replicated.  Round form (kept as a fallback): one 64-byte exchange per round.
+  significant index bit, so every fold is local.  Stage form: per k rounds the ranks all-gather their 2^k partial
+  block sums (8 KiB for k = 8; modular addition is not an RCCL reduction, so the payload is gathered and added
+  locally), run the k rounds on the summed block sums with a replicated transcript, and fold their shard by k
+  variables locally; once the remaining table fits the tail (2048 entries) it is gathered and the last rounds run
+  replicated.  Shards of 2^19..2^24 entries take the OVERLAPPED stage first (the single-GPU plan in exchange form):
+  k1 rounds on coarse sums, then k2 rounds on the fine sums folded by those k1 challenges while the shard's
+  k1-variable fold runs on the engine's fold stream -- the second exchange and the serial rounds hide behind the one
+  pass over the shard; 2^24 per rank on 8 ranks is 6 | 10 | 11 rounds and three exchanges.  Round form (kept as a
+  fallback): one 64-byte exchange per round.
 * sharded_commit -- (scalars, SRS points) are split the same way; each rank runs a full sub-MSM and the
   `world` partial commitments (104 bytes each) are all-gathered and summed.
 
@@ -88,6 +92,23 @@ class HipSumcheckEngine:
     def stage_fold(self):
         N.check(N.lib().zkhip_sc_stage_fold(self.st), "sc_stage_fold")
 
+    def overlap_plan(self, world):
+        """(k1, k2, mid_entries) of the overlapped stage, or None when it does not apply to this shard"""
+        k1, k2, mid = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        N.check(N.lib().zkhip_sc_overlap_plan(self.st, C.c_uint32(world), C.byref(k1), C.byref(k2), C.byref(mid)), "sc_overlap_plan")
+        return (k1.value, k2.value, mid.value) if k1.value else None
+
+    def overlap_sums(self, out):
+        N.check(N.lib().zkhip_sc_overlap_sums(self.st, N.ptr(out)), "sc_overlap_sums")
+
+    def overlap_rounds1(self, gathered, world, mid_out, claimed_sum=None):
+        cs = np.ascontiguousarray(claimed_sum, dtype=np.uint64) if claimed_sum is not None else None
+        N.check(N.lib().zkhip_sc_overlap_rounds1(self.st, N.ptr(gathered), C.c_uint32(world),
+                                                 cs.ctypes.data_as(C.c_void_p) if cs is not None else None, N.ptr(mid_out)), "sc_overlap_rounds1")
+
+    def overlap_rounds2(self, gathered, world):
+        N.check(N.lib().zkhip_sc_overlap_rounds2(self.st, N.ptr(gathered), C.c_uint32(world)), "sc_overlap_rounds2")
+
     def local_table(self, out):
         N.check(N.lib().zkhip_sc_local_table(self.st, N.ptr(out)), "sc_local_table")
 
@@ -146,6 +167,24 @@ class ShardedSumcheck:
         total_rounds = (n_local * world).bit_length() - 1
         absorbed = False
         self.exchanges = 0                 # collectives of this prove (what a multi-GPU run pays on top of the kernels)
+        plan = e.overlap_plan(world) if getattr(e, "use_stages", True) and hasattr(e, "overlap_plan") else None
+        if plan:
+            # overlapped stage (shards of 2^19..2^24 entries): k1 rounds on coarse block sums, then k2 rounds on the fine sums
+            # folded by those k1 challenges WHILE the shard's k1-variable fold runs on the engine's fold stream -- the second
+            # exchange and the serial rounds hide behind the one pass over the shard
+            k1, k2, mid = plan
+            mine = e.new_buffer(1 << k1, 4)
+            e.overlap_sums(mine)
+            gathered = e.new_buffer(world, 1 << k1, 4)
+            _all_gather(self.dist, self.group, gathered, mine, world)          # C1
+            mine = e.new_buffer(mid, 4)
+            e.overlap_rounds1(gathered, world, mine, claimed_sum)
+            gathered = e.new_buffer(world, mid, 4)
+            _all_gather(self.dist, self.group, gathered, mine, world)          # C2, beside the fold
+            e.overlap_rounds2(gathered, world)
+            self.exchanges += 2
+            absorbed = True
+            n_local >>= k1 + k2
         if getattr(e, "use_stages", True) and hasattr(e, "stage_plan"):
             # stage form: one exchange per k rounds (32 * 2^k bytes per rank), then one local k-variable fold
             while True:
