@@ -130,8 +130,29 @@ class MultiComposedSumcheckProof:
     """multi_composed_sumcheck.rs:12-16 (named ComposedSumcheckProof there): {round_polys, sum}"""
 
     def __init__(self, round_polys, sum_):
-        self.round_polys = round_polys
+        self._round_polys = round_polys
+        self._packed = None
         self.sum = sum_
+
+    @classmethod
+    def from_packed(cls, monomials, lens, sum_):
+        """The prover's output as it comes off the device -- monomials uint64 [n_rounds, MAX_MONO, 2, 4] (coeff, pow), lens
+        [n_rounds] -- wrapped without building a SparseUnivariatePolynomial per round; `round_polys` builds them on first
+        use (a depth-20 GKR proof has ~420 rounds, and host time between proofs is GPU idle time)."""
+        self = cls(None, sum_)
+        self._packed = (monomials, lens)
+        return self
+
+    @property
+    def round_polys(self):
+        if self._round_polys is None:
+            mono, lens = self._packed
+            self._round_polys = [SparseUnivariatePolynomial(mono[r, : lens[r], 0].copy(), mono[r, : lens[r], 1].copy()) for r in range(len(lens))]
+        return self._round_polys
+
+    @round_polys.setter
+    def round_polys(self, v):
+        self._round_polys = v
 
     def to_bytes(self):
         """multi_composed_sumcheck.rs:24-31"""

@@ -88,6 +88,40 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_table_kernel(const ui
         store_fr(out, i, acc);
     }
 }
+// Wide layers (more than GKR_EQ_LO index bits) build their eq tables from two halves instead of n_vars products per entry:
+//   eq_x(u) = hi[x >> n_lo] * lo[x & (2^n_lo - 1)],  hi over the first n_vars - n_lo points, lo over the last n_lo,
+// one product per entry after a tiny kernel for the halves (exact arithmetic: the same field elements).  blockIdx.y selects
+// the point (gate weights take two, scaled by alpha / beta through their hi halves); the points come from device memory
+// (u_dev, the challenges a sumcheck left there) or by value.
+constexpr uint32_t GKR_EQ_LO = 10;
+constexpr uint32_t GKR_EQ_HALVES = 2u << GKR_EQ_LO;        // entries reserved per point: hi (<= 2^10) then lo (2^10)
+static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_halves_kernel(const uint64_t* __restrict__ u_dev, PtsArg p0, PtsArg p1, uint32_t n_vars,
+                                                                  FrArg scale0, FrArg scale1, uint32_t scaled, uint64_t* __restrict__ out) {
+    const uint32_t n_lo = GKR_EQ_LO, n_hi = n_vars - n_lo, pt = blockIdx.y;
+    const uint32_t e = blockIdx.x * MLE_BLOCK + threadIdx.x;
+    const uint32_t hi_cnt = 1u << n_hi;
+    if (e >= hi_cnt + (1u << n_lo)) return;
+    const bool is_hi = e < hi_cnt;
+    const uint32_t idx = is_hi ? e : e - hi_cnt, first = is_hi ? 0 : n_hi, cnt = is_hi ? n_hi : n_lo;
+    const Fr one = Fr::one();
+    Fr acc = (is_hi && scaled) ? fr_from_arg(pt ? scale1 : scale0) : one;
+    for (uint32_t j = 0; j < cnt; ++j) {
+        const Fr t = u_dev ? load_fr(u_dev, first + j) : fr_from_pts(pt ? p1 : p0, first + j);
+        acc = acc * (((idx >> (cnt - 1 - j)) & 1) ? t : one - t);
+    }
+    store_fr(out, (size_t)pt * GKR_EQ_HALVES + (is_hi ? idx : (GKR_EQ_HALVES >> 1) + idx), acc);
+}
+// out[x] = sum over the n_points points of hi[x >> 10] * lo[x & 1023]
+static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_expand_kernel(const uint64_t* __restrict__ halves, uint32_t n_points, size_t n,
+                                                                  uint64_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    for (size_t i = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint32_t h = (uint32_t)(i >> GKR_EQ_LO), l = (uint32_t)(i & ((1u << GKR_EQ_LO) - 1));
+        Fr acc = load_fr(halves, h) * load_fr(halves, (GKR_EQ_HALVES >> 1) + l);
+        if (n_points == 2) acc = acc + load_fr(halves, GKR_EQ_HALVES + h) * load_fr(halves, GKR_EQ_HALVES + (GKR_EQ_HALVES >> 1) + l);
+        store_fr(out, i, acc);
+    }
+}
 // t1[c] = V(u) + V[c]  (wb_add_wc with b at u),  t2[c] = V(u) V[c]  (wb_mul_wc with b at u)
 static __global__ __launch_bounds__(MLE_BLOCK) void gkr_vu_tables_kernel(const uint64_t* __restrict__ v, size_t n, const uint64_t* __restrict__ vu_ptr,
                                                                   uint64_t* __restrict__ t1, uint64_t* __restrict__ t2) {
@@ -117,6 +151,33 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_dot_finish_kernel(const 
     for (uint32_t i = threadIdx.x; i < n_partials; i += MLE_BLOCK) s = s + load_fr(partials, i);
     s = block_reduce_fr(s, red);
     if (threadIdx.x == 0) store_fr(out, 0, s);
+}
+// eq_x(u) for all x < 2^n_vars, u in device memory
+static void launch_eq_table(zkhip_ctx* c, const uint64_t* d_u, uint32_t n_vars, uint64_t* d_halves, uint64_t* d_out) {
+    const size_t n = (size_t)1 << n_vars;
+    if (n_vars <= GKR_EQ_LO) {
+        hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid_stream(n)), dim3(MLE_BLOCK), 0, c->stream, d_u, n_vars, d_out);
+        return;
+    }
+    PtsArg none = {};
+    FrArg z = {};
+    const uint32_t cnt = (1u << (n_vars - GKR_EQ_LO)) + (1u << GKR_EQ_LO);
+    hipLaunchKernelGGL(gkr_eq_halves_kernel, dim3((cnt + MLE_BLOCK - 1) / MLE_BLOCK, 1), dim3(MLE_BLOCK), 0, c->stream, d_u, none, none, n_vars, z, z, 0u, d_halves);
+    hipLaunchKernelGGL(gkr_eq_expand_kernel, dim3(mle_grid_stream(n)), dim3(MLE_BLOCK), 0, c->stream, d_halves, 1u, n, d_out);
+}
+// w_g = eq_g(r_b)  or  alpha eq_g(r_b) + beta eq_g(r_c)
+static void launch_gate_weights(zkhip_ctx* c, size_t n_gates, uint32_t n_gate_vars, const PtsArg& pb, const PtsArg& pc, const FrArg& av,
+                                const FrArg& bv, bool two_points, uint64_t* d_halves, uint64_t* d_wg) {
+    if (!n_gates) return;
+    if (n_gate_vars <= GKR_EQ_LO) {
+        hipLaunchKernelGGL(gkr_gate_weights_kernel, dim3((unsigned)((n_gates + MLE_BLOCK - 1) / MLE_BLOCK)), dim3(MLE_BLOCK), 0, c->stream,
+                           (uint32_t)n_gates, n_gate_vars, pb, pc, av, bv, two_points ? 1u : 0u, d_wg);
+        return;
+    }
+    const uint32_t cnt = (1u << (n_gate_vars - GKR_EQ_LO)) + (1u << GKR_EQ_LO);
+    hipLaunchKernelGGL(gkr_eq_halves_kernel, dim3((cnt + MLE_BLOCK - 1) / MLE_BLOCK, two_points ? 2 : 1), dim3(MLE_BLOCK), 0, c->stream,
+                       (const uint64_t*)nullptr, pb, pc, n_gate_vars, av, bv, two_points ? 1u : 0u, d_halves);
+    hipLaunchKernelGGL(gkr_eq_expand_kernel, dim3(mle_grid_stream(n_gates)), dim3(MLE_BLOCK), 0, c->stream, d_halves, two_points ? 2u : 1u, n_gates, d_wg);
 }
 }  // namespace zk
 
@@ -167,6 +228,7 @@ static void group_gates(const uint32_t* key, size_t n_gates, size_t n_rows, std:
 // device scratch of one layer (carved from the context's aux buffer)
 struct LayerScratch {
     uint64_t *wg, *ha0, *ha1, *hm, *equ, *aa, *am, *t1, *t2;
+    uint64_t* eqh;                    // halves of the eq tables of wide layers (2 points x GKR_EQ_HALVES entries)
     uint64_t *dot_partials, *evals;   // workgroup partials of gkr_dot_kernel; evals[0..4) = V(u) = w_b, evals[4..8) = V(r_c) = w_c
 };
 // one layer of a device-resident circuit: the gate arrays and their two CSR groupings (by in0 and by in1)
@@ -195,10 +257,8 @@ int layer_prove(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_
     FrArg av = {}, bv = {};
     std::memcpy(av.v, alpha.l, 32);
     std::memcpy(bv.v, beta.l, 32);
-    const unsigned gg = (unsigned)((n_gates + MLE_BLOCK - 1) / MLE_BLOCK), gw = (unsigned)((w_len + MLE_BLOCK - 1) / MLE_BLOCK);
-    if (n_gates)
-        hipLaunchKernelGGL(gkr_gate_weights_kernel, dim3(gg), dim3(MLE_BLOCK), 0, c->stream, (uint32_t)n_gates, n_gate_vars, pb, pc, av, bv,
-                           two_points ? 1u : 0u, sc.wg);
+    const unsigned gw = (unsigned)((w_len + MLE_BLOCK - 1) / MLE_BLOCK);
+    launch_gate_weights(c, n_gates, n_gate_vars, pb, pc, av, bv, two_points, sc.eqh, sc.wg);
     // ---- rounds over b
     hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr0, ld.csr0 + w_len + 1, ld.type, ld.in1, sc.wg, d_w,
                        (uint32_t)w_len, 1u, sc.ha0, sc.ha1, sc.hm);
@@ -227,7 +287,7 @@ int layer_prove(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_
         ZK_TRY(zk_multi_composed_enqueue(c, tables, sizes, lin, 2, w_len, claimed.l, 0, 0));
     }
     // ---- rounds over c, b at u = the challenges just recorded
-    hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_ch, s, sc.equ);
+    launch_eq_table(c, d_ch, s, sc.eqh, sc.equ);
     dot(sc.evals);                                         // V(u): w_b and the factor of the second phase
     hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr1, ld.csr1 + w_len + 1, ld.type, ld.in0, sc.wg, sc.equ,
                        (uint32_t)w_len, 2u, sc.aa, (uint64_t*)nullptr, sc.am);
@@ -238,7 +298,7 @@ int layer_prove(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_
         ZK_TRY(zk_multi_composed_enqueue(c, tables, sizes, nullptr, 2, w_len, nullptr, 1, s));
     }
     // w_c = V(r_c), r_c = the second half of the challenges
-    hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_ch + 4 * (size_t)s, s, sc.equ);
+    launch_eq_table(c, d_ch + 4 * (size_t)s, s, sc.eqh, sc.equ);
     dot(sc.evals + 4);
     ZK_HIP(c, hipGetLastError());
     zkhost::Fr eval_wb, eval_wc;
@@ -360,7 +420,8 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t tb = al(32 * max_w);
     const size_t o_w0 = 0, o_tab = al(64), o_wg = o_tab + 8 * tb, o_dot = o_wg + al(32 * max_g), o_ev = o_dot + al(32 * (size_t)zk::MLE_MAX_GRID);
-    ZK_TRY(c->reserve_aux(o_ev + 256));
+    const size_t o_eqh = o_ev + 256;
+    ZK_TRY(c->reserve_aux(o_eqh + 32 * 2 * (size_t)zk::GKR_EQ_HALVES));
     char* aux = (char*)c->d_aux;
     uint64_t* d_w0 = (uint64_t*)(aux + o_w0);
     LayerScratch sc;
@@ -368,7 +429,7 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
     sc.equ = (uint64_t*)(aux + o_tab + 3 * tb); sc.aa = (uint64_t*)(aux + o_tab + 4 * tb); sc.am = (uint64_t*)(aux + o_tab + 5 * tb);
     sc.t1 = (uint64_t*)(aux + o_tab + 6 * tb); sc.t2 = (uint64_t*)(aux + o_tab + 7 * tb);
     sc.wg = (uint64_t*)(aux + o_wg);
-    sc.dot_partials = (uint64_t*)(aux + o_dot); sc.evals = (uint64_t*)(aux + o_ev);
+    sc.dot_partials = (uint64_t*)(aux + o_dot); sc.evals = (uint64_t*)(aux + o_ev); sc.eqh = (uint64_t*)(aux + o_eqh);
     LayerOut out = {h_sums, h_round_polys, h_wb, h_wc, h_challenges, h_n_rounds, h_round_poly_lens, 2 * n_layers};
 
     // w_0 = circuit_evaluation[0] padded with a zero (protocol.rs:30-33); commit its bytes, draw n_r
@@ -423,8 +484,10 @@ extern "C" int zkhip_gkr_layer_tables(zkhip_circuit* cir, uint32_t layer, const 
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_wg = 0, o_equ = o_wg + al(32 * std::max<size_t>(ld.n_gates, 1)), o_dot = o_equ + al(32 * w_len),
                  o_ev = o_dot + al(32 * (size_t)zk::MLE_MAX_GRID);
-    ZK_TRY(c->reserve_aux(o_ev + 256));
+    const size_t o_eqh = o_ev + 256;
+    ZK_TRY(c->reserve_aux(o_eqh + 32 * 2 * (size_t)zk::GKR_EQ_HALVES));
     char* aux = (char*)c->d_aux;
+    uint64_t* eqh = (uint64_t*)(aux + o_eqh);
     uint64_t* wg = (uint64_t*)(aux + o_wg);
     uint64_t* equ = (uint64_t*)(aux + o_equ);
     uint64_t* dot_partials = (uint64_t*)(aux + o_dot);
@@ -435,10 +498,8 @@ extern "C" int zkhip_gkr_layer_tables(zkhip_circuit* cir, uint32_t layer, const 
     FrArg av = {}, bv = {};
     std::memcpy(av.v, h_alpha, 32);
     std::memcpy(bv.v, h_beta, 32);
-    const unsigned gg = (unsigned)((ld.n_gates + MLE_BLOCK - 1) / MLE_BLOCK), gw = (unsigned)((w_len + MLE_BLOCK - 1) / MLE_BLOCK);
-    if (ld.n_gates)
-        hipLaunchKernelGGL(gkr_gate_weights_kernel, dim3(gg), dim3(MLE_BLOCK), 0, c->stream, (uint32_t)ld.n_gates, n_gate_vars, pb, pc, av, bv,
-                           two_points ? 1u : 0u, wg);
+    const unsigned gw = (unsigned)((w_len + MLE_BLOCK - 1) / MLE_BLOCK);
+    launch_gate_weights(c, ld.n_gates, n_gate_vars, pb, pc, av, bv, two_points, eqh, wg);
     if (phase == 0) {
         hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr0, ld.csr0 + w_len + 1, ld.type, ld.in1, wg, d_w,
                            (uint32_t)w_len, 1u, d_out[0], d_out[1], d_out[2]);
@@ -446,7 +507,7 @@ extern "C" int zkhip_gkr_layer_tables(zkhip_circuit* cir, uint32_t layer, const 
         return ZKHIP_OK;
     }
     const uint64_t* d_ch = zk_composed_challenges_dev(c);       // the s challenges of the rounds over b
-    hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_ch, s, equ);
+    launch_eq_table(c, d_ch, s, eqh, equ);
     const int dot_grid = mle_grid(w_len);
     if (dot_grid == 1) {
         hipLaunchKernelGGL(gkr_dot_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, equ, d_w, w_len, evals);

@@ -190,7 +190,7 @@ class GKRProtocol:
     def prove(circuit, circuit_evaluation):
         """GKRProtocol::prove (protocol.rs:21-117) through the single C-ABI entry point zkhip_gkr_prove;
         circuit_evaluation as returned by Circuit.evaluation (device tables)."""
-        from zk_cryptography_amd.composed import MAX_MONO, MultiComposedSumcheckProof, SparseUnivariatePolynomial
+        from zk_cryptography_amd.composed import MAX_MONO, MultiComposedSumcheckProof
         nl = len(circuit.layers)
         assert len(circuit_evaluation) == nl + 1
         shape = [len(layer.layer) for layer in circuit.layers]
@@ -213,13 +213,11 @@ class GKRProtocol:
             dev = circuit._device = _DeviceCircuit(ctx, circuit, shape)
         st = N.lib().zkhip_gkr_prove_circuit(dev.handle, ptrs, lens, p(sums), p(n_rounds), p(rp_lens), p(rps), p(wb), p(wc), p(w0), p(chal))
         N.check(st, "gkr_prove: every layer must hold a power-of-two number of values, 2^l gates in layer l")
-        proofs = []
-        for k in range(nl):
-            polys = [SparseUnivariatePolynomial(rps[k, r, : rp_lens[k, r], 0].copy(), rps[k, r, : rp_lens[k, r], 1].copy())
-                     for r in range(n_rounds[k])]
-            proofs.append(MultiComposedSumcheckProof(polys, sums[k].copy()))
-        proof = GKRProof(proofs, [wb[k].copy() for k in range(nl)], [wc[k].copy() for k in range(nl)], Multilinear(w0))
-        proof._challenges = [chal[k, : n_rounds[k]].copy() for k in range(nl)]   # not part of the reference's struct
+        # the arrays above belong to this proof alone: the per-layer proofs are views into them (round polynomials are
+        # unpacked into SparseUnivariatePolynomial objects on first use)
+        proofs = [MultiComposedSumcheckProof.from_packed(rps[k, : n_rounds[k]], rp_lens[k, : n_rounds[k]], sums[k]) for k in range(nl)]
+        proof = GKRProof(proofs, list(wb), list(wc), Multilinear(w0))
+        proof._challenges = [chal[k, : n_rounds[k]] for k in range(nl)]   # not part of the reference's struct
         return proof
 
     @staticmethod
