@@ -14,6 +14,7 @@
 // Algorithmic traffic per round and table: read 32 n + write 16 n bytes (n = entries before the fold).
 #pragma once
 #include "mle_kernels.hpp"
+#include "stamps.hpp"
 
 namespace zk {
 
@@ -83,6 +84,24 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_elementwise_kernel(
     }
 }
 
+// x / 2 mod r on the limbs (any representation: halving is linear): x even -> x >> 1, else (x + r) >> 1 (x + r < 2^256)
+__device__ __forceinline__ Fr fr_half(const Fr& x) {
+    uint32_t t[9];
+    const uint32_t odd = x.l[0] & 1u;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint64_t s = (uint64_t)x.l[i] + (odd ? FrParams::p(i) : 0u) + carry;
+        t[i] = (uint32_t)s;
+        carry = s >> 32;
+    }
+    t[8] = (uint32_t)carry;
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = (t[i] >> 1) | (t[i + 1] << 31);
+    return r;
+}
+
 // ---- closing a round ------------------------------------------------------------------------------------
 struct ComposedMeta {
     uint32_t n_terms;
@@ -101,6 +120,7 @@ struct ComposedDev {                   // one per context, persistent: a continu
 struct CloseShared {                   // LDS scratch of close_round
     Fr evals[CMP_MAX_REC];             // the round's sums: term p's evaluations at t = 0..K_p from rec_off[p]
     Fr prod[CMP_MAX_REC * (CMP_MAX_K + 1)];   // interpolation products, (record entry, i)
+    Fr interp_c[CMP_MAX_TERMS * (CMP_MAX_K + 1) * (CMP_MAX_K + 1)];   // this lane's interpolation matrix entry (close_preload), by product index
     Fr term_coeff[CMP_MAX_TERMS][CMP_MAX_MONO];
     Fr canon[CMP_MAX_MONO];            // canonical integers of what the transcript absorbs, in order
     uint32_t pow_of[CMP_MAX_MONO];
@@ -122,11 +142,25 @@ struct CloseShared {                   // LDS scratch of close_round
 // Output per round (round_out + 64 * round, in u64):
 //   multi == 0: K+1 evaluations (4 u64 each);  multi == 1: [0] = #monomials, then (coeff, pow) pairs of 8 u64 from [8].
 // Only the hash chain is serial (thread 0); interpolation products and Montgomery conversions run one per lane.
+// Once per kernel, before the first close_round (every thread; a barrier must follow before the round is closed): the
+// interpolation matrix entries the lanes multiply by, out of global memory into LDS -- a 2 us load on every round's critical
+// path otherwise.
+__device__ __forceinline__ void close_preload(CloseShared& sh, const ComposedMeta& meta, const ComposedDev* st) {
+    if (!meta.multi) return;
+    const uint32_t tid = threadIdx.x;
+    uint32_t p = 0, base = 0;
+    while (p < meta.n_terms && tid >= base + (meta.k[p] + 1) * (meta.k[p] + 1)) { base += (meta.k[p] + 1) * (meta.k[p] + 1); ++p; }
+    if (p < meta.n_terms) {
+        const uint32_t d = meta.k[p], e = tid - base;
+        sh.interp_c[tid] = load_fr(&st->interp[d][e][0], 0);
+    }
+}
 __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta& meta, ComposedDev* st, const FrArg& claimed_sum, Sha256State* tr_state,
                                             uint32_t round, uint32_t first, uint64_t* __restrict__ round_out,
                                             uint64_t* __restrict__ challenges) {
     uint64_t* out = round_out + 64 * (size_t)round;
     const uint32_t tid = threadIdx.x;
+    ZK_STAMP_AT(0, round, 0);
     if (!meta.multi) {
         // transcript.commit(&vec_to_bytes(&round_poly))  composed_sumcheck.rs:51: the raw evaluations
         if (tid <= meta.k[0]) {
@@ -138,25 +172,46 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
     } else {
         // round_poly = sum over terms of interpolation(evals at x = 0..K)  (:79-95); coefficients that are zero
         // are dropped per term (sparse_univariate.rs:55) but a zero produced by the sum is kept (:159-203).
-        // coefficient k of term p = sum_i interp[d][k][i] * eval_i: one lane per product (p, k, i) -- at most 4 * 36 of them --
-        // then one lane per coefficient adds its d + 1 products; a chain of d + 1 products per lane cost 2.6 us per round
-        {
-            uint32_t p = 0, base = 0;
-            while (p < meta.n_terms && tid >= base + (meta.k[p] + 1) * (meta.k[p] + 1)) { base += (meta.k[p] + 1) * (meta.k[p] + 1); ++p; }
-            if (p < meta.n_terms) {
-                const uint32_t d = meta.k[p], e = tid - base, k = e / (d + 1), i = e % (d + 1);
-                sh.prod[(meta.rec_off[p] + k) * (CMP_MAX_K + 1) + i] =
-                    fr_mul_outlined(load_fr(&st->interp[d][k * (d + 1) + i][0], 0), sh.evals[meta.rec_off[p] + i]);
+        // Degrees <= 2 (every GKR term) need no interpolation matrix: c0 = e0, c2 = (e0 - 2 e1 + e2) / 2, c1 = e1 - e0 - c2 -- additions
+        // and one halving per lane instead of a product, a sum of products and a barrier between them (2 us of every round).
+        // Higher degrees: coefficient k of term p = sum_i interp[d][k][i] * eval_i, one lane per product (p, k, i) -- at most
+        // 4 * 36 of them -- then one lane per coefficient adds its d + 1 products.
+        bool low = true;
+        for (uint32_t p = 0; p < meta.n_terms; ++p) low = low && meta.k[p] <= 2;
+        if (low) {
+            if (tid < meta.rec) {
+                uint32_t p = 0;
+                while (p + 1 < meta.n_terms && tid >= meta.rec_off[p + 1]) ++p;
+                const uint32_t d = meta.k[p], k = tid - meta.rec_off[p];
+                const Fr e0 = sh.evals[meta.rec_off[p]], e1 = sh.evals[meta.rec_off[p] + 1];
+                Fr c = e0;
+                if (k > 0) {
+                    if (d == 1) c = e1 - e0;
+                    else {
+                        const Fr c2 = fr_half(e0 - (e1 + e1) + sh.evals[meta.rec_off[p] + 2]);
+                        c = k == 2 ? c2 : e1 - e0 - c2;
+                    }
+                }
+                sh.term_coeff[p][k] = c;
             }
-        }
-        __syncthreads();
-        if (tid < meta.rec) {
-            uint32_t p = 0;
-            while (p + 1 < meta.n_terms && tid >= meta.rec_off[p + 1]) ++p;
-            const uint32_t d = meta.k[p], k = tid - meta.rec_off[p];
-            Fr c = sh.prod[tid * (CMP_MAX_K + 1)];
-            for (uint32_t i = 1; i <= d; ++i) c = c + sh.prod[tid * (CMP_MAX_K + 1) + i];
-            sh.term_coeff[p][k] = c;
+        } else {
+            {
+                uint32_t p = 0, base = 0;
+                while (p < meta.n_terms && tid >= base + (meta.k[p] + 1) * (meta.k[p] + 1)) { base += (meta.k[p] + 1) * (meta.k[p] + 1); ++p; }
+                if (p < meta.n_terms) {
+                    const uint32_t d = meta.k[p], e = tid - base, k = e / (d + 1), i = e % (d + 1);
+                    sh.prod[(meta.rec_off[p] + k) * (CMP_MAX_K + 1) + i] = fr_mul_outlined(sh.interp_c[tid], sh.evals[meta.rec_off[p] + i]);
+                }
+            }
+            __syncthreads();
+            if (tid < meta.rec) {
+                uint32_t p = 0;
+                while (p + 1 < meta.n_terms && tid >= meta.rec_off[p + 1]) ++p;
+                const uint32_t d = meta.k[p], k = tid - meta.rec_off[p];
+                Fr c = sh.prod[tid * (CMP_MAX_K + 1)];
+                for (uint32_t i = 1; i <= d; ++i) c = c + sh.prod[tid * (CMP_MAX_K + 1) + i];
+                sh.term_coeff[p][k] = c;
+            }
         }
         __syncthreads();
         if (tid < 64) {   // lanes 0..6 of wave 0: one power each
@@ -184,6 +239,7 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
     }
     if (meta.multi && first && tid == 64) sh.sum_canon = fr_from_mont_outlined(fr_from_arg(claimed_sum));   // multi_composed_sumcheck.rs:70
     __syncthreads();
+    ZK_STAMP_AT(0, round, 1);
     // ---- the round's message, padded (FiatShamirTranscript: commit ... then challenge = finalize, fiat_shamir.rs:17-25):
     // what the hasher still holds || [claimed sum] || items || 0x80 00.. || bit length.  Every word is written by one lane.
     {
@@ -210,11 +266,13 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
         if (tid == 0) sh.n_blocks = n_blocks;
     }
     __syncthreads();
+    ZK_STAMP_AT(0, round, 2);
     {   // schedules: wave w takes the blocks w, w + #waves, ...
         const uint32_t wave = tid >> 6, n_waves = blockDim.x >> 6;
         for (uint32_t b = wave; b < sh.n_blocks; b += n_waves) sha256_schedule_block(sh.msg + 16 * b, sh.kw + 64 * b);
     }
     __syncthreads();
+    ZK_STAMP_AT(0, round, 3);
     if (tid < 64) {   // wave 0: the state rounds of every block, then the challenge
         uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
         if (first != 1) {
@@ -223,6 +281,7 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
         }
         const uint32_t n_blocks = sh.n_blocks;
         for (uint32_t b = 0; b < n_blocks; ++b) sha256_rounds_block(h, sh.kw + 64 * b);
+        ZK_STAMP_AT(0, round, 4);
         Fr c;                                                   // from_be_bytes_mod_order (fiat_shamir.rs:27-29)
 #pragma unroll
         for (int i = 0; i < 8; ++i) c.l[i] = h[7 - i];
@@ -239,6 +298,7 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
         }
     }
     __syncthreads();
+    ZK_STAMP_AT(0, round, 5);
 }
 
 // One round of one product term.
@@ -381,15 +441,35 @@ struct CloseArgs {
 static __global__ __launch_bounds__(MLE_BLOCK) void composed_close_kernel(const uint64_t* __restrict__ partials, uint32_t n_partials,
                                                                    CloseArgs ca) {
     __shared__ CloseShared sh;
+    __shared__ Sha256State trs;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t v = wave; v < ca.meta.rec; v += MLE_BLOCK / 64) {
-        Fr s = Fr::zero();
-        for (uint32_t b = lane; b < n_partials; b += 64) s = s + load_fr(partials, (size_t)b * ca.meta.rec + v);
-        s = wave_reduce_fr(s);
-        if (lane == 0) sh.evals[v] = s;
+    ZK_STAMP_AT(0, ca.round, 6);
+    // the transcript state and the interpolation entries travel to LDS while the records are summed
+    if (ca.first != 1 && threadIdx.x < sizeof(Sha256State) / 4)
+        reinterpret_cast<uint32_t*>(&trs)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&ca.st->transcript)[threadIdx.x];
+    close_preload(sh, ca.meta, ca.st);
+    // wave w sums the values v = w, w + 4, ... of the records; the loads of all its values are issued before the first reduction
+    constexpr int PER_WAVE = (CMP_MAX_REC + MLE_BLOCK / 64 - 1) / (MLE_BLOCK / 64);
+    Fr s[PER_WAVE];
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; ++q) {
+        const uint32_t v = wave + q * (MLE_BLOCK / 64);
+        s[q] = Fr::zero();
+        if (v < ca.meta.rec)
+            for (uint32_t b = lane; b < n_partials; b += 64) s[q] = s[q] + load_fr(partials, (size_t)b * ca.meta.rec + v);
+    }
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; ++q) {
+        const uint32_t v = wave + q * (MLE_BLOCK / 64);
+        if (v < ca.meta.rec) {
+            const Fr t = wave_reduce_fr(s[q]);
+            if (lane == 0) sh.evals[v] = t;
+        }
     }
     __syncthreads();
-    close_round(sh, ca.meta, ca.st, ca.sum, &ca.st->transcript, ca.round, ca.first, ca.round_out, ca.challenges);
+    close_round(sh, ca.meta, ca.st, ca.sum, &trs, ca.round, ca.first, ca.round_out, ca.challenges);
+    if (threadIdx.x < sizeof(Sha256State) / 4)
+        reinterpret_cast<uint32_t*>(&ca.st->transcript)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&trs)[threadIdx.x];
 }
 
 // the records of a round summed into one (what a rank contributes to the exchange of the sharded protocol)
@@ -500,11 +580,13 @@ static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(Ta
         }
         if (threadIdx.x < sizeof(Sha256State) / 4)
             reinterpret_cast<uint32_t*>(&trs)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&ca.st->transcript)[threadIdx.x];
+        close_preload(sh, ca.meta, ca.st);
     }
     __syncthreads();
     uint32_t cn = m, first = ca.first;
     const uint32_t wave = threadIdx.x >> 6;
     for (uint32_t round = ca.round; round < ca.round + n_rounds; ++round) {
+        ZK_STAMP_AT(0, round, 6);
         // Late rounds (all pairs fit one wave): wave w computes evaluation w of the record -- one point t of one term -- for
         // every pair and reduces it, so the critical path is K - 1 products and ONE wave reduction instead of all (K + 1) points
         // of all terms one after another on the same lanes.  Field arithmetic is exact: same sums.
@@ -551,6 +633,7 @@ static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(Ta
                 lds_store_fr(tab, q * m + j, fold_pair(lo, hi, r));
             }
             __syncthreads();
+            ZK_STAMP_AT(0, round, 7);
             cn = half;
             continue;
         }
@@ -585,6 +668,7 @@ static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(Ta
             lds_store_fr(tab, q * m + j, fold_pair(lo, hi, r));
         }
         __syncthreads();
+        ZK_STAMP_AT(0, round, 7);
         cn = half;
     }
     // hand the transcript back (a later call may continue this sumcheck's rounds: composed.hip `cont`)
