@@ -37,12 +37,19 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { r
 __device__ __forceinline__ uint32_t choose(uint32_t e, uint32_t f, uint32_t g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA); }
 __device__ __forceinline__ uint32_t majority(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
 
+// A lone wave issues one instruction per 4 (VOP2) or 5 (VOP3) cycles whatever the dependencies (profiles/r02/ubench_salu_gfx950.txt),
+// so a round costs its instruction count: 6 rotates + 4 three-input booleans + 4 additions -- two of them v_add3_u32, which the
+// compiler does not form by itself here (it emitted six two-input additions).
+__device__ __forceinline__ uint32_t add3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 #define ZK_SHA_ROUND(a, b, c, d, e, f, g, h, kw)                                      \
     {                                                                                 \
-        uint32_t t1 = h + xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)) + choose(e, f, g) + (kw); \
-        uint32_t t2 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)) + majority(a, b, c);          \
+        uint32_t t1 = add3(h + (kw), xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)), choose(e, f, g)); \
         d += t1;                                                                      \
-        h = t1 + t2;                                                                  \
+        h = add3(t1, xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)), majority(a, b, c));             \
     }
 #define ZK_SHA_8ROUNDS(W, KB)                                    \
     ZK_SHA_ROUND(a, b, c, d, e, f, g, hh, SHA256_K[KB + 0] + W[0]) \
