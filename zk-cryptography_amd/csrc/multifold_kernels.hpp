@@ -553,12 +553,6 @@ static __global__ __launch_bounds__(1024) void multifold_kernel(const uint64_t* 
     }
 }
 
-// ---- k-variable fold of a SMALL table (<= 2^18 entries), spread over the chip -----------------------------------------
-// partial[y*m + c] = sum over the term range y of w[b] * in[b*m + c], as CANONICAL integers (the serial kernel's form; the
-// conversion is linear, so partial tables still add up).  multifold_kernel<16> gives such a table to m/16 workgroups (16 at
-// m = 256: ~16 us of one-wave-per-SIMD latency); here a workgroup of 1024 lanes takes OW outputs x (1024/OW) term slices
-// of <= 4 terms each, sums the slices in LDS, and the term ranges go to blockIdx.y: 2^18 entries are 64 workgroups of
-// 4 products per lane.  The serial kernel adds the gridDim.y (<= 8) partial tables (SmallArgs::stride).
 // out[j] = to_mont(sum_y in[y*m + j]): the partial tables of blockfold_kernel added up and brought back to Montgomery form
 // (the sharded prover's local 256-entry table before it is gathered)
 static __global__ __launch_bounds__(MLE_BLOCK) void slice_sums_kernel(const uint64_t* __restrict__ in, uint32_t ny, uint32_t m,
@@ -570,6 +564,12 @@ static __global__ __launch_bounds__(MLE_BLOCK) void slice_sums_kernel(const uint
     store_fr(out, j, fr_to_mont_outlined(s));
 }
 
+// ---- k-variable fold of a SMALL table (<= 2^18 entries), spread over the chip -----------------------------------------
+// partial[y*m + c] = sum over the term range y of w[b] * in[b*m + c], as CANONICAL integers (the serial kernel's form; the
+// conversion is linear, so partial tables still add up).  multifold_kernel<16> gives such a table to m/16 workgroups (16 at
+// m = 256: ~16 us of one-wave-per-SIMD latency); here a workgroup of 1024 lanes takes OW outputs x (1024/OW) term slices
+// of <= 4 terms each, sums the slices in LDS, and the term ranges go to blockIdx.y: 2^18 entries are 64 workgroups of
+// 4 products per lane.  The serial kernel adds the gridDim.y (<= 8) partial tables (SmallArgs::stride).
 constexpr int BF_BLOCK = 1024;
 static __global__ __launch_bounds__(BF_BLOCK) void blockfold_kernel(const uint64_t* __restrict__ in, uint32_t m, uint32_t log_ow,
                                                                     uint32_t per, const uint64_t* __restrict__ weights,
