@@ -125,7 +125,7 @@ struct CloseShared {                   // LDS scratch of close_round
     Fr canon[CMP_MAX_MONO];            // canonical integers of what the transcript absorbs, in order
     uint32_t pow_of[CMP_MAX_MONO];
     uint32_t n_items;
-    Fr challenge;                      // Montgomery form, for the caller
+    Fr challenge_canon;                // the round's challenge as the hash yields it (canonical integer), for the caller
     Fr sum_canon;                      // canonical claimed sum (absorbed in the first round of a multi-composed proof)
     uint32_t msg[16 * CMP_MAX_BLOCKS]; // the padded message of the round: pending bytes || items || padding
     uint32_t kw[64 * CMP_MAX_BLOCKS];  // K + W of every block
@@ -134,7 +134,7 @@ struct CloseShared {                   // LDS scratch of close_round
 };
 
 // Closes a round with the whole workgroup (>= 64 threads; every thread must call): sh.evals hold the sums.
-// Builds the round polynomial, absorbs it, derives the challenge (left in sh.challenge and challenges[round]).
+// Builds the round polynomial, absorbs it, derives the challenge (left in sh.challenge_canon and, in Montgomery form, challenges[round]).
 //   first: 1 = the transcript is started here (ComposedSumcheck: nothing absorbed before, composed_sumcheck.rs:33;
 //              multi-composed prove_partial: the claimed sum, multi_composed_sumcheck.rs:60,70),
 //          2 = the transcript state was prepared by the host (multi-composed `prove`: all table bytes were
@@ -156,9 +156,15 @@ __device__ __forceinline__ void close_preload(CloseShared& sh, const ComposedMet
         sh.interp_c[tid] = load_fr(&st->interp[d][e][0], 0);
     }
 }
+// shadow(lane, n_lanes): optional work of the caller's that needs neither the round's challenge nor the hash wave; the waves that
+// compute the message schedules run it once they are done, i.e. beside the hash (lane < n_lanes = blockDim.x - 64).
+// On return sh.challenge_canon holds the challenge as a CANONICAL integer (what the hash yields) for every thread; its Montgomery
+// form goes to challenges[round] without anyone waiting for the conversion.
+struct NoShadow { __device__ __forceinline__ void operator()(uint32_t, uint32_t) const {} };
+template <class Shadow = NoShadow>
 __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta& meta, ComposedDev* st, const FrArg& claimed_sum, Sha256State* tr_state,
                                             uint32_t round, uint32_t first, uint64_t* __restrict__ round_out,
-                                            uint64_t* __restrict__ challenges) {
+                                            uint64_t* __restrict__ challenges, const Shadow& shadow = Shadow()) {
     uint64_t* out = round_out + 64 * (size_t)round;
     const uint32_t tid = threadIdx.x;
     ZK_STAMP_AT(0, round, 0);
@@ -281,6 +287,7 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
             for (int j = 0; j < 16; ++j) w[j] = sh.msg[16 * b + j];
             sha256_schedule_to_lds(w, sh.kw + 64 * b, &sh.kw_ready[b], 0u, b == 0 ? 1u : 0u);
         }
+        shadow(tid - 64, blockDim.x - 64);
     } else {
         uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
         if (first != 1) {
@@ -301,17 +308,16 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
         for (int i = 0; i < 8; ++i) c.l[i] = h[7 - i];
         c.reduce_once();
         c.reduce_once();
-        const Fr r = fr_to_mont_outlined(c);
         if (tid == 0) {
             Transcript tr;                                      // finalize_reset + update(digest)
             tr.init();
             tr.commit_words8(h);
             tr.store(tr_state);
-            store_fr(challenges, round, r);
-            sh.challenge = r;
+            sh.challenge_canon = c;
         }
     }
     __syncthreads();
+    if (tid == 0) store_fr(challenges, round, fr_to_mont_outlined(sh.challenge_canon));   // nobody in this kernel waits for it
     ZK_STAMP_AT(0, round, 5);
 }
 
@@ -575,6 +581,29 @@ __device__ __forceinline__ void tail_term_sums(const uint32_t* tab, const uint32
     }
 }
 
+// The tail's work beside the hash: the upper half of every table becomes d^ = to_mont(hi - lo), so that the fold behind the
+// round needs the challenge only as the hash yields it -- lo + mont(c, d^) = lo + r (hi - lo) for the canonical c -- and nobody
+// waits for the challenge's conversion to Montgomery form (0.95 us per round).
+struct TailShadow {
+    uint32_t* tab;
+    uint32_t total, m, half;   // half = 0: nothing to prepare (last round)
+    __device__ __forceinline__ void operator()(uint32_t lane, uint32_t n_lanes) const {
+        for (uint32_t idx = lane; idx < total * half; idx += n_lanes) {
+            const uint32_t q = idx / half, j = idx % half;
+            const Fr lo = lds_load_fr(tab, q * m + j), hi = lds_load_fr(tab, q * m + j + half);
+            lds_store_fr(tab, q * m + j + half, fr_to_mont_outlined(hi - lo));
+        }
+    }
+};
+// the fold itself, by the waves that do not convert the challenge (1..): tables of `half` entries afterwards
+__device__ __forceinline__ void tail_fold(uint32_t* tab, uint32_t total, uint32_t m, uint32_t half, const Fr& c_canon) {
+    if (threadIdx.x < 64) return;
+    for (uint32_t idx = threadIdx.x - 64; idx < total * half; idx += CMP_TAIL_BLOCK - 64) {
+        const uint32_t q = idx / half, j = idx % half;
+        const Fr lo = lds_load_fr(tab, q * m + j), dhat = lds_load_fr(tab, q * m + j + half);
+        lds_store_fr(tab, q * m + j, lo + fr_mul_outlined(c_canon, dhat));
+    }
+}
 static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(TailTables tt, uint32_t total, uint32_t m, uint32_t load_fold,
                                                                        const uint64_t* __restrict__ r_ptr, CloseArgs ca,
                                                                        uint32_t n_rounds) {
@@ -637,15 +666,10 @@ static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(Ta
                 if (lane == 0) sh.evals[wave] = s;
             }
             __syncthreads();
-            close_round(sh, ca.meta, ca.st, ca.sum, &trs, round, first, ca.round_out, ca.challenges);
+            close_round(sh, ca.meta, ca.st, ca.sum, &trs, round, first, ca.round_out, ca.challenges, TailShadow{tab, total, m, cn == 2 ? 0u : half});
             first = 0;
             if (cn == 2) break;
-            const Fr r = sh.challenge;
-            for (uint32_t idx = threadIdx.x; idx < total * half; idx += CMP_TAIL_BLOCK) {
-                const uint32_t q = idx / half, j = idx % half;
-                const Fr lo = lds_load_fr(tab, q * m + j), hi = lds_load_fr(tab, q * m + j + half);
-                lds_store_fr(tab, q * m + j, fold_pair(lo, hi, r));
-            }
+            tail_fold(tab, total, m, half, sh.challenge_canon);
             __syncthreads();
             ZK_STAMP_AT(0, round, 7);
             cn = half;
@@ -671,16 +695,11 @@ static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(Ta
             sh.evals[threadIdx.x] = s;
         }
         __syncthreads();
-        close_round(sh, ca.meta, ca.st, ca.sum, &trs, round, first, ca.round_out, ca.challenges);
+        const uint32_t half = cn >> 1;
+        close_round(sh, ca.meta, ca.st, ca.sum, &trs, round, first, ca.round_out, ca.challenges, TailShadow{tab, total, m, cn == 2 ? 0u : half});
         first = 0;
         if (cn == 2) break;   // the fold after the last round has no consumer
-        const Fr r = sh.challenge;
-        const uint32_t half = cn >> 1;
-        for (uint32_t idx = threadIdx.x; idx < total * half; idx += CMP_TAIL_BLOCK) {
-            const uint32_t q = idx / half, j = idx % half;
-            const Fr lo = lds_load_fr(tab, q * m + j), hi = lds_load_fr(tab, q * m + j + half);
-            lds_store_fr(tab, q * m + j, fold_pair(lo, hi, r));
-        }
+        tail_fold(tab, total, m, half, sh.challenge_canon);
         __syncthreads();
         ZK_STAMP_AT(0, round, 7);
         cn = half;
