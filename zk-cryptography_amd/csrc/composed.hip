@@ -216,12 +216,16 @@ struct ComposedRun {
     int round_sums(int* n_records) {
         const bool fold = folds();
         const size_t work = fold ? cn / 4 : cn / 2;
-        const int grid = mle_grid(work ? work : 1);
+        // small folding rounds of K = 2 terms: four lanes per output pair (composed_round_split2_kernel), all terms in one launch
+        bool split = fold && work >= 1 && work <= CMP_SPLIT_MAX;
+        for (uint32_t p = 0; p < n_terms; ++p) split = split && term_sizes[p] == 2;
+        const int grid = split ? (int)((4 * work + MLE_BLOCK - 1) / MLE_BLOCK) : mle_grid(work ? work : 1);
         uint32_t off = 0;
         // every term with the same number of tables (<= 2 when one has an additive table): ONE launch, blockIdx.y = term
         bool same_k = n_terms > 1;
         for (uint32_t p = 1; p < n_terms; ++p) same_k = same_k && term_sizes[p] == term_sizes[0];
         for (uint32_t p = 0; p < n_terms; ++p) if (lin_cur[p] && term_sizes[p] > 2) same_k = false;
+        same_k = same_k || split;
         MultiTablePtrs mp = {};
         for (uint32_t p = 0; p < n_terms; ++p) {
             TablePtrs tp = {};
@@ -253,11 +257,14 @@ struct ComposedRun {
         if (same_k) {
             ProfScope ps(c, "composed_round", 0.0);
             const uint64_t* rp = fold ? prev_challenge() : nullptr;
+            if (split) hipLaunchKernelGGL(composed_round_split2_kernel, dim3(grid, n_terms), dim3(MLE_BLOCK), 0, c->stream, mp, cn, rp, meta.rec, d_partials);
+            else {
 #define CALL(KK)                                                                                                                                   \
             if (fold) hipLaunchKernelGGL((composed_round_multi_kernel<KK, true>), dim3(grid, n_terms), dim3(MLE_BLOCK), 0, c->stream, mp, cn, rp, meta.rec, d_partials); \
             else hipLaunchKernelGGL((composed_round_multi_kernel<KK, false>), dim3(grid, n_terms), dim3(MLE_BLOCK), 0, c->stream, mp, cn, rp, meta.rec, d_partials)
             ZK_DISPATCH_K(term_sizes[0], CALL)
 #undef CALL
+            }
         }
         if (fold) cn /= 2;
         *n_records = grid;

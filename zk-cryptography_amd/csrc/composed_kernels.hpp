@@ -449,6 +449,56 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_multi_kernel(
     }
 }
 
+// The same folding round for SMALL tables of K = 2 terms (<= CMP_SPLIT_MAX output pairs): FOUR lanes per output pair.  With one
+// lane per pair a round is 9-11 Montgomery products one after another on a lone wave (0.9 us each: the chip has far more SIMDs
+// than such a round has waves), which is what made a small round kernel 13 us; here lane g of a group folds ONE of the four
+// values (table g / 2, lower or upper output), the group exchanges them, and lanes 0 / 1 / 2 multiply for t = 0 / 1 / 2: two
+// products deep (three with an additive table).  Same values, same record layout (gridDim.x records).
+constexpr size_t CMP_SPLIT_MAX = 16384;
+static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_split2_kernel(MultiTablePtrs mp, size_t n, const uint64_t* __restrict__ r_ptr,
+                                                                          uint32_t rec, uint64_t* __restrict__ partials) {
+    __shared__ Fr red[3][MLE_BLOCK / 64];
+    const TablePtrs& tp = mp.t[blockIdx.y];
+    const uint32_t rec_off = mp.rec_off[blockIdx.y];
+    const bool lin = tp.lin_in != nullptr;
+    const Fr r = load_fr(r_ptr, 0);
+    const size_t h = n >> 1, q = n >> 2;
+    const uint32_t lane = threadIdx.x & 63, g = threadIdx.x & 3;
+    const size_t j = ((size_t)blockIdx.x * MLE_BLOCK + threadIdx.x) >> 2;
+    const bool act = j < q;
+    Fr mine = Fr::zero(), lmine = Fr::zero();
+    if (act) {
+        const size_t o = j + ((g & 1) ? q : 0);
+        mine = fold_pair(load_fr(tp.in[g >> 1], o), load_fr(tp.in[g >> 1], o + h), r);
+        store_fr(tp.out[g >> 1], o, mine);
+        if (lin && g < 2) {
+            lmine = fold_pair(load_fr(tp.lin_in, o), load_fr(tp.lin_in, o + h), r);
+            store_fr(tp.lin_out, o, lmine);
+        }
+    }
+    const int base = (int)(lane & ~3u);
+    const Fr lo0 = shfl_fr(mine, base), hi0 = shfl_fr(mine, base + 1), lo1 = shfl_fr(mine, base + 2), hi1 = shfl_fr(mine, base + 3);
+    Fr e = Fr::zero();
+    if (act && g < 3) {
+        const Fr x = g == 0 ? lo0 : g == 1 ? hi0 : hi0 + hi0 - lo0;
+        const Fr y = g == 0 ? lo1 : g == 1 ? hi1 : hi1 + hi1 - lo1;
+        e = x * y;
+    }
+    if (lin) {
+        const Fr llo = shfl_fr(lmine, base), lhi = shfl_fr(lmine, base + 1);
+        if (act && g < 3) e = e + (g == 0 ? llo : g == 1 ? lhi : lhi + lhi - llo);
+    }
+#pragma unroll
+    for (int d = 32; d >= 4; d >>= 1) e = e + shfl_down_fr(e, d);   // lanes 0..2: the wave's sums for t = lane
+    if (lane < 3) red[lane][threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        Fr s = red[threadIdx.x][0];
+        for (int w = 1; w < MLE_BLOCK / 64; ++w) s = s + red[threadIdx.x][w];
+        store_fr(partials, (size_t)blockIdx.x * rec + rec_off + threadIdx.x, s);
+    }
+}
+
 struct CloseArgs {
     ComposedMeta meta;
     ComposedDev* st;
