@@ -95,21 +95,53 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_table_kernel(const ui
 // (u_dev, the challenges a sumcheck left there) or by value.
 constexpr uint32_t GKR_EQ_LO = 10;
 constexpr uint32_t GKR_EQ_HALVES = 2u << GKR_EQ_LO;        // entries reserved per point: hi (<= 2^10) then lo (2^10)
+// A lone wave pays 0.9 us per product and 2 us per dependent load, so an entry is NOT built as a chain over its index bits
+// (10 loads + 10 products: 28 us per launch): the points are fetched once into LDS with their complements, each half is split
+// again into two parts of <= 5 bits whose <= 32-entry tables 128 lanes build (5 products deep), and an entry is one product of two
+// part entries -- 6-7 products deep in all.  Every workgroup rebuilds the part tables (they are tiny).
 static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_halves_kernel(const uint64_t* __restrict__ u_dev, PtsArg p0, PtsArg p1, uint32_t n_vars,
                                                                   FrArg scale0, FrArg scale1, uint32_t scaled, uint64_t* __restrict__ out) {
-    const uint32_t n_lo = GKR_EQ_LO, n_hi = n_vars - n_lo, pt = blockIdx.y;
-    const uint32_t e = blockIdx.x * MLE_BLOCK + threadIdx.x;
+    __shared__ Fr fac[2 * GKR_EQ_LO + 2][2];   // [variable][bit]: 1 - t, t
+    __shared__ Fr part[2][2][32];              // [half: hi, lo][part: leading bits, trailing bits][index]
+    const uint32_t n_lo = GKR_EQ_LO, n_hi = n_vars - n_lo, pt = blockIdx.y, tid = threadIdx.x;
+    {
+        // by-value points are read with a UNIFORM index (scalar loads from the kernel arguments): indexing them by lane would put
+        // both 640-byte arrays into scratch memory, and a dispatch that needs scratch costs ~15 us more
+        Fr t = Fr::zero();
+        if (u_dev) {
+            if (tid < n_vars) t = load_fr(u_dev, tid);
+        } else {
+            for (uint32_t j = 0; j < n_vars; ++j) {
+                const Fr tj = pt ? fr_from_pts(p1, j) : fr_from_pts(p0, j);
+                if (tid == j) t = tj;
+            }
+        }
+        if (tid < n_vars) {
+            fac[tid][1] = t;
+            fac[tid][0] = Fr::one() - t;
+        }
+    }
+    __syncthreads();
+    // part tables: half h covers the variables [first, first + cnt), its part 0 the leading cnt - cnt/2 of them
+    if (tid < 128) {
+        const uint32_t hh = tid >> 6, pp = (tid >> 5) & 1, idx = tid & 31;
+        const uint32_t first = hh ? n_hi : 0, cnt = hh ? n_lo : n_hi;
+        const uint32_t nb = cnt / 2, na = cnt - nb;                    // bits of part 0 / part 1
+        const uint32_t bits = pp ? nb : na, v0 = first + (pp ? na : 0);
+        if (idx < (1u << bits)) {
+            Fr acc = (hh == 0 && pp == 0 && scaled) ? fr_from_arg(pt ? scale1 : scale0) : Fr::one();
+            for (uint32_t j = 0; j < bits; ++j) acc = acc * fac[v0 + j][(idx >> (bits - 1 - j)) & 1];
+            part[hh][pp][idx] = acc;
+        }
+    }
+    __syncthreads();
+    const uint32_t e = blockIdx.x * MLE_BLOCK + tid;
     const uint32_t hi_cnt = 1u << n_hi;
     if (e >= hi_cnt + (1u << n_lo)) return;
     const bool is_hi = e < hi_cnt;
-    const uint32_t idx = is_hi ? e : e - hi_cnt, first = is_hi ? 0 : n_hi, cnt = is_hi ? n_hi : n_lo;
-    const Fr one = Fr::one();
-    Fr acc = (is_hi && scaled) ? fr_from_arg(pt ? scale1 : scale0) : one;
-    for (uint32_t j = 0; j < cnt; ++j) {
-        const Fr t = u_dev ? load_fr(u_dev, first + j) : fr_from_pts(pt ? p1 : p0, first + j);
-        acc = acc * (((idx >> (cnt - 1 - j)) & 1) ? t : one - t);
-    }
-    store_fr(out, (size_t)pt * GKR_EQ_HALVES + (is_hi ? idx : (GKR_EQ_HALVES >> 1) + idx), acc);
+    const uint32_t idx = is_hi ? e : e - hi_cnt, cnt = is_hi ? n_hi : n_lo, nb = cnt / 2;
+    const Fr v = part[is_hi ? 0 : 1][0][idx >> nb] * part[is_hi ? 0 : 1][1][idx & ((1u << nb) - 1)];
+    store_fr(out, (size_t)pt * GKR_EQ_HALVES + (is_hi ? idx : (GKR_EQ_HALVES >> 1) + idx), v);
 }
 // out[x] = sum over the n_points points of hi[x >> 10] * lo[x & 1023]
 static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_expand_kernel(const uint64_t* __restrict__ halves, uint32_t n_points, size_t n,
