@@ -58,9 +58,16 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_rows_kernel(const u
                                                                   const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ other_in,
                                                                   const uint64_t* __restrict__ wg, const uint64_t* __restrict__ factor,
                                                                   uint32_t n_rows, uint32_t phase, uint64_t* __restrict__ add_out,
-                                                                  uint64_t* __restrict__ lin_out, uint64_t* __restrict__ mul_out) {
+                                                                  uint64_t* __restrict__ lin_out, uint64_t* __restrict__ mul_out,
+                                                                  const uint64_t* __restrict__ v, const uint64_t* __restrict__ vu_ptr,
+                                                                  uint64_t* __restrict__ t1, uint64_t* __restrict__ t2) {
     const uint32_t x = blockIdx.x * MLE_BLOCK + threadIdx.x;
     if (x >= n_rows) return;
+    if (t1) {   // phase 2 also lays out the other factor of each term (one launch less per layer): t1[c] = V(u) + V[c], t2[c] = V(u) V[c]
+        const Fr vu = load_fr(vu_ptr, 0), vx = load_fr(v, x);
+        store_fr(t1, x, vu + vx);
+        store_fr(t2, x, vu * vx);
+    }
     Fr a = Fr::zero(), l = Fr::zero(), m = Fr::zero();
     for (uint32_t q = row_off[x]; q < row_off[x + 1]; ++q) {
         const uint32_t g = ids[q];
@@ -76,9 +83,14 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_rows_kernel(const u
 }
 // eq_x(u) over n_vars index bits, MSB first (the b side of the wiring at the phase-1 challenges).  The points are read from
 // DEVICE memory -- where the sumcheck that produced them left them -- so the host never waits for them.
-static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_table_kernel(const uint64_t* __restrict__ u, uint32_t n_vars, uint64_t* __restrict__ out) {
+// With v: also the workgroup's share of <eq(u), v> into partials[blockIdx.x] (V(u) = sum_x eq_x(u) V[x]: the same field element as
+// MultilinearTrait::evaluation's chain of folds, exact arithmetic) -- the evaluation costs no pass of its own.
+static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_table_kernel(const uint64_t* __restrict__ u, uint32_t n_vars, uint64_t* __restrict__ out,
+                                                                 const uint64_t* __restrict__ v, uint64_t* __restrict__ partials) {
+    __shared__ Fr red[MLE_BLOCK / 64];
     const size_t n = (size_t)1 << n_vars, stride = (size_t)gridDim.x * MLE_BLOCK;
     const Fr one = Fr::one();
+    Fr dot = Fr::zero();
     for (size_t i = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; i < n; i += stride) {
         Fr acc = one;
         for (uint32_t j = 0; j < n_vars; ++j) {
@@ -86,6 +98,11 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_table_kernel(const ui
             acc = acc * (((i >> (n_vars - 1 - j)) & 1) ? t : one - t);
         }
         store_fr(out, i, acc);
+        if (v) dot = dot + acc * load_fr(v, i);
+    }
+    if (v) {
+        dot = block_reduce_fr(dot, red);
+        if (threadIdx.x == 0) store_fr(partials, blockIdx.x, dot);
     }
 }
 // Wide layers (more than GKR_EQ_LO index bits) build their eq tables from two halves instead of n_vars products per entry:
@@ -145,37 +162,24 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_halves_kernel(const u
 }
 // out[x] = sum over the n_points points of hi[x >> 10] * lo[x & 1023]
 static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_expand_kernel(const uint64_t* __restrict__ halves, uint32_t n_points, size_t n,
-                                                                  uint64_t* __restrict__ out) {
+                                                                  uint64_t* __restrict__ out, const uint64_t* __restrict__ v,
+                                                                  uint64_t* __restrict__ partials) {
+    __shared__ Fr red[MLE_BLOCK / 64];
     const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    Fr dot = Fr::zero();
     for (size_t i = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; i < n; i += stride) {
         const uint32_t h = (uint32_t)(i >> GKR_EQ_LO), l = (uint32_t)(i & ((1u << GKR_EQ_LO) - 1));
         Fr acc = load_fr(halves, h) * load_fr(halves, (GKR_EQ_HALVES >> 1) + l);
         if (n_points == 2) acc = acc + load_fr(halves, GKR_EQ_HALVES + h) * load_fr(halves, GKR_EQ_HALVES + (GKR_EQ_HALVES >> 1) + l);
         store_fr(out, i, acc);
+        if (v) dot = dot + acc * load_fr(v, i);
+    }
+    if (v) {   // as gkr_eq_table_kernel
+        dot = block_reduce_fr(dot, red);
+        if (threadIdx.x == 0) store_fr(partials, blockIdx.x, dot);
     }
 }
-// t1[c] = V(u) + V[c]  (wb_add_wc with b at u),  t2[c] = V(u) V[c]  (wb_mul_wc with b at u)
-static __global__ __launch_bounds__(MLE_BLOCK) void gkr_vu_tables_kernel(const uint64_t* __restrict__ v, size_t n, const uint64_t* __restrict__ vu_ptr,
-                                                                  uint64_t* __restrict__ t1, uint64_t* __restrict__ t2) {
-    const Fr vu = load_fr(vu_ptr, 0);                      // V(u), left on the device by gkr_dot_* below
-    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
-    for (size_t i = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; i < n; i += stride) {
-        const Fr x = load_fr(v, i);
-        store_fr(t1, i, vu + x);
-        store_fr(t2, i, vu * x);
-    }
-}
-// V(point) = sum_x eq_x(point) V[x]: the same field element as MultilinearTrait::evaluation's chain of folds (exact arithmetic).
-// One partial per workgroup, then one workgroup adds them; the result stays on the device.
-static __global__ __launch_bounds__(MLE_BLOCK) void gkr_dot_kernel(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, size_t n,
-                                                            uint64_t* __restrict__ partials) {
-    __shared__ Fr red[MLE_BLOCK / 64];
-    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
-    Fr s = Fr::zero();
-    for (size_t i = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; i < n; i += stride) s = s + load_fr(a, i) * load_fr(b, i);
-    s = block_reduce_fr(s, red);
-    if (threadIdx.x == 0) store_fr(partials, blockIdx.x, s);
-}
+// the per-workgroup shares of <eq(point), V> (gkr_eq_table_kernel / gkr_eq_expand_kernel) summed; the result stays on the device
 static __global__ __launch_bounds__(MLE_BLOCK) void gkr_dot_finish_kernel(const uint64_t* __restrict__ partials, uint32_t n_partials,
                                                                    uint64_t* __restrict__ out) {
     __shared__ Fr red[MLE_BLOCK / 64];
@@ -184,18 +188,24 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_dot_finish_kernel(const 
     s = block_reduce_fr(s, red);
     if (threadIdx.x == 0) store_fr(out, 0, s);
 }
-// eq_x(u) for all x < 2^n_vars, u in device memory
-static void launch_eq_table(zkhip_ctx* c, const uint64_t* d_u, uint32_t n_vars, uint64_t* d_halves, uint64_t* d_out) {
+// eq_x(u) for all x < 2^n_vars, u in device memory; with d_v also <eq(u), v> -> d_dot (one value), summed from the table
+// kernel's per-workgroup shares (d_partials: MLE_MAX_GRID entries of scratch)
+static void launch_eq_table(zkhip_ctx* c, const uint64_t* d_u, uint32_t n_vars, uint64_t* d_halves, uint64_t* d_out,
+                            const uint64_t* d_v = nullptr, uint64_t* d_partials = nullptr, uint64_t* d_dot = nullptr) {
     const size_t n = (size_t)1 << n_vars;
+    const int grid = d_v ? mle_grid(n) : mle_grid_stream(n);          // one share per workgroup: the capped grid
+    uint64_t* shares = grid == 1 ? d_dot : d_partials;                 // a single workgroup's share IS the result
     if (n_vars <= GKR_EQ_LO) {
-        hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(mle_grid_stream(n)), dim3(MLE_BLOCK), 0, c->stream, d_u, n_vars, d_out);
-        return;
+        hipLaunchKernelGGL(gkr_eq_table_kernel, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_u, n_vars, d_out, d_v, shares);
+    } else {
+        PtsArg none = {};
+        FrArg z = {};
+        const uint32_t cnt = (1u << (n_vars - GKR_EQ_LO)) + (1u << GKR_EQ_LO);
+        hipLaunchKernelGGL(gkr_eq_halves_kernel, dim3((cnt + MLE_BLOCK - 1) / MLE_BLOCK, 1), dim3(MLE_BLOCK), 0, c->stream, d_u, none, none, n_vars, z, z, 0u, d_halves);
+        hipLaunchKernelGGL(gkr_eq_expand_kernel, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_halves, 1u, n, d_out, d_v, shares);
     }
-    PtsArg none = {};
-    FrArg z = {};
-    const uint32_t cnt = (1u << (n_vars - GKR_EQ_LO)) + (1u << GKR_EQ_LO);
-    hipLaunchKernelGGL(gkr_eq_halves_kernel, dim3((cnt + MLE_BLOCK - 1) / MLE_BLOCK, 1), dim3(MLE_BLOCK), 0, c->stream, d_u, none, none, n_vars, z, z, 0u, d_halves);
-    hipLaunchKernelGGL(gkr_eq_expand_kernel, dim3(mle_grid_stream(n)), dim3(MLE_BLOCK), 0, c->stream, d_halves, 1u, n, d_out);
+    if (d_v && grid > 1)
+        hipLaunchKernelGGL(gkr_dot_finish_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_partials, (uint32_t)grid, d_dot);
 }
 // w_g = eq_g(r_b)  or  alpha eq_g(r_b) + beta eq_g(r_c)
 static void launch_gate_weights(zkhip_ctx* c, size_t n_gates, uint32_t n_gate_vars, const PtsArg& pb, const PtsArg& pc, const FrArg& av,
@@ -209,7 +219,7 @@ static void launch_gate_weights(zkhip_ctx* c, size_t n_gates, uint32_t n_gate_va
     const uint32_t cnt = (1u << (n_gate_vars - GKR_EQ_LO)) + (1u << GKR_EQ_LO);
     hipLaunchKernelGGL(gkr_eq_halves_kernel, dim3((cnt + MLE_BLOCK - 1) / MLE_BLOCK, two_points ? 2 : 1), dim3(MLE_BLOCK), 0, c->stream,
                        (const uint64_t*)nullptr, pb, pc, n_gate_vars, av, bv, two_points ? 1u : 0u, d_halves);
-    hipLaunchKernelGGL(gkr_eq_expand_kernel, dim3(mle_grid_stream(n_gates)), dim3(MLE_BLOCK), 0, c->stream, d_halves, two_points ? 2u : 1u, n_gates, d_wg);
+    hipLaunchKernelGGL(gkr_eq_expand_kernel, dim3(mle_grid_stream(n_gates)), dim3(MLE_BLOCK), 0, c->stream, d_halves, two_points ? 2u : 1u, n_gates, d_wg, (const uint64_t*)nullptr, (uint64_t*)nullptr);
 }
 }  // namespace zk
 
@@ -261,7 +271,7 @@ static void group_gates(const uint32_t* key, size_t n_gates, size_t n_rows, std:
 struct LayerScratch {
     uint64_t *wg, *ha0, *ha1, *hm, *equ, *aa, *am, *t1, *t2;
     uint64_t* eqh;                    // halves of the eq tables of wide layers (2 points x GKR_EQ_HALVES entries)
-    uint64_t *dot_partials, *evals;   // workgroup partials of gkr_dot_kernel; evals[0..4) = V(u) = w_b, evals[4..8) = V(r_c) = w_c
+    uint64_t *dot_partials, *evals;   // workgroup shares of <eq, V>; evals[0..4) = V(u) = w_b, evals[4..8) = V(r_c) = w_c
 };
 // one layer of a device-resident circuit: the gate arrays and their two CSR groupings (by in0 and by in1)
 struct LayerDev {
@@ -293,7 +303,7 @@ int layer_prove(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_
     launch_gate_weights(c, n_gates, n_gate_vars, pb, pc, av, bv, two_points, sc.eqh, sc.wg);
     // ---- rounds over b
     hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr0, ld.csr0 + w_len + 1, ld.type, ld.in1, sc.wg, d_w,
-                       (uint32_t)w_len, 1u, sc.ha0, sc.ha1, sc.hm);
+                       (uint32_t)w_len, 1u, sc.ha0, sc.ha1, sc.hm, (const uint64_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr);
     ZK_HIP(c, hipGetLastError());
     // Everything up to the end of the layer's sumcheck is enqueued without waiting for the host: the rounds over c read the
     // challenges of the rounds over b, V(u) and the eq table from device memory, the two composed-prover calls append to one
@@ -304,34 +314,22 @@ int layer_prove(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_
     std::vector<uint64_t> challenges(4 * (size_t)nv);
     const uint32_t sizes[2] = {2, 2};
     const uint64_t* d_ch = zk_composed_challenges_dev(c);
-    const int dot_grid = mle_grid(w_len);
-    auto dot = [&](uint64_t* d_out) {                       // <eq table, V> -> d_out; one workgroup's partial IS the result
-        if (dot_grid == 1) {
-            hipLaunchKernelGGL(gkr_dot_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, sc.equ, d_w, w_len, d_out);
-        } else {
-            hipLaunchKernelGGL(gkr_dot_kernel, dim3(dot_grid), dim3(MLE_BLOCK), 0, c->stream, sc.equ, d_w, w_len, sc.dot_partials);
-            hipLaunchKernelGGL(gkr_dot_finish_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, sc.dot_partials, (uint32_t)dot_grid, d_out);
-        }
-    };
     {
         const uint64_t* tables[4] = {sc.ha0, d_w, sc.hm, d_w};          // [Ha0, V] + Ha1,  [Hm, V]
         const uint64_t* lin[2] = {sc.ha1, nullptr};
         ZK_TRY(zk_multi_composed_enqueue(c, tables, sizes, lin, 2, w_len, claimed.l, 0, 0));
     }
     // ---- rounds over c, b at u = the challenges just recorded
-    launch_eq_table(c, d_ch, s, sc.eqh, sc.equ);
-    dot(sc.evals);                                         // V(u): w_b and the factor of the second phase
+    launch_eq_table(c, d_ch, s, sc.eqh, sc.equ, d_w, sc.dot_partials, sc.evals);   // eq(u) and V(u) = <eq(u), V>: w_b and the factor of the second phase
     hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr1, ld.csr1 + w_len + 1, ld.type, ld.in0, sc.wg, sc.equ,
-                       (uint32_t)w_len, 2u, sc.aa, (uint64_t*)nullptr, sc.am);
-    hipLaunchKernelGGL(gkr_vu_tables_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_w, w_len, sc.evals, sc.t1, sc.t2);
+                       (uint32_t)w_len, 2u, sc.aa, (uint64_t*)nullptr, sc.am, d_w, (const uint64_t*)sc.evals, sc.t1, sc.t2);
     ZK_HIP(c, hipGetLastError());
     {
         const uint64_t* tables[4] = {sc.aa, sc.t1, sc.am, sc.t2};        // [add~(u, c), V(u) + V(c)],  [mul~(u, c), V(u) V(c)]
         ZK_TRY(zk_multi_composed_enqueue(c, tables, sizes, nullptr, 2, w_len, nullptr, 1, s));
     }
     // w_c = V(r_c), r_c = the second half of the challenges
-    launch_eq_table(c, d_ch + 4 * (size_t)s, s, sc.eqh, sc.equ);
-    dot(sc.evals + 4);
+    launch_eq_table(c, d_ch + 4 * (size_t)s, s, sc.eqh, sc.equ, d_w, sc.dot_partials, sc.evals + 4);
     ZK_HIP(c, hipGetLastError());
     zkhost::Fr eval_wb, eval_wc;
     ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), sc.evals, 64, hipMemcpyDeviceToHost, c->stream));
@@ -534,22 +532,14 @@ extern "C" int zkhip_gkr_layer_tables(zkhip_circuit* cir, uint32_t layer, const 
     launch_gate_weights(c, ld.n_gates, n_gate_vars, pb, pc, av, bv, two_points, eqh, wg);
     if (phase == 0) {
         hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr0, ld.csr0 + w_len + 1, ld.type, ld.in1, wg, d_w,
-                           (uint32_t)w_len, 1u, d_out[0], d_out[1], d_out[2]);
+                           (uint32_t)w_len, 1u, d_out[0], d_out[1], d_out[2], (const uint64_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr);
         ZK_HIP(c, hipGetLastError());
         return ZKHIP_OK;
     }
     const uint64_t* d_ch = zk_composed_challenges_dev(c);       // the s challenges of the rounds over b
-    launch_eq_table(c, d_ch, s, eqh, equ);
-    const int dot_grid = mle_grid(w_len);
-    if (dot_grid == 1) {
-        hipLaunchKernelGGL(gkr_dot_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, equ, d_w, w_len, evals);
-    } else {
-        hipLaunchKernelGGL(gkr_dot_kernel, dim3(dot_grid), dim3(MLE_BLOCK), 0, c->stream, equ, d_w, w_len, dot_partials);
-        hipLaunchKernelGGL(gkr_dot_finish_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, dot_partials, (uint32_t)dot_grid, evals);
-    }
+    launch_eq_table(c, d_ch, s, eqh, equ, d_w, dot_partials, evals);
     hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr1, ld.csr1 + w_len + 1, ld.type, ld.in0, wg, equ,
-                       (uint32_t)w_len, 2u, d_out[0], (uint64_t*)nullptr, d_out[2]);
-    hipLaunchKernelGGL(gkr_vu_tables_kernel, dim3(mle_grid_stream(w_len)), dim3(MLE_BLOCK), 0, c->stream, d_w, w_len, evals, d_out[1], d_out[3]);
+                       (uint32_t)w_len, 2u, d_out[0], (uint64_t*)nullptr, d_out[2], d_w, (const uint64_t*)evals, d_out[1], d_out[3]);
     ZK_HIP(c, hipGetLastError());
     ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), evals, 32, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
