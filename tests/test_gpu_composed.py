@@ -81,7 +81,7 @@ def test_sum_check_proof(zk, ora, tables):   # composed_sumcheck.rs:143-241
 
 
 @pytest.mark.parametrize("k,log_n", [(1, 1), (2, 5), (2, 12), (3, 9), (5, 8), (5, 13), (4, 10),
-                                     (2, 20), (3, 18), (2, 22)])   # the last three: grids above the workgroup cap (grid-stride rounds)
+                                     (2, 20), (3, 18), (2, 21), (2, 22)])   # the last four: grids above the workgroup cap (grid-stride rounds); (2, 21) / (2, 22): one / two rounds on the unreduced K = 2 sums
 def test_composed_prove_random(zk, ora, k, log_n):   # benches: 2 and 5 tables (composed_sumcheck_benchmark.rs)
     t = np.stack([ora.random_fr(1 << log_n, 900 + 10 * k + q) for q in range(k)])
     poly = zk.ComposedMultilinear(list(t))

@@ -219,7 +219,14 @@ struct ComposedRun {
         // small folding rounds of K = 2 terms: four lanes per output pair (composed_round_split2_kernel), all terms in one launch
         bool split = fold && work >= 1 && work <= CMP_SPLIT_MAX;
         for (uint32_t p = 0; p < n_terms; ++p) split = split && term_sizes[p] == 2;
-        const int grid = split ? (int)((4 * work + MLE_BLOCK - 1) / MLE_BLOCK) : mle_grid(work ? work : 1);
+        // the first rounds of a LARGE claim of one K = 2 term: unreduced sums of products, >= 8 (folding) / 16 pairs per lane
+        // (composed_round_wide2_kernel); at most 256 products per accumulator
+        const size_t per_lane = fold ? 8 : 16;
+        const bool wide = n_terms == 1 && term_sizes[0] == 2 && !lin_cur[0] && work >= CMP_WIDE_MIN_WORK &&
+                          work <= (size_t)MLE_MAX_GRID * MLE_BLOCK * 256;
+        const int grid = split ? (int)((4 * work + MLE_BLOCK - 1) / MLE_BLOCK)
+                         : wide ? (int)std::min<size_t>(MLE_MAX_GRID, std::max<size_t>(256, work / (MLE_BLOCK * per_lane)))
+                         : mle_grid(work ? work : 1);
         uint32_t off = 0;
         // every term with the same number of tables (<= 2 when one has an additive table): ONE launch, blockIdx.y = term
         bool same_k = n_terms > 1;
@@ -246,9 +253,14 @@ struct ComposedRun {
                 mp.rec_off[p] = meta.rec_off[p];
             } else {
                 ProfScope ps(c, "composed_round", 0.0);
+                if (wide) {
+                    if (fold) hipLaunchKernelGGL(composed_round_wide2_kernel<true>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, cn, prev_challenge(), meta.rec, meta.rec_off[p], d_partials);
+                    else hipLaunchKernelGGL(composed_round_wide2_kernel<false>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, cn, (const uint64_t*)nullptr, meta.rec, meta.rec_off[p], d_partials);
+                } else {
 #define CALL(KK) launch_round<KK>(c, fold, tp, cn, fold ? prev_challenge() : nullptr, meta.rec, meta.rec_off[p], d_partials, grid)
                 ZK_DISPATCH_K(term_sizes[p], CALL)
 #undef CALL
+                }
             }
             if (fold) for (uint32_t q = 0; q < term_sizes[p]; ++q) cur[off + q] = tp.out[q];
             if (fold && lin_cur[p]) lin_cur[p] = tp.lin_out;

@@ -15,6 +15,7 @@
 #pragma once
 #include "mle_kernels.hpp"
 #include "stamps.hpp"
+#include "wide_acc.hpp"
 
 namespace zk {
 
@@ -380,6 +381,61 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TableP
 #pragma unroll
     for (int t = 0; t <= K; ++t) {
         Fr s = block_reduce_fr(sums[t], red);
+        if (threadIdx.x == 0) store_fr(partials, (size_t)blockIdx.x * rec + rec_off + t, s);
+    }
+}
+
+// The K = 2 round of ONE term without additive table on LARGE tables (>= CMP_WIDE_MIN_WORK pairs): the round polynomial
+// p(t) = sum_j (lo0 + t d0)(lo1 + t d1) is fixed by E0 = sum lo0 lo1, E1 = sum hi0 hi1 and D = sum d0 d1 (p(2) = 2 E1 - E0 + 2 D),
+// and the three sums of products are accumulated UNREDUCED (wide_acc.hpp): a pair costs 3 x (64 mads + carries) instead of 3
+// Montgomery products + 9 modular additions.  The three 9-word reductions + rescalings at the end cost ~2.5 pairs' worth, so a
+// lane takes >= 8-16 pairs (a small grid; the three accumulators also hold the kernel at two waves per SIMD) -- which is why
+// only the first rounds of a large claim come here.  Exact arithmetic: the same canonical values as composed_round_kernel.
+constexpr size_t CMP_WIDE_MIN_WORK = (size_t)1 << 20;
+template <bool FOLD>
+static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_wide2_kernel(TablePtrs tp, size_t n, const uint64_t* __restrict__ r_ptr,
+                                                                         uint32_t rec, uint32_t rec_off, uint64_t* __restrict__ partials) {
+    __shared__ Fr red[MLE_BLOCK / 64];
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    WideAcc e0, e1, dd;
+    e0.clear(); e1.clear(); dd.clear();
+    if (FOLD) {
+        const Fr r = load_fr(r_ptr, 0);
+        const size_t h = n >> 1, q = n >> 2;
+        for (size_t j = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; j < q; j += stride) {
+            Fr lo[2], hi[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const Fr a0 = load_fr(tp.in[k], j), a1 = load_fr(tp.in[k], j + q);
+                const Fr b0 = load_fr(tp.in[k], j + h), b1 = load_fr(tp.in[k], j + h + q);
+                lo[k] = fold_pair(a0, b0, r);
+                hi[k] = fold_pair(a1, b1, r);
+                store_fr(tp.out[k], j, lo[k]);
+                store_fr(tp.out[k], j + q, hi[k]);
+            }
+            e0.mac(lo[0], lo[1]);
+            e1.mac(hi[0], hi[1]);
+            dd.mac(hi[0] - lo[0], hi[1] - lo[1]);
+        }
+    } else {
+        const size_t h = n >> 1;
+        for (size_t j = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; j < h; j += stride) {
+            const Fr lo0 = load_fr(tp.in[0], j), hi0 = load_fr(tp.in[0], j + h);
+            const Fr lo1 = load_fr(tp.in[1], j), hi1 = load_fr(tp.in[1], j + h);
+            e0.mac(lo0, lo1);
+            e1.mac(hi0, hi1);
+            dd.mac(hi0 - lo0, hi1 - lo1);
+        }
+    }
+    const Fr fix = fr_mont_2_32();
+    Fr sums[3];
+    sums[0] = wide_reduce(e0.lo, e0.hi) * fix;
+    sums[1] = wide_reduce(e1.lo, e1.hi) * fix;
+    const Fr D = wide_reduce(dd.lo, dd.hi) * fix;
+    sums[2] = (sums[1] + sums[1] - sums[0]) + (D + D);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const Fr s = block_reduce_fr(sums[t], red);
         if (threadIdx.x == 0) store_fr(partials, (size_t)blockIdx.x * rec + rec_off + t, s);
     }
 }
