@@ -582,7 +582,12 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_close_kernel(const 
         const uint32_t v = wave + q * (MLE_BLOCK / 64);
         s[q] = Fr::zero();
         if (v < ca.meta.rec)
-            for (uint32_t b = lane; b < n_partials; b += 64) s[q] = s[q] + load_fr(partials, (size_t)b * ca.meta.rec + v);
+            for (uint32_t b = lane; b < n_partials; b += 256) {   // four loads in flight per lane (up to 2048 records: 8 trips instead of 32)
+                Fr x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = b + 64 * u < n_partials ? load_fr(partials, (size_t)(b + 64 * u) * ca.meta.rec + v) : Fr::zero();
+                s[q] = s[q] + ((x[0] + x[1]) + (x[2] + x[3]));
+            }
     }
 #pragma unroll
     for (int q = 0; q < PER_WAVE; ++q) {
