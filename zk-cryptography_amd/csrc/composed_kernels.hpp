@@ -510,7 +510,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_multi_kernel(
 // than such a round has waves), which is what made a small round kernel 13 us; here lane g of a group folds ONE of the four
 // values (table g / 2, lower or upper output), the group exchanges them, and lanes 0 / 1 / 2 multiply for t = 0 / 1 / 2: two
 // products deep (three with an additive table).  Same values, same record layout (gridDim.x records).
-constexpr size_t CMP_SPLIT_MAX = 16384;
+constexpr size_t CMP_SPLIT_MAX = 65536;   // measured: 16384 / 65536 / 262144 output pairs -> 0.710 / 0.705 / 0.72 ms (K = 2, 2^22), 11.63 / 11.57 / 11.70 ms (GKR depth 20)
 static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_split2_kernel(MultiTablePtrs mp, size_t n, const uint64_t* __restrict__ r_ptr,
                                                                           uint32_t rec, uint64_t* __restrict__ partials) {
     __shared__ Fr red[3][MLE_BLOCK / 64];
