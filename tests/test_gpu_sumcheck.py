@@ -115,3 +115,30 @@ def test_proofs_in_flight_match_synchronous_proofs(zk, ora):
     a.wait()
     del b
     scs[2].prove()
+
+
+@pytest.mark.parametrize("log_n", [19, 21])
+def test_poly_sum_with_the_total_deferred(zk, ora, log_n):
+    """Tables of 2^19..2^24 entries: poly_sum() leaves the total to prove()'s own sum tree (zkhip_mle_block_sums_deferred).  The
+    proof absorbs the true sum either way, `sum` read before or after the proof is the true sum, and a sum the caller overrides
+    is absorbed as given."""
+    evals = ora.random_fr(1 << log_n, 7100 + log_n)
+    ws, wrp, wch = ora.sumcheck_prove(evals)
+    poly = zk.Multilinear(evals)
+    sc = zk.Sumcheck(poly)
+    sc.poly_sum()
+    assert sc._sum_deferred
+    proof, ch = sc.prove()                                   # the total never computed by poly_sum
+    assert np.array_equal(proof.sum, ws) and np.array_equal(proof.univariate_poly, wrp) and np.array_equal(ch, wch)
+    assert np.array_equal(sc.sum, ws)                        # ... and delivered on demand
+    sc2 = zk.Sumcheck(poly)
+    sc2.poly_sum()
+    assert np.array_equal(sc2.sum, ws)                       # read first, then prove
+    proof2, ch2 = sc2.prove()
+    assert np.array_equal(proof2.univariate_poly, wrp) and np.array_equal(ch2, wch)
+    sc3 = zk.Sumcheck(poly)
+    sc3.poly_sum()
+    sc3.sum = zk.Fr.from_int(5)                              # an overridden sum is absorbed as it is
+    proof3, ch3 = sc3.prove()
+    assert zk.Fr.to_ints(proof3.sum) == [5] and not np.array_equal(ch3, wch)
+    assert np.array_equal(proof3.univariate_poly[0], wrp[0])

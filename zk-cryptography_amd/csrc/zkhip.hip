@@ -563,8 +563,32 @@ static int launch_fine_sums(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uin
 }
 
 // (2^log_blocks block sums, then the total) of a table, on the device
+static int block_sums_impl(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint32_t log_blocks, uint64_t* d_out, uint64_t* h_total, bool want_total);
 extern "C" int zkhip_mle_block_sums(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint32_t log_blocks,
                                     uint64_t* d_out, uint64_t* h_total) {
+    return block_sums_impl(c, d_evals, n, log_blocks, d_out, h_total, true);
+}
+// The same without the total where it would cost a launch of its own (the fine granularity of the overlapped plan): a prover that
+// is going to absorb the TRUE sum gets it from its own sum tree (zkhip_sumcheck_prove with both claimed-sum arguments NULL), and
+// zkhip_mle_block_sums_total delivers it to a caller who wants to look at it first.
+extern "C" int zkhip_mle_block_sums_deferred(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint32_t log_blocks, uint64_t* d_out) {
+    return block_sums_impl(c, d_evals, n, log_blocks, d_out, nullptr, false);
+}
+extern "C" int zkhip_mle_block_sums_total(zkhip_ctx* c, uint64_t* d_block_sums, uint32_t log_blocks, uint64_t* h_total) {
+    if (!c || !d_block_sums || !h_total || log_blocks > 16) return ZKHIP_ERR_ARG;
+    ZK_TRY(c->activate());
+    // two levels: 2^(lb/2) workgroups sum runs of the block sums into the context's scratch, one workgroup adds those
+    const uint32_t hi = log_blocks / 2, lo = log_blocks - hi;
+    uint64_t* tmp = c->small_u64(ZK_SMALL_PARTIALS);
+    hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << hi), dim3(MLE_BLOCK), 0, c->stream, d_block_sums, 1u << lo, tmp, (uint64_t*)nullptr);
+    hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, tmp, 1u << hi, d_block_sums + 4 * ((size_t)1 << log_blocks), (uint64_t*)nullptr);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_block_sums + 4 * ((size_t)1 << log_blocks), 32, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(h_total, c->pinned_u64(ZK_PIN_RES), 32);
+    return ZKHIP_OK;
+}
+static int block_sums_impl(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint32_t log_blocks, uint64_t* d_out, uint64_t* h_total, bool want_total) {
     if (!c || !d_evals || !d_out) return ZKHIP_ERR_ARG;
     if (!is_pow2(n) || log_blocks > 16 || ((size_t)1 << log_blocks) > n) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
@@ -582,7 +606,7 @@ extern "C" int zkhip_mle_block_sums(zkhip_ctx* c, const uint64_t* d_evals, size_
             ProfScope ps(c, "coarse_sums", 0.0);
             hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, c->stream, d_out, 1u << (log_blocks - k1), coarse_mont, coarse_canon);
         }
-        {
+        if (want_total) {
             ProfScope ps(c, "total_sum", 0.0);
             hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, coarse_mont, 1u << k1, d_out + 4 * ((size_t)1 << log_blocks), (uint64_t*)nullptr);
         }

@@ -58,11 +58,17 @@ class Sumcheck:
         self._sum_ptr = None                       # its device address (no tensor view per call: host time is GPU idle time)
         self._block_sums = None                    # device tensor kept by poly_sum() for prove()
         self._log_blocks = 0
+        self._sum_deferred = False                 # poly_sum() ran but left the total to prove()'s own sum tree (zkhip_mle_block_sums_deferred)
 
     @property
     def sum(self):
         """`self.sum` (private in the reference, sumcheck.rs:7-10): fetched from the device on first read."""
-        if self._sum_dev is not None:
+        if self._sum_deferred:
+            out = np.empty(4, dtype=np.uint64)
+            N.check(N.lib().zkhip_mle_block_sums_total(self.poly._ctx.handle, C.c_void_p(self._block_sums.data_ptr()), C.c_uint32(self._log_blocks),
+                                                       out.ctypes.data_as(C.c_void_p)), "block_sums_total")
+            self._sum_host, self._sum_deferred = out, False
+        elif self._sum_dev is not None:
             self._sum_host = self._sum_dev[-1].cpu().numpy().view(np.uint64).reshape(4).copy()
             self._sum_dev = None
         return self._sum_host
@@ -71,6 +77,7 @@ class Sumcheck:
     def sum(self, v):
         self._sum_host = np.ascontiguousarray(v, dtype=np.uint64).reshape(4)
         self._sum_dev = None
+        self._sum_deferred = False
 
     def poly_sum(self):
         """sumcheck.rs:25-27.  One streaming pass, asynchronous: the sum and the block sums it produces on the way
@@ -87,10 +94,19 @@ class Sumcheck:
             cached = (lb, torch.empty(((1 << lb) + 1, 4), dtype=torch.int64, device=self.poly.evaluations.device))
             self.poly._block_sum_buf = cached
         lb, buf = cached
+        if lb > 9:
+            # the fine granularity of the overlapped plan: the total would be a launch of its own, and prove() has it as the root of
+            # its sum tree -- deferred until someone reads `self.sum`
+            N.check(N.lib().zkhip_mle_block_sums_deferred(self.poly._ctx.handle, C.c_void_p(self.poly.evaluations.data_ptr()), C.c_size_t(n),
+                                                          C.c_uint32(lb), C.c_void_p(buf.data_ptr())), "block_sums")
+            self._block_sums, self._log_blocks = buf, lb
+            self._sum_dev, self._sum_ptr, self._sum_deferred = None, None, True
+            return
         N.check(N.lib().zkhip_mle_block_sums(self.poly._ctx.handle, C.c_void_p(self.poly.evaluations.data_ptr()), C.c_size_t(n),
                                              C.c_uint32(lb), C.c_void_p(buf.data_ptr()), None), "block_sums")
         self._block_sums, self._log_blocks = (buf, lb) if lb else (None, 0)
         self._sum_dev = buf
+        self._sum_deferred = False
         self._sum_ptr = buf.data_ptr() + 32 * (1 << lb)
 
     def prove_begin(self):
@@ -100,7 +116,7 @@ class Sumcheck:
             raise AssertionError("prove_begin needs a table of at least two entries")
         ticket = C.c_uint32(0)
         st = N.lib().zkhip_sumcheck_prove_begin(self.poly._ctx.handle, N.ptr(self.poly.evaluations), C.c_size_t(len(self.poly)),
-                                                None if self._sum_dev is not None else self._sum_host.ctypes.data_as(C.c_void_p),
+                                                None if (self._sum_dev is not None or self._sum_deferred) else self._sum_host.ctypes.data_as(C.c_void_p),
                                                 C.c_void_p(self._sum_ptr) if self._sum_dev is not None else None,
                                                 C.c_void_p(self._block_sums.data_ptr()) if self._block_sums is not None else None,
                                                 C.c_uint32(self._log_blocks), C.byref(ticket))
@@ -118,7 +134,7 @@ class Sumcheck:
         ch = np.empty((max(nv, 1), 4), dtype=np.uint64)
         st = N.lib().zkhip_sumcheck_prove(self.poly._ctx.handle, N.ptr(self.poly.evaluations),
                                           C.c_size_t(len(self.poly)),
-                                          None if self._sum_dev is not None else self._sum_host.ctypes.data_as(C.c_void_p),
+                                          None if (self._sum_dev is not None or self._sum_deferred) else self._sum_host.ctypes.data_as(C.c_void_p),
                                           C.c_void_p(self._sum_ptr) if self._sum_dev is not None else None,
                                           C.c_void_p(self._block_sums.data_ptr()) if self._block_sums is not None else None,
                                           C.c_uint32(self._log_blocks), s.ctypes.data_as(C.c_void_p),
