@@ -224,6 +224,15 @@ def test_overlapped_stage_shards_in_lockstep_match_full_prover(zk, ora, world, l
         sh = D.ShardedSumcheck(D.HipSumcheckEngine(torch.from_numpy(full.view(np.int64)).cuda()), 1, None, None)
         s, rp, ch = sh.prove()
         assert sh.exchanges == 3 and np.array_equal(s, ws) and np.array_equal(rp, wrp) and np.array_equal(ch, wch)
+        # a claimed sum the caller overrides is absorbed as given, as by the single-GPU prover
+        five = zk.Fr.from_int(5)
+        sh = D.ShardedSumcheck(D.HipSumcheckEngine(torch.from_numpy(full.view(np.int64)).cuda()), 1, None, None)
+        s5, rp5, ch5 = sh.prove(claimed_sum=five)
+        sc = zk.Sumcheck(zk.Multilinear(full))
+        sc.sum = five
+        want5, wch5 = sc.prove()
+        assert np.array_equal(s5, want5.sum) and np.array_equal(rp5, want5.univariate_poly) and np.array_equal(ch5, wch5)
+        assert not np.array_equal(ch5, wch)
     # shards outside the plan's range fall back to the stage form
     small = D.HipSumcheckEngine(torch.from_numpy(np.ascontiguousarray(full[: 1 << 12]).view(np.int64)).cuda())
     assert small.overlap_plan(world) is None

@@ -609,7 +609,12 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_reduce_kernel(const
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t v = wave; v < rec; v += MLE_BLOCK / 64) {
         Fr s = Fr::zero();
-        for (uint32_t b = lane; b < n_partials; b += 64) s = s + load_fr(partials, (size_t)b * rec + v);
+        for (uint32_t b = lane; b < n_partials; b += 256) {   // four loads in flight per lane, as in composed_close_kernel
+            Fr x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = b + 64 * u < n_partials ? load_fr(partials, (size_t)(b + 64 * u) * rec + v) : Fr::zero();
+            s = s + ((x[0] + x[1]) + (x[2] + x[3]));
+        }
         s = wave_reduce_fr(s);
         if (lane == 0) store_fr(out, v, s);
     }
