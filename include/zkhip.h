@@ -368,12 +368,12 @@ int zkhip_kzg_commit_table(zkhip_ctx *ctx, const void *d_table, const uint8_t *d
                            uint8_t *h_out_inf);
 /* The same commitments, in flight: begin enqueues everything (on a stream of the context's own, ordered behind the caller's
  * stream) and returns a ticket; end waits for that commit, runs its host epilogue and delivers the result (all-NULL outputs
- * abandon it).  Up to TWO commits may be in flight: a commit is a throughput-bound bucket accumulation followed by
+ * abandon it).  Up to THREE commits may be in flight: a commit is a throughput-bound bucket accumulation followed by
  * latency-bound reductions and a host epilogue, and back to back the latter hide behind the next commit's accumulation
  * (the reference commits one polynomial at a time; a prover with several polynomials to commit -- plonk's wires, every round
  * of an opening -- issues them this way).  Exactly one of d_points_xy / d_table (zkhip_srs_precompute) is given.  While a
  * commit is in flight the context's workspace is lent (other entry points that need it return ZKHIP_ERR_BUSY), and so is a
- * third begin, or a second one larger than the first. */
+ * fourth begin, or a later one larger than the first. */
 int zkhip_kzg_commit_begin(zkhip_ctx *ctx, const uint64_t *d_points_xy, const void *d_table, const uint8_t *d_points_inf,
                            size_t n_points, const uint64_t *d_scalars, size_t n_scalars, int require_equal_len,
                            uint32_t *ticket);

@@ -382,18 +382,22 @@ def test_commits_in_flight_match_synchronous_commits(zk, ora, table):
     polys = [zk.Multilinear(ora.random_fr(1 << log_n, 890 + i)) for i in range(5)]
     want = [zk.MultilinearKZG.commitment(p, srs) for p in polys]
     got, pending = [], []
-    for p in polys:                       # depth-2 pipeline, as bench.py issues them
-        pending.append(zk.MultilinearKZG.commitment_begin(p, srs))
-        if len(pending) == 2:
-            got.append(pending.pop(0).wait())
-    got += [h.wait() for h in pending]
-    assert got == want
-    # two in flight: a third begin, and anything else that needs the workspace, is refused until one has ended
-    a, b = zk.MultilinearKZG.commitment_begin(polys[0], srs), zk.MultilinearKZG.commitment_begin(polys[1], srs)
+    for depth in (2, 3):                  # depth-3 pipeline, as bench.py issues them
+        got, pending = [], []
+        for p in polys:
+            pending.append(zk.MultilinearKZG.commitment_begin(p, srs))
+            if len(pending) == depth:
+                got.append(pending.pop(0).wait())
+        got += [h.wait() for h in pending]
+        assert got == want
+    # three in flight: a fourth begin, and anything else that needs the workspace, is refused until one has ended
+    a, b, c3 = (zk.MultilinearKZG.commitment_begin(polys[i], srs) for i in range(3))
     with pytest.raises(N.ZkhipError, match="split-phase|lent"):
-        zk.MultilinearKZG.commitment_begin(polys[2], srs)
+        zk.MultilinearKZG.commitment_begin(polys[3], srs)
     with pytest.raises(N.ZkhipError, match="split-phase|lent"):
-        zk.MultilinearKZG.commitment(polys[2], srs)
+        zk.MultilinearKZG.commitment(polys[3], srs)
     assert a.wait() == want[0]
+    d4 = zk.MultilinearKZG.commitment_begin(polys[3], srs)     # the freed slot is taken again while two are still in flight
+    assert c3.wait() == want[2] and d4.wait() == want[3]
     del b                                  # an abandoned commitment is drained and its slot released
     assert zk.MultilinearKZG.commitment(polys[2], srs) == want[2]

@@ -215,7 +215,7 @@ class MultilinearKZG:
 
     @staticmethod
     def commitment_begin(poly, srs):
-        """The same commitment, in flight: -> PendingCommitment (at most two at a time); .wait() yields the G1Affine."""
+        """The same commitment, in flight: -> PendingCommitment (at most three at a time); .wait() yields the G1Affine."""
         assert isinstance(poly, Multilinear)
         return _commit_begin(srs.powers_of_tau_in_g1, srs.inf, len(srs), poly.evaluations, len(poly), True, getattr(srs, "_table", None))
 
