@@ -263,6 +263,23 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
         assert len(got) == steps and all(g == com for g in got), "commitments in flight differ from the synchronous ones"
         pipelined = {"value": round(float(n) * steps / dt_pipe, 1), "unit": "points/s", "ms_per_commit": round(1e3 * dt_pipe / steps, 3),
                      "in_flight": depth, "note": "zkhip_kzg_commit_begin / _end: same commitments, issued back to back"}
+    # informational (SURVEY 8f rows built on the commit): SRS generation on the device and MultilinearKZG::open over the same SRS
+    extras = None
+    if world == 1 and log_n <= 22:
+        t_s = time.perf_counter()
+        zk.TrustedSetup.setup(tau)
+        torch.cuda.synchronize()
+        t_s = time.perf_counter() - t_s
+        z = zk.Fr.synthetic(log_n, SEED_SCALARS + 0x200)
+        zk.MultilinearKZG.open(poly, z, plain_srs)                 # first call derives and caches the folded SRS levels
+        torch.cuda.synchronize()
+        t_o = time.perf_counter()
+        for _ in range(3):
+            proof = zk.MultilinearKZG.open(poly, z, plain_srs)
+        torch.cuda.synchronize()
+        t_o = (time.perf_counter() - t_o) / 3
+        extras = {"srs_setup_ms": round(1e3 * t_s, 2), "open": {"ms_per_open": round(1e3 * t_o, 3), "proofs": len(proof.proofs),
+                  "note": "MultilinearKZG::open (multilinear_kzg.rs:50-88): %d quotient commitments, folded SRS levels cached" % len(proof.proofs)}}
     # the same commitments without the table (16 instead of 13 bucket additions per point, 16 bucket reductions)
     zk.MultilinearKZG.commitment(poly, plain_srs)
     torch.cuda.synchronize()
@@ -286,6 +303,7 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
            "srs_table": {"bytes": int(srs._table.numel()), "build_ms": round(1e3 * t_tab, 1),
                          "note": "2^(20 w) * point for the 13 windows of a scalar; depends on the SRS only, built once, not timed"},
            "pipelined": pipelined,
+           "extras": extras,
            "without_srs_table": {"value": round(float(n) * steps / dt_plain, 1), "unit": "points/s (this rank)",
                                  "ms_per_commit": round(1e3 * dt_plain / steps, 3)},
            "roofline": {"bound": "integer ALU (not HBM: ~10 Fq products of ~900 instructions per bucket addition)",

@@ -15,7 +15,7 @@ for l in sys.stdin:
         if "error" in v: print(" ", k, "ERROR", v["error"]); continue
         if k == "fold": print("  fold ms", v["ms_per_fold"], "frac", v["roofline"]["frac"], "us", v["roofline"]["avg_launch_us"])
         if k == "msm": print("  msm ms", v["ms_per_commit"], "pipelined", g(v, "pipelined", "ms_per_commit"), "plain", g(v, "without_srs_table", "ms_per_commit"), "alu frac", g(v, "roofline_alu", "frac"),
-                             "cpu", g(v, "cpu_baseline", "value"), g(v, "cpu_baseline", "all_cores", "value"), g(v, "cpu_baseline", "cpu_pippenger_context", "value"))
+                             "cpu", g(v, "cpu_baseline", "value"), g(v, "cpu_baseline", "all_cores", "value"), g(v, "cpu_baseline", "cpu_pippenger_context", "value"), "| srs", g(v, "extras", "srs_setup_ms"), "open", g(v, "extras", "open", "ms_per_open"))
         if k == "ntt": print("  ntt fft", v["ms_per_fft"], "ifft", v["ms_per_ifft"], "multiply", v["ms_per_multiply"], "hbm frac", v["roofline"]["frac"], "valu frac", v["roofline_alu"]["frac"])
         if k == "composed": print("  composed ms", v["ms_per_prove"], "exch", v.get("exchanges_per_prove"), "same", v.get("transcript_replicated_on_all_ranks"))
         if k == "gkr": print("  gkr", v["ms_per_proof"])
