@@ -14,7 +14,7 @@ def zk():
     return z
 
 
-@pytest.mark.parametrize("world,log_n", [(2, 14), (4, 9), (2, 3), (8, 16), (2, 18)])
+@pytest.mark.parametrize("world,log_n", [(2, 14), (4, 9), (2, 3), (8, 16), (2, 18), (8, 11)])   # (8, 11): the 2048-entry tail opens the transcript itself
 def test_two_shards_in_lockstep_match_full_prover(zk, ora, world, log_n):
     import torch
     from zk_cryptography_amd import distributed as D
@@ -168,6 +168,30 @@ def test_stage_form_2_27_over_8_shards_matches_single_gpu_prover(zk):
         e.tail(rest, n_local * world)
         s, rp, ch = e.finish(log_n)
         assert np.array_equal(s, want.sum) and np.array_equal(rp, want.univariate_poly) and np.array_equal(ch, want_ch)
+
+
+def test_gathered_tail_of_2048_entries_with_a_claimed_sum(zk, ora):
+    """zkhip_sc_tail on a 2048-entry table that no round has touched yet: its first round (run by itself: the serial kernel holds 1024
+    entries) opens the transcript and absorbs the caller's sum as given."""
+    import torch
+    from zk_cryptography_amd import distributed as D
+    full = ora.random_fr(1 << 11, 4711)
+    t = torch.from_numpy(full.view(np.int64)).cuda()
+    five = zk.Fr.from_int(5)
+    for claimed in (None, five):
+        sh = D.ShardedSumcheck(D.HipSumcheckEngine(t), 1, None, None)
+        s, rp, ch = sh.prove(claimed_sum=claimed)
+        sc = zk.Sumcheck(zk.Multilinear(full))
+        if claimed is None:
+            sc.poly_sum()
+        else:
+            sc.sum = claimed
+        want, wch = sc.prove()
+        assert np.array_equal(s, want.sum) and np.array_equal(rp, want.univariate_poly) and np.array_equal(ch, wch)
+    ws, wrp, wch = ora.sumcheck_prove(full)
+    sh = D.ShardedSumcheck(D.HipSumcheckEngine(t), 1, None, None)
+    s, rp, ch = sh.prove()
+    assert np.array_equal(s, ws) and np.array_equal(rp, wrp) and np.array_equal(ch, wch)
 
 
 def _drive_overlapped(torch, engines, world, log_n):
