@@ -44,6 +44,14 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.zkhip_status_string.restype = C.c_char_p
         _lib.zkhip_sumcheck_plan_log_blocks.argtypes = [C.c_size_t]
+        # the prover's hot calls take plain integers for their pointers (no ctypes object per argument: host time between a
+        # proof and the next call's first launch is GPU idle time)
+        vp = C.c_void_p
+        _lib.zkhip_mle_block_sums_deferred.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp]
+        _lib.zkhip_mle_block_sums.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, vp]
+        _lib.zkhip_sumcheck_prove.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp, vp, vp]
+        _lib.zkhip_sumcheck_prove_begin.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp]
+        _lib.zkhip_sumcheck_prove_end.argtypes = [vp, C.c_uint32, vp, vp, vp]
     return _lib
 
 

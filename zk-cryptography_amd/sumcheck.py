@@ -23,6 +23,13 @@ class SumcheckProof:
         self.univariate_poly = univariate_poly
 
 
+def _proof_buffers(nv):
+    """(sum [4], round polynomials [nv, 2, 4], challenges [nv, 4]) as views of ONE fresh allocation, and its address"""
+    m = max(nv, 1)
+    buf = np.empty(4 + 12 * m, dtype=np.uint64)
+    return buf[:4], buf[4:4 + 8 * m].reshape(m, 2, 4)[:nv], buf[4 + 8 * m:].reshape(m, 4)[:nv], buf.ctypes.data
+
+
 class PendingProof:
     """A Sumcheck::prove in flight (zkhip_sumcheck_prove_begin / _end)."""
 
@@ -33,12 +40,9 @@ class PendingProof:
         if self._ticket is None:
             raise RuntimeError("proof already collected")
         nv = self._poly.n_vars
-        s = np.empty(4, dtype=np.uint64)
-        rp = np.empty((nv, 2, 4), dtype=np.uint64)
-        ch = np.empty((nv, 4), dtype=np.uint64)
+        s, rp, ch, base = _proof_buffers(nv)
         t, self._ticket = self._ticket, None
-        N.check(N.lib().zkhip_sumcheck_prove_end(self._poly._ctx.handle, C.c_uint32(t), s.ctypes.data_as(C.c_void_p),
-                                                 rp.ctypes.data_as(C.c_void_p), ch.ctypes.data_as(C.c_void_p)), "sumcheck_prove_end")
+        N.check(N.lib().zkhip_sumcheck_prove_end(self._poly._ctx.handle, t, base, base + 32, base + 32 + 64 * max(nv, 1)), "sumcheck_prove_end")
         return SumcheckProof(self._poly, s, rp), ch
 
     def __del__(self):
@@ -97,13 +101,11 @@ class Sumcheck:
         if lb > 9:
             # the fine granularity of the overlapped plan: the total would be a launch of its own, and prove() has it as the root of
             # its sum tree -- deferred until someone reads `self.sum`
-            N.check(N.lib().zkhip_mle_block_sums_deferred(self.poly._ctx.handle, C.c_void_p(self.poly.evaluations.data_ptr()), C.c_size_t(n),
-                                                          C.c_uint32(lb), C.c_void_p(buf.data_ptr())), "block_sums")
+            N.check(N.lib().zkhip_mle_block_sums_deferred(self.poly._ctx.handle, self.poly.evaluations.data_ptr(), n, lb, buf.data_ptr()), "block_sums")
             self._block_sums, self._log_blocks = buf, lb
             self._sum_dev, self._sum_ptr, self._sum_deferred = None, None, True
             return
-        N.check(N.lib().zkhip_mle_block_sums(self.poly._ctx.handle, C.c_void_p(self.poly.evaluations.data_ptr()), C.c_size_t(n),
-                                             C.c_uint32(lb), C.c_void_p(buf.data_ptr()), None), "block_sums")
+        N.check(N.lib().zkhip_mle_block_sums(self.poly._ctx.handle, self.poly.evaluations.data_ptr(), n, lb, buf.data_ptr(), None), "block_sums")
         self._block_sums, self._log_blocks = (buf, lb) if lb else (None, 0)
         self._sum_dev = buf
         self._sum_deferred = False
@@ -115,11 +117,11 @@ class Sumcheck:
         if len(self.poly) < 2:
             raise AssertionError("prove_begin needs a table of at least two entries")
         ticket = C.c_uint32(0)
-        st = N.lib().zkhip_sumcheck_prove_begin(self.poly._ctx.handle, N.ptr(self.poly.evaluations), C.c_size_t(len(self.poly)),
-                                                None if (self._sum_dev is not None or self._sum_deferred) else self._sum_host.ctypes.data_as(C.c_void_p),
-                                                C.c_void_p(self._sum_ptr) if self._sum_dev is not None else None,
-                                                C.c_void_p(self._block_sums.data_ptr()) if self._block_sums is not None else None,
-                                                C.c_uint32(self._log_blocks), C.byref(ticket))
+        st = N.lib().zkhip_sumcheck_prove_begin(self.poly._ctx.handle, self.poly.evaluations.data_ptr(), len(self.poly),
+                                                None if (self._sum_dev is not None or self._sum_deferred) else self._sum_host.ctypes.data,
+                                                self._sum_ptr if self._sum_dev is not None else None,
+                                                self._block_sums.data_ptr() if self._block_sums is not None else None,
+                                                self._log_blocks, C.addressof(ticket))
         N.check(st, "sumcheck_prove_begin")
         return PendingProof(self.poly, ticket.value)
 
@@ -129,15 +131,11 @@ class Sumcheck:
         The transcript absorbs `self.sum` exactly as the reference does (zero if poly_sum() was never
         called)."""
         nv = self.poly.n_vars
-        s = np.empty(4, dtype=np.uint64)
-        rp = np.empty((max(nv, 1), 2, 4), dtype=np.uint64)
-        ch = np.empty((max(nv, 1), 4), dtype=np.uint64)
-        st = N.lib().zkhip_sumcheck_prove(self.poly._ctx.handle, N.ptr(self.poly.evaluations),
-                                          C.c_size_t(len(self.poly)),
-                                          None if (self._sum_dev is not None or self._sum_deferred) else self._sum_host.ctypes.data_as(C.c_void_p),
-                                          C.c_void_p(self._sum_ptr) if self._sum_dev is not None else None,
-                                          C.c_void_p(self._block_sums.data_ptr()) if self._block_sums is not None else None,
-                                          C.c_uint32(self._log_blocks), s.ctypes.data_as(C.c_void_p),
-                                          rp.ctypes.data_as(C.c_void_p), ch.ctypes.data_as(C.c_void_p))
+        s, rp, ch, base = _proof_buffers(nv)
+        st = N.lib().zkhip_sumcheck_prove(self.poly._ctx.handle, self.poly.evaluations.data_ptr(), len(self.poly),
+                                          None if (self._sum_dev is not None or self._sum_deferred) else self._sum_host.ctypes.data,
+                                          self._sum_ptr if self._sum_dev is not None else None,
+                                          self._block_sums.data_ptr() if self._block_sums is not None else None,
+                                          self._log_blocks, base, base + 32, base + 32 + 64 * max(nv, 1))
         N.check(st, "sumcheck_prove")
-        return SumcheckProof(self.poly, s, rp[:nv]), ch[:nv]
+        return SumcheckProof(self.poly, s, rp), ch
