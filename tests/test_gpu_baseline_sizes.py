@@ -3,6 +3,7 @@ seconds (sumcheck prover up to 2^27, the full 2^24 fold) and through exact ident
 2^23 / 2^26 points, a depth-20 GKR proof under the restated verifier).
 
   configs[1]  24-var multilinear evaluate + fold, basic prover   sumcheck/src/sumcheck.rs:25-61, evaluation_form.rs:123-175
+  configs[2]  univariate KZG commit, 2^20 tau^i SRS points           kzg/src/univariate_kzg.rs:18-58
   configs[3]  GKR prover, Circuit::random(20) (width 2^20)          gkr/src/protocol.rs:21-196
   configs[4]  multilinear KZG commit, 2^26 evals (2^23 per GPU)     kzg/src/multilinear_kzg.rs:33-48
 """
@@ -12,6 +13,7 @@ import pytest
 from gkr_cases import random_circuit
 
 pytestmark = pytest.mark.gpu
+R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 
 
 @pytest.fixture(scope="module")
@@ -117,7 +119,8 @@ def _commit_identity(zk, ora, log_n, table):
     t = torch.randint(0, 2 ** 62, (1 << log_n, 4), dtype=torch.int64, device="cuda", generator=g)
     poly = zk.Multilinear(t)
     com = zk.MultilinearKZG.commitment(poly, srs)
-    p_tau = zk.Fr.to_ints(poly.evaluation(tau))[0]
+    # p(tau) from the ORACLE's evaluation (CPU, ~5 s at 2^26), not from the GPU's own: the scalar of the identity is independent of HIP
+    p_tau = ora.fr_to_ints(ora.mle_evaluation(t.cpu().numpy().view(np.uint64), tau))[0]
     a = ora.g1_to_affine(ora.g1_mul_int(ora.g1_generator(), p_tau))
     assert com.infinity == bool(a[12]) and np.array_equal(com.xy, a[:12])
     del srs, poly, t
@@ -134,6 +137,32 @@ def test_commit_2_23_shard_identity(zk, ora, table):
 def test_commit_2_26_identity(zk, ora, table):
     """The whole 2^26 commit on one GPU (6 GiB SRS + 2 GiB of evaluations; 84 GiB with the table)."""
     _commit_identity(zk, ora, 26, table)
+
+
+# ---- configs[2] through its own entry points: UnivariateKZG::generate_srs + UnivariateKZG::commitment at 2^20 -------------
+@pytest.mark.parametrize("table", [False, True])
+def test_univariate_commit_2_20_identity(zk, ora, table):
+    """kzg/src/univariate_kzg.rs:18-58 at BASELINE configs[2]'s size: the tau^i SRS generated on the device
+    (generate_srs(tau, 2^20 - 1): 2^20 G1 powers), commitment of 2^20 coefficients == p(tau) G with p(tau) from the ORACLE's
+    DenseUnivariatePolynomial::evaluate (dense_univariate.rs:184-196), plain and shifted-SRS-table paths."""
+    n = 1 << 20
+    tau = ora.random_fr(1, 0xC0FFEE)[0]
+    srs = zk.UnivariateKZG.generate_srs(tau, n - 1)
+    assert srs.powers_of_tau_in_g1.shape[0] == n and not bool(srs.inf.any())
+    # spot-check the generated powers against the oracle's double-and-add: tau^0, tau^1 and two far entries
+    g_aff = ora.g1_to_affine(ora.g1_generator())
+    pts = srs.powers_of_tau_in_g1.cpu().numpy().view(np.uint64).reshape(n, 12)
+    assert np.array_equal(pts[0], g_aff[:12])
+    t_int = ora.fr_to_ints(tau)[0]
+    for i in (1, 4097, n - 1):
+        assert np.array_equal(pts[i], ora.g1_to_affine(ora.g1_mul_int(ora.g1_generator(), pow(t_int, i, R)))[:12]), i
+    if table:
+        srs.precompute()
+    coeffs = ora.random_fr(n, 0x5EED00001001)
+    com = zk.UnivariateKZG.commitment(zk.DenseUnivariatePolynomial(coeffs), srs)
+    p_tau = ora.fr_to_ints(ora.dense_evaluate(coeffs, tau))[0]
+    a = ora.g1_to_affine(ora.g1_mul_int(ora.g1_generator(), p_tau))
+    assert com.infinity == bool(a[12]) and np.array_equal(com.xy, a[:12])
 
 
 # ---- configs[3]: Circuit::random(20) --------------------------------------------------------------------------------------

@@ -154,7 +154,7 @@ def test_commit_random_matches_naive_oracle(zk, ora, log_n):
 
 def test_commit_2_20_identity(zk, ora):
     """BASELINE config 3 size: 2^20-point SRS generated on the device from tau; commit == p(tau) * G where
-    p(tau) comes from the (independently verified) GPU evaluation and the product from the oracle."""
+    p(tau) comes from the oracle's evaluation of the same table and the product from the oracle."""
     import torch
     log_n = 20
     tau = ora.random_fr(log_n, 4242)
@@ -163,7 +163,7 @@ def test_commit_2_20_identity(zk, ora):
     t = torch.randint(0, 2 ** 62, (1 << log_n, 4), dtype=torch.int64, device="cuda", generator=g)
     poly = zk.Multilinear(t)
     com = zk.MultilinearKZG.commitment(poly, srs)
-    p_tau = zk.Fr.to_ints(poly.evaluation(tau))[0]
+    p_tau = ora.fr_to_ints(ora.mle_evaluation(t.cpu().numpy().view(np.uint64), tau))[0]
     _same(zk, com, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), p_tau)))
 
 
@@ -190,7 +190,7 @@ def test_commit_skewed_scalars(zk, ora, log_n, kind):
     sc = ora.random_fr(n, 77 + log_n) if ints is None else zk.Fr.from_ints([int(v) for v in ints])
     poly = zk.Multilinear(sc)
     com = zk.MultilinearKZG.commitment(poly, srs)
-    p_tau = zk.Fr.to_ints(poly.evaluation(tau))[0]
+    p_tau = ora.fr_to_ints(ora.mle_evaluation(np.ascontiguousarray(sc), tau))[0]     # the oracle's p(tau), not the GPU's
     _same(zk, com, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), p_tau)))
 
 
@@ -227,23 +227,26 @@ def test_kzg_open_random_matches_naive_oracle(zk, ora, n_vars):
 @pytest.mark.parametrize("n_vars", [14, 20])   # 20 = BASELINE config 3's SRS size
 def test_kzg_open_exponent_identity(zk, ora, n_vars):
     """Beyond what the naive oracle can do in seconds: proof_i == Q_i(tau) * G, Q_i the round's quotient evaluated at
-    the remaining tau (through the independently verified GPU folds), and the verifier's equation in the exponent."""
+    the remaining tau, and the verifier's equation in the exponent.  Every scalar (quotients, remainders, p(tau), p(z))
+    comes from the ORACLE's folds of the same table; the GPU supplies only the proof under test."""
     tau, z = ora.random_fr(n_vars, 71), ora.random_fr(n_vars, 72)
     vals = ora.random_fr(1 << n_vars, 73)
     srs = zk.TrustedSetup.setup(tau)
     poly = zk.Multilinear(vals)
     proof = zk.MultilinearKZG.open(poly, z, srs)
-    assert np.array_equal(proof.evaluation, poly.evaluation(z))
+    assert np.array_equal(proof.evaluation, ora.mle_evaluation(vals, z))
     tau_i, z_i = zk.Fr.to_ints(tau), zk.Fr.to_ints(z)
     one, zero = zk.Fr.from_int(1), zk.Fr.from_int(0)
-    f, acc = poly, 0
+    f, acc = vals, 0
     for i in range(n_vars):
-        q = f.partial_evaluation(one, 0) - f.partial_evaluation(zero, 0)
-        q_tau = zk.Fr.to_ints(q.evaluation(tau[i + 1:]) if i + 1 < n_vars else q.evaluations.cpu().numpy().view(np.uint64))[0]
+        # the quotient q = f(1, .) - f(0, .) (kzg/src/utils.rs:5-10) evaluated at the remaining tau; evaluation is linear
+        hi, lo = ora.mle_partial_evaluation(f, one, 0), ora.mle_partial_evaluation(f, zero, 0)
+        ev = (lambda t: ora.fr_to_ints(ora.mle_evaluation(t, tau[i + 1:]) if i + 1 < n_vars else t)[0])
+        q_tau = (ev(hi) - ev(lo)) % R
         _same(zk, proof.proofs[i], *_aff(ora, ora.g1_mul_int(ora.g1_generator(), q_tau)))
         acc = (acc + q_tau * (tau_i[i] - z_i[i])) % R
-        f = f.partial_evaluation(z[i], 0)
-    p_tau = zk.Fr.to_ints(poly.evaluation(tau))[0]
+        f = ora.mle_partial_evaluation(f, z[i], 0)
+    p_tau = ora.fr_to_ints(ora.mle_evaluation(vals, tau))[0]
     assert (p_tau - zk.Fr.to_ints(proof.evaluation)[0]) % R == acc
 
 

@@ -66,7 +66,7 @@ def _worker(rank, world, port, q):
         got = [zk.SparseUnivariatePolynomial(c, p).monomials() for c, p in rps]
         res["multi_composed"] = bool(got == [p.monomials() for p in wproof.round_polys] and np.array_equal(ch, wch))
         # GKRProtocol::prove with every layer's sumcheck sharded (narrow layers run whole on every rank)
-        for depth in (5, 9):
+        for depth in (5, 9, 20):      # 20 = BASELINE configs[3]'s width (2^20-value layers, 161 exchanges)
             circuit = zk.Circuit.random(depth)
             ev = circuit.evaluation(zk.Fr.random(2 ** depth, 300 + depth))
             want = zk.GKRProtocol.prove(circuit, ev)

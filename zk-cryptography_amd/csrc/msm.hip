@@ -116,22 +116,10 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     const size_t items_max = n * pl.w_per;
     const size_t rec_cap = items_max / heavy_min + items_max / MSM_HEAVY_REC + 2;
     const size_t slots_cap = 3 * (items_max / MSM_HEAVY_REC) + 8;
-    // two-level pass 6 when a window has more than 4096 segments: `term_sel` selected segments per workgroup, chosen so
-    // that the launch has about two workgroups per CU (see msm_terms_part_kernel)
-    const bool wide_terms = pl.ns > 4096;
-    const uint32_t term_block = MSM_BLOCK;
-    uint32_t term_sel = term_block;
-    {
-        const size_t selected = (size_t)pl.n_windows * ((size_t)pl.ns + (size_t)pl.n_bits * (pl.ns / 2));
-        const size_t cap = 464;   // measured best of 58..2000 workgroups (tools/perf_msm.py with TABLE=1): 0.6 ms at 2^16 segments
-        while ((selected + term_sel - 1) / term_sel > cap) term_sel += term_block;
-    }
-    const uint32_t term_chunks = (pl.ns + term_sel - 1) / term_sel;   // chunks of term 0 (the longest row)
     const size_t o_tparts = o_terms + al(n_out * 192);
     // rows / columns of the segment sums (msm_rowcol_kernel): per window R row sums of S, R of A, C column sums of S
     const uint32_t lo_bits = pl.n_bits / 2;
     const uint32_t rc_C = 1u << lo_bits, rc_R = pl.ns >> lo_bits;
-    (void)wide_terms; (void)term_chunks;
     const size_t o_ovf = o_tparts + al((size_t)pl.n_windows * (2 * rc_R + rc_C) * 256);
     const size_t o_rec = o_ovf + al(sizeof(MsmOverflow));
     const size_t o_part = o_rec + al(MSM_HEAVY_LEVELS * rec_cap * sizeof(MsmHeavyRec));
@@ -333,7 +321,13 @@ extern "C" int zkhip_kzg_commit_begin(zkhip_ctx* c, const uint64_t* d_points_xy,
         c->stream = main_stream;
         c->ws_lent = lent;
     }
-    if (rc != ZKHIP_OK) { delete pend; return rc; }
+    if (rc != ZKHIP_OK) {
+        // a partially enqueued commit may have kernels running on the side stream: drain them before the slot, its workspace
+        // region and its pinned buffer are handed out again
+        hipStreamSynchronize(c->side[slot]);
+        delete pend;
+        return rc;
+    }
     c->async_pend[slot] = pend;
     c->ws_lent = true;                    // until the last commit in flight has ended
     *ticket = (uint32_t)slot;

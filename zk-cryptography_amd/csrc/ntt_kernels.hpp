@@ -213,7 +213,7 @@ static __global__ __launch_bounds__(NTT_BIG_BLOCK) void ntt_first8_kernel(const 
 }
 
 template <bool LAST_SCALED>
-static __global__ __launch_bounds__(NTT_BIG_BLOCK) void ntt_pass_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst,
+static __global__ __launch_bounds__(NTT_BIG_BLOCK) void ntt_pass_kernel(const uint64_t* src, uint64_t* dst,   /* may alias: the middle passes run in place */
                                                                         uint32_t s0, uint32_t T, const uint64_t* __restrict__ tw,
                                                                         FrArg scale, size_t n_dst) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];

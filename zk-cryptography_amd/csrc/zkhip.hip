@@ -1214,6 +1214,7 @@ extern "C" int zkhip_sc_finish(zkhip_sc_state* st, uint64_t* h_sum, uint64_t* h_
     uint64_t* pin = c->pinned_u64(ZK_PIN_PROOF);
     if (rc == ZKHIP_OK && hipMemcpyAsync(pin, st->small, 8 * span, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
+    if (st->ov_phase == 2 && c->fold_stream && hipStreamSynchronize(c->fold_stream) != hipSuccess) rc = ZKHIP_ERR_HIP;   // un-joined fold (see zkhip_sc_abort)
     if (rc == ZKHIP_OK) {
         if (h_sum) std::memcpy(h_sum, pin + ((const uint64_t*)st->dev()->sum - st->small), 32);
         if (h_rp && st->round) std::memcpy(h_rp, pin + 64, 64 * (size_t)st->round);
@@ -1228,6 +1229,10 @@ extern "C" int zkhip_sc_abort(zkhip_sc_state* st) {
     zkhip_ctx* c = st->c;
     int rc = ZKHIP_OK;
     if (c->activate() != ZKHIP_OK || hipStreamSynchronize(c->stream) != hipSuccess) rc = ZKHIP_ERR_HIP;   // kernels may still read the buffers
+    // between zkhip_sc_overlap_rounds1 and _rounds2 the shard's k1-variable fold runs on the fold stream and is joined to
+    // c->stream only inside _rounds2: an abort in that window must wait for it too (it reads the caller's table and writes the
+    // workspace and the cached stage buffer that sc_release hands back)
+    if (c->fold_stream && hipStreamSynchronize(c->fold_stream) != hipSuccess) rc = ZKHIP_ERR_HIP;
     sc_release(st);
     return rc;
 }
