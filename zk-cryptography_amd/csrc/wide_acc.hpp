@@ -27,23 +27,8 @@ struct WideAcc {
     }
 };
 
-// x = sum_c col[c] * 2^(32c) as 17 limbs, then 9-word Montgomery reduction: returns x * 2^-288 mod r, canonical
-__device__ __forceinline__ Fr wide_reduce(const uint64_t (&lo)[15], const uint32_t (&hi)[15]) {
-    uint32_t x[18];
-    uint64_t carry = 0;     // running value above the current limb (< 2^64 + small)
-    uint32_t carry_hi = 0;
-#pragma unroll
-    for (int c = 0; c < 15; ++c) {
-        // add column c (96 bits) at limb c to the running carry (carry: 64 bit + carry_hi: 32 bit)
-        uint64_t s = carry + lo[c];
-        uint32_t ov = s < carry ? 1u : 0u;
-        x[c] = (uint32_t)s;
-        carry = (s >> 32) | ((uint64_t)(carry_hi + hi[c] + ov) << 32);
-        carry_hi = 0;   // (carry_hi + hi[c] + ov) < 2^32: hi[c] counts at most 2^11 carries
-    }
-    x[15] = (uint32_t)carry;
-    x[16] = (uint32_t)(carry >> 32);
-    x[17] = 0;
+// 9-word Montgomery reduction of a 17-limb integer x (x[17] = 0 on entry): returns x * 2^-288 mod r, canonical
+__device__ __forceinline__ Fr wide_redc(uint32_t (&x)[18]) {
     // word-serial REDC, 9 words: after step i, limb i is zero
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -65,9 +50,29 @@ __device__ __forceinline__ Fr wide_reduce(const uint64_t (&lo)[15], const uint32
     Fr r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.l[i] = x[9 + i];
-    // x < 2^518  =>  x / 2^288 + r < 2r: one conditional subtraction (x[17] is zero)
+    // x < 2^520  =>  x / 2^288 + r < 2r: one conditional subtraction (x[17] is zero)
     r.reduce_once();
     return r;
+}
+
+// x = sum_c col[c] * 2^(32c) as 17 limbs, then 9-word Montgomery reduction: returns x * 2^-288 mod r, canonical
+__device__ __forceinline__ Fr wide_reduce(const uint64_t (&lo)[15], const uint32_t (&hi)[15]) {
+    uint32_t x[18];
+    uint64_t carry = 0;     // running value above the current limb (< 2^64 + small)
+    uint32_t carry_hi = 0;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) {
+        // add column c (96 bits) at limb c to the running carry (carry: 64 bit + carry_hi: 32 bit)
+        uint64_t s = carry + lo[c];
+        uint32_t ov = s < carry ? 1u : 0u;
+        x[c] = (uint32_t)s;
+        carry = (s >> 32) | ((uint64_t)(carry_hi + hi[c] + ov) << 32);
+        carry_hi = 0;   // (carry_hi + hi[c] + ov) < 2^32: hi[c] counts at most 2^11 carries
+    }
+    x[15] = (uint32_t)carry;
+    x[16] = (uint32_t)(carry >> 32);
+    x[17] = 0;
+    return wide_redc(x);
 }
 
 // Montgomery form of 2^32: wide_reduce divides by 2^288, so either one operand of every product carries this factor

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -16,6 +17,7 @@
 #include "mle_kernels.hpp"
 #include "sumcheck_kernels.hpp"
 #include "multifold_kernels.hpp"
+#include "mfma_fold.hpp"
 
 using namespace zk;
 
@@ -210,6 +212,8 @@ extern "C" int zkhip_mle_partial_evaluation(zkhip_ctx* c, const uint64_t* d_eval
     return launch_fold(c, d_evals, n, d_r, h_r, var_index, d_out, false, nullptr, nullptr);
 }
 
+static int launch_multifold(zkhip_ctx* c, hipStream_t stream, const uint64_t* cur, size_t cn, uint32_t k, const uint64_t* d_w,
+                            uint64_t* dst, uint64_t* pdst, uint32_t* n_parts);
 // Successive folds of variable 0 (or of h_var_indices); the points are host values, passed by value per launch.
 static int fold_chain(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_pts,
                       const uint32_t* var_indices, size_t n_pts, uint64_t* d_out) {
@@ -220,17 +224,20 @@ static int fold_chain(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uin
         ZK_HIP(c, hipMemcpyAsync(d_out, d_evals, n * 32, hipMemcpyDeviceToDevice, c->stream));
         return ZKHIP_OK;
     }
-    const size_t need = (n / 2 + n / 4 + 8) * 32 + (256 + n / 1024 + 4096) * 32;
+    const size_t need = (n / 2 + n / 4 + 8) * 32 + (256 + n / 512 + 4096) * 32;
     ZK_TRY(c->reserve_ws(need));
     uint64_t* A = (uint64_t*)c->d_ws;
     uint64_t* B = A + 4 * (n / 2);
     uint64_t* d_w = B + 4 * (n / 4 + 4);
-    uint64_t* d_dummy = d_w + 4 * 256;            // per-workgroup output sums of the k-variable fold (unused here)
+    uint64_t* d_dummy = d_w + 4 * 256;            // per-workgroup output sums of the k-variable fold (unused here; <= n / 512 of them)
     const uint64_t* cur = d_evals;
     size_t cn = n;
     size_t p0 = 0;
-    if (!var_indices) {
-        // every point folds variable 0: collapse k of them per pass (weights = eq table of those points)
+    // every point folds variable 0 (`evaluation`, and partial_evaluations(&r, &vec![0; k]) as GKR calls it, gkr/src/protocol.rs:64-68):
+    // collapse k of them per pass (weights = eq table of those points)
+    bool all_zero = true;
+    if (var_indices) for (size_t q = 0; q < n_pts; ++q) all_zero = all_zero && var_indices[q] == 0;
+    if (all_zero) {
         uint32_t stage = 0;
         while (cn > (size_t)TAIL_N && n_pts - p0 >= 3) {
             uint32_t k = log2_exact(cn) - TAIL_LOG;
@@ -241,16 +248,7 @@ static int fold_chain(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uin
             const bool last = (p0 + k == n_pts);
             uint64_t* dst = last ? d_out : ((stage & 1) ? B : A);
             hipLaunchKernelGGL(eq_weights_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, pa, (uint32_t)p0, k, d_w);
-            if (m >= 8192) {
-                ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m);
-                hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), ((size_t)32 << k) + 32 * 3 * 64, c->stream, cur, m, k, d_w, dst, d_dummy);
-            } else {
-                uint32_t waves = 16;
-                while (waves * 4 > (1u << k)) waves >>= 1;
-                ProfScope ps(c, "multifold_small", 32.0 * (double)cn + 32.0 * (double)m);
-                hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), ((size_t)32 << k) + 32 * (size_t)(waves - 1) * 16, c->stream, cur, m, k, d_w, dst, d_dummy);
-            }
-            ZK_HIP(c, hipGetLastError());
+            ZK_TRY(launch_multifold(c, c->stream, cur, cn, k, d_w, dst, d_dummy, nullptr));
             cur = dst; cn = m; p0 += k; ++stage;
             if (last) return ZKHIP_OK;
         }
@@ -504,7 +502,21 @@ static int launch_multifold(zkhip_ctx* c, hipStream_t stream, const uint64_t* cu
                             uint64_t* dst, uint64_t* pdst, uint32_t* n_parts) {
     const size_t m = cn >> k;
     uint32_t out_per_wg;
-    if (m >= 8192) {          // streaming shape: 64 outputs per workgroup, its waves split the terms
+    // tuning knob (diagnostics only): ZKHIP_MF = 0 keeps the VALU form; "WDR" = the MFMA form's waves per workgroup, load depth and
+    // the rotation of the term order (tile T starts at term R * T mod 2^k; 0 = every wave at term 0)
+    static const int mf_cfg = [] { const char* e = getenv("ZKHIP_MF"); return e ? atoi(e) : 441; }();
+    if (m >= 8192 && k >= 4 && mf_cfg != 0) {   // streaming shape, limb products on the matrix cores (mfma_fold.hpp)
+        out_per_wg = 64;
+        ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m, stream);
+        const unsigned tiles = (unsigned)(m / 64), rot = (unsigned)(mf_cfg % 10);
+        const size_t q_bytes = mfm_lds_bytes(std::min<uint32_t>(1u << k, (uint32_t)MFM_CHUNK));
+        switch (mf_cfg / 10) {
+#define ZK_MF_CASE(W, D) case W * 10 + D: hipLaunchKernelGGL((multifold_mfma_kernel<W, D>), dim3(tiles / W), dim3(64 * W), q_bytes, stream, cur, m, k, d_w, dst, pdst, rot); break;
+            ZK_MF_CASE(1, 4) ZK_MF_CASE(2, 4) ZK_MF_CASE(4, 2) ZK_MF_CASE(1, 2)
+            default: hipLaunchKernelGGL((multifold_mfma_kernel<4, 4>), dim3(tiles / 4), dim3(256), q_bytes, stream, cur, m, k, d_w, dst, pdst, rot); break;
+#undef ZK_MF_CASE
+        }
+    } else if (m >= 8192) {   // streaming shape: 64 outputs per workgroup, its waves split the terms
         out_per_wg = 64;
         // >= 64 terms per lane: every lane pays one 9-word reduction (~a product), which at 16 terms per lane made the
         // 6-variable fold of the overlapped plan 12 % slower than the 8-variable one
@@ -989,21 +1001,10 @@ extern "C" int zkhip_sc_stage_fold(zkhip_sc_state* st) {
     const size_t m = st->cn >> k;
     uint64_t* dst = (st->cur == st->A) ? st->B : st->A;     // m <= n_local/8 fits either buffer
     uint64_t* pdst = (st->parts == st->spx() || st->stage_idx == 0) ? st->spy() : st->spx();
-    uint32_t out_per_wg;
-    if (m >= 8192) {
-        out_per_wg = 64;
-        ProfScope ps(c, "multifold", 32.0 * (double)st->cn + 32.0 * (double)m);
-        hipLaunchKernelGGL(multifold_kernel<64>, dim3((unsigned)(m / 64)), dim3(256), ((size_t)32 << k) + 32 * 3 * 64, c->stream, st->cur, m, k, st->sw(), dst, pdst);
-    } else {
-        out_per_wg = 16;
-        uint32_t waves = 16;
-        while (waves * 4 > (1u << k)) waves >>= 1;
-        ProfScope ps(c, "multifold_small", 32.0 * (double)st->cn + 32.0 * (double)m);
-        hipLaunchKernelGGL(multifold_kernel<16>, dim3((unsigned)(m / 16)), dim3(64 * waves), ((size_t)32 << k) + 32 * (size_t)(waves - 1) * 16, c->stream, st->cur, m, k, st->sw(), dst, pdst);
-    }
-    ZK_HIP(c, hipGetLastError());
+    uint32_t n_parts = 0;
+    ZK_TRY(launch_multifold(c, c->stream, st->cur, st->cn, k, st->sw(), dst, pdst, &n_parts));
     st->parts = pdst;
-    st->n_parts = (uint32_t)(m / out_per_wg);
+    st->n_parts = n_parts;
     st->cur = dst;
     st->cn = m;
     st->partials_valid = false;
