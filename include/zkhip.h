@@ -207,11 +207,12 @@ int zkhip_sumcheck_prove(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, cons
                          uint64_t *h_round_polys, uint64_t *h_challenges);
 
 /* Sumcheck::prove in flight: begin enqueues the whole proof (same inputs as zkhip_sumcheck_prove) and returns a ticket, end
- * waits for that proof and delivers the same outputs (all-NULL outputs abandon it).  Up to two proofs may be in flight; they
- * execute in stream order on the device -- what the pair removes is the idle time between a proof's last kernel and the next
- * proof's first one (host wake-up, return to the caller, the next call's first launch: ~10 % of a 2^24 proof).  While a
- * proof is in flight zkhip_sumcheck_prove returns ZKHIP_ERR_BUSY (the result slots are taken); zkhip_mle_block_sums for the
- * next table may be called (it is ordered behind the proof). */
+ * waits for that proof and delivers the same outputs (all-NULL outputs abandon it).  Up to four proofs may be in flight.  Each
+ * runs on streams, workspace and scratch of its own behind what the caller's stream held at `begin`, so the streaming passes
+ * of one proof (and the zkhip_mle_block_sums of the next table, on the caller's stream) overlap the transcript rounds of the
+ * others; `end` orders the caller's stream behind the proof again.  The table, its block sums and a device-resident claimed sum
+ * must stay untouched between begin and end.  While a proof is in flight zkhip_sumcheck_prove returns ZKHIP_ERR_BUSY (the
+ * result slots are taken). */
 int zkhip_sumcheck_prove_begin(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint64_t *h_claimed_sum,
                                const uint64_t *d_claimed_sum, const uint64_t *d_block_sums, uint32_t log_blocks, uint32_t *ticket);
 int zkhip_sumcheck_prove_end(zkhip_ctx *ctx, uint32_t ticket, uint64_t *h_sum, uint64_t *h_round_polys, uint64_t *h_challenges);

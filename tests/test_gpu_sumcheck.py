@@ -90,31 +90,54 @@ def test_prove_2_24_self_consistency(zk, ora):
     assert zk.Fr.to_ints(poly.evaluation(ch)) == [claim]
 
 
-def test_proofs_in_flight_match_synchronous_proofs(zk, ora):
-    """zkhip_sumcheck_prove_begin / _end: two proofs in flight, different tables and sizes, each equal to the oracle's."""
+@pytest.mark.parametrize("depth", [2, 4])
+def test_proofs_in_flight_match_synchronous_proofs(zk, ora, depth):
+    """zkhip_sumcheck_prove_begin / _end: up to four proofs in flight on lanes of their own (streams, workspace, scratch),
+    different tables and sizes -- overlapped and generic plans side by side -- each equal to the oracle's."""
     from zk_cryptography_amd import _native as N
-    tables = [ora.random_fr(1 << log_n, 5100 + log_n) for log_n in (20, 12, 21, 3, 19)]
+    tables = [ora.random_fr(1 << log_n, 5100 + log_n) for log_n in (20, 12, 21, 3, 19, 20, 22, 9)]
     want = [ora.sumcheck_prove(t) for t in tables]
     got, pending = [], []
-    for t in tables:
-        sc = zk.Sumcheck(zk.Multilinear(t))
-        sc.poly_sum()
-        pending.append(sc.prove_begin())
-        if len(pending) == 2:
-            got.append(pending.pop(0).wait())
-    got += [h.wait() for h in pending]
-    for (proof, ch), (s, rp, och) in zip(got, want):
+    for rep in range(2):                       # twice: the second pass reuses every lane
+        for t in tables:
+            sc = zk.Sumcheck(zk.Multilinear(t))
+            sc.poly_sum()
+            pending.append(sc.prove_begin())
+            if len(pending) == depth:
+                got.append(pending.pop(0).wait())
+        got += [h.wait() for h in pending]
+        pending = []
+    for (proof, ch), (s, rp, och) in zip(got, want + want):
         assert np.array_equal(proof.sum, s) and np.array_equal(proof.univariate_poly, rp) and np.array_equal(ch, och)
-    # a third proof in flight and a synchronous prove are refused while two are pending
-    scs = [zk.Sumcheck(zk.Multilinear(t)) for t in tables[:3]]
-    a, b = scs[0].prove_begin(), scs[1].prove_begin()
+    # a fifth proof in flight and a synchronous prove are refused while four are pending
+    scs = [zk.Sumcheck(zk.Multilinear(t)) for t in tables[:5]]
+    held = [sc.prove_begin() for sc in scs[:4]]
     with pytest.raises(N.ZkhipError):
-        scs[2].prove_begin()
+        scs[4].prove_begin()
     with pytest.raises(N.ZkhipError):
-        scs[2].prove()
-    a.wait()
-    del b
-    scs[2].prove()
+        scs[4].prove()
+    held[0].wait()
+    del held
+    scs[4].prove()                             # every ticket is free again
+
+
+def test_proofs_in_flight_without_poly_sum_and_same_table(zk, ora):
+    """In flight without poly_sum() (the prover derives fine and coarse sums itself, on its lane) and two proofs of ONE table
+    begun back to back (same block sums read by both)."""
+    t = ora.random_fr(1 << 20, 777)
+    s, rp, och = ora.sumcheck_prove(t)
+    poly = zk.Multilinear(t)
+    a = zk.Sumcheck(poly)
+    a.poly_sum()
+    b = zk.Sumcheck(poly)
+    b._block_sums, b._log_blocks, b._sum_deferred = a._block_sums, a._log_blocks, True    # the same device block sums, no second pass
+    ha, hb = a.prove_begin(), b.prove_begin()
+    for proof, ch in (ha.wait(), hb.wait()):
+        assert np.array_equal(proof.sum, s) and np.array_equal(proof.univariate_poly, rp) and np.array_equal(ch, och)
+    c = zk.Sumcheck(zk.Multilinear(t))
+    c.sum = s                                    # claimed sum given by the caller, no block sums at all
+    proof, ch = c.prove_begin().wait()
+    assert np.array_equal(proof.univariate_poly, rp) and np.array_equal(ch, och)
 
 
 @pytest.mark.parametrize("log_n", [19, 21])

@@ -91,11 +91,49 @@ struct zkhip_ctx {
         if (hipStreamCreateWithPriority(&fold_stream, hipStreamNonBlocking, least) != hipSuccess) return ZKHIP_ERR_HIP;
         return ensure_side_streams();
     }
-    // coarse block sums left by zkhip_mle_block_sums for the prover's first rounds (valid for the fine-sum buffer coarse_of)
-    void* d_coarse = nullptr;
-    const void* coarse_of = nullptr; size_t coarse_n = 0; uint32_t coarse_k1 = 0;
-    int ensure_coarse() {
-        if (!d_coarse && hipMalloc(&d_coarse, 2 * 1024 * 32) != hipSuccess) return ZKHIP_ERR_NOMEM;   // canonical, then Montgomery
+    // coarse block sums left by zkhip_mle_block_sums for the prover's first rounds: a ring (canonical, then Montgomery: 64 KiB
+    // each; more entries than proofs in flight), so that the sums of a table whose proof is in flight survive the poly_sum() of the next tables
+    static constexpr int COARSE_RING = 8;
+    void* d_coarse[COARSE_RING] = {};
+    const void* coarse_of[COARSE_RING] = {}; size_t coarse_n[COARSE_RING] = {}; uint32_t coarse_k1[COARSE_RING] = {};
+    int coarse_next = 0;
+    int next_coarse(int* slot) {
+        const int k = coarse_next;
+        coarse_next = (coarse_next + 1) % COARSE_RING;
+        if (!d_coarse[k] && hipMalloc(&d_coarse[k], 2 * 1024 * 32) != hipSuccess) return ZKHIP_ERR_NOMEM;
+        coarse_of[k] = nullptr;
+        *slot = k;
+        return ZKHIP_OK;
+    }
+    // Sumcheck::prove in flight (zkhip_sumcheck_prove_begin): every ticket has a LANE of its own -- a serial stream, a low-priority
+    // fold stream, events, workspace and small scratch -- so that the streaming passes of one proof run while the transcript rounds
+    // of the other hash (the synchronous call keeps the caller's stream and the context's buffers)
+    struct ProofLane {
+        hipStream_t serial = nullptr, fold = nullptr;
+        hipEvent_t begin_ev = nullptr, fork_ev = nullptr, serial_ev = nullptr;
+        void* ws = nullptr; size_t ws_bytes = 0;
+        void* small = nullptr;
+    };
+    static constexpr int PROOF_SLOTS = 4;      // proofs in flight (measured at 2^24: 2 / 3 / 4 in flight, see bench.py `pipelined`)
+    ProofLane lanes[PROOF_SLOTS];
+    int ensure_lane(int k, size_t ws_need) {
+        ProofLane& L = lanes[k];
+        if (!L.serial) {
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return ZKHIP_ERR_HIP;
+            if (hipStreamCreateWithPriority(&L.serial, hipStreamNonBlocking, greatest) != hipSuccess) return ZKHIP_ERR_HIP;
+            if (hipStreamCreateWithPriority(&L.fold, hipStreamNonBlocking, least) != hipSuccess) return ZKHIP_ERR_HIP;
+            if (hipEventCreateWithFlags(&L.begin_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
+            if (hipEventCreateWithFlags(&L.fork_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
+            if (hipEventCreateWithFlags(&L.serial_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
+            if (hipMalloc(&L.small, ZK_SMALL_BYTES) != hipSuccess) return ZKHIP_ERR_NOMEM;
+        }
+        if (ws_need > L.ws_bytes) {                 // grow-only; the lane is idle here (its ticket is free)
+            if (L.ws) { if (hipStreamSynchronize(L.serial) != hipSuccess || hipStreamSynchronize(L.fold) != hipSuccess) return ZKHIP_ERR_HIP; hipFree(L.ws); }
+            L.ws = nullptr; L.ws_bytes = 0;
+            if (hipMalloc(&L.ws, ws_need) != hipSuccess) return ZKHIP_ERR_NOMEM;
+            L.ws_bytes = ws_need;
+        }
         return ZKHIP_OK;
     }
     int reserve_msm_pin(int slot, size_t bytes) {
@@ -165,9 +203,9 @@ struct zkhip_ctx {
     }
     // result slots of the basic prover: pinned copies of [state .. round polynomials] + the event their copy completes at;
     // proof_pending[k] = n_vars of the proof in flight in slot k (0: free)
-    void* proof_pin[2] = {nullptr, nullptr};
-    hipEvent_t proof_ev[2] = {nullptr, nullptr};
-    uint32_t proof_pending[2] = {0, 0};
+    void* proof_pin[PROOF_SLOTS] = {};
+    hipEvent_t proof_ev[PROOF_SLOTS] = {};
+    uint32_t proof_pending[PROOF_SLOTS] = {};
     int ensure_proof_slot(int k) {
         if (!proof_ev[k] && hipEventCreateWithFlags(&proof_ev[k], hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
         if (!proof_pin[k] && hipHostMalloc(&proof_pin[k], ((ZK_SMALL_ROUNDPOLYS - ZK_SMALL_STATE) + 8 * ZK_MAX_ROUNDS) * 8, hipHostMallocDefault) != hipSuccess)

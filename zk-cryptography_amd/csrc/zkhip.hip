@@ -74,9 +74,18 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     if (c->join_ev) hipEventDestroy(c->join_ev);
     if (c->serial_ev) hipEventDestroy(c->serial_ev);
     if (c->done_ev) hipEventDestroy(c->done_ev);
-    for (int k = 0; k < 2; ++k) { if (c->proof_ev[k]) hipEventDestroy(c->proof_ev[k]); if (c->proof_pin[k]) hipHostFree(c->proof_pin[k]); }
+    for (int k = 0; k < zkhip_ctx::PROOF_SLOTS; ++k) { if (c->proof_ev[k]) hipEventDestroy(c->proof_ev[k]); if (c->proof_pin[k]) hipHostFree(c->proof_pin[k]); }
     if (c->fold_stream) hipStreamDestroy(c->fold_stream);
-    if (c->d_coarse) hipFree(c->d_coarse);
+    for (int k = 0; k < zkhip_ctx::COARSE_RING; ++k) if (c->d_coarse[k]) hipFree(c->d_coarse[k]);
+    for (auto& L : c->lanes) {
+        if (L.serial) hipStreamDestroy(L.serial);
+        if (L.fold) hipStreamDestroy(L.fold);
+        if (L.begin_ev) hipEventDestroy(L.begin_ev);
+        if (L.fork_ev) hipEventDestroy(L.fork_ev);
+        if (L.serial_ev) hipEventDestroy(L.serial_ev);
+        if (L.ws) hipFree(L.ws);
+        if (L.small) hipFree(L.small);
+    }
     if (c->d_small) hipFree(c->d_small);
     if (c->sc_small) hipFree(c->sc_small);
     if (c->sc_stage) hipFree(c->sc_stage);
@@ -509,7 +518,11 @@ static int launch_multifold(zkhip_ctx* c, hipStream_t stream, const uint64_t* cu
         out_per_wg = 64;
         ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m, stream);
         const unsigned tiles = (unsigned)(m / 64), rot = (unsigned)(mf_cfg % 10);
-        const size_t q_bytes = mfm_lds_bytes(std::min<uint32_t>(1u << k, (uint32_t)MFM_CHUNK));
+        // ZKHIP_MF_OCC = n: at most n workgroups per CU (through the LDS request); 0 = as many as registers allow (2 at <4, 4>)
+        static const int mf_occ = [] { const char* e = getenv("ZKHIP_MF_OCC"); return e ? atoi(e) : 0; }();
+        size_t q_bytes = mfm_lds_bytes(std::min<uint32_t>(1u << k, (uint32_t)MFM_CHUNK));
+        if (mf_occ > 0) q_bytes = std::max(q_bytes, (size_t)(((158 * 1024 / mf_occ) - 1024) & ~255));
+        if (q_bytes > 64 * 1024) ZK_TRY(c->allow_big_lds((const void*)multifold_mfma_kernel<4, 4>, 158 * 1024));   // (the kernel has ~0.6 KiB of static LDS on top)
         switch (mf_cfg / 10) {
 #define ZK_MF_CASE(W, D) case W * 10 + D: hipLaunchKernelGGL((multifold_mfma_kernel<W, D>), dim3(tiles / W), dim3(64 * W), q_bytes, stream, cur, m, k, d_w, dst, pdst, rot); break;
             ZK_MF_CASE(1, 4) ZK_MF_CASE(2, 4) ZK_MF_CASE(4, 2) ZK_MF_CASE(1, 2)
@@ -561,15 +574,17 @@ static int launch_blockfold(zkhip_ctx* c, hipStream_t stream, const uint64_t* in
 }
 // fine block sums: d_fine[2^lb] = sums of the 2^lb equal consecutive blocks of the table (each >= FINE_CHUNK entries);
 // d_chunk (n / FINE_CHUNK entries of scratch) is only touched when a block is longer than FINE_CHUNK
-static int launch_fine_sums(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint32_t lb, uint64_t* d_fine, uint64_t* d_chunk) {
+static int launch_fine_sums(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint32_t lb, uint64_t* d_fine, uint64_t* d_chunk,
+                            hipStream_t stream = nullptr) {
+    if (!stream) stream = c->stream;
     const size_t blk = n >> lb, n_chunks = n / FINE_CHUNK;
     uint64_t* first = blk == (size_t)FINE_CHUNK ? d_fine : d_chunk;
     {
-        ProfScope ps(c, "chunk_sums", 32.0 * (double)n);
-        hipLaunchKernelGGL(fine_sums_kernel, dim3((unsigned)((n_chunks + 7) / 8)), dim3(MLE_BLOCK), 0, c->stream, d_evals, n_chunks, first);
+        ProfScope ps(c, "chunk_sums", 32.0 * (double)n, stream);
+        hipLaunchKernelGGL(fine_sums_kernel, dim3((unsigned)((n_chunks + 7) / 8)), dim3(MLE_BLOCK), 0, stream, d_evals, n_chunks, first);
     }
     if (first != d_fine)
-        hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << lb), dim3(MLE_BLOCK), 0, c->stream, first, (uint32_t)(blk / FINE_CHUNK), d_fine, (uint64_t*)nullptr);
+        hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << lb), dim3(MLE_BLOCK), 0, stream, first, (uint32_t)(blk / FINE_CHUNK), d_fine, (uint64_t*)nullptr);
     ZK_HIP(c, hipGetLastError());
     return ZKHIP_OK;
 }
@@ -610,19 +625,25 @@ static int block_sums_impl(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint
         uint64_t* d_chunk = nullptr;
         if (m > (size_t)FINE_CHUNK) { ZK_TRY(c->reserve_ws((n / FINE_CHUNK) * 32)); d_chunk = (uint64_t*)c->d_ws; }
         ZK_TRY(launch_fine_sums(c, d_evals, n, log_blocks, d_out, d_chunk));
-        // coarse sums at the granularity the prover's first rounds want (kept for it: zkhip_ctx::coarse), then the total
-        const uint32_t k1 = overlapped_plan(n) && log_blocks == log2_exact(n) - 8 ? log_blocks - overlapped_k2(n) : 8;
-        ZK_TRY(c->ensure_coarse());
-        uint64_t* coarse_canon = (uint64_t*)c->d_coarse, *coarse_mont = coarse_canon + 4 * 1024;
-        {
-            ProfScope ps(c, "coarse_sums", 0.0);
-            hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, c->stream, d_out, 1u << (log_blocks - k1), coarse_mont, coarse_canon);
-        }
+        // With the total: coarse sums at the granularity the prover's first rounds want (kept for it in the context's ring), then the
+        // total from those.  Without (the deferred form): nothing more here -- the prover derives the coarse sums itself, on the
+        // stream of the proof (a high-priority one when the proof is in flight), instead of queueing a tiny kernel on the caller's
+        // stream behind whatever streaming pass occupies the chip.
         if (want_total) {
-            ProfScope ps(c, "total_sum", 0.0);
-            hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, coarse_mont, 1u << k1, d_out + 4 * ((size_t)1 << log_blocks), (uint64_t*)nullptr);
+            const uint32_t k1 = overlapped_plan(n) && log_blocks == log2_exact(n) - 8 ? log_blocks - overlapped_k2(n) : 8;
+            int cs = 0;
+            ZK_TRY(c->next_coarse(&cs));
+            uint64_t* coarse_canon = (uint64_t*)c->d_coarse[cs], *coarse_mont = coarse_canon + 4 * 1024;
+            {
+                ProfScope ps(c, "coarse_sums", 0.0);
+                hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, c->stream, d_out, 1u << (log_blocks - k1), coarse_mont, coarse_canon);
+            }
+            {
+                ProfScope ps(c, "total_sum", 0.0);
+                hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, coarse_mont, 1u << k1, d_out + 4 * ((size_t)1 << log_blocks), (uint64_t*)nullptr);
+            }
+            c->coarse_of[cs] = d_out; c->coarse_n[cs] = n; c->coarse_k1[cs] = k1;
         }
-        c->coarse_of = d_out; c->coarse_n = n; c->coarse_k1 = k1;
     } else {
         const uint32_t chunk = (uint32_t)std::min<size_t>(m, 4096);
         const size_t n_chunks = n / chunk;
@@ -651,8 +672,10 @@ static int block_sums_impl(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint
 // sumcheck_collect waits for that copy (polling its event) and hands the proof out.  A caller with several tables to prove
 // begins the next proof before it collects the previous one (zkhip_sumcheck_prove_begin / _end): the kernels of successive
 // proofs run in stream order, what disappears is the idle time between them (host wake-up, return, next call's first launch).
+// `lane` < 0: on the caller's stream with the context's buffers (the synchronous call); otherwise on the private streams and buffers of
+// c->lanes[lane], behind everything the caller's stream holds at this moment
 static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_claimed_sum,
-                            const uint64_t* d_claimed_sum, const uint64_t* d_block_sums, uint32_t log_blocks, int slot) {
+                            const uint64_t* d_claimed_sum, const uint64_t* d_block_sums, uint32_t log_blocks, int slot, int lane) {
     const uint32_t n_vars = log2_exact(n);
     const bool overlap = overlapped_plan(n);
     // workspace: stage tables (n/4 + n/16 + ...; overlapped: n / 2^k1 <= n/8), partial sums, fold weights, and for the
@@ -662,20 +685,34 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
     const size_t part_entries = std::max<size_t>(n / 4096, n / 256) + 1024;   // chunk sums of stage 0, per-workgroup sums of stage outputs
     const size_t w_entries = (size_t)1 << TREE_MAX_LOG;
     const size_t fine_entries = overlap ? 65536 + 2 * 1024 + 32 * 256 : 0;
-    ZK_TRY(c->reserve_ws((tab_entries + 2 * part_entries + 2 * w_entries + fine_entries) * 32));
-    uint64_t* tabA = (uint64_t*)c->d_ws;
+    const size_t ws_need = (tab_entries + 2 * part_entries + 2 * w_entries + fine_entries) * 32;
+    hipStream_t S, F = nullptr;                   // serial / fold streams of this proof
+    hipEvent_t fork_ev = nullptr, serial_ev = nullptr;
+    uint64_t *ws, *small;
+    if (lane < 0) {
+        ZK_TRY(c->reserve_ws(ws_need));
+        ws = (uint64_t*)c->d_ws; small = (uint64_t*)c->d_small; S = c->stream;
+        if (overlap) { ZK_TRY(c->ensure_fold_stream()); F = c->fold_stream; fork_ev = c->fork_ev; serial_ev = c->serial_ev; }
+    } else {
+        ZK_TRY(c->ensure_lane(lane, ws_need));
+        zkhip_ctx::ProofLane& L = c->lanes[lane];
+        ws = (uint64_t*)L.ws; small = (uint64_t*)L.small; S = L.serial; F = L.fold; fork_ev = L.fork_ev; serial_ev = L.serial_ev;
+        ZK_HIP(c, hipEventRecord(L.begin_ev, c->stream));          // the table, its block sums and the claimed sum are ready behind this
+        ZK_HIP(c, hipStreamWaitEvent(S, L.begin_ev, 0));
+    }
+    uint64_t* tabA = ws;
     uint64_t* tabB = tabA + 4 * tabA_entries;
-    uint64_t* partA = (uint64_t*)c->d_ws + 4 * tab_entries;
+    uint64_t* partA = ws + 4 * tab_entries;
     uint64_t* partB = partA + 4 * part_entries;
     uint64_t* d_w = partB + 4 * part_entries;
     uint64_t* d_w2 = d_w + 4 * w_entries;
     uint64_t* d_fine = d_w2 + 4 * w_entries;           // overlapped plan only from here on
     uint64_t* d_p1 = d_fine + 4 * 65536;
     uint64_t* d_p2 = d_p1 + 4 * 2 * 1024;
-    SumcheckDev* st = (SumcheckDev*)c->small_u64(ZK_SMALL_STATE);
-    uint64_t* d_rp = c->small_u64(ZK_SMALL_ROUNDPOLYS);
-    uint64_t* d_ch = c->small_u64(ZK_SMALL_CHALLENGES);
-    uint64_t* d_fin = c->small_u64(ZK_SMALL_RES);
+    SumcheckDev* st = (SumcheckDev*)(small + ZK_SMALL_STATE);
+    uint64_t* d_rp = small + ZK_SMALL_ROUNDPOLYS;
+    uint64_t* d_ch = small + ZK_SMALL_CHALLENGES;
+    uint64_t* d_fin = small + ZK_SMALL_RES;
 
     FrArg claimed = {};
     uint32_t first = 1;
@@ -688,24 +725,31 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
     const uint64_t* parts = nullptr;   // partial sums of `cur`, `group` consecutive ones per block of this stage
     uint32_t n_parts = 0;
     bool done = false;
-    hipStream_t tail_stream = c->stream;      // where the last kernels of the proof run (the overlapped plan ends on its fold stream)
+    hipStream_t tail_stream = S;              // where the last kernels of the proof run (the overlapped plan ends on its fold stream)
     if (overlap) {
         const uint32_t g = n_vars - 8, k2 = overlapped_k2(n), k1 = g - k2;
-        ZK_TRY(c->ensure_fold_stream());
-        ZK_TRY(c->ensure_coarse());
         const uint64_t* fine = d_block_sums;
-        bool have_coarse = fine && log_blocks == g && c->coarse_of == fine && c->coarse_n == n && c->coarse_k1 == k1;
         if (!fine || log_blocks != g) {             // poly_sum() was not called (or with another granularity)
-            ZK_TRY(launch_fine_sums(c, d_evals, n, g, d_fine, nullptr));
+            ZK_TRY(launch_fine_sums(c, d_evals, n, g, d_fine, nullptr, S));
             fine = d_fine;
         }
-        if (!have_coarse)
-            hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, c->stream, fine, 1u << k2, (uint64_t*)nullptr, (uint64_t*)c->d_coarse);
-        c->coarse_of = nullptr;                     // d_coarse belongs to this call from here on
+        // the coarse sums poly_sum() left for this table (the newest ring entry that names its fine sums), or our own
+        int cs = -1;
+        for (int q = 1; q <= zkhip_ctx::COARSE_RING && cs < 0; ++q) {
+            const int e = (c->coarse_next - q + 2 * zkhip_ctx::COARSE_RING) % zkhip_ctx::COARSE_RING;
+            if (fine == d_block_sums && c->coarse_of[e] == fine && c->coarse_n[e] == n && c->coarse_k1[e] == k1) cs = e;
+        }
+        if (cs < 0) {
+            ZK_TRY(c->next_coarse(&cs));
+            ProfScope ps(c, "coarse_sums", 0.0, S);
+            hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, S, fine, 1u << k2, (uint64_t*)nullptr, (uint64_t*)c->d_coarse[cs]);
+        }
+        const uint64_t* coarse = (const uint64_t*)c->d_coarse[cs];
+        c->coarse_of[cs] = nullptr;                 // the entry belongs to this proof from here on (the ring gives it three more poly_sum() calls of life)
         SmallArgs a = {};
-        a.src = (const uint64_t*)c->d_coarse; a.group = 0; a.canon = 1; a.log_n = k1; a.n_rounds = k1; a.round0 = 0; a.first = first; a.claimed = claimed;
+        a.src = coarse; a.group = 0; a.canon = 1; a.log_n = k1; a.n_rounds = k1; a.round0 = 0; a.first = first; a.claimed = claimed;
         a.d_claimed = d_claimed_sum; a.weights_out = d_w; a.final_out = nullptr;
-        ZK_TRY(launch_small(c, a, st, d_rp, d_ch));
+        ZK_TRY(launch_small(c, a, st, d_rp, d_ch, 0, S));
         first = 0;
         // fork: the big fold on the fold stream next to rounds k1+1 .. g.  The serial kernel of those rounds asks for
         // (nearly) a whole CU's LDS, so no fold workgroup shares its CU (beside 8+ fold waves per SIMD the transcript
@@ -714,20 +758,20 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
         // an event) then become ready together and the serial kernel's single workgroup is placed first.  Forked before
         // the small fold, the big fold filled every CU first and the serial kernel waited for one to drain (~60 us).
         uint32_t ny = 0;
-        ZK_TRY(launch_blockfold(c, c->stream, fine, 1u << k2, k1, d_w, d_p1, &ny));
-        ZK_HIP(c, hipEventRecord(c->fork_ev, c->stream));
-        ZK_HIP(c, hipStreamWaitEvent(c->fold_stream, c->fork_ev, 0));
-        ZK_TRY(launch_multifold(c, c->fold_stream, d_evals, n, k1, d_w, tabA, partA, &n_parts));
+        ZK_TRY(launch_blockfold(c, S, fine, 1u << k2, k1, d_w, d_p1, &ny));
+        ZK_HIP(c, hipEventRecord(fork_ev, S));
+        ZK_HIP(c, hipStreamWaitEvent(F, fork_ev, 0));
+        ZK_TRY(launch_multifold(c, F, d_evals, n, k1, d_w, tabA, partA, &n_parts));
         SmallArgs b = {};
         b.src = d_p1; b.group = ny; b.stride = 1u << k2; b.canon = 1; b.log_n = k2; b.n_rounds = k2; b.round0 = k1; b.first = 0;
         b.weights_out = d_w2; b.final_out = nullptr;
-        ZK_TRY(launch_small(c, b, st, d_rp, d_ch, 156 * 1024));
+        ZK_TRY(launch_small(c, b, st, d_rp, d_ch, 156 * 1024, S));
         // join ON THE FOLD STREAM: the serial kernel ends well before the big fold, so its event is long set when the fold
         // ends and the last stage follows the fold in stream order (joining on the caller's stream left the chip idle for the
         // ~13 us a cross-stream dependency takes to resolve); the proof is copied from there too
-        ZK_HIP(c, hipEventRecord(c->serial_ev, c->stream));
-        ZK_HIP(c, hipStreamWaitEvent(c->fold_stream, c->serial_ev, 0));
-        tail_stream = c->fold_stream;
+        ZK_HIP(c, hipEventRecord(serial_ev, S));
+        ZK_HIP(c, hipStreamWaitEvent(F, serial_ev, 0));
+        tail_stream = F;
         round = g;
         ZK_TRY(launch_blockfold(c, tail_stream, tabA, 256, k2, d_w2, d_p2, &ny));       // 2^(8 + k2) entries -> 2^8, the last 8 rounds
         SmallArgs t = {};
@@ -745,8 +789,8 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
             a.group = 1u << (log_blocks - k);
         } else if (stage == 0) {
             const uint32_t chunk = (uint32_t)std::min<size_t>(m, 4096);   // m >= 256 here
-            ProfScope ps(c, "chunk_sums", 32.0 * (double)cn);
-            hipLaunchKernelGGL(chunk_sums_kernel, dim3((unsigned)(cn / chunk)), dim3(MLE_BLOCK), 0, c->stream, cur, chunk, partA);
+            ProfScope ps(c, "chunk_sums", 32.0 * (double)cn, S);
+            hipLaunchKernelGGL(chunk_sums_kernel, dim3((unsigned)(cn / chunk)), dim3(MLE_BLOCK), 0, S, cur, chunk, partA);
             a.src = partA;
             a.group = (uint32_t)(m / chunk);
         } else {
@@ -755,11 +799,11 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
         }
         a.log_n = k; a.n_rounds = k; a.round0 = round; a.first = first; a.claimed = claimed; a.d_claimed = d_claimed_sum;
         a.weights_out = d_w; a.final_out = nullptr;
-        ZK_TRY(launch_small(c, a, st, d_rp, d_ch));
+        ZK_TRY(launch_small(c, a, st, d_rp, d_ch, 0, S));
         first = 0;
         uint64_t* dst = (stage & 1) ? tabB : tabA;
         uint64_t* pdst = (stage & 1) ? partB : partA;
-        ZK_TRY(launch_multifold(c, c->stream, cur, cn, k, d_w, dst, pdst, &n_parts));
+        ZK_TRY(launch_multifold(c, S, cur, cn, k, d_w, dst, pdst, &n_parts));
         parts = pdst;
         cur = dst;
         cn = m;
@@ -770,14 +814,14 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
         SmallArgs a = {};
         a.src = cur; a.group = 0; a.log_n = log2_exact(cn); a.n_rounds = a.log_n; a.round0 = round; a.first = first;
         a.claimed = claimed; a.d_claimed = d_claimed_sum; a.weights_out = nullptr; a.final_out = d_fin;
-        ZK_TRY(launch_small(c, a, st, d_rp, d_ch));
+        ZK_TRY(launch_small(c, a, st, d_rp, d_ch, 0, S));
     }
     // results -> host
     // one copy of the small-scratch span [state .. round polynomials]: the sum, the challenges and the round
     // polynomials are a few KiB apart in one allocation, and three small copies cost three launches
     ZK_TRY(c->ensure_proof_slot(slot));
     uint64_t* pin = (uint64_t*)c->proof_pin[slot];
-    const uint64_t* span = c->small_u64(ZK_SMALL_STATE);
+    const uint64_t* span = small + ZK_SMALL_STATE;
     const size_t span_words = (size_t)(ZK_SMALL_ROUNDPOLYS - ZK_SMALL_STATE) + 8 * (size_t)n_vars;
     {
         ProfScope ps(c, "proof_copy", 0.0, tail_stream);
@@ -785,7 +829,8 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
     }
     // the event the collector polls; the caller's stream stays ordered behind the proof (the next call reuses the scratch)
     ZK_HIP(c, hipEventRecord(c->proof_ev[slot], tail_stream));
-    if (tail_stream != c->stream) ZK_HIP(c, hipStreamWaitEvent(c->stream, c->proof_ev[slot], 0));
+    // (a proof on a lane of its own is joined to the caller's stream when it is collected, so that the caller's next poly_sum() does not wait for it)
+    if (lane < 0 && tail_stream != c->stream) ZK_HIP(c, hipStreamWaitEvent(c->stream, c->proof_ev[slot], 0));
     return ZKHIP_OK;
 }
 static int sumcheck_collect(zkhip_ctx* c, int slot, uint32_t n_vars, uint64_t* h_sum, uint64_t* h_round_polys, uint64_t* h_challenges) {
@@ -813,7 +858,7 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
     if (!h_sum) return ZKHIP_ERR_ARG;
     const uint32_t n_vars = log2_exact(n);
     if (n_vars && (!h_round_polys || !h_challenges)) return ZKHIP_ERR_ARG;
-    if (c->proof_pending[0] || c->proof_pending[1]) return ZKHIP_ERR_BUSY;     // proofs in flight own the result slots
+    for (int k = 0; k < zkhip_ctx::PROOF_SLOTS; ++k) if (c->proof_pending[k]) return ZKHIP_ERR_BUSY;     // proofs in flight own the result slots
     ZK_TRY(c->activate());
     if (n == 1) {   // no rounds: nothing is proven; report the sum the transcript would have absorbed
         if (h_claimed_sum) { std::memcpy(h_sum, h_claimed_sum, 32); return ZKHIP_OK; }
@@ -822,32 +867,34 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
         std::memcpy(h_sum, c->pinned_u64(ZK_PIN_RES), 32);
         return ZKHIP_OK;
     }
-    ZK_TRY(sumcheck_enqueue(c, d_evals, n, h_claimed_sum, d_claimed_sum, d_block_sums, log_blocks, 0));
+    ZK_TRY(sumcheck_enqueue(c, d_evals, n, h_claimed_sum, d_claimed_sum, d_block_sums, log_blocks, 0, -1));
     return sumcheck_collect(c, 0, n_vars, h_sum, h_round_polys, h_challenges);
 }
 // Sumcheck::prove in flight: begin enqueues the whole proof and returns a ticket, end waits for it and delivers the outputs of
-// zkhip_sumcheck_prove.  Up to two proofs of tables with >= 2 entries may be in flight; they execute in stream order.
+// zkhip_sumcheck_prove.  Up to four proofs of tables with >= 2 entries may be in flight, each on streams and buffers of its own
+// (zkhip_ctx::ProofLane): the streaming passes of one run while the transcript rounds of the others hash.
 extern "C" int zkhip_sumcheck_prove_begin(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_claimed_sum,
                                           const uint64_t* d_claimed_sum, const uint64_t* d_block_sums, uint32_t log_blocks,
                                           uint32_t* ticket) {
     ZK_TRY(sumcheck_check_args(c, d_evals, n));
     if (!ticket || n < 2) return ZKHIP_ERR_ARG;
     int slot = -1;
-    for (int k = 0; k < 2; ++k) if (!c->proof_pending[k]) { slot = k; break; }
+    for (int k = 0; k < zkhip_ctx::PROOF_SLOTS; ++k) if (!c->proof_pending[k]) { slot = k; break; }
     if (slot < 0) return ZKHIP_ERR_BUSY;
     ZK_TRY(c->activate());
-    ZK_TRY(sumcheck_enqueue(c, d_evals, n, h_claimed_sum, d_claimed_sum, d_block_sums, log_blocks, slot));
+    ZK_TRY(sumcheck_enqueue(c, d_evals, n, h_claimed_sum, d_claimed_sum, d_block_sums, log_blocks, slot, slot));
     c->proof_pending[slot] = log2_exact(n);
     *ticket = (uint32_t)slot;
     return ZKHIP_OK;
 }
 extern "C" int zkhip_sumcheck_prove_end(zkhip_ctx* c, uint32_t ticket, uint64_t* h_sum, uint64_t* h_round_polys, uint64_t* h_challenges) {
-    if (!c || ticket > 1 || !c->proof_pending[ticket]) return ZKHIP_ERR_ARG;
+    if (!c || ticket >= (uint32_t)zkhip_ctx::PROOF_SLOTS || !c->proof_pending[ticket]) return ZKHIP_ERR_ARG;
     const uint32_t n_vars = c->proof_pending[ticket];
     int rc = c->activate();
     if (rc == ZKHIP_OK) {
         if (h_sum && h_round_polys && h_challenges) rc = sumcheck_collect(c, (int)ticket, n_vars, h_sum, h_round_polys, h_challenges);
         else rc = c->wait_event(c->proof_ev[ticket]);                          // abandoned: just wait it out
+        if (hipStreamWaitEvent(c->stream, c->proof_ev[ticket], 0) != hipSuccess && rc == ZKHIP_OK) rc = ZKHIP_ERR_HIP;   // the caller's stream is ordered behind the proof again
     }
     c->proof_pending[ticket] = 0;
     return rc;

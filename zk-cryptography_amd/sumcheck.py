@@ -113,7 +113,9 @@ class Sumcheck:
 
     def prove_begin(self):
         """The same proof, in flight (zkhip_sumcheck_prove_begin): -> PendingProof; .wait() yields what prove() returns.  At most
-        two per context; a prover with several tables begins the next proof before it collects the previous one."""
+        four per context, each on streams and buffers of its own: a prover with several tables begins the next proofs before it
+        collects the previous ones, and their streaming passes overlap the others' transcript rounds.  The table and its block
+        sums (poly_sum() of the SAME Multilinear) must stay untouched until wait()."""
         if len(self.poly) < 2:
             raise AssertionError("prove_begin needs a table of at least two entries")
         ticket = C.c_uint32(0)
