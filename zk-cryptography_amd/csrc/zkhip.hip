@@ -629,7 +629,8 @@ static int block_sums_impl(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint
         // total from those.  Without (the deferred form): nothing more here -- the prover derives the coarse sums itself, on the
         // stream of the proof (a high-priority one when the proof is in flight), instead of queueing a tiny kernel on the caller's
         // stream behind whatever streaming pass occupies the chip.
-        if (want_total) {
+        static const bool coarse_here = [] { const char* e = getenv("ZKHIP_COARSE_IN_SUMS"); return e && atoi(e) != 0; }();   // diagnostics
+        if (want_total || coarse_here) {
             const uint32_t k1 = overlapped_plan(n) && log_blocks == log2_exact(n) - 8 ? log_blocks - overlapped_k2(n) : 8;
             int cs = 0;
             ZK_TRY(c->next_coarse(&cs));
@@ -638,7 +639,7 @@ static int block_sums_impl(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint
                 ProfScope ps(c, "coarse_sums", 0.0);
                 hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, c->stream, d_out, 1u << (log_blocks - k1), coarse_mont, coarse_canon);
             }
-            {
+            if (want_total) {
                 ProfScope ps(c, "total_sum", 0.0);
                 hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, coarse_mont, 1u << k1, d_out + 4 * ((size_t)1 << log_blocks), (uint64_t*)nullptr);
             }
