@@ -172,10 +172,17 @@ int zkhip_gkr_prove_circuit(zkhip_circuit *circuit, const uint64_t *const *h_lay
  *            (n = max(layer, 1) field elements each; h_rc NULL for the first layer proof), h_alpha / h_beta their weights.
  *   phase 1 (the rounds over c):  reads the s = layer + 1 challenges of phase 0 where the context recorded them;
  *            d_out[0] = Aa, d_out[1] = W(u) + W, d_out[2] = Am, d_out[3] = W(u) W; h_wu[4] = W(u) (= w_b of the proof).
- * Every rank of a sharded proof builds the same tables (they are as wide as the layer); the sumcheck rounds are what shards. */
+ * zkhip_gkr_layer_tables_sharded is what a rank of a sharded proof calls (gkr/src/protocol.rs:61-108 with the evaluation tables
+ * of BASELINE configs[3] "sharded across 8"): it builds ONLY the rows j * world + rank of every table -- w_len / world entries per
+ * output, the rank-interleaved shard the sumcheck sweeps -- and phase 0 additionally writes the shard of W itself to d_out[3]
+ * (world > 1).  What the rows gather from by wire index (gate weights, W, eq(u)) stays whole on every rank.  world = 1, rank = 0 is
+ * zkhip_gkr_layer_tables. */
 int zkhip_gkr_layer_tables(zkhip_circuit *circuit, uint32_t layer, const uint64_t *d_w, size_t w_len, const uint64_t *h_rb,
                            const uint64_t *h_rc, const uint64_t *h_alpha, const uint64_t *h_beta, int phase,
                            uint64_t *const *d_out, uint64_t *h_wu);
+int zkhip_gkr_layer_tables_sharded(zkhip_circuit *circuit, uint32_t layer, const uint64_t *d_w, size_t w_len, const uint64_t *h_rb,
+                                   const uint64_t *h_rc, const uint64_t *h_alpha, const uint64_t *h_beta, int phase,
+                                   uint32_t world, uint32_t rank, uint64_t *const *d_out, uint64_t *h_wu);
 
 
 /* ---- basic sumcheck prover (sumcheck/src/sumcheck.rs:25-61) -------------------------- */

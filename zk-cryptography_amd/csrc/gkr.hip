@@ -54,20 +54,26 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_weights_kernel(uint
 // rows of a CSR grouping of the gates by one of their inputs: row_off[x] .. row_off[x+1] index `ids` (gate numbers).
 // phase 1 (rows = in0):  add_out[x] = sum_{add} w_g (Ha0),  lin_out[x] = sum_{add} w_g V[in1] (Ha1),  mul_out[x] = sum_{mul} w_g V[in1] (Hm)
 // phase 2 (rows = in1):  add_out[x] = sum_{add} w_g eq_u[in0] (Aa),  mul_out[x] = sum_{mul} w_g eq_u[in0] (Am);  lin_out unused
+// A rank of a sharded proof builds only ITS rows: lane j takes row x = j * row_stride + row_first and writes entry j of the outputs
+// (row_stride = world, row_first = rank: the rank-interleaved shard the sumcheck sweeps); v_shard (phase 1, optional) receives V[x].
+// What the rows GATHER from -- the gate weights, V, eq(u) -- is indexed by arbitrary wires and stays whole on every rank.
 static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_rows_kernel(const uint32_t* __restrict__ row_off, const uint32_t* __restrict__ ids,
                                                                   const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ other_in,
                                                                   const uint64_t* __restrict__ wg, const uint64_t* __restrict__ factor,
                                                                   uint32_t n_rows, uint32_t phase, uint64_t* __restrict__ add_out,
                                                                   uint64_t* __restrict__ lin_out, uint64_t* __restrict__ mul_out,
                                                                   const uint64_t* __restrict__ v, const uint64_t* __restrict__ vu_ptr,
-                                                                  uint64_t* __restrict__ t1, uint64_t* __restrict__ t2) {
-    const uint32_t x = blockIdx.x * MLE_BLOCK + threadIdx.x;
-    if (x >= n_rows) return;
+                                                                  uint64_t* __restrict__ t1, uint64_t* __restrict__ t2,
+                                                                  uint32_t row_stride = 1, uint32_t row_first = 0, uint64_t* __restrict__ v_shard = nullptr) {
+    const uint32_t j = blockIdx.x * MLE_BLOCK + threadIdx.x;
+    if (j >= n_rows) return;
+    const uint32_t x = j * row_stride + row_first;
     if (t1) {   // phase 2 also lays out the other factor of each term (one launch less per layer): t1[c] = V(u) + V[c], t2[c] = V(u) V[c]
         const Fr vu = load_fr(vu_ptr, 0), vx = load_fr(v, x);
-        store_fr(t1, x, vu + vx);
-        store_fr(t2, x, vu * vx);
+        store_fr(t1, j, vu + vx);
+        store_fr(t2, j, vu * vx);
     }
+    if (v_shard) store_fr(v_shard, j, load_fr(factor, x));            // phase 1: factor = V
     Fr a = Fr::zero(), l = Fr::zero(), m = Fr::zero();
     for (uint32_t q = row_off[x]; q < row_off[x + 1]; ++q) {
         const uint32_t g = ids[q];
@@ -77,9 +83,9 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_rows_kernel(const u
         else if (phase == 1) { a = a + w; l = l + wf; }
         else a = a + wf;
     }
-    store_fr(add_out, x, a);
-    if (phase == 1) store_fr(lin_out, x, l);
-    store_fr(mul_out, x, m);
+    store_fr(add_out, j, a);
+    if (phase == 1) store_fr(lin_out, j, l);
+    store_fr(mul_out, j, m);
 }
 // eq_x(u) over n_vars index bits, MSB first (the b side of the wiring at the phase-1 challenges).  The points are read from
 // DEVICE memory -- where the sumcheck that produced them left them -- so the host never waits for them.
@@ -497,15 +503,19 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
     return ZKHIP_OK;
 }
 
-extern "C" int zkhip_gkr_layer_tables(zkhip_circuit* cir, uint32_t layer, const uint64_t* d_w, size_t w_len, const uint64_t* h_rb,
-                                      const uint64_t* h_rc, const uint64_t* h_alpha, const uint64_t* h_beta, int phase,
-                                      uint64_t* const* d_out, uint64_t* h_wu) {
+// The layer's linear-size sumcheck tables for a rank of a sharded proof (world = 1, rank = 0: the whole tables).  phase 0: d_out =
+// {Ha0, Ha1, Hm, V} rows j * world + rank; phase 1 (after the rounds over b: the challenges lie in the context): d_out = {Aa, V(u) + V,
+// Am, V(u) V} rows likewise, h_wu = V(u).  Every output holds w_len / world entries.
+extern "C" int zkhip_gkr_layer_tables_sharded(zkhip_circuit* cir, uint32_t layer, const uint64_t* d_w, size_t w_len, const uint64_t* h_rb,
+                                              const uint64_t* h_rc, const uint64_t* h_alpha, const uint64_t* h_beta, int phase,
+                                              uint32_t world, uint32_t rank, uint64_t* const* d_out, uint64_t* h_wu) {
     using namespace zk;
     if (!cir || !d_w || !h_rb || !h_alpha || !h_beta || !d_out || phase < 0 || phase > 1 || layer >= cir->n_layers) return ZKHIP_ERR_ARG;
     if (phase == 1 && !h_wu) return ZKHIP_ERR_ARG;
+    if (world == 0 || (world & (world - 1)) || rank >= world) return ZKHIP_ERR_ARG;
     zkhip_ctx* c = cir->c;
     const LayerDev& ld = cir->layers[layer];
-    if (!is_pow2(w_len) || w_len != ld.w_len) return ZKHIP_ERR_SHAPE;
+    if (!is_pow2(w_len) || w_len != ld.w_len || w_len < world) return ZKHIP_ERR_SHAPE;
     if (ld.bad_label) return ZKHIP_ERR_INDEX;
     ZK_TRY(c->activate());
     const uint32_t s = log2_exact(w_len);
@@ -528,23 +538,30 @@ extern "C" int zkhip_gkr_layer_tables(zkhip_circuit* cir, uint32_t layer, const 
     FrArg av = {}, bv = {};
     std::memcpy(av.v, h_alpha, 32);
     std::memcpy(bv.v, h_beta, 32);
-    const unsigned gw = (unsigned)((w_len + MLE_BLOCK - 1) / MLE_BLOCK);
+    const uint32_t rows = (uint32_t)(w_len / world);
+    const unsigned gw = (unsigned)((rows + MLE_BLOCK - 1) / MLE_BLOCK);
     launch_gate_weights(c, ld.n_gates, n_gate_vars, pb, pc, av, bv, two_points, eqh, wg);
     if (phase == 0) {
         hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr0, ld.csr0 + w_len + 1, ld.type, ld.in1, wg, d_w,
-                           (uint32_t)w_len, 1u, d_out[0], d_out[1], d_out[2], (const uint64_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr);
+                           rows, 1u, d_out[0], d_out[1], d_out[2], (const uint64_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr,
+                           world, rank, world > 1 ? d_out[3] : (uint64_t*)nullptr);
         ZK_HIP(c, hipGetLastError());
         return ZKHIP_OK;
     }
     const uint64_t* d_ch = zk_composed_challenges_dev(c);       // the s challenges of the rounds over b
     launch_eq_table(c, d_ch, s, eqh, equ, d_w, dot_partials, evals);
     hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr1, ld.csr1 + w_len + 1, ld.type, ld.in0, wg, equ,
-                       (uint32_t)w_len, 2u, d_out[0], (uint64_t*)nullptr, d_out[2], d_w, (const uint64_t*)evals, d_out[1], d_out[3]);
+                       rows, 2u, d_out[0], (uint64_t*)nullptr, d_out[2], d_w, (const uint64_t*)evals, d_out[1], d_out[3], world, rank, (uint64_t*)nullptr);
     ZK_HIP(c, hipGetLastError());
     ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), evals, 32, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     std::memcpy(h_wu, c->pinned_u64(ZK_PIN_RES), 32);
     return ZKHIP_OK;
+}
+extern "C" int zkhip_gkr_layer_tables(zkhip_circuit* cir, uint32_t layer, const uint64_t* d_w, size_t w_len, const uint64_t* h_rb,
+                                      const uint64_t* h_rc, const uint64_t* h_alpha, const uint64_t* h_beta, int phase,
+                                      uint64_t* const* d_out, uint64_t* h_wu) {
+    return zkhip_gkr_layer_tables_sharded(cir, layer, d_w, w_len, h_rb, h_rc, h_alpha, h_beta, phase, 1, 0, d_out, h_wu);
 }
 
 // one-shot form: the circuit is grouped and uploaded for this proof only

@@ -222,13 +222,14 @@ class GKRProtocol:
 
     @staticmethod
     def prove_sharded(circuit, circuit_evaluation, world=1, rank=0, group=None, dist=None):
-        """GKRProtocol::prove (protocol.rs:21-117) with every layer's sumcheck SHARDED over `world` ranks (SURVEY 8e, "GKR
-        tables"; BASELINE configs[3]).  Every rank holds the evaluation tables and builds the layer's linear-size sumcheck tables
-        (zkhip_gkr_layer_tables: they are as wide as the layer); the rounds over b and over c then run on shards -- rank g folds
-        entries j * world + g -- with one record of partial sums all-gathered per round
-        (distributed.ShardedComposedSumcheck over zkhip_mc_*; the transcript is replicated).  Layers narrower than 2 * world
-        values run unsharded on every rank.  Returns the proof GKRProtocol.prove returns, bit for bit, on every rank; the
-        number of collectives is left in proof._exchanges."""
+        """GKRProtocol::prove (protocol.rs:21-117) with every layer's tables and sumcheck SHARDED over `world` ranks (SURVEY 8e,
+        "GKR tables"; BASELINE configs[3]: "evals sharded across 8").  Rank g builds ONLY rows j * world + g of the layer's seven
+        linear-size sumcheck tables and of the layer's values (zkhip_gkr_layer_tables_sharded: w_len / world entries each, 1 / world
+        of the table-building work and memory), and the rounds over b and over c run on those shards with one record of partial sums
+        all-gathered per round (distributed.ShardedComposedSumcheck over zkhip_mc_*; the transcript is replicated).  What the rows
+        gather from by wire index -- the layer's values, the gate weights, eq(u) -- stays whole on every rank (random wiring reads
+        any of them).  Layers narrower than 2 * world values run unsharded on every rank.  Returns the proof GKRProtocol.prove
+        returns, bit for bit, on every rank; the number of collectives is left in proof._exchanges."""
         import torch
         from zk_cryptography_amd import distributed as D
         from zk_cryptography_amd.composed import MultiComposedSumcheckProof, SparseUnivariatePolynomial
@@ -252,32 +253,31 @@ class GKRProtocol:
         r_b, r_c = np.ascontiguousarray(n_r), None
         p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
 
-        def shard(t, w):
-            return t if w == 1 else t.view(-1, w, 4)[:, rank].contiguous()
-
         for li in range(1, nl + 1):
             layer, V = li - 1, tables[li]
             w_len = V.shape[0]
             s_vars = w_len.bit_length() - 1
             w = world if w_len >= 2 * world else 1                    # narrow layers: every rank proves them whole
+            rk = rank if w > 1 else 0
             grp, dst = (group, dist) if w > 1 else (None, None)
-            out = [torch.empty((w_len, 4), dtype=torch.int64, device=V.device) for _ in range(4)]
+            out = [torch.empty((w_len // w, 4), dtype=torch.int64, device=V.device) for _ in range(4)]    # this rank's rows only
             ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in out])
             wu = np.zeros(4, dtype=np.uint64)
             rc_p = p(np.ascontiguousarray(r_c)) if r_c is not None else None
             rb_a, al_a, be_a = np.ascontiguousarray(r_b), np.ascontiguousarray(alpha), np.ascontiguousarray(beta)
-            N.check(N.lib().zkhip_gkr_layer_tables(dev.handle, C.c_uint32(layer), N.ptr(V), C.c_size_t(w_len), p(rb_a), rc_p, p(al_a), p(be_a),
-                                                   C.c_int(0), ptrs, None), "gkr_layer_tables")
+            N.check(N.lib().zkhip_gkr_layer_tables_sharded(dev.handle, C.c_uint32(layer), N.ptr(V), C.c_size_t(w_len), p(rb_a), rc_p, p(al_a), p(be_a),
+                                                           C.c_int(0), C.c_uint32(w), C.c_uint32(rk), ptrs, None), "gkr_layer_tables")
             ha0, ha1, hm = out[0], out[1], out[2]
-            eng = D.HipComposedEngine([[shard(ha0, w), shard(V, w)], [shard(hm, w), shard(V, w)]], w, multi=True, claimed_sum=claimed, ctx=ctx,
-                                      lin=[shard(ha1, w), None])
+            v_sh = out[3] if w > 1 else V                             # rows j * w + rank of the layer's values
+            eng = D.HipComposedEngine([[ha0, v_sh], [hm, v_sh]], w, multi=True, claimed_sum=claimed, ctx=ctx, lin=[ha1, None])
             sh = D.ShardedComposedSumcheck(eng, w, grp, dst)
             sh.prove(collect=False)                                   # the rounds over b; recorded on the device
             proof._exchanges += sh.exchanges
-            N.check(N.lib().zkhip_gkr_layer_tables(dev.handle, C.c_uint32(layer), N.ptr(V), C.c_size_t(w_len), p(rb_a), rc_p, p(al_a), p(be_a),
-                                                   C.c_int(1), ptrs, p(wu)), "gkr_layer_tables")
-            eng = D.HipComposedEngine([[shard(out[0], w), shard(out[1], w)], [shard(out[2], w), shard(out[3], w)]], w, multi=True, ctx=ctx,
-                                      cont=True, out_base=s_vars)
+            out2 = [torch.empty((w_len // w, 4), dtype=torch.int64, device=V.device) for _ in range(4)]
+            ptrs2 = (C.c_void_p * 4)(*[t.data_ptr() for t in out2])
+            N.check(N.lib().zkhip_gkr_layer_tables_sharded(dev.handle, C.c_uint32(layer), N.ptr(V), C.c_size_t(w_len), p(rb_a), rc_p, p(al_a), p(be_a),
+                                                           C.c_int(1), C.c_uint32(w), C.c_uint32(rk), ptrs2, p(wu)), "gkr_layer_tables")
+            eng = D.HipComposedEngine([[out2[0], out2[1]], [out2[2], out2[3]]], w, multi=True, ctx=ctx, cont=True, out_base=s_vars)
             sh = D.ShardedComposedSumcheck(eng, w, grp, dst)
             rps, ch = sh.prove(finish_rounds=2 * s_vars)              # the rounds over c; delivers all 2 s rounds
             proof._exchanges += sh.exchanges
