@@ -214,15 +214,9 @@ def bench_fold(args, zk, N, poly, torch):
     n = len(poly)
     r = zk.Fr.synthetic(1, SEED_TABLE + 0x777)[0]
     ctx = N.Context.get()
-    for _ in range(2):
-        poly.partial_evaluation(r, 0)
-    torch.cuda.synchronize()
     reps = max(3, min(args.steps, 10))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        poly.partial_evaluation(r, 0)
-    torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / reps
+    ts = _timed(lambda: poly.partial_evaluation(r, 0), torch, reps=reps)
+    wall = sorted(ts)[len(ts) // 2]
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 1), "profile_enable")
     for _ in range(reps):
         poly.partial_evaluation(r, 0)
@@ -230,7 +224,7 @@ def bench_fold(args, zk, N, poly, torch):
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
     ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     return {"workload": "partial_evaluation of the 2^%d table at variable 0 (one product per output)" % args.log_n,
-            "value": round(n / wall, 1), "unit": "field-evals/s", "ms_per_fold": round(1e3 * wall, 4),
+            "value": round(n / wall, 1), "unit": "field-evals/s", "ms_per_fold": round(1e3 * wall, 4), "batches": _stats(ts, 1e3),
             "roofline": {"bound": "hbm", "kernel": "fold_kernel<false>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "launches": cnt, "avg_launch_us": round(1e3 * ms / max(1, cnt), 2),
                          "algorithmic_bytes_per_launch": "48 B x table entries (32 n read + 16 n written)"}}
@@ -247,13 +241,9 @@ def bench_ntt(args, zk, N, torch):
     out = {"workload": "Domain::fft / ifft at 2^%d points; UnivariateEval::multiply 2^%d x 2^%d coefficients" % (log_n, log_n - 1, log_n - 1)}
     reps = max(3, min(args.steps, 10))
     for name, fn in (("fft", lambda: d.fft(x)), ("ifft", lambda: d.ifft(x))):
-        fn(); fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        out["ms_per_" + name] = round(1e3 * (time.perf_counter() - t0) / reps, 4)
+        ts = _timed(fn, torch, reps=reps)
+        out["ms_per_" + name] = round(1e3 * sorted(ts)[len(ts) // 2], 4)
+        out["batches_" + name] = _stats(ts, 1e3)
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 1), "profile_enable")
     for _ in range(reps):
         d.fft(x)
@@ -275,13 +265,9 @@ def bench_ntt(args, zk, N, torch):
                            "ops_per_launch": "n/2 log2 n butterflies x 380 VALU instructions (one Montgomery product + add + sub; counted in the ISA)"}
     a = zk.DenseUnivariatePolynomial(_synthetic(zk, torch, n // 2, SEED_TABLE + 0x101))
     b = zk.DenseUnivariatePolynomial(_synthetic(zk, torch, n // 2, SEED_TABLE + 0x102))
-    zk.UnivariateEval.multiply(a, b)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        zk.UnivariateEval.multiply(a, b)
-    torch.cuda.synchronize()
-    out["ms_per_multiply"] = round(1e3 * (time.perf_counter() - t0) / reps, 4)
+    ts = _timed(lambda: zk.UnivariateEval.multiply(a, b), torch, reps=reps)
+    out["ms_per_multiply"] = round(1e3 * sorted(ts)[len(ts) // 2], 4)
+    out["batches_multiply"] = _stats(ts, 1e3)
     return out
 
 
@@ -312,17 +298,10 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
 
     for _ in range(2):
         com = commit()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        com = commit()
-    barrier()
-    dt = time.perf_counter() - t0
+    commit_batches, com = _batches(commit, steps, barrier, dist, world, torch)
+    dt = sorted(commit_batches)[len(commit_batches) // 2]
     same = True
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
         same = _same_on_all_ranks(dist, torch, np, np.concatenate([np.asarray(com[0], dtype=np.uint64), np.array([1 if com[1] else 0], dtype=np.uint64)]))
         assert same, "rank %d: the sharded commitment differs from rank 0's" % rank
     # the same commitments three in flight (zkhip_kzg_commit_begin / _end): the latency-bound reductions and the host epilogue
@@ -332,16 +311,21 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
         depth = 3                            # zkhip_kzg_commit_begin takes three (measured 2 / 3 / 4 in flight: 3.03 / 2.91 / 2.98 ms per commit)
         zk.MultilinearKZG.commitment_begin(poly, srs).wait()
         torch.cuda.synchronize()
-        tp = time.perf_counter()             # the pipeline fills and drains inside the timed region: `steps` whole commits
-        pend, got = [], []
-        for _ in range(steps):
-            pend.append(zk.MultilinearKZG.commitment_begin(poly, srs))
-            if len(pend) == depth:
-                got.append(pend.pop(0).wait())
-        got += [h.wait() for h in pend]
-        dt_pipe = time.perf_counter() - tp
-        assert len(got) == steps and all(g == com for g in got), "commitments in flight differ from the synchronous ones"
+        runs, total = [], 0.0
+        while total < MIN_LEG_SECONDS and len(runs) < 20:
+            tp = time.perf_counter()             # the pipeline fills and drains inside the timed region: `steps` whole commits
+            pend, got = [], []
+            for _ in range(steps):
+                pend.append(zk.MultilinearKZG.commitment_begin(poly, srs))
+                if len(pend) == depth:
+                    got.append(pend.pop(0).wait())
+            got += [h.wait() for h in pend]
+            runs.append(time.perf_counter() - tp)
+            total += runs[-1]
+            assert len(got) == steps and all(g == com for g in got), "commitments in flight differ from the synchronous ones"
+        dt_pipe = sorted(runs)[len(runs) // 2]
         pipelined = {"value": round(float(n) * steps / dt_pipe, 1), "unit": "points/s", "ms_per_commit": round(1e3 * dt_pipe / steps, 3),
+                     "batches": _stats([r_ / steps for r_ in runs], 1e3, 3),
                      "in_flight": depth, "note": "zkhip_kzg_commit_begin / _end: same commitments, issued back to back"}
     # informational (SURVEY 8f rows built on the commit): SRS generation on the device and MultilinearKZG::open over the same SRS
     extras = None
@@ -353,21 +337,15 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
         z = zk.Fr.synthetic(log_n, SEED_SCALARS + 0x200)
         zk.MultilinearKZG.open(poly, z, plain_srs)                 # first call derives and caches the folded SRS levels
         torch.cuda.synchronize()
-        t_o = time.perf_counter()
-        for _ in range(3):
-            proof = zk.MultilinearKZG.open(poly, z, plain_srs)
-        torch.cuda.synchronize()
-        t_o = (time.perf_counter() - t_o) / 3
-        extras = {"srs_setup_ms": round(1e3 * t_s, 2), "open": {"ms_per_open": round(1e3 * t_o, 3), "proofs": len(proof.proofs),
+        proof = zk.MultilinearKZG.open(poly, z, plain_srs)
+        t_open = _timed(lambda: zk.MultilinearKZG.open(poly, z, plain_srs), torch, reps=3)
+        t_o = sorted(t_open)[len(t_open) // 2]
+        extras = {"srs_setup_ms": round(1e3 * t_s, 2), "open": {"ms_per_open": round(1e3 * t_o, 3), "batches": _stats(t_open, 1e3, 3), "proofs": len(proof.proofs),
                   "note": "MultilinearKZG::open (multilinear_kzg.rs:50-88): %d quotient commitments, folded SRS levels cached" % len(proof.proofs)}}
     # the same commitments without the table (16 instead of 13 bucket additions per point, 16 bucket reductions)
-    zk.MultilinearKZG.commitment(poly, plain_srs)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(steps):
-        com_plain = zk.MultilinearKZG.commitment(poly, plain_srs)
-    torch.cuda.synchronize()
-    dt_plain = time.perf_counter() - t1
+    com_plain = zk.MultilinearKZG.commitment(poly, plain_srs)
+    t_plain = _timed(lambda: zk.MultilinearKZG.commitment(poly, plain_srs), torch, reps=steps)
+    dt_plain = steps * sorted(t_plain)[len(t_plain) // 2]
     assert world > 1 or com_plain == com, "table and plain commitments differ"
     ctx = N.Context.get()
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 1), "profile_enable")
@@ -376,7 +354,7 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
     out = {"metric": "MSM points/s (KZG commit, 2^%d-point SRS per GPU)" % log_n,
            "value": round(float(n) * world * steps / dt, 1), "unit": "points/s", "ms_per_commit": round(1e3 * dt / steps, 3),
-           "steps": steps,
+           "steps": steps, "batches": _stats([b_ / steps for b_ in commit_batches], 1e3, 3),
            "sharding": ("(scalars, SRS) of one %d-point commit split over %d GPUs; one all-gather of %d partial commitments (104 B each, "
                         "device to device over RCCL) per commit, summed on every rank" % (n * world, world, world)) if world > 1 else "single GPU",
            "points_per_gpu": n, "exchanges_per_commit": 1 if world > 1 else 0, "commitment_replicated_on_all_ranks": same,
@@ -461,21 +439,14 @@ def bench_composed(args, zk, N, rank, world, barrier, dist, torch, np):
     steps = max(2, min(args.steps, 10))
     for _ in range(2):
         rp, ch = prove()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        rp, ch = prove()
-    barrier()
-    dt = time.perf_counter() - t0
+    bs, (rp, ch) = _batches(prove, steps, barrier, dist, world, torch)
+    dt = sorted(bs)[len(bs) // 2]
     same = True
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
         same = _same_on_all_ranks(dist, torch, np, np.concatenate([np.asarray(rp, dtype=np.uint64).reshape(-1), np.asarray(ch, dtype=np.uint64).reshape(-1)]))
     return {"workload": "ComposedSumcheck::prove, product of %d tables, 2^%d entries per table per GPU" % (K, args.composed_log_n),
             "value": round(K * n * world * steps / dt, 1), "unit": "field-evals/s (table entries consumed)",
-            "ms_per_prove": round(1e3 * dt / steps, 4), "rounds": int(len(ch)), "steps": steps,
+            "ms_per_prove": round(1e3 * dt / steps, 4), "batches": _stats([b_ / steps for b_ in bs], 1e3), "rounds": int(len(ch)), "steps": steps,
             "entries_per_table_per_gpu": n, "exchanges_per_prove": exch[0] if world > 1 else 0,
             "transcript_replicated_on_all_ranks": same,
             "sharding": "tables sharded by low index bits, one 96-byte record per rank all-gathered per round" if world > 1 else "single GPU"}
@@ -490,18 +461,11 @@ def bench_gkr(args, zk, rank, world, barrier, dist, torch, np):
         circuit = zk.Circuit.random(depth)
         ev = circuit.evaluation(zk.Fr.synthetic(2 ** depth, SEED_GKR + rank))
         zk.GKRProtocol.prove(circuit, ev)
-        barrier()
         reps = 5 if depth <= 8 else 3
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            zk.GKRProtocol.prove(circuit, ev)
-        barrier()
-        dt = (time.perf_counter() - t0) / reps
-        if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+        bs, _ = _batches(lambda: zk.GKRProtocol.prove(circuit, ev), reps, barrier, dist, world, torch)
+        dt = sorted(bs)[len(bs) // 2] / reps
         out["ms_per_proof"]["depth_%d" % depth] = round(1e3 * dt, 3)
+        out.setdefault("batches", {})["depth_%d" % depth] = _stats([b_ / reps for b_ in bs], 1e3, 3)
     # BASELINE configs[3]: ONE depth-20 proof with every layer's sumcheck sharded over the ranks (GKRProtocol.prove_sharded:
     # the layer tables are built on every rank, the rounds over b and c run on shards with one record all-gathered per round)
     # next to the replicated figure above -- whichever is faster is the answer to "should GKR shard at this width"
@@ -532,6 +496,156 @@ def bench_gkr(args, zk, rank, world, barrier, dist, torch, np):
     return out
 
 
+def bench_h2d(args, zk, N, table, poly, torch, np):
+    """PCIe-inclusive figures: the reference's Multilinear owns a host Vec<F> (evaluation_form.rs:6-9), so a literal drop-in that keeps
+    nothing resident uploads the table (512 MiB at 2^24) before every proof and the scalars (32 MiB at 2^20) before every commit.  Never
+    `value`: tables and SRS stay resident in the product."""
+    out = {}
+    n = len(poly)
+    host = torch.empty_like(table, device="cpu").pin_memory()
+    host.copy_(table)
+    dev = torch.empty_like(table)
+    p2 = zk.Multilinear(dev)
+
+    def step():
+        dev.copy_(host, non_blocking=True)
+        sc = zk.Sumcheck(p2)
+        sc.poly_sum()
+        return sc.prove()
+
+    ts = _timed(step, torch, reps=3, min_total=0.2, max_batches=8)
+    med = sorted(ts)[len(ts) // 2]
+    out["sumcheck"] = {"ms_per_step": round(1e3 * med, 3), "value": round(n / med, 1), "unit": "field-evals/s",
+                       "upload_bytes": int(n * 32), "upload_GBps": None, "batches": _stats(ts, 1e3, 3),
+                       "note": "pinned host table -> HBM (hipMemcpyAsync) + poly_sum + prove per step"}
+    t_up = _timed(lambda: dev.copy_(host, non_blocking=True), torch, reps=3, min_total=0.1, max_batches=6)
+    out["sumcheck"]["upload_GBps"] = round(n * 32 / sorted(t_up)[len(t_up) // 2] / 1e9, 1)
+    del host, dev, p2
+    return out
+
+
+def bench_strong_and_config4(args, zk, N, rank, world, barrier, dist, torch, np):
+    """N > 1 only.  (a) STRONG scaling of the headline: ONE 2^log_n-entry table over all ranks (2^log_n / N entries per GPU), where the
+    default line is weak scaling (2^log_n per GPU).  (b) BASELINE configs[4]'s shape: a multilinear KZG commit of 2^26 evaluations
+    sharded 8-way = 2^23 points per GPU (here: 2^23 per GPU at any N), one all-gather of the partial commitments."""
+    from zk_cryptography_amd import distributed as D
+    out = {}
+    n_total = 1 << args.log_n
+    if n_total // world >= 1 << 12:
+        shard = _synthetic(zk, torch, n_total // world, SEED_TABLE + 0x400 + rank)
+        ex = [0]
+
+        def step():
+            sh = D.ShardedSumcheck(D.HipSumcheckEngine(shard), world, None, dist)
+            r = sh.prove()
+            ex[0] = sh.exchanges
+            return r
+
+        for _ in range(3):
+            step()
+        bs, res = _batches(step, args.steps, barrier, dist, world, torch)
+        med = sorted(bs)[len(bs) // 2]
+        out["sumcheck_strong"] = {"workload": "ONE 2^%d-entry table over %d GPUs (2^%d entries per GPU)" % (args.log_n, world, (n_total // world).bit_length() - 1),
+                                  "value": round(n_total * args.steps / med, 1), "unit": "field-evals/s", "ms_per_step": round(1e3 * med / args.steps, 4),
+                                  "batches": _stats([b / args.steps for b in bs], 1e3), "exchanges_per_prove": ex[0], "scaling": "strong"}
+        del shard
+    log_c = args.config4_log_n
+    tau = zk.Fr.synthetic(log_c, SEED_SCALARS + 0x300 + rank)
+    srs = zk.TrustedSetup.setup(tau)
+    srs.precompute()
+    poly = zk.Multilinear(_synthetic(zk, torch, 1 << log_c, SEED_SCALARS + 0x310 + rank))
+
+    def commit():
+        def local():
+            c = zk.MultilinearKZG.commitment(poly, srs)
+            return c.xy, c.infinity
+        return D.sharded_commit(local, D.hip_sum_affine, world, None, dist, device="cuda")
+
+    commit()
+    bs, com = _batches(commit, 3, barrier, dist, world, torch, min_total=0.2, max_batches=6)
+    med = sorted(bs)[len(bs) // 2]
+    same = _same_on_all_ranks(dist, torch, np, np.concatenate([np.asarray(com[0], dtype=np.uint64), np.array([1 if com[1] else 0], dtype=np.uint64)]))
+    out["commit_config4_shape"] = {"workload": "multilinear KZG commit of 2^%d evaluations, (scalars, SRS) sharded over %d GPUs: 2^%d points per GPU" % (log_c + world.bit_length() - 1, world, log_c),
+                                   "value": round(float(1 << log_c) * world * 3 / med, 1), "unit": "points/s", "ms_per_commit": round(1e3 * med / 3, 3),
+                                   "batches": _stats([b / 3 for b in bs], 1e3, 3), "exchanges_per_commit": 1, "commitment_replicated_on_all_ranks": same}
+    return out
+
+
+def bench_prediction(args, zk, N, torch, np, dist_mod, exchange):
+    """N = 1 only: what the sharded paths cost WITHOUT their exchanges -- the protocols run with world = 1 on inputs of the size one rank
+    of an 8-GPU job holds -- so that t(N) = t_local + exchanges x exchange_us is a prediction the first real multi-GPU run can be checked
+    against.  exchange_us for 8 ranks cannot be measured here: the measured one-rank cost of the call path plus an
+    ASSUMED 15 us for an 8-rank RCCL all-gather of <= 64 KiB over xGMI."""
+    from zk_cryptography_amd import distributed as D
+    x1 = exchange["64_B"]["back_to_back_us"] if exchange and "64_B" in exchange else None
+    x64k = exchange["65536_B"]["back_to_back_us"] if exchange and "65536_B" in exchange else None
+    xh = exchange["64_B"]["with_host_wait_us"] if exchange and "64_B" in exchange else None
+    assumed_fabric_us = 15.0
+    out = {"model": "t(N) = t_local(shard) + exchanges(N) x exchange_us; t_local measured here with world = 1 on one rank's share, exchange_us = "
+                    "measured one-rank call path + %.0f us ASSUMED for an 8-rank RCCL all-gather of <= 64 KiB over xGMI" % assumed_fabric_us,
+           "exchange_us_world_1": {"64_B": x1, "65536_B": x64k, "64_B_with_host_wait": xh}, "assumed_fabric_us_8_ranks": assumed_fabric_us, "n_gpus": 8}
+    if x1 is None:
+        return out
+    x8, x8k, x8h = x1 + assumed_fabric_us, x64k + assumed_fabric_us, xh + assumed_fabric_us
+
+    def local_sumcheck(log_shard):
+        t = _synthetic(zk, torch, 1 << log_shard, SEED_TABLE + 0x500)
+        ex = [0]
+
+        def step():
+            sh = D.ShardedSumcheck(D.HipSumcheckEngine(t), 1, None, None)
+            sh.prove()
+            ex[0] = sh.exchanges
+        ts = _timed(step, torch, reps=5, min_total=0.15, max_batches=20)
+        return sorted(ts)[len(ts) // 2], ex[0]
+
+    t24, e24 = local_sumcheck(args.log_n)
+    t21, e21 = local_sumcheck(args.log_n - 3)
+    out["sumcheck_weak_2^%d_per_gpu" % args.log_n] = {"t_local_ms": round(1e3 * t24, 4), "exchanges": 3,
+                                                      "predicted_ms_per_step": round(1e3 * t24 + 2e-3 * x8 + 1e-3 * x8k, 4),
+                                                      "predicted_field_evals_per_s": round(8.0 * (1 << args.log_n) / (t24 + 2e-6 * x8 + 1e-6 * x8k), 1)}
+    out["sumcheck_strong_2^%d_total" % args.log_n] = {"t_local_ms": round(1e3 * t21, 4), "exchanges": 3,
+                                                     "predicted_ms_per_step": round(1e3 * t21 + 2e-3 * x8 + 1e-3 * x8k, 4),
+                                                     "predicted_field_evals_per_s": round(float(1 << args.log_n) / (t21 + 2e-6 * x8 + 1e-6 * x8k), 1)}
+    # composed prover: K = 2, 2^composed_log_n per table per GPU; at 8 ranks three more exchanged rounds than the one-rank run
+    K, nloc = 2, 1 << args.composed_log_n
+    tabs = [_synthetic(zk, torch, nloc, SEED_TABLE + 0x510 + k) for k in range(K)]
+    ex = [0]
+
+    def cstep():
+        sh = D.ShardedComposedSumcheck(D.HipComposedEngine([tabs], 1, multi=False), 1, None, None)
+        sh.prove()
+        ex[0] = sh.exchanges
+    ts = _timed(cstep, torch, reps=3, min_total=0.15, max_batches=20)
+    tc = sorted(ts)[len(ts) // 2]
+    e8 = ex[0] + 3
+    out["composed_2x2^%d_per_gpu" % args.composed_log_n] = {"t_local_ms": round(1e3 * tc, 4), "exchanges": e8, "predicted_ms_per_prove": round(1e3 * tc + 1e-3 * e8 * x8, 4)}
+    del tabs
+    # GKR, Circuit::random(20): one proof sharded over 8 ranks against one proof per rank (replicas)
+    circuit = zk.Circuit.random(20)
+    ev = circuit.evaluation(zk.Fr.synthetic(1 << 20, SEED_GKR))
+    tr = _timed(lambda: zk.GKRProtocol.prove(circuit, ev), torch, reps=2, min_total=0.15, max_batches=8)
+    exg = [0]
+
+    def gstep():
+        exg[0] = zk.GKRProtocol.prove_sharded(circuit, ev, 1, 0, None, None)._exchanges
+    tg = _timed(gstep, torch, reps=1, min_total=0.15, max_batches=8)
+    t_rep, t_sh = sorted(tr)[len(tr) // 2], sorted(tg)[len(tg) // 2]
+    # exchanges: a session exchanges one record per round while (local entries x world) exceeds the tail and then gathers once -- a count
+    # that depends on the LAYER's width, not on the rank count; the one-rank run counts them (layers narrower than 16 values, which 8
+    # ranks prove unsharded, included: an upper bound by a handful)
+    e8g = exg[0]
+    out["gkr_depth_20"] = {"replicas_ms_per_proof": round(1e3 * t_rep, 3), "sharded_t_local_ms": round(1e3 * t_sh, 3), "sharded_exchanges_8_ranks": e8g,
+                           "sharded_predicted_ms_per_proof": round(1e3 * t_sh + 1e-3 * e8g * x8, 3),
+                           "expected_winner": "replicas" if t_rep < t_sh + 1e-6 * e8g * x8 else "sharded",
+                           "note": "the sharded t_local is the WHOLE layer on one rank (upper bound of an 8-rank rank's share: table building and "
+                                   "streaming rounds shrink 8-fold, the serial rounds and launches do not)"}
+    # commit, BASELINE configs[4]: 2^23 points per GPU + one 104-byte all-gather whose result the host reads
+    out["commit_2^23_per_gpu"] = {"exchanges": 1, "exchange_us_with_host_wait": round(x8h, 1),
+                                  "note": "t_local = the 2^23-point commit of `msm` run with --msm-log-n 23 (21.9 ms in round 2); predicted = t_local + exchange"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -548,6 +662,9 @@ def main():
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-fold", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="diagnostic: run the sharded prover protocol even on one GPU")
+    ap.add_argument("--no-h2d", action="store_true")
+    ap.add_argument("--config4-log-n", type=int, default=23, help="N > 1: log2 of the per-GPU points of the configs[4]-shaped commit (2^26 over 8 = 2^23)")
+    ap.add_argument("--no-exchange", action="store_true", help="skip the exchange-cost measurement and the N = 8 prediction")
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")
@@ -683,14 +800,14 @@ def main():
     # profiles/ (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); a file constant, labelled as such
     traffic, traffic_source = None, None
     try:
-        src = os.path.join("profiles", "r02", "pmc_traffic.json")
+        src = os.path.join("profiles", "r03", "pmc_traffic.json")
         pmc = json.load(open(os.path.join(ROOT, src)))
         if args.log_n == 24 and world == 1:
             traffic = pmc["multifold"]["hbm_bytes_per_launch"]
             traffic_source = src + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not collected in this run)"
     except Exception:
         traffic = None
-    roofline = {"bound": "hbm", "kernel": "multifold_kernel<64> (k-variable fold of the 2^%d table next to the serial rounds; k = 6 at 2^24 on one GPU)" % args.log_n,
+    roofline = {"bound": "hbm", "kernel": "multifold_mfma_kernel<4, 4> (k-variable fold of the 2^%d table next to the serial rounds, limb products as int8 MFMA; k = 6 at 2^24 on one GPU)" % args.log_n,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "launches": cnt, "avg_launch_us": round(1e3 * ms / max(1, cnt), 2),
@@ -699,6 +816,8 @@ def main():
     def leg(skip, fn, *a):
         if skip:
             return None
+        if world > 1:
+            return fn(*a)        # several ranks: a leg with collectives that failed on ONE rank would leave the others blocked -- let torchrun end the job
         try:
             return fn(*a)
         except Exception as e:   # reported, not hidden: the headline legs above are already measured
@@ -715,6 +834,29 @@ def main():
     # ---- the composed prover (GKR's sumcheck shape) on sharded tables; informational, never part of `value`
     composed = leg(args.no_composed, bench_composed, args, zk, N, rank, world, barrier, dist, torch, np)
     gkr = leg(args.no_gkr, bench_gkr, args, zk, rank, world, barrier, dist, torch, np)
+    # ---- PCIe-inclusive figure (never `value`), exchange cost and the N = 8 prediction (N = 1), strong scaling + configs[4] shape (N > 1)
+    h2d = leg(args.no_h2d or world > 1, bench_h2d, args, zk, N, table, poly, torch, np)
+    exchange = prediction = multi = None
+    if not args.no_exchange and not one_gpu:
+        import torch.distributed as tdist
+        own = False
+        try:
+            if world == 1 and not tdist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+                tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+                own = True
+            exchange = bench_exchange(tdist if world == 1 else dist, world, torch, own)
+        except Exception as e:
+            if world > 1:
+                raise
+            exchange = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1:
+            prediction = leg(False, bench_prediction, args, zk, N, torch, np, tdist, exchange if exchange and "error" not in exchange else None)
+        if own:
+            tdist.destroy_process_group()
+    if world > 1:
+        multi = bench_strong_and_config4(args, zk, N, rank, world, barrier, dist, torch, np)
 
     # ---- CPU baseline: the oracle's single-threaded restatement of poly_sum + prove, rank 0 only.  Last: the all-cores leg
     # loads every host core, which would disturb the host-side share of the GPU legs above if it ran before them
@@ -751,6 +893,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "batches": {**step_stats, "unit": "ms per step", "note": "batches of exactly `steps` steps between barrier + synchronize; value / ms_per_step = the median batch"},
             "pipelined": pipelined,
             "higher_is_better": True,
             "scaling": "weak",
@@ -774,6 +917,10 @@ def main():
             "ntt": ntt,
             "composed": composed,
             "gkr": gkr,
+            "h2d_inclusive": h2d,
+            "exchange": exchange,
+            **({"prediction_n8": prediction} if prediction is not None else {}),
+            **({"multi_gpu": multi} if multi is not None else {}),
         }
         print(json.dumps(out))
     if world > 1:

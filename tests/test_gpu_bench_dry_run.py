@@ -18,7 +18,7 @@ def test_bench_multi_rank_dry_run(world):
     port = 29800 + (os.getpid() % 1000) + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
-           "--log-n", "22", "--msm-log-n", "12", "--composed-log-n", "15", "--no-cpu-baseline"]   # the gkr leg runs too (replicas)
+           "--log-n", "22", "--msm-log-n", "12", "--composed-log-n", "15", "--config4-log-n", "12", "--no-cpu-baseline"]   # the gkr leg runs too (replicas)
     out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
@@ -32,5 +32,9 @@ def test_bench_multi_rank_dry_run(world):
     assert "dry_run" in d
     assert d["config"]["exchanges_per_prove"] >= 1 and d["config"]["transcript_replicated_on_all_ranks"] is True
     assert d["msm"]["commitment_replicated_on_all_ranks"] is True and d["msm"]["exchanges_per_commit"] == 1
+    mg = d["multi_gpu"]                                       # strong scaling of the headline + the configs[4]-shaped commit
+    assert mg["sumcheck_strong"]["scaling"] == "strong" and mg["sumcheck_strong"]["value"] > 0 and mg["sumcheck_strong"]["exchanges_per_prove"] >= 1
+    assert mg["commit_config4_shape"]["commitment_replicated_on_all_ranks"] is True and mg["commit_config4_shape"]["value"] > 0
+    assert d["batches"]["n"] >= 3 and d["batches"]["min"] <= d["ms_per_step"] <= d["batches"]["max"]
     sh = d["gkr"]["sharded"]
     assert sh["proof_equals_single_gpu_proof"] is True and sh["proof_replicated_on_all_ranks"] is True and sh["exchanges_per_proof"] > 0
