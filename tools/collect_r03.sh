@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round-3 profile collection on the GPU box (repo root): rocprofv3 kernel stats of the default bench, PMC FETCH / WRITE passes of the
+# prover leg, an SQ pass over the NTT leg.  Every profiler run is bounded by `timeout`; outputs under gpurun_out/r03/.
+mkdir -p gpurun_out/r03
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+P="--steps 3 --warmup 1 --no-cpu-baseline --no-msm --no-composed --no-gkr --no-ntt --no-h2d --no-exchange"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03/stats -- python3 bench.py --no-cpu-baseline > gpurun_out/r03/bench_under_rocprof.json 2> gpurun_out/r03/stats.err
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r03/pmc_fetch -- python3 bench.py $P > /dev/null 2> gpurun_out/r03/pmc_fetch.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r03/pmc_write -- python3 bench.py $P > /dev/null 2> gpurun_out/r03/pmc_write.err
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/r03/pmc_sq_ntt -- python3 tools/perf_ntt.py 21 > gpurun_out/r03/pmc_sq_ntt.txt 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/r03/pmc_sq_prover -- python3 bench.py $P > /dev/null 2> gpurun_out/r03/pmc_sq_prover.err
+find gpurun_out/r03 -name "*.csv" | head -20
+f=$(ls gpurun_out/r03/stats/*/*kernel_stats.csv | head -1); head -30 "$f" | cut -d, -f1-5 | sed 's/(.*),/",/' | cut -c1-160
+# keep what is small: stats CSVs and counter collections (the kernel traces themselves are large)
+find gpurun_out/r03 -name "*kernel_trace.csv" -size +4M -delete
+find gpurun_out/r03 -name "*.db" -delete
+du -sh gpurun_out/r03

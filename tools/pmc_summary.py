@@ -19,14 +19,14 @@ def per_kernel(path, counter):
 fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
 write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"_about": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `python3 bench.py --steps 3 --warmup 1 "
-                 "--no-cpu-baseline --no-msm --no-composed --no-gkr --no-ntt` on MI355X; FETCH_SIZE doubled per the gfx950 correction; units of the "
+                 "--no-cpu-baseline --no-msm --no-composed --no-gkr --no-ntt --no-h2d --no-exchange` on MI355X; FETCH_SIZE doubled per the gfx950 correction; units of the "
                  "counters: KB; hbm_bytes_per_launch = 2 * FETCH + WRITE", "kernels": {}}
 for k in sorted(fetch):
     if not k.startswith("zk::"):
         continue
     out["kernels"][k] = {"launches": nf[k], "FETCH_SIZE_KB_avg": fetch[k], "WRITE_SIZE_KB_avg": write.get(k, 0.0),
                          "hbm_bytes_per_launch": int(round((2 * fetch[k] + write.get(k, 0.0)) * 1024))}
-big = [k for k in out["kernels"] if "multifold_kernel" in k]
+big = [k for k in out["kernels"] if "multifold_mfma_kernel" in k or "multifold_kernel" in k]
 if big:
     k = max(big, key=lambda q: out["kernels"][q]["hbm_bytes_per_launch"])
     out["multifold"] = dict(out["kernels"][k], kernel=k)
