@@ -449,7 +449,7 @@ def bench_composed(args, zk, N, rank, world, barrier, dist, torch, np):
             "ms_per_prove": round(1e3 * dt / steps, 4), "batches": _stats([b_ / steps for b_ in bs], 1e3), "rounds": int(len(ch)), "steps": steps,
             "entries_per_table_per_gpu": n, "exchanges_per_prove": exch[0] if world > 1 else 0,
             "transcript_replicated_on_all_ranks": same,
-            "sharding": "tables sharded by low index bits, one 96-byte record per rank all-gathered per round" if world > 1 else "single GPU"}
+            "sharding": "tables sharded by low index bits; two rounds per exchange: one record of 16 cross-block sums (+ 4 block sums) per term and rank all-gathered per stage" if world > 1 else "single GPU"}
 
 
 def bench_gkr(args, zk, rank, world, barrier, dist, torch, np):
@@ -613,12 +613,12 @@ def bench_prediction(args, zk, N, torch, np, dist_mod, exchange):
     ex = [0]
 
     def cstep():
-        sh = D.ShardedComposedSumcheck(D.HipComposedEngine([tabs], 1, multi=False), 1, None, None)
+        sh = D.ShardedComposedSumcheck(D.HipComposedEngine([tabs], 1, multi=False), 1, None, None, use_stages=True)
         sh.prove()
         ex[0] = sh.exchanges
     ts = _timed(cstep, torch, reps=3, min_total=0.15, max_batches=20)
     tc = sorted(ts)[len(ts) // 2]
-    e8 = ex[0] + 3
+    e8 = ex[0] + 2              # three more rounds are exchanged at 8 ranks (the table is 8 times larger): two exchanges with two rounds per exchange
     out["composed_2x2^%d_per_gpu" % args.composed_log_n] = {"t_local_ms": round(1e3 * tc, 4), "exchanges": e8, "predicted_ms_per_prove": round(1e3 * tc + 1e-3 * e8 * x8, 4)}
     del tabs
     # GKR, Circuit::random(20): one proof sharded over 8 ranks against one proof per rank (replicas)
@@ -628,7 +628,7 @@ def bench_prediction(args, zk, N, torch, np, dist_mod, exchange):
     exg = [0]
 
     def gstep():
-        exg[0] = zk.GKRProtocol.prove_sharded(circuit, ev, 1, 0, None, None)._exchanges
+        exg[0] = zk.GKRProtocol.prove_sharded(circuit, ev, 1, 0, None, None, use_stages=True)._exchanges     # two rounds per exchange, as the ranks of a real job run it
     tg = _timed(gstep, torch, reps=1, min_total=0.15, max_batches=8)
     t_rep, t_sh = sorted(tr)[len(tr) // 2], sorted(tg)[len(tg) // 2]
     # exchanges: a session exchanges one record per round while (local entries x world) exceeds the tail and then gathers once -- a count

@@ -341,6 +341,16 @@ int zkhip_mc_round_sums(zkhip_mc_state *st, uint64_t *d_out);
 /* d_gathered[world][rec][4]: every rank's record in rank order */
 int zkhip_mc_absorb(zkhip_mc_state *st, const uint64_t *d_gathered, uint32_t world);
 /* the local tables as the next round would see them, d_out[n_tables][local_len][4] */
+/* Two rounds per exchange for claims whose terms are products of TWO tables (csrc/composed_stage.hpp): a product does not commute
+ * with block sums but is bilinear in them, so the next two round polynomials are functions of the 16 cross-block sums
+ * C[a][b] = sum_j A[a][j] B[b][j] (a, b = the two leading index bits) and the 4 block sums of an additive table.
+ * zkhip_mc_stage_record_len: the record length in field elements (n_terms * 20), or 0 when the next step cannot be a stage;
+ * zkhip_mc_stage_sums: this rank's record; zkhip_mc_stage_absorb: the gathered records of all ranks -> two transcript rounds
+ * (round polynomials and challenges recorded as by zkhip_mc_absorb) and the fold of every local table by both challenges.
+ * Bit-identical to two zkhip_mc_round_sums / zkhip_mc_absorb steps (multi_composed_sumcheck.rs:76-104). */
+int zkhip_mc_stage_record_len(zkhip_mc_state *s, uint32_t *vals);
+int zkhip_mc_stage_sums(zkhip_mc_state *s, uint64_t *d_out);
+int zkhip_mc_stage_absorb(zkhip_mc_state *s, const uint64_t *d_gathered, uint32_t world);
 int zkhip_mc_local_tables(zkhip_mc_state *st, uint64_t *d_out);
 /* d_tables[n_tables][m][4]: the whole remaining tables in natural order (entry j*world + g = rank g's local entry j),
  * m = local_len * world <= tail_capacity; runs ALL remaining log2(m) rounds */

@@ -271,6 +271,59 @@ class OracleComposedEngine:
         self._apply_pending()
         out.copy_(torch.from_numpy(self._record(self.ora, self.terms).view(np.int64)))
 
+    # ---- two rounds per exchange (zkhip_mc_stage_*): the record is, per term, C[a][b] = sum_j A[a][j] B[b][j] over the four blocks
+    # of the next two variables (16 values, index 4 a + b) and 4 block sums of an additive table (none here: zeros)
+    def stage_record_len(self):
+        if self.pending is not None or self.terms[0].shape[1] < 4 or any(t.shape[0] != 2 for t in self.terms):
+            return 0
+        return 20 * len(self.terms)
+
+    def stage_sums(self, out):
+        o, rec = self.ora, []
+        zero = o.fr_from_ints([0])[0]
+        for t in self.terms:
+            m = t.shape[1] // 4
+            for a in range(4):
+                for b in range(4):
+                    acc = zero
+                    for j in range(m):
+                        acc = o.fr_add(acc, o.fr_mul(t[0][a * m + j], t[1][b * m + j]))
+                    rec.append(acc)
+            rec += [zero] * 4
+        out.copy_(torch.from_numpy(np.stack(rec).view(np.int64)))
+
+    def stage_absorb(self, gathered, world):
+        o = self.ora
+        g = gathered.numpy().view(np.uint64)
+        rec = g[0].copy()
+        for k in range(1, world):
+            rec = np.stack([o.fr_add(rec[i], g[k, i]) for i in range(rec.shape[0])])
+        add, sub, mul = o.fr_add, o.fr_sub, o.fr_mul
+        dbl = lambda v: add(v, v)           # noqa: E731
+        one = o.fr_from_ints([1])[0]
+        # round 1: p(0), p(1), p(2) of every term from C (the additive sums are zero here)
+        evals = []
+        for p_ in range(len(self.terms)):
+            C = rec[20 * p_: 20 * p_ + 16]
+            ll, hh = add(C[0], C[5]), add(C[10], C[15])
+            lh = add(add(C[2], C[7]), add(C[8], C[13]))
+            evals += [ll, hh, sub(add(ll, dbl(dbl(hh))), dbl(lh))]
+        r1 = self._close(np.stack(evals))
+        l0 = sub(one, r1)
+        evals = []
+        for p_ in range(len(self.terms)):
+            C = rec[20 * p_: 20 * p_ + 16]
+            B = []
+            for x in range(2):
+                for y in range(2):
+                    t0 = add(mul(C[4 * x + y], l0), mul(C[4 * x + 2 + y], r1))
+                    t1 = add(mul(C[4 * (2 + x) + y], l0), mul(C[4 * (2 + x) + 2 + y], r1))
+                    B.append(add(mul(t0, l0), mul(t1, r1)))
+            evals += [B[0], B[3], sub(add(B[0], dbl(dbl(B[3]))), dbl(add(B[1], B[2])))]
+        r2 = self._close(np.stack(evals))
+        for r in (r1, r2):
+            self.terms = [np.stack([o.mle_partial_evaluation(t[k], r, 0) for k in range(t.shape[0])]) for t in self.terms]
+
     def _close(self, rec):
         o = self.ora
         if not self.multi:
@@ -334,6 +387,16 @@ def _composed_worker(rank, world, port, log_n, q):
         wrp, wch = ora.composed_prove(full)
         ok_c = np.array_equal(rp, wrp) and np.array_equal(ch, wch)
         # MultiComposedSumcheckProver::prove_partial, the GKR shape (two terms of two tables) and a single term
+        # ComposedSumcheck::prove with two tables: two rounds per exchange (stage records of 20 values)
+        full2 = np.stack([ora.random_fr(n, 177 + k) for k in range(2)])
+        shard2 = np.stack([D.shard_interleaved(full2[k], rank, world) for k in range(2)])
+        sh = D.ShardedComposedSumcheck(OracleComposedEngine(ora, [shard2], False), world, None, dist, use_stages=True)
+        rp, ch = sh.prove()
+        wrp, wch = ora.composed_prove(full2)
+        ok_c = ok_c and np.array_equal(rp, wrp) and np.array_equal(ch, wch)
+        plain = D.ShardedComposedSumcheck(OracleComposedEngine(ora, [shard2], False), world, None, dist, use_stages=False)
+        plain.prove()
+        ok_c = ok_c and (sh.exchanges < plain.exchanges or n // world < 4)
         ok_m = True
         for sizes in ([2, 2], [3]):
             flat = np.stack([ora.random_fr(n, 91 + k) for k in range(sum(sizes))])

@@ -280,11 +280,29 @@ def test_overlapped_stage_2_27_over_8_shards_matches_single_gpu_prover(zk):
         assert np.array_equal(s, want.sum) and np.array_equal(rp, want.univariate_poly) and np.array_equal(ch, want_ch)
 
 
-def _drive_composed_shards(D, torch, engines, world, n_local):
-    """What ShardedComposedSumcheck.prove does, with the all-gather done by stacking the shards' buffers."""
+def _drive_composed_shards(D, torch, engines, world, n_local, stages=False, counts=None):
+    """What ShardedComposedSumcheck.prove does, with the all-gather done by stacking the shards' buffers.  stages: two rounds per
+    exchange where the claim allows it (zkhip_mc_stage_*: every term a product of two tables)."""
     cap, rec, nt = engines[0].tail_capacity(), engines[0].record_len(), engines[0].table_count()
     sends = [e.new_buffer(rec, 4) for e in engines]
-    n_exchanges = 0
+    n_exchanges = n_rounds_done = 0
+    while stages and n_local * world > cap and n_local >= 4:
+        vals = engines[0].stage_record_len()
+        assert all(e.stage_record_len() == vals for e in engines)
+        if not vals:
+            break
+        st_sends = [e.new_buffer(vals, 4) for e in engines]
+        for e, s in zip(engines, st_sends):
+            e.stage_sums(s)
+        gathered = torch.stack(st_sends).contiguous()
+        for e in engines:
+            e.stage_absorb(gathered, world)
+        n_local //= 4
+        n_exchanges += 1
+        n_rounds_done += 2
+    if counts is not None:
+        counts["stage_exchanges"] = n_exchanges
+    n_stage_exchanges = n_exchanges
     while n_local * world > cap and n_local > 1:
         for e, s in zip(engines, sends):
             e.round_sums(s)
@@ -300,7 +318,7 @@ def _drive_composed_shards(D, torch, engines, world, n_local):
         e.local_tables(t)
         tabs.append(t)
     full = torch.stack(tabs).permute(1, 2, 0, 3).contiguous().view(nt, n_local * world, 4)
-    total_rounds = (n_local * world).bit_length() - 1 + n_exchanges
+    total_rounds = (n_local * world).bit_length() - 1 + (n_exchanges - n_stage_exchanges) + 2 * n_stage_exchanges
     for e in engines:
         e.tail(full, n_local * world)
     return [e.finish(total_rounds) for e in engines]
@@ -322,6 +340,16 @@ def test_sharded_composed_sumcheck_matches_full_prover(zk, ora, world, k, log_n)
     wrp, wch = ora.composed_prove(full)
     for rp, ch in outs:
         assert np.array_equal(rp, wrp) and np.array_equal(ch, wch)
+    if k == 2:     # the same proof with two rounds per exchange
+        engines = []
+        for g in range(world):
+            shard = [torch.from_numpy(np.ascontiguousarray(D.shard_interleaved(full[q], g, world)).view(np.int64)).cuda() for q in range(k)]
+            engines.append(D.HipComposedEngine([shard], world, multi=False, ctx=N.Context(0)))
+        counts = {}
+        outs = _drive_composed_shards(D, torch, engines, world, (1 << log_n) // world, stages=True, counts=counts)
+        for rp, ch in outs:
+            assert np.array_equal(rp, wrp) and np.array_equal(ch, wch)
+        assert counts["stage_exchanges"] > 0 or (1 << log_n) // world < 4 or (1 << log_n) <= engines[0].tail_capacity()
 
 
 @pytest.mark.parametrize("world,sizes,log_n", [(2, [2, 2], 12), (8, [2, 3], 13), (4, [1, 5], 10), (2, [2, 2, 1, 1], 7), (4, [3], 16)])
@@ -340,12 +368,15 @@ def test_sharded_multi_composed_prove_partial_matches_full_prover(zk, ora, world
                           for i in range(k)])
             q += k
         engines.append(D.HipComposedEngine(terms, world, multi=True, claimed_sum=s, ctx=N.Context(0)))
-    outs = _drive_composed_shards(D, torch, engines, world, (1 << log_n) // world)
+    stages = all(k == 2 for k in sizes)          # the GKR shape: two rounds per exchange
+    counts = {}
+    outs = _drive_composed_shards(D, torch, engines, world, (1 << log_n) // world, stages=stages, counts=counts)
     orps, och = ora.multi_composed_prove(flat, sizes, s, partial=True)
     want = [o.monomials() for o in orps]
     for rps, ch in outs:
         got = [zk.SparseUnivariatePolynomial(c, p).monomials() for c, p in rps]
         assert got == want and np.array_equal(ch, och)
+    assert not stages or counts["stage_exchanges"] > 0
 
 
 def test_sharded_composed_orchestration_world_1(zk, ora):

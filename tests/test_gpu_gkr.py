@@ -183,8 +183,9 @@ def test_gkr_device_circuit_reused_across_inputs(zk, ora):
         zk.GKRProtocol.prove(zk.Circuit.from_tuples(bad), ev)
 
 
+@pytest.mark.parametrize("stages", [False, True])
 @pytest.mark.parametrize("depth", [1, 2, 4, 8, 12])
-def test_gkr_prove_sharded_world_1_matches_prove(zk, ora, depth):
+def test_gkr_prove_sharded_world_1_matches_prove(zk, ora, depth, stages):
     """The sharded prover's code path (layer tables from zkhip_gkr_layer_tables, the rounds over b and over c as two zkhip_mc_*
     sessions with an additive table and a continued transcript) on one rank: the proof must be zkhip_gkr_prove's, bit for bit."""
     layers = random_circuit(depth)
@@ -192,7 +193,7 @@ def test_gkr_prove_sharded_world_1_matches_prove(zk, ora, depth):
     inp = ora.random_fr(2 ** depth, 800 + depth)
     ev = circuit.evaluation(inp)
     want = zk.GKRProtocol.prove(circuit, ev)
-    got = zk.GKRProtocol.prove_sharded(circuit, ev)
+    got = zk.GKRProtocol.prove_sharded(circuit, ev, use_stages=stages)      # stages: two rounds per exchange (zkhip_mc_stage_*)
     assert len(got.sumcheck_proofs) == depth
     for a, b in zip(got.sumcheck_proofs, want.sumcheck_proofs):
         assert np.array_equal(a.sum, b.sum) and a.to_bytes() == b.to_bytes()

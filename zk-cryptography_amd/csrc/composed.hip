@@ -12,6 +12,7 @@
 #include "ctx.hpp"
 #include "host_util.hpp"
 #include "composed_kernels.hpp"
+#include "composed_stage.hpp"
 #include "host_fr.hpp"
 
 using namespace zk;
@@ -101,6 +102,9 @@ struct ComposedRun {
     std::vector<const uint64_t*> cur, lin_cur;
     uint32_t round = 0, first = 1, tail_len = 0;
     uint32_t out_base = 0;   // rounds already recorded in d_rp / d_ch by an earlier call of the same sumcheck (cont): this call appends
+    bool pending = false;    // the tables are still to be folded at the last challenge (the round kernels fold while they sum the next round)
+    int cur_buf = 0;         // where the current tables lie: 0 the caller's, 1 the n/2-entry buffer, 2 the n/4-entry buffer
+    uint64_t* d_stage_w = nullptr;   // fold weights of a two-round stage (composed_stage.hpp)
     FrArg sum_arg = {};      // the claimed sum, passed to the closing kernels by value
 
     // n = entries per table held here, n_rounds = rounds of the whole sumcheck (log2 n, more when other ranks hold shards)
@@ -137,10 +141,14 @@ struct ComposedRun {
         cur.assign(ptrs, ptrs + total);
         // workspace: per table a ping (n/2) and a pong (n/4) buffer, then the state
         per_table = (n / 2 + n / 4 + 2) * 32;
-        const size_t bytes_off = (total_all * per_table + 255) & ~(size_t)255;
+        const size_t w_off = (total_all * per_table + 255) & ~(size_t)255;
+        const size_t bytes_off = w_off + 256;
         const size_t chunk = std::min<size_t>(n, (size_t)1 << 18);   // entries per staging buffer of prove()'s table-bytes pass
         ZK_TRY(c->reserve_ws(bytes_off + (multi && !partial ? 64 * chunk : 0)));
         ws = (char*)c->d_ws;
+        d_stage_w = (uint64_t*)(ws + w_off);
+        pending = false;
+        cur_buf = 0;
         // the device-resident state (transcript, interpolation matrices of every degree) belongs to the context: uploaded once,
         // and a continuation (cont) finds the transcript where the previous call's kernels left it -- no copies, no waiting
         if (!c->d_composed) {
@@ -203,7 +211,7 @@ struct ComposedRun {
         }
         return ZKHIP_OK;
     }
-    bool folds() const { return round > 0; }
+    bool folds() const { return pending; }
     const uint64_t* prev_challenge() const { return d_ch + 4 * (size_t)(out_base + round - 1); }   // valid when folds()
     size_t after() const { return folds() ? cn / 2 : cn; }   // entries the current round's sums run over
     CloseArgs close_args() const {
@@ -236,17 +244,14 @@ struct ComposedRun {
         MultiTablePtrs mp = {};
         for (uint32_t p = 0; p < n_terms; ++p) {
             TablePtrs tp = {};
-            // ping-pong: folds happen in rounds 1, 2, ...; round r writes n >> r entries.  Odd rounds use the
-            // n/2-entry buffer, even rounds the n/4-entry one.
+            // ping-pong: a fold writes into the buffer the current tables do not lie in (out_buf)
             for (uint32_t q = 0; q < term_sizes[p]; ++q) {
                 tp.in[q] = cur[off + q];
-                char* base = ws + (size_t)(off + q) * per_table;
-                tp.out[q] = (uint64_t*)((round & 1) ? base : base + (n / 2 + 1) * 32);
+                tp.out[q] = out_buf(off + q);
             }
             if (lin_cur[p]) {
                 tp.lin_in = lin_cur[p];
-                char* base = ws + (size_t)meta.lin_tab[p] * per_table;
-                tp.lin_out = (uint64_t*)((round & 1) ? base : base + (n / 2 + 1) * 32);
+                tp.lin_out = out_buf(meta.lin_tab[p]);
             }
             if (same_k) {
                 mp.t[p] = tp;
@@ -278,15 +283,90 @@ struct ComposedRun {
 #undef CALL
             }
         }
-        if (fold) cn /= 2;
+        if (fold) { cn /= 2; cur_buf = cur_buf == 1 ? 2 : 1; }
         *n_records = grid;
         return ZKHIP_OK;
+    }
+    // the buffer a fold of table slot `q` writes: the n/2-entry one unless the current tables lie there (then they hold <= n/2 entries
+    // and the result fits the n/4-entry one)
+    uint64_t* out_buf(uint32_t q) const {
+        char* base = ws + (size_t)q * per_table;
+        return (uint64_t*)(cur_buf == 1 ? base + (n / 2 + 1) * 32 : base);
+    }
+    // ---- two rounds per pass (composed_stage.hpp): every term a product of two tables, nothing pending, and enough entries that the
+    // passes are throughput work (below that the four-lane round kernel and the LDS tail are faster)
+    // Single GPU: measured at 2^22 (tools/perf_composed.py, tools/gkr_run.py) the stage does NOT pay -- its cross sums are 16 products per
+    // index where two fused rounds are 13, and the serial part is the same two transcript rounds: K = 2 0.747 against 0.706 ms,
+    // GKR depth 20 11.8 against 11.4 ms, two terms of two tables 1.149 against 1.186 ms -- so it is off unless ZKHIP_STAGE=1 asks for it.
+    // The sharded sessions use it for every pair of rounds their shard allows: there a stage saves an EXCHANGE (zkhip_mc_stage_*).
+    bool stage_possible(size_t min_n) const {
+        if (pending || cn < min_n || cn < 4 || n_rounds - round < 2) return false;
+        for (uint32_t p = 0; p < n_terms; ++p) if (term_sizes[p] != 2) return false;
+        return true;
+    }
+    bool stage_ok() const {
+        static const bool on = [] { const char* e = std::getenv("ZKHIP_STAGE"); return e && std::atoi(e) != 0; }();
+        return on && stage_possible((size_t)1 << 15);
+    }
+    MultiTablePtrs stage_tables() const {
+        MultiTablePtrs mp = {};
+        uint32_t off = 0;
+        for (uint32_t p = 0; p < n_terms; ++p) {
+            mp.t[p].in[0] = cur[off];
+            mp.t[p].in[1] = cur[off + 1];
+            mp.t[p].lin_in = lin_cur[p];
+            mp.rec_off[p] = meta.rec_off[p];
+            off += 2;
+        }
+        return mp;
+    }
+    // first part: the cross-block sums, one record of n_terms * CST_VALS values per workgroup in d_partials
+    int stage_sums(int* n_records) {
+        const size_t m = cn / 4;
+        const int grid = (int)std::min<size_t>(CST_MAX_GRID, std::max<size_t>(1, m / 256));
+        ProfScope ps(c, "composed_cross2", 0.0);
+        hipLaunchKernelGGL(composed_cross2_kernel, dim3(grid, n_terms), dim3(CST_CROSS_BLOCK), 0, c->stream, stage_tables(), cn, n_terms, d_partials);
+        *n_records = grid;
+        return ZKHIP_OK;
+    }
+    // second part: sum the records (the workgroups' here, the ranks' in the sharded protocol), run the two rounds, fold every table by both
+    int stage_close(const uint64_t* records, uint32_t n_records) {
+        StageArgs sa = {};
+        sa.ca = close_args();
+        sa.n_records = n_records;
+        sa.weights_out = d_stage_w;
+        {
+            ProfScope ps(c, "composed_stage_close", 0.0);
+            hipLaunchKernelGGL(composed_stage_close_kernel, dim3(1), dim3(CST_BLOCK), 0, c->stream, records, sa);
+        }
+        first = 0;
+        round += 2;
+        const size_t m = cn / 4;
+        Fold2Tables ft = {};
+        uint32_t nt = 0;
+        for (uint32_t q = 0; q < total; ++q) { ft.in[nt] = cur[q]; ft.out[nt] = out_buf(q); cur[q] = ft.out[nt]; ++nt; }
+        for (uint32_t p = 0; p < n_terms; ++p)
+            if (lin_cur[p]) { ft.in[nt] = lin_cur[p]; ft.out[nt] = out_buf(meta.lin_tab[p]); lin_cur[p] = ft.out[nt]; ++nt; }
+        {
+            ProfScope ps(c, "composed_fold2", 0.0);
+            const int grid = (int)std::min<size_t>(2048, (m + CST_BLOCK - 1) / CST_BLOCK);
+            hipLaunchKernelGGL(composed_fold2_kernel, dim3(grid, nt), dim3(CST_BLOCK), 0, c->stream, ft, m, (const uint64_t*)d_stage_w);
+        }
+        cn = m;
+        cur_buf = cur_buf == 1 ? 2 : 1;
+        return ZKHIP_OK;
+    }
+    int stage() {
+        int grid = 0;
+        ZK_TRY(stage_sums(&grid));
+        return stage_close(d_partials, (uint32_t)grid);
     }
     // second part: sum the records (the workgroups' here, the ranks' in the sharded protocol) and close the round
     void close(const uint64_t* records, uint32_t n_records) {
         hipLaunchKernelGGL(composed_close_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, records, n_records, close_args());
         first = 0;
         ++round;
+        pending = true;
     }
     // all remaining rounds in one launch, on tables of m = after() entries that fit the LDS (fold: they are still to be
     // folded at the previous challenge while loading)
@@ -357,6 +437,7 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
             ZK_TRY(run.tail(run.current_tables(), (uint32_t)run.after(), run.folds()));
             break;
         }
+        if (run.stage_ok()) { ZK_TRY(run.stage()); continue; }
         int grid = 0;
         ZK_TRY(run.round_sums(&grid));
         run.close(run.d_partials, (uint32_t)grid);
@@ -382,6 +463,7 @@ int zk_multi_composed_enqueue(zkhip_ctx* c, const uint64_t* const* ptrs, const u
             ZK_TRY(run.tail(run.current_tables(), (uint32_t)run.after(), run.folds()));
             break;
         }
+        if (run.stage_ok()) { ZK_TRY(run.stage()); continue; }
         int grid = 0;
         ZK_TRY(run.round_sums(&grid));
         run.close(run.d_partials, (uint32_t)grid);
@@ -499,6 +581,35 @@ extern "C" int zkhip_mc_absorb(zkhip_mc_state* s, const uint64_t* d_gathered, ui
     if (!s || !d_gathered || world != s->world || !s->sums_pending) return ZKHIP_ERR_ARG;
     ZK_TRY(s->run.c->activate());
     s->run.close(d_gathered, world);
+    ZK_HIP(s->run.c, hipGetLastError());
+    s->sums_pending = false;
+    return ZKHIP_OK;
+}
+// Two rounds per exchange (composed_stage.hpp) when every term is a product of two tables: *vals = the length of the stage record
+// (n_terms * 20 field elements: the cross-block sums C[4][4] and the additive table's block sums L[4] of every term), or 0 when the
+// session's next step cannot be a stage (a term with K != 2, a fold pending from a plain round, fewer than 4 local entries or fewer
+// than 2 rounds left).
+extern "C" int zkhip_mc_stage_record_len(zkhip_mc_state* s, uint32_t* vals) {
+    if (!s || !vals) return ZKHIP_ERR_ARG;
+    *vals = (!s->sums_pending && s->run.stage_possible(4)) ? s->run.n_terms * (uint32_t)CST_VALS : 0u;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_mc_stage_sums(zkhip_mc_state* s, uint64_t* d_out) {
+    if (!s || !d_out) return ZKHIP_ERR_ARG;
+    ComposedRun& run = s->run;
+    if (s->sums_pending || !run.stage_possible(4)) return ZKHIP_ERR_ARG;
+    ZK_TRY(run.c->activate());
+    int grid = 0;
+    ZK_TRY(run.stage_sums(&grid));
+    hipLaunchKernelGGL(composed_stage_reduce_kernel, dim3(1), dim3(CST_BLOCK), 0, run.c->stream, run.d_partials, (uint32_t)grid, run.n_terms * (uint32_t)CST_VALS, d_out);
+    ZK_HIP(run.c, hipGetLastError());
+    s->sums_pending = true;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_mc_stage_absorb(zkhip_mc_state* s, const uint64_t* d_gathered, uint32_t world) {
+    if (!s || !d_gathered || world != s->world || !s->sums_pending) return ZKHIP_ERR_ARG;
+    ZK_TRY(s->run.c->activate());
+    ZK_TRY(s->run.stage_close(d_gathered, world));
     ZK_HIP(s->run.c, hipGetLastError());
     s->sums_pending = false;
     return ZKHIP_OK;

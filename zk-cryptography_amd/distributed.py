@@ -287,6 +287,18 @@ class HipComposedEngine:
         N.check(N.lib().zkhip_mc_tail_capacity(self.st, C.byref(cap)), "mc_tail_capacity")
         return cap.value
 
+    def stage_record_len(self):
+        """field elements of the two-round stage record (zkhip_mc_stage_*), 0 when the next step cannot be a stage"""
+        v = C.c_uint32(0)
+        N.check(N.lib().zkhip_mc_stage_record_len(self.st, C.byref(v)), "mc_stage_record_len")
+        return v.value
+
+    def stage_sums(self, out):
+        N.check(N.lib().zkhip_mc_stage_sums(self.st, N.ptr(out)), "mc_stage_sums")
+
+    def stage_absorb(self, gathered, world):
+        N.check(N.lib().zkhip_mc_stage_absorb(self.st, N.ptr(gathered), C.c_uint32(world)), "mc_stage_absorb")
+
     def round_sums(self, out):
         N.check(N.lib().zkhip_mc_round_sums(self.st, N.ptr(out)), "mc_round_sums")
 
@@ -321,15 +333,20 @@ class ShardedComposedSumcheck:
     """ComposedSumcheck::prove (composed_sumcheck.rs:32-67) / MultiComposedSumcheckProver::prove_partial
     (multi_composed_sumcheck.rs:56-121) over tables sharded by low index bits ("GKR tables").
 
-    One exchange per round: a record of (K_p + 1) partial sums per term (a product of tables does not commute with block
-    sums, so the stage form of the basic prover does not apply).  Every rank returns what engine.finish yields -- the
-    round polynomials and challenges a single-GPU / reference prover produces on the whole tables."""
+    One exchange per round: a record of (K_p + 1) partial sums per term.  Claims whose terms are products of TWO tables (the
+    reference's ComposedSumcheck bench shape and every GKR layer claim) take TWO rounds per exchange instead: a product does not
+    commute with block sums, but it is bilinear in them, so the next two round polynomials are functions of the 16 cross-block
+    sums per term (csrc/composed_stage.hpp) -- the record is 20 field elements per term, the ranks' records are added, two
+    transcript rounds run replicated and every rank folds its shards by both challenges.  Every rank returns what engine.finish
+    yields -- the round polynomials and challenges a single-GPU / reference prover produces on the whole tables."""
 
-    def __init__(self, engine, world=1, group=None, dist=None):
+    def __init__(self, engine, world=1, group=None, dist=None, use_stages=None):
         self.e = engine
         self.world = world
         self.group = group
         self.dist = dist
+        # stages save exchanges, not work (on one rank two fused rounds are cheaper than a stage: DESIGN.md section 6)
+        self.use_stages = (world > 1) if use_stages is None else bool(use_stages)
         if world & (world - 1):
             raise AssertionError("world size must be a power of two (the tables have 2^n entries)")
 
@@ -351,6 +368,19 @@ class ShardedComposedSumcheck:
         self.exchanges = 0
         cap = e.tail_capacity()
         rec = e.record_len()
+        if self.use_stages and hasattr(e, "stage_record_len"):
+            send = recv = None
+            while n_local * world > cap and n_local >= 4:
+                vals = e.stage_record_len()
+                if not vals:
+                    break
+                if send is None:
+                    send, recv = e.new_buffer(vals, 4), e.new_buffer(world, vals, 4)
+                e.stage_sums(send)                                            # 16 cross-block sums (+ 4 block sums) per term
+                _all_gather(self.dist, self.group, recv, send, world)         # ONE exchange for two rounds
+                self.exchanges += 1
+                e.stage_absorb(recv, world)                                   # two transcript rounds + the fold by both challenges
+                n_local //= 4
         if n_local * world > cap and n_local > 1:
             send = e.new_buffer(rec, 4)
             recv = e.new_buffer(world, rec, 4)

@@ -221,7 +221,7 @@ class GKRProtocol:
         return proof
 
     @staticmethod
-    def prove_sharded(circuit, circuit_evaluation, world=1, rank=0, group=None, dist=None):
+    def prove_sharded(circuit, circuit_evaluation, world=1, rank=0, group=None, dist=None, use_stages=None):
         """GKRProtocol::prove (protocol.rs:21-117) with every layer's tables and sumcheck SHARDED over `world` ranks (SURVEY 8e,
         "GKR tables"; BASELINE configs[3]: "evals sharded across 8").  Rank g builds ONLY rows j * world + g of the layer's seven
         linear-size sumcheck tables and of the layer's values (zkhip_gkr_layer_tables_sharded: w_len / world entries each, 1 / world
@@ -229,7 +229,9 @@ class GKRProtocol:
         all-gathered per round (distributed.ShardedComposedSumcheck over zkhip_mc_*; the transcript is replicated).  What the rows
         gather from by wire index -- the layer's values, the gate weights, eq(u) -- stays whole on every rank (random wiring reads
         any of them).  Layers narrower than 2 * world values run unsharded on every rank.  Returns the proof GKRProtocol.prove
-        returns, bit for bit, on every rank; the number of collectives is left in proof._exchanges."""
+        returns, bit for bit, on every rank; the number of collectives is left in proof._exchanges.  Every layer claim is two
+        terms of two tables (+ an additive table), so the sessions take TWO rounds per exchange (distributed.ShardedComposedSumcheck,
+        use_stages: default on for world > 1)."""
         import torch
         from zk_cryptography_amd import distributed as D
         from zk_cryptography_amd.composed import MultiComposedSumcheckProof, SparseUnivariatePolynomial
@@ -270,7 +272,7 @@ class GKRProtocol:
             ha0, ha1, hm = out[0], out[1], out[2]
             v_sh = out[3] if w > 1 else V                             # rows j * w + rank of the layer's values
             eng = D.HipComposedEngine([[ha0, v_sh], [hm, v_sh]], w, multi=True, claimed_sum=claimed, ctx=ctx, lin=[ha1, None])
-            sh = D.ShardedComposedSumcheck(eng, w, grp, dst)
+            sh = D.ShardedComposedSumcheck(eng, w, grp, dst, use_stages=(use_stages if w > 1 or use_stages is not None else False))
             sh.prove(collect=False)                                   # the rounds over b; recorded on the device
             proof._exchanges += sh.exchanges
             out2 = [torch.empty((w_len // w, 4), dtype=torch.int64, device=V.device) for _ in range(4)]
@@ -278,7 +280,7 @@ class GKRProtocol:
             N.check(N.lib().zkhip_gkr_layer_tables_sharded(dev.handle, C.c_uint32(layer), N.ptr(V), C.c_size_t(w_len), p(rb_a), rc_p, p(al_a), p(be_a),
                                                            C.c_int(1), C.c_uint32(w), C.c_uint32(rk), ptrs2, p(wu)), "gkr_layer_tables")
             eng = D.HipComposedEngine([[out2[0], out2[1]], [out2[2], out2[3]]], w, multi=True, ctx=ctx, cont=True, out_base=s_vars)
-            sh = D.ShardedComposedSumcheck(eng, w, grp, dst)
+            sh = D.ShardedComposedSumcheck(eng, w, grp, dst, use_stages=(use_stages if w > 1 or use_stages is not None else False))
             rps, ch = sh.prove(finish_rounds=2 * s_vars)              # the rounds over c; delivers all 2 s rounds
             proof._exchanges += sh.exchanges
             sumcheck_proof = MultiComposedSumcheckProof([SparseUnivariatePolynomial(c_, p_) for c_, p_ in rps], np.array(claimed, copy=True))
