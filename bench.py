@@ -663,6 +663,7 @@ def main():
     ap.add_argument("--no-fold", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="diagnostic: run the sharded prover protocol even on one GPU")
     ap.add_argument("--no-h2d", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the proofs-in-flight leg (profiling: keeps the kernel averages those of the synchronous steps)")
     ap.add_argument("--config4-log-n", type=int, default=23, help="N > 1: log2 of the per-GPU points of the configs[4]-shaped commit (2^26 over 8 = 2^23)")
     ap.add_argument("--no-exchange", action="store_true", help="skip the exchange-cost measurement and the N = 8 prediction")
     args = ap.parse_args()
@@ -736,7 +737,7 @@ def main():
     # informational: the same steps with two proofs in flight (zkhip_sumcheck_prove_begin / _end) -- the way a prover with
     # several tables calls the library; the device runs the proofs in stream order, the idle time between them shrinks
     pipelined = None
-    if world == 1 and not args.force_sharded:
+    if world == 1 and not args.force_sharded and not args.no_pipelined:
         # several tables, proved round robin with up to `depth` proofs in flight: every ticket has its own streams and buffers
         # (zkhip_ctx::ProofLane), so the streaming passes of one table's proof run while the transcript rounds of the others hash
         n_tab = 4

@@ -3,8 +3,10 @@
 # prover leg, an SQ pass over the NTT leg.  Every profiler run is bounded by `timeout`; outputs under gpurun_out/r03/.
 mkdir -p gpurun_out/r03
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-P="--steps 3 --warmup 1 --no-cpu-baseline --no-msm --no-composed --no-gkr --no-ntt --no-h2d --no-exchange"
+P="--steps 3 --warmup 1 --no-cpu-baseline --no-msm --no-composed --no-gkr --no-ntt --no-h2d --no-exchange --no-pipelined"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03/stats -- python3 bench.py --no-cpu-baseline > gpurun_out/r03/bench_under_rocprof.json 2> gpurun_out/r03/stats.err
+# the prover leg alone (no proofs in flight, whose overlapped kernels run longer): the averages the roofline object is checked against
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03/stats_prover -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-msm --no-composed --no-gkr --no-ntt --no-h2d --no-exchange --no-pipelined > gpurun_out/r03/bench_prover_under_rocprof.json 2> gpurun_out/r03/stats_prover.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r03/pmc_fetch -- python3 bench.py $P > /dev/null 2> gpurun_out/r03/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r03/pmc_write -- python3 bench.py $P > /dev/null 2> gpurun_out/r03/pmc_write.err
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/r03/pmc_sq_ntt -- python3 tools/perf_ntt.py 21 > gpurun_out/r03/pmc_sq_ntt.txt 2>&1

@@ -162,7 +162,43 @@ def case_table_ops():
     return ok, ("table_ops", la, lb, k)
 
 
-cases = [case_open, case_uni_open, case_table_ops, case_sumcheck, case_fold_eval, case_composed, case_multi, case_commit, case_ntt, case_gkr]
+
+def case_multifold():
+    """partial_evaluations(points, [0] * k) -- the k-variable fold (VALU and MFMA forms, chunked weights, small-table form) -- against k
+    single folds of the oracle"""
+    log_n = rng.randint(4, 21 + BIG // 2)
+    k = rng.randint(1, min(log_n - 1, 12))
+    t = ora.random_fr(1 << log_n, rng.randrange(1 << 30))
+    kind = rng.random()
+    if kind < 0.15: t[:] = 0
+    elif kind < 0.3: t = zk.Fr.from_ints([zk.Fr.MODULUS - 1] * 8)[rng.randrange(8)][None, :].repeat(1 << log_n, axis=0)   # r - 1 everywhere: largest limbs
+    pts = ora.random_fr(k, rng.randrange(1 << 30))
+    got = dev(zk.Multilinear(t).partial_evaluations(pts, [0] * k).evaluations)
+    want = t
+    for i in range(k):
+        want = ora.mle_partial_evaluation(want, pts[i], 0)
+    return np.array_equal(got, want), ("multifold", log_n, k)
+
+
+def case_in_flight():
+    """up to four Sumcheck proofs in flight on lanes of their own, tables of mixed sizes"""
+    depth = rng.randint(2, 4)
+    logs = [rng.choice([3, 9, 12, 18, 19, 20, 21]) for _ in range(rng.randint(2, 6))]
+    tabs = [ora.random_fr(1 << l, rng.randrange(1 << 30)) for l in logs]
+    pend, got = [], []
+    for t in tabs:
+        sc = zk.Sumcheck(zk.Multilinear(t)); sc.poly_sum()
+        pend.append(sc.prove_begin())
+        if len(pend) == depth: got.append(pend.pop(0).wait())
+    got += [h.wait() for h in pend]
+    ok = True
+    for t, (proof, ch) in zip(tabs, got):
+        ws, wrp, wch = ora.sumcheck_prove(t)
+        ok = ok and np.array_equal(proof.sum, ws) and np.array_equal(proof.univariate_poly, wrp) and np.array_equal(ch, wch)
+    return ok, ("in_flight", depth, logs)
+
+
+cases = [case_multifold, case_in_flight, case_open, case_uni_open, case_table_ops, case_sumcheck, case_fold_eval, case_composed, case_multi, case_commit, case_ntt, case_gkr]
 if len(sys.argv) > 3:
     cases = [c for c in cases if c.__name__ in sys.argv[3:]]
 t0 = time.time()
