@@ -429,10 +429,51 @@ __device__ __forceinline__ Fr shfl_fr(const Fr& v, int src_lane) {
     for (int i = 0; i < Fr::N; ++i) r.l[i] = __shfl(v.l[i], src_lane, 64);
     return r;
 }
-__device__ __forceinline__ Fr wave_reduce_fr(Fr v) {
+// Cross-lane moves of a reduction as DPP / permlane VALU instructions, not ds_bpermute: a shuffle tree over a field element is 48
+// LDS crossbar operations per value, and the block-sum pass (two values per 16 KiB per wave) kept every CU's LDS busy with them --
+// fine_sums ran at 94-96 us where its loads alone take 81 (tools/ubench_rows.hip).
+// row_shr:n (0x110 + n) within rows of 16 lanes, row_bcast:15 (0x142) / row_bcast:31 (0x143) across rows; lanes without a source, and
+// rows masked out, contribute zero.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Fr dpp_fr(const Fr& v) {
+    Fr r;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = v + shfl_down_fr(v, d);
-    return v;   // lane 0 holds the sum
+    for (int i = 0; i < Fr::N; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], CTRL, ROW_MASK, 0xf, true);
+    return r;
+}
+__device__ __forceinline__ Fr readlane_fr(const Fr& v, int lane) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < Fr::N; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[i], lane);
+    return r;
+}
+__device__ __forceinline__ Fr wave_reduce_fr(Fr v) {
+    v = v + dpp_fr<0x111, 0xf>(v);
+    v = v + dpp_fr<0x112, 0xf>(v);
+    v = v + dpp_fr<0x114, 0xf>(v);
+    v = v + dpp_fr<0x118, 0xf>(v);      // lane 15 of every row: the row's sum
+    v = v + dpp_fr<0x142, 0xa>(v);      // rows 1 and 3 += lane 15 of the row before
+    v = v + dpp_fr<0x143, 0xc>(v);      // rows 2 and 3 += lane 31
+    return readlane_fr(v, 63);          // every lane holds the sum
+}
+// Two sums for six steps instead of twelve: the halves of the wave trade one value each (v_permlane32_swap), then every half reduces
+// ONE value.  On return every lane holds both sums.
+__device__ __forceinline__ void wave_reduce_fr2(Fr& a, Fr& b) {
+    Fr lo, hi;
+#pragma unroll
+    for (int i = 0; i < Fr::N; ++i) {
+        const auto s = __builtin_amdgcn_permlane32_swap(a.l[i], b.l[i], false, false);   // -> [a.lo, b.lo], [a.hi, b.hi]
+        lo.l[i] = s[0];
+        hi.l[i] = s[1];
+    }
+    Fr v = lo + hi;                     // lanes 0..31: partial sums of a, lanes 32..63: of b
+    v = v + dpp_fr<0x111, 0xf>(v);
+    v = v + dpp_fr<0x112, 0xf>(v);
+    v = v + dpp_fr<0x114, 0xf>(v);
+    v = v + dpp_fr<0x118, 0xf>(v);
+    v = v + dpp_fr<0x142, 0xa>(v);      // lane 31: the sum of a, lane 63: the sum of b
+    a = readlane_fr(v, 31);
+    b = readlane_fr(v, 63);
 }
 // Sum over the workgroup; result valid in thread 0.  smem: (blockDim/64) Fr slots.
 __device__ __forceinline__ Fr block_reduce_fr(Fr v, Fr* smem) {
@@ -452,12 +493,7 @@ __device__ __forceinline__ Fr block_reduce_fr(Fr v, Fr* smem) {
 // Two sums at once (one barrier set, two independent dependency chains for the scheduler to interleave).
 __device__ __forceinline__ void block_reduce_fr2(Fr& a, Fr& b, Fr* smem /* 2 * n_waves */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63) >> 6;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        Fr ta = shfl_down_fr(a, d), tb = shfl_down_fr(b, d);
-        a = a + ta;
-        b = b + tb;
-    }
+    wave_reduce_fr2(a, b);
     if (lane == 0) { smem[2 * wave] = a; smem[2 * wave + 1] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {

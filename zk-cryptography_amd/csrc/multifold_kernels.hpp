@@ -75,12 +75,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void fine_sums_kernel(const uint6
     for (int u = 4; u < 8; ++u) v[u] = two ? load_fr(base, lane + 64 * u) : Fr::zero();
     Fr a = (v[0] + v[1]) + (v[2] + v[3]);
     Fr b = (v[4] + v[5]) + (v[6] + v[7]);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        Fr ta = shfl_down_fr(a, d), tb = shfl_down_fr(b, d);
-        a = a + ta;
-        b = b + tb;
-    }
+    wave_reduce_fr2(a, b);              // DPP / permlane moves: no LDS traffic beside the loads
     if (lane == 0) {
         store_fr(sums, c0, a);
         if (two) store_fr(sums, c0 + 1, b);
