@@ -6,14 +6,19 @@ Metric (BASELINE.json): field-evals/s of the sumcheck prover over a 24-variable 
 table: Sumcheck::poly_sum + Sumcheck::prove (sumcheck/benches/sumcheck_benchmark.rs:13-22 minus
 the verifier) -- block sums, k-variable folds and the Fiat-Shamir transcript on the device --
 with the table already resident in HBM.  value = (tables' entries consumed by all ranks) / time.
+Timing: after `warmup` steps, batches of EXACTLY `steps` steps, each between barrier + synchronize (MAX over ranks per batch), until
+>= 0.3 s are measured; the line reports the median batch and min / median / max under `batches`.
 
-Extra objects on the JSON line: `roofline` for the dominant kernel (the streaming k-variable fold) from HIP
-events on its launch stream, and `cpu_baseline`: the CPU oracle (a C port of the reference
+Extra objects on the JSON line: `roofline` for the dominant kernel (the streaming k-variable fold, limb products on the matrix cores)
+from HIP events on its launch stream, and `cpu_baseline`: the CPU oracle (a C port of the reference
 algorithm, single-threaded like the reference) timed on rank 0 at N=1 (plus the same port on all host cores at once).
-Informational objects that never enter `value`: `fold` (the single-variable fold of SURVEY 8d's 48 n row, with its own
-roofline), `msm` (the second half of BASELINE's metric: KZG commit points/s with its roofline and CPU baselines), `ntt`
-(the 2^21-point transform and the 2^20 x 2^20 product), `composed` (ComposedSumcheck::prove over sharded tables) and
-`gkr` (GKRProtocol::prove, replicas).
+Informational objects that never enter `value`: `pipelined` (the same proofs with up to four in flight), `fold` (the single-variable
+fold of SURVEY 8d's 48 n row, with its own roofline), `msm` (the second half of BASELINE's metric: KZG commit points/s with its roofline
+and CPU baselines), `ntt` (the 2^21-point transform and the 2^20 x 2^20 product), `composed` (ComposedSumcheck::prove over sharded
+tables), `gkr` (GKRProtocol::prove, replicas; at N > 1 also ONE proof sharded), `h2d_inclusive` (the step with the table uploaded over
+PCIe first), `exchange` (what one all-gather of the sharded provers costs on this backend), `prediction_n8` (N = 1: the sharded paths
+priced for 8 GPUs from their one-rank cost and the exchange cost) and `multi_gpu` (N > 1: strong scaling of the
+headline and BASELINE configs[4]'s commit shape).
 
 Synthetic inputs follow SURVEY 8d: uniform field elements from splitmix64-seeded xoshiro256** streams
 (zkhip_synthetic_fr): table t of rank g seed 0x5EED000000000001 + t + 16 g, commit scalars 0x5EED000000001001 + g, GKR inputs

@@ -11,6 +11,9 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpu
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r03/pmc_write -- python3 bench.py $P > /dev/null 2> gpurun_out/r03/pmc_write.err
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/r03/pmc_sq_ntt -- python3 tools/perf_ntt.py 21 > gpurun_out/r03/pmc_sq_ntt.txt 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/r03/pmc_sq_prover -- python3 bench.py $P > /dev/null 2> gpurun_out/r03/pmc_sq_prover.err
+timeout 200 python3 tools/timeline.py 24 2>&1 | grep -v "^W2026\|amdgpu.ids" | tail -30 > gpurun_out/r03/b_prover_timeline.txt
+timeout 200 python3 tools/timeline_pipelined.py 24 8 2>&1 | grep -v "^W2026\|amdgpu.ids" > gpurun_out/r03/c_proofs_in_flight_timeline.txt
+timeout 300 python3 bench.py > gpurun_out/r03/a_bench_line_default_run.json 2> gpurun_out/r03/a_bench_line_default_run.err
 find gpurun_out/r03 -name "*.csv" | head -20
 f=$(ls gpurun_out/r03/stats/*/*kernel_stats.csv | head -1); head -30 "$f" | cut -d, -f1-5 | sed 's/(.*),/",/' | cut -c1-160
 # keep what is small: stats CSVs and counter collections (the kernel traces themselves are large)
