@@ -497,7 +497,11 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
         const int v = std::atoi(e);
         if (v >= 8 && v <= 20) OPEN_BATCH_MAX = (size_t)1 << v;
     }
-    constexpr int NSLOT = zkhip_ctx::MSM_SLOTS - 1;  // large rounds in flight; the last slot is the batch's
+    int NSLOT = zkhip_ctx::MSM_SLOTS - 1;  // large rounds in flight; the last slot is the batch's
+    if (const char* e = std::getenv("ZKHIP_OPEN_SLOTS")) {   // tuning aid (tools/perf_open.py): fewer pipelines beside each other
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= zkhip_ctx::MSM_SLOTS - 1) NSLOT = v;
+    }
     const uint64_t* cur = d_evals;
     size_t cn = n, lvl_off = 0;
     MsmProblems batch = {};
@@ -559,12 +563,12 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
     // the batch of small rounds FIRST: its chain of latency-bound passes is the longest of all (26 narrow windows per problem), and issued
     // last it only started when the first large round's queue had drained (profiles/r03: 5.2 ms into an 8.5 ms open)
     if (batch.n && rc == ZKHIP_OK) {
-        const int sl = NSLOT;
+        const int sl = zkhip_ctx::MSM_SLOTS - 1;
         if (hipStreamWaitEvent(c->side[sl], c->fork_ev, 0) != hipSuccess) rc = ZKHIP_ERR_HIP;
         if (rc == ZKHIP_OK) {
             c->stream = c->side[sl];
             rc = msm_enqueue(c, d_folded_xy + 12 * batch_first_off, d_folded_inf + batch_first_off, d_q + 4 * batch_first_off,
-                             lvl_off - batch_first_off, batch, nullptr, 0, region_off[sl], sl, &pend[sl], nullptr);
+                             lvl_off - batch_first_off, batch, nullptr, 0, region_off[NSLOT], sl, &pend[sl], nullptr);
             c->stream = main_stream;
             if (rc == ZKHIP_OK) pend_round[sl] = (int)batch_first_round;
         }
