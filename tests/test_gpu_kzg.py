@@ -374,6 +374,24 @@ def test_commit_table_with_identity_points_and_short_polynomial(zk, ora):
     assert zk.UnivariateKZG.commitment(coeffs, usrs) == zk.UnivariateKZG.commitment(coeffs, utab)
 
 
+def test_srs_caches_follow_in_place_edits(zk, ora):
+    """The shifted-SRS table and the folded levels are derived from the SRS tensors once -- and again when those tensors are edited in
+    place or replaced (torch's version counters are part of the cache key): never a stale table."""
+    tau = ora.random_fr(8, 321)
+    srs = zk.TrustedSetup.setup(tau).precompute()
+    poly = zk.Multilinear(ora.random_fr(256, 322))
+    before = zk.MultilinearKZG.commitment(poly, srs)
+    z = ora.random_fr(8, 323)
+    zk.MultilinearKZG.open(poly, z, srs)                                   # caches the folded levels too
+    srs.powers_of_tau_in_g1[[0, 1]] = srs.powers_of_tau_in_g1[[1, 0]]      # in place: the first two points swapped
+    plain = zk.TrustedSetup(srs.powers_of_tau_in_g1.clone(), srs.inf.clone())
+    after = zk.MultilinearKZG.commitment(poly, srs)                        # plain path now: the stale table was dropped
+    assert srs.table is None and not (after == before) and after == zk.MultilinearKZG.commitment(poly, plain)
+    assert zk.MultilinearKZG.commitment(poly, srs.precompute()) == after   # and a table rebuilt from the edited points agrees
+    a, b = zk.MultilinearKZG.open(poly, z, srs), zk.MultilinearKZG.open(poly, z, plain, cache_folded_srs=False)
+    assert all(p == q for p, q in zip(a.proofs, b.proofs))
+
+
 # ---- commits in flight (zkhip_kzg_commit_begin / _end) ------------------------------------------------------------------
 @pytest.mark.parametrize("table", [False, True])
 def test_commits_in_flight_match_synchronous_commits(zk, ora, table):

@@ -22,4 +22,4 @@ for r in rows[start:]:
 out.close()
 PY
 wc -l gpurun_out/r03/open_last_call_trace.txt
-find gpurun_out/r03/open -name "*kernel_trace.csv" -delete
+

@@ -92,9 +92,27 @@ class TrustedSetup:
     def __len__(self):
         return self.powers_of_tau_in_g1.shape[0]
 
+    def _stamp(self):
+        """Identity of the SRS the derived caches were built from: the tensors' storage and torch's in-place version counters (an
+        in-place edit of `powers_of_tau_in_g1` / `inf`, or assigning new tensors, invalidates the shifted table and the folded levels)."""
+        p, i = self.powers_of_tau_in_g1, self.inf
+        return (p.data_ptr(), p.shape[0], p._version, i.data_ptr(), i._version)
+
+    def _check_caches(self):
+        if getattr(self, "_cache_stamp", None) != self._stamp():
+            self._table = self._folded = None
+            self._cache_stamp = self._stamp()
+
+    @property
+    def table(self):
+        """the shifted-SRS table, or None (never a stale one: see _stamp)"""
+        self._check_caches()
+        return getattr(self, "_table", None)
+
     def precompute(self):
         """Build (once) the shifted-SRS table 2^(20 w) * point for the 13 windows of a scalar: commitments then need
         13 instead of 16 bucket additions per point and one bucket reduction (zkhip_srs_precompute); 1.6 GiB at 2^20."""
+        self._check_caches()
         if getattr(self, "_table", None) is None:
             import torch
             n = len(self)
@@ -110,6 +128,7 @@ class TrustedSetup:
     def folded(self):
         """The SRS summed over its leading variables, level after level (n - 1 points): what commitments to the
         blown-up quotients of `open` reduce to.  Depends on the SRS only; derived once and kept."""
+        self._check_caches()
         if getattr(self, "_folded", None) is None:
             n = len(self)
             xy, inf = TrustedSetup._alloc(n - 1)
@@ -211,13 +230,13 @@ class MultilinearKZG:
     def commitment(poly, srs):
         """MultilinearKZGInterface::commitment (multilinear_kzg.rs:33-48)"""
         assert isinstance(poly, Multilinear)
-        return _commit(srs.powers_of_tau_in_g1, srs.inf, len(srs), poly.evaluations, len(poly), True, getattr(srs, "_table", None))
+        return _commit(srs.powers_of_tau_in_g1, srs.inf, len(srs), poly.evaluations, len(poly), True, srs.table)
 
     @staticmethod
     def commitment_begin(poly, srs):
         """The same commitment, in flight: -> PendingCommitment (at most three at a time); .wait() yields the G1Affine."""
         assert isinstance(poly, Multilinear)
-        return _commit_begin(srs.powers_of_tau_in_g1, srs.inf, len(srs), poly.evaluations, len(poly), True, getattr(srs, "_table", None))
+        return _commit_begin(srs.powers_of_tau_in_g1, srs.inf, len(srs), poly.evaluations, len(poly), True, srs.table)
 
     @staticmethod
     def open(poly, evaluation_points, srs, cache_folded_srs=True):
@@ -281,4 +300,4 @@ class UnivariateKZG:
         """UnivariateKZGInterface::commitment (univariate_kzg.rs:37-58): no length assert; a polynomial longer
         than the SRS indexes out of bounds (IndexError), exactly what the unregistered bench would hit."""
         assert isinstance(poly, DenseUnivariatePolynomial)
-        return _commit(srs.powers_of_tau_in_g1, srs.inf, len(srs), poly.coefficients, len(poly), False, getattr(srs, "_table", None))
+        return _commit(srs.powers_of_tau_in_g1, srs.inf, len(srs), poly.coefficients, len(poly), False, srs.table)
