@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/ab_multifold.sh "0 14 24 42 44 48 84" -- the prover's bench leg per ZKHIP_MF setting (0 = VALU form)
+# usage (GPU box, repo root): tools/ab_multifold.sh "0 1 3" -- the prover's bench leg per ZKHIP_MF setting (0 = VALU form, r = rotation of the term order)
 for cfg in $1; do
   for rep in 1 2; do
     ZKHIP_MF=$cfg python bench.py --steps 40 --warmup 5 --no-msm --no-ntt --no-composed --no-gkr --no-cpu-baseline --no-fold 2>/dev/null | python -c "

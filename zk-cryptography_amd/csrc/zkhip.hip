@@ -511,24 +511,19 @@ static int launch_multifold(zkhip_ctx* c, hipStream_t stream, const uint64_t* cu
                             uint64_t* dst, uint64_t* pdst, uint32_t* n_parts) {
     const size_t m = cn >> k;
     uint32_t out_per_wg;
-    // tuning knob (diagnostics only): ZKHIP_MF = 0 keeps the VALU form; "WDR" = the MFMA form's waves per workgroup, load depth and
-    // the rotation of the term order (tile T starts at term R * T mod 2^k; 0 = every wave at term 0)
-    static const int mf_cfg = [] { const char* e = getenv("ZKHIP_MF"); return e ? atoi(e) : 441; }();
+    // diagnostics: ZKHIP_MF=0 keeps the VALU form for an A/B on the same box (tools/ab_multifold.sh); ZKHIP_MF=r (1..9) sets the rotation of
+    // the term order (tile T starts at term r * T mod 2^k; the default 1 -- 3 and 5 measured the same, 0 = every wave at term 0: 108 vs 112 us
+    // before the aligned planes); ZKHIP_MF_OCC=n caps the workgroups per CU through the LDS request (1: 95 us, 2 = the register limit: 84 us)
+    static const int mf_cfg = [] { const char* e = getenv("ZKHIP_MF"); return e ? atoi(e) : 1; }();
     if (m >= 8192 && k >= 4 && mf_cfg != 0) {   // streaming shape, limb products on the matrix cores (mfma_fold.hpp)
         out_per_wg = 64;
         ProfScope ps(c, "multifold", 32.0 * (double)cn + 32.0 * (double)m, stream);
         const unsigned tiles = (unsigned)(m / 64), rot = (unsigned)(mf_cfg % 10);
-        // ZKHIP_MF_OCC = n: at most n workgroups per CU (through the LDS request); 0 = as many as registers allow (2 at <4, 4>)
         static const int mf_occ = [] { const char* e = getenv("ZKHIP_MF_OCC"); return e ? atoi(e) : 0; }();
         size_t q_bytes = mfm_lds_bytes(std::min<uint32_t>(1u << k, (uint32_t)MFM_CHUNK));
         if (mf_occ > 0) q_bytes = std::max(q_bytes, (size_t)(((158 * 1024 / mf_occ) - 1024) & ~255));
         if (q_bytes > 64 * 1024) ZK_TRY(c->allow_big_lds((const void*)multifold_mfma_kernel<4, 4>, 158 * 1024));   // (the kernel has ~0.6 KiB of static LDS on top)
-        switch (mf_cfg / 10) {
-#define ZK_MF_CASE(W, D) case W * 10 + D: hipLaunchKernelGGL((multifold_mfma_kernel<W, D>), dim3(tiles / W), dim3(64 * W), q_bytes, stream, cur, m, k, d_w, dst, pdst, rot); break;
-            ZK_MF_CASE(1, 4) ZK_MF_CASE(2, 4) ZK_MF_CASE(4, 2) ZK_MF_CASE(1, 2)
-            default: hipLaunchKernelGGL((multifold_mfma_kernel<4, 4>), dim3(tiles / 4), dim3(256), q_bytes, stream, cur, m, k, d_w, dst, pdst, rot); break;
-#undef ZK_MF_CASE
-        }
+        hipLaunchKernelGGL((multifold_mfma_kernel<4, 4>), dim3(tiles / 4), dim3(256), q_bytes, stream, cur, m, k, d_w, dst, pdst, rot);
     } else if (m >= 8192) {   // streaming shape: 64 outputs per workgroup, its waves split the terms
         out_per_wg = 64;
         // >= 64 terms per lane: every lane pays one 9-word reduction (~a product), which at 16 terms per lane made the
@@ -631,8 +626,7 @@ static int block_sums_impl(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint
         // total from those.  Without (the deferred form): nothing more here -- the prover derives the coarse sums itself, on the
         // stream of the proof (a high-priority one when the proof is in flight), instead of queueing a tiny kernel on the caller's
         // stream behind whatever streaming pass occupies the chip.
-        static const bool coarse_here = [] { const char* e = getenv("ZKHIP_COARSE_IN_SUMS"); return e && atoi(e) != 0; }();   // diagnostics
-        if (want_total || coarse_here) {
+        if (want_total) {
             const uint32_t k1 = overlapped_plan(n) && log_blocks == log2_exact(n) - 8 ? log_blocks - overlapped_k2(n) : 8;
             int cs = 0;
             ZK_TRY(c->next_coarse(&cs));
@@ -641,7 +635,7 @@ static int block_sums_impl(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint
                 ProfScope ps(c, "coarse_sums", 0.0);
                 hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, c->stream, d_out, 1u << (log_blocks - k1), coarse_mont, coarse_canon);
             }
-            if (want_total) {
+            {
                 ProfScope ps(c, "total_sum", 0.0);
                 hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, coarse_mont, 1u << k1, d_out + 4 * ((size_t)1 << log_blocks), (uint64_t*)nullptr);
             }
