@@ -119,6 +119,10 @@ struct SmallArgs {
     const uint64_t* d_claimed;
     uint64_t* weights_out;  // nullable: 2^n_rounds fold weights eq_b(r) * 2^32 (Montgomery form)
     uint64_t* final_out;    // nullable: the table left after n_rounds folds
+    // The LAST kernel of a proof delivers it: host_delta != 0 is the distance (in u64) from the device span [state .. round polynomials] to
+    // its pinned host mirror -- the rounds of earlier kernels are copied there at entry, this kernel's own outputs are stored twice -- so
+    // no hipMemcpyAsync (8 us with its launch gap) follows the last round.  The host waits for the kernel's completion event.
+    long long host_delta;
 };
 
 constexpr int SMALL_BLOCK = 512;   // 8 waves: the transcript wave, two schedule waves, five waves for the trees and weights
@@ -156,6 +160,12 @@ static __global__ __launch_bounds__(SMALL_BLOCK) void sumcheck_small_kernel(Smal
     Fr* scratch = w0 + w_all + w_all / 2 + 1;           // SMALL_BLOCK entries, only in the grouped mode
     Fr* e_sh = scratch + (grouped ? SMALL_BLOCK : 0);   // 2 x 2: to_mont(level-2 differences) of tree0 / tree1
     Fr* r_sh = e_sh + 4;                                // 2: canonical challenge, double-buffered
+    if (a.host_delta && a.round0) {   // what earlier kernels of this proof recorded: sum, round polynomials and challenges of rounds < round0
+        for (uint32_t i = threadIdx.x; i < 12 * a.round0 + 4; i += SMALL_BLOCK) {
+            const uint64_t* p = i < 4 ? st->sum + i : i < 4 + 8 * a.round0 ? round_polys + (i - 4) : challenges + (i - 4 - 8 * a.round0);
+            *const_cast<uint64_t*>(p + a.host_delta) = *p;
+        }
+    }
     // ---- leaves (sums are taken as they come -- the conversion to canonical integers is linear -- then converted once)
     if (a.group == 0) {
         for (uint32_t j = threadIdx.x; j < n; j += SMALL_BLOCK) {
@@ -341,10 +351,16 @@ static __global__ __launch_bounds__(SMALL_BLOCK) void sumcheck_small_kernel(Smal
                 if (absorb_sum) {
                     Fr sum_m = (a.first == 2) ? fr_from_arg(a.claimed) : (a.first == 3) ? load_fr(a.d_claimed, 0) : lo_m + hi_m;
                     store_fr(st->sum, 0, sum_m);
+                    if (a.host_delta) store_fr(st->sum + a.host_delta, 0, sum_m);
                 }
                 store_fr(round_polys, 2 * (size_t)round, lo_m);
                 store_fr(round_polys, 2 * (size_t)round + 1, hi_m);
                 store_fr(challenges, round, r);
+                if (a.host_delta) {
+                    store_fr(round_polys + a.host_delta, 2 * (size_t)round, lo_m);
+                    store_fr(round_polys + a.host_delta, 2 * (size_t)round + 1, hi_m);
+                    store_fr(challenges + a.host_delta, round, r);
+                }
             }
             const uint32_t nodes = 1u << (depth - 1);   // the new tree has nodes 1 .. 2*nodes - 1
             if (helper >= N_HELPERS - 2 && depth >= 3) {

@@ -710,6 +710,9 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
     uint64_t* d_rp = small + ZK_SMALL_ROUNDPOLYS;
     uint64_t* d_ch = small + ZK_SMALL_CHALLENGES;
     uint64_t* d_fin = small + ZK_SMALL_RES;
+    // the proof leaves through the LAST serial kernel: it writes [sum .. round polynomials] into the pinned slot itself (SmallArgs::host_delta)
+    ZK_TRY(c->ensure_proof_slot(slot));
+    const long long host_delta = ((long long)(intptr_t)c->proof_pin[slot] - (long long)(intptr_t)(small + ZK_SMALL_STATE)) / 8;
 
     FrArg claimed = {};
     uint32_t first = 1;
@@ -773,7 +776,7 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
         ZK_TRY(launch_blockfold(c, tail_stream, tabA, 256, k2, d_w2, d_p2, &ny));       // 2^(8 + k2) entries -> 2^8, the last 8 rounds
         SmallArgs t = {};
         t.src = d_p2; t.group = ny; t.stride = 256; t.canon = 1; t.log_n = 8; t.n_rounds = 8; t.round0 = round; t.first = 0;
-        t.weights_out = nullptr; t.final_out = d_fin;
+        t.weights_out = nullptr; t.final_out = d_fin; t.host_delta = host_delta;
         ZK_TRY(launch_small(c, t, st, d_rp, d_ch, 0, tail_stream));
         done = true;
     }
@@ -810,20 +813,10 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
     if (!done) {
         SmallArgs a = {};
         a.src = cur; a.group = 0; a.log_n = log2_exact(cn); a.n_rounds = a.log_n; a.round0 = round; a.first = first;
-        a.claimed = claimed; a.d_claimed = d_claimed_sum; a.weights_out = nullptr; a.final_out = d_fin;
+        a.claimed = claimed; a.d_claimed = d_claimed_sum; a.weights_out = nullptr; a.final_out = d_fin; a.host_delta = host_delta;
         ZK_TRY(launch_small(c, a, st, d_rp, d_ch, 0, S));
     }
-    // results -> host
-    // one copy of the small-scratch span [state .. round polynomials]: the sum, the challenges and the round
-    // polynomials are a few KiB apart in one allocation, and three small copies cost three launches
-    ZK_TRY(c->ensure_proof_slot(slot));
-    uint64_t* pin = (uint64_t*)c->proof_pin[slot];
-    const uint64_t* span = small + ZK_SMALL_STATE;
-    const size_t span_words = (size_t)(ZK_SMALL_ROUNDPOLYS - ZK_SMALL_STATE) + 8 * (size_t)n_vars;
-    {
-        ProfScope ps(c, "proof_copy", 0.0, tail_stream);
-        ZK_HIP(c, hipMemcpyAsync(pin, span, 8 * span_words, hipMemcpyDeviceToHost, tail_stream));
-    }
+    // results -> host: written by the last kernel into the pinned slot (no copy launch); the collector polls the event behind it
     // the event the collector polls; the caller's stream stays ordered behind the proof (the next call reuses the scratch)
     ZK_HIP(c, hipEventRecord(c->proof_ev[slot], tail_stream));
     // (a proof on a lane of its own is joined to the caller's stream when it is collected, so that the caller's next poly_sum() does not wait for it)
