@@ -60,6 +60,10 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     if (!c) return ZKHIP_ERR_ARG;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    // proofs still in flight write their results into the pinned slots from their lanes' streams: drain every stream of the context first
+    if (c->fold_stream) hipStreamSynchronize(c->fold_stream);
+    for (auto& L : c->lanes) { if (L.serial) hipStreamSynchronize(L.serial); if (L.fold) hipStreamSynchronize(L.fold); }
+    for (int i = 0; i < zkhip_ctx::MSM_SLOTS; ++i) if (c->side[i]) hipStreamSynchronize(c->side[i]);
     for (auto& e : c->prof_events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
     if (c->d_ws) hipFree(c->d_ws);
     if (c->d_aux) hipFree(c->d_aux);
