@@ -122,6 +122,35 @@ def _check_multi(zk, ora, terms, partial):
     return flat, sizes, s, orps
 
 
+@pytest.mark.parametrize("stage", ["0", "1"])
+def test_composed_forms_forced(stage):
+    """Large claims of two-table terms take two rounds per pass by default (csrc/composed_stage.hpp, cross sums on the matrix cores);
+    ZKHIP_STAGE=0 forces the round form (its unreduced K = 2 kernel is otherwise idle), ZKHIP_STAGE=1 the stage form from 2^15 entries on
+    (the VALU cross sums below 2^12 indices per block): both must give the oracle's proof."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys; sys.path.insert(0, %r)
+import numpy as np
+import zk_cryptography_amd as zk
+from oracle import oracle as ora
+for k, log_n in ((2, 21), (2, 16)):
+    t = np.stack([ora.random_fr(1 << log_n, 4000 + 10 * log_n + q) for q in range(k)])
+    proof, ch = zk.ComposedSumcheck(zk.ComposedMultilinear(list(t))).prove()
+    rp, och = ora.composed_prove(t)
+    assert np.array_equal(proof.round_polys, rp) and np.array_equal(ch, och), (k, log_n)
+flat = np.stack([ora.random_fr(1 << 17, 4500 + q) for q in range(4)])
+s = ora.multi_composed_sum(flat, [2, 2])
+terms = [zk.ComposedMultilinear([zk.Multilinear(flat[0]), zk.Multilinear(flat[1])]), zk.ComposedMultilinear([zk.Multilinear(flat[2]), zk.Multilinear(flat[3])])]
+proof, ch = zk.MultiComposedSumcheckProver.prove_partial(terms, s)
+orps, och = ora.multi_composed_prove(flat, [2, 2], s, partial=True)
+assert proof.to_bytes() == ora.multi_composed_proof_bytes(orps) and np.array_equal(ch, och)
+print("forms ok")
+""" % root
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZKHIP_STAGE=stage), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "forms ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
 @pytest.mark.parametrize("case", range(4))
 @pytest.mark.parametrize("partial", [False, True])
 def test_multi_composed_sumcheck_proof(zk, ora, case, partial):   # multi_composed_sumcheck.rs:217-311

@@ -295,18 +295,22 @@ struct ComposedRun {
     }
     // ---- two rounds per pass (composed_stage.hpp): every term a product of two tables, nothing pending, and enough entries that the
     // passes are throughput work (below that the four-lane round kernel and the LDS tail are faster)
-    // Single GPU: measured at 2^22 (tools/perf_composed.py, tools/gkr_run.py) the stage does NOT pay -- its cross sums are 16 products per
-    // index where two fused rounds are 13, and the serial part is the same two transcript rounds: K = 2 0.747 against 0.706 ms,
-    // GKR depth 20 11.8 against 11.4 ms, two terms of two tables 1.149 against 1.186 ms -- so it is off unless ZKHIP_STAGE=1 asks for it.
-    // The sharded sessions use it for every pair of rounds their shard allows: there a stage saves an EXCHANGE (zkhip_mc_stage_*).
+    // Single GPU: a stage is cross sums + ONE serial kernel (two transcript rounds, ~36 us) + a fold by both challenges against two fused
+    // round kernels + two closing kernels (~13 us each).  With the cross sums on the VALU (16 products per index against 13 for two
+    // rounds) it never paid; with them on the matrix cores (composed_cross2_mfma_kernel: 53 us at 2^22 against 113) it pays where the
+    // passes are long: measured per stage / per two rounds (tools/prof_composed_k2.py, one term) 156 / 195 us at 2^22, 88 / 81 at 2^20,
+    // 62 / 46 at 2^18; claims of several terms (no unreduced wide kernel in their round form) gain from 2^18 on.  ZKHIP_STAGE=0 / 1
+    // forces it off / on from 2^15 (measurements); the sharded sessions use it wherever their shard allows: there it saves an EXCHANGE.
     bool stage_possible(size_t min_n) const {
         if (pending || cn < min_n || cn < 4 || n_rounds - round < 2) return false;
         for (uint32_t p = 0; p < n_terms; ++p) if (term_sizes[p] != 2) return false;
         return true;
     }
     bool stage_ok() const {
-        static const bool on = [] { const char* e = std::getenv("ZKHIP_STAGE"); return e && std::atoi(e) != 0; }();
-        return on && stage_possible((size_t)1 << 15);
+        static const int mode = [] { const char* e = std::getenv("ZKHIP_STAGE"); return e ? std::atoi(e) : -1; }();
+        if (mode == 0) return false;
+        if (mode == 1) return stage_possible((size_t)1 << 15);
+        return stage_possible(n_terms >= 2 ? (size_t)1 << 18 : (size_t)1 << 21);
     }
     MultiTablePtrs stage_tables() const {
         MultiTablePtrs mp = {};
@@ -323,8 +327,18 @@ struct ComposedRun {
     // first part: the cross-block sums, one record of n_terms * CST_VALS values per workgroup in d_partials
     int stage_sums(int* n_records) {
         const size_t m = cn / 4;
-        const int grid = (int)std::min<size_t>(CST_MAX_GRID, std::max<size_t>(1, m / 256));
         ProfScope ps(c, "composed_cross2", 0.0);
+        static const bool no_mfma = [] { const char* e = std::getenv("ZKHIP_CROSS_VALU"); return e && std::atoi(e) != 0; }();   // diagnostics: A/B
+        if (!no_mfma && m >= 1024 && m <= (size_t)256 * 65536) {
+            // byte outer products on the matrix cores: >= 128 indices and <= 65536 per workgroup (int32 accumulators)
+            // up to four workgroups per CU (42 KiB of LDS each), as many records as the scratch holds
+            const size_t cap = std::min<size_t>(512, (size_t)(8 * ZK_MAX_PARTIALS) / ((size_t)CST_VALS * n_terms));
+            const int grid = (int)std::max<size_t>(std::min<size_t>(cap, m / 128), (m + 65535) / 65536);
+            hipLaunchKernelGGL(composed_cross2_mfma_kernel, dim3(grid, n_terms), dim3(256), 0, c->stream, stage_tables(), cn, n_terms, d_partials);
+            *n_records = grid;
+            return ZKHIP_OK;
+        }
+        const int grid = (int)std::min<size_t>(CST_MAX_GRID, std::max<size_t>(1, m / 256));
         hipLaunchKernelGGL(composed_cross2_kernel, dim3(grid, n_terms), dim3(CST_CROSS_BLOCK), 0, c->stream, stage_tables(), cn, n_terms, d_partials);
         *n_records = grid;
         return ZKHIP_OK;

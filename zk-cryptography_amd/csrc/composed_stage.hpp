@@ -17,6 +17,7 @@
 // kernels; a sharded proof exchanges one record per two rounds.
 #pragma once
 #include "composed_kernels.hpp"
+#include "mfma_fold.hpp"
 
 namespace zk {
 
@@ -80,6 +81,168 @@ static __global__ __launch_bounds__(CST_CROSS_BLOCK) void composed_cross2_kernel
     }
 }
 
+// ---- the cross-block sums on the matrix cores ---------------------------------------------------------------------------------
+// C[a][b] = sum_j A[a][j] * B[b][j] is data x data -- no fixed operand to lay out as a Toeplitz matrix (mfma_fold.hpp) -- but byte by
+// byte it is an outer product accumulated over j:  G[d][i] = sum_j A[a][j].byte[d] * B[b][j].byte[i]  (32 x 32), a GEMM whose
+// contraction index is j, and C[a][b] = sum_c 2^(8c) sum_{d+i=c} G[d][i].  The MFMA wants, per lane, 16 consecutive K of one row:
+// byte d of 16 consecutive entries, i.e. the table TRANSPOSED -- which gfx950 does on the way out of LDS: ds_read_b64_tr_b8 reads, per
+// 16 lanes, 8 rows of 16 bytes (row p at the addresses of lanes 2p and 2p + 1) and hands lane c column c (tools/probe_tr_b8.hip).  A
+// tile of 32 entries staged in LDS as it lies in memory therefore yields the operand with two such reads per lane.
+// One workgroup = 4 waves; wave a multiplies block a of the first table with the four blocks of the second: per step of 32 indices
+// 8 KiB staged, 10 transposed reads and 4 MFMAs per wave.  Bytes are fed as u ^ 0x80 = u - 128 (int8 is signed); the true unsigned sums
+// follow from the per-position byte sums (v_sad_u8):  sum ua ub = G + 128 UA[d] + 128 UB[i] - 16384 J.  At most 65536 indices per
+// workgroup: |G| <= 2^30 and the true sums fit 32 bits.
+constexpr int CSM_STEP = 32;           // indices per step = K of one MFMA
+constexpr int CSM_TILE = 1024;         // bytes of one staged tile (32 entries)
+
+// the five operands of a wave's step in one go -- block a of the first table, the four blocks of the second -- so that the ten
+// transposed reads are in flight together (one wait instead of five LDS round trips per step)
+typedef uint32_t csm_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void csm_operands(const unsigned char* buf, uint32_t wave, uint32_t lane, mf_v4i& xa, mf_v4i (&yb)[4]) {
+    // lane (g = lane / 16, i = lane % 16): byte 16 (g % 2) + i of entries 16 (g / 2) .. + 15 of a tile
+    const uint32_t g = lane >> 4, i = lane & 15;
+    const uint32_t in_tile = 32 * (16 * (g >> 1) + (i >> 1)) + 16 * (g & 1) + 8 * (i & 1);
+    const uint32_t a0 = (uint32_t)(uintptr_t)(buf + wave * CSM_TILE + in_tile);
+    const uint32_t b0 = (uint32_t)(uintptr_t)(buf + 4 * CSM_TILE + in_tile);
+    csm_u32x2 r[10];
+    asm volatile(
+        "ds_read_b64_tr_b8 %0, %10\n\tds_read_b64_tr_b8 %1, %10 offset:256\n\t"
+        "ds_read_b64_tr_b8 %2, %11\n\tds_read_b64_tr_b8 %3, %11 offset:256\n\t"
+        "ds_read_b64_tr_b8 %4, %11 offset:1024\n\tds_read_b64_tr_b8 %5, %11 offset:1280\n\t"
+        "ds_read_b64_tr_b8 %6, %11 offset:2048\n\tds_read_b64_tr_b8 %7, %11 offset:2304\n\t"
+        "ds_read_b64_tr_b8 %8, %11 offset:3072\n\tds_read_b64_tr_b8 %9, %11 offset:3328\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]), "=&v"(r[9])
+        : "v"(a0), "v"(b0)
+        : "memory");
+    xa.x = (int)r[0].x; xa.y = (int)r[0].y; xa.z = (int)r[1].x; xa.w = (int)r[1].y;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { yb[b].x = (int)r[2 + 2 * b].x; yb[b].y = (int)r[2 + 2 * b].y; yb[b].z = (int)r[3 + 2 * b].x; yb[b].w = (int)r[3 + 2 * b].y; }
+}
+__device__ __forceinline__ uint32_t csm_bytesum(const mf_v4i& o, uint32_t acc) {
+    acc = __builtin_amdgcn_sad_u8((uint32_t)o.x, 0u, acc);
+    acc = __builtin_amdgcn_sad_u8((uint32_t)o.y, 0u, acc);
+    acc = __builtin_amdgcn_sad_u8((uint32_t)o.z, 0u, acc);
+    return __builtin_amdgcn_sad_u8((uint32_t)o.w, 0u, acc);
+}
+static __global__ __launch_bounds__(256) void composed_cross2_mfma_kernel(MultiTablePtrs mp, size_t n, uint32_t n_terms,
+                                                                          uint64_t* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) unsigned char tiles[2][8 * CSM_TILE];      // double-buffered: A0..A3, B0..B3
+    __shared__ uint32_t tmat[4][32 * 33];         // per wave: the true byte-product sums of one (a, b), [d][i] padded
+    __shared__ uint32_t ua_sh[4][32], ub_sh[4][4][32];
+    __shared__ unsigned long long cols[4][4][64]; // per wave and b: the 63 anti-diagonal sums
+    __shared__ Fr red[4][4];
+    __shared__ Fr lred[4][4];
+    const uint32_t term = blockIdx.y;
+    const TablePtrs& tp = mp.t[term];
+    const size_t m = n / 4;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t per = ((m + gridDim.x - 1) / gridDim.x + CSM_STEP - 1) / CSM_STEP * CSM_STEP;     // a multiple of the step
+    const size_t j0 = (size_t)blockIdx.x * per, j1 = j0 + per < m ? j0 + per : m;                  // m is a multiple of 32 (host)
+    const uint32_t n_steps = j0 < j1 ? (uint32_t)((j1 - j0) / CSM_STEP) : 0;
+    // this thread's two 16-byte chunks of a step's 8 KiB: chunk q = tid + 256 u -> tile q / 64, bytes 16 (q % 64) of it
+    const unsigned char* src[2];
+    uint32_t dst[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t q = tid + 256 * u, tile = q >> 6, off = 16 * (q & 63);
+        const uint64_t* base = tile < 4 ? tp.in[0] + 4 * ((size_t)tile * m) : tp.in[1] + 4 * ((size_t)(tile - 4) * m);
+        src[u] = reinterpret_cast<const unsigned char*>(base) + 32 * j0 + off;
+        dst[u] = tile * CSM_TILE + off;
+    }
+    mf_v16i acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = mf_v16i{0};
+    uint32_t ua = 0, ub[4] = {0, 0, 0, 0};
+    mf_v4i ld[2];
+    if (n_steps) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ld[u] = mfm_load_nt(src[u]);
+    }
+    for (uint32_t s = 0; s < n_steps; ++s) {
+        unsigned char* buf = tiles[s & 1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<mf_v4i*>(buf + dst[u]) = ld[u];
+        if (s + 1 < n_steps) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) ld[u] = mfm_load_nt(src[u] + (size_t)(s + 1) * (32 * CSM_STEP));
+        }
+        __syncthreads();                     // the step's tiles are staged (the other buffer is free again: its readers passed this barrier)
+        mf_v4i xa, yb[4];
+        csm_operands(buf, wave, lane, xa, yb);
+        ua = csm_bytesum(xa, ua);
+        const mf_v4i xs = mfm_signed(xa);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            ub[b] = csm_bytesum(yb[b], ub[b]);
+            acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xs, mfm_signed(yb[b]), acc[b], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // ---- epilogue: per wave, the four (a = wave, b) sums as field elements
+    const uint32_t col_i = lane & 31, hh = lane >> 5;
+    const uint32_t jcount = (uint32_t)(j0 < j1 ? j1 - j0 : 0);
+    {   // byte sums of both lane halves, by byte position
+        const uint32_t ua_t = ua + (uint32_t)__shfl_xor((int)ua, 32, 64);
+        if (lane < 32) ua_sh[wave][lane] = ua_t;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t t = ub[b] + (uint32_t)__shfl_xor((int)ub[b], 32, 64);
+            if (lane < 32) ub_sh[wave][b][lane] = t;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        // result register r = 4 q + t of lane (i, h): row d = 8 q + 4 h + t, column i
+        const uint32_t ubi = ub_sh[wave][b][col_i];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t d = 8 * (r >> 2) + 4 * hh + (r & 3);
+            tmat[wave][d * 33 + col_i] = (uint32_t)acc[b][r] + 128u * (ua_sh[wave][d] + ubi) - 16384u * jcount;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 63) {                     // anti-diagonal c = lane
+            unsigned long long sacc = 0;
+            const int lo = (int)lane - 31 < 0 ? 0 : (int)lane - 31, hi = lane < 31 ? (int)lane : 31;
+            for (int d = lo; d <= hi; ++d) sacc += tmat[wave][d * 33 + (lane - d)];
+            cols[wave][b][lane] = sacc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < 4) {                          // lane b: columns -> 17 limbs -> REDC -> back to the product's residue
+        uint32_t x[18];
+        unsigned long long carry = 0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            unsigned long long v = carry;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = 4 * g + t;
+                if (c < 63) v += cols[wave][lane][c] << (8 * t);     // cols < 2^37: no overflow
+            }
+            x[g] = (uint32_t)v;
+            carry = v >> 32;
+        }
+        x[16] = (uint32_t)carry;
+        x[17] = 0;
+        red[wave][lane] = wide_redc(x) * fr_mont_2_32();
+    }
+    // the additive table's block sums (plain additions)
+    if (tp.lin_in) {
+        Fr ls = Fr::zero();
+        const uint64_t* pl = tp.lin_in + 4 * ((size_t)wave * m);       // wave a sums block a
+        for (size_t j = j0 + lane; j < j1; j += 64) ls = ls + load_fr(pl, j);
+        ls = wave_reduce_fr(ls);
+        if (lane == 0) lred[wave][0] = ls;
+    }
+    __syncthreads();
+    if (tid < 16) store_fr(partials, ((size_t)blockIdx.x * n_terms + term) * CST_VALS + tid, red[tid >> 2][tid & 3]);
+    else if (tid < 20) store_fr(partials, ((size_t)blockIdx.x * n_terms + term) * CST_VALS + tid, tp.lin_in ? lred[tid - 16][0] : Fr::zero());
+}
+
 struct StageArgs {
     CloseArgs ca;                 // ca.round = the first of the two rounds
     uint32_t n_records;
@@ -93,21 +256,32 @@ static __global__ __launch_bounds__(CST_BLOCK) void composed_stage_close_kernel(
     __shared__ Fr bound[CMP_MAX_TERMS][6];       // C'[x][y] at 2 x + y, then L'[0], L'[1]
     __shared__ Fr r1m;
     const CloseArgs& ca = sa.ca;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x;
     const uint32_t P = ca.meta.n_terms, n_vals = P * CST_VALS;
     if (ca.first != 1 && tid < sizeof(Sha256State) / 4)
         reinterpret_cast<uint32_t*>(&trs)[tid] = reinterpret_cast<const uint32_t*>(&ca.st->transcript)[tid];
     close_preload(sh, ca.meta, ca.st);
-    for (uint32_t v = wave; v < n_vals; v += CST_BLOCK / 64) {
-        Fr s = Fr::zero();
-        for (uint32_t rdx = lane; rdx < sa.n_records; rdx += 256) {
-            Fr x[4];
+    {
+        // thread (value v = tid % n_vals, chunk = tid / n_vals) sums the records chunk, chunk + n_chunks, ...: neighbouring threads read
+        // neighbouring values of one record (coalesced), eight loads in flight per thread; the chunks are added in LDS
+        __shared__ Fr rsum[CST_BLOCK];
+        const uint32_t n_chunks = CST_BLOCK / n_vals, v = tid % n_vals, chunk = tid / n_vals;
+        Fr acc = Fr::zero();
+        if (chunk < n_chunks) {
+            for (uint32_t r0 = chunk; r0 < sa.n_records; r0 += 8 * n_chunks) {
+                Fr x[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = rdx + 64 * u < sa.n_records ? load_fr(partials, (size_t)(rdx + 64 * u) * n_vals + v) : Fr::zero();
-            s = s + ((x[0] + x[1]) + (x[2] + x[3]));
+                for (int u = 0; u < 8; ++u) x[u] = r0 + u * n_chunks < sa.n_records ? load_fr(partials, (size_t)(r0 + u * n_chunks) * n_vals + v) : Fr::zero();
+                acc = acc + (((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7])));
+            }
         }
-        s = wave_reduce_fr(s);
-        if (lane == 0) vals[v / CST_VALS][v % CST_VALS] = s;
+        rsum[tid] = acc;
+        __syncthreads();
+        if (tid < n_vals) {
+            Fr t = rsum[tid];
+            for (uint32_t q = 1; q < n_chunks; ++q) t = t + rsum[q * n_vals + tid];
+            vals[tid / CST_VALS][tid % CST_VALS] = t;
+        }
     }
     __syncthreads();
     // ---- round 1: p(0), p(1), p(2) of every term from C and L
