@@ -154,18 +154,26 @@ static __global__ __launch_bounds__(256) void composed_cross2_mfma_kernel(MultiT
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = mf_v16i{0};
     uint32_t ua = 0, ub[4] = {0, 0, 0, 0};
-    mf_v4i ld[2];
-    if (n_steps) {
+    // loads run CSM_AHEAD steps ahead of the MFMAs (one step ahead left every step waiting for memory: 16 steps of a 2^20 claim took 16 us)
+    constexpr int CSM_AHEAD = 4;
+    mf_v4i ld[CSM_AHEAD][2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) ld[u] = mfm_load_nt(src[u]);
-    }
-    for (uint32_t s = 0; s < n_steps; ++s) {
+    for (int q = 0; q < CSM_AHEAD; ++q)
+        if ((uint32_t)q < n_steps) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) ld[q][u] = mfm_load_nt(src[u] + (size_t)q * (32 * CSM_STEP));
+        }
+    for (uint32_t s0 = 0; s0 < n_steps; s0 += CSM_AHEAD) {
+#pragma unroll
+      for (int q = 0; q < CSM_AHEAD; ++q) {
+        const uint32_t s = s0 + q;
+        if (s >= n_steps) break;
         unsigned char* buf = tiles[s & 1];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) *reinterpret_cast<mf_v4i*>(buf + dst[u]) = ld[u];
-        if (s + 1 < n_steps) {
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<mf_v4i*>(buf + dst[u]) = ld[q][u];
+        if (s + CSM_AHEAD < n_steps) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) ld[u] = mfm_load_nt(src[u] + (size_t)(s + 1) * (32 * CSM_STEP));
+            for (int u = 0; u < 2; ++u) ld[q][u] = mfm_load_nt(src[u] + (size_t)(s + CSM_AHEAD) * (32 * CSM_STEP));
         }
         __syncthreads();                     // the step's tiles are staged (the other buffer is free again: its readers passed this barrier)
         mf_v4i xa, yb[4];
@@ -177,6 +185,7 @@ static __global__ __launch_bounds__(256) void composed_cross2_mfma_kernel(MultiT
             ub[b] = csm_bytesum(yb[b], ub[b]);
             acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xs, mfm_signed(yb[b]), acc[b], 0, 0, 0);
         }
+      }
     }
     __syncthreads();
     // ---- epilogue: per wave, the four (a = wave, b) sums as field elements
