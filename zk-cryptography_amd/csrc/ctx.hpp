@@ -68,11 +68,23 @@ struct zkhip_ctx {
     void* msm_pin[MSM_SLOTS] = {};
     size_t msm_pin_bytes[MSM_SLOTS] = {};
     hipEvent_t msm_ev[MSM_SLOTS] = {};
+    hipEvent_t msm_front[MSM_SLOTS] = {};                                        // the front of a commit (sort, bucket order) is through
+    int ensure_msm_slot_events(int slot) {
+        if (!msm_front[slot] && hipEventCreateWithFlags(&msm_front[slot], hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
+        return ZKHIP_OK;
+    }
     hipStream_t side[MSM_SLOTS] = {};
     hipEvent_t fork_ev = nullptr, join_ev = nullptr, serial_ev = nullptr;
+    // low-priority twins of side[0] and side[1]: the throughput-bound batched commits of MultilinearKZG::open run there, so that the
+    // latency-bound passes beside them (the small batch, the heavy-bucket passes) get their few workgroups placed as soon as a slot frees up
+    hipStream_t side_low[2] = {};
     int ensure_side_streams() {
         for (int i = 0; i < MSM_SLOTS; ++i)
             if (!side[i] && hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) return ZKHIP_ERR_HIP;
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return ZKHIP_ERR_HIP;
+        for (int i = 0; i < 2; ++i)
+            if (!side_low[i] && hipStreamCreateWithPriority(&side_low[i], hipStreamNonBlocking, least) != hipSuccess) return ZKHIP_ERR_HIP;
         if (!fork_ev && hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
         if (!join_ev && hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
         if (!serial_ev && hipEventCreateWithFlags(&serial_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;

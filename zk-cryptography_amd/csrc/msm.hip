@@ -29,7 +29,17 @@ static MsmPlan msm_plan(size_t n, uint32_t n_problems = 1) {
     // as soon as the bucket reduction is not the larger cost (measured with tools/perf_msm.py, ZKHIP_MSM_C sweep:
     // c = 16 wins from 2^13 points on; below that every c ends at the ~1 ms latency floor of the reduction passes).
     uint32_t c = lg >= 13 ? 16 : lg >= 10 ? 12 : 8;
-    if (n_problems > 1) c = lg >= 11 ? 10 : 8;   // batched: windows x problems x partitions must stay within the sort's 2048 partitions
+    if (n_problems > 1) {
+        // Batched: one pass of every kernel for all problems, so the chip is full and the window is chosen for the WORK (additions per point
+        // plus buckets to reduce), not for the latency floor; windows x problems x partitions must stay within the sort's partitions.
+        c = lg >= 15 ? std::min<uint32_t>(14, lg - 5) : lg >= 11 ? 10 : 8;   // lists of ~64 points for the largest problem (one lane per bucket: the pass takes as long as its longest lists)
+        if (const char* e = std::getenv("ZKHIP_MSM_BATCH_C")) {   // tuning aid (tools/perf_open.py): the wide batch only
+            const int v = std::atoi(e);
+            if (lg >= 15 && v >= 8 && v <= 16) c = (uint32_t)v;
+        }
+        auto parts = [&](uint32_t cc) { return (uint64_t)((256 + cc - 1) / cc) * n_problems * ((1u << (cc - 1)) >> std::min<uint32_t>(cc - 1, 8)); };
+        while (c > 8 && parts(c) > (uint64_t)SORT_MAX_PARTS) --c;
+    }
     if (const char* e = std::getenv("ZKHIP_MSM_C")) {   // tuning aid (tools/perf_msm.py); any 4 <= c <= 16 is correct
         const int v = std::atoi(e);
         if (v >= 4 && v <= 16) c = (uint32_t)v;
@@ -44,7 +54,8 @@ static MsmPlan msm_plan(size_t n, uint32_t n_problems = 1) {
     pl.n_terms = 1 + pl.n_bits;
     pl.sub_bits = (c - 1) < 8 ? (c - 1) : 8;
     pl.parts_pw = pl.nb >> pl.sub_bits;
-    pl.n_parts = pl.n_windows * pl.parts_pw;     // c = 16: 16 * 128 = 2048; small c: n_windows <= 64
+    pl.part_bits = c - 1 - pl.sub_bits;
+    pl.n_parts = pl.n_windows * pl.parts_pw;     // c = 16: 16 * 128 = 2048
     return pl;
 }
 
@@ -68,6 +79,7 @@ static MsmPlan msm_plan_table(size_t stride) {
     pl.n_terms = 1 + pl.n_bits;
     pl.sub_bits = 8;
     pl.parts_pw = pl.nb >> pl.sub_bits;            // 2048
+    pl.part_bits = pl.c - 1 - pl.sub_bits;
     pl.n_parts = pl.parts_pw;
     return pl;
 }
@@ -86,7 +98,7 @@ struct MsmPending {
 };
 static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, const uint64_t* d_scalars, size_t n,
                        const MsmProblems& pr, const uint32_t* d_table, size_t table_stride, size_t ws_off, int slot, MsmPending* pend,
-                       size_t* ws_used) {
+                       size_t* ws_used, int phases = 3) {
     size_t max_n = 0;
     for (uint32_t j = 0; j < pr.n; ++j) max_n = std::max<size_t>(max_n, pr.off[j + 1] - pr.off[j]);
     const MsmPlan pl = d_table ? msm_plan_table(table_stride) : msm_plan(max_n, pr.n);
@@ -111,7 +123,7 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     const size_t o_sega = o_segs + al(n_segments * 256);
     const size_t o_terms = o_sega + al(n_segments * 256);
     // heavy buckets (msm_kernels.hpp pass 4b/4c): more than heavy_min points, so at most n W / heavy_min of them;
-    // a bucket of k points files ceil(k / 8192) level-0 records and, above one record, a <= 256-way tree over them
+    // a bucket of k points files ceil(k / MSM_HEAVY_REC) level-0 records and, above one record, a <= 256-way tree over them
     const uint32_t heavy_min = (uint32_t)std::max<size_t>(32, 4 * ((max_n * (pl.shared ? pl.w_per : 1) + pl.nb - 1) / pl.nb));
     const size_t items_max = n * pl.w_per;
     const size_t rec_cap = items_max / heavy_min + items_max / MSM_HEAVY_REC + 2;
@@ -149,6 +161,10 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
 
     if (pl.n_parts > (uint32_t)SORT_MAX_PARTS) return ZKHIP_ERR_SHAPE;
     const int grid_n = (int)std::min<size_t>((n + MSM_BLOCK - 1) / MSM_BLOCK, 256 * 8);
+    // phases (a caller with several commits beside each other, MultilinearKZG::open): 1 = the FRONT, everything up to the bucket order --
+    // many short kernels, which crawl when another commit's accumulate pass fills the chip (a one-workgroup scan took 250 us there) --
+    // 2 = the BACK from the accumulate pass on; the caller lines the fronts of all its commits up before the first back
+    if (phases & 1) {
     if (!d_table) {
         ProfScope ps(c, "msm_convert_points", 224.0 * (double)n);
         hipLaunchKernelGGL(msm_convert_points_kernel, dim3(grid_n), dim3(MSM_BLOCK), 0, c->stream, d_points_xy, n, (uint32_t*)(ws + o_points));
@@ -163,27 +179,35 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
                            wg_counts, part_off, items);
         hipLaunchKernelGGL(msm_sort_local_kernel, dim3(pl.n_parts), dim3(SORT_LOCAL_BLOCK), 0, c->stream, items, part_off, pl, sorted, counts, offsets);
     }
-    {   // bucket order by descending point count
-        ProfScope ps(c, "msm_order", 0.0);
-        const unsigned gb = (unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK);
-        ZK_HIP(c, hipMemsetAsync(bins, 0, MSM_COUNT_BINS * 4, c->stream));
-        ZK_HIP(c, hipMemsetAsync(ovf, 0, sizeof(MsmOverflow), c->stream));
-        hipLaunchKernelGGL(msm_order_hist_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins);
-        hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bins);
-        hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins, order);
-    }
     {
-        ProfScope ps(c, "msm_accumulate", 128.0 * (double)n);
-        hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK)), dim3(MSM_BLOCK), 0,
-                           c->stream, points_u, sorted, offsets, counts, order, (uint32_t)n_buckets, heavy_min, ovf, rec, (uint32_t)rec_cap, buckets);
-    }
-    {   // heavy buckets (none with uniform scalars: four empty launches)
+        // heavy buckets (none with uniform scalars and a full top window: five empty launches): filed by a pass of their own and summed by
+        // passes 4b / 4c IN FRONT of the accumulate pass.  Behind it they were ~0.8 ms of a batched commit of MultilinearKZG::open (whose
+        // sparse top windows put 1/2^k of all points into each of a few buckets); on a second stream beside it they did not find a free
+        // slot for most of its duration -- its first workgroups walk the longest lists and hold every register of the chip.
         ProfScope ps(c, "msm_overflow", 0.0);
+        ZK_HIP(c, hipMemsetAsync(ovf, 0, sizeof(MsmOverflow), c->stream));
+        hipLaunchKernelGGL(msm_file_heavy_kernel, dim3((unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK)), dim3(MSM_BLOCK), 0, c->stream, offsets, counts,
+                           (uint32_t)n_buckets, heavy_min, ovf, rec, (uint32_t)rec_cap);
         hipLaunchKernelGGL(msm_heavy_points_kernel, dim3(512) /* 64 KiB of LDS each: two per CU are resident, the records are walked in a loop */, dim3(MSM_BLOCK), MSM_BLOCK * 256, c->stream, points_u, sorted, ovf, rec,
                            partials, buckets);
         for (int level = 1; level < MSM_HEAVY_LEVELS; ++level)
             hipLaunchKernelGGL(msm_heavy_tree_kernel, dim3(level == 1 ? 256 : 16), dim3(MSM_BLOCK), MSM_BLOCK * 256, c->stream, ovf,
                                (uint32_t)level, rec + (size_t)level * rec_cap, partials, buckets);
+    }
+    {   // bucket order by descending point count
+        ProfScope ps(c, "msm_order", 0.0);
+        const unsigned gb = (unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK);
+        ZK_HIP(c, hipMemsetAsync(bins, 0, MSM_COUNT_BINS * 4, c->stream));
+        hipLaunchKernelGGL(msm_order_hist_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins);
+        hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bins);
+        hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins, order);
+    }
+    }   // front
+    if (!(phases & 2)) return ZKHIP_OK;
+    {
+        ProfScope ps(c, "msm_accumulate", 128.0 * (double)n);
+        hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK)), dim3(MSM_BLOCK), 0,
+                           c->stream, points_u, sorted, offsets, counts, order, (uint32_t)n_buckets, heavy_min, buckets);
     }
     {
         ProfScope ps(c, "msm_segment", 0.0);
@@ -233,7 +257,7 @@ static int msm_finish(zkhip_ctx* c, const MsmPending& pend, uint64_t* h_out_xy, 
         h_out_inf[j] = zkhost::xyzz_to_affine(res, h_out_xy + 12 * (size_t)j) ? 0 : 1;
     };
     // the chains of different problems are independent (~0.25 ms each): a batch spreads them over host threads
-    const uint32_t n_threads = std::min<uint32_t>(std::min<uint32_t>(pr.n, 8u), std::max(1u, std::thread::hardware_concurrency()));
+    const uint32_t n_threads = std::min<uint32_t>(std::min<uint32_t>(pr.n, 32u), std::max(1u, std::thread::hardware_concurrency()));
     if (n_threads <= 1) {
         for (uint32_t j = 0; j < pr.n; ++j) finish(j);
     } else {
@@ -486,51 +510,78 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
         d_folded_inf = (const uint8_t*)(aux + o_finf);
     }
     uint64_t* d_q = (uint64_t*)(aux + o_q);
-    // All quotients first (a chain of n_vars small kernels on the caller's stream; none of them depends on a commit).
-    // Then the commits: rounds with more than OPEN_BATCH_MAX quotient entries one by one, the remaining (<= 15) small rounds,
-    // each far below the size at which a commit stops being latency bound, in one batched commit -- every one of them on
-    // its own side stream, workspace region and pinned result slot.  A commit is a throughput-bound accumulate pass followed
-    // by latency-bound reduction passes that leave the chip mostly idle; next to each other, the reductions of one round
-    // hide behind the accumulate pass of the next, and the host epilogues (~0.25 ms of serial point arithmetic each) behind both.
-    size_t OPEN_BATCH_MAX = (size_t)1 << 14;   // measured with the rounds on side streams (2^20 / 2^22 open): 2^12 9.9 / 20.0 ms, 2^13 10.4 / 19.1, 2^14 8.1 / 19.6, 2^15 9.5 / 20.2, 2^16 10.0 / 19.5, 2^17 13.1 / 23.2
+    // All quotients first (a chain of n_vars small kernels on the caller's stream; none of them depends on a commit).  Then the commits,
+    // beside each other on side streams (workspace regions and pinned result slots of their own), in three groups by quotient length h:
+    //   h > 2^19          one commit each, two in flight (a commit of that size fills the chip by itself);
+    //   2^17 < h <= 2^19  ONE batched commit with 14-bit windows, and
+    //   2^13 < h <= 2^17  one with 12-bit windows: every pass of a batch runs once for all its problems, so each pass fills the chip and
+    //                     the bucket reduction (latency bound, ~0.6 ms whatever the size) is paid once per batch, not per round.  The
+    //                     window gives the largest problem of a batch lists of 64 points: the accumulate pass (one lane per bucket) takes
+    //                     as long as its longest lists (13-bit windows for all six rounds: 10 ms instead of 6.9), while every further
+    //                     bit doubles the buckets the reduction passes walk -- hence two batches, not one;
+    //   h <= 2^13         one batched commit with 10-bit windows.
+    // (Rounds 1-3 ran every round above 2^14 as a commit pipeline of its own, five beside each other: each paid the full reduction of 2^19
+    // buckets, and on three hardware queues every kernel ran at 2-3 x its stand-alone duration -- 8.5-9.2 ms at 2^20 against 3.2 ms for
+    // ONE commit of as many points; profiles/r03/open_last_call_trace.txt.  ZKHIP_OPEN_PIPELINES=1 restores that form for an A/B.)
+    const bool pipelines = [] { const char* e = std::getenv("ZKHIP_OPEN_PIPELINES"); return e && e[0] == '1'; }();
+    size_t OPEN_BATCH_MAX = pipelines ? (size_t)1 << 14 : (size_t)1 << 13;   // pipelines, measured (2^20 / 2^22 open): 2^12 9.9 / 20.0 ms, 2^13 10.4 / 19.1, 2^14 8.1 / 19.6, 2^15 9.5 / 20.2, 2^16 10.0 / 19.5, 2^17 13.1 / 23.2
     if (const char* e = std::getenv("ZKHIP_OPEN_BATCH_LOG")) {   // tuning aid (tools/perf_open.py)
         const int v = std::atoi(e);
         if (v >= 8 && v <= 20) OPEN_BATCH_MAX = (size_t)1 << v;
     }
-    int NSLOT = zkhip_ctx::MSM_SLOTS - 1;  // large rounds in flight; the last slot is the batch's
-    if (const char* e = std::getenv("ZKHIP_OPEN_SLOTS")) {   // tuning aid (tools/perf_open.py): fewer pipelines beside each other
+    const size_t OPEN_WIDE_MAX = pipelines ? 0 : (size_t)1 << 19;
+    size_t OPEN_MID_MAX = (size_t)1 << 17;
+    if (const char* e = std::getenv("ZKHIP_OPEN_MID_LOG")) {     // tuning aid: where the two wide batches are cut (>= 19: one batch)
         const int v = std::atoi(e);
-        if (v >= 1 && v <= zkhip_ctx::MSM_SLOTS - 1) NSLOT = v;
+        if (v >= 13 && v <= 20) OPEN_MID_MAX = (size_t)1 << v;
     }
+    // result slot / stream of every group member: single commits rotate over `single_slots`
+    const int single_slots_pipe[5] = {0, 1, 2, 3, 4}, single_slots_grp[2] = {3, 4};
+    const int* single_slots = pipelines ? single_slots_pipe : single_slots_grp;
+    int NSLOT = pipelines ? 5 : 2;
+    if (const char* e = std::getenv("ZKHIP_OPEN_SLOTS")) {   // tuning aid (tools/perf_open.py): fewer single commits beside each other
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= NSLOT) NSLOT = v;
+    }
+    // the small batch runs on the caller's stream, idle meanwhile (HIP streams share a few hardware queues -- three beside the caller's
+    // stream's on this runtime, streams {0, 5}, {1, 4}, {2, 3} of ctx.side pairwise -- and a queue runs its kernels in order)
+    const int sl_wide = 1, sl_mid = 0, sl_small = zkhip_ctx::MSM_SLOTS - 1;
     const uint64_t* cur = d_evals;
     size_t cn = n, lvl_off = 0;
-    MsmProblems batch = {};
-    size_t batch_first_off = 0;
-    uint32_t batch_first_round = 0;
+    struct Group { MsmProblems pr = {}; size_t first_off = 0, total = 0; uint32_t first_round = 0; };
+    Group wide, mid, small;
     struct Large { uint32_t round; size_t off, h; };
     std::vector<Large> large;
+    ZK_TRY(c->ensure_side_streams());
+    // a batch may start as soon as ITS quotients are written (the two of the wide batch after the first two of the n_vars steps)
+    hipEvent_t const wide_ready = c->join_ev, mid_ready = c->serial_ev;
+    auto group_of = [&](size_t h) { return h > OPEN_BATCH_MAX && h > OPEN_WIDE_MAX ? 0 : h <= OPEN_BATCH_MAX ? 3 : h <= OPEN_MID_MAX ? 2 : 1; };
     for (uint32_t i = 0; i < n_vars; ++i) {
         FrArg z = {};
         std::memcpy(z.v, h_points + 4 * (size_t)i, 32);
         uint64_t* rem = (uint64_t*)(aux + ((i & 1) ? o_pong : o_ping));
         hipLaunchKernelGGL(open_step_kernel, dim3(mle_grid_stream(cn / 2)), dim3(MLE_BLOCK), 0, c->stream, cur, cn, z, d_q + 4 * lvl_off, rem);
         const size_t h = cn / 2;   // |q_i| = |S_i|
-        if (h > OPEN_BATCH_MAX) {
+        const int grp = group_of(h);
+        if (grp == 0) {
             large.push_back({i, lvl_off, h});
-        } else {
-            if (batch.n == 0) { batch_first_off = lvl_off; batch_first_round = i; }
-            batch.off[batch.n] = (uint32_t)(lvl_off - batch_first_off);
-            batch.off[++batch.n] = (uint32_t)(lvl_off + h - batch_first_off);
+        } else {                   // the rounds of a group follow each other, so its problems lie end to end
+            Group& g = grp == 3 ? small : grp == 2 ? mid : wide;
+            if (g.pr.n == 0) { g.first_off = lvl_off; g.first_round = i; }
+            g.pr.off[g.pr.n] = (uint32_t)(lvl_off - g.first_off);
+            g.pr.off[++g.pr.n] = (uint32_t)(lvl_off + h - g.first_off);
+            g.total = lvl_off + h - g.first_off;
         }
+        if ((grp == 1 || grp == 2) && (i + 1 == n_vars || group_of(h / 2) != grp)) ZK_HIP(c, hipEventRecord(grp == 1 ? wide_ready : mid_ready, c->stream));
         lvl_off += h;
         cur = rem;
         cn = h;
     }
     ZK_HIP(c, hipGetLastError());
-    // workspace: region k (k < NSLOT) is sized for the k-th large round and reused by rounds k + NSLOT, k + 2 NSLOT, ... (each
-    // half the size of its predecessor in the region or less); the batch has its own region.  Reserved once, up front: a
+    // workspace: region k (k < NSLOT) is sized for the k-th single commit and reused by the commits k + NSLOT, k + 2 NSLOT, ... (each
+    // half the size of its predecessor in the region or less); the batches have regions of their own.  Reserved once, up front: a
     // commit that grew the workspace later would move it under the commits in flight.
-    size_t region_off[zkhip_ctx::MSM_SLOTS + 1] = {};
+    size_t region_off[zkhip_ctx::MSM_SLOTS + 3] = {};
     for (int k = 0; k < NSLOT; ++k) {
         size_t used = 0;
         if ((size_t)k < large.size()) {
@@ -541,13 +592,16 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
         }
         region_off[k + 1] = region_off[k] + ((used + 4095) & ~(size_t)4095);
     }
+    size_t group_region[4] = {region_off[NSLOT], 0, 0, 0};
     {
-        size_t used = 0;
-        if (batch.n) ZK_TRY(msm_enqueue(c, nullptr, nullptr, nullptr, lvl_off - batch_first_off, batch, nullptr, 0, 0, 0, nullptr, &used));
-        region_off[NSLOT + 1] = region_off[NSLOT] + used;
+        const Group* gs[3] = {&wide, &mid, &small};
+        for (int k = 0; k < 3; ++k) {
+            size_t used = 0;
+            if (gs[k]->pr.n) ZK_TRY(msm_enqueue(c, nullptr, nullptr, nullptr, gs[k]->total, gs[k]->pr, nullptr, 0, 0, 0, nullptr, &used));
+            group_region[k + 1] = group_region[k] + ((used + 4095) & ~(size_t)4095);
+        }
+        ZK_TRY(c->reserve_ws(group_region[3]));
     }
-    ZK_TRY(c->reserve_ws(region_off[NSLOT + 1]));
-    ZK_TRY(c->ensure_side_streams());
     ZK_HIP(c, hipEventRecord(c->fork_ev, c->stream));
     MsmPending pend[zkhip_ctx::MSM_SLOTS];
     int pend_round[zkhip_ctx::MSM_SLOTS];
@@ -560,40 +614,73 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
     };
     hipStream_t const main_stream = c->stream;
     int rc = ZKHIP_OK;
-    // the batch of small rounds FIRST: its chain of latency-bound passes is the longest of all (26 narrow windows per problem), and issued
-    // last it only started when the first large round's queue had drained (profiles/r03: 5.2 ms into an 8.5 ms open)
-    if (batch.n && rc == ZKHIP_OK) {
-        const int sl = zkhip_ctx::MSM_SLOTS - 1;
-        if (hipStreamWaitEvent(c->side[sl], c->fork_ev, 0) != hipSuccess) rc = ZKHIP_ERR_HIP;
-        if (rc == ZKHIP_OK) {
-            c->stream = c->side[sl];
-            rc = msm_enqueue(c, d_folded_xy + 12 * batch_first_off, d_folded_inf + batch_first_off, d_q + 4 * batch_first_off,
-                             lvl_off - batch_first_off, batch, nullptr, 0, region_off[NSLOT], sl, &pend[sl], nullptr);
-            c->stream = main_stream;
-            if (rc == ZKHIP_OK) pend_round[sl] = (int)batch_first_round;
+    // The batches in two phases: the fronts of all of them (sorts and bucket orders: many short kernels) beside each other, and only when
+    // ALL fronts are through, the backs -- a front beside another batch's accumulate pass, whose workgroups hold every slot of the chip for
+    // about a millisecond each, crawled (a one-workgroup scan 250 us, the order passes of the small batch 1.5 ms).
+    struct Lane { const Group* g; int sl; hipStream_t on; size_t region; hipEvent_t ready; };   // ready: the group's quotients are written
+    const bool wide_first = [] { const char* e = std::getenv("ZKHIP_OPEN_WIDE_FIRST"); return !(e && e[0] == '0'); }();   // tuning aid
+    const Lane lanes[3] = {{&wide, sl_wide, pipelines || wide_first ? c->side[sl_wide] : c->side_low[1], group_region[0], wide_ready},
+                           {&mid, sl_mid, pipelines ? c->side[sl_mid] : c->side_low[0], group_region[1], mid_ready},
+                           {&small, sl_small, pipelines ? c->side[sl_small] : main_stream, group_region[2], c->fork_ev}};
+    auto enqueue_lane = [&](const Lane& L, int phases) {
+        const Group& g = *L.g;
+        if (!g.pr.n || rc != ZKHIP_OK) return;
+        c->stream = L.on;                                  // msm_enqueue launches on the context's stream
+        rc = msm_enqueue(c, d_folded_xy + 12 * g.first_off, d_folded_inf + g.first_off, d_q + 4 * g.first_off, g.total, g.pr, nullptr, 0,
+                         L.region, L.sl, &pend[L.sl], nullptr, phases);
+        c->stream = main_stream;
+        if (rc == ZKHIP_OK && (phases & 2)) pend_round[L.sl] = (int)g.first_round;
+    };
+    for (const Lane& L : lanes) {
+        if (!L.g->pr.n || rc != ZKHIP_OK) continue;
+        if (L.on != main_stream && hipStreamWaitEvent(L.on, L.ready, 0) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
+        enqueue_lane(L, pipelines ? 3 : 1);
+        if (!pipelines && rc == ZKHIP_OK) {
+            if ((rc = c->ensure_msm_slot_events(L.sl)) != ZKHIP_OK) break;
+            if (hipEventRecord(c->msm_front[L.sl], L.on) != hipSuccess) rc = ZKHIP_ERR_HIP;
+        }
+    }
+    if (!pipelines) {
+        for (const Lane& L : lanes) {
+            if (!L.g->pr.n || rc != ZKHIP_OK) continue;
+            for (const Lane& O : lanes)
+                if (O.g->pr.n && O.sl != L.sl && hipStreamWaitEvent(L.on, c->msm_front[O.sl], 0) != hipSuccess) rc = ZKHIP_ERR_HIP;
+            enqueue_lane(L, 2);
         }
     }
     for (size_t j = 0; j < large.size() && rc == ZKHIP_OK; ++j) {
-        const int sl = (int)(j % NSLOT);
-        if ((rc = finish_slot(sl)) != ZKHIP_OK) break;     // round j - NSLOT used this region, stream and result slot
+        const int k = (int)(j % NSLOT), sl = single_slots[k];
+        if ((rc = finish_slot(sl)) != ZKHIP_OK) break;     // commit j - NSLOT used this region, stream and result slot
         MsmProblems one = {};
         one.n = 1;
         one.off[1] = (uint32_t)large[j].h;
         if (hipStreamWaitEvent(c->side[sl], c->fork_ev, 0) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
-        c->stream = c->side[sl];                           // msm_enqueue launches on the context's stream
+        c->stream = c->side[sl];
         rc = msm_enqueue(c, d_folded_xy + 12 * large[j].off, d_folded_inf + large[j].off, d_q + 4 * large[j].off, large[j].h, one, nullptr, 0,
-                         region_off[sl], sl, &pend[sl], nullptr);
+                         region_off[k], sl, &pend[sl], nullptr);
         c->stream = main_stream;
         if (rc == ZKHIP_OK) pend_round[sl] = (int)large[j].round;
     }
-    // the remaining epilogues; every slot is drained even after an error, so that nothing is left running on a side stream
-    for (int pass = 0; pass < 2; ++pass)
+    // the remaining epilogues, each as soon as its commit's results have landed (a commit waited for in a fixed order kept the host idle
+    // while others were ready: 1.2 ms of epilogues behind the last kernel); every slot is drained even after an error, so that nothing
+    // is left running on a side stream
+    for (;;) {
+        int left = 0, ready = -1;
         for (int k = 0; k < zkhip_ctx::MSM_SLOTS; ++k) {
             if (pend_round[k] < 0) continue;
-            const int r2 = finish_slot(k);
-            if (rc == ZKHIP_OK) rc = r2;
+            ++left;
+            if (ready < 0 && hipEventQuery(c->msm_ev[k]) != hipErrorNotReady) ready = k;
         }
-    if (rc != ZKHIP_OK) return rc;
+        if (!left) break;
+        if (ready < 0) { std::this_thread::yield(); continue; }
+        const int r2 = finish_slot(ready);
+        if (rc == ZKHIP_OK) rc = r2;
+    }
+    if (rc != ZKHIP_OK) {
+        for (int k = 0; k < zkhip_ctx::MSM_SLOTS; ++k) hipStreamSynchronize(c->side[k]);   // a heavy-pass stream may still be running
+        for (int k = 0; k < 2; ++k) hipStreamSynchronize(c->side_low[k]);
+        return rc;
+    }
     // the last remainder is poly(z): `evaluation`, and what the reference checks it against (:84-86)
     ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), cur, 32, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));

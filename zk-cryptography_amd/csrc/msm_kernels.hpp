@@ -44,9 +44,10 @@ struct MsmPlan {
     uint32_t ns;         // segments per window = nb / L
     uint32_t n_bits;     // bits of the segment index = c - 1 - log2 L
     uint32_t n_terms;    // 1 + n_bits
-    uint32_t sub_bits;   // low bits of the bucket index resolved inside a partition (<= 8)
-    uint32_t parts_pw;   // partitions per window = nb >> sub_bits
-    uint32_t n_parts;    // n_windows * parts_pw (<= 2048)
+    uint32_t sub_bits;   // HIGH bits of the bucket index, resolved inside a partition (<= 8)
+    uint32_t parts_pw;   // partitions per window = nb >> sub_bits: a partition holds the buckets with the same LOW part_bits bits, so
+    uint32_t part_bits;  //   a sparse top window (few distinct digits) still spreads over min(#digits, parts_pw) partitions
+    uint32_t n_parts;    // n_windows * parts_pw (<= SORT_MAX_PARTS)
 };
 
 // Signed base-2^c digit stream of a canonical scalar (8 x u32, little endian); digits lie in [-nb, nb].
@@ -115,12 +116,13 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_order_scatter_kernel(con
 }
 
 // ---- counting sort in two levels, without global atomics -------------------------------------------------
-// Level 1 splits the (point, window) pairs by (window, high bits of the bucket) into <= 2048 partitions; a workgroup
+// Level 1 splits the (point, window) pairs by (window, high bits of the bucket) into <= 4096 partitions; a workgroup
 // counts its tile in LDS (sort_count), a column scan turns the per-workgroup counts into exclusive write positions
 // (sort_bases), and the same tile walk scatters 8-byte items (sort_scatter).  Level 2 runs one workgroup per
-// partition: the low <= 8 bucket bits are resolved in LDS, which also yields every bucket's count and offset.
+// partition: the remaining <= 8 bucket bits are resolved in LDS, which also yields every bucket's count and offset.
+// (The buckets of a window lie in `sorted` partition by partition, not in index order: nothing reads them but through offsets[].)
 constexpr int SORT_TILE = 2048;          // scalars per workgroup tile (8 per lane)
-constexpr int SORT_MAX_PARTS = 2048;
+constexpr int SORT_MAX_PARTS = 4096;
 
 // Batched commits (several independent (points, scalars) problems laid end to end, e.g. the small levels of
 // MultilinearKZG::open): problem j owns the entries [off[j], off[j+1]) and the windows [j * w_per, (j+1) * w_per).
@@ -139,7 +141,7 @@ __device__ __forceinline__ uint32_t msm_problem_of(const MsmProblems& pr, uint32
 }
 
 __device__ __forceinline__ uint32_t msm_partition_of(uint32_t w, uint32_t mag, const MsmPlan& pl) {
-    return w * pl.parts_pw + ((mag - 1) >> pl.sub_bits);
+    return w * pl.parts_pw + ((mag - 1) & (pl.parts_pw - 1));
 }
 
 static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_count_kernel(const uint64_t* __restrict__ scalars,
@@ -190,23 +192,33 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_bases_kernel(uint32
     }
     if (lane == 63) part_count[p] = incl;
 }
-// exclusive scan of <= 2048 partition totals by one workgroup; part_off[n_parts] = grand total
+// exclusive scan of <= SORT_MAX_PARTS partition totals by one workgroup (four consecutive ones per lane); part_off[n_parts] = grand total
 static __global__ __launch_bounds__(1024) void msm_sort_part_scan_kernel(const uint32_t* __restrict__ part_count, uint32_t n_parts,
                                                                          uint32_t* __restrict__ part_off) {
+    static_assert(SORT_MAX_PARTS <= 4 * 1024, "four partitions per lane");
     __shared__ uint32_t part[1024];
-    const uint32_t a = 2 * threadIdx.x, b = a + 1;
-    const uint32_t va = a < n_parts ? part_count[a] : 0, vb = b < n_parts ? part_count[b] : 0;
-    part[threadIdx.x] = va + vb;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t a = 4 * threadIdx.x + u;
+        v[u] = a < n_parts ? part_count[a] : 0;
+        sum += v[u];
+    }
+    part[threadIdx.x] = sum;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        uint32_t t = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
         __syncthreads();
-        part[threadIdx.x] += v;
+        part[threadIdx.x] += t;
         __syncthreads();
     }
-    const uint32_t excl = part[threadIdx.x] - (va + vb);
-    if (a < n_parts) part_off[a] = excl;
-    if (b < n_parts) part_off[b] = excl + va;
+    uint32_t run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t a = 4 * threadIdx.x + u;
+        if (a < n_parts) part_off[a] = run;
+        run += v[u];
+    }
     if (threadIdx.x == 1023) part_off[n_parts] = part[1023];
 }
 
@@ -220,7 +232,6 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_scatter_kernel(cons
         cur[i] = part_off[i] + wg_bases[(size_t)blockIdx.x * pl.n_parts + i];
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * SORT_TILE;
-    const uint32_t sub_mask = (1u << pl.sub_bits) - 1;
     for (uint32_t u = 0; u < SORT_TILE / MSM_BLOCK; ++u) {
         const size_t i = base + u * MSM_BLOCK + threadIdx.x;
         if (i >= n || (inf && inf[i])) continue;
@@ -233,7 +244,7 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_scatter_kernel(cons
             const uint32_t mag = neg ? (uint32_t)(-d) : (uint32_t)d;
             const uint32_t pos = atomicAdd(&cur[msm_partition_of(pl.shared ? 0u : wbase + w, mag, pl)], 1u);
             const uint32_t entry = pl.shared ? w * pl.stride + (uint32_t)i : (uint32_t)i;
-            items[pos] = make_uint2(entry | (neg ? 0x80000000u : 0u), (mag - 1) & sub_mask);
+            items[pos] = make_uint2(entry | (neg ? 0x80000000u : 0u), (mag - 1) >> pl.part_bits);
         }
     }
 }
@@ -281,8 +292,8 @@ static __global__ __launch_bounds__(SORT_LOCAL_BLOCK) void msm_sort_local_kernel
     }
     if (threadIdx.x < n_sub) {
         const uint32_t excl = scan[threadIdx.x] - v;
-        const uint32_t w = p / pl.parts_pw, top = p % pl.parts_pw;
-        const uint32_t bucket = w * pl.nb + (top << pl.sub_bits) + threadIdx.x;
+        const uint32_t w = p / pl.parts_pw, low = p % pl.parts_pw;
+        const uint32_t bucket = w * pl.nb + (threadIdx.x << pl.part_bits) + low;
         counts[bucket] = v;
         offsets[bucket] = lo + excl;
         bins[threadIdx.x] = lo + excl;      // becomes the write cursor
@@ -309,10 +320,10 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_convert_points_kernel(co
 // Skewed scalars (small table values, constant polynomials, a sparse top window) can put a large share of all
 // points into a handful of buckets, and one lane adding 2^20 points one after the other would take seconds.  A
 // bucket holding more than `heavy_min` points is therefore not walked by its lane: the lane files it as records of
-// <= 8192 points for pass 4b, where a whole workgroup sums a record (<= 32 points per lane, then a tree in LDS),
+// <= 2048 points for pass 4b, where a whole workgroup sums a record (<= 8 points per lane, then a tree in LDS),
 // and, when the bucket spans several records, as a tree of <= 256-way sums over the record sums for pass 4c.
 // With uniform scalars no bucket is heavy and 4b / 4c find empty lists.
-constexpr uint32_t MSM_HEAVY_LANE_MAX = 32;                       // points per lane inside a record
+constexpr uint32_t MSM_HEAVY_LANE_MAX = 8;                        // points per lane inside a record (32 in rounds 1-3: the pass is a latency chain of that many additions plus the tree)
 constexpr uint32_t MSM_HEAVY_REC = MSM_BLOCK * MSM_HEAVY_LANE_MAX;   // points per record
 constexpr int MSM_HEAVY_LEVELS = 4;                               // 0: records of points; 1..3: 256-way sums of sums
 struct MsmHeavyRec {
@@ -385,18 +396,23 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_accumulate_kernel(const 
                                                                    const uint32_t* __restrict__ offsets,
                                                                    const uint32_t* __restrict__ counts,
                                                                    const uint32_t* __restrict__ order,
-                                                                   uint32_t n_buckets, uint32_t heavy_min,
-                                                                   MsmOverflow* __restrict__ ovf, MsmHeavyRec* __restrict__ rec,
-                                                                   uint32_t rec_cap, uint32_t* __restrict__ buckets) {
+                                                                   uint32_t n_buckets, uint32_t heavy_min, uint32_t* __restrict__ buckets) {
     const uint32_t t = blockIdx.x * MSM_BLOCK + threadIdx.x;
     if (t >= n_buckets) return;
     const uint32_t b = order[t];
     const uint32_t start = offsets[b], cnt = counts[b];
-    if (cnt > heavy_min) {
-        msm_file_heavy(b, start, cnt, ovf, rec, rec_cap);   // passes 4b / 4c write buckets[b]
-        return;
-    }
+    if (cnt > heavy_min) return;                            // filed by msm_file_heavy_kernel; passes 4b / 4c write buckets[b]
     store_xyzz_u(buckets, b, msm_sum_run(points, sorted, start, cnt));
+}
+// The heavy buckets are filed by a pass of their own: 4b / 4c then depend on the sort alone and run in FRONT of the accumulate pass
+// (a few hundred latency-bound workgroups; see msm_enqueue).
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_file_heavy_kernel(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                                                          uint32_t n_buckets, uint32_t heavy_min, MsmOverflow* __restrict__ ovf,
+                                                                          MsmHeavyRec* __restrict__ rec, uint32_t rec_cap) {
+    const uint32_t b = blockIdx.x * MSM_BLOCK + threadIdx.x;
+    if (b >= n_buckets) return;
+    const uint32_t cnt = counts[b];
+    if (cnt > heavy_min) msm_file_heavy(b, offsets[b], cnt, ovf, rec, rec_cap);
 }
 
 // tree sum over the first `width` lanes' values (width a power of two <= MSM_BLOCK); the result is lane 0's `acc`
@@ -420,12 +436,13 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_heavy_points_kernel(cons
                                                                      const MsmHeavyRec* __restrict__ rec,
                                                                      uint32_t* __restrict__ partials,
                                                                      uint32_t* __restrict__ buckets) {
+    __builtin_amdgcn_s_setprio(3);   // a latency-bound pass: beside another commit's accumulate pass its few waves win the issue arbitration
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
     uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);   // MSM_BLOCK x 64 u32
     const uint32_t n_rec = ovf->n_rec[0];
     for (uint32_t i = blockIdx.x; i < n_rec; i += gridDim.x) {
         const MsmHeavyRec r = rec[i];
-        // at least 8 points per lane (the tree's general additions stay a small share of the work), at most 32
+        // 8 points per lane (the tree's general additions stay a small share of the work); the last lanes of a short record fewer
         const uint32_t per = max(8u, (r.count + MSM_BLOCK - 1) / MSM_BLOCK);
         const uint32_t lanes = (r.count + per - 1) / per;
         uint32_t width = 1;
@@ -445,6 +462,7 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_heavy_tree_kernel(const 
                                                                    const MsmHeavyRec* __restrict__ rec,
                                                                    uint32_t* __restrict__ partials,
                                                                    uint32_t* __restrict__ buckets) {
+    __builtin_amdgcn_s_setprio(3);   // a latency-bound pass: beside another commit's accumulate pass its few waves win the issue arbitration
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
     uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);
     const uint32_t n_rec = ovf->n_rec[level];

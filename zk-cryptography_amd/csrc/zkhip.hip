@@ -64,6 +64,7 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     if (c->fold_stream) hipStreamSynchronize(c->fold_stream);
     for (auto& L : c->lanes) { if (L.serial) hipStreamSynchronize(L.serial); if (L.fold) hipStreamSynchronize(L.fold); }
     for (int i = 0; i < zkhip_ctx::MSM_SLOTS; ++i) if (c->side[i]) hipStreamSynchronize(c->side[i]);
+    for (int i = 0; i < 2; ++i) if (c->side_low[i]) { hipStreamSynchronize(c->side_low[i]); hipStreamDestroy(c->side_low[i]); }
     for (auto& e : c->prof_events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
     if (c->d_ws) hipFree(c->d_ws);
     if (c->d_aux) hipFree(c->d_aux);
@@ -72,6 +73,7 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     for (int i = 0; i < zkhip_ctx::MSM_SLOTS; ++i) {
         if (c->msm_pin[i]) hipHostFree(c->msm_pin[i]);
         if (c->msm_ev[i]) hipEventDestroy(c->msm_ev[i]);
+        if (c->msm_front[i]) hipEventDestroy(c->msm_front[i]);
         if (c->side[i]) hipStreamDestroy(c->side[i]);
     }
     if (c->fork_ev) hipEventDestroy(c->fork_ev);
@@ -630,6 +632,10 @@ static int block_sums_impl(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint
         // total from those.  Without (the deferred form): nothing more here -- the prover derives the coarse sums itself, on the
         // stream of the proof (a high-priority one when the proof is in flight), instead of queueing a tiny kernel on the caller's
         // stream behind whatever streaming pass occupies the chip.
+        // (Round 3 tried to have the sums pass deliver the coarse sums too and dropped both forms.  Per-workgroup sums (n / 2048 values)
+        // added up by the first serial kernel's prologue: the 8 us kernel and its 6 us launch gap went, the prologue grew by 9 us and the
+        // step stayed at 0.334 ms.  The workgroup that finishes LAST under a coarse block adds them up (a device-scope release + counter
+        // per workgroup): that release writes the L2 back once per workgroup, 8192 times -- 0.75 ms per step instead of 0.33.)
         if (want_total) {
             const uint32_t k1 = overlapped_plan(n) && log_blocks == log2_exact(n) - 8 ? log_blocks - overlapped_k2(n) : 8;
             int cs = 0;
@@ -749,7 +755,7 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
             hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, S, fine, 1u << k2, (uint64_t*)nullptr, (uint64_t*)c->d_coarse[cs]);
         }
         const uint64_t* coarse = (const uint64_t*)c->d_coarse[cs];
-        c->coarse_of[cs] = nullptr;                 // the entry belongs to this proof from here on (the ring gives it three more poly_sum() calls of life)
+        c->coarse_of[cs] = nullptr;                 // the entry belongs to this proof from here on (the ring gives it seven more poly_sum() calls of life)
         SmallArgs a = {};
         a.src = coarse; a.group = 0; a.canon = 1; a.log_n = k1; a.n_rounds = k1; a.round0 = 0; a.first = first; a.claimed = claimed;
         a.d_claimed = d_claimed_sum; a.weights_out = d_w; a.final_out = nullptr;
