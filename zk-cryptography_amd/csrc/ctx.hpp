@@ -3,10 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <new>
 #include <set>
 #include <vector>
 
 #include "../../include/zkhip.h"
+#include "host_util.hpp"
 
 #define ZK_MAX_ROUNDS 40          /* tables up to 2^40 entries: far beyond 288 GB */
 #define ZK_MAX_PARTIALS 4096      /* (lo, hi) pairs: >= the largest grid any reducing kernel uses */
@@ -68,23 +71,11 @@ struct zkhip_ctx {
     void* msm_pin[MSM_SLOTS] = {};
     size_t msm_pin_bytes[MSM_SLOTS] = {};
     hipEvent_t msm_ev[MSM_SLOTS] = {};
-    hipEvent_t msm_front[MSM_SLOTS] = {};                                        // the front of a commit (sort, bucket order) is through
-    int ensure_msm_slot_events(int slot) {
-        if (!msm_front[slot] && hipEventCreateWithFlags(&msm_front[slot], hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
-        return ZKHIP_OK;
-    }
     hipStream_t side[MSM_SLOTS] = {};
     hipEvent_t fork_ev = nullptr, join_ev = nullptr, serial_ev = nullptr;
-    // low-priority twins of side[0] and side[1]: the throughput-bound batched commits of MultilinearKZG::open run there, so that the
-    // latency-bound passes beside them (the small batch, the heavy-bucket passes) get their few workgroups placed as soon as a slot frees up
-    hipStream_t side_low[2] = {};
     int ensure_side_streams() {
         for (int i = 0; i < MSM_SLOTS; ++i)
             if (!side[i] && hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) return ZKHIP_ERR_HIP;
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return ZKHIP_ERR_HIP;
-        for (int i = 0; i < 2; ++i)
-            if (!side_low[i] && hipStreamCreateWithPriority(&side_low[i], hipStreamNonBlocking, least) != hipSuccess) return ZKHIP_ERR_HIP;
         if (!fork_ev && hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
         if (!join_ev && hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
         if (!serial_ev && hipEventCreateWithFlags(&serial_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
@@ -156,6 +147,30 @@ struct zkhip_ctx {
         if (hipHostMalloc(&msm_pin[slot], bytes, hipHostMallocDefault) != hipSuccess) return ZKHIP_ERR_NOMEM;
         msm_pin_bytes[slot] = bytes;
         return ZKHIP_OK;
+    }
+    // geometry tables of the commit in slot `slot` (msm_build_geometry): device copy + pinned staging, kept while the signature matches
+    void* msm_tab_dev[MSM_SLOTS] = {};
+    void* msm_tab_pin[MSM_SLOTS] = {};
+    size_t msm_tab_bytes[MSM_SLOTS] = {};
+    uint64_t msm_tab_sig[MSM_SLOTS] = {};
+    int reserve_msm_tab(int slot, size_t bytes) {
+        if (bytes <= msm_tab_bytes[slot]) return ZKHIP_OK;
+        if (msm_tab_dev[slot]) hipFree(msm_tab_dev[slot]);
+        if (msm_tab_pin[slot]) hipHostFree(msm_tab_pin[slot]);
+        msm_tab_dev[slot] = nullptr; msm_tab_pin[slot] = nullptr; msm_tab_bytes[slot] = 0; msm_tab_sig[slot] = 0;
+        const size_t cap = (bytes + 65535) & ~(size_t)65535;
+        if (hipMalloc(&msm_tab_dev[slot], cap) != hipSuccess) return ZKHIP_ERR_NOMEM;
+        if (hipHostMalloc(&msm_tab_pin[slot], cap, hipHostMallocDefault) != hipSuccess) return ZKHIP_ERR_NOMEM;
+        msm_tab_bytes[slot] = cap;
+        return ZKHIP_OK;
+    }
+    ZkHostPool* host_pool = nullptr;     // host epilogues of batched commits (created on first use, min(hardware threads, 32) - 1 workers)
+    ZkHostPool* pool() {
+        if (!host_pool) {
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            host_pool = new (std::nothrow) ZkHostPool(std::min(hw, 32u) - 1);
+        }
+        return host_pool;
     }
     bool ws_lent = false;       // the workspace currently backs a split-phase prover state or commits in flight
     // commits in flight (zkhip_kzg_commit_begin / _end): two slots, each with a region of the workspace, a side stream and a

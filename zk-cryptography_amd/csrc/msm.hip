@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -22,89 +24,181 @@ using namespace zk;
 // ---------------------------------------------------------------------------------------
 // KZG commit (MSM)
 // ---------------------------------------------------------------------------------------
-static MsmPlan msm_plan(size_t n, uint32_t n_problems = 1) {
-    uint32_t lg = 0;
-    while (((size_t)1 << lg) < n) ++lg;
-    // One lane per bucket: the accumulate pass wants many short lists, so the window is as wide as the sort allows
-    // as soon as the bucket reduction is not the larger cost (measured with tools/perf_msm.py, ZKHIP_MSM_C sweep:
-    // c = 16 wins from 2^13 points on; below that every c ends at the ~1 ms latency floor of the reduction passes).
-    uint32_t c = lg >= 13 ? 16 : lg >= 10 ? 12 : 8;
-    if (n_problems > 1) {
-        // Batched: one pass of every kernel for all problems, so the chip is full and the window is chosen for the WORK (additions per point
-        // plus buckets to reduce), not for the latency floor; windows x problems x partitions must stay within the sort's partitions.
-        c = lg >= 15 ? std::min<uint32_t>(14, lg - 5) : lg >= 11 ? 10 : 8;   // lists of ~64 points for the largest problem (one lane per bucket: the pass takes as long as its longest lists)
-        if (const char* e = std::getenv("ZKHIP_MSM_BATCH_C")) {   // tuning aid (tools/perf_open.py): the wide batch only
-            const int v = std::atoi(e);
-            if (lg >= 15 && v >= 8 && v <= 16) c = (uint32_t)v;
-        }
-        auto parts = [&](uint32_t cc) { return (uint64_t)((256 + cc - 1) / cc) * n_problems * ((1u << (cc - 1)) >> std::min<uint32_t>(cc - 1, 8)); };
-        while (c > 8 && parts(c) > (uint64_t)SORT_MAX_PARTS) --c;
-    }
-    if (const char* e = std::getenv("ZKHIP_MSM_C")) {   // tuning aid (tools/perf_msm.py); any 4 <= c <= 16 is correct
-        const int v = std::atoi(e);
-        if (v >= 4 && v <= 16) c = (uint32_t)v;
-    }
-    MsmPlan pl = {};
-    pl.c = c;
-    pl.w_per = (256 + c - 1) / c;
-    pl.n_windows = pl.w_per * n_problems;
-    pl.nb = 1u << (c - 1);
-    pl.ns = pl.nb / MSM_SEG;
-    pl.n_bits = c - 1 - MSM_SEG_LOG;
-    pl.n_terms = 1 + pl.n_bits;
-    pl.sub_bits = (c - 1) < 8 ? (c - 1) : 8;
-    pl.parts_pw = pl.nb >> pl.sub_bits;
-    pl.part_bits = c - 1 - pl.sub_bits;
-    pl.n_parts = pl.n_windows * pl.parts_pw;     // c = 16: 16 * 128 = 2048
-    return pl;
-}
-
-// Problem j = sum_i scalars[i] * points[i] over the entries [off[j], off[j+1]) of the n given -> affine results on the
-// host (h_out_xy[12 j], h_out_inf[j]).  All problems share one pass of every kernel: the windows of problem j are the
-// "virtual windows" [j * w_per, (j+1) * w_per) of one bucket array.
-// The window width of the shifted-SRS table (zkhip_srs_precompute): 255-bit scalars are twelve full 20-bit windows and a
-// 15-bit top window, so no window is sparse; 2^19 buckets in all.
+// Geometry of one pass (msm_kernels.hpp: MsmWin / MsmSet / MsmPlan): how every problem's 256 scalar bits are cut into digit windows,
+// and the bucket sets behind them.
+//   one problem:   uniform windows of c bits, c = 16 from 2^13 points on (one lane per bucket: the accumulate pass wants many short
+//                  lists, so the window is as wide as the sort allows as soon as the bucket reduction is not the larger cost; measured
+//                  with tools/perf_msm.py, ZKHIP_MSM_C sweep: below 2^13 every c ends at the ~1 ms latency floor of the reduction
+//                  passes).  16 x 16 = 256: the top window has 15 significant bits, half full, never sparse.
+//   shifted table: thirteen 20-bit digit windows on ONE bucket set of 2^19 buckets (MSM_TABLE_C).
+//   several:       every problem gets a width of its OWN, about log2(n_j) - 4 bits (lists of 32-64 points: the accumulate pass takes as
+//                  long as its longest lists, and every further bit doubles the buckets the reduction passes walk), as w = ceil(256 / c)
+//                  windows of the two widths ceil(256 / w) and one less that add up to exactly 256 -- so no window of any problem is
+//                  sparse (a 3-bit top window put an eighth of all points into each of 4 buckets: the heavy-bucket passes, 0.6 ms) and
+//                  all problems share ONE pass of every kernel (MultilinearKZG::open at 2^20: twenty problems, ~0.45 M buckets).
+struct MsmGeometry {
+    MsmPlan pl = {};                 // totals; the device pointers are set by msm_enqueue
+    std::vector<MsmWin> wins;
+    std::vector<MsmSet> sets;
+    std::vector<uint16_t> part_set, rcwg_set, termwg_set;
+    std::vector<uint32_t> set_exp;   // weight 2^set_exp of a set's total (the first bit of its digit window; 0 with the table)
+    std::vector<uint32_t> prob_set_first;   // problem j owns the sets [prob_set_first[j], prob_set_first[j+1])
+    uint16_t win_first[MSM_MAX_PROBLEMS + 1] = {};
+    size_t items = 0;                // (point, window) pairs of the pass
+    uint32_t heavy_min = 32;
+    uint32_t tb = 64;                // workgroup size of the row / column passes
+    uint64_t sig = 0;
+};
 constexpr uint32_t MSM_TABLE_C = 20;
-constexpr uint32_t MSM_TABLE_WINDOWS = (256 + MSM_TABLE_C - 1) / MSM_TABLE_C;   // 13
-static MsmPlan msm_plan_table(size_t stride) {
-    MsmPlan pl = {};
-    pl.c = MSM_TABLE_C;
-    pl.w_per = MSM_TABLE_WINDOWS;
-    pl.n_windows = 1;                              // one bucket set for the digits of all windows
-    pl.shared = 1;
-    pl.stride = (uint32_t)stride;
-    pl.nb = 1u << (pl.c - 1);
-    pl.ns = pl.nb / MSM_SEG;
-    pl.n_bits = pl.c - 1 - MSM_SEG_LOG;
-    pl.n_terms = 1 + pl.n_bits;
-    pl.sub_bits = 8;
-    pl.parts_pw = pl.nb >> pl.sub_bits;            // 2048
-    pl.part_bits = pl.c - 1 - pl.sub_bits;
-    pl.n_parts = pl.parts_pw;
-    return pl;
+constexpr uint32_t MSM_TABLE_WINDOWS = (256 + MSM_TABLE_C - 1) / MSM_TABLE_C;   // 13: twelve full 20-bit windows and a 15-bit top window
+static int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t table_stride, int delta, MsmGeometry& g);
+static int msm_build_geometry(const MsmProblems& pr, bool shared, size_t table_stride, MsmGeometry& g);
+// the geometries of the last few shapes (an opening builds its twenty-problem geometry twice per call otherwise: ~0.1 ms of host time each)
+static int msm_geometry(const MsmProblems& pr, bool shared, size_t table_stride, std::shared_ptr<const MsmGeometry>* out) {
+    struct Entry { MsmProblems pr; bool shared; size_t stride; std::shared_ptr<const MsmGeometry> geo; };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Entry& e : cache)
+        if (e.shared == shared && e.stride == table_stride && e.pr.n == pr.n && std::memcmp(e.pr.off, pr.off, sizeof(uint32_t) * (pr.n + 1)) == 0) {
+            *out = e.geo;
+            return ZKHIP_OK;
+        }
+    auto g = std::make_shared<MsmGeometry>();
+    ZK_TRY(msm_build_geometry(pr, shared, table_stride, *g));
+    if (cache.size() >= 8) cache.erase(cache.begin());
+    cache.push_back({pr, shared, table_stride, g});
+    *out = g;
+    return ZKHIP_OK;
+}
+static int msm_build_geometry(const MsmProblems& pr, bool shared, size_t table_stride, MsmGeometry& g) {
+    int delta = 4;
+    if (const char* e = std::getenv("ZKHIP_MSM_BATCH_DELTA")) {   // tuning aid (tools/perf_open.py): width = log2(n_j) - delta
+        const int v = std::atoi(e);
+        if (v >= 0 && v <= 8) delta = v;
+    }
+    int rc = ZKHIP_ERR_SHAPE;
+    for (; delta <= 9 && rc == ZKHIP_ERR_SHAPE; ++delta) rc = msm_build_geometry_at(pr, shared, table_stride, delta, g);   // narrower windows until the sort's partitions suffice
+    return rc;
+}
+static int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t table_stride, int delta, MsmGeometry& g) {
+    g = MsmGeometry();
+    uint32_t max_chain = 1, rc_max = 1;
+    uint64_t sig = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
+    mix(pr.n); mix(shared); mix(table_stride);
+    g.prob_set_first.push_back(0);
+    auto add_set = [&](uint32_t c, uint32_t exp) {
+        MsmSet s = {};
+        const uint32_t part_bits = c - 1 > 8 ? c - 1 - 8 : 0;
+        s.bucket_base = g.pl.n_buckets;
+        s.part_base = g.pl.n_parts;
+        s.bits = c | (part_bits << 8);
+        s.term_base = g.pl.n_terms;
+        s.rc_base = g.pl.n_rc;
+        s.rcwg_base = g.pl.n_rcwg;
+        s.termwg_base = g.pl.n_termwg;
+        const MsmSetShape sh = msm_set_shape_c(c);
+        const uint32_t n_bits = sh.n_bits, C = sh.C, R = sh.R;
+        const uint32_t idx = (uint32_t)g.sets.size();
+        for (uint32_t p = 0; p < (1u << part_bits); ++p) g.part_set.push_back((uint16_t)idx);
+        for (uint32_t b = 0; b < sh.row_wgs + sh.col_wgs; ++b) g.rcwg_set.push_back((uint16_t)idx);
+        for (uint32_t t = 0; t < sh.term_wgs; ++t) g.termwg_set.push_back((uint16_t)idx);
+        g.pl.n_buckets += 1u << (c - 1);
+        g.pl.n_parts += 1u << part_bits;
+        g.pl.n_terms += 1 + n_bits;
+        g.pl.n_rc += 2 * R + C;
+        g.pl.n_rcwg += sh.row_wgs + sh.col_wgs;
+        g.pl.n_termwg += sh.term_wgs;
+        rc_max = std::max(rc_max, std::max(R, C));
+        g.sets.push_back(s);
+        g.set_exp.push_back(exp);
+        return s;
+    };
+    auto add_win = [&](const MsmSet& s, uint32_t c, uint32_t entry_off) {
+        MsmWin w = {};
+        w.part_base = s.part_base;
+        w.entry_off = entry_off;
+        w.bits = c | (s.bits & 0xff00u);
+        g.wins.push_back(w);
+    };
+    for (uint32_t j = 0; j < pr.n; ++j) {
+        const size_t nj = pr.off[j + 1] - pr.off[j];
+        mix(nj);
+        g.win_first[j] = (uint16_t)g.wins.size();
+        uint32_t lg = 0;
+        while (((size_t)1 << lg) < nj) ++lg;
+        if (shared) {
+            const MsmSet s = add_set(MSM_TABLE_C, 0);
+            for (uint32_t w = 0; w < MSM_TABLE_WINDOWS; ++w) add_win(s, MSM_TABLE_C, (uint32_t)(w * table_stride));
+            g.items += nj * MSM_TABLE_WINDOWS;
+            max_chain = std::max<uint32_t>(max_chain, (uint32_t)((nj * MSM_TABLE_WINDOWS + (1u << (MSM_TABLE_C - 1)) - 1) >> (MSM_TABLE_C - 1)));
+        } else {
+            uint32_t w, hi, n_hi;
+            if (pr.n == 1) {
+                uint32_t c = lg >= 13 ? 16 : lg >= 10 ? 12 : 8;
+                if (const char* e = std::getenv("ZKHIP_MSM_C")) {   // tuning aid (tools/perf_msm.py); any 4 <= c <= 16 is correct
+                    const int v = std::atoi(e);
+                    if (v >= 4 && v <= 16) c = (uint32_t)v;
+                }
+                w = (256 + c - 1) / c; hi = c; n_hi = w;
+            } else {
+                const uint32_t c = (uint32_t)std::min(16, std::max(7, (int)lg - delta));
+                w = (256 + c - 1) / c;
+                hi = (256 + w - 1) / w;
+                n_hi = 256 - w * (hi - 1);      // n_hi windows of hi bits (the low ones), the rest of hi - 1: exactly 256 bits
+            }
+            uint32_t bit = 0;
+            for (uint32_t v = 0; v < w; ++v) {
+                const uint32_t c = v < n_hi ? hi : hi - 1;
+                const MsmSet s = add_set(c, bit);
+                add_win(s, c, 0);
+                bit += c;
+            }
+            const uint32_t c_lo = n_hi < w ? hi - 1 : hi;
+            g.items += nj * w;
+            max_chain = std::max<uint32_t>(max_chain, (uint32_t)((nj + (1u << (c_lo - 1)) - 1) >> (c_lo - 1)));
+        }
+        g.prob_set_first.push_back((uint32_t)g.sets.size());
+        if (g.wins.size() > (size_t)MSM_MAX_WINS) return ZKHIP_ERR_SHAPE;
+    }
+    g.win_first[pr.n] = (uint16_t)g.wins.size();
+    g.pl.n_sets = (uint32_t)g.sets.size();
+    g.pl.n_wins = (uint32_t)g.wins.size();
+    g.pl.shared = shared ? 1u : 0u;
+    if (g.pl.n_parts > (uint32_t)SORT_MAX_PARTS || g.pl.n_sets > 65535u) return ZKHIP_ERR_SHAPE;
+    // a bucket holding more than heavy_min points (four average lists of the densest set) is summed by whole workgroups
+    g.heavy_min = std::max<uint32_t>(32, 4 * max_chain);
+    g.tb = std::min<uint32_t>(128, std::max<uint32_t>(64, rc_max));
+    mix(g.pl.n_buckets); mix(g.pl.n_wins);
+    g.sig = sig ? sig : 1;
+    return ZKHIP_OK;
 }
 
 // d_table (nullable): shifted-SRS table in the internal layout, entry w * table_stride + i = 2^(20 w) * point i; then
 // d_points_xy is not read and there is exactly one problem.
 // A commit in two halves, so that a caller with several commits in a row (MultilinearKZG::open) can run the host epilogue
-// of one while the GPU works on the next: msm_enqueue launches everything and the copy of the (window, term) points into
+// of one while the GPU works on the next: msm_enqueue launches everything and the copy of the (set, term) points into
 // pinned slot `slot` (workspace from byte offset ws_off; *ws_used = what it occupies), msm_finish waits for that copy
 // and runs the epilogue.
 struct MsmPending {
-    MsmPlan pl;
+    std::shared_ptr<const MsmGeometry> geo;
     MsmProblems pr;
     size_t n_out = 0;
     int slot = 0;
 };
 static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, const uint64_t* d_scalars, size_t n,
-                       const MsmProblems& pr, const uint32_t* d_table, size_t table_stride, size_t ws_off, int slot, MsmPending* pend,
-                       size_t* ws_used, int phases = 3) {
-    size_t max_n = 0;
-    for (uint32_t j = 0; j < pr.n; ++j) max_n = std::max<size_t>(max_n, pr.off[j + 1] - pr.off[j]);
-    const MsmPlan pl = d_table ? msm_plan_table(table_stride) : msm_plan(max_n, pr.n);
-    const size_t n_buckets = (size_t)pl.n_windows * pl.nb;
-    const size_t n_segments = (size_t)pl.n_windows * pl.ns;
-    const size_t n_out = (size_t)pl.n_windows * pl.n_terms;
+                       const MsmProblems& pr_in, const uint32_t* d_table, size_t table_stride, size_t ws_off, int slot, MsmPending* pend,
+                       size_t* ws_used) {
+    std::shared_ptr<const MsmGeometry> geo_p;
+    ZK_TRY(msm_geometry(pr_in, d_table != nullptr, table_stride, &geo_p));
+    const MsmGeometry& geo = *geo_p;
+    MsmProblems pr = pr_in;
+    std::memcpy(pr.win_first, geo.win_first, sizeof(pr.win_first));
+    MsmPlan pl = geo.pl;
+    const size_t n_buckets = pl.n_buckets;
+    const size_t n_segments = n_buckets / MSM_SEG;
+    const size_t n_out = pl.n_terms;
     // workspace carve-up (all 256-byte aligned)
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_counts = 0;
@@ -113,8 +207,8 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     const size_t o_bins = o_order + al(n_buckets * 4);
     const size_t o_sorted = o_bins + al(MSM_COUNT_BINS * 4);
     const size_t n_wgs = (n + SORT_TILE - 1) / SORT_TILE;
-    const size_t o_items = o_sorted + al(n * pl.w_per * 4);
-    const size_t o_wgc = o_items + al(n * pl.w_per * 8);
+    const size_t o_items = o_sorted + al(geo.items * 4);
+    const size_t o_wgc = o_items + al(geo.items * 8);
     const size_t o_pcnt = o_wgc + al(n_wgs * pl.n_parts * 4);
     const size_t o_poff = o_pcnt + al((pl.n_parts + 1) * 4);
     const size_t o_points = o_poff + al((pl.n_parts + 1) * 4);          // SRS in the internal 28-bit-limb layout
@@ -122,17 +216,14 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     const size_t o_segs = o_buckets + al(n_buckets * 256);
     const size_t o_sega = o_segs + al(n_segments * 256);
     const size_t o_terms = o_sega + al(n_segments * 256);
-    // heavy buckets (msm_kernels.hpp pass 4b/4c): more than heavy_min points, so at most n W / heavy_min of them;
+    // heavy buckets (msm_kernels.hpp pass 4b/4c): more than heavy_min points, so at most items / heavy_min of them;
     // a bucket of k points files ceil(k / MSM_HEAVY_REC) level-0 records and, above one record, a <= 256-way tree over them
-    const uint32_t heavy_min = (uint32_t)std::max<size_t>(32, 4 * ((max_n * (pl.shared ? pl.w_per : 1) + pl.nb - 1) / pl.nb));
-    const size_t items_max = n * pl.w_per;
+    const uint32_t heavy_min = geo.heavy_min;
+    const size_t items_max = geo.items;
     const size_t rec_cap = items_max / heavy_min + items_max / MSM_HEAVY_REC + 2;
     const size_t slots_cap = 3 * (items_max / MSM_HEAVY_REC) + 8;
-    const size_t o_tparts = o_terms + al(n_out * 192);
-    // rows / columns of the segment sums (msm_rowcol_kernel): per window R row sums of S, R of A, C column sums of S
-    const uint32_t lo_bits = pl.n_bits / 2;
-    const uint32_t rc_C = 1u << lo_bits, rc_R = pl.ns >> lo_bits;
-    const size_t o_ovf = o_tparts + al((size_t)pl.n_windows * (2 * rc_R + rc_C) * 256);
+    const size_t o_rc = o_terms + al(n_out * 192);                       // rows / columns of the segment sums (msm_rowcol_kernel)
+    const size_t o_ovf = o_rc + al((size_t)pl.n_rc * 256);
     const size_t o_rec = o_ovf + al(sizeof(MsmOverflow));
     const size_t o_part = o_rec + al(MSM_HEAVY_LEVELS * rec_cap * sizeof(MsmHeavyRec));
     const size_t total = o_part + al(slots_cap * 256);
@@ -146,7 +237,7 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     uint32_t* order = (uint32_t*)(ws + o_order);
     uint32_t* bins = (uint32_t*)(ws + o_bins);
     const uint32_t* points_u = d_table ? d_table : (const uint32_t*)(ws + o_points);
-    uint32_t* tparts = (uint32_t*)(ws + o_tparts);
+    uint32_t* rc = (uint32_t*)(ws + o_rc);
     uint2* items = (uint2*)(ws + o_items);
     uint32_t* wg_counts = (uint32_t*)(ws + o_wgc);
     uint32_t* part_count = (uint32_t*)(ws + o_pcnt);
@@ -159,12 +250,31 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     MsmHeavyRec* rec = (MsmHeavyRec*)(ws + o_rec);
     uint32_t* partials = (uint32_t*)(ws + o_part);
 
-    if (pl.n_parts > (uint32_t)SORT_MAX_PARTS) return ZKHIP_ERR_SHAPE;
+    {   // the geometry tables: device copy of this slot, uploaded when they differ from the last commit's
+        const size_t b_wins = al(geo.wins.size() * sizeof(MsmWin)), b_sets = al(geo.sets.size() * sizeof(MsmSet));
+        const size_t b_part = al(geo.part_set.size() * 2), b_rcwg = al(geo.rcwg_set.size() * 2), b_term = al(geo.termwg_set.size() * 2);
+        const size_t bytes = b_wins + b_sets + b_part + b_rcwg + b_term;
+        ZK_TRY(c->reserve_msm_tab(slot, bytes));
+        char* dev = (char*)c->msm_tab_dev[slot];
+        if (c->msm_tab_sig[slot] != geo.sig) {
+            char* pin = (char*)c->msm_tab_pin[slot];
+            // the staging buffer may still feed the upload of the slot's previous commit only if that commit has not been waited for;
+            // every caller ends (msm_finish / stream synchronize) a slot's commit before it enqueues the next one there
+            std::memcpy(pin, geo.wins.data(), geo.wins.size() * sizeof(MsmWin));
+            std::memcpy(pin + b_wins, geo.sets.data(), geo.sets.size() * sizeof(MsmSet));
+            std::memcpy(pin + b_wins + b_sets, geo.part_set.data(), geo.part_set.size() * 2);
+            std::memcpy(pin + b_wins + b_sets + b_part, geo.rcwg_set.data(), geo.rcwg_set.size() * 2);
+            std::memcpy(pin + b_wins + b_sets + b_part + b_rcwg, geo.termwg_set.data(), geo.termwg_set.size() * 2);
+            ZK_HIP(c, hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, c->stream));
+            c->msm_tab_sig[slot] = geo.sig;
+        }
+        pl.wins = (const MsmWin*)dev;
+        pl.sets = (const MsmSet*)(dev + b_wins);
+        pl.part_set = (const uint16_t*)(dev + b_wins + b_sets);
+        pl.rcwg_set = (const uint16_t*)(dev + b_wins + b_sets + b_part);
+        pl.termwg_set = (const uint16_t*)(dev + b_wins + b_sets + b_part + b_rcwg);
+    }
     const int grid_n = (int)std::min<size_t>((n + MSM_BLOCK - 1) / MSM_BLOCK, 256 * 8);
-    // phases (a caller with several commits beside each other, MultilinearKZG::open): 1 = the FRONT, everything up to the bucket order --
-    // many short kernels, which crawl when another commit's accumulate pass fills the chip (a one-workgroup scan took 250 us there) --
-    // 2 = the BACK from the accumulate pass on; the caller lines the fronts of all its commits up before the first back
-    if (phases & 1) {
     if (!d_table) {
         ProfScope ps(c, "msm_convert_points", 224.0 * (double)n);
         hipLaunchKernelGGL(msm_convert_points_kernel, dim3(grid_n), dim3(MSM_BLOCK), 0, c->stream, d_points_xy, n, (uint32_t*)(ws + o_points));
@@ -180,10 +290,9 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
         hipLaunchKernelGGL(msm_sort_local_kernel, dim3(pl.n_parts), dim3(SORT_LOCAL_BLOCK), 0, c->stream, items, part_off, pl, sorted, counts, offsets);
     }
     {
-        // heavy buckets (none with uniform scalars and a full top window: five empty launches): filed by a pass of their own and summed by
-        // passes 4b / 4c IN FRONT of the accumulate pass.  Behind it they were ~0.8 ms of a batched commit of MultilinearKZG::open (whose
-        // sparse top windows put 1/2^k of all points into each of a few buckets); on a second stream beside it they did not find a free
-        // slot for most of its duration -- its first workgroups walk the longest lists and hold every register of the chip.
+        // heavy buckets (none with uniform scalars: five empty launches): filed by a pass of their own and summed by passes 4b / 4c IN
+        // FRONT of the accumulate pass (on a second stream beside it they did not find a free slot for most of its duration -- its
+        // first workgroups walk the longest lists and hold every register of the chip)
         ProfScope ps(c, "msm_overflow", 0.0);
         ZK_HIP(c, hipMemsetAsync(ovf, 0, sizeof(MsmOverflow), c->stream));
         hipLaunchKernelGGL(msm_file_heavy_kernel, dim3((unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK)), dim3(MSM_BLOCK), 0, c->stream, offsets, counts,
@@ -202,8 +311,6 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
         hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bins);
         hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins, order);
     }
-    }   // front
-    if (!(phases & 2)) return ZKHIP_OK;
     {
         ProfScope ps(c, "msm_accumulate", 128.0 * (double)n);
         hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK)), dim3(MSM_BLOCK), 0,
@@ -216,23 +323,15 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     }
     {
         ProfScope ps(c, "msm_terms", 0.0);
-        uint32_t* row_s = tparts;
-        uint32_t* row_a = row_s + (size_t)pl.n_windows * rc_R * 64;
-        uint32_t* col_s = row_a + (size_t)pl.n_windows * rc_R * 64;
-        // one or two waves per tree, LDS sized to match: all trees of a commit are then resident at once (at 64 KiB per
-        // workgroup two shared a CU and the third waited: the new pass took as long as the old one)
-        const uint32_t rc_max = std::max(rc_R, rc_C);
-        const uint32_t tb = std::min<uint32_t>(128, std::max<uint32_t>(64, rc_max));
-        hipLaunchKernelGGL(msm_rowcol_kernel, dim3(pl.n_windows, 2 * rc_R + rc_C), dim3(tb), tb * 256, c->stream, segs, sega, pl, lo_bits,
-                           row_s, row_a, col_s);
-        hipLaunchKernelGGL(msm_rowcol_terms_kernel, dim3((unsigned)n_out), dim3(tb), tb * 256, c->stream, row_s, row_a, col_s, pl, lo_bits,
-                           terms);
+        const uint32_t tb = geo.tb, lds = tb > 64 ? tb * 256 : 0;     // lines of <= 64 values are summed inside a wave, without LDS
+        hipLaunchKernelGGL(msm_rowcol_kernel, dim3(pl.n_rcwg), dim3(tb), lds, c->stream, segs, sega, pl, rc);
+        hipLaunchKernelGGL(msm_rowcol_terms_kernel, dim3(pl.n_termwg), dim3(tb), lds, c->stream, rc, pl, terms);
     }
     ZK_HIP(c, hipGetLastError());
     ZK_TRY(c->reserve_msm_pin(slot, n_out * 192));
     ZK_HIP(c, hipMemcpyAsync(c->msm_pin[slot], terms, n_out * 192, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipEventRecord(c->msm_ev[slot], c->stream));
-    pend->pl = pl;
+    pend->geo = geo_p;
     pend->pr = pr;
     pend->n_out = n_out;
     pend->slot = slot;
@@ -240,31 +339,32 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
 }
 static int msm_finish(zkhip_ctx* c, const MsmPending& pend, uint64_t* h_out_xy, uint8_t* h_out_inf) {
     ZK_HIP(c, hipEventSynchronize(c->msm_ev[pend.slot]));
-    const MsmPlan& pl = pend.pl;
+    const MsmGeometry& geo = *pend.geo;
     const MsmProblems& pr = pend.pr;
     const uint64_t* h_terms = (const uint64_t*)c->msm_pin[pend.slot];
-    // host epilogue, per problem: sum over (window w, term t) of 2^exp * point
-    const size_t per_problem = (size_t)(pl.shared ? 1 : pl.w_per) * pl.n_terms;
+    // host epilogue, per problem: sum over its (set, term) points of 2^exp * point
     auto finish = [&](uint32_t j) {
-        std::vector<zkhost::Xyzz> pts(per_problem);
-        std::vector<uint32_t> exps(per_problem);
-        for (size_t i = 0; i < per_problem; ++i) {
-            std::memcpy(&pts[i], &h_terms[24 * (j * per_problem + i)], 192);
-            const uint32_t w = (uint32_t)(i / pl.n_terms), t = (uint32_t)(i % pl.n_terms);
-            exps[i] = w * pl.c + (t == 0 ? 0 : MSM_SEG_LOG + (t - 1));
+        std::vector<zkhost::Xyzz> pts;
+        std::vector<uint32_t> exps;
+        for (uint32_t s = geo.prob_set_first[j]; s < geo.prob_set_first[j + 1]; ++s) {
+            const uint32_t n_terms = (geo.sets[s].bits & 0xffu) - MSM_SEG_LOG;      // 1 + n_bits
+            for (uint32_t t = 0; t < n_terms; ++t) {
+                zkhost::Xyzz p;
+                std::memcpy(&p, &h_terms[24 * ((size_t)geo.sets[s].term_base + t)], 192);
+                pts.push_back(p);
+                exps.push_back(geo.set_exp[s] + (t == 0 ? 0 : MSM_SEG_LOG + (t - 1)));
+            }
         }
         zkhost::Xyzz res = zkhost::weighted_sum_pow2(pts, exps);
         h_out_inf[j] = zkhost::xyzz_to_affine(res, h_out_xy + 12 * (size_t)j) ? 0 : 1;
     };
-    // the chains of different problems are independent (~0.25 ms each): a batch spreads them over host threads
-    const uint32_t n_threads = std::min<uint32_t>(std::min<uint32_t>(pr.n, 32u), std::max(1u, std::thread::hardware_concurrency()));
-    if (n_threads <= 1) {
+    // the chains of different problems are independent (~0.25 ms each): a batch spreads them over the context's host threads, the
+    // largest problems (most points) first
+    ZkHostPool* pool = pr.n > 1 ? c->pool() : nullptr;
+    if (!pool) {
         for (uint32_t j = 0; j < pr.n; ++j) finish(j);
     } else {
-        std::vector<std::thread> pool;
-        for (uint32_t t = 0; t < n_threads; ++t)
-            pool.emplace_back([&, t] { for (uint32_t j = t; j < pr.n; j += n_threads) finish(j); });
-        for (auto& th : pool) th.join();
+        pool->run(pr.n, [&](unsigned j) { finish(j); });
     }
     return ZKHIP_OK;
 }
@@ -510,78 +610,58 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
         d_folded_inf = (const uint8_t*)(aux + o_finf);
     }
     uint64_t* d_q = (uint64_t*)(aux + o_q);
-    // All quotients first (a chain of n_vars small kernels on the caller's stream; none of them depends on a commit).  Then the commits,
-    // beside each other on side streams (workspace regions and pinned result slots of their own), in three groups by quotient length h:
-    //   h > 2^19          one commit each, two in flight (a commit of that size fills the chip by itself);
-    //   2^17 < h <= 2^19  ONE batched commit with 14-bit windows, and
-    //   2^13 < h <= 2^17  one with 12-bit windows: every pass of a batch runs once for all its problems, so each pass fills the chip and
-    //                     the bucket reduction (latency bound, ~0.6 ms whatever the size) is paid once per batch, not per round.  The
-    //                     window gives the largest problem of a batch lists of 64 points: the accumulate pass (one lane per bucket) takes
-    //                     as long as its longest lists (13-bit windows for all six rounds: 10 ms instead of 6.9), while every further
-    //                     bit doubles the buckets the reduction passes walk -- hence two batches, not one;
-    //   h <= 2^13         one batched commit with 10-bit windows.
-    // (Rounds 1-3 ran every round above 2^14 as a commit pipeline of its own, five beside each other: each paid the full reduction of 2^19
-    // buckets, and on three hardware queues every kernel ran at 2-3 x its stand-alone duration -- 8.5-9.2 ms at 2^20 against 3.2 ms for
-    // ONE commit of as many points; profiles/r03/open_last_call_trace.txt.  ZKHIP_OPEN_PIPELINES=1 restores that form for an A/B.)
+    // All quotients first (a chain of n_vars small kernels on the caller's stream; none of them depends on a commit).  Then the commits:
+    // every round with at most 2^19 quotient entries -- all twenty of a 2^20 opening -- as problems of ONE batched commit, each with a
+    // window width of its own (msm_build_geometry), on the caller's stream: one pass of every MSM kernel, each filling the chip, one
+    // bucket reduction.  Larger rounds (openings above 2^20) are commits of their own, two in flight on side streams beside the batch.
+    // (History.  Rounds 1-3: every round above 2^14 as a commit pipeline of its own, five beside each other on three hardware queues, each
+    // paying the full reduction of 2^19 buckets and every kernel running at 2-3 x its stand-alone duration beside the others' accumulate
+    // passes: 8.5-9.2 ms at 2^20 against 3.2 ms for ONE commit of as many points (profiles/r03/open_last_call_trace.txt).  Then three
+    // batches of one width each (14 / 12 / 10 bits) beside each other, fronts lined up: 6.7 ms -- their sparse top windows needed the
+    // heavy-bucket passes (0.6 ms) and the three reductions ended 0.9 ms after the last accumulate pass.  ZKHIP_OPEN_PIPELINES=1 runs the
+    // rounds above 2^14 as pipelines again for an A/B.)
     const bool pipelines = [] { const char* e = std::getenv("ZKHIP_OPEN_PIPELINES"); return e && e[0] == '1'; }();
-    size_t OPEN_BATCH_MAX = pipelines ? (size_t)1 << 14 : (size_t)1 << 13;   // pipelines, measured (2^20 / 2^22 open): 2^12 9.9 / 20.0 ms, 2^13 10.4 / 19.1, 2^14 8.1 / 19.6, 2^15 9.5 / 20.2, 2^16 10.0 / 19.5, 2^17 13.1 / 23.2
+    size_t OPEN_BATCH_MAX = pipelines ? (size_t)1 << 14 : (size_t)1 << 19;
     if (const char* e = std::getenv("ZKHIP_OPEN_BATCH_LOG")) {   // tuning aid (tools/perf_open.py)
         const int v = std::atoi(e);
         if (v >= 8 && v <= 20) OPEN_BATCH_MAX = (size_t)1 << v;
     }
-    const size_t OPEN_WIDE_MAX = pipelines ? 0 : (size_t)1 << 19;
-    size_t OPEN_MID_MAX = (size_t)1 << 17;
-    if (const char* e = std::getenv("ZKHIP_OPEN_MID_LOG")) {     // tuning aid: where the two wide batches are cut (>= 19: one batch)
-        const int v = std::atoi(e);
-        if (v >= 13 && v <= 20) OPEN_MID_MAX = (size_t)1 << v;
-    }
-    // result slot / stream of every group member: single commits rotate over `single_slots`
-    const int single_slots_pipe[5] = {0, 1, 2, 3, 4}, single_slots_grp[2] = {3, 4};
-    const int* single_slots = pipelines ? single_slots_pipe : single_slots_grp;
+    // result slot / stream of the single commits (they rotate over the slots); the batch has the last slot
     int NSLOT = pipelines ? 5 : 2;
     if (const char* e = std::getenv("ZKHIP_OPEN_SLOTS")) {   // tuning aid (tools/perf_open.py): fewer single commits beside each other
         const int v = std::atoi(e);
         if (v >= 1 && v <= NSLOT) NSLOT = v;
     }
-    // the small batch runs on the caller's stream, idle meanwhile (HIP streams share a few hardware queues -- three beside the caller's
-    // stream's on this runtime, streams {0, 5}, {1, 4}, {2, 3} of ctx.side pairwise -- and a queue runs its kernels in order)
-    const int sl_wide = 1, sl_mid = 0, sl_small = zkhip_ctx::MSM_SLOTS - 1;
+    const int sl_batch = zkhip_ctx::MSM_SLOTS - 1;
     const uint64_t* cur = d_evals;
     size_t cn = n, lvl_off = 0;
-    struct Group { MsmProblems pr = {}; size_t first_off = 0, total = 0; uint32_t first_round = 0; };
-    Group wide, mid, small;
+    MsmProblems batch = {};
+    size_t batch_first_off = 0;
+    uint32_t batch_first_round = 0;
     struct Large { uint32_t round; size_t off, h; };
     std::vector<Large> large;
-    ZK_TRY(c->ensure_side_streams());
-    // a batch may start as soon as ITS quotients are written (the two of the wide batch after the first two of the n_vars steps)
-    hipEvent_t const wide_ready = c->join_ev, mid_ready = c->serial_ev;
-    auto group_of = [&](size_t h) { return h > OPEN_BATCH_MAX && h > OPEN_WIDE_MAX ? 0 : h <= OPEN_BATCH_MAX ? 3 : h <= OPEN_MID_MAX ? 2 : 1; };
     for (uint32_t i = 0; i < n_vars; ++i) {
         FrArg z = {};
         std::memcpy(z.v, h_points + 4 * (size_t)i, 32);
         uint64_t* rem = (uint64_t*)(aux + ((i & 1) ? o_pong : o_ping));
         hipLaunchKernelGGL(open_step_kernel, dim3(mle_grid_stream(cn / 2)), dim3(MLE_BLOCK), 0, c->stream, cur, cn, z, d_q + 4 * lvl_off, rem);
         const size_t h = cn / 2;   // |q_i| = |S_i|
-        const int grp = group_of(h);
-        if (grp == 0) {
+        if (h > OPEN_BATCH_MAX) {
             large.push_back({i, lvl_off, h});
-        } else {                   // the rounds of a group follow each other, so its problems lie end to end
-            Group& g = grp == 3 ? small : grp == 2 ? mid : wide;
-            if (g.pr.n == 0) { g.first_off = lvl_off; g.first_round = i; }
-            g.pr.off[g.pr.n] = (uint32_t)(lvl_off - g.first_off);
-            g.pr.off[++g.pr.n] = (uint32_t)(lvl_off + h - g.first_off);
-            g.total = lvl_off + h - g.first_off;
+        } else {                   // the batched rounds follow each other, so the problems lie end to end
+            if (batch.n == 0) { batch_first_off = lvl_off; batch_first_round = i; }
+            batch.off[batch.n] = (uint32_t)(lvl_off - batch_first_off);
+            batch.off[++batch.n] = (uint32_t)(lvl_off + h - batch_first_off);
         }
-        if ((grp == 1 || grp == 2) && (i + 1 == n_vars || group_of(h / 2) != grp)) ZK_HIP(c, hipEventRecord(grp == 1 ? wide_ready : mid_ready, c->stream));
         lvl_off += h;
         cur = rem;
         cn = h;
     }
     ZK_HIP(c, hipGetLastError());
     // workspace: region k (k < NSLOT) is sized for the k-th single commit and reused by the commits k + NSLOT, k + 2 NSLOT, ... (each
-    // half the size of its predecessor in the region or less); the batches have regions of their own.  Reserved once, up front: a
+    // half the size of its predecessor in the region or less); the batch has a region of its own.  Reserved once, up front: a
     // commit that grew the workspace later would move it under the commits in flight.
-    size_t region_off[zkhip_ctx::MSM_SLOTS + 3] = {};
+    size_t region_off[zkhip_ctx::MSM_SLOTS + 1] = {};
     for (int k = 0; k < NSLOT; ++k) {
         size_t used = 0;
         if ((size_t)k < large.size()) {
@@ -592,16 +672,12 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
         }
         region_off[k + 1] = region_off[k] + ((used + 4095) & ~(size_t)4095);
     }
-    size_t group_region[4] = {region_off[NSLOT], 0, 0, 0};
     {
-        const Group* gs[3] = {&wide, &mid, &small};
-        for (int k = 0; k < 3; ++k) {
-            size_t used = 0;
-            if (gs[k]->pr.n) ZK_TRY(msm_enqueue(c, nullptr, nullptr, nullptr, gs[k]->total, gs[k]->pr, nullptr, 0, 0, 0, nullptr, &used));
-            group_region[k + 1] = group_region[k] + ((used + 4095) & ~(size_t)4095);
-        }
-        ZK_TRY(c->reserve_ws(group_region[3]));
+        size_t used = 0;
+        if (batch.n) ZK_TRY(msm_enqueue(c, nullptr, nullptr, nullptr, lvl_off - batch_first_off, batch, nullptr, 0, 0, 0, nullptr, &used));
+        ZK_TRY(c->reserve_ws(region_off[NSLOT] + used));
     }
+    ZK_TRY(c->ensure_side_streams());
     ZK_HIP(c, hipEventRecord(c->fork_ev, c->stream));
     MsmPending pend[zkhip_ctx::MSM_SLOTS];
     int pend_round[zkhip_ctx::MSM_SLOTS];
@@ -614,42 +690,20 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
     };
     hipStream_t const main_stream = c->stream;
     int rc = ZKHIP_OK;
-    // The batches in two phases: the fronts of all of them (sorts and bucket orders: many short kernels) beside each other, and only when
-    // ALL fronts are through, the backs -- a front beside another batch's accumulate pass, whose workgroups hold every slot of the chip for
-    // about a millisecond each, crawled (a one-workgroup scan 250 us, the order passes of the small batch 1.5 ms).
-    struct Lane { const Group* g; int sl; hipStream_t on; size_t region; hipEvent_t ready; };   // ready: the group's quotients are written
-    const bool wide_first = [] { const char* e = std::getenv("ZKHIP_OPEN_WIDE_FIRST"); return !(e && e[0] == '0'); }();   // tuning aid
-    const Lane lanes[3] = {{&wide, sl_wide, pipelines || wide_first ? c->side[sl_wide] : c->side_low[1], group_region[0], wide_ready},
-                           {&mid, sl_mid, pipelines ? c->side[sl_mid] : c->side_low[0], group_region[1], mid_ready},
-                           {&small, sl_small, pipelines ? c->side[sl_small] : main_stream, group_region[2], c->fork_ev}};
-    auto enqueue_lane = [&](const Lane& L, int phases) {
-        const Group& g = *L.g;
-        if (!g.pr.n || rc != ZKHIP_OK) return;
-        c->stream = L.on;                                  // msm_enqueue launches on the context's stream
-        rc = msm_enqueue(c, d_folded_xy + 12 * g.first_off, d_folded_inf + g.first_off, d_q + 4 * g.first_off, g.total, g.pr, nullptr, 0,
-                         L.region, L.sl, &pend[L.sl], nullptr, phases);
-        c->stream = main_stream;
-        if (rc == ZKHIP_OK && (phases & 2)) pend_round[L.sl] = (int)g.first_round;
-    };
-    for (const Lane& L : lanes) {
-        if (!L.g->pr.n || rc != ZKHIP_OK) continue;
-        if (L.on != main_stream && hipStreamWaitEvent(L.on, L.ready, 0) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
-        enqueue_lane(L, pipelines ? 3 : 1);
-        if (!pipelines && rc == ZKHIP_OK) {
-            if ((rc = c->ensure_msm_slot_events(L.sl)) != ZKHIP_OK) break;
-            if (hipEventRecord(c->msm_front[L.sl], L.on) != hipSuccess) rc = ZKHIP_ERR_HIP;
-        }
-    }
-    if (!pipelines) {
-        for (const Lane& L : lanes) {
-            if (!L.g->pr.n || rc != ZKHIP_OK) continue;
-            for (const Lane& O : lanes)
-                if (O.g->pr.n && O.sl != L.sl && hipStreamWaitEvent(L.on, c->msm_front[O.sl], 0) != hipSuccess) rc = ZKHIP_ERR_HIP;
-            enqueue_lane(L, 2);
+    if (batch.n) {
+        // on the caller's stream (nothing else runs there meanwhile); pipelines: on a side stream, and FIRST -- its chain of passes is the longest
+        hipStream_t on = pipelines ? c->side[sl_batch] : main_stream;
+        if (on != main_stream && hipStreamWaitEvent(on, c->fork_ev, 0) != hipSuccess) rc = ZKHIP_ERR_HIP;
+        if (rc == ZKHIP_OK) {
+            c->stream = on;                                // msm_enqueue launches on the context's stream
+            rc = msm_enqueue(c, d_folded_xy + 12 * batch_first_off, d_folded_inf + batch_first_off, d_q + 4 * batch_first_off,
+                             lvl_off - batch_first_off, batch, nullptr, 0, region_off[NSLOT], sl_batch, &pend[sl_batch], nullptr);
+            c->stream = main_stream;
+            if (rc == ZKHIP_OK) pend_round[sl_batch] = (int)batch_first_round;
         }
     }
     for (size_t j = 0; j < large.size() && rc == ZKHIP_OK; ++j) {
-        const int k = (int)(j % NSLOT), sl = single_slots[k];
+        const int sl = (int)(j % NSLOT);
         if ((rc = finish_slot(sl)) != ZKHIP_OK) break;     // commit j - NSLOT used this region, stream and result slot
         MsmProblems one = {};
         one.n = 1;
@@ -657,13 +711,12 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
         if (hipStreamWaitEvent(c->side[sl], c->fork_ev, 0) != hipSuccess) { rc = ZKHIP_ERR_HIP; break; }
         c->stream = c->side[sl];
         rc = msm_enqueue(c, d_folded_xy + 12 * large[j].off, d_folded_inf + large[j].off, d_q + 4 * large[j].off, large[j].h, one, nullptr, 0,
-                         region_off[k], sl, &pend[sl], nullptr);
+                         region_off[sl], sl, &pend[sl], nullptr);
         c->stream = main_stream;
         if (rc == ZKHIP_OK) pend_round[sl] = (int)large[j].round;
     }
-    // the remaining epilogues, each as soon as its commit's results have landed (a commit waited for in a fixed order kept the host idle
-    // while others were ready: 1.2 ms of epilogues behind the last kernel); every slot is drained even after an error, so that nothing
-    // is left running on a side stream
+    // the remaining epilogues, each as soon as its commit's results have landed; every slot is drained even after an error, so that
+    // nothing is left running on a side stream
     for (;;) {
         int left = 0, ready = -1;
         for (int k = 0; k < zkhip_ctx::MSM_SLOTS; ++k) {
@@ -677,8 +730,7 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
         if (rc == ZKHIP_OK) rc = r2;
     }
     if (rc != ZKHIP_OK) {
-        for (int k = 0; k < zkhip_ctx::MSM_SLOTS; ++k) hipStreamSynchronize(c->side[k]);   // a heavy-pass stream may still be running
-        for (int k = 0; k < 2; ++k) hipStreamSynchronize(c->side_low[k]);
+        for (int k = 0; k < zkhip_ctx::MSM_SLOTS; ++k) hipStreamSynchronize(c->side[k]);
         return rc;
     }
     // the last remainder is poly(z): `evaluation`, and what the reference checks it against (:84-86)

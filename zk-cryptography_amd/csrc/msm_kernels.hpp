@@ -31,38 +31,52 @@ namespace zk {
 constexpr int MSM_BLOCK = 256;
 constexpr int MSM_SEG_LOG = 3;              // L = 8 buckets per segment (L = 4 measured again with the row / column term sums: segment pass 0.30 instead of 0.33 ms, term sums 0.74 instead of 0.47 ms)
 constexpr int MSM_SEG = 1 << MSM_SEG_LOG;
-constexpr int MSM_MAX_WINDOWS = 64;
+constexpr int MSM_MAX_WINS = 1024;          // digit windows of all problems of one pass (the sort kernels keep their table in LDS)
 
-struct MsmPlan {
-    uint32_t c;          // window bits
-    uint32_t n_windows;  // windows in all = w_per * number of batched problems (one problem: ceil(256 / c))
-    uint32_t w_per;      // windows of one scalar = ceil(256 / c)
-    uint32_t shared;     // 1: the points come from a table holding 2^(c w) P for every window w, so the digits of all
-                         //    windows share ONE bucket set (n_windows = 1) and an item names table entry w * stride + i
-    uint32_t stride;     // shared: entries per window in the table
-    uint32_t nb;         // buckets per window = 2^(c-1); bucket i holds digit magnitude i+1
-    uint32_t ns;         // segments per window = nb / L
-    uint32_t n_bits;     // bits of the segment index = c - 1 - log2 L
-    uint32_t n_terms;    // 1 + n_bits
-    uint32_t sub_bits;   // HIGH bits of the bucket index, resolved inside a partition (<= 8)
-    uint32_t parts_pw;   // partitions per window = nb >> sub_bits: a partition holds the buckets with the same LOW part_bits bits, so
-    uint32_t part_bits;  //   a sparse top window (few distinct digits) still spreads over min(#digits, parts_pw) partitions
-    uint32_t n_parts;    // n_windows * parts_pw (<= SORT_MAX_PARTS)
+// Geometry of one pass over one or several problems (built on the host: msm_build_geometry, msm.hip).  A problem's 256 scalar bits
+// are cut into DIGIT WINDOWS of its own widths -- two widths one bit apart, so that they add up to exactly 256 and no window is sparse
+// (a 255-bit scalar leaves the top window one spare bit: its digit never carries out) -- and every window owns a BUCKET SET of
+// 2^(bits-1) buckets (bucket i holds digit magnitude i+1).  With the shifted-SRS table all windows of the one problem share one set.
+struct MsmWin {
+    uint32_t part_base;   // first sort partition of its bucket set
+    uint32_t entry_off;   // shifted-SRS table: w * stride, added to the point index (0 otherwise)
+    uint32_t bits;        // byte 0: window width c (digits in [-2^(c-1), 2^(c-1)]); byte 1: part_bits of its bucket set
+    uint32_t pad;
 };
+struct MsmSet {
+    uint32_t bucket_base; // first bucket, a multiple of MSM_SEG
+    uint32_t part_base;   // first sort partition: a partition holds the buckets with the same LOW part_bits bits of the index, so a
+    uint32_t bits;        //   set with few distinct digits still spreads over its partitions.  byte 0: c, byte 1: part_bits
+    uint32_t term_base;   // its c - 3 (set, term) points start here
+    uint32_t rc_base;     // its row / column sums (2 R + C points) start here
+    uint32_t rcwg_base;   // its first workgroup in msm_rowcol_kernel's grid
+    uint32_t termwg_base; // ... and in msm_rowcol_terms_kernel's
+};
+struct MsmPlan {
+    uint32_t n_sets, n_buckets, n_parts, n_terms, n_rc, n_rcwg, n_termwg;
+    uint32_t n_wins;      // digit windows in all
+    uint32_t shared;      // 1: shifted-SRS table, one bucket set
+    const MsmWin* wins;   // device tables
+    const MsmSet* sets;
+    const uint16_t* part_set;   // partition -> bucket set
+    const uint16_t* rcwg_set;   // msm_rowcol_kernel workgroup -> bucket set
+    const uint16_t* termwg_set; // msm_rowcol_terms_kernel workgroup -> bucket set
+};
+__device__ __forceinline__ uint32_t msm_set_c(const MsmSet& s) { return s.bits & 0xffu; }
+__device__ __forceinline__ uint32_t msm_set_part_bits(const MsmSet& s) { return (s.bits >> 8) & 0xffu; }
 
-// Signed base-2^c digit stream of a canonical scalar (8 x u32, little endian); digits lie in [-nb, nb].
-// The scalar is consumed by shifting (no dynamically indexed registers).
+// Signed digit stream of a canonical scalar (8 x u32, little endian): next(c) takes the next c bits (1 <= c <= 31) and returns a
+// digit in [-2^(c-1), 2^(c-1)].  The scalar is consumed by shifting (no dynamically indexed registers).
 struct DigitStream {
     Fr v;
     uint32_t carry;
     __device__ __forceinline__ explicit DigitStream(const Fr& canon) : v(canon), carry(0) {}
-    __device__ __forceinline__ int32_t next(const MsmPlan& pl) {
-        const uint32_t c = pl.c;
+    __device__ __forceinline__ int32_t next(uint32_t c) {
         uint32_t raw = (v.l[0] & ((1u << c) - 1)) + carry;
 #pragma unroll
         for (int i = 0; i < 7; ++i) v.l[i] = (v.l[i] >> c) | (v.l[i + 1] << (32 - c));
         v.l[7] >>= c;
-        if (raw > pl.nb) { carry = 1; return (int32_t)raw - (int32_t)(1u << c); }
+        if (raw > (1u << (c - 1))) { carry = 1; return (int32_t)raw - (int32_t)(1u << c); }
         carry = 0;
         return (int32_t)raw;
     }
@@ -124,42 +138,57 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_order_scatter_kernel(con
 constexpr int SORT_TILE = 2048;          // scalars per workgroup tile (8 per lane)
 constexpr int SORT_MAX_PARTS = 4096;
 
-// Batched commits (several independent (points, scalars) problems laid end to end, e.g. the small levels of
-// MultilinearKZG::open): problem j owns the entries [off[j], off[j+1]) and the windows [j * w_per, (j+1) * w_per).
+// Batched commits (several independent (points, scalars) problems laid end to end, e.g. the rounds of
+// MultilinearKZG::open): problem j owns the entries [off[j], off[j+1]) and the digit windows [win_first[j], win_first[j+1]).
 constexpr int MSM_MAX_PROBLEMS = 64;
 struct MsmProblems {
     uint32_t n;
     uint32_t off[MSM_MAX_PROBLEMS + 1];
+    uint16_t win_first[MSM_MAX_PROBLEMS + 1];
 };
-__device__ __forceinline__ uint32_t msm_problem_of(const MsmProblems& pr, uint32_t i) {
-    uint32_t lo = 0, hi = pr.n;            // off[lo] <= i < off[hi]
+// the problems' ranges and the digit windows in LDS (read per scalar / per (scalar, window) by both passes over the scalars; the
+// kernel argument itself, indexed by a value that differs from lane to lane, is read through a loop over the lanes' values)
+struct MsmSortTables {
+    uint4 wl[MSM_MAX_WINS];
+    uint32_t off[MSM_MAX_PROBLEMS + 1];
+    uint32_t win_first[MSM_MAX_PROBLEMS + 1];
+};
+__device__ __forceinline__ void msm_load_tables(const MsmPlan& pl, const MsmProblems& pr, MsmSortTables& t) {
+    const uint4* src = reinterpret_cast<const uint4*>(pl.wins);
+    for (uint32_t i = threadIdx.x; i < pl.n_wins; i += MSM_BLOCK) t.wl[i] = src[i];
+    for (uint32_t i = threadIdx.x; i <= pr.n; i += MSM_BLOCK) { t.off[i] = pr.off[i]; t.win_first[i] = pr.win_first[i]; }
+}
+__device__ __forceinline__ uint32_t msm_problem_of(const MsmSortTables& t, uint32_t n_problems, uint32_t i) {
+    uint32_t lo = 0, hi = n_problems;      // off[lo] <= i < off[hi]
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (i >= pr.off[mid]) lo = mid; else hi = mid;
+        if (i >= t.off[mid]) lo = mid; else hi = mid;
     }
     return lo;
 }
-
-__device__ __forceinline__ uint32_t msm_partition_of(uint32_t w, uint32_t mag, const MsmPlan& pl) {
-    return w * pl.parts_pw + ((mag - 1) & (pl.parts_pw - 1));
+__device__ __forceinline__ uint32_t msm_partition_of(const uint4& w, uint32_t mag) {   // w = an MsmWin
+    return w.x + ((mag - 1) & ((1u << ((w.z >> 8) & 0xffu)) - 1));
 }
 
 static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_count_kernel(const uint64_t* __restrict__ scalars,
                                                                           const uint8_t* __restrict__ inf, size_t n, MsmPlan pl,
                                                                           MsmProblems pr, uint32_t* __restrict__ wg_counts) {
     __shared__ uint32_t local[SORT_MAX_PARTS];
+    __shared__ MsmSortTables tab;
     for (uint32_t i = threadIdx.x; i < pl.n_parts; i += MSM_BLOCK) local[i] = 0;
+    msm_load_tables(pl, pr, tab);
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * SORT_TILE;
     for (uint32_t u = 0; u < SORT_TILE / MSM_BLOCK; ++u) {
         const size_t i = base + u * MSM_BLOCK + threadIdx.x;
         if (i >= n || (inf && inf[i])) continue;
         DigitStream ds(load_fr(scalars, i).from_mont());
-        const uint32_t wbase = pr.n > 1 ? msm_problem_of(pr, (uint32_t)i) * pl.w_per : 0u;
-        for (uint32_t w = 0; w < pl.w_per; ++w) {
-            const int32_t d = ds.next(pl);
+        const uint32_t j = pr.n > 1 ? msm_problem_of(tab, pr.n, (uint32_t)i) : 0u;
+        for (uint32_t v = tab.win_first[j], v_end = tab.win_first[j + 1]; v < v_end; ++v) {
+            const uint4 w = tab.wl[v];
+            const int32_t d = ds.next(w.z & 0xffu);
             if (d == 0) continue;
-            atomicAdd(&local[msm_partition_of(pl.shared ? 0u : wbase + w, d < 0 ? (uint32_t)(-d) : (uint32_t)d, pl)], 1u);
+            atomicAdd(&local[msm_partition_of(w, d < 0 ? (uint32_t)(-d) : (uint32_t)d)], 1u);
         }
     }
     __syncthreads();
@@ -228,23 +257,25 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_scatter_kernel(cons
                                                                             const uint32_t* __restrict__ part_off,
                                                                             uint2* __restrict__ items) {
     __shared__ uint32_t cur[SORT_MAX_PARTS];
+    __shared__ MsmSortTables tab;
     for (uint32_t i = threadIdx.x; i < pl.n_parts; i += MSM_BLOCK)
         cur[i] = part_off[i] + wg_bases[(size_t)blockIdx.x * pl.n_parts + i];
+    msm_load_tables(pl, pr, tab);
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * SORT_TILE;
     for (uint32_t u = 0; u < SORT_TILE / MSM_BLOCK; ++u) {
         const size_t i = base + u * MSM_BLOCK + threadIdx.x;
         if (i >= n || (inf && inf[i])) continue;
         DigitStream ds(load_fr(scalars, i).from_mont());
-        const uint32_t wbase = pr.n > 1 ? msm_problem_of(pr, (uint32_t)i) * pl.w_per : 0u;
-        for (uint32_t w = 0; w < pl.w_per; ++w) {
-            const int32_t d = ds.next(pl);
+        const uint32_t j = pr.n > 1 ? msm_problem_of(tab, pr.n, (uint32_t)i) : 0u;
+        for (uint32_t v = tab.win_first[j], v_end = tab.win_first[j + 1]; v < v_end; ++v) {
+            const uint4 w = tab.wl[v];
+            const int32_t d = ds.next(w.z & 0xffu);
             if (d == 0) continue;
             const bool neg = d < 0;
             const uint32_t mag = neg ? (uint32_t)(-d) : (uint32_t)d;
-            const uint32_t pos = atomicAdd(&cur[msm_partition_of(pl.shared ? 0u : wbase + w, mag, pl)], 1u);
-            const uint32_t entry = pl.shared ? w * pl.stride + (uint32_t)i : (uint32_t)i;
-            items[pos] = make_uint2(entry | (neg ? 0x80000000u : 0u), (mag - 1) >> pl.part_bits);
+            const uint32_t pos = atomicAdd(&cur[msm_partition_of(w, mag)], 1u);
+            items[pos] = make_uint2((w.y + (uint32_t)i) | (neg ? 0x80000000u : 0u), (mag - 1) >> ((w.z >> 8) & 0xffu));
         }
     }
 }
@@ -275,7 +306,9 @@ static __global__ __launch_bounds__(SORT_LOCAL_BLOCK) void msm_sort_local_kernel
     __shared__ uint32_t scan[256];
     const uint32_t p = blockIdx.x;
     const uint32_t lo = part_off[p], hi = part_off[p + 1];
-    const uint32_t n_sub = 1u << pl.sub_bits;
+    const MsmSet set = pl.sets[pl.part_set[p]];
+    const uint32_t part_bits = msm_set_part_bits(set);
+    const uint32_t n_sub = 1u << (msm_set_c(set) - 1 - part_bits);      // the partition's buckets: the high bits of the index (<= 8)
     if (threadIdx.x < 256) bins[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t q = lo + threadIdx.x; q < hi; q += SORT_LOCAL_BLOCK) msm_lds_rank(bins, items[q].y);
@@ -292,8 +325,7 @@ static __global__ __launch_bounds__(SORT_LOCAL_BLOCK) void msm_sort_local_kernel
     }
     if (threadIdx.x < n_sub) {
         const uint32_t excl = scan[threadIdx.x] - v;
-        const uint32_t w = p / pl.parts_pw, low = p % pl.parts_pw;
-        const uint32_t bucket = w * pl.nb + (threadIdx.x << pl.part_bits) + low;
+        const uint32_t bucket = set.bucket_base + (threadIdx.x << part_bits) + (p - set.part_base);
         counts[bucket] = v;
         offsets[bucket] = lo + excl;
         bins[threadIdx.x] = lo + excl;      // becomes the write cursor
@@ -429,6 +461,27 @@ __device__ __forceinline__ void msm_block_tree_sum(G1XyzzU& acc, uint32_t width,
     }
 }
 
+// the same inside ONE wave without LDS or barriers: aligned groups of `width` lanes (a power of two <= 64) are summed independently,
+// the result of a group is in its first lane.  The operands travel by ds_bpermute (56 words per level, against ~7 k instructions per addition).
+__device__ __forceinline__ G1XyzzU msm_shfl_down(const G1XyzzU& v, uint32_t d) {
+    G1XyzzU o;
+#pragma unroll
+    for (int i = 0; i < FqU::N; ++i) {
+        o.x.l[i] = __shfl_down(v.x.l[i], d, 64);
+        o.y.l[i] = __shfl_down(v.y.l[i], d, 64);
+        o.zz.l[i] = __shfl_down(v.zz.l[i], d, 64);
+        o.zzz.l[i] = __shfl_down(v.zzz.l[i], d, 64);
+    }
+    return o;
+}
+__device__ __forceinline__ void msm_wave_tree_sum(G1XyzzU& acc, uint32_t width) {
+    const uint32_t pos = threadIdx.x & (width - 1);
+    for (uint32_t d = width >> 1; d >= 1; d >>= 1) {
+        G1XyzzU o = msm_shfl_down(acc, d);
+        if (pos < d) g1u_add(acc, o);
+    }
+}
+
 // pass 4b: one workgroup per level-0 record (fixed grid; the list length is read on the device)
 static __global__ __launch_bounds__(MSM_BLOCK) void msm_heavy_points_kernel(const uint32_t* __restrict__ points,
                                                                      const uint32_t* __restrict__ sorted,
@@ -494,69 +547,96 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_segment_kernel(const uin
     store_xyzz_u(seg_a, s, acc);
 }
 
-// pass 6: one workgroup per (window, term).  term 0: sum of A_s over the window's segments;
-// term 1+k: sum of S_s over the segments whose index has bit k set.  The result leaves in the arkworks layout
-// (XYZZ, 4 x 48 B) for the host epilogue.
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_terms_kernel(const uint32_t* __restrict__ seg_s,
-                                                              const uint32_t* __restrict__ seg_a, MsmPlan pl,
-                                                              uint64_t* __restrict__ terms) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
-    uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);   // MSM_BLOCK x 64 u32
-    const uint32_t w = blockIdx.x / pl.n_terms, t = blockIdx.x % pl.n_terms;
-    const uint32_t* src = (t == 0 ? seg_a : seg_s) + (size_t)w * pl.ns * 64;
-    G1XyzzU acc = G1XyzzU::identity();
-    for (uint32_t s = threadIdx.x; s < pl.ns; s += MSM_BLOCK) {
-        if (t != 0 && !((s >> (t - 1)) & 1)) continue;
-        G1XyzzU v = load_xyzz_u(src, s);
-        g1u_add(acc, v);
-    }
-    store_xyzz_u(lds, threadIdx.x, acc);
-    __syncthreads();
-    for (int d = MSM_BLOCK / 2; d >= 1; d >>= 1) {
-        if ((int)threadIdx.x < d) {
-            G1XyzzU o = load_xyzz_u(lds, threadIdx.x + d);
-            g1u_add(acc, o);
-            store_xyzz_u(lds, threadIdx.x, acc);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        uint64_t* o = terms + 24 * (size_t)blockIdx.x;
-        store_fq(o, fqu_to_ark(acc.x));
-        store_fq(o + 6, fqu_to_ark(acc.y));
-        store_fq(o + 12, fqu_to_ark(acc.zz));
-        store_fq(o + 18, fqu_to_ark(acc.zzz));
-    }
-}
-
-// pass 6 by rows and columns: write the segment index as s = h C + l (C = 2^lo_bits columns, R = ns / C rows).  Then
-//     T_k = sum_{s: bit k} S_s  =  sum_{l: bit k} colS_l            (k < lo_bits),   colS_l = sum_h S_{h C + l}
-//                               =  sum_{h: bit k - lo_bits} rowS_h  (k >= lo_bits),  rowS_h = sum_l S_{h C + l}
-// and sum_s A_s = sum_h rowA_h: 3 ns additions in R + R + C independent workgroup trees, then n_terms trees over <= max(R, C)
+// pass 6, per bucket set (ns = 2^n_bits segments, n_bits = c - 1 - log2 L): the set's total is sum_s A_s + L sum_k 2^k T_k with
+// T_k = sum_{s: bit k} S_s.  By rows and columns: write the segment index as s = h C + l (C = 2^lo_bits columns, R = ns / C rows).  Then
+//     T_k = sum_{l: bit k} colS_l            (k < lo_bits),   colS_l = sum_h S_{h C + l}
+//         = sum_{h: bit k - lo_bits} rowS_h  (k >= lo_bits),  rowS_h = sum_l S_{h C + l}
+// and sum_s A_s = sum_h rowA_h: 3 ns additions in R + R + C independent trees, then 1 + n_bits trees over <= max(R, C)
 // values -- instead of ns (1 + n_bits / 2) additions in chains of a dozen and trees of 256 (the shared bucket set of the
 // table path: 2^16 segments, 0.56 ms of mostly idle chip).  Every addition is ~7 k instructions (~15 us on a lone wave), so
 // what counts is the depth: log2 C + log2 R tree levels.
+// A tree of <= 64 values is summed inside one wave (msm_wave_tree_sum: no LDS, so the waves of a commit are all resident at once --
+// with a 16 KiB tree buffer per workgroup ten fitted a CU and the 3072 trees of a 2^20-point commit ran in two rounds), and a wave
+// takes as many lines (rows / columns) of its set as fit: 64 / width.  Wider lines (the shared bucket set of the table path) keep a
+// workgroup each and the LDS tree.  The grid is flat over the sets, which differ in size: rcwg_set names the set of a workgroup.
+// A lane first adds MSM_LINE_Q values of its line one after the other, then the lanes of the line form the tree: a tree level costs a
+// whole wave one addition however few lanes still take part, so a 64-value line as 16 lanes x 4 values is 3 + 4 additions for FOUR lines
+// per wave instead of 6 for one (the row / column pass of a 2^20-point commit: 768 waves, each alone on a SIMD, instead of 3072).
+constexpr uint32_t MSM_LINE_Q = 4;
+__host__ __device__ __forceinline__ uint32_t msm_line_q(uint32_t count) { return count >= 4 * MSM_LINE_Q ? MSM_LINE_Q : 1; }
+constexpr uint32_t MSM_TERMS_PER_WG = 4;     // (set, term) trees per wave of msm_rowcol_terms_kernel: 16 lanes each
+struct MsmSetShape { uint32_t n_bits, lo_bits, C, R, row_lines, col_lines, row_wgs, col_wgs, term_wgs; };
+__host__ __device__ __forceinline__ MsmSetShape msm_set_shape_c(uint32_t c) {
+    MsmSetShape sh;
+    sh.n_bits = c - 1 - MSM_SEG_LOG;
+    sh.lo_bits = sh.n_bits / 2;
+    sh.C = 1u << sh.lo_bits;
+    sh.R = (1u << sh.n_bits) >> sh.lo_bits;
+    sh.row_lines = sh.C <= 64 ? 64 / (sh.C / msm_line_q(sh.C)) : 1;          // rows (C values each) per workgroup
+    sh.col_lines = sh.R <= 64 ? 64 / (sh.R / msm_line_q(sh.R)) : 1;          // columns (R values each) per workgroup
+    sh.row_wgs = (2 * sh.R + sh.row_lines - 1) / sh.row_lines;   // the R rows of S, then the R rows of A
+    sh.col_wgs = (sh.C + sh.col_lines - 1) / sh.col_lines;
+    // (set, term) trees: <= max(R, C) values each; four per workgroup while a tree fits 16 lanes x 4 values, else one
+    sh.term_wgs = (sh.R <= 64 && sh.C <= 64) ? (1 + sh.n_bits + MSM_TERMS_PER_WG - 1) / MSM_TERMS_PER_WG : 1 + sh.n_bits;
+    return sh;
+}
 static __global__ __launch_bounds__(MSM_BLOCK) void msm_rowcol_kernel(const uint32_t* __restrict__ seg_s, const uint32_t* __restrict__ seg_a,
-                                                                    MsmPlan pl, uint32_t lo_bits, uint32_t* __restrict__ row_s,
-                                                                    uint32_t* __restrict__ row_a, uint32_t* __restrict__ col_s) {
+                                                                    MsmPlan pl, uint32_t* __restrict__ rc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
-    uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);   // blockDim.x x 64 u32
+    uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);   // blockDim.x x 64 u32 when blockDim.x > 64 (wide lines), else unused
     __builtin_amdgcn_s_setprio(2);
-    const uint32_t C = 1u << lo_bits, R = pl.ns >> lo_bits;
-    const uint32_t w = blockIdx.x, b = blockIdx.y;
+    const MsmSet set = pl.sets[pl.rcwg_set[blockIdx.x]];
+    const MsmSetShape sh = msm_set_shape_c(msm_set_c(set));
+    const uint32_t C = sh.C, R = sh.R, b = blockIdx.x - set.rcwg_base;
+    const size_t seg0 = set.bucket_base >> MSM_SEG_LOG;
+    uint32_t* row_s = rc + (size_t)set.rc_base * 64;    // R row sums of S, R of A, C column sums of S
+    uint32_t* row_a = row_s + (size_t)R * 64;
+    uint32_t* col_s = row_a + (size_t)R * 64;
+    const bool rows = b < sh.row_wgs;
+    const uint32_t count = rows ? C : R;                 // values per line
+    if (count <= 64) {
+        // packed: lane = (line of this workgroup, position in the line), q values per lane; one wave
+        if (threadIdx.x >= 64) return;
+        const uint32_t q = msm_line_q(count), lpl = count / q;      // lanes per line
+        const uint32_t lines = rows ? sh.row_lines : sh.col_lines;
+        const uint32_t line = (rows ? b : b - sh.row_wgs) * lines + threadIdx.x / lpl, pos = threadIdx.x & (lpl - 1);
+        const uint32_t n_lines = rows ? 2 * R : C;
+        G1XyzzU acc = G1XyzzU::identity();
+        uint32_t* dst = nullptr;
+        if (line < n_lines) {
+            const uint32_t* src;
+            size_t first, stride;
+            if (rows) {
+                const uint32_t h = line < R ? line : line - R;
+                src = (line < R ? seg_s : seg_a) + seg0 * 64; first = (size_t)h * C + (size_t)pos * q; stride = 1;
+                dst = (line < R ? row_s : row_a) + (size_t)h * 64;
+            } else {
+                src = seg_s + seg0 * 64; first = (size_t)pos * q * C + line; stride = C;
+                dst = col_s + (size_t)line * 64;
+            }
+            acc = load_xyzz_u(src, first);
+            for (uint32_t u = 1; u < q; ++u) {
+                G1XyzzU v = load_xyzz_u(src, first + u * stride);
+                g1u_add(acc, v);
+            }
+        }
+        msm_wave_tree_sum(acc, lpl);
+        if (dst && pos == 0) store_xyzz_u(dst, 0, acc);
+        return;
+    }
     const uint32_t* src;
-    uint32_t first, stride, count;
+    uint32_t first, stride;
     uint32_t* dst;
-    if (b < 2 * R) {                       // a row of S (b < R) or of A
+    if (rows) {                            // a row of S (b < R) or of A
         const uint32_t h = b < R ? b : b - R;
-        src = (b < R ? seg_s : seg_a) + (size_t)w * pl.ns * 64;
-        first = h * C; stride = 1; count = C;
-        dst = (b < R ? row_s : row_a) + ((size_t)w * R + h) * 64;
+        src = (b < R ? seg_s : seg_a) + seg0 * 64;
+        first = h * C; stride = 1;
+        dst = (b < R ? row_s : row_a) + (size_t)h * 64;
     } else {                               // a column of S
-        const uint32_t l = b - 2 * R;
-        src = seg_s + (size_t)w * pl.ns * 64;
-        first = l; stride = C; count = R;
-        dst = col_s + ((size_t)w * C + l) * 64;
+        const uint32_t l = b - sh.row_wgs;
+        src = seg_s + seg0 * 64;
+        first = l; stride = C;
+        dst = col_s + (size_t)l * 64;
     }
     G1XyzzU acc = G1XyzzU::identity();
     for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
@@ -568,35 +648,49 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_rowcol_kernel(const uint
     msm_block_tree_sum(acc, width, lds);
     if (threadIdx.x == 0) store_xyzz_u(dst, 0, acc);
 }
-// ... then one workgroup per (window, term); the result leaves in the arkworks layout (XYZZ, 4 x 48 B) for the host epilogue
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_rowcol_terms_kernel(const uint32_t* __restrict__ row_s, const uint32_t* __restrict__ row_a,
-                                                                          const uint32_t* __restrict__ col_s, MsmPlan pl, uint32_t lo_bits,
-                                                                          uint64_t* __restrict__ terms) {
+// ... then one tree per (set, term): term 0 = sum_s A_s, term 1 + k = T_k; the result leaves in the arkworks layout (XYZZ, 4 x 48 B)
+// for the host epilogue.  Four trees of a set per wave (16 lanes x <= 4 selected values each) while R, C <= 64; a workgroup with the LDS
+// tree per term otherwise.  termwg_set names the set of a workgroup.
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_rowcol_terms_kernel(const uint32_t* __restrict__ rc, MsmPlan pl, uint64_t* __restrict__ terms) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
     uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);
     __builtin_amdgcn_s_setprio(2);
-    const uint32_t C = 1u << lo_bits, R = pl.ns >> lo_bits;
-    const uint32_t w = blockIdx.x / pl.n_terms, t = blockIdx.x % pl.n_terms;
+    const MsmSet set = pl.sets[pl.termwg_set[blockIdx.x]];
+    const MsmSetShape sh = msm_set_shape_c(msm_set_c(set));
+    const uint32_t C = sh.C, R = sh.R, lo_bits = sh.lo_bits;
+    const bool packed = R <= 64 && C <= 64;
+    if (packed && threadIdx.x >= 64) return;
+    const uint32_t lanes = packed ? 64 / MSM_TERMS_PER_WG : blockDim.x;         // lanes of one tree
+    const uint32_t t = packed ? (blockIdx.x - set.termwg_base) * MSM_TERMS_PER_WG + threadIdx.x / lanes : blockIdx.x - set.termwg_base;
+    const uint32_t pos = packed ? threadIdx.x & (lanes - 1) : threadIdx.x;
+    const bool live = t < 1 + sh.n_bits;
+    const uint32_t* row_s = rc + (size_t)set.rc_base * 64;
+    const uint32_t* row_a = row_s + (size_t)R * 64;
+    const uint32_t* col_s = row_a + (size_t)R * 64;
     const uint32_t* src;
     uint32_t count, bit = 0;
-    bool select = t != 0;
-    if (t == 0) { src = row_a + (size_t)w * R * 64; count = R; }
-    else if (t - 1 < lo_bits) { src = col_s + (size_t)w * C * 64; count = C; bit = t - 1; }
-    else { src = row_s + (size_t)w * R * 64; count = R; bit = t - 1 - lo_bits; }
+    const bool select = t != 0;
+    if (t == 0) { src = row_a; count = R; }
+    else if (t - 1 < lo_bits) { src = col_s; count = C; bit = t - 1; }
+    else { src = row_s; count = R; bit = t - 1 - lo_bits; }
     G1XyzzU acc = G1XyzzU::identity();
     // selected entries: every one (term 0), or those with `bit` set -- the j-th of them is j with a one inserted at `bit`
-    const uint32_t n_sel = select ? count >> 1 : count;
-    for (uint32_t j = threadIdx.x; j < n_sel; j += blockDim.x) {
+    const uint32_t n_sel = live ? (select ? count >> 1 : count) : 0;
+    for (uint32_t j = pos; j < n_sel; j += lanes) {
         uint32_t i = j;
         if (select) i = ((j >> bit) << (bit + 1)) | (1u << bit) | (j & ((1u << bit) - 1));
         G1XyzzU v = load_xyzz_u(src, i);
         g1u_add(acc, v);
     }
-    uint32_t width = 1;
-    while (width < n_sel && width < blockDim.x) width <<= 1;
-    msm_block_tree_sum(acc, width, lds);
-    if (threadIdx.x == 0) {
-        uint64_t* o = terms + 24 * (size_t)blockIdx.x;
+    if (packed) {
+        msm_wave_tree_sum(acc, lanes);
+    } else {
+        uint32_t width = 1;
+        while (width < n_sel && width < blockDim.x) width <<= 1;
+        msm_block_tree_sum(acc, width, lds);
+    }
+    if (live && pos == 0) {
+        uint64_t* o = terms + 24 * ((size_t)set.term_base + t);
         store_fq(o, fqu_to_ark(acc.x));
         store_fq(o + 6, fqu_to_ark(acc.y));
         store_fq(o + 12, fqu_to_ark(acc.zz));
@@ -630,62 +724,6 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_shift_points_kernel(cons
     store_fq(o + 6, fqu_to_ark(acc.y));
     store_fq(o + 12, fqu_to_ark(acc.zz));
     store_fq(o + 18, fqu_to_ark(acc.zzz));
-}
-
-// pass 6 for windows with many segments (one shared bucket set has 2^16 of them): first every workgroup sums `sel`
-// SELECTED segments of its (window, term) (blockIdx.x), chunk blockIdx.y -- term 0 selects every segment, term 1+k the
-// segments whose index has bit k set (the j-th of them is j with a one inserted at bit k), so every lane adds the same
-// number of points whatever the term.  These kernels are chains of ~7 k-instruction additions: a wave alone on a SIMD
-// issues nearly as fast as the SIMD can, so what counts is the length of the chain (serial additions + tree levels) and
-// that waves do not pile up on one SIMD; the launch asks for more than half of a CU's LDS so that two workgroups never
-// share a CU at the same time.
-constexpr uint32_t MSM_TERMS_LDS = 96 * 1024;
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_terms_part_kernel(const uint32_t* __restrict__ seg_s,
-                                                                   const uint32_t* __restrict__ seg_a, MsmPlan pl, uint32_t sel,
-                                                                   uint32_t* __restrict__ parts) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
-    uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);
-    const uint32_t w = blockIdx.x / pl.n_terms, t = blockIdx.x % pl.n_terms;
-    const uint32_t n_sel = t == 0 ? pl.ns : pl.ns >> 1;                    // selected segments of this term
-    const uint32_t first = blockIdx.y * sel;
-    if (first >= n_sel) return;
-    const uint32_t* src = (t == 0 ? seg_a : seg_s) + (size_t)w * pl.ns * 64;
-    G1XyzzU acc = G1XyzzU::identity();
-    for (uint32_t j = first + threadIdx.x; j < first + sel && j < n_sel; j += blockDim.x) {
-        uint32_t s = j;
-        if (t != 0) {
-            const uint32_t k = t - 1, low = j & ((1u << k) - 1);
-            s = ((j >> k) << (k + 1)) | (1u << k) | low;
-        }
-        G1XyzzU v = load_xyzz_u(src, s);
-        g1u_add(acc, v);
-    }
-    msm_block_tree_sum(acc, blockDim.x, lds);
-    if (threadIdx.x == 0) store_xyzz_u(parts, (size_t)blockIdx.x * gridDim.y + blockIdx.y, acc);
-}
-// ... then one workgroup per (window, term) sums the chunk sums and converts to the arkworks layout for the host
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_terms_final_kernel(const uint32_t* __restrict__ parts, uint32_t row, MsmPlan pl,
-                                                                    uint32_t sel, uint64_t* __restrict__ terms) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
-    uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);
-    const uint32_t t = blockIdx.x % pl.n_terms;
-    const uint32_t n_sel = t == 0 ? pl.ns : pl.ns >> 1;
-    const uint32_t n_chunks = (n_sel + sel - 1) / sel;
-    G1XyzzU acc = G1XyzzU::identity();
-    for (uint32_t k = threadIdx.x; k < n_chunks; k += MSM_BLOCK) {
-        G1XyzzU v = load_xyzz_u(parts, (size_t)blockIdx.x * row + k);
-        g1u_add(acc, v);
-    }
-    uint32_t width = 1;
-    while (width < n_chunks && width < (uint32_t)MSM_BLOCK) width <<= 1;
-    msm_block_tree_sum(acc, width, lds);
-    if (threadIdx.x == 0) {
-        uint64_t* o = terms + 24 * (size_t)blockIdx.x;
-        store_fq(o, fqu_to_ark(acc.x));
-        store_fq(o + 6, fqu_to_ark(acc.y));
-        store_fq(o + 12, fqu_to_ark(acc.zz));
-        store_fq(o + 18, fqu_to_ark(acc.zzz));
-    }
 }
 
 }  // namespace zk

@@ -64,7 +64,6 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     if (c->fold_stream) hipStreamSynchronize(c->fold_stream);
     for (auto& L : c->lanes) { if (L.serial) hipStreamSynchronize(L.serial); if (L.fold) hipStreamSynchronize(L.fold); }
     for (int i = 0; i < zkhip_ctx::MSM_SLOTS; ++i) if (c->side[i]) hipStreamSynchronize(c->side[i]);
-    for (int i = 0; i < 2; ++i) if (c->side_low[i]) { hipStreamSynchronize(c->side_low[i]); hipStreamDestroy(c->side_low[i]); }
     for (auto& e : c->prof_events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
     if (c->d_ws) hipFree(c->d_ws);
     if (c->d_aux) hipFree(c->d_aux);
@@ -72,10 +71,12 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     if (c->d_composed) hipFree(c->d_composed);
     for (int i = 0; i < zkhip_ctx::MSM_SLOTS; ++i) {
         if (c->msm_pin[i]) hipHostFree(c->msm_pin[i]);
+        if (c->msm_tab_dev[i]) hipFree(c->msm_tab_dev[i]);
+        if (c->msm_tab_pin[i]) hipHostFree(c->msm_tab_pin[i]);
         if (c->msm_ev[i]) hipEventDestroy(c->msm_ev[i]);
-        if (c->msm_front[i]) hipEventDestroy(c->msm_front[i]);
         if (c->side[i]) hipStreamDestroy(c->side[i]);
     }
+    delete c->host_pool;
     if (c->fork_ev) hipEventDestroy(c->fork_ev);
     if (c->join_ev) hipEventDestroy(c->join_ev);
     if (c->serial_ev) hipEventDestroy(c->serial_ev);
