@@ -616,7 +616,7 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
     // bucket reduction.  Larger rounds (openings above 2^20) are commits of their own, two in flight on side streams beside the batch.
     // (History.  Rounds 1-3: every round above 2^14 as a commit pipeline of its own, five beside each other on three hardware queues, each
     // paying the full reduction of 2^19 buckets and every kernel running at 2-3 x its stand-alone duration beside the others' accumulate
-    // passes: 8.5-9.2 ms at 2^20 against 3.2 ms for ONE commit of as many points (profiles/r03/open_last_call_trace.txt).  Then three
+    // passes: 8.5-9.2 ms at 2^20 against 3.2 ms for ONE commit of as many points (profiles/r03/open_trace_pipelines.txt).  Then three
     // batches of one width each (14 / 12 / 10 bits) beside each other, fronts lined up: 6.7 ms -- their sparse top windows needed the
     // heavy-bucket passes (0.6 ms) and the three reductions ended 0.9 ms after the last accumulate pass.  ZKHIP_OPEN_PIPELINES=1 runs the
     // rounds above 2^14 as pipelines again for an A/B.)
