@@ -31,8 +31,8 @@ using namespace zk;
 //                  with tools/perf_msm.py, ZKHIP_MSM_C sweep: below 2^13 every c ends at the ~1 ms latency floor of the reduction
 //                  passes).  16 x 16 = 256: the top window has 15 significant bits, half full, never sparse.
 //   shifted table: thirteen 20-bit digit windows on ONE bucket set of 2^19 buckets (MSM_TABLE_C).
-//   several:       every problem gets a width of its OWN, about log2(n_j) - 4 bits (lists of 32-64 points: the accumulate pass takes as
-//                  long as its longest lists, and every further bit doubles the buckets the reduction passes walk), as w = ceil(256 / c)
+//   several:       every problem gets a width of its OWN, log2(n_j) - delta bits (lists of 2^delta .. 2^(delta+1) points: the accumulate pass
+//                  takes as long as its longest lists, and every further bit doubles the buckets the reduction passes walk), as w = ceil(256 / c)
 //                  windows of the two widths ceil(256 / w) and one less that add up to exactly 256 -- so no window of any problem is
 //                  sparse (a 3-bit top window put an eighth of all points into each of 4 buckets: the heavy-bucket passes, 0.6 ms) and
 //                  all problems share ONE pass of every kernel (MultilinearKZG::open at 2^20: twenty problems, ~0.45 M buckets).
@@ -72,7 +72,10 @@ static int msm_geometry(const MsmProblems& pr, bool shared, size_t table_stride,
     return ZKHIP_OK;
 }
 static int msm_build_geometry(const MsmProblems& pr, bool shared, size_t table_stride, MsmGeometry& g) {
-    int delta = 4;
+    // widths log2(n_j) - delta, delta = the smallest from 1 on whose partitions fit the sort (MultilinearKZG::open: 3-4 at 2^20, where the
+    // pass is throughput bound and the width hardly matters -- 4.92 / 4.97 / 5.36 ms at delta 4 / 3 / 5 -- and 1 below 2^19, where the accumulate
+    // pass is as long as its longest lists: 2^16 1.66 / 1.74 / 1.96 / 2.77 ms at delta 1 / 2 / 3 / 4)
+    int delta = 1;
     if (const char* e = std::getenv("ZKHIP_MSM_BATCH_DELTA")) {   // tuning aid (tools/perf_open.py): width = log2(n_j) - delta
         const int v = std::atoi(e);
         if (v >= 0 && v <= 8) delta = v;
