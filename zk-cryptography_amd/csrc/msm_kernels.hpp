@@ -45,8 +45,8 @@ struct MsmWin {
 };
 struct MsmSet {
     uint32_t bucket_base; // first bucket, a multiple of MSM_SEG
-    uint32_t part_base;   // first sort partition: a partition holds the buckets with the same LOW part_bits bits of the index, so a
-    uint32_t bits;        //   set with few distinct digits still spreads over its partitions.  byte 0: c, byte 1: part_bits
+    uint32_t part_base;   // first sort partition: a partition holds the 2^(c-1-part_bits) <= 256 buckets with the same HIGH part_bits bits
+    uint32_t bits;        //   of the index.  byte 0: c, byte 1: part_bits
     uint32_t term_base;   // its c - 3 (set, term) points start here
     uint32_t rc_base;     // its row / column sums (2 R + C points) start here
     uint32_t rcwg_base;   // its first workgroup in msm_rowcol_kernel's grid
@@ -134,7 +134,6 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_order_scatter_kernel(con
 // counts its tile in LDS (sort_count), a column scan turns the per-workgroup counts into exclusive write positions
 // (sort_bases), and the same tile walk scatters 8-byte items (sort_scatter).  Level 2 runs one workgroup per
 // partition: the remaining <= 8 bucket bits are resolved in LDS, which also yields every bucket's count and offset.
-// (The buckets of a window lie in `sorted` partition by partition, not in index order: nothing reads them but through offsets[].)
 constexpr int SORT_TILE = 2048;          // scalars per workgroup tile (8 per lane)
 constexpr int SORT_MAX_PARTS = 4096;
 
@@ -166,9 +165,10 @@ __device__ __forceinline__ uint32_t msm_problem_of(const MsmSortTables& t, uint3
     }
     return lo;
 }
-__device__ __forceinline__ uint32_t msm_partition_of(const uint4& w, uint32_t mag) {   // w = an MsmWin
-    return w.x + ((mag - 1) & ((1u << ((w.z >> 8) & 0xffu)) - 1));
-}
+// the partition of a digit: the HIGH part_bits bits of its bucket index (all windows of every geometry are dense, so the partitions of a
+// set fill evenly; level 2 resolves the low <= 8 bits and writes a partition's counts / offsets / sorted run contiguously)
+__device__ __forceinline__ uint32_t msm_win_sub_bits(const uint4& w) { return (w.z & 0xffu) - 1 - ((w.z >> 8) & 0xffu); }   // w = an MsmWin
+__device__ __forceinline__ uint32_t msm_partition_of(const uint4& w, uint32_t mag) { return w.x + ((mag - 1) >> msm_win_sub_bits(w)); }
 
 static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_count_kernel(const uint64_t* __restrict__ scalars,
                                                                           const uint8_t* __restrict__ inf, size_t n, MsmPlan pl,
@@ -275,7 +275,7 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_scatter_kernel(cons
             const bool neg = d < 0;
             const uint32_t mag = neg ? (uint32_t)(-d) : (uint32_t)d;
             const uint32_t pos = atomicAdd(&cur[msm_partition_of(w, mag)], 1u);
-            items[pos] = make_uint2((w.y + (uint32_t)i) | (neg ? 0x80000000u : 0u), (mag - 1) >> ((w.z >> 8) & 0xffu));
+            items[pos] = make_uint2((w.y + (uint32_t)i) | (neg ? 0x80000000u : 0u), (mag - 1) & ((1u << msm_win_sub_bits(w)) - 1));
         }
     }
 }
@@ -307,8 +307,8 @@ static __global__ __launch_bounds__(SORT_LOCAL_BLOCK) void msm_sort_local_kernel
     const uint32_t p = blockIdx.x;
     const uint32_t lo = part_off[p], hi = part_off[p + 1];
     const MsmSet set = pl.sets[pl.part_set[p]];
-    const uint32_t part_bits = msm_set_part_bits(set);
-    const uint32_t n_sub = 1u << (msm_set_c(set) - 1 - part_bits);      // the partition's buckets: the high bits of the index (<= 8)
+    const uint32_t sub_bits = msm_set_c(set) - 1 - msm_set_part_bits(set);
+    const uint32_t n_sub = 1u << sub_bits;                              // the partition's buckets: the low bits of the index (<= 8)
     if (threadIdx.x < 256) bins[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t q = lo + threadIdx.x; q < hi; q += SORT_LOCAL_BLOCK) msm_lds_rank(bins, items[q].y);
@@ -325,7 +325,7 @@ static __global__ __launch_bounds__(SORT_LOCAL_BLOCK) void msm_sort_local_kernel
     }
     if (threadIdx.x < n_sub) {
         const uint32_t excl = scan[threadIdx.x] - v;
-        const uint32_t bucket = set.bucket_base + (threadIdx.x << part_bits) + (p - set.part_base);
+        const uint32_t bucket = set.bucket_base + ((p - set.part_base) << sub_bits) + threadIdx.x;
         counts[bucket] = v;
         offsets[bucket] = lo + excl;
         bins[threadIdx.x] = lo + excl;      // becomes the write cursor
