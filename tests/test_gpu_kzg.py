@@ -308,16 +308,23 @@ def test_univariate_kzg_open_exponent_identity(zk, ora, n, z_int):
     _same(zk, proof.proof, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), q_tau)))
 
 
-@pytest.mark.parametrize("sizes", [[1, 2, 4, 8], [4096, 2048, 1024, 512, 256, 128, 64, 32, 16, 8, 4, 2, 1], [300, 17, 5000], [16384, 3]])
-def test_commit_batch_matches_single_commits(zk, ora, sizes):
-    """zkhip_kzg_commit_batch (the small rounds of MultilinearKZG::open share one pass): every slice's commitment equals
-    the stand-alone commitment of that slice (itself checked against the oracle above)."""
+@pytest.mark.parametrize("kind", ["uniform", "bits"])
+@pytest.mark.parametrize("sizes", [[1, 2, 4, 8], [4096, 2048, 1024, 512, 256, 128, 64, 32, 16, 8, 4, 2, 1], [300, 17, 5000], [16384, 3],
+                                   [131072, 5, 70000, 0, 1]])
+def test_commit_batch_matches_single_commits(zk, ora, sizes, kind):
+    """zkhip_kzg_commit_batch (the rounds of MultilinearKZG::open share one pass, every problem with window widths of its own --
+    here problems from 0 to 2^17 entries in one batch): every slice's commitment equals the stand-alone commitment of that slice
+    (itself checked against the oracle above).  `bits`: 0 / 1 scalars, the heavy-bucket passes inside a batch."""
     from zk_cryptography_amd.kzg import commit_batch
     import torch
     total = sum(sizes)
     tau = ora.random_fr(1, 3100 + len(sizes))[0]
     srs = zk.UnivariateKZG.generate_srs(tau, total - 1)
-    sc = torch.from_numpy(ora.random_fr(total, 3200 + total).view(np.int64)).cuda()
+    if kind == "bits":
+        ints = np.random.default_rng(total).integers(0, 2, total)
+        sc = torch.from_numpy(np.ascontiguousarray(zk.Fr.from_ints([int(v) for v in ints])).view(np.int64)).cuda()
+    else:
+        sc = torch.from_numpy(ora.random_fr(total, 3200 + total).view(np.int64)).cuda()
     offsets = [0]
     for s in sizes:
         offsets.append(offsets[-1] + s)
@@ -326,7 +333,7 @@ def test_commit_batch_matches_single_commits(zk, ora, sizes):
         lo, hi = offsets[j], offsets[j + 1]
         sub = zk.TrustedSetup(srs.powers_of_tau_in_g1[lo:hi], srs.inf[lo:hi])
         want = zk.UnivariateKZG.commitment(zk.DenseUnivariatePolynomial(sc[lo:hi]), sub)
-        assert got[j] == want
+        assert got[j] == want, (j, s)
 
 
 # ---- shifted-SRS table (zkhip_srs_precompute / zkhip_kzg_commit_table): same commitments, fewer bucket additions ----
