@@ -398,8 +398,9 @@ int zkhip_kzg_commit_begin(zkhip_ctx *ctx, const uint64_t *d_points_xy, const vo
 int zkhip_kzg_commit_end(zkhip_ctx *ctx, uint32_t ticket, uint64_t *h_out_xy, uint8_t *h_out_inf);
 /* Several independent commitments in one pass of every kernel: problem j commits d_scalars[h_offsets[j] .. h_offsets[j+1])
  * against d_points_xy[same range] (n_problems <= 64; no reference counterpart -- the reference commits one polynomial at
- * a time; MultilinearKZG::open uses this for its small rounds, and a caller that commits many short polynomials should
- * too: a single small commit is latency bound at ~1 ms).  Outputs: h_out_xy[12 j], h_out_inf[j]. */
+ * a time; MultilinearKZG::open commits ALL its rounds this way, and a caller that commits many polynomials of any sizes
+ * should too: a single small commit is latency bound at ~1 ms, and every problem of a batch gets window widths of its own, so
+ * problems of 1 and of 2^19 entries share a pass without slowing each other).  Outputs: h_out_xy[12 j], h_out_inf[j]. */
 int zkhip_kzg_commit_batch(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t *d_points_inf,
                            const uint64_t *d_scalars, const size_t *h_offsets, uint32_t n_problems, uint64_t *h_out_xy,
                            uint8_t *h_out_inf);
