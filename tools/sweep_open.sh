@@ -1,8 +1,11 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/sweep_open.sh -- MultilinearKZG::open at 2^20 per setting of the grouping knobs (ZKHIP_OPEN_*), two runs each
+# usage (GPU box, repo root): tools/sweep_open.sh [sizes] -- MultilinearKZG::open per setting of the batch's window-width knob
+# (ZKHIP_MSM_BATCH_DELTA: width = log2(n_j) - delta, raised until the sort's partitions fit) and of the pipelines form, two runs each
 for rep in 1 2; do
-  for mid in 17 18 19; do for wf in 0 1; do for bl in 12 13 14; do
-    echo -n "MID=$mid WIDE_FIRST=$wf BATCH_LOG=$bl: "
-    ZKHIP_OPEN_MID_LOG=$mid ZKHIP_OPEN_WIDE_FIRST=$wf ZKHIP_OPEN_BATCH_LOG=$bl timeout 120 python tools/perf_open.py 20 2>&1 | grep cached
-  done; done; done
+  for d in 1 2 3 4 5; do
+    echo "DELTA=$d"
+    ZKHIP_MSM_BATCH_DELTA=$d timeout 200 python tools/perf_open.py ${1:-12 16 20 22} 2>&1 | grep cached
+  done
+  echo "PIPELINES=1"
+  ZKHIP_OPEN_PIPELINES=1 timeout 200 python tools/perf_open.py ${1:-12 16 20 22} 2>&1 | grep cached
 done
