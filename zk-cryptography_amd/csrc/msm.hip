@@ -46,7 +46,6 @@ struct MsmGeometry {
     uint16_t win_first[MSM_MAX_PROBLEMS + 1] = {};
     size_t items = 0;                // (point, window) pairs of the pass
     uint32_t heavy_min = 32;
-    uint32_t tb = 64;                // workgroup size of the row / column passes
     uint64_t sig = 0;
 };
 constexpr uint32_t MSM_TABLE_C = 20;
@@ -172,7 +171,7 @@ static int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t tabl
     if (g.pl.n_parts > (uint32_t)SORT_MAX_PARTS || g.pl.n_sets > 65535u) return ZKHIP_ERR_SHAPE;
     // a bucket holding more than heavy_min points (four average lists of the densest set) is summed by whole workgroups
     g.heavy_min = std::max<uint32_t>(32, 4 * max_chain);
-    g.tb = std::min<uint32_t>(128, std::max<uint32_t>(64, rc_max));
+    if (rc_max > MSM_LINE_MAX) return ZKHIP_ERR_SHAPE;      // a row / column is summed by one wave
     mix(g.pl.n_buckets); mix(g.pl.n_wins);
     g.sig = sig ? sig : 1;
     return ZKHIP_OK;
@@ -326,9 +325,9 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     }
     {
         ProfScope ps(c, "msm_terms", 0.0);
-        const uint32_t tb = geo.tb, lds = tb > 64 ? tb * 256 : 0;     // lines of <= 64 values are summed inside a wave, without LDS
-        hipLaunchKernelGGL(msm_rowcol_kernel, dim3(pl.n_rcwg), dim3(tb), lds, c->stream, segs, sega, pl, rc);
-        hipLaunchKernelGGL(msm_rowcol_terms_kernel, dim3(pl.n_termwg), dim3(tb), lds, c->stream, rc, pl, terms);
+        // one wave per workgroup: lines and trees are summed inside a wave, without LDS
+        hipLaunchKernelGGL(msm_rowcol_kernel, dim3(pl.n_rcwg), dim3(64), 0, c->stream, segs, sega, pl, rc);
+        hipLaunchKernelGGL(msm_rowcol_terms_kernel, dim3(pl.n_termwg), dim3(64), 0, c->stream, rc, pl, terms);
     }
     ZK_HIP(c, hipGetLastError());
     ZK_TRY(c->reserve_msm_pin(slot, n_out * 192));

@@ -557,14 +557,15 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_segment_kernel(const uin
 // what counts is the depth: log2 C + log2 R tree levels.
 // A tree of <= 64 values is summed inside one wave (msm_wave_tree_sum: no LDS, so the waves of a commit are all resident at once --
 // with a 16 KiB tree buffer per workgroup ten fitted a CU and the 3072 trees of a 2^20-point commit ran in two rounds), and a wave
-// takes as many lines (rows / columns) of its set as fit: 64 / width.  Wider lines (the shared bucket set of the table path) keep a
-// workgroup each and the LDS tree.  The grid is flat over the sets, which differ in size: rcwg_set names the set of a workgroup.
+// takes as many lines (rows / columns) of its set as fit; the 256-value lines of the table path's one wide set take a wave each
+// (64 lanes x 4 values).  The grid is flat over the sets, which differ in size: rcwg_set names the set of a workgroup.
 // A lane first adds MSM_LINE_Q values of its line one after the other, then the lanes of the line form the tree: a tree level costs a
 // whole wave one addition however few lanes still take part, so a 64-value line as 16 lanes x 4 values is 3 + 4 additions for FOUR lines
 // per wave instead of 6 for one (the row / column pass of a 2^20-point commit: 768 waves, each alone on a SIMD, instead of 3072).
 constexpr uint32_t MSM_LINE_Q = 4;
+constexpr uint32_t MSM_LINE_MAX = 64 * MSM_LINE_Q;     // the longest line a wave sums: R = C = 256, the 2^19-bucket set of the shifted-SRS table
 __host__ __device__ __forceinline__ uint32_t msm_line_q(uint32_t count) { return count >= 4 * MSM_LINE_Q ? MSM_LINE_Q : 1; }
-constexpr uint32_t MSM_TERMS_PER_WG = 4;     // (set, term) trees per wave of msm_rowcol_terms_kernel: 16 lanes each
+constexpr uint32_t MSM_TERMS_PER_WG = 4;     // (set, term) trees per wave of msm_rowcol_terms_kernel while a tree fits 16 lanes x 4 values
 struct MsmSetShape { uint32_t n_bits, lo_bits, C, R, row_lines, col_lines, row_wgs, col_wgs, term_wgs; };
 __host__ __device__ __forceinline__ MsmSetShape msm_set_shape_c(uint32_t c) {
     MsmSetShape sh;
@@ -572,18 +573,16 @@ __host__ __device__ __forceinline__ MsmSetShape msm_set_shape_c(uint32_t c) {
     sh.lo_bits = sh.n_bits / 2;
     sh.C = 1u << sh.lo_bits;
     sh.R = (1u << sh.n_bits) >> sh.lo_bits;
-    sh.row_lines = sh.C <= 64 ? 64 / (sh.C / msm_line_q(sh.C)) : 1;          // rows (C values each) per workgroup
-    sh.col_lines = sh.R <= 64 ? 64 / (sh.R / msm_line_q(sh.R)) : 1;          // columns (R values each) per workgroup
+    sh.row_lines = sh.C <= 64 ? 64 / (sh.C / msm_line_q(sh.C)) : 1;          // rows (C values each) per wave; a longer line has a wave to itself
+    sh.col_lines = sh.R <= 64 ? 64 / (sh.R / msm_line_q(sh.R)) : 1;          // columns (R values each) per wave
     sh.row_wgs = (2 * sh.R + sh.row_lines - 1) / sh.row_lines;   // the R rows of S, then the R rows of A
     sh.col_wgs = (sh.C + sh.col_lines - 1) / sh.col_lines;
     // (set, term) trees: <= max(R, C) values each; four per workgroup while a tree fits 16 lanes x 4 values, else one
     sh.term_wgs = (sh.R <= 64 && sh.C <= 64) ? (1 + sh.n_bits + MSM_TERMS_PER_WG - 1) / MSM_TERMS_PER_WG : 1 + sh.n_bits;
     return sh;
 }
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_rowcol_kernel(const uint32_t* __restrict__ seg_s, const uint32_t* __restrict__ seg_a,
-                                                                    MsmPlan pl, uint32_t* __restrict__ rc) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
-    uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);   // blockDim.x x 64 u32 when blockDim.x > 64 (wide lines), else unused
+static __global__ __launch_bounds__(64) void msm_rowcol_kernel(const uint32_t* __restrict__ seg_s, const uint32_t* __restrict__ seg_a,
+                                                             MsmPlan pl, uint32_t* __restrict__ rc) {
     __builtin_amdgcn_s_setprio(2);
     const MsmSet set = pl.sets[pl.rcwg_set[blockIdx.x]];
     const MsmSetShape sh = msm_set_shape_c(msm_set_c(set));
@@ -593,76 +592,47 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_rowcol_kernel(const uint
     uint32_t* row_a = row_s + (size_t)R * 64;
     uint32_t* col_s = row_a + (size_t)R * 64;
     const bool rows = b < sh.row_wgs;
-    const uint32_t count = rows ? C : R;                 // values per line
-    if (count <= 64) {
-        // packed: lane = (line of this workgroup, position in the line), q values per lane; one wave
-        if (threadIdx.x >= 64) return;
-        const uint32_t q = msm_line_q(count), lpl = count / q;      // lanes per line
-        const uint32_t lines = rows ? sh.row_lines : sh.col_lines;
-        const uint32_t line = (rows ? b : b - sh.row_wgs) * lines + threadIdx.x / lpl, pos = threadIdx.x & (lpl - 1);
-        const uint32_t n_lines = rows ? 2 * R : C;
-        G1XyzzU acc = G1XyzzU::identity();
-        uint32_t* dst = nullptr;
-        if (line < n_lines) {
-            const uint32_t* src;
-            size_t first, stride;
-            if (rows) {
-                const uint32_t h = line < R ? line : line - R;
-                src = (line < R ? seg_s : seg_a) + seg0 * 64; first = (size_t)h * C + (size_t)pos * q; stride = 1;
-                dst = (line < R ? row_s : row_a) + (size_t)h * 64;
-            } else {
-                src = seg_s + seg0 * 64; first = (size_t)pos * q * C + line; stride = C;
-                dst = col_s + (size_t)line * 64;
-            }
-            acc = load_xyzz_u(src, first);
-            for (uint32_t u = 1; u < q; ++u) {
-                G1XyzzU v = load_xyzz_u(src, first + u * stride);
-                g1u_add(acc, v);
-            }
-        }
-        msm_wave_tree_sum(acc, lpl);
-        if (dst && pos == 0) store_xyzz_u(dst, 0, acc);
-        return;
-    }
-    const uint32_t* src;
-    uint32_t first, stride;
-    uint32_t* dst;
-    if (rows) {                            // a row of S (b < R) or of A
-        const uint32_t h = b < R ? b : b - R;
-        src = (b < R ? seg_s : seg_a) + seg0 * 64;
-        first = h * C; stride = 1;
-        dst = (b < R ? row_s : row_a) + (size_t)h * 64;
-    } else {                               // a column of S
-        const uint32_t l = b - sh.row_wgs;
-        src = seg_s + seg0 * 64;
-        first = l; stride = C;
-        dst = col_s + (size_t)l * 64;
-    }
+    const uint32_t count = rows ? C : R;                 // values per line (<= MSM_LINE_MAX)
+    // lane = (line of this wave, position in the line), q values per lane one after the other, then the tree over the line's lanes
+    const uint32_t lpl = count <= 64 ? count / msm_line_q(count) : 64;      // lanes per line
+    const uint32_t q = count / lpl;
+    const uint32_t lines = rows ? sh.row_lines : sh.col_lines;
+    const uint32_t line = (rows ? b : b - sh.row_wgs) * lines + threadIdx.x / lpl, pos = threadIdx.x & (lpl - 1);
+    const uint32_t n_lines = rows ? 2 * R : C;
     G1XyzzU acc = G1XyzzU::identity();
-    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
-        G1XyzzU v = load_xyzz_u(src, first + (size_t)i * stride);
-        g1u_add(acc, v);
+    uint32_t* dst = nullptr;
+    if (line < n_lines) {
+        const uint32_t* src;
+        size_t first, stride;
+        if (rows) {
+            const uint32_t h = line < R ? line : line - R;
+            src = (line < R ? seg_s : seg_a) + seg0 * 64; first = (size_t)h * C + (size_t)pos * q; stride = 1;
+            dst = (line < R ? row_s : row_a) + (size_t)h * 64;
+        } else {
+            src = seg_s + seg0 * 64; first = (size_t)pos * q * C + line; stride = C;
+            dst = col_s + (size_t)line * 64;
+        }
+        acc = load_xyzz_u(src, first);
+        for (uint32_t u = 1; u < q; ++u) {
+            G1XyzzU v = load_xyzz_u(src, first + u * stride);
+            g1u_add(acc, v);
+        }
     }
-    uint32_t width = 1;
-    while (width < count && width < blockDim.x) width <<= 1;
-    msm_block_tree_sum(acc, width, lds);
-    if (threadIdx.x == 0) store_xyzz_u(dst, 0, acc);
+    msm_wave_tree_sum(acc, lpl);
+    if (dst && pos == 0) store_xyzz_u(dst, 0, acc);
 }
 // ... then one tree per (set, term): term 0 = sum_s A_s, term 1 + k = T_k; the result leaves in the arkworks layout (XYZZ, 4 x 48 B)
-// for the host epilogue.  Four trees of a set per wave (16 lanes x <= 4 selected values each) while R, C <= 64; a workgroup with the LDS
-// tree per term otherwise.  termwg_set names the set of a workgroup.
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_rowcol_terms_kernel(const uint32_t* __restrict__ rc, MsmPlan pl, uint64_t* __restrict__ terms) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
-    uint32_t* lds = reinterpret_cast<uint32_t*>(zk_dyn_lds);
+// for the host epilogue.  Four trees of a set per wave (16 lanes x <= 4 selected values each) while R, C <= 64; a wave per tree (64 lanes
+// x <= 4 values) for the wide set of the table path.  termwg_set names the set of a workgroup.
+static __global__ __launch_bounds__(64) void msm_rowcol_terms_kernel(const uint32_t* __restrict__ rc, MsmPlan pl, uint64_t* __restrict__ terms) {
     __builtin_amdgcn_s_setprio(2);
     const MsmSet set = pl.sets[pl.termwg_set[blockIdx.x]];
     const MsmSetShape sh = msm_set_shape_c(msm_set_c(set));
     const uint32_t C = sh.C, R = sh.R, lo_bits = sh.lo_bits;
     const bool packed = R <= 64 && C <= 64;
-    if (packed && threadIdx.x >= 64) return;
-    const uint32_t lanes = packed ? 64 / MSM_TERMS_PER_WG : blockDim.x;         // lanes of one tree
+    const uint32_t lanes = packed ? 64 / MSM_TERMS_PER_WG : 64;         // lanes of one tree
     const uint32_t t = packed ? (blockIdx.x - set.termwg_base) * MSM_TERMS_PER_WG + threadIdx.x / lanes : blockIdx.x - set.termwg_base;
-    const uint32_t pos = packed ? threadIdx.x & (lanes - 1) : threadIdx.x;
+    const uint32_t pos = threadIdx.x & (lanes - 1);
     const bool live = t < 1 + sh.n_bits;
     const uint32_t* row_s = rc + (size_t)set.rc_base * 64;
     const uint32_t* row_a = row_s + (size_t)R * 64;
@@ -682,13 +652,7 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_rowcol_terms_kernel(cons
         G1XyzzU v = load_xyzz_u(src, i);
         g1u_add(acc, v);
     }
-    if (packed) {
-        msm_wave_tree_sum(acc, lanes);
-    } else {
-        uint32_t width = 1;
-        while (width < n_sel && width < blockDim.x) width <<= 1;
-        msm_block_tree_sum(acc, width, lds);
-    }
+    msm_wave_tree_sum(acc, lanes);
     if (live && pos == 0) {
         uint64_t* o = terms + 24 * ((size_t)set.term_base + t);
         store_fq(o, fqu_to_ark(acc.x));
