@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <memory>
 #include <new>
 #include <set>
 #include <vector>
@@ -148,16 +149,16 @@ struct zkhip_ctx {
         msm_pin_bytes[slot] = bytes;
         return ZKHIP_OK;
     }
-    // geometry tables of the commit in slot `slot` (msm_build_geometry): device copy + pinned staging, kept while the signature matches
+    // geometry tables of the commit in slot `slot` (msm_build_geometry): device copy + pinned staging, kept while the geometry is the same
     void* msm_tab_dev[MSM_SLOTS] = {};
     void* msm_tab_pin[MSM_SLOTS] = {};
     size_t msm_tab_bytes[MSM_SLOTS] = {};
-    uint64_t msm_tab_sig[MSM_SLOTS] = {};
+    std::shared_ptr<const void> msm_tab_geo[MSM_SLOTS];   // the geometry whose tables the device copy holds (kept alive: its address is its identity)
     int reserve_msm_tab(int slot, size_t bytes) {
         if (bytes <= msm_tab_bytes[slot]) return ZKHIP_OK;
         if (msm_tab_dev[slot]) hipFree(msm_tab_dev[slot]);
         if (msm_tab_pin[slot]) hipHostFree(msm_tab_pin[slot]);
-        msm_tab_dev[slot] = nullptr; msm_tab_pin[slot] = nullptr; msm_tab_bytes[slot] = 0; msm_tab_sig[slot] = 0;
+        msm_tab_dev[slot] = nullptr; msm_tab_pin[slot] = nullptr; msm_tab_bytes[slot] = 0; msm_tab_geo[slot].reset();
         const size_t cap = (bytes + 65535) & ~(size_t)65535;
         if (hipMalloc(&msm_tab_dev[slot], cap) != hipSuccess) return ZKHIP_ERR_NOMEM;
         if (hipHostMalloc(&msm_tab_pin[slot], cap, hipHostMallocDefault) != hipSuccess) return ZKHIP_ERR_NOMEM;

@@ -46,7 +46,6 @@ struct MsmGeometry {
     uint16_t win_first[MSM_MAX_PROBLEMS + 1] = {};
     size_t items = 0;                // (point, window) pairs of the pass
     uint32_t heavy_min = 32;
-    uint64_t sig = 0;
 };
 constexpr uint32_t MSM_TABLE_C = 20;
 constexpr uint32_t MSM_TABLE_WINDOWS = (256 + MSM_TABLE_C - 1) / MSM_TABLE_C;   // 13: twelve full 20-bit windows and a 15-bit top window
@@ -86,9 +85,6 @@ static int msm_build_geometry(const MsmProblems& pr, bool shared, size_t table_s
 static int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t table_stride, int delta, MsmGeometry& g) {
     g = MsmGeometry();
     uint32_t max_chain = 1, rc_max = 1;
-    uint64_t sig = 1469598103934665603ull;
-    auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
-    mix(pr.n); mix(shared); mix(table_stride);
     g.prob_set_first.push_back(0);
     auto add_set = [&](uint32_t c, uint32_t exp) {
         MsmSet s = {};
@@ -126,7 +122,6 @@ static int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t tabl
     };
     for (uint32_t j = 0; j < pr.n; ++j) {
         const size_t nj = pr.off[j + 1] - pr.off[j];
-        mix(nj);
         g.win_first[j] = (uint16_t)g.wins.size();
         uint32_t lg = 0;
         while (((size_t)1 << lg) < nj) ++lg;
@@ -172,8 +167,6 @@ static int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t tabl
     // a bucket holding more than heavy_min points (four average lists of the densest set) is summed by whole workgroups
     g.heavy_min = std::max<uint32_t>(32, 4 * max_chain);
     if (rc_max > MSM_LINE_MAX) return ZKHIP_ERR_SHAPE;      // a row / column is summed by one wave
-    mix(g.pl.n_buckets); mix(g.pl.n_wins);
-    g.sig = sig ? sig : 1;
     return ZKHIP_OK;
 }
 
@@ -258,7 +251,7 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
         const size_t bytes = b_wins + b_sets + b_part + b_rcwg + b_term;
         ZK_TRY(c->reserve_msm_tab(slot, bytes));
         char* dev = (char*)c->msm_tab_dev[slot];
-        if (c->msm_tab_sig[slot] != geo.sig) {
+        if (c->msm_tab_geo[slot].get() != (const void*)geo_p.get()) {
             char* pin = (char*)c->msm_tab_pin[slot];
             // the staging buffer may still feed the upload of the slot's previous commit only if that commit has not been waited for;
             // every caller ends (msm_finish / stream synchronize) a slot's commit before it enqueues the next one there
@@ -268,7 +261,7 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
             std::memcpy(pin + b_wins + b_sets + b_part, geo.rcwg_set.data(), geo.rcwg_set.size() * 2);
             std::memcpy(pin + b_wins + b_sets + b_part + b_rcwg, geo.termwg_set.data(), geo.termwg_set.size() * 2);
             ZK_HIP(c, hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, c->stream));
-            c->msm_tab_sig[slot] = geo.sig;
+            c->msm_tab_geo[slot] = geo_p;
         }
         pl.wins = (const MsmWin*)dev;
         pl.sets = (const MsmSet*)(dev + b_wins);
