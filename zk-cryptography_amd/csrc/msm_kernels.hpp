@@ -5,21 +5,22 @@
 //     MultilinearKZG::commitment  kzg/src/multilinear_kzg.rs:33-48
 // which compute sum_i srs[i].mul_bigint(coeff[i].into_bigint()) by double-and-add.  The group element is
 // the same; the algorithm is Pippenger's:
-//   1. digits:   scalars leave Montgomery form (into_bigint) and are recoded into signed base-2^c digits;
+//   1. digits:   scalars leave Montgomery form (into_bigint) and are recoded into signed digits, one per DIGIT WINDOW
+//                (MsmWin: the widths are the geometry's, built on the host per problem);
 //   2. sort:     the (point, window) pairs are counting-sorted by bucket in two levels without global atomics
 //                (msm_sort_*), which also yields every bucket's count and offset;
 //   3. order:    buckets are ranked by point count, heaviest first;
 //   4. accumulate: one lane per bucket adds its points (mixed XYZZ additions); buckets far heavier than the
-//                mean are summed by whole workgroups instead (4b / 4c);
+//                mean are filed (msm_file_heavy_kernel) and summed by whole workgroups in front of it (4b / 4c);
 //   5. segments: every L consecutive buckets are folded by a local running sum into
 //                S_s = sum B and A_s = sum (j+1) B  -- short dependency chains only;
-//   6. terms:    per window, sum_s A_s and, for every bit k of the segment index, T_k = sum_{s: bit k} S_s
-//                by workgroup tree reductions.  The window total is sum_s A_s + L * sum_k 2^k T_k.
-//   7. the (#windows x #terms) points, each tagged with its power-of-two weight, go to the host, which runs
-//      the final 255-step double-and-add chain (inherently serial; a few hundred group operations).
-// Variants of the same passes: several independent problems in one pass (MsmProblems: problem j owns its own
-// "virtual windows" of the bucket array -- the small rounds of MultilinearKZG::open), and the shifted-SRS table
-// (MsmPlan::shared: the points 2^(c w) P are read from a table built once per SRS, so the digits of all windows share
+//   6. terms:    per BUCKET SET (MsmSet), sum_s A_s and, for every bit k of the segment index, T_k = sum_{s: bit k} S_s
+//                by row / column sums and trees inside single waves.  The set's total is sum_s A_s + L * sum_k 2^k T_k.
+//   7. the (set, term) points, each tagged with its power-of-two weight, go to the host, which runs
+//      the final 255-step double-and-add chain per problem (inherently serial; a few hundred group operations).
+// One pass serves one problem or several independent ones (MsmProblems: problem j owns its own digit windows and bucket sets,
+// each problem with window widths that suit its size -- all rounds of MultilinearKZG::open are one pass), or the shifted-SRS
+// table (MsmPlan::shared: the points 2^(c w) P are read from a table built once per SRS, so the digits of all windows share
 // ONE bucket set and one bucket reduction).
 // MSM is integer-ALU bound (10 Fq products of ~500 instructions per added point, VALU issue saturated), not HBM bound.
 #pragma once
