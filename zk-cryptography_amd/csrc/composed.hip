@@ -232,9 +232,14 @@ struct ComposedRun {
         const size_t per_lane = fold ? 8 : 16;
         const bool wide = n_terms == 1 && term_sizes[0] == 2 && !lin_cur[0] && work >= CMP_WIDE_MIN_WORK &&
                           work <= (size_t)MLE_MAX_GRID * MLE_BLOCK * 256;
+        // one record per workgroup, and the closing kernel -- one workgroup, on the critical path -- adds them up: a claim of ONE term
+        // launches at most 512 workgroups (K = 2 at 2^22: 0.626 / 0.621 / 0.614-0.621 / 0.619 ms at 2048 / 1024 / 512 / 256; the GKR layers,
+        // two terms per claim, measured no better with fewer).  ZKHIP_ROUND_GRID overrides (diagnostics).
+        static const int grid_env = [] { const char* e = std::getenv("ZKHIP_ROUND_GRID"); return e ? std::atoi(e) : 0; }();
+        const int grid_cap = grid_env > 0 ? grid_env : n_terms == 1 ? 512 : (int)MLE_MAX_GRID;
         const int grid = split ? (int)((4 * work + MLE_BLOCK - 1) / MLE_BLOCK)
                          : wide ? (int)std::min<size_t>(MLE_MAX_GRID, std::max<size_t>(256, work / (MLE_BLOCK * per_lane)))
-                         : mle_grid(work ? work : 1);
+                         : std::min(grid_cap, mle_grid(work ? work : 1));
         uint32_t off = 0;
         // every term with the same number of tables (<= 2 when one has an additive table): ONE launch, blockIdx.y = term
         bool same_k = n_terms > 1;
