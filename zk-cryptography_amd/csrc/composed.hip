@@ -337,7 +337,8 @@ struct ComposedRun {
         if (!no_mfma && m >= 1024 && m <= (size_t)256 * 65536) {
             // byte outer products on the matrix cores: >= 128 indices and <= 65536 per workgroup (int32 accumulators)
             // up to four workgroups per CU (42 KiB of LDS each), as many records as the scratch holds
-            const size_t cap = std::min<size_t>(512, (size_t)(8 * ZK_MAX_PARTIALS) / ((size_t)CST_VALS * n_terms));
+            static const size_t cap_env = [] { const char* e = std::getenv("ZKHIP_CROSS_GRID"); return e ? (size_t)std::atoi(e) : (size_t)0; }();   // diagnostics
+            const size_t cap = std::min<size_t>(cap_env ? cap_env : 512, (size_t)(8 * ZK_MAX_PARTIALS) / ((size_t)CST_VALS * n_terms));
             const int grid = (int)std::max<size_t>(std::min<size_t>(cap, m / 128), (m + 65535) / 65536);
             hipLaunchKernelGGL(composed_cross2_mfma_kernel, dim3(grid, n_terms), dim3(256), 0, c->stream, stage_tables(), cn, n_terms, d_partials);
             *n_records = grid;
