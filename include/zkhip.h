@@ -404,6 +404,14 @@ int zkhip_kzg_commit_end(zkhip_ctx *ctx, uint32_t ticket, uint64_t *h_out_xy, ui
 int zkhip_kzg_commit_batch(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t *d_points_inf,
                            const uint64_t *d_scalars, const size_t *h_offsets, uint32_t n_problems, uint64_t *h_out_xy,
                            uint8_t *h_out_inf);
+/* Diagnostics (host only, no GPU): the geometry the batched commit above would use for these problem sizes -- how every problem's 256
+ * scalar bits are cut into digit windows and how many buckets, sort partitions and reduction workgroups the pass has.
+ *   h_win_first[n_problems + 1]: problem j owns the windows [h_win_first[j], h_win_first[j+1]);  h_win_bits[<= 2048]: their widths;
+ *   h_totals[8] = { windows, bucket sets, buckets, sort partitions, (set, term) points, row/column workgroups, term workgroups,
+ *                   heavy-bucket threshold }.
+ * Returns ZKHIP_ERR_SHAPE when no window widths fit the sort's partitions (more than 64 problems' worth). */
+int zkhip_msm_geometry_info(const size_t *h_offsets, uint32_t n_problems, uint16_t *h_win_first, uint8_t *h_win_bits,
+                            uint32_t *h_totals);
 /* SRS generation on the device (G1 side; the G2 powers are only used by the pairing verifier, out of scope).
  *   multilinear: TrustedSetup::generate_powers_of_tau_in_g1 (kzg/src/trusted_setup.rs:25-35):
  *                point i = G * prod_j (bit_j(i) ? tau_j : 1 - tau_j), hypercube bits MSB first; 2^n_vars points.

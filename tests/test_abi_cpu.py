@@ -42,3 +42,40 @@ def test_missing_gpu_fails_loudly():
     import zk_cryptography_amd as z
     with pytest.raises(Exception):
         z.Multilinear(z.Fr.from_ints([1, 2]))
+
+
+def test_msm_batch_geometry_host_logic():
+    """zkhip_msm_geometry_info (host only): for the problem sizes of a 2^20 opening, of tiny and of lopsided batches every problem's digit
+    windows are 256 bits in all, of two widths one bit apart (no sparse window), between 4 and 16 bits, and the pass fits the sort's
+    4096 partitions and the 2048-window table the sort kernels keep in LDS -- up to the 64 problems the entry point takes."""
+    import ctypes as C
+    from zk_cryptography_amd import _native
+    _native.build()
+    lib = C.CDLL(_native.LIB_PATH)
+    lib.zkhip_msm_geometry_info.restype = C.c_int
+    cases = [[1 << (19 - i) for i in range(20)], [1, 1, 1], [5], [1 << 19, 3], [4096] * 40, [1 << 17] * 8, [0, 7, 0], [1 << 19] * 2 + [1 << 10] * 30, [3] * 64, [1 << 14] * 64, [1 << 19] + [100] * 63]
+    for sizes in cases:
+        n = len(sizes)
+        offs = (C.c_size_t * (n + 1))(*[sum(sizes[:j]) for j in range(n + 1)])
+        first = (C.c_uint16 * (n + 1))()
+        bits = (C.c_uint8 * 2048)()
+        totals = (C.c_uint32 * 8)()
+        rc = lib.zkhip_msm_geometry_info(offs, C.c_uint32(n), first, bits, totals)
+        assert rc == 0, (sizes, rc)
+        assert first[0] == 0 and first[n] == totals[0] <= 2048
+        assert totals[3] <= 4096 and totals[2] % 8 == 0
+        buckets = 0
+        for j in range(n):
+            w = [bits[v] for v in range(first[j], first[j + 1])]
+            if n == 1:
+                assert len(set(w)) == 1 and sum(w) >= 256, (sizes, w)       # one problem: uniform windows
+            else:
+                assert sum(w) == 256 and max(w) - min(w) <= 1 and 7 <= min(w) and max(w) <= 16, (sizes, j, w)
+                assert w == sorted(w, reverse=True)                         # the wider windows first
+            buckets += sum(1 << (b - 1) for b in w)
+        assert buckets == totals[2], (sizes, buckets, totals[2])
+    # wider windows for larger problems
+    offs = (C.c_size_t * 3)(0, 1 << 18, (1 << 18) + (1 << 10))
+    first = (C.c_uint16 * 3)(); bits = (C.c_uint8 * 2048)(); totals = (C.c_uint32 * 8)()
+    assert lib.zkhip_msm_geometry_info(offs, C.c_uint32(2), first, bits, totals) == 0
+    assert bits[first[0]] > bits[first[1]]

@@ -310,7 +310,7 @@ def test_univariate_kzg_open_exponent_identity(zk, ora, n, z_int):
 
 @pytest.mark.parametrize("kind", ["uniform", "bits"])
 @pytest.mark.parametrize("sizes", [[1, 2, 4, 8], [4096, 2048, 1024, 512, 256, 128, 64, 32, 16, 8, 4, 2, 1], [300, 17, 5000], [16384, 3],
-                                   [131072, 5, 70000, 0, 1]])
+                                   [131072, 5, 70000, 0, 1], [5] * 64, [700] * 50 + [9000]])
 def test_commit_batch_matches_single_commits(zk, ora, sizes, kind):
     """zkhip_kzg_commit_batch (the rounds of MultilinearKZG::open share one pass, every problem with window widths of its own --
     here problems from 0 to 2^17 entries in one batch): every slice's commitment equals the stand-alone commitment of that slice

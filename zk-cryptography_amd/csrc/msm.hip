@@ -140,7 +140,7 @@ static int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t tabl
                 }
                 w = (256 + c - 1) / c; hi = c; n_hi = w;
             } else {
-                const uint32_t c = (uint32_t)std::min(16, std::max(7, (int)lg - delta));
+                const uint32_t c = (uint32_t)std::min(16, std::max(8, (int)lg - delta));   // >= 8 bits: at most 32 windows per problem, 2048 for 64 problems
                 w = (256 + c - 1) / c;
                 hi = (256 + w - 1) / w;
                 n_hi = 256 - w * (hi - 1);      // n_hi windows of hi bits (the low ones), the rest of hi - 1: exactly 256 bits
@@ -519,6 +519,25 @@ extern "C" int zkhip_kzg_commit_table(zkhip_ctx* c, const void* d_table, const u
     one.n = 1;
     one.off[1] = (uint32_t)n;
     return msm_commit_multi(c, nullptr, d_points_inf, d_scalars, n, one, h_out_xy, h_out_inf, (const uint32_t*)d_table, n_points);
+}
+
+extern "C" int zkhip_msm_geometry_info(const size_t* h_offsets, uint32_t n_problems, uint16_t* h_win_first, uint8_t* h_win_bits,
+                                       uint32_t* h_totals) {
+    if (!h_offsets || !h_win_first || !h_win_bits || !h_totals) return ZKHIP_ERR_ARG;
+    if (n_problems == 0 || n_problems > (uint32_t)MSM_MAX_PROBLEMS) return ZKHIP_ERR_SHAPE;
+    MsmProblems pr = {};
+    pr.n = n_problems;
+    for (uint32_t j = 0; j <= n_problems; ++j) {
+        if (h_offsets[j] >= ((size_t)1 << 31) || (j && h_offsets[j] < h_offsets[j - 1])) return ZKHIP_ERR_SHAPE;
+        pr.off[j] = (uint32_t)(h_offsets[j] - h_offsets[0]);
+    }
+    MsmGeometry g;
+    ZK_TRY(msm_build_geometry(pr, false, 0, g));
+    for (uint32_t j = 0; j <= n_problems; ++j) h_win_first[j] = g.win_first[j];
+    for (size_t v = 0; v < g.wins.size(); ++v) h_win_bits[v] = (uint8_t)(g.wins[v].bits & 0xffu);
+    const uint32_t totals[8] = {g.pl.n_wins, g.pl.n_sets, g.pl.n_buckets, g.pl.n_parts, g.pl.n_terms, g.pl.n_rcwg, g.pl.n_termwg, g.heavy_min};
+    std::memcpy(h_totals, totals, sizeof(totals));
+    return ZKHIP_OK;
 }
 
 extern "C" int zkhip_kzg_commit_batch(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf,

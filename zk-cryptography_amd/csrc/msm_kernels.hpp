@@ -32,7 +32,7 @@ namespace zk {
 constexpr int MSM_BLOCK = 256;
 constexpr int MSM_SEG_LOG = 3;              // L = 8 buckets per segment (L = 4 measured again with the row / column term sums: segment pass 0.30 instead of 0.33 ms, term sums 0.74 instead of 0.47 ms)
 constexpr int MSM_SEG = 1 << MSM_SEG_LOG;
-constexpr int MSM_MAX_WINS = 1024;          // digit windows of all problems of one pass (the sort kernels keep their table in LDS)
+constexpr int MSM_MAX_WINS = 2048;          // digit windows of all problems of one pass: 64 problems x 32 windows of 8 bits, the narrowest a batch uses (the sort kernels keep the table in LDS: 32 KiB)
 
 // Geometry of one pass over one or several problems (built on the host: msm_build_geometry, msm.hip).  A problem's 256 scalar bits
 // are cut into DIGIT WINDOWS of its own widths -- two widths one bit apart, so that they add up to exactly 256 and no window is sparse
