@@ -53,7 +53,7 @@ def test_msm_batch_geometry_host_logic():
     _native.build()
     lib = C.CDLL(_native.LIB_PATH)
     lib.zkhip_msm_geometry_info.restype = C.c_int
-    cases = [[1 << (19 - i) for i in range(20)], [1, 1, 1], [5], [1 << 19, 3], [4096] * 40, [1 << 17] * 8, [0, 7, 0], [1 << 19] * 2 + [1 << 10] * 30, [3] * 64, [1 << 14] * 64, [1 << 19] + [100] * 63]
+    cases = [[1 << (19 - i) for i in range(20)], [1, 1, 1], [5], [1 << 19, 3], [4096] * 40, [1 << 17] * 8, [0, 7, 0], [1 << 19] * 2 + [1 << 10] * 30, [3] * 64, [1 << 14] * 64, [1 << 19] + [100] * 63, [1 << 20] * 64, [1 << 24] * 64]
     for sizes in cases:
         n = len(sizes)
         offs = (C.c_size_t * (n + 1))(*[sum(sizes[:j]) for j in range(n + 1)])

@@ -79,7 +79,8 @@ static int msm_build_geometry(const MsmProblems& pr, bool shared, size_t table_s
         if (v >= 0 && v <= 8) delta = v;
     }
     int rc = ZKHIP_ERR_SHAPE;
-    for (; delta <= 9 && rc == ZKHIP_ERR_SHAPE; ++delta) rc = msm_build_geometry_at(pr, shared, table_stride, delta, g);   // narrower windows until the sort's partitions suffice
+    // narrower windows until the sort's partitions suffice (at 8 bits -- the floor -- 64 problems have 2048)
+    for (; delta <= 24 && rc == ZKHIP_ERR_SHAPE; ++delta) rc = msm_build_geometry_at(pr, shared, table_stride, delta, g);
     return rc;
 }
 static int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t table_stride, int delta, MsmGeometry& g) {
