@@ -200,8 +200,9 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     const size_t o_counts = 0;
     const size_t o_offsets = o_counts + al(n_buckets * 4);
     const size_t o_order = o_offsets + al(n_buckets * 4);
-    const size_t o_bins = o_order + al(n_buckets * 4);
-    const size_t o_sorted = o_bins + al(MSM_COUNT_BINS * 4);
+    const size_t o_bins = o_order + al(n_buckets * 4);                  // the order pass's bins and, right behind them, the heavy lists' counters:
+    const size_t o_ovf = o_bins + al(MSM_COUNT_BINS * 4);               //   ONE memset clears both
+    const size_t o_sorted = o_ovf + al(sizeof(MsmOverflow));
     const size_t n_wgs = (n + SORT_TILE - 1) / SORT_TILE;
     const size_t o_items = o_sorted + al(geo.items * 4);
     const size_t o_wgc = o_items + al(geo.items * 8);
@@ -219,8 +220,7 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     const size_t rec_cap = items_max / heavy_min + items_max / MSM_HEAVY_REC + 2;
     const size_t slots_cap = 3 * (items_max / MSM_HEAVY_REC) + 8;
     const size_t o_rc = o_terms + al(n_out * 192);                       // rows / columns of the segment sums (msm_rowcol_kernel)
-    const size_t o_ovf = o_rc + al((size_t)pl.n_rc * 256);
-    const size_t o_rec = o_ovf + al(sizeof(MsmOverflow));
+    const size_t o_rec = o_rc + al((size_t)pl.n_rc * 256);
     const size_t o_part = o_rec + al(MSM_HEAVY_LEVELS * rec_cap * sizeof(MsmHeavyRec));
     const size_t total = o_part + al(slots_cap * 256);
     if (ws_used) *ws_used = total;
@@ -290,7 +290,7 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
         // FRONT of the accumulate pass (on a second stream beside it they did not find a free slot for most of its duration -- its
         // first workgroups walk the longest lists and hold every register of the chip)
         ProfScope ps(c, "msm_overflow", 0.0);
-        ZK_HIP(c, hipMemsetAsync(ovf, 0, sizeof(MsmOverflow), c->stream));
+        ZK_HIP(c, hipMemsetAsync(bins, 0, (size_t)(o_sorted - o_bins), c->stream));      // bins + MsmOverflow
         hipLaunchKernelGGL(msm_file_heavy_kernel, dim3((unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK)), dim3(MSM_BLOCK), 0, c->stream, offsets, counts,
                            (uint32_t)n_buckets, heavy_min, ovf, rec, (uint32_t)rec_cap);
         hipLaunchKernelGGL(msm_heavy_points_kernel, dim3(512) /* 64 KiB of LDS each: two per CU are resident, the records are walked in a loop */, dim3(MSM_BLOCK), MSM_BLOCK * 256, c->stream, points_u, sorted, ovf, rec,
@@ -302,7 +302,6 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     {   // bucket order by descending point count
         ProfScope ps(c, "msm_order", 0.0);
         const unsigned gb = (unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK);
-        ZK_HIP(c, hipMemsetAsync(bins, 0, MSM_COUNT_BINS * 4, c->stream));
         hipLaunchKernelGGL(msm_order_hist_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins);
         hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bins);
         hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins, order);
