@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage (this container, repo root, after `gpurun -- tools/collect_r03.sh; tools/prof_open.sh` merged gpurun_out/r03/): copy what is judged into profiles/r03/
+set -e
+R=gpurun_out/r03 P=profiles/r03
+cp $R/stats/runc/*kernel_stats.csv $P/a_bench_kernel_stats.csv
+cp $R/bench_under_rocprof.json $P/a_bench_line_under_rocprof.json
+cp $R/stats_prover/runc/*kernel_stats.csv $P/a2_prover_kernel_stats.csv
+cp $R/bench_prover_under_rocprof.json $P/a2_prover_line_under_rocprof.json
+cp $R/a_bench_line_default_run.json $P/
+cp $R/b_prover_timeline.txt $R/c_proofs_in_flight_timeline.txt $R/open_last_call_trace.txt $P/
+cp $R/pmc_fetch/runc/*counter_collection.csv $P/pmc_fetch_counter_collection.csv
+cp $R/pmc_write/runc/*counter_collection.csv $P/pmc_write_counter_collection.csv
+python tools/pmc_summary.py $P/pmc_fetch_counter_collection.csv $P/pmc_write_counter_collection.csv $P/pmc_traffic.json | grep -i "multifold\|fine_sums\|fold_kernel"
+python tools/bench_summary.py < $P/a_bench_line_default_run.json | head -8
+grep "fine_sums\|multifold_mfma\|fold_kernel<false>" $P/a2_prover_kernel_stats.csv | sed 's/(.*)"/"/' | cut -d, -f1-4
+grep "fine_sums\|multifold_mfma" $P/a_bench_kernel_stats.csv | sed 's/(.*)"/"/' | cut -d, -f1-4
