@@ -149,7 +149,7 @@ struct MsmProblems {
 // the problems' ranges and the digit windows in LDS (read per scalar / per (scalar, window) by both passes over the scalars; the
 // kernel argument itself, indexed by a value that differs from lane to lane, is read through a loop over the lanes' values)
 struct MsmSortTables {
-    uint4 wl[MSM_MAX_WINS];
+    uint4 wl[MSM_MAX_WINS + 1];          // one entry of slack: the loops read the descriptor behind the last window
     uint32_t off[MSM_MAX_PROBLEMS + 1];
     uint32_t win_first[MSM_MAX_PROBLEMS + 1];
 };
@@ -185,11 +185,14 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_count_kernel(const 
         if (i >= n || (inf && inf[i])) continue;
         DigitStream ds(load_fr(scalars, i).from_mont());
         const uint32_t j = pr.n > 1 ? msm_problem_of(tab, pr.n, (uint32_t)i) : 0u;
-        for (uint32_t v = tab.win_first[j], v_end = tab.win_first[j + 1]; v < v_end; ++v) {
-            const uint4 w = tab.wl[v];
+        uint32_t v = tab.win_first[j];
+        const uint32_t v_end = tab.win_first[j + 1];
+        uint4 w = tab.wl[v];
+        for (; v < v_end; ++v) {
+            const uint4 w_next = tab.wl[v + 1];      // the next window's descriptor is on its way while this digit is cut (one entry of slack behind the table)
             const int32_t d = ds.next(w.z & 0xffu);
-            if (d == 0) continue;
-            atomicAdd(&local[msm_partition_of(w, d < 0 ? (uint32_t)(-d) : (uint32_t)d)], 1u);
+            if (d != 0) atomicAdd(&local[msm_partition_of(w, d < 0 ? (uint32_t)(-d) : (uint32_t)d)], 1u);
+            w = w_next;
         }
     }
     __syncthreads();
@@ -269,14 +272,19 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_scatter_kernel(cons
         if (i >= n || (inf && inf[i])) continue;
         DigitStream ds(load_fr(scalars, i).from_mont());
         const uint32_t j = pr.n > 1 ? msm_problem_of(tab, pr.n, (uint32_t)i) : 0u;
-        for (uint32_t v = tab.win_first[j], v_end = tab.win_first[j + 1]; v < v_end; ++v) {
-            const uint4 w = tab.wl[v];
+        uint32_t v = tab.win_first[j];
+        const uint32_t v_end = tab.win_first[j + 1];
+        uint4 w = tab.wl[v];
+        for (; v < v_end; ++v) {
+            const uint4 w_next = tab.wl[v + 1];
             const int32_t d = ds.next(w.z & 0xffu);
-            if (d == 0) continue;
-            const bool neg = d < 0;
-            const uint32_t mag = neg ? (uint32_t)(-d) : (uint32_t)d;
-            const uint32_t pos = atomicAdd(&cur[msm_partition_of(w, mag)], 1u);
-            items[pos] = make_uint2((w.y + (uint32_t)i) | (neg ? 0x80000000u : 0u), (mag - 1) & ((1u << msm_win_sub_bits(w)) - 1));
+            if (d != 0) {
+                const bool neg = d < 0;
+                const uint32_t mag = neg ? (uint32_t)(-d) : (uint32_t)d;
+                const uint32_t pos = atomicAdd(&cur[msm_partition_of(w, mag)], 1u);
+                items[pos] = make_uint2((w.y + (uint32_t)i) | (neg ? 0x80000000u : 0u), (mag - 1) & ((1u << msm_win_sub_bits(w)) - 1));
+            }
+            w = w_next;
         }
     }
 }
