@@ -283,16 +283,16 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
         hipLaunchKernelGGL(msm_sort_part_scan_kernel, dim3(1), dim3(1024), 0, c->stream, part_count, pl.n_parts, part_off);
         hipLaunchKernelGGL(msm_sort_scatter_kernel, dim3((unsigned)n_wgs), dim3(MSM_BLOCK), 0, c->stream, d_scalars, d_points_inf, n, pl, pr,
                            wg_counts, part_off, items);
-        hipLaunchKernelGGL(msm_sort_local_kernel, dim3(pl.n_parts), dim3(SORT_LOCAL_BLOCK), 0, c->stream, items, part_off, pl, sorted, counts, offsets);
+        // level 2 also takes the histogram of the bucket counts (the order pass) and files the heavy buckets: both cleared here
+        ZK_HIP(c, hipMemsetAsync(bins, 0, (size_t)(o_sorted - o_bins), c->stream));      // bins + MsmOverflow
+        hipLaunchKernelGGL(msm_sort_local_kernel, dim3(pl.n_parts), dim3(SORT_LOCAL_BLOCK), 0, c->stream, items, part_off, pl, sorted, counts, offsets,
+                           heavy_min, ovf, rec, (uint32_t)rec_cap, bins);
     }
     {
-        // heavy buckets (none with uniform scalars: five empty launches): filed by a pass of their own and summed by passes 4b / 4c IN
+        // heavy buckets (none with uniform scalars: four empty launches): filed by the sort and summed by passes 4b / 4c IN
         // FRONT of the accumulate pass (on a second stream beside it they did not find a free slot for most of its duration -- its
         // first workgroups walk the longest lists and hold every register of the chip)
         ProfScope ps(c, "msm_overflow", 0.0);
-        ZK_HIP(c, hipMemsetAsync(bins, 0, (size_t)(o_sorted - o_bins), c->stream));      // bins + MsmOverflow
-        hipLaunchKernelGGL(msm_file_heavy_kernel, dim3((unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK)), dim3(MSM_BLOCK), 0, c->stream, offsets, counts,
-                           (uint32_t)n_buckets, heavy_min, ovf, rec, (uint32_t)rec_cap);
         hipLaunchKernelGGL(msm_heavy_points_kernel, dim3(512) /* 64 KiB of LDS each: two per CU are resident, the records are walked in a loop */, dim3(MSM_BLOCK), MSM_BLOCK * 256, c->stream, points_u, sorted, ovf, rec,
                            partials, buckets);
         for (int level = 1; level < MSM_HEAVY_LEVELS; ++level)
@@ -302,7 +302,6 @@ static int msm_enqueue(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t*
     {   // bucket order by descending point count
         ProfScope ps(c, "msm_order", 0.0);
         const unsigned gb = (unsigned)((n_buckets + MSM_BLOCK - 1) / MSM_BLOCK);
-        hipLaunchKernelGGL(msm_order_hist_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins);
         hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(1024), 0, c->stream, bins);
         hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(gb), dim3(MSM_BLOCK), 0, c->stream, counts, (uint32_t)n_buckets, bins, order);
     }

@@ -11,7 +11,7 @@
 //                (msm_sort_*), which also yields every bucket's count and offset;
 //   3. order:    buckets are ranked by point count, heaviest first;
 //   4. accumulate: one lane per bucket adds its points (mixed XYZZ additions); buckets far heavier than the
-//                mean are filed (msm_file_heavy_kernel) and summed by whole workgroups in front of it (4b / 4c);
+//                mean are filed by the sort and summed by whole workgroups in front of it (4b / 4c);
 //   5. segments: every L consecutive buckets are folded by a local running sum into
 //                S_s = sum B and A_s = sum (j+1) B  -- short dependency chains only;
 //   6. terms:    per BUCKET SET (MsmSet), sum_s A_s and, for every bit k of the segment index, T_k = sum_{s: bit k} S_s
@@ -86,18 +86,7 @@ struct DigitStream {
 // Bucket processing order: buckets sorted by their point count, heaviest first, so that the 64 lanes of a wave
 // walk lists of (nearly) equal length.  Counting sort over the clamped count.
 constexpr uint32_t MSM_COUNT_BINS = 1024;
-// (counts cluster around their mean, so the bins are few and hot: aggregate in LDS, one global atomic per bin and workgroup)
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_order_hist_kernel(const uint32_t* __restrict__ counts, uint32_t n_buckets,
-                                                                          uint32_t* __restrict__ bins) {
-    __shared__ uint32_t local[MSM_COUNT_BINS];
-    for (uint32_t i = threadIdx.x; i < MSM_COUNT_BINS; i += MSM_BLOCK) local[i] = 0;
-    __syncthreads();
-    const uint32_t b = blockIdx.x * MSM_BLOCK + threadIdx.x;
-    if (b < n_buckets) atomicAdd(&local[MSM_COUNT_BINS - 1 - min(counts[b], MSM_COUNT_BINS - 1)], 1u);
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < MSM_COUNT_BINS; i += MSM_BLOCK)
-        if (local[i]) atomicAdd(&bins[i], local[i]);
-}
+// (the histogram itself is taken by msm_sort_local_kernel, which has every bucket's count in hand)
 static __global__ __launch_bounds__(1024) void msm_order_scan_kernel(uint32_t* __restrict__ bins) {
     __shared__ uint32_t part[1024];
     const uint32_t v = bins[threadIdx.x];
@@ -289,81 +278,9 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_scatter_kernel(cons
     }
 }
 
-// level 2: one workgroup per partition; writes the final order plus counts / offsets of its 2^sub_bits buckets.
-// Skewed scalars make partitions of very different sizes (all points of a 0/1 table fall into one), so the
-// workgroup is wide (1024 lanes of loads in flight) and a wave whose lanes all hold the same bucket -- the case that
-// would serialise 64-fold on one LDS word -- issues a single aggregated atomic.
-constexpr int SORT_LOCAL_BLOCK = 1024;
-__device__ __forceinline__ uint32_t msm_lds_rank(uint32_t* bins, uint32_t key) {   // atomicAdd(&bins[key], 1), aggregated
-    const uint64_t active = __ballot(1);
-    const uint32_t first = __builtin_amdgcn_readfirstlane(key);
-    if (__ballot(key == first) == active) {
-        const uint32_t lane = threadIdx.x & 63;
-        const uint32_t below = __popcll(active & (((uint64_t)1 << lane) - 1));
-        uint32_t base = 0;
-        if (below == 0) base = atomicAdd(&bins[first], (uint32_t)__popcll(active));
-        return __builtin_amdgcn_readfirstlane(base) + below;
-    }
-    return atomicAdd(&bins[key], 1u);
-}
-static __global__ __launch_bounds__(SORT_LOCAL_BLOCK) void msm_sort_local_kernel(const uint2* __restrict__ items,
-                                                                                 const uint32_t* __restrict__ part_off, MsmPlan pl,
-                                                                                 uint32_t* __restrict__ sorted,
-                                                                                 uint32_t* __restrict__ counts,
-                                                                                 uint32_t* __restrict__ offsets) {
-    __shared__ uint32_t bins[256];
-    __shared__ uint32_t scan[256];
-    const uint32_t p = blockIdx.x;
-    const uint32_t lo = part_off[p], hi = part_off[p + 1];
-    const MsmSet set = pl.sets[pl.part_set[p]];
-    const uint32_t sub_bits = msm_set_c(set) - 1 - msm_set_part_bits(set);
-    const uint32_t n_sub = 1u << sub_bits;                              // the partition's buckets: the low bits of the index (<= 8)
-    if (threadIdx.x < 256) bins[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t q = lo + threadIdx.x; q < hi; q += SORT_LOCAL_BLOCK) msm_lds_rank(bins, items[q].y);
-    __syncthreads();
-    // exclusive scan of the (<= 256) bins
-    const uint32_t v = threadIdx.x < n_sub ? bins[threadIdx.x] : 0;
-    if (threadIdx.x < 256) scan[threadIdx.x] = v;
-    __syncthreads();
-    for (uint32_t d = 1; d < 256; d <<= 1) {
-        uint32_t t = (threadIdx.x < 256 && threadIdx.x >= d) ? scan[threadIdx.x - d] : 0;
-        __syncthreads();
-        if (threadIdx.x < 256) scan[threadIdx.x] += t;
-        __syncthreads();
-    }
-    if (threadIdx.x < n_sub) {
-        const uint32_t excl = scan[threadIdx.x] - v;
-        const uint32_t bucket = set.bucket_base + ((p - set.part_base) << sub_bits) + threadIdx.x;
-        counts[bucket] = v;
-        offsets[bucket] = lo + excl;
-        bins[threadIdx.x] = lo + excl;      // becomes the write cursor
-    }
-    __syncthreads();
-    for (uint32_t q = lo + threadIdx.x; q < hi; q += SORT_LOCAL_BLOCK) {
-        const uint2 it = items[q];
-        sorted[msm_lds_rank(bins, it.y)] = it.x;
-    }
-}
-
-// pass 0: SRS points from the arkworks layout (96 B) into the internal unsaturated layout (128 B), once per commit
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_convert_points_kernel(const uint64_t* __restrict__ points, size_t n,
-                                                                              uint32_t* __restrict__ out) {
-    const size_t stride = (size_t)gridDim.x * MSM_BLOCK;
-    for (size_t i = (size_t)blockIdx.x * MSM_BLOCK + threadIdx.x; i < n; i += stride) {
-        G1Affine a = load_affine(points, i);
-        store_fqu(out + 32 * i, fqu_from_ark(a.x));
-        store_fqu(out + 32 * i + 16, fqu_from_ark(a.y));
-    }
-}
-
-// pass 4: one lane per bucket (in the order given by `order`: heaviest buckets first, equal lengths inside a wave).
-// Skewed scalars (small table values, constant polynomials, a sparse top window) can put a large share of all
-// points into a handful of buckets, and one lane adding 2^20 points one after the other would take seconds.  A
-// bucket holding more than `heavy_min` points is therefore not walked by its lane: the lane files it as records of
-// <= 2048 points for pass 4b, where a whole workgroup sums a record (<= 8 points per lane, then a tree in LDS),
-// and, when the bucket spans several records, as a tree of <= 256-way sums over the record sums for pass 4c.
-// With uniform scalars no bucket is heavy and 4b / 4c find empty lists.
+// Heavy buckets (pass 4 below walks a bucket with one lane): a bucket holding more than `heavy_min` points is filed as records of
+// <= 2048 points for pass 4b, where a whole workgroup sums a record (<= 8 points per lane, then a tree in LDS), and, when the bucket
+// spans several records, as a tree of <= 256-way sums over the record sums for pass 4c.  With uniform scalars no bucket is heavy.
 constexpr uint32_t MSM_HEAVY_LANE_MAX = 8;                        // points per lane inside a record (32 in rounds 1-3: the pass is a latency chain of that many additions plus the tree)
 constexpr uint32_t MSM_HEAVY_REC = MSM_BLOCK * MSM_HEAVY_LANE_MAX;   // points per record
 constexpr int MSM_HEAVY_LEVELS = 4;                               // 0: records of points; 1..3: 256-way sums of sums
@@ -377,25 +294,6 @@ struct MsmOverflow {
     uint32_t n_slots;
     uint32_t n_rec[MSM_HEAVY_LEVELS];
 };
-
-__device__ __forceinline__ G1XyzzU msm_sum_run(const uint32_t* __restrict__ points, const uint32_t* __restrict__ sorted,
-                                               uint32_t start, uint32_t cnt) {
-    G1XyzzU acc = G1XyzzU::identity();
-    // software pipeline: the next point's index and coordinates (a dependent pair of random loads) are in flight
-    // while the current addition (~6 k instructions) runs
-    uint32_t e_next = cnt ? sorted[start] : 0u;
-    G1AffineU p_next = load_affine_u(points, e_next & 0x7fffffffu);
-    for (uint32_t k = 0; k < cnt; ++k) {
-        const uint32_t e = e_next;
-        const G1AffineU p = p_next;
-        if (k + 1 < cnt) {
-            e_next = sorted[start + k + 1];
-            p_next = load_affine_u(points, e_next & 0x7fffffffu);
-        }
-        g1u_madd(acc, p, (e >> 31) != 0);
-    }
-    return acc;
-}
 
 // files bucket b (cnt points from `start`) into the record lists; rec[l] has room for rec_cap records per level
 __device__ __noinline__ void msm_file_heavy(uint32_t b, uint32_t start, uint32_t cnt, MsmOverflow* __restrict__ ovf,
@@ -432,6 +330,105 @@ __device__ __noinline__ void msm_file_heavy(uint32_t b, uint32_t start, uint32_t
     }
 }
 
+// level 2: one workgroup per partition; writes the final order plus counts / offsets of its 2^sub_bits buckets.
+// Skewed scalars make partitions of very different sizes (all points of a 0/1 table fall into one), so the
+// workgroup is wide (1024 lanes of loads in flight) and a wave whose lanes all hold the same bucket -- the case that
+// would serialise 64-fold on one LDS word -- issues a single aggregated atomic.
+constexpr int SORT_LOCAL_BLOCK = 1024;
+__device__ __forceinline__ uint32_t msm_lds_rank(uint32_t* bins, uint32_t key) {   // atomicAdd(&bins[key], 1), aggregated
+    const uint64_t active = __ballot(1);
+    const uint32_t first = __builtin_amdgcn_readfirstlane(key);
+    if (__ballot(key == first) == active) {
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t below = __popcll(active & (((uint64_t)1 << lane) - 1));
+        uint32_t base = 0;
+        if (below == 0) base = atomicAdd(&bins[first], (uint32_t)__popcll(active));
+        return __builtin_amdgcn_readfirstlane(base) + below;
+    }
+    return atomicAdd(&bins[key], 1u);
+}
+static __global__ __launch_bounds__(SORT_LOCAL_BLOCK) void msm_sort_local_kernel(const uint2* __restrict__ items,
+                                                                                 const uint32_t* __restrict__ part_off, MsmPlan pl,
+                                                                                 uint32_t* __restrict__ sorted,
+                                                                                 uint32_t* __restrict__ counts,
+                                                                                 uint32_t* __restrict__ offsets, uint32_t heavy_min,
+                                                                                 MsmOverflow* __restrict__ ovf, MsmHeavyRec* __restrict__ rec,
+                                                                                 uint32_t rec_cap, uint32_t* __restrict__ count_bins) {
+    __shared__ uint32_t bins[256];
+    __shared__ uint32_t scan[256];
+    __shared__ uint32_t hist[MSM_COUNT_BINS];     // this partition's share of the bucket-count histogram (pass 3 orders the buckets by it)
+    static_assert(SORT_LOCAL_BLOCK == (int)MSM_COUNT_BINS, "one histogram bin per lane");
+    hist[threadIdx.x] = 0;
+    const uint32_t p = blockIdx.x;
+    const uint32_t lo = part_off[p], hi = part_off[p + 1];
+    const MsmSet set = pl.sets[pl.part_set[p]];
+    const uint32_t sub_bits = msm_set_c(set) - 1 - msm_set_part_bits(set);
+    const uint32_t n_sub = 1u << sub_bits;                              // the partition's buckets: the low bits of the index (<= 8)
+    if (threadIdx.x < 256) bins[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t q = lo + threadIdx.x; q < hi; q += SORT_LOCAL_BLOCK) msm_lds_rank(bins, items[q].y);
+    __syncthreads();
+    // exclusive scan of the (<= 256) bins
+    const uint32_t v = threadIdx.x < n_sub ? bins[threadIdx.x] : 0;
+    if (threadIdx.x < 256) scan[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        uint32_t t = (threadIdx.x < 256 && threadIdx.x >= d) ? scan[threadIdx.x - d] : 0;
+        __syncthreads();
+        if (threadIdx.x < 256) scan[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (threadIdx.x < n_sub) {
+        const uint32_t excl = scan[threadIdx.x] - v;
+        const uint32_t bucket = set.bucket_base + ((p - set.part_base) << sub_bits) + threadIdx.x;
+        counts[bucket] = v;
+        offsets[bucket] = lo + excl;
+        bins[threadIdx.x] = lo + excl;      // becomes the write cursor
+        atomicAdd(&hist[MSM_COUNT_BINS - 1 - min(v, MSM_COUNT_BINS - 1)], 1u);
+        if (v > heavy_min) msm_file_heavy(bucket, lo + excl, v, ovf, rec, rec_cap);     // passes 4b / 4c sum it
+    }
+    __syncthreads();
+    if (hist[threadIdx.x]) atomicAdd(&count_bins[threadIdx.x], hist[threadIdx.x]);     // counts cluster around their mean: few, hot bins
+    for (uint32_t q = lo + threadIdx.x; q < hi; q += SORT_LOCAL_BLOCK) {
+        const uint2 it = items[q];
+        sorted[msm_lds_rank(bins, it.y)] = it.x;
+    }
+}
+
+// pass 0: SRS points from the arkworks layout (96 B) into the internal unsaturated layout (128 B), once per commit
+static __global__ __launch_bounds__(MSM_BLOCK) void msm_convert_points_kernel(const uint64_t* __restrict__ points, size_t n,
+                                                                              uint32_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * MSM_BLOCK;
+    for (size_t i = (size_t)blockIdx.x * MSM_BLOCK + threadIdx.x; i < n; i += stride) {
+        G1Affine a = load_affine(points, i);
+        store_fqu(out + 32 * i, fqu_from_ark(a.x));
+        store_fqu(out + 32 * i + 16, fqu_from_ark(a.y));
+    }
+}
+
+// pass 4: one lane per bucket (in the order given by `order`: heaviest buckets first, equal lengths inside a wave).
+// Skewed scalars (small table values, constant polynomials, a sparse top window) can put a large share of all
+// points into a handful of buckets, and one lane adding 2^20 points one after the other would take seconds: the
+// heavy buckets (filed by the sort, above) are left to passes 4b / 4c.
+__device__ __forceinline__ G1XyzzU msm_sum_run(const uint32_t* __restrict__ points, const uint32_t* __restrict__ sorted,
+                                               uint32_t start, uint32_t cnt) {
+    G1XyzzU acc = G1XyzzU::identity();
+    // software pipeline: the next point's index and coordinates (a dependent pair of random loads) are in flight
+    // while the current addition (~6 k instructions) runs
+    uint32_t e_next = cnt ? sorted[start] : 0u;
+    G1AffineU p_next = load_affine_u(points, e_next & 0x7fffffffu);
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const uint32_t e = e_next;
+        const G1AffineU p = p_next;
+        if (k + 1 < cnt) {
+            e_next = sorted[start + k + 1];
+            p_next = load_affine_u(points, e_next & 0x7fffffffu);
+        }
+        g1u_madd(acc, p, (e >> 31) != 0);
+    }
+    return acc;
+}
+
 static __global__ __launch_bounds__(MSM_BLOCK) void msm_accumulate_kernel(const uint32_t* __restrict__ points,
                                                                    const uint32_t* __restrict__ sorted,
                                                                    const uint32_t* __restrict__ offsets,
@@ -442,20 +439,9 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_accumulate_kernel(const 
     if (t >= n_buckets) return;
     const uint32_t b = order[t];
     const uint32_t start = offsets[b], cnt = counts[b];
-    if (cnt > heavy_min) return;                            // filed by msm_file_heavy_kernel; passes 4b / 4c write buckets[b]
+    if (cnt > heavy_min) return;                            // filed by msm_sort_local_kernel; passes 4b / 4c write buckets[b]
     store_xyzz_u(buckets, b, msm_sum_run(points, sorted, start, cnt));
 }
-// The heavy buckets are filed by a pass of their own: 4b / 4c then depend on the sort alone and run in FRONT of the accumulate pass
-// (a few hundred latency-bound workgroups; see msm_enqueue).
-static __global__ __launch_bounds__(MSM_BLOCK) void msm_file_heavy_kernel(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                                                                          uint32_t n_buckets, uint32_t heavy_min, MsmOverflow* __restrict__ ovf,
-                                                                          MsmHeavyRec* __restrict__ rec, uint32_t rec_cap) {
-    const uint32_t b = blockIdx.x * MSM_BLOCK + threadIdx.x;
-    if (b >= n_buckets) return;
-    const uint32_t cnt = counts[b];
-    if (cnt > heavy_min) msm_file_heavy(b, offsets[b], cnt, ovf, rec, rec_cap);
-}
-
 // tree sum over the first `width` lanes' values (width a power of two <= MSM_BLOCK); the result is lane 0's `acc`
 __device__ __forceinline__ void msm_block_tree_sum(G1XyzzU& acc, uint32_t width, uint32_t* __restrict__ lds) {
     if (threadIdx.x < width) store_xyzz_u(lds, threadIdx.x, acc);
