@@ -147,32 +147,54 @@ def _batches(step, steps, barrier, dist, world, torch, min_total=MIN_LEG_SECONDS
     return out, res
 
 
-def bench_exchange(dist, world, torch, own_group):
-    """What ONE exchange of the sharded provers costs end to end on this backend: torch.distributed.all_gather_into_tensor of 64 B /
-    8 KiB / 64 KiB per rank issued from Python back to back (the protocols' pattern: a collective between two C-ABI calls).  At
-    world 1 this is the fixed cost of the call path (Python -> c10d -> RCCL launch) that every rank count pays."""
-    out = {"backend": "nccl (RCCL)", "world": world}
+def bench_exchange(comm, world):
+    """What ONE exchange of the sharded provers costs, measured INSIDE the library on the communicator the provers use
+    (zkhip_comm_measure): all-gathers of 64 B / 8 KiB / 64 KiB per rank issued on the context's stream back to back -- the protocols'
+    pattern: an exchange is followed by more enqueues, never by a host wait -- and, as the upper bound, with the host waiting for each.
+    At world 1 over a one-rank RCCL communicator this is the fixed cost of the call path that every rank count pays."""
+    out = {"transport": comm.transport if isinstance(comm.transport, str) else "callback", "world": world,
+           "measured": "inside libzkhip: ncclAllGather on the context's stream (zkhip_comm_measure)"}
     for nbytes in (64, 8192, 65536):
-        send = torch.zeros(nbytes // 8, dtype=torch.int64, device="cuda")
-        recv = torch.empty(world * (nbytes // 8), dtype=torch.int64, device="cuda")
-        for _ in range(20):
-            dist.all_gather_into_tensor(recv, send)
-        torch.cuda.synchronize()
-        reps = 200
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            dist.all_gather_into_tensor(recv, send)
-        torch.cuda.synchronize()
-        us = 1e6 * (time.perf_counter() - t0) / reps
-        # one at a time, waited for (an exchange the next kernel launch depends on is followed by more enqueues, not by a host wait; this
-        # is the upper bound)
-        t0 = time.perf_counter()
-        for _ in range(50):
-            dist.all_gather_into_tensor(recv, send)
-            torch.cuda.synchronize()
-        us_sync = 1e6 * (time.perf_counter() - t0) / 50
-        out["%d_B" % nbytes] = {"back_to_back_us": round(us, 2), "with_host_wait_us": round(us_sync, 2)}
+        b2b, waited = comm.measure(nbytes, 200)
+        out["%d_B" % nbytes] = {"back_to_back_us": round(b2b, 2), "with_host_wait_us": round(waited, 2)}
     return out
+
+
+def selftest(zk, np, torch, N, D, comm, rank, world, dist, same_on_all_ranks):
+    """Before anything is timed at N > 1: one small sharded sumcheck / composed / GKR proof and one sharded commit through the in-library
+    protocols, every rank's result compared with rank 0's and with the single-GPU prover on the whole input.  Any mismatch ends the job
+    with a non-zero status (nothing is swallowed at N > 1)."""
+    res = {}
+    log_n = 18
+    full = zk.Fr.synthetic(1 << log_n, SEED_TABLE + 0x700)                # the same whole table on every rank
+    sc = zk.Sumcheck(zk.Multilinear(full))
+    sc.poly_sum()
+    want, want_ch = sc.prove()
+    shard = torch.from_numpy(np.ascontiguousarray(full[rank::world]).view(np.int64)).cuda()
+    sh = D.ShardedSumcheck(D.HipSumcheckEngine(shard), world, comm=comm)
+    s_, rp_, ch_ = sh.prove()
+    ok = np.array_equal(s_, want.sum) and np.array_equal(rp_, want.univariate_poly) and np.array_equal(ch_, want_ch)
+    res["sumcheck_2^%d" % log_n] = bool(ok and same_on_all_ranks(np.concatenate([rp_.reshape(-1), ch_.reshape(-1)])))
+    tabs = [zk.Fr.synthetic(1 << 16, SEED_TABLE + 0x710 + k) for k in range(2)]
+    wproof, wch = zk.ComposedSumcheck(zk.ComposedMultilinear([zk.Multilinear(t) for t in tabs])).prove()
+    eng = D.HipComposedEngine([[torch.from_numpy(np.ascontiguousarray(t[rank::world]).view(np.int64)).cuda() for t in tabs]], world, multi=False)
+    rp_, ch_ = D.ShardedComposedSumcheck(eng, world, comm=comm).prove()
+    ok = np.array_equal(rp_, wproof.round_polys) and np.array_equal(ch_, wch)
+    res["composed_2x2^16"] = bool(ok and same_on_all_ranks(np.concatenate([np.asarray(rp_).reshape(-1), ch_.reshape(-1)])))
+    circuit = zk.Circuit.random(12)
+    ev = circuit.evaluation(zk.Fr.synthetic(1 << 12, SEED_GKR + 0x700))
+    wgkr = zk.GKRProtocol.prove(circuit, ev)
+    got = zk.GKRProtocol.prove_sharded(circuit, ev, world, rank, comm=comm)
+    ok = all(a.to_bytes() == b.to_bytes() for a, b in zip(got.sumcheck_proofs, wgkr.sumcheck_proofs))
+    ok = ok and all(np.array_equal(a, b) for a, b in zip(got.wb_s + got.wc_s, wgkr.wb_s + wgkr.wc_s))
+    res["gkr_depth_12"] = bool(ok and same_on_all_ranks(np.concatenate([np.asarray(w, dtype=np.uint64).reshape(-1) for w in got.wb_s + got.wc_s])))
+    srs = zk.TrustedSetup.setup(zk.Fr.synthetic(12, SEED_SCALARS + 0x700))
+    scal = zk.Fr.synthetic(1 << 12, SEED_SCALARS + 0x701)
+    wc = zk.MultilinearKZG.commitment(zk.Multilinear(scal), srs)
+    xy, inf = D.sharded_commit(srs.powers_of_tau_in_g1[rank::world].contiguous(), srs.inf[rank::world].contiguous(),
+                               torch.from_numpy(np.ascontiguousarray(scal[rank::world]).view(np.int64)).cuda(), comm)
+    res["commit_2^12"] = bool((not inf) and np.array_equal(xy, wc.xy) and same_on_all_ranks(np.asarray(xy, dtype=np.uint64)))
+    return res
 
 
 def _all_cores(child_src, work_per_child, unit, what):
@@ -294,12 +316,9 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
     def commit():
         if world == 1:
             return zk.MultilinearKZG.commitment(poly, srs)
-        # N > 1: this rank's (scalars, SRS) are one shard of a world * 2^log_n commit; partial commitments
-        # (104 B per rank) are all-gathered on the device and summed on every rank
-        def local():
-            c = zk.MultilinearKZG.commitment(poly, srs)
-            return c.xy, c.infinity
-        return D.sharded_commit(local, D.hip_sum_affine, world, None, dist, device="cuda")
+        # N > 1: this rank's (scalars, SRS) are one shard of a world * 2^log_n commit; the partial commitments (128 B per rank) are
+        # all-gathered on the device and summed on every rank, inside zkhip_kzg_commit_sharded
+        return D.sharded_commit(None, srs.inf, poly.evaluations, D.Comm.get(N.Context.get(), world, rank, dist), table=srs.table)
 
     for _ in range(2):
         com = commit()
@@ -436,7 +455,7 @@ def bench_composed(args, zk, N, rank, world, barrier, dist, torch, np):
         if world == 1:
             proof, ch = zk.ComposedSumcheck(poly).prove()
             return proof.round_polys, ch
-        sh = D.ShardedComposedSumcheck(D.HipComposedEngine([tables], world, multi=False), world, None, dist)
+        sh = D.ShardedComposedSumcheck(D.HipComposedEngine([tables], world, multi=False), world, comm=D.Comm.get(N.Context.get(), world, rank, dist))
         res = sh.prove()
         exch[0] = sh.exchanges
         return res
@@ -457,7 +476,7 @@ def bench_composed(args, zk, N, rank, world, barrier, dist, torch, np):
             "sharding": "tables sharded by low index bits; two rounds per exchange: one record of 16 cross-block sums (+ 4 block sums) per term and rank all-gathered per stage" if world > 1 else "single GPU"}
 
 
-def bench_gkr(args, zk, rank, world, barrier, dist, torch, np):
+def bench_gkr(args, zk, N, D, rank, world, barrier, dist, torch, np):
     """GKRProtocol::prove (gkr/src/protocol.rs:21-117) on Circuit::random(depth) -- the reference's gkr bench shape at depth 8,
     BASELINE configs[3]'s width 2^20 at depth 20.  Replicas only: every rank proves its own circuit."""
     out = {"workload": "GKRProtocol::prove on Circuit::random(depth), evaluation resident in HBM, circuit resident (zkhip_circuit)",
@@ -478,12 +497,13 @@ def bench_gkr(args, zk, rank, world, barrier, dist, torch, np):
         depth = 20
         circuit = zk.Circuit.random(depth)
         ev = circuit.evaluation(zk.Fr.synthetic(2 ** depth, SEED_GKR))          # the same input on every rank
-        proof = zk.GKRProtocol.prove_sharded(circuit, ev, world, rank, None, dist if world > 1 else None)
+        gcomm = D.Comm.get(N.Context.get(), world, rank, dist if world > 1 else None)
+        proof = zk.GKRProtocol.prove_sharded(circuit, ev, world, rank, comm=gcomm)
         barrier()
         reps = 2
         t0 = time.perf_counter()
         for _ in range(reps):
-            proof = zk.GKRProtocol.prove_sharded(circuit, ev, world, rank, None, dist if world > 1 else None)
+            proof = zk.GKRProtocol.prove_sharded(circuit, ev, world, rank, comm=gcomm)
         barrier()
         dt = (time.perf_counter() - t0) / reps
         same = True
@@ -534,6 +554,7 @@ def bench_strong_and_config4(args, zk, N, rank, world, barrier, dist, torch, np)
     default line is weak scaling (2^log_n per GPU).  (b) BASELINE configs[4]'s shape: a multilinear KZG commit of 2^26 evaluations
     sharded 8-way = 2^23 points per GPU (here: 2^23 per GPU at any N), one all-gather of the partial commitments."""
     from zk_cryptography_amd import distributed as D
+    comm = D.Comm.get(N.Context.get(), world, rank, dist)
     out = {}
     n_total = 1 << args.log_n
     if n_total // world >= 1 << 12:
@@ -541,7 +562,7 @@ def bench_strong_and_config4(args, zk, N, rank, world, barrier, dist, torch, np)
         ex = [0]
 
         def step():
-            sh = D.ShardedSumcheck(D.HipSumcheckEngine(shard), world, None, dist)
+            sh = D.ShardedSumcheck(D.HipSumcheckEngine(shard), world, comm=comm)
             r = sh.prove()
             ex[0] = sh.exchanges
             return r
@@ -561,10 +582,7 @@ def bench_strong_and_config4(args, zk, N, rank, world, barrier, dist, torch, np)
     poly = zk.Multilinear(_synthetic(zk, torch, 1 << log_c, SEED_SCALARS + 0x310 + rank))
 
     def commit():
-        def local():
-            c = zk.MultilinearKZG.commitment(poly, srs)
-            return c.xy, c.infinity
-        return D.sharded_commit(local, D.hip_sum_affine, world, None, dist, device="cuda")
+        return D.sharded_commit(None, srs.inf, poly.evaluations, comm, table=srs.table)
 
     commit()
     bs, com = _batches(commit, 3, barrier, dist, world, torch, min_total=0.2, max_batches=6)
@@ -598,7 +616,7 @@ def bench_prediction(args, zk, N, torch, np, dist_mod, exchange):
         ex = [0]
 
         def step():
-            sh = D.ShardedSumcheck(D.HipSumcheckEngine(t), 1, None, None)
+            sh = D.ShardedSumcheck(D.HipSumcheckEngine(t), 1)
             sh.prove()
             ex[0] = sh.exchanges
         ts = _timed(step, torch, reps=5, min_total=0.15, max_batches=20)
@@ -618,7 +636,7 @@ def bench_prediction(args, zk, N, torch, np, dist_mod, exchange):
     ex = [0]
 
     def cstep():
-        sh = D.ShardedComposedSumcheck(D.HipComposedEngine([tabs], 1, multi=False), 1, None, None, use_stages=True)
+        sh = D.ShardedComposedSumcheck(D.HipComposedEngine([tabs], 1, multi=False), 1, use_stages=True)
         sh.prove()
         ex[0] = sh.exchanges
     ts = _timed(cstep, torch, reps=3, min_total=0.15, max_batches=20)
@@ -633,7 +651,7 @@ def bench_prediction(args, zk, N, torch, np, dist_mod, exchange):
     exg = [0]
 
     def gstep():
-        exg[0] = zk.GKRProtocol.prove_sharded(circuit, ev, 1, 0, None, None, use_stages=True)._exchanges     # two rounds per exchange, as the ranks of a real job run it
+        exg[0] = zk.GKRProtocol.prove_sharded(circuit, ev, 1, 0, use_stages=True)._exchanges     # two rounds per exchange, as the ranks of a real job run it
     tg = _timed(gstep, torch, reps=1, min_total=0.15, max_batches=8)
     t_rep, t_sh = sorted(tr)[len(tr) // 2], sorted(tg)[len(tg) // 2]
     # exchanges: a session exchanges one record per round while (local entries x world) exceeds the tail and then gathers once -- a count
@@ -671,6 +689,7 @@ def main():
     ap.add_argument("--no-pipelined", action="store_true", help="skip the proofs-in-flight leg (profiling: keeps the kernel averages those of the synchronous steps)")
     ap.add_argument("--config4-log-n", type=int, default=23, help="N > 1: log2 of the per-GPU points of the configs[4]-shaped commit (2^26 over 8 = 2^23)")
     ap.add_argument("--no-exchange", action="store_true", help="skip the exchange-cost measurement and the N = 8 prediction")
+    ap.add_argument("--selftest", action="store_true", help="run the sharded provers' self-test (always on at N > 1) on one GPU too")
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")
@@ -712,6 +731,21 @@ def main():
 
     from zk_cryptography_amd import distributed as D
     exchanges = [0]
+    # the communicator of the sharded provers: the library's own RCCL communicator on the `nccl` group (the unique id travels through the
+    # group once), a host-staged callback in the one-GPU dry run, none on one rank
+    comm = D.Comm.get(N.Context.get(), world, rank, dist if world > 1 else None)
+    exchange = None
+    if world > 1 or args.selftest:
+        # ---- self-test before anything is timed: the measured exchange first, then one small proof of every sharded prover against
+        # rank 0 and against the single-GPU prover; a mismatch ends the job (non-zero status on every rank)
+        if world > 1 and not args.no_exchange:
+            exchange = bench_exchange(comm, world)
+        st = selftest(zk, np, torch, N, D, comm, rank, world, dist, (lambda a: _same_on_all_ranks(dist, torch, np, a)) if world > 1 else (lambda a: True))
+        if rank == 0:
+            print("bench.py selftest: " + json.dumps({"exchange": exchange, "n_gpus": world, "sharded_provers_match_single_gpu_and_rank_0": st}), file=sys.stderr, flush=True)
+        if not all(st.values()):
+            sys.stderr.write("bench.py: rank %d: sharded self-test FAILED: %r\n" % (rank, st))
+            sys.exit(3)
 
     def step():
         if world == 1 and not args.force_sharded:
@@ -721,7 +755,7 @@ def main():
         # N > 1: ONE prover over the world * 2^log_n-entry table whose rank-interleaved shard is `table`
         # (overlapped stage: two all-gathers of block sums -- the second one beside the shard's fold -- and one of the 256-entry
         # local tables, over RCCL/xGMI, replicated transcript)
-        sh = D.ShardedSumcheck(D.HipSumcheckEngine(table), world, None, dist)
+        sh = D.ShardedSumcheck(D.HipSumcheckEngine(table), world, comm=comm)
         res = sh.prove()
         exchanges[0] = sh.exchanges
         return res
@@ -800,24 +834,47 @@ def main():
     for _ in range(prof_steps):
         step()
     ms, cnt, by = _profile(N, ctx, b"multifold")
+    per_kernel = {}
+    step_bytes = 0.0
+    for kname, label in ((b"fine_sums", "fine_sums_kernel (poly_sum: sums of every run of 256 entries, 32 n B)"),
+                         (b"multifold", "multifold_mfma_kernel<4, 4> (k-variable fold, 32 (n + n / 2^k) B)"),
+                         (b"chunk_sums", "chunk_sums_kernel (block sums of the generic plan, 32 n B)"),
+                         (b"multifold_small", "multifold_kernel<16> (k-variable fold, few outputs)"), (b"blockfold", "blockfold_kernel (L2-resident)")):
+        kms, kcnt, kby = _profile(N, ctx, kname)
+        step_bytes += kby / prof_steps
+        if kcnt and kby > 0 and kname in (b"fine_sums", b"multifold", b"chunk_sums"):
+            kgbs = kby / (kms * 1e-3) / 1e9
+            per_kernel[kname.decode()] = {"kernel": label, "achieved": round(kgbs, 1), "frac": round(kgbs / HBM_PEAK_GBS, 4), "launches": kcnt,
+                                          "avg_launch_us": round(1e3 * kms / kcnt, 2), "bytes_per_launch": kby / kcnt}
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
     achieved = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    # HBM bytes of that launch from the PMC counters: separate rocprofv3 --pmc passes of this command, committed under
-    # profiles/ (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); a file constant, labelled as such
-    traffic, traffic_source = None, None
+    # HBM bytes per launch from the PMC counters: separate rocprofv3 --pmc passes of this command, committed under profiles/rNN
+    # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); the NEWEST round's file is read and named -- a file constant of that
+    # round's build, labelled as such, not a counter of this run
+    traffic, traffic_source, traffic_all = None, None, None
     try:
-        src = os.path.join("profiles", "r03", "pmc_traffic.json")
-        pmc = json.load(open(os.path.join(ROOT, src)))
-        if args.log_n == 24 and world == 1:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "pmc_traffic.json")))
+        if files and args.log_n == 24 and world == 1:
+            pmc = json.load(open(files[-1]))
+            src = os.path.relpath(files[-1], ROOT)
             traffic = pmc["multifold"]["hbm_bytes_per_launch"]
-            traffic_source = src + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not collected in this run)"
+            traffic_all = {k: v.get("hbm_bytes_per_launch") for k, v in pmc.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
+            traffic_source = src + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in round %s; not collected in this run)" % src.split(os.sep)[1]
     except Exception:
         traffic = None
+    longest = max(per_kernel, key=lambda k: per_kernel[k]["avg_launch_us"]) if per_kernel else None
     roofline = {"bound": "hbm", "kernel": "multifold_mfma_kernel<4, 4> (k-variable fold of the 2^%d table next to the serial rounds, limb products as int8 MFMA; k = 6 at 2^24 on one GPU)" % args.log_n,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "launches": cnt, "avg_launch_us": round(1e3 * ms / max(1, cnt), 2),
-                "algorithmic_bytes_per_launch": "32 B x (table entries read + folded entries written), k variables per launch"}
+                "algorithmic_bytes_per_launch": "32 B x (table entries read + folded entries written), k variables per launch",
+                # every streaming kernel of a step against the same roof, and the step as a whole on the bytes it REALLY moves
+                "per_kernel": per_kernel, "longest_streaming_kernel": longest, "traffic_per_kernel": traffic_all,
+                "step_bytes_moved": step_bytes,
+                "step_hbm_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4) if dt > 0 else None,
+                "step_hbm_frac_note": "bytes the step's kernels really move (their algorithmic bytes, summed) / ms_per_step / 8 TB/s: the proof is "
+                                      "latency-bound by its Fiat-Shamir rounds between and beside the two streaming passes"}
 
     def leg(skip, fn, *a):
         if skip:
@@ -839,28 +896,19 @@ def main():
     ntt = leg(args.no_ntt, bench_ntt, args, zk, N, torch)
     # ---- the composed prover (GKR's sumcheck shape) on sharded tables; informational, never part of `value`
     composed = leg(args.no_composed, bench_composed, args, zk, N, rank, world, barrier, dist, torch, np)
-    gkr = leg(args.no_gkr, bench_gkr, args, zk, rank, world, barrier, dist, torch, np)
+    gkr = leg(args.no_gkr, bench_gkr, args, zk, N, D, rank, world, barrier, dist, torch, np)
     # ---- PCIe-inclusive figure (never `value`), exchange cost and the N = 8 prediction (N = 1), strong scaling + configs[4] shape (N > 1)
     h2d = leg(args.no_h2d or world > 1, bench_h2d, args, zk, N, table, poly, torch, np)
-    exchange = prediction = multi = None
-    if not args.no_exchange and not one_gpu:
-        import torch.distributed as tdist
-        own = False
+    prediction = multi = None
+    if not args.no_exchange and world == 1:
+        # one rank: the call path's fixed cost over a ONE-RANK RCCL communicator of the library's own (librccl resolved at run time)
         try:
-            if world == 1 and not tdist.is_initialized():
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
-                tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-                own = True
-            exchange = bench_exchange(tdist if world == 1 else dist, world, torch, own)
+            rc1 = D.Comm(N.Context.get(), 1, 0, transport="rccl")
+            exchange = bench_exchange(rc1, 1)
+            rc1.close()
         except Exception as e:
-            if world > 1:
-                raise
             exchange = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1:
-            prediction = leg(False, bench_prediction, args, zk, N, torch, np, tdist, exchange if exchange and "error" not in exchange else None)
-        if own:
-            tdist.destroy_process_group()
+        prediction = leg(False, bench_prediction, args, zk, N, torch, np, None, exchange if exchange and "error" not in exchange else None)
     if world > 1:
         multi = bench_strong_and_config4(args, zk, N, rank, world, barrier, dist, torch, np)
 
@@ -929,6 +977,7 @@ def main():
             **({"multi_gpu": multi} if multi is not None else {}),
         }
         print(json.dumps(out))
+    D.Comm.close_all()                   # RCCL communicators before the process group that carried their id
     if world > 1:
         dist.destroy_process_group()
 

@@ -360,6 +360,81 @@ int zkhip_mc_tail(zkhip_mc_state *st, const uint64_t *d_tables, uint32_t m);
 int zkhip_mc_finish(zkhip_mc_state *st, uint32_t *h_round_poly_lens, uint64_t *h_round_polys, uint64_t *h_challenges);
 int zkhip_mc_abort(zkhip_mc_state *st);
 
+/* ---- the sharded provers behind ONE call each (BASELINE configs[3] / [4]) -------------------------------------
+ * The exchange protocols -- stage plans, exchange order, tail gather, the per-layer GKR loop, the commit merge -- run INSIDE the
+ * library (csrc/shard_protocol.hpp): a host binds one entry point per prover and supplies a communicator.  The loops they stand
+ * for: sumcheck/src/sumcheck.rs:29-61, sumcheck/src/composed/composed_sumcheck.rs:32-67,
+ * sumcheck/src/composed/multi_composed_sumcheck.rs:64-121, gkr/src/protocol.rs:61-108, kzg/src/multilinear_kzg.rs:33-48.
+ *
+ * zkhip_comm = this rank's end of the exchange, bound to a context (one process per GPU; rank g holds entry j * world + g of every
+ * sharded table / SRS at local index j).  Every exchange is an ALL-GATHER of a few hundred bytes to 64 KiB per rank, issued on the
+ * context's stream: it is ordered behind the kernels that produced its payload and the kernels that consume it are enqueued behind
+ * it -- no host wait per exchange.  Two transports:
+ *   zkhip_comm_create       a caller-supplied all-gather.  fn(user, d_send, d_recv, bytes_per_rank, stream) must deliver every rank's
+ *                           d_send[bytes_per_rank] into d_recv[rank * bytes_per_rank ..] on all ranks, ordered on `stream` (a
+ *                           hipStream_t) or completed before it returns; 0 = success.  A Rust host plugs in rccl-sys
+ *                           (ncclAllGather(d_send, d_recv, bytes, ncclUint8, comm, stream)), the tests plug in gloo.  world == 1:
+ *                           fn may be NULL (nothing is exchanged).
+ *   zkhip_comm_create_rccl  the library opens librccl.so itself (dlopen at run time: libzkhip does not link it; ZKHIP_RCCL_LIB
+ *                           overrides the name) and creates an RCCL communicator from a 128-byte unique id: rank 0 calls
+ *                           zkhip_rccl_unique_id, the host distributes the id to all ranks by any means, every rank calls
+ *                           zkhip_comm_create_rccl (collective, like ncclCommInitRank).
+ * world must be a power of two (the tables have 2^n entries).  A comm is used by one host thread at a time, like its context. */
+typedef int (*zkhip_all_gather_fn)(void *user, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
+typedef struct zkhip_comm zkhip_comm;
+int zkhip_comm_create(zkhip_ctx *ctx, uint32_t rank, uint32_t world, zkhip_all_gather_fn fn, void *user, zkhip_comm **out);
+int zkhip_rccl_unique_id(uint8_t *h_id128);
+int zkhip_comm_create_rccl(zkhip_ctx *ctx, const uint8_t *h_id128, uint32_t rank, uint32_t world, zkhip_comm **out);
+int zkhip_comm_destroy(zkhip_comm *comm);
+/* one exchange as the provers issue them (d_recv: world * bytes_per_rank); cumulative counters of this comm */
+int zkhip_comm_all_gather(zkhip_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank);
+int zkhip_comm_stats(zkhip_comm *comm, uint64_t *exchanges, uint64_t *bytes_sent);
+/* the in-library cost of an exchange: `iters` all-gathers of bytes_per_rank back to back (one wait at the end), then `iters` with
+ * the host waiting for each -- microseconds per exchange (what bench.py reports as `exchange`) */
+int zkhip_comm_measure(zkhip_comm *comm, size_t bytes_per_rank, uint32_t iters, double *us_back_to_back, double *us_host_wait);
+
+/* Sumcheck::prove (sumcheck/src/sumcheck.rs:29-61) of the table whose rank-interleaved shard d_local_evals[n_local] this rank
+ * holds.  Outputs as zkhip_sumcheck_prove, identical on every rank (the transcript is replicated): log2(n_local * world) rounds.
+ * h_claimed_sum as zkhip_sumcheck_prove (NULL: the true sum of the WHOLE table).  *exchanges (nullable): all-gathers issued
+ * (3 for shards of 2^19..2^24 entries: coarse sums | fine sums beside the shard's fold | the gathered tail).
+ * zkhip_sc_prove_sharded: the same on a session from zkhip_sc_begin, which it finishes (releases) whatever it returns. */
+int zkhip_sumcheck_prove_sharded(zkhip_comm *comm, const uint64_t *d_local_evals, size_t n_local, const uint64_t *h_claimed_sum,
+                                 uint64_t *h_sum, uint64_t *h_round_polys, uint64_t *h_challenges, uint32_t *exchanges);
+int zkhip_sc_prove_sharded(zkhip_sc_state *st, zkhip_comm *comm, const uint64_t *h_claimed_sum, uint64_t *h_sum,
+                           uint64_t *h_round_polys, uint64_t *h_challenges, uint32_t *exchanges);
+/* ComposedSumcheck::prove (composed_sumcheck.rs:32-67) and MultiComposedSumcheckProver::prove_partial
+ * (multi_composed_sumcheck.rs:56-121; h_sum = the claimed sum of the WHOLE tables) over rank-interleaved shards of every table;
+ * outputs in the layouts of zkhip_composed_prove / zkhip_multi_composed_prove, identical on every rank.
+ * use_stages: 1 = two rounds per exchange where every term is a product of two tables, 0 = one exchange per round, < 0 = the
+ * default (stages when world > 1: they save exchanges, not work).
+ * zkhip_mc_prove_sharded: the same on a session from zkhip_mc_begin / _begin_ex, which it finishes whatever it returns; all-NULL
+ * outputs run the rounds and release the session without reading anything back (a session that continues it delivers both). */
+int zkhip_composed_prove_sharded(zkhip_comm *comm, const uint64_t *const *h_local_table_ptrs, uint32_t k, size_t n_local,
+                                 int use_stages, uint64_t *h_round_polys, uint64_t *h_challenges, uint32_t *exchanges);
+int zkhip_multi_composed_prove_sharded(zkhip_comm *comm, const uint64_t *const *h_local_table_ptrs, const uint32_t *h_term_sizes,
+                                       uint32_t n_terms, size_t n_local, const uint64_t *h_sum, int use_stages,
+                                       uint32_t *h_round_poly_lens, uint64_t *h_round_polys, uint64_t *h_challenges,
+                                       uint32_t *exchanges);
+int zkhip_mc_prove_sharded(zkhip_mc_state *st, zkhip_comm *comm, int use_stages, uint32_t *h_round_poly_lens,
+                           uint64_t *h_round_polys, uint64_t *h_challenges, uint32_t *exchanges);
+/* GKRProtocol::prove (gkr/src/protocol.rs:21-117) with every layer's sumcheck tables SHARDED over the ranks (BASELINE configs[3]:
+ * "evals sharded across 8"): rank g builds only rows j * world + g of a layer's seven linear-size tables and the two sessions per
+ * layer (rounds over b, rounds over c) run on those shards, two rounds per exchange; layers narrower than 2 * world values run whole
+ * on every rank.  The layer VALUES (h_layer_ptrs, as zkhip_gkr_prove_circuit) stay whole on every rank -- random wiring reads any of
+ * them.  Inputs and outputs as zkhip_gkr_prove_circuit, the proof identical on every rank and to the unsharded prover's, bit for
+ * bit.  One host synchronisation per layer (the outer transcript), none per exchange. */
+int zkhip_gkr_prove_sharded(zkhip_circuit *circuit, zkhip_comm *comm, const uint64_t *const *h_layer_ptrs, const size_t *h_layer_len,
+                            int use_stages, uint64_t *h_sums, uint32_t *h_n_rounds, uint32_t *h_round_poly_lens,
+                            uint64_t *h_round_polys, uint64_t *h_wb, uint64_t *h_wc, uint64_t *h_w0, uint64_t *h_challenges,
+                            uint32_t *exchanges);
+/* MultilinearKZG::commitment / UnivariateKZG::commitment (kzg/src/multilinear_kzg.rs:33-48, univariate_kzg.rs:37-58) over
+ * (scalars, SRS) sharded the same way: a full sub-MSM on this rank's shard (arguments as zkhip_kzg_commit; d_table non-NULL: the
+ * shard's shifted-SRS table, as zkhip_kzg_commit_table), ONE all-gather of the partial commitments (128 bytes per rank), their group
+ * sum on every rank.  require_equal_len applies to the local shard. */
+int zkhip_kzg_commit_sharded(zkhip_comm *comm, const uint64_t *d_points_xy, const void *d_table, const uint8_t *d_points_inf,
+                             size_t n_points, const uint64_t *d_scalars, size_t n_scalars, int require_equal_len,
+                             uint64_t *h_out_xy, uint8_t *h_out_inf);
+
 /* ---- KZG commit = multi-scalar multiplication over G1 -------------------------------------- */
 /* MultilinearKZG::commitment (kzg/src/multilinear_kzg.rs:33-48; require_equal_len = 1 reproduces its
  * assert_eq!(srs.len(), evaluations.len())) and UnivariateKZG::commitment (kzg/src/univariate_kzg.rs:37-58;

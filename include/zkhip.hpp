@@ -59,7 +59,8 @@ class Context {
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
     zkhip_ctx* raw() const { return c_; }
-    static Context& instance() { static Context ctx(0); return ctx; }
+    // one context per HOST THREAD (include/zkhip.h): threads that prove at once never share one
+    static Context& instance() { static thread_local Context ctx(0); return ctx; }
   private:
     zkhip_ctx* c_ = nullptr;
 };
@@ -211,6 +212,59 @@ class Sumcheck {
     Fr sum_;
 };
 
+// ---- the sharded provers (include/zkhip.h, "the sharded provers behind ONE call each") ----------------------------------------
+// Comm = this rank's end of the exchange (zkhip_comm): a caller-supplied all-gather (a Rust host: rccl-sys; the tests: a barrier
+// between threads), the library's own RCCL communicator, or none (one rank).
+class Comm {
+  public:
+    Comm() { check(zkhip_comm_create(ctx(), 0, 1, nullptr, nullptr, &m_), "comm_create"); }                         // one rank
+    Comm(uint32_t rank, uint32_t world, zkhip_all_gather_fn fn, void* user) : rank_(rank), world_(world) {
+        int st = zkhip_comm_create(ctx(), rank, world, fn, user, &m_);
+        if (st == ZKHIP_ERR_SHAPE) throw Panic("world size must be a power of two");
+        check(st, "comm_create");
+    }
+    static Comm rccl(const uint8_t id[128], uint32_t rank, uint32_t world) {                                         // collective over the ranks
+        Comm c(nullptr);
+        c.rank_ = rank; c.world_ = world;
+        check(zkhip_comm_create_rccl(ctx(), id, rank, world, &c.m_), "comm_create_rccl");
+        return c;
+    }
+    ~Comm() { if (m_) zkhip_comm_destroy(m_); }
+    Comm(Comm&& o) noexcept : m_(o.m_), rank_(o.rank_), world_(o.world_) { o.m_ = nullptr; }
+    Comm(const Comm&) = delete;
+    Comm& operator=(const Comm&) = delete;
+    zkhip_comm* raw() const { return m_; }
+    uint32_t rank() const { return rank_; }
+    uint32_t world() const { return world_; }
+    uint64_t exchanges() const { uint64_t e = 0; zkhip_comm_stats(m_, &e, nullptr); return e; }
+  private:
+    explicit Comm(std::nullptr_t) {}
+    zkhip_comm* m_ = nullptr;
+    uint32_t rank_ = 0, world_ = 1;
+};
+// rank `rank`'s shard of a table / vector sharded by its low index bits: entries rank, rank + world, ...
+template <class T>
+inline std::vector<T> shard_interleaved(const std::vector<T>& full, uint32_t rank, uint32_t world) {
+    std::vector<T> out;
+    for (size_t i = rank; i < full.size(); i += world) out.push_back(full[i]);
+    return out;
+}
+// Sumcheck::prove (sumcheck.rs:29-61) of the table whose shard this rank holds; every rank gets the proof of the whole table
+// (SumcheckProof::poly is this rank's shard: the whole table lives on no single GPU)
+struct ShardedSumcheck {
+    static std::pair<SumcheckProof, std::vector<Fr>> prove(const Multilinear& shard, const Comm& comm, const Fr* claimed_sum = nullptr, uint32_t* exchanges = nullptr) {
+        size_t nv = shard.n_vars;
+        for (uint32_t w = comm.world(); w > 1; w >>= 1) ++nv;
+        std::vector<Fr> rp(2 * (nv ? nv : 1)), ch(nv ? nv : 1);
+        Fr s;
+        check(zkhip_sumcheck_prove_sharded(comm.raw(), shard.device(), shard.len(), claimed_sum ? claimed_sum->l : nullptr, s.l, rp[0].l, ch[0].l, exchanges), "sumcheck_prove_sharded");
+        SumcheckProof proof{shard, s, {}};
+        for (size_t i = 0; i < nv; ++i) proof.univariate_poly.emplace_back(std::vector<Fr>{rp[2 * i], rp[2 * i + 1]});
+        ch.resize(nv);
+        return {std::move(proof), std::move(ch)};
+    }
+};
+
 // ---- polynomial::ComposedMultilinear + composed provers ---------------------------------------------------------
 class ComposedMultilinear {
   public:
@@ -295,19 +349,22 @@ class MultiComposedSumcheckProver {
     }
     static std::pair<MultiComposedSumcheckProof, std::vector<Fr>> prove(const std::vector<ComposedMultilinear>& poly, const Fr& sum) { return run(poly, sum, 0); }          // :47-54
     static std::pair<MultiComposedSumcheckProof, std::vector<Fr>> prove_partial(const std::vector<ComposedMultilinear>& poly, const Fr& sum) { return run(poly, sum, 1); }  // :56-62
-  private:
-    static void flatten(const std::vector<ComposedMultilinear>& poly, std::vector<const uint64_t*>& ptrs, std::vector<uint32_t>& sizes) {
-        for (auto& t : poly) { for (auto& p : t.polys) ptrs.push_back(p.device()); sizes.push_back((uint32_t)t.polys.size()); }
-    }
-    static std::pair<MultiComposedSumcheckProof, std::vector<Fr>> run(const std::vector<ComposedMultilinear>& poly, const Fr& sum, int partial) {
+    // prove_partial over rank-interleaved shards of every table (sum = the claimed sum of the WHOLE tables); the proof of the whole claim on every rank
+    static std::pair<MultiComposedSumcheckProof, std::vector<Fr>> prove_partial_sharded(const std::vector<ComposedMultilinear>& shards, const Fr& sum, const Comm& comm,
+                                                                                         int use_stages = -1, uint32_t* exchanges = nullptr) {
         std::vector<const uint64_t*> ptrs; std::vector<uint32_t> sizes;
-        flatten(poly, ptrs, sizes);
-        const size_t nv = poly[0].n_vars();
+        flatten(shards, ptrs, sizes);
+        size_t nv = shards[0].n_vars();
+        for (uint32_t w = comm.world(); w > 1; w >>= 1) ++nv;
         std::vector<uint32_t> lens(nv ? nv : 1);
         std::vector<uint64_t> rp(7 * 8 * (nv ? nv : 1));
         std::vector<Fr> ch(nv ? nv : 1);
-        check(zkhip_multi_composed_prove(ctx(), ptrs.data(), sizes.data(), (uint32_t)sizes.size(), poly[0].polys[0].len(), sum.l, partial, lens.data(), rp.data(), ch[0].l),
-              "multi_composed_prove");
+        check(zkhip_multi_composed_prove_sharded(comm.raw(), ptrs.data(), sizes.data(), (uint32_t)sizes.size(), shards[0].polys[0].len(), sum.l, use_stages, lens.data(),
+                                                 rp.data(), ch[0].l, exchanges), "multi_composed_prove_sharded");
+        return unpack(sum, nv, lens, rp, ch);
+    }
+  private:
+    static std::pair<MultiComposedSumcheckProof, std::vector<Fr>> unpack(const Fr& sum, size_t nv, const std::vector<uint32_t>& lens, const std::vector<uint64_t>& rp, std::vector<Fr>& ch) {
         MultiComposedSumcheckProof proof;
         proof.sum = sum;
         for (size_t r = 0; r < nv; ++r) {
@@ -322,6 +379,20 @@ class MultiComposedSumcheckProver {
         }
         ch.resize(nv);
         return {std::move(proof), std::move(ch)};
+    }
+    static void flatten(const std::vector<ComposedMultilinear>& poly, std::vector<const uint64_t*>& ptrs, std::vector<uint32_t>& sizes) {
+        for (auto& t : poly) { for (auto& p : t.polys) ptrs.push_back(p.device()); sizes.push_back((uint32_t)t.polys.size()); }
+    }
+    static std::pair<MultiComposedSumcheckProof, std::vector<Fr>> run(const std::vector<ComposedMultilinear>& poly, const Fr& sum, int partial) {
+        std::vector<const uint64_t*> ptrs; std::vector<uint32_t> sizes;
+        flatten(poly, ptrs, sizes);
+        const size_t nv = poly[0].n_vars();
+        std::vector<uint32_t> lens(nv ? nv : 1);
+        std::vector<uint64_t> rp(7 * 8 * (nv ? nv : 1));
+        std::vector<Fr> ch(nv ? nv : 1);
+        check(zkhip_multi_composed_prove(ctx(), ptrs.data(), sizes.data(), (uint32_t)sizes.size(), poly[0].polys[0].len(), sum.l, partial, lens.data(), rp.data(), ch[0].l),
+              "multi_composed_prove");
+        return unpack(sum, nv, lens, rp, ch);
     }
 };
 
@@ -382,12 +453,24 @@ inline G1Affine commit_impl(const TrustedSetup& srs, const uint64_t* d_scalars, 
     g.infinity = inf != 0;
     return g;
 }
+// MultilinearKZG::commitment over (scalars, SRS) sharded by low index bits: this rank's shards in, the whole commitment out on every rank
+inline G1Affine commit_sharded(const TrustedSetup& srs_shard, const uint64_t* d_scalars, size_t n, int require_equal, const Comm& comm) {
+    G1Affine g; uint8_t inf = 0;
+    int st = zkhip_kzg_commit_sharded(comm.raw(), srs_shard.table() ? nullptr : srs_shard.points(), srs_shard.table(), srs_shard.inf(), srs_shard.len(), d_scalars, n,
+                                      require_equal, g.xy, &inf);
+    if (st == ZKHIP_ERR_SHAPE) throw Panic("The length of powers_of_tau_in_g1 and the length of the evaluations of the polynomial should tally!");
+    if (st == ZKHIP_ERR_INDEX) throw std::out_of_range("index out of bounds: the len of powers_of_tau_in_g1 is smaller than the polynomial");
+    check(st, "kzg_commit_sharded");
+    g.infinity = inf != 0;
+    return g;
+}
 struct MultilinearKZGProof {                                                                   // multilinear_kzg.rs:17-21
     Fr evaluation;
     std::vector<G1Affine> proofs;
 };
 struct MultilinearKZG {
     static G1Affine commitment(const Multilinear& poly, const TrustedSetup& srs) { return commit_impl(srs, poly.device(), poly.len(), 1); }   // multilinear_kzg.rs:33-48
+    static G1Affine commitment_sharded(const Multilinear& poly_shard, const TrustedSetup& srs_shard, const Comm& comm) { return commit_sharded(srs_shard, poly_shard.device(), poly_shard.len(), 1, comm); }
     static MultilinearKZGProof open(const Multilinear& poly, const std::vector<Fr>& evaluation_points, const TrustedSetup& srs) {             // :50-88
         MultilinearKZGProof pr;
         const size_t nv = evaluation_points.size();
@@ -483,7 +566,13 @@ class DeviceCircuit {
     ~DeviceCircuit() { zkhip_circuit_destroy(handle_); }
     DeviceCircuit(const DeviceCircuit&) = delete;
     DeviceCircuit& operator=(const DeviceCircuit&) = delete;
-    GKRProof prove(const Circuit::Evaluation& ev) const {                                        // protocol.rs:21-117
+    GKRProof prove(const Circuit::Evaluation& ev) const { return prove_impl(ev, nullptr, -1, nullptr); }   // protocol.rs:21-117
+    // the same proof with every layer's sumcheck tables sharded over the ranks of `comm` (the layer values stay whole on every rank)
+    GKRProof prove_sharded(const Circuit::Evaluation& ev, const Comm& comm, int use_stages = -1, uint32_t* exchanges = nullptr) const {
+        return prove_impl(ev, &comm, use_stages, exchanges);
+    }
+  private:
+    GKRProof prove_impl(const Circuit::Evaluation& ev, const Comm* comm, int use_stages, uint32_t* exchanges) const {
         const uint32_t nl = n_layers_, stride = 2 * nl;
         if (ev.tables.size() != (size_t)nl + 1) throw Panic("circuit evaluation does not match the circuit");
         std::vector<const uint64_t*> ptrs;
@@ -491,8 +580,10 @@ class DeviceCircuit {
         std::vector<Fr> sums(nl), wb(nl), wc(nl), w0(2);
         std::vector<uint32_t> n_rounds(nl), lens((size_t)nl * stride);
         std::vector<uint64_t> rps((size_t)nl * stride * 7 * 8);
-        int st = zkhip_gkr_prove_circuit(handle_, ptrs.data(), ev.lens.data(), sums[0].l, n_rounds.data(), lens.data(), rps.data(), wb[0].l,
-                                         wc[0].l, w0[0].l, nullptr);
+        int st = comm ? zkhip_gkr_prove_sharded(handle_, comm->raw(), ptrs.data(), ev.lens.data(), use_stages, sums[0].l, n_rounds.data(), lens.data(), rps.data(),
+                                                wb[0].l, wc[0].l, w0[0].l, nullptr, exchanges)
+                      : zkhip_gkr_prove_circuit(handle_, ptrs.data(), ev.lens.data(), sums[0].l, n_rounds.data(), lens.data(), rps.data(), wb[0].l,
+                                                wc[0].l, w0[0].l, nullptr);
         if (st == ZKHIP_ERR_SHAPE) throw Panic("Number of evaluations must be a power of 2");
         if (st == ZKHIP_ERR_INDEX) throw std::out_of_range("index out of bounds: gate input");
         check(st, "gkr_prove");
@@ -515,13 +606,15 @@ class DeviceCircuit {
         proof.wb_s = wb; proof.wc_s = wc; proof.w_0_mle = w0;
         return proof;
     }
-  private:
     uint32_t n_layers_;
     zkhip_circuit* handle_ = nullptr;
 };
 struct GKRProtocol {
     static GKRProof prove(const Circuit& circuit, const Circuit::Evaluation& ev) {             // protocol.rs:21-117
         return DeviceCircuit(circuit).prove(ev);
+    }
+    static GKRProof prove_sharded(const Circuit& circuit, const Circuit::Evaluation& ev, const Comm& comm) {
+        return DeviceCircuit(circuit).prove_sharded(ev, comm);
     }
 };
 

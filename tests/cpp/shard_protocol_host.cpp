@@ -1,0 +1,116 @@
+// Host build of the library's exchange protocols (zk-cryptography_amd/csrc/shard_protocol.hpp -- the code libzkhip runs on its HIP
+// engines) over a CALLBACK engine on host memory: tests/test_distributed_cpu.py plugs in checker engines built on the CPU oracle and an
+// all-gather over gloo, so the protocol itself runs with world_size 2 / 4 on a box without a GPU.  g++ only, no HIP.
+#include <cstdint>
+#include <cstddef>
+#include <vector>
+
+#include "../../zk-cryptography_amd/csrc/shard_protocol.hpp"
+
+extern "C" {
+struct zkshard_sc_callbacks {
+    size_t (*local_len)(void);
+    int (*use_stages)(void);
+    uint32_t (*tail_capacity)(void);
+    int (*overlap_plan)(uint32_t world, uint32_t* k1, uint32_t* k2, uint32_t* mid);
+    int (*overlap_sums)(uint64_t* out, size_t n);
+    int (*overlap_rounds1)(const uint64_t* g, uint32_t world, const uint64_t* claimed, uint64_t* mid_out, uint32_t mid);
+    int (*overlap_rounds2)(const uint64_t* g, uint32_t world, uint32_t mid);
+    int (*stage_plan)(uint32_t world, uint32_t* k);
+    int (*stage_block_sums)(uint64_t* out, size_t n);
+    int (*stage_absorb)(const uint64_t* g, uint32_t world, const uint64_t* claimed, size_t n);
+    int (*stage_fold)(void);
+    int (*local_half_sums)(uint64_t* out);
+    int (*absorb)(const uint64_t* g, uint32_t world, const uint64_t* claimed);
+    int (*fold)(void);
+    int (*local_table)(uint64_t* out, size_t n);
+    int (*tail)(const uint64_t* values, uint32_t m, const uint64_t* claimed);
+    int (*all_gather)(const void* send, void* recv, size_t bytes);
+};
+struct zkshard_mc_callbacks {
+    size_t (*local_len)(void);
+    uint32_t (*tail_capacity)(void);
+    uint32_t (*record_len)(void);
+    uint32_t (*table_count)(void);
+    int (*stage_record_len)(uint32_t* vals);
+    int (*stage_sums)(uint64_t* out, uint32_t vals);
+    int (*stage_absorb)(const uint64_t* g, uint32_t world, uint32_t vals);
+    int (*round_sums)(uint64_t* out, uint32_t rec);
+    int (*absorb)(const uint64_t* g, uint32_t world, uint32_t rec);
+    int (*local_tables)(uint64_t* out, uint32_t n_tables, size_t n_local);
+    int (*tail)(const uint64_t* tables, uint32_t m, uint32_t n_tables);
+    int (*all_gather)(const void* send, void* recv, size_t bytes);
+};
+}
+
+namespace {
+struct HostBuffers {
+    std::vector<uint64_t> bufs[4];
+    uint64_t* buffer(int id, size_t elems) {
+        bufs[id].assign(4 * (elems ? elems : 1), 0);
+        return bufs[id].data();
+    }
+    int nomem() const { return -5; }
+    // out[t][j * world + g] = in[g][t][j]
+    int interleave(const uint64_t* g, uint32_t world, uint32_t nt, size_t n_local, uint64_t* out) {
+        for (uint32_t r = 0; r < world; ++r)
+            for (uint32_t t = 0; t < nt; ++t)
+                for (size_t j = 0; j < n_local; ++j)
+                    for (int q = 0; q < 4; ++q) out[4 * ((size_t)t * n_local * world + j * world + r) + q] = g[4 * (((size_t)r * nt + t) * n_local + j) + q];
+        return 0;
+    }
+};
+template <class CB>
+struct HostComm {
+    const CB* cb;
+    uint32_t w;
+    uint32_t world() const { return w; }
+    int all_gather(const void* send, void* recv, size_t bytes) { return cb->all_gather(send, recv, bytes); }
+};
+struct ScEngine : HostBuffers {
+    const zkshard_sc_callbacks* cb;
+    size_t local_len() { return cb->local_len(); }
+    bool use_stages() { return cb->use_stages() != 0; }
+    uint32_t tail_capacity() { return cb->tail_capacity(); }
+    int overlap_plan(uint32_t world, uint32_t* k1, uint32_t* k2, uint32_t* mid) { return cb->overlap_plan(world, k1, k2, mid); }
+    int overlap_sums(uint64_t* out, size_t n) { return cb->overlap_sums(out, n); }
+    int overlap_rounds1(const uint64_t* g, uint32_t world, const uint64_t* claimed, uint64_t* mid_out, uint32_t mid) { return cb->overlap_rounds1(g, world, claimed, mid_out, mid); }
+    int overlap_rounds2(const uint64_t* g, uint32_t world, uint32_t mid) { return cb->overlap_rounds2(g, world, mid); }
+    int stage_plan(uint32_t world, uint32_t* k) { return cb->stage_plan(world, k); }
+    int stage_block_sums(uint64_t* out, size_t n) { return cb->stage_block_sums(out, n); }
+    int stage_absorb(const uint64_t* g, uint32_t world, const uint64_t* claimed, size_t n) { return cb->stage_absorb(g, world, claimed, n); }
+    int stage_fold() { return cb->stage_fold(); }
+    int local_half_sums(uint64_t* out) { return cb->local_half_sums(out); }
+    int absorb(const uint64_t* g, uint32_t world, const uint64_t* claimed) { return cb->absorb(g, world, claimed); }
+    int fold() { return cb->fold(); }
+    int local_table(uint64_t* out, size_t n) { return cb->local_table(out, n); }
+    int tail(const uint64_t* values, uint32_t m, const uint64_t* claimed) { return cb->tail(values, m, claimed); }
+};
+struct McEngine : HostBuffers {
+    const zkshard_mc_callbacks* cb;
+    size_t local_len() { return cb->local_len(); }
+    uint32_t tail_capacity() { return cb->tail_capacity(); }
+    uint32_t record_len() { return cb->record_len(); }
+    uint32_t table_count() { return cb->table_count(); }
+    int stage_record_len(uint32_t* vals) { return cb->stage_record_len(vals); }
+    int stage_sums(uint64_t* out, uint32_t vals) { return cb->stage_sums(out, vals); }
+    int stage_absorb(const uint64_t* g, uint32_t world, uint32_t vals) { return cb->stage_absorb(g, world, vals); }
+    int round_sums(uint64_t* out, uint32_t rec) { return cb->round_sums(out, rec); }
+    int absorb(const uint64_t* g, uint32_t world, uint32_t rec) { return cb->absorb(g, world, rec); }
+    int local_tables(uint64_t* out, uint32_t nt, size_t n_local) { return cb->local_tables(out, nt, n_local); }
+    int tail(const uint64_t* tables, uint32_t m, uint32_t nt) { return cb->tail(tables, m, nt); }
+};
+}  // namespace
+
+extern "C" int zkshard_host_sumcheck(const zkshard_sc_callbacks* cb, uint32_t world, const uint64_t* claimed, uint32_t* exchanges) {
+    ScEngine e;
+    e.cb = cb;
+    HostComm<zkshard_sc_callbacks> comm{cb, world};
+    return zkshard::sumcheck_prove(e, comm, claimed, exchanges);
+}
+extern "C" int zkshard_host_composed(const zkshard_mc_callbacks* cb, uint32_t world, int use_stages, uint32_t* exchanges) {
+    McEngine e;
+    e.cb = cb;
+    HostComm<zkshard_mc_callbacks> comm{cb, world};
+    return zkshard::composed_prove(e, comm, use_stages != 0, exchanges);
+}

@@ -3,7 +3,10 @@
 // Built and run by tests/test_cpp_mirror.py.  Exit code 0 = all passed.
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
+#include <mutex>
 #include <random>
+#include <thread>
 
 #include "../../include/zkhip.hpp"
 extern "C" {
@@ -297,6 +300,109 @@ TEST(test_gkr_device_circuit_reused) {   // one resident circuit, two inputs: ea
         EXPECT(a.wb_s == b.wb_s && a.wc_s == b.wc_s && a.w_0_mle == b.w_0_mle && a.sumcheck_proofs.size() == b.sumcheck_proofs.size());
         for (size_t k = 0; k < a.sumcheck_proofs.size(); ++k) EXPECT(a.sumcheck_proofs[k].to_bytes() == b.sumcheck_proofs[k].to_bytes());
     }
+}
+// ---- the sharded provers through the C ABI's one-call entry points (include/zkhip.h): ranks = host threads with a context each,
+// the all-gather a barrier + a shared host buffer.  Every rank must return the single-GPU prover's proof of the WHOLE input.
+namespace {
+struct ThreadExchange {
+    uint32_t world;
+    std::vector<uint8_t> buf;
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t waiting = 0;
+    uint64_t generation = 0;
+    explicit ThreadExchange(uint32_t w) : world(w), buf((size_t)w << 20) {}
+    void barrier() {
+        std::unique_lock<std::mutex> lk(m);
+        const uint64_t g = generation;
+        if (++waiting == world) { waiting = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != g; });
+    }
+};
+struct RankEnd { ThreadExchange* x; uint32_t rank; zkhip_ctx* c; };
+// zkhip_all_gather_fn: completes before it returns (zkhip_memcpy_* wait for the context's stream), as the contract allows
+int thread_all_gather(void* user, const void* d_send, void* d_recv, size_t bytes, void*) {
+    RankEnd* e = (RankEnd*)user;
+    if (bytes * e->x->world > e->x->buf.size()) return 1;
+    if (zkhip_memcpy_d2h(e->c, e->x->buf.data() + (size_t)e->rank * bytes, d_send, bytes) != 0) return 1;
+    e->x->barrier();
+    if (zkhip_memcpy_h2d(e->c, d_recv, e->x->buf.data(), bytes * e->x->world) != 0) return 1;
+    e->x->barrier();
+    return 0;
+}
+}  // namespace
+TEST(test_sharded_provers_with_threads_as_ranks) {
+    const uint32_t world = 2;
+    // whole inputs and the single-GPU provers' results, on the main thread's context
+    auto full = random_fr(1 << 14, 4141);
+    Sumcheck sc{Multilinear(full)};
+    sc.poly_sum();
+    auto want_sc = sc.prove();
+    std::vector<std::vector<Fr>> tabs;
+    for (int k = 0; k < 4; ++k) tabs.push_back(random_fr(1 << 12, 4150 + k));
+    std::vector<ComposedMultilinear> poly;
+    poly.push_back(ComposedMultilinear({Multilinear(tabs[0]), Multilinear(tabs[1])}));
+    poly.push_back(ComposedMultilinear({Multilinear(tabs[2]), Multilinear(tabs[3])}));
+    const Fr claimed = MultiComposedSumcheckProver::calculate_poly_sum(poly);
+    auto want_mc = MultiComposedSumcheckProver::prove_partial(poly, claimed);
+    Circuit circuit = make_circuit({{{0, 0, 1}},
+                                    {{1, 0, 1}, {0, 2, 3}},
+                                    {{0, 0, 1}, {1, 2, 3}, {1, 4, 5}, {1, 6, 7}},
+                                    {{1, 0, 1}, {1, 2, 3}, {1, 4, 5}, {0, 6, 7}, {1, 8, 9}, {0, 10, 11}, {1, 12, 13}, {1, 14, 15}}});
+    auto gkr_in = F({2, 1, 3, 1, 4, 1, 2, 2, 3, 3, 4, 4, 2, 3, 3, 4});
+    GKRProof want_gkr = GKRProtocol::prove(circuit, circuit.evaluation(gkr_in));
+    auto tau = random_fr(8, 4160), scal = random_fr(256, 4161);
+    TrustedSetup srs = TrustedSetup::setup(tau);
+    G1Affine want_c = MultilinearKZG::commitment(Multilinear(scal), srs);
+    std::vector<uint64_t> srs_xy(12 * 256);
+    std::vector<uint8_t> srs_inf(256);
+    srs.pts_->download(srs_xy.data(), 96 * 256);
+    srs.inf_->download(srs_inf.data(), 256);
+
+    ThreadExchange x(world);
+    std::vector<int> ok(world, 0);
+    std::vector<uint64_t> n_ex(world, 0);
+    auto body = [&](uint32_t rank) {
+        try {
+            RankEnd end{&x, rank, ctx()};                                   // this thread's own context
+            Comm comm(rank, world, thread_all_gather, &end);
+            bool good = true;
+            auto got = ShardedSumcheck::prove(Multilinear(shard_interleaved(full, rank, world)), comm);
+            good = good && got.first.sum == want_sc.first.sum && got.second == want_sc.second && got.first.univariate_poly.size() == want_sc.first.univariate_poly.size();
+            for (size_t i = 0; good && i < got.first.univariate_poly.size(); ++i) good = got.first.univariate_poly[i] == want_sc.first.univariate_poly[i];
+            std::vector<ComposedMultilinear> sh;
+            sh.push_back(ComposedMultilinear({Multilinear(shard_interleaved(tabs[0], rank, world)), Multilinear(shard_interleaved(tabs[1], rank, world))}));
+            sh.push_back(ComposedMultilinear({Multilinear(shard_interleaved(tabs[2], rank, world)), Multilinear(shard_interleaved(tabs[3], rank, world))}));
+            auto mc = MultiComposedSumcheckProver::prove_partial_sharded(sh, claimed, comm);
+            good = good && mc.first.to_bytes() == want_mc.first.to_bytes() && mc.second == want_mc.second;
+            GKRProof g = GKRProtocol::prove_sharded(circuit, circuit.evaluation(gkr_in), comm);
+            good = good && g.wb_s == want_gkr.wb_s && g.wc_s == want_gkr.wc_s && g.w_0_mle == want_gkr.w_0_mle && g.sumcheck_proofs.size() == want_gkr.sumcheck_proofs.size();
+            for (size_t k = 0; good && k < g.sumcheck_proofs.size(); ++k) good = g.sumcheck_proofs[k].to_bytes() == want_gkr.sumcheck_proofs[k].to_bytes();
+            TrustedSetup my_srs(256 / world);
+            std::vector<uint64_t> my_xy;
+            auto my_scal = shard_interleaved(scal, rank, world);
+            std::vector<uint8_t> my_inf;
+            for (size_t i = rank; i < 256; i += world) { my_xy.insert(my_xy.end(), srs_xy.begin() + 12 * i, srs_xy.begin() + 12 * (i + 1)); my_inf.push_back(srs_inf[i]); }
+            my_srs.pts_->upload(my_xy.data(), 8 * my_xy.size());
+            my_srs.inf_->upload(my_inf.data(), my_inf.size());
+            G1Affine c = MultilinearKZG::commitment_sharded(Multilinear(my_scal), my_srs, comm);
+            good = good && c == want_c;
+            n_ex[rank] = comm.exchanges();
+            ok[rank] = good ? 1 : 0;
+        } catch (const std::exception& e) {
+            std::printf("  rank %u: %s\n", rank, e.what());
+        }
+    };
+    std::vector<std::thread> ts;
+    for (uint32_t r = 0; r < world; ++r) ts.emplace_back(body, r);
+    for (auto& t : ts) t.join();
+    for (uint32_t r = 0; r < world; ++r) EXPECT(ok[r] == 1);
+    EXPECT(n_ex[0] == n_ex[1] && n_ex[0] >= 4);
+    // one rank, no transport: the same entry points give the same proofs
+    Comm solo;
+    auto got1 = ShardedSumcheck::prove(Multilinear(full), solo);
+    EXPECT(got1.second == want_sc.second && got1.first.sum == want_sc.first.sum);
+    EXPECT(panics([&] { Comm bad(0, 3, thread_all_gather, nullptr); }));       // world must be a power of two
 }
 // ---- domain / NTT ---------------------------------------------------------------------------------------------------------
 TEST(test_domain_new) {   // domain.rs:154-168 (the decimal strings are checked through the oracle's KAT-pinned root)

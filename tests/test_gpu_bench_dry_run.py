@@ -38,3 +38,9 @@ def test_bench_multi_rank_dry_run(world):
     assert d["batches"]["n"] >= 3 and d["batches"]["min"] <= d["ms_per_step"] <= d["batches"]["max"]
     sh = d["gkr"]["sharded"]
     assert sh["proof_equals_single_gpu_proof"] is True and sh["proof_replicated_on_all_ranks"] is True and sh["exchanges_per_proof"] > 0
+    # the self-test ran before anything was timed and printed the measured exchange first (stderr: stdout stays ONE line)
+    st = [l for l in out.stderr.decode().splitlines() if l.startswith("bench.py selftest: ")]
+    assert len(st) == 1
+    st = json.loads(st[0][len("bench.py selftest: "):])
+    assert st["n_gpus"] == world and all(st["sharded_provers_match_single_gpu_and_rank_0"].values()) and len(st["sharded_provers_match_single_gpu_and_rank_0"]) == 4
+    assert st["exchange"]["64_B"]["back_to_back_us"] > 0 and d["exchange"]["64_B"]["back_to_back_us"] > 0

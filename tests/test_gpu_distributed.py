@@ -49,37 +49,95 @@ def test_two_shards_in_lockstep_match_full_prover(zk, ora, world, log_n):
         assert np.array_equal(s, ws) and np.array_equal(rp, wrp) and np.array_equal(ch, wch)
 
 
-def test_orchestration_over_nccl_world_1(zk, ora):
+def test_orchestration_over_rccl_world_1(zk, ora):
+    """The in-library protocols over the library's OWN RCCL communicator (librccl resolved at run time; one rank -- RCCL refuses two
+    ranks on one device): every exchange of the provers is a real ncclAllGather on the context's stream."""
     import torch
-    import torch.distributed as dist
+    from zk_cryptography_amd import _native as N
     from zk_cryptography_amd import distributed as D
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29631")
-    created = False
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-        created = True
+    ctx = N.Context.get(0)
+    comm = D.Comm(ctx, 1, 0, transport="rccl")
     try:
-        full = ora.random_fr(1 << 13, 5)
-        t = torch.from_numpy(full.view(np.int64)).cuda()
-        s, rp, ch = D.ShardedSumcheck(D.HipSumcheckEngine(t), 1, None, dist).prove()
-        ws, wrp, wch = ora.sumcheck_prove(full)
-        assert np.array_equal(s, ws) and np.array_equal(rp, wrp) and np.array_equal(ch, wch)
-        # exercise a real RCCL all-gather on the device buffers the protocol uses
-        send = torch.arange(8, dtype=torch.int64, device="cuda").view(2, 4)
-        recv = torch.empty((1, 2, 4), dtype=torch.int64, device="cuda")
-        dist.all_gather_into_tensor(recv, send)
-        assert torch.equal(recv[0], send)
+        for log_n in (13, 20):                     # stage form; overlapped stage (three exchanges, one beside the fold)
+            full = ora.random_fr(1 << log_n, 5 + log_n)
+            t = torch.from_numpy(full.view(np.int64)).cuda()
+            sh = D.ShardedSumcheck(D.HipSumcheckEngine(t), 1, comm=comm)
+            s, rp, ch = sh.prove()
+            ws, wrp, wch = ora.sumcheck_prove(full)
+            assert np.array_equal(s, ws) and np.array_equal(rp, wrp) and np.array_equal(ch, wch)
+            assert sh.exchanges >= 2
+        assert comm.stats()[0] >= 5                # they went through the communicator
+        # composed prover, two rounds per exchange
+        tabs = [ora.random_fr(1 << 15, 900 + q) for q in range(2)]
+        shard = [torch.from_numpy(t_.view(np.int64)).cuda() for t_ in tabs]
+        sh = D.ShardedComposedSumcheck(D.HipComposedEngine([shard], 1, multi=False), 1, use_stages=True, comm=comm)
+        rp, ch = sh.prove()
+        wrp, wch = ora.composed_prove(np.stack(tabs))
+        assert np.array_equal(rp, wrp) and np.array_equal(ch, wch) and sh.exchanges > 0
         # sharded commit with one rank = plain commit
         tau = ora.random_fr(6, 3)
         srs = zk.TrustedSetup.setup(tau)
         poly = zk.Multilinear(ora.random_fr(64, 4))
         want = zk.MultilinearKZG.commitment(poly, srs)
-        xy, inf = D.sharded_commit(lambda: (want.xy, want.infinity), D.hip_sum_affine, 1, None, dist, device="cuda")
+        xy, inf = D.sharded_commit(srs.powers_of_tau_in_g1, srs.inf, poly.evaluations, comm)
         assert (not inf) and np.array_equal(xy, want.xy)
+        # GKR, sharded entry point
+        circuit = zk.Circuit.random(9)
+        ev = circuit.evaluation(zk.Fr.random(2 ** 9, 309))
+        want = zk.GKRProtocol.prove(circuit, ev)
+        got = zk.GKRProtocol.prove_sharded(circuit, ev, 1, 0, use_stages=True, comm=comm)
+        assert all(a.to_bytes() == b.to_bytes() for a, b in zip(got.sumcheck_proofs, want.sumcheck_proofs)) and got._exchanges > 0
+        # the in-library cost of an exchange
+        b2b, waited = comm.measure(64, 50)
+        assert 0 < b2b <= waited * 1.5
     finally:
-        if created:
-            dist.destroy_process_group()
+        comm.close()
+
+
+def test_one_call_sharded_entry_points_world_1(zk, ora):
+    """zkhip_sumcheck_prove_sharded / zkhip_composed_prove_sharded / zkhip_multi_composed_prove_sharded (begin + protocol + finish in
+    one call) with a one-rank communicator without a transport."""
+    import ctypes as C
+    import torch
+    from zk_cryptography_amd import _native as N
+    from zk_cryptography_amd import distributed as D
+    ctx = N.Context.get(0)
+    comm = D.Comm.get(ctx, 1)
+    lib = N.lib()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    full = ora.random_fr(1 << 12, 77)
+    t = torch.from_numpy(full.view(np.int64)).cuda()
+    s, rp, ch = np.zeros(4, np.uint64), np.zeros((12, 2, 4), np.uint64), np.zeros((12, 4), np.uint64)
+    ex = C.c_uint32(0)
+    N.check(lib.zkhip_sumcheck_prove_sharded(comm.handle, N.ptr(t), C.c_size_t(1 << 12), None, p(s), p(rp), p(ch), C.byref(ex)), "sc")
+    ws, wrp, wch = ora.sumcheck_prove(full)
+    assert np.array_equal(s, ws) and np.array_equal(rp, wrp) and np.array_equal(ch, wch) and ex.value >= 1
+    tabs = [ora.random_fr(1 << 12, 80 + q) for q in range(3)]
+    dev = [torch.from_numpy(t_.view(np.int64)).cuda() for t_ in tabs]
+    ptrs = (C.c_void_p * 3)(*[d.data_ptr() for d in dev])
+    rp, ch = np.zeros((12, 4, 4), np.uint64), np.zeros((12, 4), np.uint64)
+    N.check(lib.zkhip_composed_prove_sharded(comm.handle, ptrs, C.c_uint32(3), C.c_size_t(1 << 12), C.c_int(-1), p(rp), p(ch), C.byref(ex)), "composed")
+    wrp, wch = ora.composed_prove(np.stack(tabs))
+    assert np.array_equal(rp, wrp) and np.array_equal(ch, wch)
+    sizes = [2, 1]
+    claimed = ora.multi_composed_sum(np.stack(tabs), sizes)
+    lens, rps, ch = np.zeros(12, np.uint32), np.zeros((12, 7, 2, 4), np.uint64), np.zeros((12, 4), np.uint64)
+    N.check(lib.zkhip_multi_composed_prove_sharded(comm.handle, ptrs, (C.c_uint32 * 2)(*sizes), C.c_uint32(2), C.c_size_t(1 << 12), p(claimed),
+                                                   C.c_int(-1), p(lens), p(rps), p(ch), C.byref(ex)), "multi")
+    orps, och = ora.multi_composed_prove(np.stack(tabs), sizes, claimed, partial=True)
+    got = [zk.SparseUnivariatePolynomial(rps[r, : lens[r], 0], rps[r, : lens[r], 1]).monomials() for r in range(12)]
+    assert got == [o.monomials() for o in orps] and np.array_equal(ch, och)
+    # shape errors as the reference panics, argument errors as statuses; a failed call leaves the context usable
+    with pytest.raises(AssertionError):
+        N.check(lib.zkhip_sumcheck_prove_sharded(comm.handle, N.ptr(t), C.c_size_t(3000), None, p(s), p(rp), p(ch), None), "sc")
+    with pytest.raises(N.ZkhipError):
+        N.check(lib.zkhip_sumcheck_prove_sharded(None, N.ptr(t), C.c_size_t(1 << 12), None, p(s), p(rp), p(ch), None), "sc")
+    with pytest.raises(AssertionError):
+        D.Comm(ctx, 3, 0, transport="staged")
+    s2, rp2, ch2 = np.zeros(4, np.uint64), np.zeros((12, 2, 4), np.uint64), np.zeros((12, 4), np.uint64)
+    N.check(lib.zkhip_sumcheck_prove_sharded(comm.handle, N.ptr(t), C.c_size_t(1 << 12), None, p(s2), p(rp2), p(ch2), None), "sc")
+    want = ora.sumcheck_prove(full)
+    assert np.array_equal(s2, want[0]) and np.array_equal(rp2, want[1]) and np.array_equal(ch2, want[2])
 
 
 @pytest.mark.parametrize("world,log_n", [(2, 14), (4, 13), (8, 20), (2, 22), (8, 12), (4, 5), (2, 19)])   # (2, 19): one 9-variable stage

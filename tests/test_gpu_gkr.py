@@ -202,3 +202,32 @@ def test_gkr_prove_sharded_world_1_matches_prove(zk, ora, depth, stages):
     assert np.array_equal(_host(got.w_0_mle.evaluations), _host(want.w_0_mle.evaluations))
     if 3 <= depth <= 8:
         assert ora.gkr_verify(layers, inp, _to_oracle_proof(zk, ora, got))
+
+
+def test_gate_replaced_in_place_proves_the_edited_circuit(zk, ora):
+    """The reference reads &Circuit on every call (gkr/src/protocol.rs:21-25); the mirror keeps the circuit resident in HBM.  Gates are
+    immutable and a layer's gate list counts its mutations, so a gate REPLACED in place (same shape) reaches the device copy: the next
+    proof is the edited circuit's, for both provers."""
+    depth = 6
+    circuit = zk.Circuit.random(depth)
+    inp = ora.random_fr(2 ** depth, 4400)
+    before = zk.GKRProtocol.prove(circuit, circuit.evaluation(inp))
+    with pytest.raises(AttributeError):
+        circuit.layers[3].layer[2].inputs = (0, 0)                        # no silent in-place edits of a gate
+    old = circuit.layers[3].layer[2]
+    circuit.layers[3].layer[2] = zk.Gate("mul" if old.gate_type == "add" else "add", (old.inputs[1], old.inputs[0]))
+    ev = circuit.evaluation(inp)
+    after = zk.GKRProtocol.prove(circuit, ev)
+    fresh_layers = [[(g.gate_type, g.inputs[0], g.inputs[1]) for g in layer.layer] for layer in circuit.layers]
+    fresh = zk.Circuit.from_tuples(fresh_layers)
+    want = zk.GKRProtocol.prove(fresh, fresh.evaluation(inp))
+    assert [p.to_bytes() for p in after.sumcheck_proofs] == [p.to_bytes() for p in want.sumcheck_proofs]
+    assert [p.to_bytes() for p in after.sumcheck_proofs] != [p.to_bytes() for p in before.sumcheck_proofs]
+    assert ora.gkr_verify(fresh_layers, inp, _to_oracle_proof(zk, ora, after))
+    sharded = zk.GKRProtocol.prove_sharded(circuit, ev, use_stages=True)
+    assert [p.to_bytes() for p in sharded.sumcheck_proofs] == [p.to_bytes() for p in want.sumcheck_proofs]
+    # a whole layer replaced, and appended gates, are seen too
+    circuit.layers[2] = zk.CircuitLayer([zk.Gate("add", (g.inputs[1], g.inputs[0])) for g in circuit.layers[2].layer])
+    again = zk.GKRProtocol.prove(circuit, circuit.evaluation(inp))
+    fresh2 = zk.Circuit.from_tuples([[(g.gate_type, g.inputs[0], g.inputs[1]) for g in layer.layer] for layer in circuit.layers])
+    assert [p.to_bytes() for p in again.sumcheck_proofs] == [p.to_bytes() for p in zk.GKRProtocol.prove(fresh2, fresh2.evaluation(inp)).sumcheck_proofs]

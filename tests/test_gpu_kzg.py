@@ -399,6 +399,31 @@ def test_srs_caches_follow_in_place_edits(zk, ora):
     assert all(p == q for p, q in zip(a.proofs, b.proofs))
 
 
+def test_srs_caches_follow_raw_pointer_writes(zk, ora):
+    """A write into the SRS tensors through their raw pointers (what the library's own kernels do: no torch version bump) is caught by
+    the content fingerprint of the cache key; TrustedSetup.invalidate() is the explicit form."""
+    import ctypes as C
+    from zk_cryptography_amd import _native as N
+    tau = ora.random_fr(8, 421)
+    srs = zk.TrustedSetup.setup(tau).precompute()
+    poly = zk.Multilinear(ora.random_fr(256, 422))
+    before = zk.MultilinearKZG.commitment(poly, srs)
+    zk.MultilinearKZG.open(poly, ora.random_fr(8, 423), srs)
+    version = srs.powers_of_tau_in_g1._version
+    swapped = srs.powers_of_tau_in_g1[[1, 0]].cpu().numpy().copy()
+    ctx = N.Context.get(srs.powers_of_tau_in_g1.device.index)
+    N.check(N.lib().zkhip_memcpy_h2d(ctx.handle, C.c_void_p(srs.powers_of_tau_in_g1.data_ptr()), swapped.ctypes.data_as(C.c_void_p),
+                                     C.c_size_t(swapped.nbytes)), "memcpy")
+    assert srs.powers_of_tau_in_g1._version == version                     # torch saw nothing
+    plain = zk.TrustedSetup(srs.powers_of_tau_in_g1.clone(), srs.inf.clone())
+    after = zk.MultilinearKZG.commitment(poly, srs)
+    assert srs.table is None and not (after == before) and after == zk.MultilinearKZG.commitment(poly, plain)
+    srs.precompute()
+    assert srs.table is not None
+    srs.invalidate()
+    assert srs.table is None
+
+
 # ---- commits in flight (zkhip_kzg_commit_begin / _end) ------------------------------------------------------------------
 @pytest.mark.parametrize("table", [False, True])
 def test_commits_in_flight_match_synchronous_commits(zk, ora, table):

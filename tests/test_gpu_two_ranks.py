@@ -1,7 +1,8 @@
 """Two (and four) real ranks -- separate processes, torch.distributed rendezvous, one HIP context each -- sharing the one
-GPU of the test box.  RCCL refuses two ranks on one device, so the exchange runs over gloo through a shim that stages the
-(tiny) payloads through host memory; everything else is the production path: HipSumcheckEngine / HipComposedEngine,
-ShardedSumcheck / ShardedComposedSumcheck / sharded_commit, compared on every rank with the single-GPU provers."""
+GPU of the test box.  RCCL refuses two ranks on one device, so the communicator's transport is the CALLBACK one (zkhip_comm_create:
+an all-gather over gloo that stages the tiny payloads through host memory); everything else is the production path: the protocols
+inside libzkhip (zkhip_sc_prove_sharded / zkhip_mc_prove_sharded / zkhip_gkr_prove_sharded / zkhip_kzg_commit_sharded), compared on
+every rank with the single-GPU provers."""
 import os
 import sys
 
@@ -10,18 +11,6 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-class GlooStaged:
-    """all_gather_into_tensor for CUDA tensors over a gloo group (payloads are at most a few KiB)."""
-
-    def __init__(self, dist):
-        self.dist = dist
-
-    def all_gather_into_tensor(self, out, inp, group=None):
-        o = out.cpu()
-        self.dist.all_gather_into_tensor(o, inp.cpu(), group=group)
-        out.copy_(o)
 
 
 def _worker(rank, world, port, q):
@@ -33,9 +22,10 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import zk_cryptography_amd as zk
+        from zk_cryptography_amd import _native as N
         from zk_cryptography_amd import distributed as D
         torch.cuda.set_device(0)
-        shim = GlooStaged(dist)
+        shim = dist                     # gloo: distributed.Comm picks the staged (callback) transport
 
         def cuda(a):
             return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
@@ -66,7 +56,7 @@ def _worker(rank, world, port, q):
         got = [zk.SparseUnivariatePolynomial(c, p).monomials() for c, p in rps]
         res["multi_composed"] = bool(got == [p.monomials() for p in wproof.round_polys] and np.array_equal(ch, wch))
         # GKRProtocol::prove with every layer's sumcheck sharded (narrow layers run whole on every rank)
-        for depth in (5, 9, 20):      # 20 = BASELINE configs[3]'s width (2^20-value layers, 161 exchanges)
+        for depth in (5, 9, 20):      # 20 = BASELINE configs[3]'s width (2^20-value layers)
             circuit = zk.Circuit.random(depth)
             ev = circuit.evaluation(zk.Fr.random(2 ** depth, 300 + depth))
             want = zk.GKRProtocol.prove(circuit, ev)
@@ -84,13 +74,14 @@ def _worker(rank, world, port, q):
         want = zk.MultilinearKZG.commitment(zk.Multilinear(scal), srs)
         my_srs = zk.TrustedSetup(srs.powers_of_tau_in_g1[rank::world].contiguous(), srs.inf[rank::world].contiguous())
         my_poly = zk.Multilinear(cuda(D.shard_interleaved(scal, rank, world)))
-
-        def local():
-            c = zk.MultilinearKZG.commitment(my_poly, my_srs)
-            return c.xy, c.infinity
-
-        xy, inf = D.sharded_commit(local, D.hip_sum_affine, world, None, shim, device="cuda")
-        res["commit"] = bool((not inf) and np.array_equal(xy, want.xy))
+        comm = D.Comm.get(N.Context.get(0), world, rank, dist, None)
+        xy, inf = D.sharded_commit(my_srs.powers_of_tau_in_g1, my_srs.inf, my_poly.evaluations, comm)
+        ok = (not inf) and np.array_equal(xy, want.xy)
+        xy, inf = D.sharded_commit(None, my_srs.inf, my_poly.evaluations, comm, table=my_srs.precompute().table)   # the shard's shifted-SRS table
+        ok = ok and (not inf) and np.array_equal(xy, want.xy)
+        res["commit"] = bool(ok)
+        res["exchanges_counted"] = comm.stats()[0] > 10
+        D.Comm.close_all()
         q.put((rank, res))
     finally:
         dist.destroy_process_group()

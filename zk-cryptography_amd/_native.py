@@ -6,6 +6,7 @@ stream and torch.distributed; it is plumbing only -- all arithmetic happens in l
 import ctypes as C
 import os
 import subprocess
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
@@ -69,7 +70,9 @@ def check(status, what=""):
 
 
 class Context:
-    """One libzkhip context per (process, device), enqueueing on torch's current stream."""
+    """One libzkhip context per (host thread, device), enqueueing on torch's current stream (include/zkhip.h: "one context per
+    host thread; contexts are independent" -- the mirror classes reach theirs through Context.get, so two Python threads that prove
+    at once never share one)."""
 
     _instances = {}
 
@@ -90,11 +93,21 @@ class Context:
         import torch
         if device_index is None:
             device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
-        ctx = cls._instances.get(device_index)
+        key = (threading.get_ident(), device_index)
+        ctx = cls._instances.get(key)
         if ctx is None:
-            ctx = cls._instances[device_index] = Context(device_index)
+            ctx = cls._instances[key] = Context(device_index)
         ctx.sync_stream()
         return ctx
+
+    def destroy(self):
+        """zkhip_ctx_destroy: waits for the context's streams and returns every buffer it holds"""
+        if self.handle:
+            h, self.handle = self.handle, None
+            for k, v in list(Context._instances.items()):
+                if v is self:
+                    del Context._instances[k]
+            check(lib().zkhip_ctx_destroy(h), "ctx_destroy")
 
     def sync_stream(self):
         s = self.torch.cuda.current_stream(self.device).cuda_stream

@@ -534,7 +534,8 @@ extern "C" int zkhip_multi_composed_prove(zkhip_ctx* c, const uint64_t* const* p
 struct zkhip_mc_state {
     ComposedRun run;
     uint32_t world = 1;
-    bool sums_pending = false;   // round_sums done, absorb not yet
+    int sums_pending = 0;        // which record is out and not absorbed yet: 0 none, 1 a round record (zkhip_mc_round_sums), 2 a stage record
+    size_t pending_cn = 0;       // entries per table when that record was taken (the matching absorb must find the session where it left it)
 };
 
 extern "C" int zkhip_mc_begin_ex(zkhip_ctx* c, const uint64_t* const* d_local_tables, const uint32_t* term_sizes, uint32_t n_terms,
@@ -594,15 +595,17 @@ extern "C" int zkhip_mc_round_sums(zkhip_mc_state* s, uint64_t* d_out) {
     ZK_TRY(run.round_sums(&grid));
     hipLaunchKernelGGL(composed_reduce_kernel, dim3(1), dim3(MLE_BLOCK), 0, run.c->stream, run.d_partials, (uint32_t)grid, run.meta.rec, d_out);
     ZK_HIP(run.c, hipGetLastError());
-    s->sums_pending = true;
+    s->sums_pending = 1;
+    s->pending_cn = run.cn;
     return ZKHIP_OK;
 }
 extern "C" int zkhip_mc_absorb(zkhip_mc_state* s, const uint64_t* d_gathered, uint32_t world) {
-    if (!s || !d_gathered || world != s->world || !s->sums_pending) return ZKHIP_ERR_ARG;
+    // a ROUND record only: a stage record (n_terms * 20 values) read with a round record's length would give a wrong transcript silently
+    if (!s || !d_gathered || world != s->world || s->sums_pending != 1 || s->pending_cn != s->run.cn) return ZKHIP_ERR_ARG;
     ZK_TRY(s->run.c->activate());
     s->run.close(d_gathered, world);
     ZK_HIP(s->run.c, hipGetLastError());
-    s->sums_pending = false;
+    s->sums_pending = 0;
     return ZKHIP_OK;
 }
 // Two rounds per exchange (composed_stage.hpp) when every term is a product of two tables: *vals = the length of the stage record
@@ -623,15 +626,16 @@ extern "C" int zkhip_mc_stage_sums(zkhip_mc_state* s, uint64_t* d_out) {
     ZK_TRY(run.stage_sums(&grid));
     hipLaunchKernelGGL(composed_stage_reduce_kernel, dim3(1), dim3(CST_BLOCK), 0, run.c->stream, run.d_partials, (uint32_t)grid, run.n_terms * (uint32_t)CST_VALS, d_out);
     ZK_HIP(run.c, hipGetLastError());
-    s->sums_pending = true;
+    s->sums_pending = 2;
+    s->pending_cn = run.cn;
     return ZKHIP_OK;
 }
 extern "C" int zkhip_mc_stage_absorb(zkhip_mc_state* s, const uint64_t* d_gathered, uint32_t world) {
-    if (!s || !d_gathered || world != s->world || !s->sums_pending) return ZKHIP_ERR_ARG;
+    if (!s || !d_gathered || world != s->world || s->sums_pending != 2 || s->pending_cn != s->run.cn || !s->run.stage_possible(4)) return ZKHIP_ERR_ARG;
     ZK_TRY(s->run.c->activate());
     ZK_TRY(s->run.stage_close(d_gathered, world));
     ZK_HIP(s->run.c, hipGetLastError());
-    s->sums_pending = false;
+    s->sums_pending = 0;
     return ZKHIP_OK;
 }
 extern "C" int zkhip_mc_local_tables(zkhip_mc_state* s, uint64_t* d_out) {

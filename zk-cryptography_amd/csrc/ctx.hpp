@@ -64,6 +64,8 @@ struct zkhip_ctx {
     size_t ws_bytes = 0;
     void* d_composed = nullptr;      // composed provers: ComposedDev (transcript + interpolation matrices of every degree), uploaded once
     void* d_gen_table = nullptr;   // SRS generation: d * 2^(8w) * G for 32 windows x 255 digits, affine (+ infinity flags); built on first use
+    void* ntt_state = nullptr;     // twiddle tables and pass plans of the transforms this context has run (ntt.hip); ntt_free releases them
+    void (*ntt_free)(void*) = nullptr;
     void* d_aux = nullptr;      // second grow-only buffer for entry points that call others which own d_ws (kzg_open)
     size_t aux_bytes = 0;
     // pinned result buffers + events for commits whose host epilogue is deferred (msm_enqueue / msm_finish), and the side
@@ -100,14 +102,22 @@ struct zkhip_ctx {
     static constexpr int COARSE_RING = 8;
     void* d_coarse[COARSE_RING] = {};
     const void* coarse_of[COARSE_RING] = {}; size_t coarse_n[COARSE_RING] = {}; uint32_t coarse_k1[COARSE_RING] = {};
+    int coarse_owner[COARSE_RING] = {};     // result slot + 1 of the proof that still reads the entry (0: nobody): such an entry is never handed out
     int coarse_next = 0;
     int next_coarse(int* slot) {
-        const int k = coarse_next;
-        coarse_next = (coarse_next + 1) % COARSE_RING;
-        if (!d_coarse[k] && hipMalloc(&d_coarse[k], 2 * 1024 * 32) != hipSuccess) return ZKHIP_ERR_NOMEM;
-        coarse_of[k] = nullptr;
-        *slot = k;
-        return ZKHIP_OK;
+        for (int tries = 0; tries < COARSE_RING; ++tries) {
+            const int k = coarse_next;
+            coarse_next = (coarse_next + 1) % COARSE_RING;
+            if (coarse_owner[k]) continue;          // a proof in flight reads it from a stream of its own: no event orders a rewrite behind that
+            if (!d_coarse[k] && hipMalloc(&d_coarse[k], 2 * 1024 * 32) != hipSuccess) return ZKHIP_ERR_NOMEM;
+            coarse_of[k] = nullptr;
+            *slot = k;
+            return ZKHIP_OK;
+        }
+        return ZKHIP_ERR_BUSY;                       // unreachable with <= PROOF_SLOTS proofs in flight (one entry each), kept as a guard
+    }
+    void release_coarse(int proof_slot) {
+        for (int k = 0; k < COARSE_RING; ++k) if (coarse_owner[k] == proof_slot + 1) coarse_owner[k] = 0;
     }
     // Sumcheck::prove in flight (zkhip_sumcheck_prove_begin): every ticket has a LANE of its own -- a serial stream, a low-priority
     // fold stream, events, workspace and small scratch -- so that the streaming passes of one proof run while the transcript rounds

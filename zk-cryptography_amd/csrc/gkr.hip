@@ -16,6 +16,7 @@
 #include "host_util.hpp"
 #include "host_fr.hpp"
 #include "mle_kernels.hpp"
+#include "shard.hpp"
 
 // ---- a layer's sumcheck in time linear in its width -------------------------------------------------------------
 // The reference proves, per layer,   sum_{b,c} add~(b,c) (V(b) + V(c)) + mul~(b,c) V(b) V(c)   with the multi-composed
@@ -505,33 +506,32 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
 
 // The layer's linear-size sumcheck tables for a rank of a sharded proof (world = 1, rank = 0: the whole tables).  phase 0: d_out =
 // {Ha0, Ha1, Hm, V} rows j * world + rank; phase 1 (after the rounds over b: the challenges lie in the context): d_out = {Aa, V(u) + V,
-// Am, V(u) V} rows likewise, h_wu = V(u).  Every output holds w_len / world entries.
-extern "C" int zkhip_gkr_layer_tables_sharded(zkhip_circuit* cir, uint32_t layer, const uint64_t* d_w, size_t w_len, const uint64_t* h_rb,
-                                              const uint64_t* h_rc, const uint64_t* h_alpha, const uint64_t* h_beta, int phase,
-                                              uint32_t world, uint32_t rank, uint64_t* const* d_out, uint64_t* h_wu) {
+// Am, V(u) V} rows likewise, V(u) left at ts.evals[0..4).  Every output holds w_len / world entries.  Enqueue only: nothing here waits.
+namespace {
+struct TablesScratch { uint64_t *wg, *equ, *dot_partials, *evals, *eqh; };
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t tables_scratch_bytes(size_t n_gates, size_t w_len) {
+    return al256(32 * std::max<size_t>(n_gates, 1)) + al256(32 * w_len) + al256(32 * (size_t)zk::MLE_MAX_GRID) + 256 + 32 * 2 * (size_t)zk::GKR_EQ_HALVES;
+}
+TablesScratch carve_tables_scratch(char* base, size_t n_gates, size_t w_len) {
+    TablesScratch ts;
+    const size_t o_wg = 0, o_equ = o_wg + al256(32 * std::max<size_t>(n_gates, 1)), o_dot = o_equ + al256(32 * w_len),
+                 o_ev = o_dot + al256(32 * (size_t)zk::MLE_MAX_GRID), o_eqh = o_ev + 256;
+    ts.wg = (uint64_t*)(base + o_wg); ts.equ = (uint64_t*)(base + o_equ); ts.dot_partials = (uint64_t*)(base + o_dot);
+    ts.evals = (uint64_t*)(base + o_ev); ts.eqh = (uint64_t*)(base + o_eqh);
+    return ts;
+}
+int layer_tables_enqueue(zkhip_circuit* cir, uint32_t layer, const uint64_t* d_w, size_t w_len, const uint64_t* h_rb, const uint64_t* h_rc,
+                         const uint64_t* h_alpha, const uint64_t* h_beta, int phase, uint32_t world, uint32_t rank, uint64_t* const* d_out,
+                         const TablesScratch& ts) {
     using namespace zk;
-    if (!cir || !d_w || !h_rb || !h_alpha || !h_beta || !d_out || phase < 0 || phase > 1 || layer >= cir->n_layers) return ZKHIP_ERR_ARG;
-    if (phase == 1 && !h_wu) return ZKHIP_ERR_ARG;
-    if (world == 0 || (world & (world - 1)) || rank >= world) return ZKHIP_ERR_ARG;
     zkhip_ctx* c = cir->c;
     const LayerDev& ld = cir->layers[layer];
     if (!is_pow2(w_len) || w_len != ld.w_len || w_len < world) return ZKHIP_ERR_SHAPE;
     if (ld.bad_label) return ZKHIP_ERR_INDEX;
-    ZK_TRY(c->activate());
     const uint32_t s = log2_exact(w_len);
     const uint32_t n_gate_vars = layer == 0 ? 1u : layer;
     const bool two_points = h_rc != nullptr;
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_wg = 0, o_equ = o_wg + al(32 * std::max<size_t>(ld.n_gates, 1)), o_dot = o_equ + al(32 * w_len),
-                 o_ev = o_dot + al(32 * (size_t)zk::MLE_MAX_GRID);
-    const size_t o_eqh = o_ev + 256;
-    ZK_TRY(c->reserve_aux(o_eqh + 32 * 2 * (size_t)zk::GKR_EQ_HALVES));
-    char* aux = (char*)c->d_aux;
-    uint64_t* eqh = (uint64_t*)(aux + o_eqh);
-    uint64_t* wg = (uint64_t*)(aux + o_wg);
-    uint64_t* equ = (uint64_t*)(aux + o_equ);
-    uint64_t* dot_partials = (uint64_t*)(aux + o_dot);
-    uint64_t* evals = (uint64_t*)(aux + o_ev);
     PtsArg pb = {}, pc = {};
     std::memcpy(pb.v, h_rb, 32 * (size_t)n_gate_vars);
     if (two_points) std::memcpy(pc.v, h_rc, 32 * (size_t)n_gate_vars);
@@ -540,20 +540,38 @@ extern "C" int zkhip_gkr_layer_tables_sharded(zkhip_circuit* cir, uint32_t layer
     std::memcpy(bv.v, h_beta, 32);
     const uint32_t rows = (uint32_t)(w_len / world);
     const unsigned gw = (unsigned)((rows + MLE_BLOCK - 1) / MLE_BLOCK);
-    launch_gate_weights(c, ld.n_gates, n_gate_vars, pb, pc, av, bv, two_points, eqh, wg);
+    launch_gate_weights(c, ld.n_gates, n_gate_vars, pb, pc, av, bv, two_points, ts.eqh, ts.wg);
     if (phase == 0) {
-        hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr0, ld.csr0 + w_len + 1, ld.type, ld.in1, wg, d_w,
+        hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr0, ld.csr0 + w_len + 1, ld.type, ld.in1, ts.wg, d_w,
                            rows, 1u, d_out[0], d_out[1], d_out[2], (const uint64_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr,
                            world, rank, world > 1 ? d_out[3] : (uint64_t*)nullptr);
         ZK_HIP(c, hipGetLastError());
         return ZKHIP_OK;
     }
     const uint64_t* d_ch = zk_composed_challenges_dev(c);       // the s challenges of the rounds over b
-    launch_eq_table(c, d_ch, s, eqh, equ, d_w, dot_partials, evals);
-    hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr1, ld.csr1 + w_len + 1, ld.type, ld.in0, wg, equ,
-                       rows, 2u, d_out[0], (uint64_t*)nullptr, d_out[2], d_w, (const uint64_t*)evals, d_out[1], d_out[3], world, rank, (uint64_t*)nullptr);
+    launch_eq_table(c, d_ch, s, ts.eqh, ts.equ, d_w, ts.dot_partials, ts.evals);
+    hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr1, ld.csr1 + w_len + 1, ld.type, ld.in0, ts.wg, ts.equ,
+                       rows, 2u, d_out[0], (uint64_t*)nullptr, d_out[2], d_w, (const uint64_t*)ts.evals, d_out[1], d_out[3], world, rank, (uint64_t*)nullptr);
     ZK_HIP(c, hipGetLastError());
-    ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), evals, 32, hipMemcpyDeviceToHost, c->stream));
+    return ZKHIP_OK;
+}
+}  // namespace
+extern "C" int zkhip_gkr_layer_tables_sharded(zkhip_circuit* cir, uint32_t layer, const uint64_t* d_w, size_t w_len, const uint64_t* h_rb,
+                                              const uint64_t* h_rc, const uint64_t* h_alpha, const uint64_t* h_beta, int phase,
+                                              uint32_t world, uint32_t rank, uint64_t* const* d_out, uint64_t* h_wu) {
+    if (!cir || !d_w || !h_rb || !h_alpha || !h_beta || !d_out || phase < 0 || phase > 1 || layer >= cir->n_layers) return ZKHIP_ERR_ARG;
+    if (phase == 1 && !h_wu) return ZKHIP_ERR_ARG;
+    if (world == 0 || (world & (world - 1)) || rank >= world) return ZKHIP_ERR_ARG;
+    zkhip_ctx* c = cir->c;
+    const LayerDev& ld = cir->layers[layer];
+    if (!is_pow2(w_len) || w_len != ld.w_len || w_len < world) return ZKHIP_ERR_SHAPE;
+    if (ld.bad_label) return ZKHIP_ERR_INDEX;
+    ZK_TRY(c->activate());
+    ZK_TRY(c->reserve_aux(tables_scratch_bytes(ld.n_gates, w_len)));
+    const TablesScratch ts = carve_tables_scratch((char*)c->d_aux, ld.n_gates, w_len);
+    ZK_TRY(layer_tables_enqueue(cir, layer, d_w, w_len, h_rb, h_rc, h_alpha, h_beta, phase, world, rank, d_out, ts));
+    if (phase == 0) return ZKHIP_OK;
+    ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), ts.evals, 32, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     std::memcpy(h_wu, c->pinned_u64(ZK_PIN_RES), 32);
     return ZKHIP_OK;
@@ -562,6 +580,139 @@ extern "C" int zkhip_gkr_layer_tables(zkhip_circuit* cir, uint32_t layer, const 
                                       const uint64_t* h_rc, const uint64_t* h_alpha, const uint64_t* h_beta, int phase,
                                       uint64_t* const* d_out, uint64_t* h_wu) {
     return zkhip_gkr_layer_tables_sharded(cir, layer, d_w, w_len, h_rb, h_rc, h_alpha, h_beta, phase, 1, 0, d_out, h_wu);
+}
+
+// GKRProtocol::prove (protocol.rs:21-117) with every layer's sumcheck tables sharded over the ranks of `comm` (include/zkhip.h): per layer
+// this rank's rows of the tables of the rounds over b -> a composed session on them (two rounds per exchange) -> the rows of the tables of
+// the rounds over c (b bound to the challenges the first session left in the context) -> a session that continues the first one's
+// transcript -> w_b, w_c -> the outer transcript on the host (the ONE synchronisation of the layer).  Exchanges are stream-ordered.
+extern "C" int zkhip_gkr_prove_sharded(zkhip_circuit* cir, zkhip_comm* comm, const uint64_t* const* h_layer_ptrs, const size_t* h_layer_len,
+                                       int use_stages, uint64_t* h_sums, uint32_t* h_n_rounds, uint32_t* h_round_poly_lens,
+                                       uint64_t* h_round_polys, uint64_t* h_wb, uint64_t* h_wc, uint64_t* h_w0, uint64_t* h_challenges,
+                                       uint32_t* exchanges) {
+    if (!cir || !comm || !h_layer_ptrs || !h_layer_len || !h_sums || !h_n_rounds || !h_round_poly_lens || !h_round_polys || !h_wb || !h_wc || !h_w0)
+        return ZKHIP_ERR_ARG;
+    zkhip_ctx* c = cir->c;
+    if (comm->c != c) return ZKHIP_ERR_ARG;                       // the circuit and the communicator live on one context (one GPU, one stream)
+    const uint32_t n_layers = cir->n_layers, world = comm->world_, rank = comm->rank_;
+    if (h_layer_len[0] != 1) return ZKHIP_ERR_SHAPE;
+    for (uint32_t k = 1; k <= n_layers; ++k)
+        if (!is_pow2(h_layer_len[k])) return ZKHIP_ERR_SHAPE;     // Multilinear::new (evaluation_form.rs:16-20)
+    ZK_TRY(c->activate());
+    // aux layout: w_0 (2 entries) | the table builders' scratch | 8 tables of this rank's rows of the widest layer
+    size_t max_rows = 1, max_scratch = 0;
+    for (uint32_t l = 0; l < n_layers; ++l) {
+        const size_t w_len = h_layer_len[l + 1];
+        max_rows = std::max(max_rows, w_len >= 2 * (size_t)world ? w_len / world : w_len);
+        max_scratch = std::max(max_scratch, tables_scratch_bytes(cir->layers[l].n_gates, w_len));
+    }
+    const size_t tb = al256(32 * max_rows), o_scr = 256, o_tab = o_scr + al256(max_scratch);
+    ZK_TRY(c->reserve_aux(o_tab + 8 * tb));
+    char* aux = (char*)c->d_aux;
+    uint64_t* d_w0 = (uint64_t*)aux;
+    uint64_t* tab[8];
+    for (int q = 0; q < 8; ++q) tab[q] = (uint64_t*)(aux + o_tab + (size_t)q * tb);
+    zkhip_comm* solo = comm->solo_comm();                         // narrow layers run whole on every rank: a one-rank exchange (no transport)
+    if (!solo) return ZKHIP_ERR_NOMEM;
+    uint32_t n_ex = 0;
+    const uint32_t stride = 2 * n_layers;
+
+    // w_0 = circuit_evaluation[0] padded with a zero (protocol.rs:30-33); commit its bytes, draw n_r
+    zkhost::Transcript tr;
+    ZK_HIP(c, hipMemsetAsync(d_w0, 0, 64, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(d_w0, h_layer_ptrs[0], 32, hipMemcpyDeviceToDevice, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(h_w0, d_w0, 64, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    {
+        zkhost::Fr one_canon = zkhost::fr_zero();
+        one_canon.l[0] = 1;
+        uint8_t be[64];
+        for (int e = 0; e < 2; ++e) {
+            zkhost::Fr v;
+            std::memcpy(v.l, h_w0 + 4 * e, 32);
+            const zkhost::Fr cv = zkhost::fr_mul(v, one_canon);
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 8; ++j) be[32 * e + 8 * i + j] = (uint8_t)(cv.l[3 - i] >> (56 - 8 * j));
+        }
+        tr.commit(be, 64);                                           // w_0_mle.to_bytes()
+    }
+    std::vector<zkhost::Fr> r_b(1, tr.challenge_fr()), r_c;          // evaluate_n_challenge_into_field(&w_0_mle.n_vars)
+    zkhost::Fr claimed;
+    ZK_TRY(zkhip_mle_evaluation(c, d_w0, 2, r_b[0].l, 1, claimed.l));
+    zkhost::Fr alpha = zkhost::fr_one(), beta = zkhost::fr_zero();
+
+    int rc = ZKHIP_OK;
+    for (uint32_t li = 1; li <= n_layers && rc == ZKHIP_OK; ++li) {   // layer one (gkr/src/utils.rs:12-56), then protocol.rs:64-108
+        const uint32_t l = li - 1, k = li - 1;
+        const uint64_t* V = h_layer_ptrs[li];
+        const size_t w_len = h_layer_len[li];
+        const LayerDev& ld = cir->layers[l];
+        const uint32_t s = log2_exact(w_len), n_gate_vars = l == 0 ? 1u : l;
+        const bool two_points = li > 1;
+        if (s != l + 1 || w_len != ld.w_len || 2 * s > stride) { rc = ZKHIP_ERR_SHAPE; break; }
+        if (r_b.size() != n_gate_vars || (two_points && r_c.size() != n_gate_vars)) { rc = ZKHIP_ERR_SHAPE; break; }
+        const uint32_t w = w_len >= 2 * (size_t)world ? world : 1;    // narrow layers: every rank proves them whole
+        const uint32_t rk = w > 1 ? rank : 0;
+        zkhip_comm* cm = w > 1 ? comm : solo;
+        const bool stages = use_stages >= 0 ? use_stages != 0 : w > 1;
+        const size_t rows = w_len / w;
+        const TablesScratch ts = carve_tables_scratch(aux + o_scr, ld.n_gates, w_len);
+        const uint32_t sizes[2] = {2, 2};
+        // ---- rounds over b on this rank's rows of [Ha0, V] + Ha1, [Hm, V]
+        if ((rc = layer_tables_enqueue(cir, l, V, w_len, r_b[0].l, two_points ? r_c[0].l : nullptr, alpha.l, beta.l, 0, w, rk, tab, ts)) != ZKHIP_OK) break;
+        const uint64_t* v_sh = w > 1 ? tab[3] : V;
+        {
+            const uint64_t* tables[4] = {tab[0], v_sh, tab[2], v_sh};
+            const uint64_t* lin[2] = {tab[1], nullptr};
+            zkhip_mc_state* st = nullptr;
+            if ((rc = zkhip_mc_begin_ex(c, tables, sizes, 2, lin, rows, w, 1, claimed.l, 0, 0, &st)) != ZKHIP_OK) break;
+            uint32_t ex = 0;
+            rc = zkhip_mc_prove_sharded(st, cm, stages ? 1 : 0, nullptr, nullptr, nullptr, &ex);   // recorded on the device; releases the session
+            n_ex += ex;
+            if (rc != ZKHIP_OK) break;
+        }
+        // ---- rounds over c, b at u = the challenges just recorded: rows of [Aa, V(u) + V], [Am, V(u) V]; V(u) = w_b stays on the device
+        if ((rc = layer_tables_enqueue(cir, l, V, w_len, r_b[0].l, two_points ? r_c[0].l : nullptr, alpha.l, beta.l, 1, w, rk, tab + 4, ts)) != ZKHIP_OK) break;
+        uint64_t* polys = h_round_polys + (size_t)k * stride * GKR_MONO * 8;
+        uint32_t* lens = h_round_poly_lens + (size_t)k * stride;
+        std::vector<uint64_t> challenges(4 * (size_t)(2 * s));
+        {
+            const uint64_t* tables[4] = {tab[4], tab[5], tab[6], tab[7]};
+            zkhip_mc_state* st = nullptr;
+            if ((rc = zkhip_mc_begin_ex(c, tables, sizes, 2, nullptr, rows, w, 1, nullptr, 1, s, &st)) != ZKHIP_OK) break;
+            zkshard::HipMcEngine e{st, cm};
+            uint32_t ex = 0;
+            rc = zkshard::composed_prove(e, *cm, stages, &ex);
+            n_ex += ex;
+            if (rc != ZKHIP_OK) { zkhip_mc_abort(st); break; }
+            // w_c = V(r_c), r_c = the second half of the challenges: enqueued behind the rounds, read back with them
+            zk::launch_eq_table(c, zk_composed_challenges_dev(c) + 4 * (size_t)s, s, ts.eqh, ts.equ, V, ts.dot_partials, ts.evals + 4);
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), ts.evals, 64, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+                zkhip_mc_abort(st);
+                rc = ZKHIP_ERR_HIP;
+                break;
+            }
+            if ((rc = zkhip_mc_finish(st, lens, polys, challenges.data())) != ZKHIP_OK) break;   // all 2 s rounds; synchronises the stream
+        }
+        zkhost::Fr eval_wb, eval_wc;
+        std::memcpy(eval_wb.l, c->pinned_u64(ZK_PIN_RES), 32);
+        std::memcpy(eval_wc.l, c->pinned_u64(ZK_PIN_RES) + 4, 32);
+        if (h_challenges) std::memcpy(h_challenges + (size_t)k * stride * 4, challenges.data(), 32 * (size_t)(2 * s));
+        std::memcpy(h_sums + 4 * (size_t)k, claimed.l, 32);
+        h_n_rounds[k] = 2 * s;
+        absorb_proof(tr, polys, lens, 2 * s);                          // transcript.commit(&sumcheck_proof.to_bytes())
+        r_b.assign(s, zkhost::fr_zero());                              // challenges.split_at(len / 2)
+        std::memcpy(r_b.data(), challenges.data(), 32 * (size_t)s);
+        r_c.assign(s, zkhost::fr_zero());
+        std::memcpy(r_c.data(), challenges.data() + 4 * (size_t)s, 32 * (size_t)s);
+        std::memcpy(h_wb + 4 * (size_t)k, eval_wb.l, 32);
+        std::memcpy(h_wc + 4 * (size_t)k, eval_wc.l, 32);
+        alpha = tr.challenge_fr();
+        beta = tr.challenge_fr();
+        claimed = zkhost::fr_add(zkhost::fr_mul(alpha, eval_wb), zkhost::fr_mul(beta, eval_wc));
+    }
+    if (exchanges) *exchanges = n_ex;
+    return rc;
 }
 
 // one-shot form: the circuit is grouped and uploaded for this proof only

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <new>
 #include <vector>
 
 #include "ctx.hpp"
@@ -44,20 +45,44 @@ extern "C" int zkhip_domain_params(uint64_t size, uint64_t* h_generator, uint64_
     return ZKHIP_OK;
 }
 
+// Twiddle tables and pass plans live in the CONTEXT that built them (zkhip_ctx::ntt_state): contexts on different host threads share
+// nothing, and zkhip_ctx_destroy returns their device memory (they used to be process-wide maps keyed by the context's address).
 struct TwiddleKey {
-    zkhip_ctx* c; uint32_t log_n; int inverse;
+    uint32_t log_n; int inverse;
     bool operator<(const TwiddleKey& o) const {
-        if (c != o.c) return c < o.c;
         if (log_n != o.log_n) return log_n < o.log_n;
         return inverse < o.inverse;
     }
 };
-static std::map<TwiddleKey, uint64_t*> g_twiddles;   // device tables, kept for the life of the process
+struct NttPass { uint32_t s0, T; uint64_t* table; };
+struct NttPlan { uint64_t* tw1 = nullptr; std::vector<NttPass> passes; zkhost::Fr n_inv; };
+struct NttCache {
+    std::map<TwiddleKey, uint64_t*> twiddles;
+    std::map<TwiddleKey, NttPlan> plans;
+};
+static void ntt_cache_free(void* p) {
+    NttCache* nc = (NttCache*)p;
+    for (auto& kv : nc->twiddles) (void)hipFree(kv.second);
+    for (auto& kv : nc->plans) {
+        if (kv.second.tw1) (void)hipFree(kv.second.tw1);
+        for (auto& ps : kv.second.passes) if (ps.table) (void)hipFree(ps.table);
+    }
+    delete nc;
+}
+static NttCache* ntt_cache(zkhip_ctx* c) {
+    if (!c->ntt_state) {
+        c->ntt_state = new (std::nothrow) NttCache();
+        c->ntt_free = ntt_cache_free;
+    }
+    return (NttCache*)c->ntt_state;
+}
 
 static int get_twiddles(zkhip_ctx* c, uint32_t log_n, int inverse, uint64_t** out) {
-    TwiddleKey key{c, log_n, inverse};
-    auto it = g_twiddles.find(key);
-    if (it != g_twiddles.end()) { *out = it->second; return ZKHIP_OK; }
+    NttCache* nc = ntt_cache(c);
+    if (!nc) return ZKHIP_ERR_NOMEM;
+    TwiddleKey key{log_n, inverse};
+    auto it = nc->twiddles.find(key);
+    if (it != nc->twiddles.end()) { *out = it->second; return ZKHIP_OK; }
     const uint32_t log_half = log_n ? log_n - 1 : 0;
     const size_t half = (size_t)1 << log_half;
     zkhost::Fr w = root_of_unity(log_n);
@@ -71,20 +96,18 @@ static int get_twiddles(zkhip_ctx* c, uint32_t log_n, int inverse, uint64_t** ou
     hipLaunchKernelGGL(ntt_twiddle_kernel, dim3(mle_grid(half)), dim3(MLE_BLOCK), 0, c->stream, d_pw, log_half, d_tab);
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     ZK_HIP(c, hipFree(d_pw));
-    g_twiddles[key] = d_tab;
+    nc->twiddles[key] = d_tab;
     *out = d_tab;
     return ZKHIP_OK;
 }
 
 // ---- transforms of >= 2^12 points (ntt_kernels.hpp, second half) ------------------------------------------------------------
-struct NttPass { uint32_t s0, T; uint64_t* table; };
-struct NttPlan { uint64_t* tw1 = nullptr; std::vector<NttPass> passes; zkhost::Fr n_inv; };
-static std::map<TwiddleKey, NttPlan> g_plans;        // device tables, kept for the life of the process
-
 static int get_plan(zkhip_ctx* c, uint32_t log_n, int inverse, NttPlan** out) {
-    TwiddleKey key{c, log_n, inverse};
-    auto it = g_plans.find(key);
-    if (it != g_plans.end()) { *out = &it->second; return ZKHIP_OK; }
+    NttCache* nc = ntt_cache(c);
+    if (!nc) return ZKHIP_ERR_NOMEM;
+    TwiddleKey key{log_n, inverse};
+    auto it = nc->plans.find(key);
+    if (it != nc->plans.end()) { *out = &it->second; return ZKHIP_OK; }
     uint64_t* W = nullptr;
     ZK_TRY(get_twiddles(c, log_n, inverse, &W));
     NttPlan plan;
@@ -110,7 +133,7 @@ static int get_plan(zkhip_ctx* c, uint32_t log_n, int inverse, NttPlan** out) {
     }
     ZK_HIP(c, hipGetLastError());
     ZK_HIP(c, hipStreamSynchronize(c->stream));
-    *out = &(g_plans[key] = plan);
+    *out = &(nc->plans[key] = plan);
     return ZKHIP_OK;
 }
 

@@ -59,6 +59,7 @@ extern "C" int zkhip_ctx_create(zkhip_ctx** out, int device, void* stream) {
 extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     if (!c) return ZKHIP_ERR_ARG;
     hipSetDevice(c->device);
+    for (int k = 0; k < zkhip_ctx::ASYNC_SLOTS; ++k) if (c->async_pend[k]) zkhip_kzg_commit_end(c, (uint32_t)k, nullptr, nullptr);   // commits never collected
     hipStreamSynchronize(c->stream);
     // proofs still in flight write their results into the pinned slots from their lanes' streams: drain every stream of the context first
     if (c->fold_stream) hipStreamSynchronize(c->fold_stream);
@@ -69,6 +70,7 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     if (c->d_aux) hipFree(c->d_aux);
     if (c->d_gen_table) hipFree(c->d_gen_table);
     if (c->d_composed) hipFree(c->d_composed);
+    if (c->ntt_state && c->ntt_free) c->ntt_free(c->ntt_state);
     for (int i = 0; i < zkhip_ctx::MSM_SLOTS; ++i) {
         if (c->msm_pin[i]) hipHostFree(c->msm_pin[i]);
         if (c->msm_tab_dev[i]) hipFree(c->msm_tab_dev[i]);
@@ -584,7 +586,7 @@ static int launch_fine_sums(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uin
     {
         // (measured and dropped in round 3: waves that stay and loop over run pairs with the next pair's loads in flight -- 100-115 us
         // against 94-96 us for this one-shot form at 2^24; the loads alone take 81 us, tools/ubench_rows.hip "pieces")
-        ProfScope ps(c, "chunk_sums", 32.0 * (double)n, stream);
+        ProfScope ps(c, "fine_sums", 32.0 * (double)n, stream);
         hipLaunchKernelGGL(fine_sums_kernel, dim3((unsigned)((n_chunks + 7) / 8)), dim3(MLE_BLOCK), 0, stream, d_evals, n_chunks, first);
     }
     if (first != d_fine)
@@ -756,7 +758,8 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
             hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << k1), dim3(MLE_BLOCK), 0, S, fine, 1u << k2, (uint64_t*)nullptr, (uint64_t*)c->d_coarse[cs]);
         }
         const uint64_t* coarse = (const uint64_t*)c->d_coarse[cs];
-        c->coarse_of[cs] = nullptr;                 // the entry belongs to this proof from here on (the ring gives it seven more poly_sum() calls of life)
+        c->coarse_of[cs] = nullptr;                 // the entry belongs to this proof from here on:
+        c->coarse_owner[cs] = slot + 1;             // the ring skips it until the proof has been collected (sumcheck_collect / prove_end)
         SmallArgs a = {};
         a.src = coarse; a.group = 0; a.canon = 1; a.log_n = k1; a.n_rounds = k1; a.round0 = 0; a.first = first; a.claimed = claimed;
         a.d_claimed = d_claimed_sum; a.weights_out = d_w; a.final_out = nullptr;
@@ -835,7 +838,9 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
     return ZKHIP_OK;
 }
 static int sumcheck_collect(zkhip_ctx* c, int slot, uint32_t n_vars, uint64_t* h_sum, uint64_t* h_round_polys, uint64_t* h_challenges) {
-    ZK_TRY(c->wait_event(c->proof_ev[slot]));
+    const int wrc = c->wait_event(c->proof_ev[slot]);
+    c->release_coarse(slot);                    // the proof's kernels are done with their coarse sums (or the device is lost)
+    ZK_TRY(wrc);
     const uint64_t* pin = (const uint64_t*)c->proof_pin[slot];
     const uint64_t* span = c->small_u64(ZK_SMALL_STATE);
     const SumcheckDev* st = (const SumcheckDev*)c->small_u64(ZK_SMALL_STATE);
@@ -894,7 +899,7 @@ extern "C" int zkhip_sumcheck_prove_end(zkhip_ctx* c, uint32_t ticket, uint64_t*
     int rc = c->activate();
     if (rc == ZKHIP_OK) {
         if (h_sum && h_round_polys && h_challenges) rc = sumcheck_collect(c, (int)ticket, n_vars, h_sum, h_round_polys, h_challenges);
-        else rc = c->wait_event(c->proof_ev[ticket]);                          // abandoned: just wait it out
+        else { rc = c->wait_event(c->proof_ev[ticket]); c->release_coarse((int)ticket); }   // abandoned: just wait it out
         if (hipStreamWaitEvent(c->stream, c->proof_ev[ticket], 0) != hipSuccess && rc == ZKHIP_OK) rc = ZKHIP_ERR_HIP;   // the caller's stream is ordered behind the proof again
     }
     c->proof_pending[ticket] = 0;

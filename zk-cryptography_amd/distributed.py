@@ -1,29 +1,131 @@
-"""Multi-GPU host logic: one process per GPU, torch.distributed over RCCL/xGMI (backend "nccl" on ROCm).
+"""Multi-GPU host side: one process per GPU, every exchange an all-gather on the context's stream (RCCL over xGMI).
 
-Only the hot path's two sharding schemes live here:
+The exchange PROTOCOLS of the sharded provers -- stage plans, exchange order, tail gather, the per-layer GKR loop, the commit merge --
+live inside libzkhip (csrc/shard_protocol.hpp, csrc/shard.hip; include/zkhip.h "the sharded provers"); this module only binds them:
 
-* ShardedSumcheck -- the evaluation table of N = n_local * world entries is partitioned by the LOW index
-  bits (rank g holds entry j*world + g at local index j).  Sumcheck rounds fold variable 0 = the most
-  significant index bit, so every fold is local.  Stage form: per k rounds the ranks all-gather their 2^k partial
-  block sums (8 KiB for k = 8; modular addition is not an RCCL reduction, so the payload is gathered and added
-  locally), run the k rounds on the summed block sums with a replicated transcript, and fold their shard by k
-  variables locally; once the remaining table fits the tail (2048 entries) it is gathered and the last rounds run
-  replicated.  Shards of 2^19..2^24 entries take the OVERLAPPED stage first (the single-GPU plan in exchange form):
-  k1 rounds on coarse sums, then k2 rounds on the fine sums folded by those k1 challenges while the shard's
-  k1-variable fold runs on the engine's fold stream -- the second exchange and the serial rounds hide behind the one
-  pass over the shard; 2^24 per rank on 8 ranks is 6 | 10 | 11 rounds and three exchanges.  Round form (kept as a
-  fallback): one 64-byte exchange per round.
-* sharded_commit -- (scalars, SRS points) are split the same way; each rank runs a full sub-MSM and the
-  `world` partial commitments (104 bytes each) are all-gathered and summed.
-
-The per-rank compute sits behind a small "engine" interface so that the exchange protocol can be exercised
-on CPU (gloo) in tests with a checker engine; the product engine below is the HIP one.
+* Comm -- zkhip_comm: this rank's end of the exchange.  Transports: an RCCL communicator the library creates itself (when the
+  torch.distributed group runs on the "nccl" backend: the 128-byte unique id travels through the group once), or a callback that
+  stages the (tiny) payloads through host memory and any torch.distributed backend (gloo in the tests), or none (world == 1).
+* ShardedSumcheck -- zkhip_sc_prove_sharded: Sumcheck::prove over a table partitioned by the LOW index bits (rank g holds entry
+  j*world + g at local index j; rounds fold the most significant variable, so every fold is local).  Shards of 2^19..2^24 entries
+  take the overlapped stage (2^24 per rank on 8 ranks: 6 | 10 | 11 rounds and three exchanges), others the stage / round forms.
+* ShardedComposedSumcheck -- zkhip_mc_prove_sharded: ComposedSumcheck::prove / MultiComposedSumcheckProver::prove_partial over
+  shards, two rounds per exchange where every term is a product of two tables.
+* sharded_commit -- zkhip_kzg_commit_sharded: (scalars, SRS points) split the same way, a sub-MSM per rank, one all-gather of the
+  partial commitments, their group sum on every rank.
+* HipSumcheckEngine / HipComposedEngine -- the split-phase sessions (zkhip_sc_* / zkhip_mc_*) the protocols run on; the tests also
+  drive several of them in lockstep on one GPU.
 """
 import ctypes as C
 
 import numpy as np
 
 from zk_cryptography_amd import _native as N
+
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class Comm:
+    """zkhip_comm (include/zkhip.h): one per (context, group); cached, closed explicitly (Comm.close_all) or never."""
+
+    _cache = {}
+
+    def __init__(self, ctx, world=1, rank=0, dist=None, group=None, transport=None):
+        """transport: None = pick ("none" for world 1, "rccl" when `dist` runs the nccl backend, else "staged"); or a callable
+        fn(user, d_send, d_recv, bytes_per_rank, stream) -> 0: the caller's own all-gather (zkhip_all_gather_fn)."""
+        if world & (world - 1):
+            raise AssertionError("world size must be a power of two (the tables have 2^n entries)")
+        self.ctx, self.world, self.rank, self.dist, self.group = ctx, world, rank, dist, group
+        self.handle = C.c_void_p()
+        self.error = None
+        if transport is None:
+            transport = "none" if world == 1 else ("rccl" if _is_nccl(dist, group) else "staged")
+        self.transport = transport
+        lib = N.lib()
+        if callable(transport):
+            self._cb = transport if isinstance(transport, ALL_GATHER_FN) else ALL_GATHER_FN(transport)
+            N.check(lib.zkhip_comm_create(ctx.handle, C.c_uint32(rank), C.c_uint32(world), self._cb, None, C.byref(self.handle)), "comm_create")
+        elif transport == "none":
+            assert world == 1
+            N.check(lib.zkhip_comm_create(ctx.handle, C.c_uint32(0), C.c_uint32(1), None, None, C.byref(self.handle)), "comm_create")
+        elif transport == "rccl":
+            uid = np.zeros(128, dtype=np.uint8)
+            if rank == 0:
+                N.check(lib.zkhip_rccl_unique_id(uid.ctypes.data_as(C.c_void_p)), "rccl_unique_id (librccl.so not found?)")
+            if world > 1:
+                box = [uid.tobytes()]
+                dist.broadcast_object_list(box, src=_global_rank(dist, group, 0), group=group)
+                uid = np.frombuffer(box[0], dtype=np.uint8).copy()
+            N.check(lib.zkhip_comm_create_rccl(ctx.handle, uid.ctypes.data_as(C.c_void_p), C.c_uint32(rank), C.c_uint32(world),
+                                               C.byref(self.handle)), "comm_create_rccl")
+        else:
+            self._cb = ALL_GATHER_FN(self._staged_all_gather)      # kept alive with the comm
+            N.check(lib.zkhip_comm_create(ctx.handle, C.c_uint32(rank), C.c_uint32(world), self._cb, None, C.byref(self.handle)), "comm_create")
+
+    def _staged_all_gather(self, user, d_send, d_recv, nbytes, stream):
+        """all-gather through host memory and torch.distributed (payloads are at most a few hundred KiB): waits for the stream"""
+        try:
+            import torch
+            lib = N.lib()
+            send = torch.empty(nbytes, dtype=torch.uint8)
+            recv = torch.empty(nbytes * self.world, dtype=torch.uint8)
+            N.check(lib.zkhip_memcpy_d2h(self.ctx.handle, C.c_void_p(send.data_ptr()), C.c_void_p(d_send), C.c_size_t(nbytes)), "d2h")
+            self.dist.all_gather_into_tensor(recv, send, group=self.group)
+            N.check(lib.zkhip_memcpy_h2d(self.ctx.handle, C.c_void_p(d_recv), C.c_void_p(recv.data_ptr()), C.c_size_t(nbytes * self.world)), "h2d")
+            return 0
+        except BaseException as e:      # never unwind through the C frames
+            self.error = e
+            return 1
+
+    @classmethod
+    def get(cls, ctx, world=1, rank=None, dist=None, group=None):
+        if rank is None:
+            rank = dist.get_rank(group) if (world > 1 and dist is not None) else 0
+        key = (id(ctx), world, rank, id(dist) if world > 1 else 0, id(group) if world > 1 else 0)
+        m = cls._cache.get(key)
+        if m is None:
+            m = cls._cache[key] = Comm(ctx, world, rank, dist, group)
+        return m
+
+    def stats(self):
+        ex, by = C.c_uint64(0), C.c_uint64(0)
+        N.check(N.lib().zkhip_comm_stats(self.handle, C.byref(ex), C.byref(by)), "comm_stats")
+        return ex.value, by.value
+
+    def measure(self, nbytes, iters=200):
+        """(microseconds per exchange back to back, with a host wait per exchange), measured inside the library"""
+        a, b = C.c_double(0), C.c_double(0)
+        N.check(N.lib().zkhip_comm_measure(self.handle, C.c_size_t(nbytes), C.c_uint32(iters), C.byref(a), C.byref(b)), "comm_measure")
+        return a.value, b.value
+
+    def check(self, status, what):
+        """N.check, re-raising what a staged exchange caught inside its callback"""
+        if status != N.ZKHIP_OK and self.error is not None:
+            e, self.error = self.error, None
+            raise e
+        N.check(status, what)
+
+    def close(self):
+        if self.handle:
+            h, self.handle = self.handle, None
+            N.lib().zkhip_comm_destroy(h)
+
+    @classmethod
+    def close_all(cls):
+        for m in list(cls._cache.values()):
+            m.close()
+        cls._cache.clear()
+
+
+def _is_nccl(dist, group):
+    try:
+        return dist is not None and hasattr(dist, "get_backend") and str(dist.get_backend(group)) == "nccl"
+    except Exception:
+        return False
+
+
+def _global_rank(dist, group, group_rank):
+    return dist.get_global_rank(group, group_rank) if group is not None else group_rank
 
 
 def shard_interleaved(full, rank, world):
@@ -132,98 +234,33 @@ class HipSumcheckEngine:
         return s, rp[:n_rounds], ch[:n_rounds]
 
 
-def _all_gather(dist, group, out, inp, world):
-    if world == 1:
-        out.view(-1)[:] = inp.view(-1)
-    else:
-        dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=group)   # flat: rank-major concatenation
-
-
 class ShardedSumcheck:
-    """Sumcheck::prove (sumcheck/src/sumcheck.rs:29-61) over a table sharded by low index bits.
+    """Sumcheck::prove (sumcheck/src/sumcheck.rs:29-61) over a table sharded by low index bits: zkhip_sc_prove_sharded on the
+    engine's session.  Every rank returns the same (sum, round_polys [n_vars, 2, 4], challenges [n_vars, 4]) -- the values a
+    single-GPU / reference prover yields on the full table; `exchanges` = all-gathers issued."""
 
-    Every rank returns the same (sum, round_polys [n_vars, 2, 4], challenges [n_vars, 4]) -- the values a
-    single-GPU / reference prover yields on the full table."""
-
-    def __init__(self, engine, world=1, group=None, dist=None):
-        self.e = engine
-        self.world = world
-        self.group = group
-        self.dist = dist
+    def __init__(self, engine, world=1, group=None, dist=None, comm=None):
         if world & (world - 1):
             raise AssertionError("world size must be a power of two (the table has 2^n entries)")
+        self.e = engine
+        self.world = world
+        self.comm = comm or Comm.get(engine.ctx, world, None, dist, group)
+        self.exchanges = 0
 
     def prove(self, claimed_sum=None):
-        try:
-            return self._prove(claimed_sum)
-        except BaseException:
-            if hasattr(self.e, "abort"):
-                self.e.abort()              # a failed collective / assert must not leave the context's workspace lent
-            raise
-
-    def _prove(self, claimed_sum=None):
-        e, world = self.e, self.world
-        n_local = e.local_len()
-        total_rounds = (n_local * world).bit_length() - 1
-        absorbed = False
-        self.exchanges = 0                 # collectives of this prove (what a multi-GPU run pays on top of the kernels)
-        plan = e.overlap_plan(world) if getattr(e, "use_stages", True) and hasattr(e, "overlap_plan") else None
-        if plan:
-            # overlapped stage (shards of 2^19..2^24 entries): k1 rounds on coarse block sums, then k2 rounds on the fine sums
-            # folded by those k1 challenges WHILE the shard's k1-variable fold runs on the engine's fold stream -- the second
-            # exchange and the serial rounds hide behind the one pass over the shard
-            k1, k2, mid = plan
-            mine = e.new_buffer(1 << k1, 4)
-            e.overlap_sums(mine)
-            gathered = e.new_buffer(world, 1 << k1, 4)
-            _all_gather(self.dist, self.group, gathered, mine, world)          # C1
-            mine = e.new_buffer(mid, 4)
-            e.overlap_rounds1(gathered, world, mine, claimed_sum)
-            gathered = e.new_buffer(world, mid, 4)
-            _all_gather(self.dist, self.group, gathered, mine, world)          # C2, beside the fold
-            e.overlap_rounds2(gathered, world)
-            self.exchanges += 2
-            absorbed = True
-            n_local >>= k1 + k2
-        if getattr(e, "use_stages", True) and hasattr(e, "stage_plan"):
-            # stage form: one exchange per k rounds (32 * 2^k bytes per rank), then one local k-variable fold
-            while True:
-                k = e.stage_plan(world)
-                if k == 0:
-                    break
-                mine = e.new_buffer(1 << k, 4)
-                e.stage_block_sums(mine)
-                gathered = e.new_buffer(world, 1 << k, 4)
-                _all_gather(self.dist, self.group, gathered, mine, world)      # C1: RCCL all-gather over xGMI
-                self.exchanges += 1
-                e.stage_absorb(gathered, world, None if absorbed else claimed_sum)
-                absorbed = True
-                e.stage_fold()
-                n_local >>= k
-        # round form: one 64-byte exchange per round -- the whole protocol for engines without stages, and the way down
-        # to the tail size where a stage no longer fits (shards of a few entries on many ranks)
-        cap = e.tail_capacity()
-        if n_local * world > cap and n_local > 1:
-            send = e.new_buffer(2, 4)
-            recv = e.new_buffer(world, 2, 4)
-            while n_local * world > cap and n_local > 1:
-                e.local_half_sums(send)
-                _all_gather(self.dist, self.group, recv, send, world)
-                self.exchanges += 1
-                e.absorb(recv, world, None if absorbed else claimed_sum)       # local modular add + transcript -> challenge
-                absorbed = True
-                e.fold()                                                        # local: partners share the low index bits
-                n_local //= 2
-        if n_local * world > 1:
-            # the whole remaining table now fits one workgroup's LDS: gather it and finish replicated
-            mine = e.new_buffer(n_local, 4)
-            e.local_table(mine)
-            gathered = e.new_buffer(world, n_local, 4)
-            _all_gather(self.dist, self.group, gathered, mine, world)
-            self.exchanges += 1
-            full = gathered.transpose(0, 1).contiguous().view(n_local * world, 4)   # entry j*world + g <- rank g, local j
-            e.tail(full, n_local * world, None if absorbed else claimed_sum)
-        return e.finish(total_rounds)
+        e = self.e
+        n_rounds = (e.local_len() * self.world).bit_length() - 1
+        s = np.empty(4, dtype=np.uint64)
+        rp = np.empty((max(n_rounds, 1), 2, 4), dtype=np.uint64)
+        ch = np.empty((max(n_rounds, 1), 4), dtype=np.uint64)
+        cs = np.ascontiguousarray(claimed_sum, dtype=np.uint64) if claimed_sum is not None else None
+        ex = C.c_uint32(0)
+        st, e.st = e.st, None              # the call finishes (releases) the session whatever it returns
+        p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        self.comm.check(N.lib().zkhip_sc_prove_sharded(st, self.comm.handle, p(cs) if cs is not None else None, p(s), p(rp), p(ch),
+                                                       C.byref(ex)), "sc_prove_sharded")
+        self.exchanges = ex.value
+        return s, rp[:n_rounds], ch[:n_rounds]
 
 
 class HipComposedEngine:
@@ -331,106 +368,60 @@ class HipComposedEngine:
 
 class ShardedComposedSumcheck:
     """ComposedSumcheck::prove (composed_sumcheck.rs:32-67) / MultiComposedSumcheckProver::prove_partial
-    (multi_composed_sumcheck.rs:56-121) over tables sharded by low index bits ("GKR tables").
+    (multi_composed_sumcheck.rs:56-121) over tables sharded by low index bits ("GKR tables"): zkhip_mc_prove_sharded on
+    the engine's session.  One exchange per round, or ONE PER TWO ROUNDS for claims whose terms are products of two tables
+    (use_stages; default: on when world > 1 -- stages save exchanges, not work).  Every rank returns what a single-GPU / reference
+    prover produces on the whole tables."""
 
-    One exchange per round: a record of (K_p + 1) partial sums per term.  Claims whose terms are products of TWO tables (the
-    reference's ComposedSumcheck bench shape and every GKR layer claim) take TWO rounds per exchange instead: a product does not
-    commute with block sums, but it is bilinear in them, so the next two round polynomials are functions of the 16 cross-block
-    sums per term (csrc/composed_stage.hpp) -- the record is 20 field elements per term, the ranks' records are added, two
-    transcript rounds run replicated and every rank folds its shards by both challenges.  Every rank returns what engine.finish
-    yields -- the round polynomials and challenges a single-GPU / reference prover produces on the whole tables."""
-
-    def __init__(self, engine, world=1, group=None, dist=None, use_stages=None):
-        self.e = engine
-        self.world = world
-        self.group = group
-        self.dist = dist
-        # stages save exchanges, not work (on one rank two fused rounds are cheaper than a stage: DESIGN.md section 6)
-        self.use_stages = (world > 1) if use_stages is None else bool(use_stages)
+    def __init__(self, engine, world=1, group=None, dist=None, use_stages=None, comm=None):
         if world & (world - 1):
             raise AssertionError("world size must be a power of two (the tables have 2^n entries)")
+        self.e = engine
+        self.world = world
+        self.comm = comm or Comm.get(engine.ctx, world, None, dist, group)
+        self.use_stages = -1 if use_stages is None else int(bool(use_stages))
+        self.exchanges = 0
 
     def prove(self, collect=True, finish_rounds=None):
         """collect=False: run the rounds and release the session without reading anything back (a later session that
-        continues it delivers the rounds of both); finish_rounds: how many recorded rounds finish() reads (default: this
-        session's)."""
-        try:
-            return self._prove(collect, finish_rounds)
-        except BaseException:
-            if hasattr(self.e, "abort"):
-                self.e.abort()
-            raise
-
-    def _prove(self, collect=True, finish_rounds=None):
-        e, world = self.e, self.world
-        n_local = e.local_len()
-        total_rounds = (n_local * world).bit_length() - 1
-        self.exchanges = 0
-        cap = e.tail_capacity()
-        rec = e.record_len()
-        if self.use_stages and hasattr(e, "stage_record_len"):
-            send = recv = None
-            while n_local * world > cap and n_local >= 4:
-                vals = e.stage_record_len()
-                if not vals:
-                    break
-                if send is None:
-                    send, recv = e.new_buffer(vals, 4), e.new_buffer(world, vals, 4)
-                e.stage_sums(send)                                            # 16 cross-block sums (+ 4 block sums) per term
-                _all_gather(self.dist, self.group, recv, send, world)         # ONE exchange for two rounds
-                self.exchanges += 1
-                e.stage_absorb(recv, world)                                   # two transcript rounds + the fold by both challenges
-                n_local //= 4
-        if n_local * world > cap and n_local > 1:
-            send = e.new_buffer(rec, 4)
-            recv = e.new_buffer(world, rec, 4)
-            while n_local * world > cap and n_local > 1:
-                e.round_sums(send)                                            # fold at the previous challenge + partial sums
-                _all_gather(self.dist, self.group, recv, send, world)         # RCCL all-gather over xGMI, <= 768 B per rank
-                self.exchanges += 1
-                e.absorb(recv, world)                                         # local modular add + transcript -> challenge
-                n_local //= 2
-        if n_local * world > 1:
-            nt = e.table_count()
-            mine = e.new_buffer(nt, n_local, 4)
-            e.local_tables(mine)
-            gathered = e.new_buffer(world, nt, n_local, 4)
-            _all_gather(self.dist, self.group, gathered, mine, world)
-            self.exchanges += 1
-            full = gathered.permute(1, 2, 0, 3).contiguous()                  # entry j*world + g <- rank g, local j
-            e.tail(full.view(nt, n_local * world, 4), n_local * world)
+        continues it delivers the rounds of both); finish_rounds: how many recorded rounds are read (default: this session's)."""
+        e = self.e
+        total_rounds = (e.local_len() * self.world).bit_length() - 1
+        n_rounds = finish_rounds if finish_rounds is not None else total_rounds
+        ex = C.c_uint32(0)
+        st, e.st = e.st, None              # finished (released) by the call whatever it returns
+        p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
         if not collect:
-            e.abort()
+            self.comm.check(N.lib().zkhip_mc_prove_sharded(st, self.comm.handle, C.c_int(self.use_stages), None, None, None, C.byref(ex)),
+                            "mc_prove_sharded")
+            self.exchanges = ex.value
             return None
-        return e.finish(finish_rounds if finish_rounds is not None else total_rounds)
+        ch = np.empty((n_rounds, 4), dtype=np.uint64)
+        if not e.multi:
+            rp = np.empty((n_rounds, e.sizes[0] + 1, 4), dtype=np.uint64)
+            lens = None
+        else:
+            rp = np.zeros((n_rounds, 7, 2, 4), dtype=np.uint64)
+            lens = np.zeros(n_rounds, dtype=np.uint32)
+        self.comm.check(N.lib().zkhip_mc_prove_sharded(st, self.comm.handle, C.c_int(self.use_stages), p(lens) if lens is not None else None,
+                                                       p(rp), p(ch), C.byref(ex)), "mc_prove_sharded")
+        self.exchanges = ex.value
+        if not e.multi:
+            return rp, ch
+        return [(rp[r, : lens[r], 0].copy(), rp[r, : lens[r], 1].copy()) for r in range(n_rounds)], ch
 
 
-_COMMIT_BUFS = {}
-
-
-def sharded_commit(local_commit, sum_affine, world=1, group=None, dist=None, device=None):
-    """KZG commit over (scalars, SRS) sharded across ranks.
-
-    local_commit() -> (xy uint64[12], inf bool): this rank's sub-MSM;  sum_affine(xy [world,12], inf [world]) ->
-    (xy, inf): group sum of the partial commitments.  Returns the full commitment on every rank.  The 104-byte records
-    travel device to device (one pinned staging copy in, one all-gather, one copy out; the buffers are kept)."""
-    import torch
-    xy, inf = local_commit()
-    key = (str(device), world)
-    bufs = _COMMIT_BUFS.get(key)
-    if bufs is None:
-        pin = torch.empty(13, dtype=torch.int64)
-        if device is not None and str(device).startswith("cuda"):
-            pin = pin.pin_memory()
-        bufs = _COMMIT_BUFS[key] = (pin, torch.empty(13, dtype=torch.int64, device=device), torch.empty((world, 13), dtype=torch.int64, device=device))
-    pin, rec, out = bufs
-    h = pin.numpy()
-    h[:12] = np.ascontiguousarray(xy, dtype=np.uint64).view(np.int64)
-    h[12] = 1 if inf else 0
-    rec.copy_(pin, non_blocking=True)
-    _all_gather(dist, group, out, rec, world)                            # C2: 104 bytes per rank
-    g = out.cpu().numpy().view(np.uint64)
-    return sum_affine(np.ascontiguousarray(g[:, :12]), np.ascontiguousarray(g[:, 12].astype(np.uint8)))
+def sharded_commit(points_xy, inf, scalars, comm, table=None, require_equal_len=True):
+    """KZG commit over (scalars, SRS) sharded across the ranks of `comm` (zkhip_kzg_commit_sharded): this rank's shard of the
+    SRS (points_xy int64 [n, 12] + inf uint8 [n], or its shifted-SRS `table`) and of the scalars (int64 [m, 4]) -> the full
+    commitment (xy uint64[12], inf bool) on every rank."""
+    xy = np.empty(12, dtype=np.uint64)
+    oinf = C.c_uint8(0)
+    st = N.lib().zkhip_kzg_commit_sharded(comm.handle, None if table is not None else N.ptr(points_xy), N.ptr(table) if table is not None else None,
+                                          N.ptr(inf), C.c_size_t(inf.shape[0]), N.ptr(scalars), C.c_size_t(scalars.shape[0]),
+                                          C.c_int(1 if require_equal_len else 0), xy.ctypes.data_as(C.c_void_p), C.byref(oinf))
+    comm.check(st, "kzg_commit_sharded")
+    return xy, bool(oinf.value)
 
 
 def hip_sum_affine(xy, inf):

@@ -20,27 +20,72 @@ ADD, MUL = "add", "mul"
 
 
 class Gate:
-    """circuit/src/gate.rs:7-17"""
+    """circuit/src/gate.rs:7-17.  Immutable: a gate is changed by REPLACING it in its layer (`layer.layer[i] = Gate(...)`), which
+    the layer's gate list records -- that is how a circuit edited in place reaches the device copy (GKRProtocol._device_circuit)."""
+
+    __slots__ = ("gate_type", "inputs")
 
     def __init__(self, gate_type, inputs):
         assert gate_type in (ADD, MUL)
-        self.gate_type = gate_type
-        self.inputs = (int(inputs[0]), int(inputs[1]))
+        object.__setattr__(self, "gate_type", gate_type)
+        object.__setattr__(self, "inputs", (int(inputs[0]), int(inputs[1])))
+
+    def __setattr__(self, name, value):
+        raise AttributeError("Gate is immutable: replace it in its layer (layer.layer[i] = Gate(...))")
+
+    __delattr__ = __setattr__
+
+
+class _GateList(list):
+    """A layer's gates: a list that counts its mutations (`version`), so that the arrays and the device copy derived from it are
+    never stale (Python lists carry no version counter of their own; hashing 2^20 gates per proof would cost more than the proof)."""
+
+    version = 0
+
+    def _touch(self):
+        self.version += 1
+
+
+def _counting(name):
+    base = getattr(list, name)
+
+    def method(self, *a, **k):
+        self._touch()
+        return base(self, *a, **k)
+    method.__name__ = name
+    return method
+
+
+for _m in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "extend", "insert", "pop", "remove", "clear", "reverse", "sort"):
+    setattr(_GateList, _m, _counting(_m))
 
 
 class CircuitLayer:
     """circuit/src/circuit.rs:8-22"""
 
     def __init__(self, layer):
-        self.layer = list(layer)
+        self.layer = layer
+
+    @property
+    def layer(self):
+        return self._layer
+
+    @layer.setter
+    def layer(self, gates):
+        self._layer = _GateList(gates)
+        self._arr = None
 
     def _arrays(self):
-        """(gate_type u8, in0 u32, in1 u32) as the C ABI takes them; built once (a layer of 2^19 gates is 1.5 M Python objects)"""
-        if getattr(self, "_arr", None) is None or self._arr[0].shape[0] != len(self.layer):
-            gt = np.array([0 if g.gate_type == ADD else 1 for g in self.layer], dtype=np.uint8)
-            i0 = np.array([g.inputs[0] for g in self.layer], dtype=np.uint32)
-            i1 = np.array([g.inputs[1] for g in self.layer], dtype=np.uint32)
+        """(gate_type u8, in0 u32, in1 u32) as the C ABI takes them; built once per state of the gate list (a layer of 2^19 gates
+        is 1.5 M Python objects)"""
+        if getattr(self, "_arr", None) is None or self._arr_version != self._layer.version:
+            gt = np.array([0 if g.gate_type == ADD else 1 for g in self._layer], dtype=np.uint8)
+            i0 = np.array([g.inputs[0] for g in self._layer], dtype=np.uint32)
+            i1 = np.array([g.inputs[1] for g in self._layer], dtype=np.uint32)
+            for a in (gt, i0, i1):
+                a.setflags(write=False)
             self._arr = (gt, i0, i1)
+            self._arr_version = self._layer.version
         return self._arr
 
 
@@ -49,6 +94,10 @@ class Circuit:
 
     def __init__(self, layers):
         self.layers = list(layers)
+
+    def _stamp(self):
+        """identity and mutation count of every layer's gate list: what a derived device copy is valid for"""
+        return tuple((layer, layer.layer, layer.layer.version) for layer in self.layers)
 
     @staticmethod
     def from_tuples(layers):
@@ -193,7 +242,6 @@ class GKRProtocol:
         from zk_cryptography_amd.composed import MAX_MONO, MultiComposedSumcheckProof
         nl = len(circuit.layers)
         assert len(circuit_evaluation) == nl + 1
-        shape = [len(layer.layer) for layer in circuit.layers]
         tables = [t.contiguous() for t in circuit_evaluation]
         ptrs = (C.c_void_p * (nl + 1))(*[t.data_ptr() for t in tables])
         lens = (C.c_size_t * (nl + 1))(*[t.shape[0] for t in tables])
@@ -207,10 +255,8 @@ class GKRProtocol:
         ctx = N.Context.get(tables[0].device.index)
         p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
         chal = np.zeros((nl, stride, 4), dtype=np.uint64)
-        # the circuit lives on the device: gate arrays and their groupings are validated, built and uploaded once per Circuit
-        dev = getattr(circuit, "_device", None)
-        if dev is None or dev.shape != shape or dev.ctx is not ctx:
-            dev = circuit._device = _DeviceCircuit(ctx, circuit, shape)
+        # the circuit lives on the device: gate arrays and their groupings are validated, built and uploaded once per Circuit content
+        dev = GKRProtocol._device_circuit(circuit, ctx)
         st = N.lib().zkhip_gkr_prove_circuit(dev.handle, ptrs, lens, p(sums), p(n_rounds), p(rp_lens), p(rps), p(wb), p(wc), p(w0), p(chal))
         N.check(st, "gkr_prove: every layer must hold a power-of-two number of values, 2^l gates in layer l")
         # the arrays above belong to this proof alone: the per-layer proofs are views into them (round polynomials are
@@ -221,81 +267,58 @@ class GKRProtocol:
         return proof
 
     @staticmethod
-    def prove_sharded(circuit, circuit_evaluation, world=1, rank=0, group=None, dist=None, use_stages=None):
+    def _device_circuit(circuit, ctx):
+        """The circuit resident in HBM (zkhip_circuit): gate arrays and their groupings validated, built and uploaded once per
+        Circuit STATE -- gates are immutable and every layer's gate list counts its mutations, so a gate replaced in place proves the edited circuit
+        (the reference reads &Circuit on every call, gkr/src/protocol.rs:21-25).  The key holds the layer objects themselves
+        (identity, not id(): no address reuse) and their gate lists' mutation counters."""
+        shape = [len(layer.layer) for layer in circuit.layers]
+        stamp = circuit._stamp()
+        dev = getattr(circuit, "_device", None)
+        if dev is None or dev.shape != shape or dev.ctx is not ctx or len(dev.stamp) != len(stamp) or \
+                any(a[0] is not b[0] or a[1] is not b[1] or a[2] != b[2] for a, b in zip(dev.stamp, stamp)):
+            dev = circuit._device = _DeviceCircuit(ctx, circuit, shape)
+            dev.stamp = stamp
+        return dev
+
+    @staticmethod
+    def prove_sharded(circuit, circuit_evaluation, world=1, rank=0, group=None, dist=None, use_stages=None, comm=None):
         """GKRProtocol::prove (protocol.rs:21-117) with every layer's tables and sumcheck SHARDED over `world` ranks (SURVEY 8e,
-        "GKR tables"; BASELINE configs[3]: "evals sharded across 8").  Rank g builds ONLY rows j * world + g of the layer's seven
-        linear-size sumcheck tables and of the layer's values (zkhip_gkr_layer_tables_sharded: w_len / world entries each, 1 / world
-        of the table-building work and memory), and the rounds over b and over c run on those shards with one record of partial sums
-        all-gathered per round (distributed.ShardedComposedSumcheck over zkhip_mc_*; the transcript is replicated).  What the rows
-        gather from by wire index -- the layer's values, the gate weights, eq(u) -- stays whole on every rank (random wiring reads
-        any of them).  Layers narrower than 2 * world values run unsharded on every rank.  Returns the proof GKRProtocol.prove
-        returns, bit for bit, on every rank; the number of collectives is left in proof._exchanges.  Every layer claim is two
-        terms of two tables (+ an additive table), so the sessions take TWO rounds per exchange (distributed.ShardedComposedSumcheck,
-        use_stages: default on for world > 1)."""
-        import torch
+        "GKR tables"; BASELINE configs[3]: "evals sharded across 8") through the single C-ABI entry point zkhip_gkr_prove_sharded:
+        rank g builds ONLY rows j * world + g of the layer's seven linear-size sumcheck tables and of the layer's values, and the
+        rounds over b and over c run on those shards, TWO rounds per exchange (use_stages: default on for world > 1), every
+        exchange stream-ordered inside the library.  What the rows gather from by wire index -- the layer's values, the gate
+        weights, eq(u) -- stays whole on every rank (random wiring reads any of them).  Layers narrower than 2 * world values run
+        unsharded on every rank.  Returns the proof GKRProtocol.prove returns, bit for bit, on every rank; the number of
+        collectives is left in proof._exchanges."""
         from zk_cryptography_amd import distributed as D
-        from zk_cryptography_amd.composed import MultiComposedSumcheckProof, SparseUnivariatePolynomial
+        from zk_cryptography_amd.composed import MAX_MONO, MultiComposedSumcheckProof
         nl = len(circuit.layers)
         assert len(circuit_evaluation) == nl + 1
-        shape = [len(layer.layer) for layer in circuit.layers]
         tables = [t.contiguous() for t in circuit_evaluation]
         ctx = N.Context.get(tables[0].device.index)
-        dev = getattr(circuit, "_device", None)
-        if dev is None or dev.shape != shape or dev.ctx is not ctx:
-            dev = circuit._device = _DeviceCircuit(ctx, circuit, shape)
-        transcript = FiatShamirTranscript()
-        pad = torch.zeros((1, 4), dtype=torch.int64, device=tables[0].device)
-        w_0_mle = Multilinear(torch.cat([tables[0], pad]))
-        proof = GKRProof([], [], [], w_0_mle)
-        proof._challenges, proof._exchanges = [], 0
-        transcript.commit(w_0_mle.to_bytes())
-        n_r = transcript.evaluate_n_challenge_into_field(w_0_mle.n_vars)
-        claimed = w_0_mle.evaluation(n_r)
-        alpha, beta = Fr.from_int(1), Fr.from_int(0)
-        r_b, r_c = np.ascontiguousarray(n_r), None
+        dev = GKRProtocol._device_circuit(circuit, ctx)
+        if comm is None:
+            comm = D.Comm.get(ctx, world, rank, dist, group)
+        ptrs = (C.c_void_p * (nl + 1))(*[t.data_ptr() for t in tables])
+        lens = (C.c_size_t * (nl + 1))(*[t.shape[0] for t in tables])
+        stride = 2 * nl
+        sums = np.zeros((nl, 4), dtype=np.uint64)
+        n_rounds = np.zeros(nl, dtype=np.uint32)
+        rp_lens = np.zeros((nl, stride), dtype=np.uint32)
+        rps = np.zeros((nl, stride, MAX_MONO, 2, 4), dtype=np.uint64)
+        wb, wc = np.zeros((nl, 4), dtype=np.uint64), np.zeros((nl, 4), dtype=np.uint64)
+        w0 = np.zeros((2, 4), dtype=np.uint64)
+        chal = np.zeros((nl, stride, 4), dtype=np.uint64)
+        ex = C.c_uint32(0)
         p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
-
-        for li in range(1, nl + 1):
-            layer, V = li - 1, tables[li]
-            w_len = V.shape[0]
-            s_vars = w_len.bit_length() - 1
-            w = world if w_len >= 2 * world else 1                    # narrow layers: every rank proves them whole
-            rk = rank if w > 1 else 0
-            grp, dst = (group, dist) if w > 1 else (None, None)
-            out = [torch.empty((w_len // w, 4), dtype=torch.int64, device=V.device) for _ in range(4)]    # this rank's rows only
-            ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in out])
-            wu = np.zeros(4, dtype=np.uint64)
-            rc_p = p(np.ascontiguousarray(r_c)) if r_c is not None else None
-            rb_a, al_a, be_a = np.ascontiguousarray(r_b), np.ascontiguousarray(alpha), np.ascontiguousarray(beta)
-            N.check(N.lib().zkhip_gkr_layer_tables_sharded(dev.handle, C.c_uint32(layer), N.ptr(V), C.c_size_t(w_len), p(rb_a), rc_p, p(al_a), p(be_a),
-                                                           C.c_int(0), C.c_uint32(w), C.c_uint32(rk), ptrs, None), "gkr_layer_tables")
-            ha0, ha1, hm = out[0], out[1], out[2]
-            v_sh = out[3] if w > 1 else V                             # rows j * w + rank of the layer's values
-            eng = D.HipComposedEngine([[ha0, v_sh], [hm, v_sh]], w, multi=True, claimed_sum=claimed, ctx=ctx, lin=[ha1, None])
-            sh = D.ShardedComposedSumcheck(eng, w, grp, dst, use_stages=(use_stages if w > 1 or use_stages is not None else False))
-            sh.prove(collect=False)                                   # the rounds over b; recorded on the device
-            proof._exchanges += sh.exchanges
-            out2 = [torch.empty((w_len // w, 4), dtype=torch.int64, device=V.device) for _ in range(4)]
-            ptrs2 = (C.c_void_p * 4)(*[t.data_ptr() for t in out2])
-            N.check(N.lib().zkhip_gkr_layer_tables_sharded(dev.handle, C.c_uint32(layer), N.ptr(V), C.c_size_t(w_len), p(rb_a), rc_p, p(al_a), p(be_a),
-                                                           C.c_int(1), C.c_uint32(w), C.c_uint32(rk), ptrs2, p(wu)), "gkr_layer_tables")
-            eng = D.HipComposedEngine([[out2[0], out2[1]], [out2[2], out2[3]]], w, multi=True, ctx=ctx, cont=True, out_base=s_vars)
-            sh = D.ShardedComposedSumcheck(eng, w, grp, dst, use_stages=(use_stages if w > 1 or use_stages is not None else False))
-            rps, ch = sh.prove(finish_rounds=2 * s_vars)              # the rounds over c; delivers all 2 s rounds
-            proof._exchanges += sh.exchanges
-            sumcheck_proof = MultiComposedSumcheckProof([SparseUnivariatePolynomial(c_, p_) for c_, p_ in rps], np.array(claimed, copy=True))
-            transcript.commit(sumcheck_proof.to_bytes())
-            proof.sumcheck_proofs.append(sumcheck_proof)
-            proof._challenges.append(ch.copy())
-            b, c = ch[:s_vars], ch[s_vars:]
-            eval_wb = wu
-            eval_wc = Multilinear(V).evaluation(c)
-            proof.wb_s.append(eval_wb.copy())
-            proof.wc_s.append(eval_wc)
-            alpha = transcript.evaluate_challenge_into_field()
-            beta = transcript.evaluate_challenge_into_field()
-            claimed = _fadd(_fmul(alpha, eval_wb), _fmul(beta, eval_wc))
-            r_b, r_c = b, c
+        st = N.lib().zkhip_gkr_prove_sharded(dev.handle, comm.handle, ptrs, lens, C.c_int(-1 if use_stages is None else int(bool(use_stages))),
+                                             p(sums), p(n_rounds), p(rp_lens), p(rps), p(wb), p(wc), p(w0), p(chal), C.byref(ex))
+        comm.check(st, "gkr_prove_sharded: every layer must hold a power-of-two number of values, 2^l gates in layer l")
+        proofs = [MultiComposedSumcheckProof.from_packed(rps[k, : n_rounds[k]], rp_lens[k, : n_rounds[k]], sums[k]) for k in range(nl)]
+        proof = GKRProof(proofs, list(wb), list(wc), Multilinear(w0))
+        proof._challenges = [chal[k, : n_rounds[k]] for k in range(nl)]
+        proof._exchanges = ex.value
         return proof
 
     @staticmethod

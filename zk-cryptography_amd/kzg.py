@@ -98,10 +98,35 @@ class TrustedSetup:
         p, i = self.powers_of_tau_in_g1, self.inf
         return (p.data_ptr(), p.shape[0], p._version, i.data_ptr(), i._version)
 
+    def _fingerprint(self):
+        """Content check for what the stamp cannot see -- writes through raw pointers (a kernel filling the tensors via data_ptr())
+        and a new tensor that landed on the same address with the same shape and version: the first and last two points and their
+        infinity flags (one small device->host copy, ~20 us against a >= 1 ms commitment)."""
+        import torch
+        p, i = self.powers_of_tau_in_g1, self.inf
+        n = p.shape[0]
+        if n == 0:
+            return b""
+        idx = sorted({0, min(1, n - 1), max(n - 2, 0), n - 1})
+        sel = torch.tensor(idx, device=p.device)
+        return p.index_select(0, sel).cpu().numpy().tobytes() + i.index_select(0, sel).cpu().numpy().tobytes()
+
+    def invalidate(self):
+        """Drops the shifted table and the folded levels (call after writing the SRS through raw pointers; commitments in flight
+        keep the table they were started with alive through their PendingCommitment)."""
+        self._table = self._folded = None
+        self._cache_stamp = self._cache_print = None
+
     def _check_caches(self):
-        if getattr(self, "_cache_stamp", None) != self._stamp():
+        have = getattr(self, "_table", None) is not None or getattr(self, "_folded", None) is not None
+        if getattr(self, "_cache_stamp", None) != self._stamp() or (have and getattr(self, "_cache_print", None) != self._fingerprint()):
             self._table = self._folded = None
             self._cache_stamp = self._stamp()
+            self._cache_print = None
+
+    def _caches_built(self):
+        if getattr(self, "_cache_print", None) is None:
+            self._cache_print = self._fingerprint()
 
     @property
     def table(self):
@@ -123,6 +148,7 @@ class TrustedSetup:
             N.check(N.lib().zkhip_srs_precompute(ctx.handle, N.ptr(self.powers_of_tau_in_g1), N.ptr(self.inf), C.c_size_t(n),
                                                  N.ptr(table)), "srs_precompute")
             self._table = table
+            self._caches_built()
         return self
 
     def folded(self):
@@ -136,6 +162,7 @@ class TrustedSetup:
             N.check(N.lib().zkhip_srs_fold_levels(ctx.handle, N.ptr(self.powers_of_tau_in_g1), N.ptr(self.inf), C.c_size_t(n),
                                                   N.ptr(xy), N.ptr(inf)), "srs_fold_levels")
             self._folded = (xy, inf)
+            self._caches_built()
         return self._folded
 
     @staticmethod
