@@ -65,6 +65,7 @@ struct HostComm {
     const CB* cb;
     uint32_t w;
     uint32_t world() const { return w; }
+    bool passthrough() const { return w == 1; }
     int all_gather(const void* send, void* recv, size_t bytes) { return cb->all_gather(send, recv, bytes); }
 };
 struct ScEngine : HostBuffers {

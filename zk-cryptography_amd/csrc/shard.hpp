@@ -31,6 +31,7 @@ struct zkhip_comm {
         return solo;
     }
     uint32_t world() const { return world_; }
+    bool passthrough() const { return world_ == 1 && !nccl && !fn; }
     int all_gather(const void* d_send, void* d_recv, size_t bytes);    // shard.hip
     uint64_t* buffer(int id, size_t elems) {
         const size_t need = (elems ? elems : 1) * 32;

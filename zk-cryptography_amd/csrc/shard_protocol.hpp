@@ -27,11 +27,12 @@ enum : int { OK = 0 };
         if (_rc != 0) return _rc;    \
     } while (0)
 
-// one exchange: every rank's `elems` field elements in rank order.  world == 1: the send buffer IS the gathered record.
+// one exchange: every rank's `elems` field elements in rank order.  One rank without a transport (comm.passthrough()): the send
+// buffer IS the gathered record; a one-rank comm WITH a transport (a one-rank RCCL communicator) is exchanged through it like any other.
 template <class E, class C>
 static inline int gather(E& e, C& comm, const uint64_t* send, size_t elems, int recv_id, const uint64_t** out, uint32_t* exchanges) {
     ++*exchanges;
-    if (comm.world() == 1) { *out = send; return OK; }
+    if (comm.passthrough()) { *out = send; return OK; }
     uint64_t* recv = e.buffer(recv_id, elems * comm.world());
     if (!recv) return e.nomem();
     ZKSHARD_TRY(comm.all_gather(send, recv, elems * 32));
