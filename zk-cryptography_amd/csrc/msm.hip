@@ -36,21 +36,6 @@ using namespace zk;
 //                  windows of the two widths ceil(256 / w) and one less that add up to exactly 256 -- so no window of any problem is
 //                  sparse (a 3-bit top window put an eighth of all points into each of 4 buckets: the heavy-bucket passes, 0.6 ms) and
 //                  all problems share ONE pass of every kernel (MultilinearKZG::open at 2^20: twenty problems, ~0.45 M buckets).
-struct MsmGeometry {
-    MsmPlan pl = {};                 // totals; the device pointers are set by msm_enqueue
-    std::vector<MsmWin> wins;
-    std::vector<MsmSet> sets;
-    std::vector<uint16_t> part_set, rcwg_set, termwg_set;
-    std::vector<uint32_t> set_exp;   // weight 2^set_exp of a set's total (the first bit of its digit window; 0 with the table)
-    std::vector<uint32_t> prob_set_first;   // problem j owns the sets [prob_set_first[j], prob_set_first[j+1])
-    uint16_t win_first[MSM_MAX_PROBLEMS + 1] = {};
-    size_t items = 0;                // (point, window) pairs of the pass
-    uint32_t heavy_min = 32;
-};
-constexpr uint32_t MSM_TABLE_C = 20;
-constexpr uint32_t MSM_TABLE_WINDOWS = (256 + MSM_TABLE_C - 1) / MSM_TABLE_C;   // 13: twelve full 20-bit windows and a 15-bit top window
-static int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t table_stride, int delta, MsmGeometry& g);
-static int msm_build_geometry(const MsmProblems& pr, bool shared, size_t table_stride, MsmGeometry& g);
 // the geometries of the last few shapes (an opening builds its twenty-problem geometry twice per call otherwise: ~0.1 ms of host time each)
 static int msm_geometry(const MsmProblems& pr, bool shared, size_t table_stride, std::shared_ptr<const MsmGeometry>* out) {
     struct Entry { MsmProblems pr; bool shared; size_t stride; std::shared_ptr<const MsmGeometry> geo; };
@@ -69,108 +54,6 @@ static int msm_geometry(const MsmProblems& pr, bool shared, size_t table_stride,
     *out = g;
     return ZKHIP_OK;
 }
-static int msm_build_geometry(const MsmProblems& pr, bool shared, size_t table_stride, MsmGeometry& g) {
-    // widths log2(n_j) - delta, delta = the smallest from 1 on whose partitions fit the sort (MultilinearKZG::open: 3-4 at 2^20, where the
-    // pass is throughput bound and the width hardly matters -- 4.92 / 4.97 / 5.36 ms at delta 4 / 3 / 5 -- and 1 below 2^19, where the accumulate
-    // pass is as long as its longest lists: 2^16 1.66 / 1.74 / 1.96 / 2.77 ms at delta 1 / 2 / 3 / 4)
-    int delta = 1;
-    if (const char* e = std::getenv("ZKHIP_MSM_BATCH_DELTA")) {   // tuning aid (tools/perf_open.py): width = log2(n_j) - delta
-        const int v = std::atoi(e);
-        if (v >= 0 && v <= 8) delta = v;
-    }
-    int rc = ZKHIP_ERR_SHAPE;
-    // narrower windows until the sort's partitions suffice (at 8 bits -- the floor -- 64 problems have 2048)
-    for (; delta <= 24 && rc == ZKHIP_ERR_SHAPE; ++delta) rc = msm_build_geometry_at(pr, shared, table_stride, delta, g);
-    return rc;
-}
-static int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t table_stride, int delta, MsmGeometry& g) {
-    g = MsmGeometry();
-    uint32_t max_chain = 1, rc_max = 1;
-    g.prob_set_first.push_back(0);
-    auto add_set = [&](uint32_t c, uint32_t exp) {
-        MsmSet s = {};
-        const uint32_t part_bits = c - 1 > 8 ? c - 1 - 8 : 0;
-        s.bucket_base = g.pl.n_buckets;
-        s.part_base = g.pl.n_parts;
-        s.bits = c | (part_bits << 8);
-        s.term_base = g.pl.n_terms;
-        s.rc_base = g.pl.n_rc;
-        s.rcwg_base = g.pl.n_rcwg;
-        s.termwg_base = g.pl.n_termwg;
-        const MsmSetShape sh = msm_set_shape_c(c);
-        const uint32_t n_bits = sh.n_bits, C = sh.C, R = sh.R;
-        const uint32_t idx = (uint32_t)g.sets.size();
-        for (uint32_t p = 0; p < (1u << part_bits); ++p) g.part_set.push_back((uint16_t)idx);
-        for (uint32_t b = 0; b < sh.row_wgs + sh.col_wgs; ++b) g.rcwg_set.push_back((uint16_t)idx);
-        for (uint32_t t = 0; t < sh.term_wgs; ++t) g.termwg_set.push_back((uint16_t)idx);
-        g.pl.n_buckets += 1u << (c - 1);
-        g.pl.n_parts += 1u << part_bits;
-        g.pl.n_terms += 1 + n_bits;
-        g.pl.n_rc += 2 * R + C;
-        g.pl.n_rcwg += sh.row_wgs + sh.col_wgs;
-        g.pl.n_termwg += sh.term_wgs;
-        rc_max = std::max(rc_max, std::max(R, C));
-        g.sets.push_back(s);
-        g.set_exp.push_back(exp);
-        return s;
-    };
-    auto add_win = [&](const MsmSet& s, uint32_t c, uint32_t entry_off) {
-        MsmWin w = {};
-        w.part_base = s.part_base;
-        w.entry_off = entry_off;
-        w.bits = c | (s.bits & 0xff00u);
-        g.wins.push_back(w);
-    };
-    for (uint32_t j = 0; j < pr.n; ++j) {
-        const size_t nj = pr.off[j + 1] - pr.off[j];
-        g.win_first[j] = (uint16_t)g.wins.size();
-        uint32_t lg = 0;
-        while (((size_t)1 << lg) < nj) ++lg;
-        if (shared) {
-            const MsmSet s = add_set(MSM_TABLE_C, 0);
-            for (uint32_t w = 0; w < MSM_TABLE_WINDOWS; ++w) add_win(s, MSM_TABLE_C, (uint32_t)(w * table_stride));
-            g.items += nj * MSM_TABLE_WINDOWS;
-            max_chain = std::max<uint32_t>(max_chain, (uint32_t)((nj * MSM_TABLE_WINDOWS + (1u << (MSM_TABLE_C - 1)) - 1) >> (MSM_TABLE_C - 1)));
-        } else {
-            uint32_t w, hi, n_hi;
-            if (pr.n == 1) {
-                uint32_t c = lg >= 13 ? 16 : lg >= 10 ? 12 : 8;
-                if (const char* e = std::getenv("ZKHIP_MSM_C")) {   // tuning aid (tools/perf_msm.py); any 4 <= c <= 16 is correct
-                    const int v = std::atoi(e);
-                    if (v >= 4 && v <= 16) c = (uint32_t)v;
-                }
-                w = (256 + c - 1) / c; hi = c; n_hi = w;
-            } else {
-                const uint32_t c = (uint32_t)std::min(16, std::max(8, (int)lg - delta));   // >= 8 bits: at most 32 windows per problem, 2048 for 64 problems
-                w = (256 + c - 1) / c;
-                hi = (256 + w - 1) / w;
-                n_hi = 256 - w * (hi - 1);      // n_hi windows of hi bits (the low ones), the rest of hi - 1: exactly 256 bits
-            }
-            uint32_t bit = 0;
-            for (uint32_t v = 0; v < w; ++v) {
-                const uint32_t c = v < n_hi ? hi : hi - 1;
-                const MsmSet s = add_set(c, bit);
-                add_win(s, c, 0);
-                bit += c;
-            }
-            const uint32_t c_lo = n_hi < w ? hi - 1 : hi;
-            g.items += nj * w;
-            max_chain = std::max<uint32_t>(max_chain, (uint32_t)((nj + (1u << (c_lo - 1)) - 1) >> (c_lo - 1)));
-        }
-        g.prob_set_first.push_back((uint32_t)g.sets.size());
-        if (g.wins.size() > (size_t)MSM_MAX_WINS) return ZKHIP_ERR_SHAPE;
-    }
-    g.win_first[pr.n] = (uint16_t)g.wins.size();
-    g.pl.n_sets = (uint32_t)g.sets.size();
-    g.pl.n_wins = (uint32_t)g.wins.size();
-    g.pl.shared = shared ? 1u : 0u;
-    if (g.pl.n_parts > (uint32_t)SORT_MAX_PARTS || g.pl.n_sets > 65535u) return ZKHIP_ERR_SHAPE;
-    // a bucket holding more than heavy_min points (four average lists of the densest set) is summed by whole workgroups
-    g.heavy_min = std::max<uint32_t>(32, 4 * max_chain);
-    if (rc_max > MSM_LINE_MAX) return ZKHIP_ERR_SHAPE;      // a row / column is summed by one wave
-    return ZKHIP_OK;
-}
-
 // d_table (nullable): shifted-SRS table in the internal layout, entry w * table_stride + i = 2^(20 w) * point i; then
 // d_points_xy is not read and there is exactly one problem.
 // A commit in two halves, so that a caller with several commits in a row (MultilinearKZG::open) can run the host epilogue

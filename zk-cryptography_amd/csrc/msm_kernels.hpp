@@ -26,43 +26,11 @@
 #pragma once
 #include "g1.hpp"
 #include "g1u.hpp"
+#include "msm_geometry.hpp"
 
 namespace zk {
 
 constexpr int MSM_BLOCK = 256;
-constexpr int MSM_SEG_LOG = 3;              // L = 8 buckets per segment (L = 4 measured again with the row / column term sums: segment pass 0.30 instead of 0.33 ms, term sums 0.74 instead of 0.47 ms)
-constexpr int MSM_SEG = 1 << MSM_SEG_LOG;
-constexpr int MSM_MAX_WINS = 2048;          // digit windows of all problems of one pass: 64 problems x 32 windows of 8 bits, the narrowest a batch uses (the sort kernels keep the table in LDS: 32 KiB)
-
-// Geometry of one pass over one or several problems (built on the host: msm_build_geometry, msm.hip).  A problem's 256 scalar bits
-// are cut into DIGIT WINDOWS of its own widths -- two widths one bit apart, so that they add up to exactly 256 and no window is sparse
-// (a 255-bit scalar leaves the top window one spare bit: its digit never carries out) -- and every window owns a BUCKET SET of
-// 2^(bits-1) buckets (bucket i holds digit magnitude i+1).  With the shifted-SRS table all windows of the one problem share one set.
-struct MsmWin {
-    uint32_t part_base;   // first sort partition of its bucket set
-    uint32_t entry_off;   // shifted-SRS table: w * stride, added to the point index (0 otherwise)
-    uint32_t bits;        // byte 0: window width c (digits in [-2^(c-1), 2^(c-1)]); byte 1: part_bits of its bucket set
-    uint32_t pad;
-};
-struct MsmSet {
-    uint32_t bucket_base; // first bucket, a multiple of MSM_SEG
-    uint32_t part_base;   // first sort partition: a partition holds the 2^(c-1-part_bits) <= 256 buckets with the same HIGH part_bits bits
-    uint32_t bits;        //   of the index.  byte 0: c, byte 1: part_bits
-    uint32_t term_base;   // its c - 3 (set, term) points start here
-    uint32_t rc_base;     // its row / column sums (2 R + C points) start here
-    uint32_t rcwg_base;   // its first workgroup in msm_rowcol_kernel's grid
-    uint32_t termwg_base; // ... and in msm_rowcol_terms_kernel's
-};
-struct MsmPlan {
-    uint32_t n_sets, n_buckets, n_parts, n_terms, n_rc, n_rcwg, n_termwg;
-    uint32_t n_wins;      // digit windows in all
-    uint32_t shared;      // 1: shifted-SRS table, one bucket set
-    const MsmWin* wins;   // device tables
-    const MsmSet* sets;
-    const uint16_t* part_set;   // partition -> bucket set
-    const uint16_t* rcwg_set;   // msm_rowcol_kernel workgroup -> bucket set
-    const uint16_t* termwg_set; // msm_rowcol_terms_kernel workgroup -> bucket set
-};
 __device__ __forceinline__ uint32_t msm_set_c(const MsmSet& s) { return s.bits & 0xffu; }
 __device__ __forceinline__ uint32_t msm_set_part_bits(const MsmSet& s) { return (s.bits >> 8) & 0xffu; }
 
@@ -125,16 +93,7 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_order_scatter_kernel(con
 // (sort_bases), and the same tile walk scatters 8-byte items (sort_scatter).  Level 2 runs one workgroup per
 // partition: the remaining <= 8 bucket bits are resolved in LDS, which also yields every bucket's count and offset.
 constexpr int SORT_TILE = 2048;          // scalars per workgroup tile (8 per lane; 1024: count -20 us, bases +24; 4096: count and scatter +40 us each)
-constexpr int SORT_MAX_PARTS = 4096;
 
-// Batched commits (several independent (points, scalars) problems laid end to end, e.g. the rounds of
-// MultilinearKZG::open): problem j owns the entries [off[j], off[j+1]) and the digit windows [win_first[j], win_first[j+1]).
-constexpr int MSM_MAX_PROBLEMS = 64;
-struct MsmProblems {
-    uint32_t n;
-    uint32_t off[MSM_MAX_PROBLEMS + 1];
-    uint16_t win_first[MSM_MAX_PROBLEMS + 1];
-};
 // the problems' ranges and the digit windows in LDS (read per scalar / per (scalar, window) by both passes over the scalars; the
 // kernel argument itself, indexed by a value that differs from lane to lane, is read through a loop over the lanes' values)
 struct MsmSortTables {
@@ -557,25 +516,6 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_segment_kernel(const uin
 // A lane first adds MSM_LINE_Q values of its line one after the other, then the lanes of the line form the tree: a tree level costs a
 // whole wave one addition however few lanes still take part, so a 64-value line as 16 lanes x 4 values is 3 + 4 additions for FOUR lines
 // per wave instead of 6 for one (the row / column pass of a 2^20-point commit: 768 waves, each alone on a SIMD, instead of 3072).
-constexpr uint32_t MSM_LINE_Q = 4;
-constexpr uint32_t MSM_LINE_MAX = 64 * MSM_LINE_Q;     // the longest line a wave sums: R = C = 256, the 2^19-bucket set of the shifted-SRS table
-__host__ __device__ __forceinline__ uint32_t msm_line_q(uint32_t count) { return count >= 4 * MSM_LINE_Q ? MSM_LINE_Q : 1; }
-constexpr uint32_t MSM_TERMS_PER_WG = 4;     // (set, term) trees per wave of msm_rowcol_terms_kernel while a tree fits 16 lanes x 4 values
-struct MsmSetShape { uint32_t n_bits, lo_bits, C, R, row_lines, col_lines, row_wgs, col_wgs, term_wgs; };
-__host__ __device__ __forceinline__ MsmSetShape msm_set_shape_c(uint32_t c) {
-    MsmSetShape sh;
-    sh.n_bits = c - 1 - MSM_SEG_LOG;
-    sh.lo_bits = sh.n_bits / 2;
-    sh.C = 1u << sh.lo_bits;
-    sh.R = (1u << sh.n_bits) >> sh.lo_bits;
-    sh.row_lines = sh.C <= 64 ? 64 / (sh.C / msm_line_q(sh.C)) : 1;          // rows (C values each) per wave; a longer line has a wave to itself
-    sh.col_lines = sh.R <= 64 ? 64 / (sh.R / msm_line_q(sh.R)) : 1;          // columns (R values each) per wave
-    sh.row_wgs = (2 * sh.R + sh.row_lines - 1) / sh.row_lines;   // the R rows of S, then the R rows of A
-    sh.col_wgs = (sh.C + sh.col_lines - 1) / sh.col_lines;
-    // (set, term) trees: <= max(R, C) values each; four per workgroup while a tree fits 16 lanes x 4 values, else one
-    sh.term_wgs = (sh.R <= 64 && sh.C <= 64) ? (1 + sh.n_bits + MSM_TERMS_PER_WG - 1) / MSM_TERMS_PER_WG : 1 + sh.n_bits;
-    return sh;
-}
 static __global__ __launch_bounds__(64) void msm_rowcol_kernel(const uint32_t* __restrict__ seg_s, const uint32_t* __restrict__ seg_a,
                                                              MsmPlan pl, uint32_t* __restrict__ rc) {
     __builtin_amdgcn_s_setprio(2);

@@ -1251,6 +1251,12 @@ static void sc_release(zkhip_sc_state* st) {
         c->sc_lent = false;
     } else if (!c->sc_small) {           // keep this set for the next prove instead of freeing it
         c->sc_small = st->small; c->sc_stage = st->stage_buf; c->sc_stage_cap = st->stage_parts_cap;
+    } else if (!c->sc_lent && st->stage_parts_cap > c->sc_stage_cap) {
+        // the cached set is too small for shards of this size (a steady stream of them would allocate and free per prove): this larger
+        // set replaces it.  (The caller has waited for the stream: finish / abort synchronise before they release.)
+        hipFree(c->sc_small);
+        if (c->sc_stage) hipFree(c->sc_stage);
+        c->sc_small = st->small; c->sc_stage = st->stage_buf; c->sc_stage_cap = st->stage_parts_cap;
     } else {
         hipFree(st->small);
         if (st->stage_buf) hipFree(st->stage_buf);
