@@ -1,0 +1,182 @@
+// ubench_fine.hip -- variants of fine_sums_kernel (sums of every run of 256 entries of a 2^24-entry table: the prover's first streaming
+// pass, 32 n bytes) WITH its real arithmetic, against the pure-load model of tools/ubench_rows.hip ("pieces"): which access order, load
+// flavour and work per wave come closest to the loads alone.  Every variant's sums are checked against the baseline's.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I zk-cryptography_amd/csrc -o tools/ubench_fine tools/ubench_fine.hip
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "fp.hpp"
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+using namespace zk;
+
+template <bool NT>
+__device__ __forceinline__ Fr ld(const uint64_t* __restrict__ base, size_t idx) {
+    if (!NT) return load_fr(base, idx);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* p = reinterpret_cast<const u32x4*>(base + 4 * idx);
+    const u32x4 a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 1);
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+
+// MAP 0: a wave owns two ADJACENT runs (the shipped kernel); 1: runs w and w + n_chunks / 2; 2: wave index permuted by a stride of 2^log_s
+// (consecutive waves n / 2^log_s entries apart), two adjacent runs
+template <bool NT, int MAP>
+__global__ __launch_bounds__(256) void k_fine2(const uint64_t* __restrict__ in, size_t n_chunks, uint32_t log_s, uint64_t* __restrict__ sums) {
+    const uint32_t lane = threadIdx.x & 63;
+    size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t n_w = n_chunks / 2;
+    if (w >= n_w) return;
+    size_t c0, c1;
+    if (MAP == 1) { c0 = w; c1 = w + n_w; }
+    else {
+        if (MAP == 2) { const size_t s = (size_t)1 << log_s; w = (w & (s - 1)) * (n_w >> log_s) + (w >> log_s); }
+        c0 = 2 * w; c1 = c0 + 1;
+    }
+    const uint64_t* b0 = in + 4 * (c0 * 256);
+    const uint64_t* b1 = in + 4 * (c1 * 256);
+    Fr v[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = ld<NT>(b0, lane + 64 * u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[4 + u] = ld<NT>(b1, lane + 64 * u);
+    Fr a = (v[0] + v[1]) + (v[2] + v[3]);
+    Fr b = (v[4] + v[5]) + (v[6] + v[7]);
+    wave_reduce_fr2(a, b);
+    if (lane == 0) { store_fr(sums, c0, a); store_fr(sums, c1, b); }
+}
+// four runs per wave (16 loads of 2 KiB in flight): adjacent (MAP 0) or n / 4 entries apart (MAP 1)
+template <bool NT, int MAP>
+__global__ __launch_bounds__(256) void k_fine4(const uint64_t* __restrict__ in, size_t n_chunks, uint64_t* __restrict__ sums) {
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_w = n_chunks / 4;
+    if (w >= n_w) return;
+    size_t c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = MAP == 1 ? w + q * n_w : 4 * w + q;
+    Fr v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[4 * q + u] = ld<NT>(in + 4 * (c[q] * 256), lane + 64 * u);
+    Fr s[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] = (v[4 * q] + v[4 * q + 1]) + (v[4 * q + 2] + v[4 * q + 3]);
+    wave_reduce_fr2(s[0], s[1]);
+    wave_reduce_fr2(s[2], s[3]);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_fr(sums, c[q], s[q]);
+    }
+}
+// loads only (the model the arithmetic is measured against): two adjacent runs per wave
+template <bool NT>
+__global__ __launch_bounds__(256) void k_loads(const uint64_t* __restrict__ in, size_t n_chunks, uint64_t* __restrict__ sums) {
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_chunks / 2) return;
+    const uint64_t* b0 = in + 4 * (2 * w * 256);
+    Fr v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld<NT>(b0, lane + 64 * u);
+    uint32_t x = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x ^= v[u].l[i];
+    if (x == 0x12345678u) sums[w] = x;
+}
+
+// Infinity-cache probe: the same 16 KiB pieces, waves walking the table upwards (dir 0) or downwards (dir 1), over the first `frac_num / 8` of it
+template <bool NT>
+__global__ __launch_bounds__(256) void k_sweep(const uint64_t* __restrict__ in, size_t n_w, uint32_t dir, uint64_t* __restrict__ sums) {
+    const uint32_t lane = threadIdx.x & 63;
+    size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_w) return;
+    if (dir) w = n_w - 1 - w;
+    const uint64_t* b0 = in + 4 * (2 * w * 256);
+    Fr v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld<NT>(b0, lane + 64 * u);
+    uint32_t x = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x ^= v[u].l[i];
+    if (x == 0x12345678u) sums[w] = x;
+}
+
+int main() {
+    const size_t n = (size_t)1 << 24, n_chunks = n / 256;
+    uint64_t *d_in, *d_ref, *d_out;
+    CHK(hipMalloc(&d_in, n * 32));
+    CHK(hipMalloc(&d_ref, n_chunks * 32));
+    CHK(hipMalloc(&d_out, n_chunks * 32));
+    {
+        std::vector<uint64_t> h(n * 4);
+        uint64_t s = 88172645463325252ULL;
+        for (size_t i = 0; i < n * 4; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = (i & 3) == 3 ? (s >> 3) : s; }   // < 2^253 < r
+        CHK(hipMemcpy(d_in, h.data(), n * 32, hipMemcpyHostToDevice));
+    }
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0));
+    CHK(hipEventCreate(&e1));
+    const int reps = 20;
+    std::vector<uint64_t> ref(n_chunks * 4), got(n_chunks * 4);
+    bool have_ref = false;
+    auto run = [&](const char* name, auto launch, bool check) -> int {
+        CHK(hipMemset(d_out, 0, n_chunks * 32));
+        launch(); launch();
+        CHK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) launch();
+        CHK(hipEventRecord(e1));
+        CHK(hipEventSynchronize(e1));
+        float ms;
+        CHK(hipEventElapsedTime(&ms, e0, e1));
+        const char* ok = "";
+        if (check) {
+            CHK(hipMemcpy(got.data(), d_out, n_chunks * 32, hipMemcpyDeviceToHost));
+            if (!have_ref) { ref = got; have_ref = true; ok = "(reference)"; }
+            else ok = memcmp(ref.data(), got.data(), n_chunks * 32) == 0 ? "sums ok" : "SUMS DIFFER";
+        }
+        printf("%-72s %8.1f us  %7.1f GB/s  %s\n", name, ms * 1e3 / reps, n * 32.0 * reps / (ms * 1e-3) / 1e9, ok);
+        return 0;
+    };
+    const unsigned g2 = (unsigned)(n_chunks / 2 / 4), g4 = (unsigned)(n_chunks / 4 / 4);
+    run("shipped: 2 adjacent runs per wave, plain loads", [&] { k_fine2<false, 0><<<g2, 256>>>(d_in, n_chunks, 0, d_out); }, true);
+    run("2 adjacent runs per wave, nontemporal loads", [&] { k_fine2<true, 0><<<g2, 256>>>(d_in, n_chunks, 0, d_out); }, true);
+    run("2 runs n/2 apart, plain", [&] { k_fine2<false, 1><<<g2, 256>>>(d_in, n_chunks, 0, d_out); }, true);
+    run("2 runs n/2 apart, nontemporal", [&] { k_fine2<true, 1><<<g2, 256>>>(d_in, n_chunks, 0, d_out); }, true);
+    for (uint32_t ls : {3u, 6u, 8u, 10u, 12u}) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "2 adjacent runs, waves permuted by stride 2^%u, nontemporal", ls);
+        run(nm, [&] { k_fine2<true, 2><<<g2, 256>>>(d_in, n_chunks, ls, d_out); }, true);
+    }
+    run("4 adjacent runs per wave, plain", [&] { k_fine4<false, 0><<<g4, 256>>>(d_in, n_chunks, d_out); }, true);
+    run("4 adjacent runs per wave, nontemporal", [&] { k_fine4<true, 0><<<g4, 256>>>(d_in, n_chunks, d_out); }, true);
+    run("4 runs n/4 apart, plain", [&] { k_fine4<false, 1><<<g4, 256>>>(d_in, n_chunks, d_out); }, true);
+    run("4 runs n/4 apart, nontemporal", [&] { k_fine4<true, 1><<<g4, 256>>>(d_in, n_chunks, d_out); }, true);
+    run("loads only, 2 adjacent runs, plain", [&] { k_loads<false><<<g2, 256>>>(d_in, n_chunks, d_out); }, false);
+    run("loads only, 2 adjacent runs, nontemporal", [&] { k_loads<true><<<g2, 256>>>(d_in, n_chunks, d_out); }, false);
+    // ---- does a pass that walks the table in the OPPOSITE direction of the pass before it find the tail of that pass in the 256 MiB
+    // Infinity Cache?  Pairs of sweeps (up, up) against (up, down), per pair; and a single sweep over a table that fits the cache.
+    for (int nt = 0; nt < 2; ++nt) {
+        for (size_t mib : {512, 256, 128, 64}) {
+            const size_t n_w = mib * 1024 * 1024 / 16384;
+            const unsigned g = (unsigned)((n_w + 3) / 4);
+            char nm[160];
+            auto sweep = [&](uint32_t dir) { if (nt) k_sweep<true><<<g, 256>>>(d_in, n_w, dir, d_out); else k_sweep<false><<<g, 256>>>(d_in, n_w, dir, d_out); };
+            snprintf(nm, sizeof nm, "sweep pair up, up   over %zu MiB (%s): per pair [GB/s column: x %.2f]", mib, nt ? "nontemporal" : "plain", 2.0 * mib / 512);
+            run(nm, [&] { sweep(0); sweep(0); }, false);
+            snprintf(nm, sizeof nm, "sweep pair up, down over %zu MiB (%s): per pair [GB/s column: x %.2f]", mib, nt ? "nontemporal" : "plain", 2.0 * mib / 512);
+            run(nm, [&] { sweep(0); sweep(1); }, false);
+        }
+    }
+    return 0;
+}

@@ -410,6 +410,17 @@ __device__ __forceinline__ Fr load_fr(const uint64_t* __restrict__ base, size_t 
     r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
     return r;
 }
+// once-read streaming load of a table entry (nt: no reuse to keep in the caches)
+__device__ __forceinline__ Fr load_fr_nt(const uint64_t* __restrict__ base) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* p = reinterpret_cast<const u32x4*>(base);
+    const u32x4 a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 1);
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ Fr load_fr_nt(const uint64_t* __restrict__ base, size_t idx) { return load_fr_nt(base + 4 * idx); }
 __device__ __forceinline__ void store_fr(uint64_t* __restrict__ base, size_t idx, const Fr& v) {
     uint4* p = reinterpret_cast<uint4*>(base + 4 * idx);
     p[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);

@@ -58,8 +58,15 @@ static __global__ __launch_bounds__(MLE_BLOCK) void group_sums_kernel(const uint
 }
 
 // ---- fine block sums for the overlapped plan -------------------------------------------------------------
-// sums[c] = sum of the c-th run of FINE_CHUNK consecutive entries.  A wave owns two runs at a time (8 loads of 2 KiB in
-// flight per wave); no loop, the grid covers the table (n / (8 FINE_CHUNK) workgroups).
+// sums[c] = sum of the c-th run of FINE_CHUNK consecutive entries.  A wave owns two adjacent runs (8 loads of 2 KiB in flight per
+// wave); no loop, the grid covers the table (n / (8 FINE_CHUNK) workgroups).
+// Round 4 probes (tools/ubench_fine.hip + tools/ab_fine.sh, 2^24 entries, same box; profiles/r04/NOTES.md): the loads alone take
+// 82.2-82.5 us non-temporal, 85.9 plain; this kernel 90.3-91.0.  Its two runs half a table apart + non-temporal loads: 87.1-87.7 in
+// isolation, but in the prover the k-variable fold behind it then ran 95 instead of 84 us (it had been finding the tail of THIS pass in
+// the 256 MiB Infinity Cache) and the step did not move.  Four runs per wave, waves permuted by strides of 2^3..2^12 runs: 88-96 us.
+// Successive passes in alternating directions (each starting in the half the previous one left in that cache): step 0.3277 / 0.3307
+// against 0.3297 / 0.3321 ms -- inside the noise.  All dropped.  The ceiling of a read-only stream on this part is the same from
+// anywhere: a table that FITS the Infinity Cache (64 / 128 / 256 MiB swept twice) is read at 6.4-7.2 TB/s.
 constexpr int FINE_CHUNK = 256;
 static __global__ __launch_bounds__(MLE_BLOCK) void fine_sums_kernel(const uint64_t* __restrict__ in, size_t n_chunks,
                                                                      uint64_t* __restrict__ sums) {
@@ -442,16 +449,6 @@ static __global__ __launch_bounds__(MLE_BLOCK) void eq_weights_kernel(PtsArg pts
 // groups of a wave combine by shuffles, the waves through LDS.  G = 64 streams big tables (2 KiB per wave-load);
 // G = 16 keeps the chip busy when only a few hundred outputs are left.
 // Also writes the workgroup's sum of outputs to partials[blockIdx.x] (block sums of the output table).
-// once-read streaming load of a table entry (nt: no reuse to keep in the caches)
-__device__ __forceinline__ Fr load_fr_nt(const uint64_t* __restrict__ base) {
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4* p = reinterpret_cast<const u32x4*>(base);
-    const u32x4 a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 1);
-    Fr r;
-    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    return r;
-}
 template <int G, int DEPTH = 4, bool NT = false>
 static __global__ __launch_bounds__(1024) void multifold_kernel(const uint64_t* __restrict__ in, size_t m, uint32_t k,
                                                                 const uint64_t* __restrict__ weights,
