@@ -13,6 +13,7 @@
 #include "host_util.hpp"
 #include "composed_kernels.hpp"
 #include "composed_stage.hpp"
+#include "composed_pipe.hpp"
 #include "host_fr.hpp"
 
 using namespace zk;
@@ -105,6 +106,11 @@ struct ComposedRun {
     bool pending = false;    // the tables are still to be folded at the last challenge (the round kernels fold while they sum the next round)
     int cur_buf = 0;         // where the current tables lie: 0 the caller's, 1 the n/2-entry buffer, 2 the n/4-entry buffer
     uint64_t* d_stage_w = nullptr;   // fold weights of a two-round stage (composed_stage.hpp)
+    uint64_t* d_pipe_rec[2] = {nullptr, nullptr};   // forms records of the pipelined rounds, alternating
+    static constexpr size_t PIPE_MAX_WGS = 256;
+    static constexpr size_t PIPE_REC_BYTES = PIPE_MAX_WGS * 9 * CMP_MAX_TERMS * 32;
+    uint32_t pipe_records = 0;       // > 0: the tail continues pipelined rounds -- forms records in d_pipe_rec[pipe_parity], tables unfolded
+    int pipe_parity = 0;
     FrArg sum_arg = {};      // the claimed sum, passed to the closing kernels by value
 
     // n = entries per table held here, n_rounds = rounds of the whole sumcheck (log2 n, more when other ranks hold shards)
@@ -142,11 +148,14 @@ struct ComposedRun {
         // workspace: per table a ping (n/2) and a pong (n/4) buffer, then the state
         per_table = (n / 2 + n / 4 + 2) * 32;
         const size_t w_off = (total_all * per_table + 255) & ~(size_t)255;
-        const size_t bytes_off = w_off + 256;
+        const size_t pipe_off = w_off + 256;                         // two record buffers of the pipelined rounds (composed_pipe.hpp)
+        const size_t bytes_off = pipe_off + 2 * PIPE_REC_BYTES;
         const size_t chunk = std::min<size_t>(n, (size_t)1 << 18);   // entries per staging buffer of prove()'s table-bytes pass
         ZK_TRY(c->reserve_ws(bytes_off + (multi && !partial ? 64 * chunk : 0)));
         ws = (char*)c->d_ws;
         d_stage_w = (uint64_t*)(ws + w_off);
+        d_pipe_rec[0] = (uint64_t*)(ws + pipe_off);
+        d_pipe_rec[1] = (uint64_t*)(ws + pipe_off + PIPE_REC_BYTES);
         pending = false;
         cur_buf = 0;
         // the device-resident state (transcript, interpolation matrices of every degree) belongs to the context: uploaded once,
@@ -391,10 +400,91 @@ struct ComposedRun {
     // all remaining rounds in one launch, on tables of m = after() entries that fit the LDS (fold: they are still to be
     // folded at the previous challenge while loading)
     int tail(const TailTables& tt, uint32_t m, bool fold) {
-        ZK_TRY(c->allow_big_lds((const void*)composed_tail_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
         ProfScope ps(c, "composed_tail", 0.0);
-        hipLaunchKernelGGL(composed_tail_kernel, dim3(1), dim3(CMP_TAIL_BLOCK), (size_t)total_all * m * 32, c->stream, tt, total_all, m,
-                           fold ? 1u : 0u, fold ? prev_challenge() : nullptr, close_args(), n_rounds - round);
+        // claims whose terms are products of two tables (every GKR layer, the reference's composed bench shape): one round AHEAD of the
+        // transcript (composed_pipe.hpp).  ZKHIP_PIPE=0 keeps the round-by-round tail (same-box A/B).
+        if (pipe_on() && pipe_eligible(meta)) {
+            ZK_TRY(c->allow_big_lds((const void*)composed_tail_pipe_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
+            hipLaunchKernelGGL(composed_tail_pipe_kernel, dim3(1), dim3(PIPE_BLOCK), (size_t)total_all * m * 32, c->stream, tt, total_all, m,
+                               fold ? 1u : 0u, fold ? prev_challenge() : nullptr, close_args(), n_rounds - round, (const uint64_t*)nullptr, 0u);
+        } else {
+            ZK_TRY(c->allow_big_lds((const void*)composed_tail_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
+            hipLaunchKernelGGL(composed_tail_kernel, dim3(1), dim3(CMP_TAIL_BLOCK), (size_t)total_all * m * 32, c->stream, tt, total_all, m,
+                               fold ? 1u : 0u, fold ? prev_challenge() : nullptr, close_args(), n_rounds - round);
+        }
+        round = n_rounds;
+        return ZKHIP_OK;
+    }
+    static bool pipe_on() {
+        static const bool on = [] { const char* e = std::getenv("ZKHIP_PIPE"); return !e || std::atoi(e) != 0; }();
+        return on;
+    }
+    // ---- the rounds between the streaming sizes and the LDS tail, one launch per round and one round ahead (composed_pipe.hpp) ----
+    // Entered with tables of cn entries (a fold at the last challenge pending or not) that do not fit the tail yet.
+    static constexpr size_t PIPE_MID_MAX = (size_t)1 << 17;      // entries per table: above, the streaming forms (stages, wide rounds) are faster
+    bool pipe_mid_ok() const {
+        static const bool mid_on = [] { const char* e = std::getenv("ZKHIP_PIPE_MID"); return !e || std::atoi(e) != 0; }();
+        return pipe_on() && mid_on && pipe_eligible(meta) && after() > tail_len && after() <= PIPE_MID_MAX && after() >= 4 * PIPE_TILE && n_rounds - round >= 2;
+    }
+    MultiTablePtrs pipe_tables(bool with_out) const {
+        MultiTablePtrs mp = {};
+        uint32_t off = 0;
+        for (uint32_t p = 0; p < n_terms; ++p) {
+            for (uint32_t q = 0; q < 2; ++q) { mp.t[p].in[q] = cur[off + q]; mp.t[p].out[q] = with_out ? out_buf(off + q) : nullptr; }
+            mp.t[p].lin_in = lin_cur[p];
+            mp.t[p].lin_out = (with_out && lin_cur[p]) ? out_buf(meta.lin_tab[p]) : nullptr;
+            mp.rec_off[p] = meta.rec_off[p];
+            off += 2;
+        }
+        return mp;
+    }
+    int pipe_launch(bool fold, bool do_close, const uint64_t* rec_in, uint32_t n_rec_in, uint64_t* rec_out, uint32_t* n_rec_out) {
+        PipeRoundArgs a = {};
+        a.ca = close_args();
+        a.tabs = pipe_tables(fold);
+        a.cn = fold ? cn / 2 : cn;
+        a.fold = fold ? 1u : 0u;
+        a.fold_round = out_base + round - 1;
+        a.do_close = do_close ? 1u : 0u;
+        a.records_in = rec_in; a.n_records_in = n_rec_in; a.records_out = rec_out;
+        const size_t tiles = std::max<size_t>(1, (a.cn / 4 + PIPE_TILE - 1) / PIPE_TILE);
+        const uint32_t n_cross = (uint32_t)std::min<size_t>(tiles, PIPE_MAX_WGS);
+        const size_t lds = (size_t)3 * n_terms * 4 * PIPE_TILE * 32;
+        ZK_TRY(c->allow_big_lds((const void*)composed_pipe_round_kernel, 128 * 1024));
+        ProfScope ps(c, "composed_pipe_round", 0.0);
+        hipLaunchKernelGGL(composed_pipe_round_kernel, dim3(n_cross + (do_close ? 1 : 0)), dim3(PIPE_BLOCK), lds, c->stream, a);
+        *n_rec_out = n_cross;
+        return ZKHIP_OK;
+    }
+    int pipe_mid() {
+        // the first round the round-by-round way, with the forms of the NEXT round computed between its two launches
+        int grid = 0;
+        ZK_TRY(round_sums(&grid));                       // (folds at the previous challenge on the way, if one was pending)
+        uint32_t n_rec = 0;
+        pipe_parity = 0;
+        ZK_TRY(pipe_launch(false, false, nullptr, 0, d_pipe_rec[0], &n_rec));
+        close(d_partials, (uint32_t)grid);               // -> challenge, a fold pending
+        // steady state: one launch closes a round and prepares the next one
+        while (cn > tail_len && n_rounds - round >= 2) {
+            uint32_t n_out = 0;
+            ZK_TRY(pipe_launch(true, true, d_pipe_rec[pipe_parity], n_rec, d_pipe_rec[pipe_parity ^ 1], &n_out));
+            for (uint32_t q = 0; q < total; ++q) cur[q] = out_buf(q);
+            for (uint32_t p = 0; p < n_terms; ++p) if (lin_cur[p]) lin_cur[p] = out_buf(meta.lin_tab[p]);
+            cn /= 2; cur_buf = cur_buf == 1 ? 2 : 1;
+            ++round;
+            n_rec = n_out;
+            pipe_parity ^= 1;
+        }
+        pipe_records = n_rec;
+        return ZKHIP_OK;
+    }
+    // the tail behind pipelined rounds: the tables of the last closed round (cn entries, unfolded) + the forms of the next one
+    int tail_after_pipe() {
+        ZK_TRY(c->allow_big_lds((const void*)composed_tail_pipe_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
+        ProfScope ps(c, "composed_tail", 0.0);
+        hipLaunchKernelGGL(composed_tail_pipe_kernel, dim3(1), dim3(PIPE_BLOCK), (size_t)total_all * cn * 32, c->stream, current_tables(), total_all,
+                           (uint32_t)cn, 0u, (const uint64_t*)nullptr, close_args(), n_rounds - round, (const uint64_t*)d_pipe_rec[pipe_parity], pipe_records);
+        pipe_records = 0;
         round = n_rounds;
         return ZKHIP_OK;
     }
@@ -458,6 +548,11 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
             break;
         }
         if (run.stage_ok()) { ZK_TRY(run.stage()); continue; }
+        if (run.pipe_mid_ok()) {                 // one launch per round, one round ahead, down to the LDS tail
+            ZK_TRY(run.pipe_mid());
+            if (run.pipe_records && run.cn <= run.tail_len) { ZK_TRY(run.tail_after_pipe()); break; }
+            continue;
+        }
         int grid = 0;
         ZK_TRY(run.round_sums(&grid));
         run.close(run.d_partials, (uint32_t)grid);
@@ -484,6 +579,11 @@ int zk_multi_composed_enqueue(zkhip_ctx* c, const uint64_t* const* ptrs, const u
             break;
         }
         if (run.stage_ok()) { ZK_TRY(run.stage()); continue; }
+        if (run.pipe_mid_ok()) {                 // one launch per round, one round ahead, down to the LDS tail
+            ZK_TRY(run.pipe_mid());
+            if (run.pipe_records && run.cn <= run.tail_len) { ZK_TRY(run.tail_after_pipe()); break; }
+            continue;
+        }
         int grid = 0;
         ZK_TRY(run.round_sums(&grid));
         run.close(run.d_partials, (uint32_t)grid);

@@ -116,6 +116,7 @@ struct ComposedMeta {
 // (Montgomery form), uploaded by the host once per prove.
 struct ComposedDev {                   // one per context, persistent: a continuation finds the transcript where the last call left it
     Sha256State transcript;
+    uint64_t last_canon[4];            // the most recent challenge as the hash yielded it (canonical): what the pipelined rounds evaluate their forms at (composed_pipe.hpp)
     uint64_t interp[CMP_MAX_K + 1][(CMP_MAX_K + 1) * (CMP_MAX_K + 1)][4];
 };
 struct CloseShared {                   // LDS scratch of close_round
@@ -315,6 +316,8 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
             tr.commit_words8(h);
             tr.store(tr_state);
             sh.challenge_canon = c;
+#pragma unroll
+            for (int i = 0; i < Fr::N; ++i) reinterpret_cast<uint32_t*>(st->last_canon)[i] = c.l[i];
         }
     }
     __syncthreads();
