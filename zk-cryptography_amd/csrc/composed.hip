@@ -406,7 +406,7 @@ struct ComposedRun {
         if (pipe_on() && pipe_eligible(meta)) {
             ZK_TRY(c->allow_big_lds((const void*)composed_tail_pipe_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
             hipLaunchKernelGGL(composed_tail_pipe_kernel, dim3(1), dim3(PIPE_BLOCK), (size_t)total_all * m * 32, c->stream, tt, total_all, m,
-                               fold ? 1u : 0u, fold ? prev_challenge() : nullptr, close_args(), n_rounds - round, (const uint64_t*)nullptr, 0u);
+                               fold ? 1u : 0u, fold ? prev_challenge() : nullptr, close_args(), n_rounds - round, (const uint64_t*)nullptr, 0u, pipe_max_q());
         } else {
             ZK_TRY(c->allow_big_lds((const void*)composed_tail_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
             hipLaunchKernelGGL(composed_tail_kernel, dim3(1), dim3(CMP_TAIL_BLOCK), (size_t)total_all * m * 32, c->stream, tt, total_all, m,
@@ -414,6 +414,14 @@ struct ComposedRun {
         }
         round = n_rounds;
         return ZKHIP_OK;
+    }
+    static uint32_t pipe_max_q() {     // forms are computed ahead for tables of <= 4 max_q entries (ZKHIP_PIPE_MAX_Q: tuning)
+        static const uint32_t v = [] { const char* e = std::getenv("ZKHIP_PIPE_MAX_Q"); return e ? (uint32_t)std::atoi(e) : PIPE_MAX_Q; }();
+        return v;
+    }
+    static size_t pipe_tail_max() {    // tables of at most this many entries go to the single-workgroup tail behind pipelined rounds (ZKHIP_PIPE_TAIL: tuning)
+        static const size_t v = [] { const char* e = std::getenv("ZKHIP_PIPE_TAIL"); return e ? (size_t)std::atoi(e) : (size_t)512; }();
+        return v;
     }
     static bool pipe_on() {
         static const bool on = [] { const char* e = std::getenv("ZKHIP_PIPE"); return !e || std::atoi(e) != 0; }();
@@ -465,7 +473,7 @@ struct ComposedRun {
         ZK_TRY(pipe_launch(false, false, nullptr, 0, d_pipe_rec[0], &n_rec));
         close(d_partials, (uint32_t)grid);               // -> challenge, a fold pending
         // steady state: one launch closes a round and prepares the next one
-        while (cn > tail_len && n_rounds - round >= 2) {
+        while ((cn > tail_len || cn > pipe_tail_max()) && cn >= 8 * PIPE_TILE && n_rounds - round >= 2) {
             uint32_t n_out = 0;
             ZK_TRY(pipe_launch(true, true, d_pipe_rec[pipe_parity], n_rec, d_pipe_rec[pipe_parity ^ 1], &n_out));
             for (uint32_t q = 0; q < total; ++q) cur[q] = out_buf(q);
@@ -483,7 +491,7 @@ struct ComposedRun {
         ZK_TRY(c->allow_big_lds((const void*)composed_tail_pipe_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
         ProfScope ps(c, "composed_tail", 0.0);
         hipLaunchKernelGGL(composed_tail_pipe_kernel, dim3(1), dim3(PIPE_BLOCK), (size_t)total_all * cn * 32, c->stream, current_tables(), total_all,
-                           (uint32_t)cn, 0u, (const uint64_t*)nullptr, close_args(), n_rounds - round, (const uint64_t*)d_pipe_rec[pipe_parity], pipe_records);
+                           (uint32_t)cn, 0u, (const uint64_t*)nullptr, close_args(), n_rounds - round, (const uint64_t*)d_pipe_rec[pipe_parity], pipe_records, pipe_max_q());
         pipe_records = 0;
         round = n_rounds;
         return ZKHIP_OK;

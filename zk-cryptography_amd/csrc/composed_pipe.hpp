@@ -337,7 +337,7 @@ __device__ __forceinline__ void pipe_reduce_records(CloseShared& sh, PipeShared&
 // of the round this launch closes first.
 static __global__ __launch_bounds__(PIPE_BLOCK) void composed_tail_pipe_kernel(TailTables tt, uint32_t total, uint32_t m, uint32_t load_fold,
                                                                          const uint64_t* __restrict__ r_ptr, CloseArgs ca, uint32_t n_rounds,
-                                                                         const uint64_t* __restrict__ records_in, uint32_t n_records_in) {
+                                                                         const uint64_t* __restrict__ records_in, uint32_t n_records_in, uint32_t max_q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
     uint32_t* tab = reinterpret_cast<uint32_t*>(zk_dyn_lds);   // total tables x m elements
     __shared__ CloseShared sh;
@@ -417,7 +417,7 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_tail_pipe_kernel(T
         ZK_STAMP_AT(0, round, 2);
         // ---- the hash (wave 0) | schedules, output conversions and the NEXT round's forms (waves 1..)
         const bool last = cn == 2 || round + 1 == ca.round + n_rounds;
-        const bool make_forms = !last && cn >= 4 && (cn >> 2) <= PIPE_MAX_Q;
+        const bool make_forms = !last && cn >= 4 && (cn >> 2) <= max_q;
         if (wave == 0) {
             ZK_STAMP_AT(0, round, 3);
             pipe_hash_wave(sh, &trs, first);
