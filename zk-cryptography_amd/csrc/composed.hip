@@ -446,14 +446,14 @@ struct ComposedRun {
         }
         return mp;
     }
-    int pipe_launch(bool fold, bool do_close, const uint64_t* rec_in, uint32_t n_rec_in, uint64_t* rec_out, uint32_t* n_rec_out) {
+    int pipe_launch(bool fold, uint32_t do_close, const uint64_t* rec_in, uint32_t n_rec_in, uint64_t* rec_out, uint32_t* n_rec_out) {
         PipeRoundArgs a = {};
         a.ca = close_args();
         a.tabs = pipe_tables(fold);
         a.cn = fold ? cn / 2 : cn;
         a.fold = fold ? 1u : 0u;
         a.fold_round = out_base + round - 1;
-        a.do_close = do_close ? 1u : 0u;
+        a.do_close = do_close;
         a.records_in = rec_in; a.n_records_in = n_rec_in; a.records_out = rec_out;
         const size_t tiles = std::max<size_t>(1, (a.cn / 4 + PIPE_TILE - 1) / PIPE_TILE);
         const uint32_t n_cross = (uint32_t)std::min<size_t>(tiles, PIPE_MAX_WGS);
@@ -470,12 +470,15 @@ struct ComposedRun {
         ZK_TRY(round_sums(&grid));                       // (folds at the previous challenge on the way, if one was pending)
         uint32_t n_rec = 0;
         pipe_parity = 0;
-        ZK_TRY(pipe_launch(false, false, nullptr, 0, d_pipe_rec[0], &n_rec));
-        close(d_partials, (uint32_t)grid);               // -> challenge, a fold pending
+        // ONE launch closes that round from the sums and computes the next round's forms beside it
+        ZK_TRY(pipe_launch(false, 2u, d_partials, (uint32_t)grid, d_pipe_rec[0], &n_rec));
+        first = 0;
+        ++round;
+        pending = true;                                  // a fold at the new challenge
         // steady state: one launch closes a round and prepares the next one
         while ((cn > tail_len || cn > pipe_tail_max()) && cn >= 8 * PIPE_TILE && n_rounds - round >= 2) {
             uint32_t n_out = 0;
-            ZK_TRY(pipe_launch(true, true, d_pipe_rec[pipe_parity], n_rec, d_pipe_rec[pipe_parity ^ 1], &n_out));
+            ZK_TRY(pipe_launch(true, 1u, d_pipe_rec[pipe_parity], n_rec, d_pipe_rec[pipe_parity ^ 1], &n_out));
             for (uint32_t q = 0; q < total; ++q) cur[q] = out_buf(q);
             for (uint32_t p = 0; p < n_terms; ++p) if (lin_cur[p]) lin_cur[p] = out_buf(meta.lin_tab[p]);
             cn /= 2; cur_buf = cur_buf == 1 ? 2 : 1;

@@ -463,7 +463,9 @@ struct PipeRoundArgs {
     size_t cn;                     // entries per table AFTER the fold (= of the source when fold == 0)
     uint32_t fold;                 // 1: tables = fold(source, challenge ca.st->last_canon); its Montgomery form goes to challenges[fold_round]
     uint32_t fold_round;
-    uint32_t do_close;             // 1: workgroup 0 closes round ca.round from records_in
+    uint32_t do_close;             // workgroup 0 closes round ca.round: 1 = from the forms in records_in; 2 = from the sums themselves (records of
+                                   // meta.rec Montgomery values per workgroup, as the round kernels of composed_kernels.hpp leave them: the first
+                                   // round of a pipelined stretch); 0 = no closing workgroup
     const uint64_t* records_in;
     uint32_t n_records_in;
     uint64_t* records_out;         // one record of 9 n_terms forms per cross workgroup
@@ -481,22 +483,44 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(
     if (a.do_close && blockIdx.x == 0) {
         // ---- workgroup 0: close round ca.round from the forms
         const uint32_t round = a.ca.round;
-        if (tid < sizeof(Sha256State) / 4)
+        if (a.ca.first != 1 && tid < sizeof(Sha256State) / 4)
             reinterpret_cast<uint32_t*>(&trs)[tid] = reinterpret_cast<const uint32_t*>(&a.ca.st->transcript)[tid];
         if (tid == 0) { ps.prev_valid = 0; ps.out_n = 0; }
-        pipe_reduce_records(sh, ps, a.ca.st, a.records_in, a.n_records_in, n_groups);
-        __syncthreads();
+        const uint32_t first = a.ca.first;
+        Fr e = Fr::zero();
+        if (a.do_close == 1) {
+            pipe_reduce_records(sh, ps, a.ca.st, a.records_in, a.n_records_in, n_groups);
+            __syncthreads();
+        } else {
+            if (meta.multi && first && tid == 64) sh.sum_canon = fr_from_mont_outlined(fr_from_arg(a.ca.sum));   // multi_composed_sumcheck.rs:70
+            for (uint32_t v = wave; v < meta.rec; v += PIPE_BLOCK / 64) {
+                Fr s = Fr::zero();
+                for (uint32_t b = lane; b < a.n_records_in; b += 256) {
+                    Fr x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = b + 64 * u < a.n_records_in ? load_fr(a.records_in, (size_t)(b + 64 * u) * meta.rec + v) : Fr::zero();
+                    s = s + ((x[0] + x[1]) + (x[2] + x[3]));
+                }
+                s = seg_sum_fr(s, 64);
+                if (lane == 63) sh.evals[v] = s;
+            }
+            __syncthreads();
+            if (tid < meta.rec) e = fr_from_mont_outlined(sh.evals[tid]);
+        }
         ZK_STAMP_AT(0, round, 6);
         ZK_STAMP_AT(0, round, 0);
-        if (wave == 0) pipe_items_from_forms(sh, ps, meta, round, a.ca.round_out);
+        if (wave == 0) {
+            if (a.do_close == 1) pipe_items_from_forms(sh, ps, meta, round, a.ca.round_out);
+            else pipe_items_from_evals(sh, ps, meta, e, round, a.ca.round_out);
+        }
         __syncthreads();
         ZK_STAMP_AT(0, round, 1);
-        pipe_message(sh, meta, &trs, 0u);
+        pipe_message(sh, meta, &trs, first);
         __syncthreads();
         ZK_STAMP_AT(0, round, 2);
         if (wave == 0) {
             ZK_STAMP_AT(0, round, 3);
-            pipe_hash_wave(sh, &trs, 0u);
+            pipe_hash_wave(sh, &trs, first);
             ZK_STAMP_AT(0, round, 4);
         } else {
             pipe_schedules(sh);
@@ -511,7 +535,7 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(
     }
     // ---- the other workgroups: fold the tables (or take them as they are) and compute the forms of the round after the one being closed
     uint32_t* tile = reinterpret_cast<uint32_t*>(zk_dyn_lds);          // [slot][4 blocks][PIPE_TILE] field elements; slot 3 p + {0, 1, 2}
-    const uint32_t wg = blockIdx.x - a.do_close, n_cross = gridDim.x - a.do_close;
+    const uint32_t n_close = a.do_close ? 1u : 0u, wg = blockIdx.x - n_close, n_cross = gridDim.x - n_close;
     const size_t cn = a.cn, q = cn >> 2;
     Fr cm = Fr::zero();
     if (a.fold) {
@@ -563,26 +587,19 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(
             }
         }
         __syncthreads();
-        // phase 2: a wave per group (p, t): three products per index, the additive table's values, wave sums
-        for (uint32_t g = wave; g < n_groups; g += PIPE_BLOCK / 64) {
-            const uint32_t p = g / 3, t = g - 3 * p;
-            const bool has_lin = a.tabs.t[p].lin_in != nullptr;
-            const uint32_t* ta = tile + 8 * (size_t)(3 * p) * 4 * PIPE_TILE;
-            const uint32_t* tb = tile + 8 * (size_t)(3 * p + 1) * 4 * PIPE_TILE;
-            const uint32_t* tl = tile + 8 * (size_t)(3 * p + 2) * 4 * PIPE_TILE;
-            Fr acc[5];
-#pragma unroll
-            for (int kind = 0; kind < 3; ++kind)
-                acc[kind] = seg_sum_fr(fr_mul_outlined(pipe_operand(ta, PIPE_TILE, t, kind, lane), pipe_operand(tb, PIPE_TILE, t, kind, lane)), 64);
-            acc[3] = acc[4] = Fr::zero();
-            if (has_lin) {
+        // phase 2: jobs (group (p, t), kind) spread over all waves: one product per index and a wave sum each (kind 3: the additive table)
+        for (uint32_t job = wave; job < 4 * n_groups; job += PIPE_BLOCK / 64) {
+            const uint32_t g = job >> 2, kind = job & 3, p = g / 3, t = g - 3 * p;
+            if (kind < 3) {
+                const uint32_t* ta = tile + 8 * (size_t)(3 * p) * 4 * PIPE_TILE;
+                const uint32_t* tb = tile + 8 * (size_t)(3 * p + 1) * 4 * PIPE_TILE;
+                const Fr v = seg_sum_fr(fr_mul_outlined(pipe_operand(ta, PIPE_TILE, t, kind, lane), pipe_operand(tb, PIPE_TILE, t, kind, lane)), 64);
+                if (lane == 63) ps.raw[g][kind] = ps.raw[g][kind] + v;
+            } else if (a.tabs.t[p].lin_in != nullptr) {
+                const uint32_t* tl = tile + 8 * (size_t)(3 * p + 2) * 4 * PIPE_TILE;
                 const FrPair l = pipe_lin(tl, PIPE_TILE, t, lane);
-                acc[3] = seg_sum_fr(l.a, 64);
-                acc[4] = seg_sum_fr(l.b, 64);
-            }
-            if (lane == 63) {
-#pragma unroll
-                for (int k = 0; k < 5; ++k) ps.raw[g][k] = ps.raw[g][k] + acc[k];
+                const Fr v = seg_sum_fr(l.a, 64), v2 = seg_sum_fr(l.b, 64);
+                if (lane == 63) { ps.raw[g][3] = ps.raw[g][3] + v; ps.raw[g][4] = ps.raw[g][4] + v2; }
             }
         }
     }
