@@ -65,6 +65,33 @@ def case_multi():
             and np.array_equal(ch, och)), ("multi", sizes, log_n, partial)
 
 
+def case_multi_k2():
+    """claims whose terms are all products of TWO tables: the provers run one round ahead of the transcript (csrc/composed_pipe.hpp) --
+    pipelined launches above the LDS tail, the pipelined tail below; degenerate tables make coefficients vanish (dropped per term)"""
+    n_terms = rng.randint(1, 4)
+    log_n = rng.randint(1, 15 + min(BIG, 2))
+    n = 1 << log_n
+    flat = np.stack([ora.random_fr(n, rng.randrange(1 << 30)) for _ in range(2 * n_terms)])
+    for q in range(2 * n_terms):
+        kind = rng.random()
+        if kind < 0.12: flat[q][:] = 0                                                # a zero table: every coefficient of its term vanishes
+        elif kind < 0.24: flat[q][:] = flat[q][0]                                     # a constant table: the term's x^2 coefficient vanishes
+        elif kind < 0.32: flat[q] = zk.Fr.from_ints([(i * 3 + 1) % 7 for i in range(n)])    # small values
+        elif kind < 0.38 and q > 0: flat[q] = flat[q - 1]                             # the same table twice (GKR: V in both terms)
+    sizes = [2] * n_terms
+    terms = [zk.ComposedMultilinear([zk.Multilinear(flat[2 * p]), zk.Multilinear(flat[2 * p + 1])]) for p in range(n_terms)]
+    if n_terms == 1 and rng.random() < 0.5:          # ComposedSumcheck (raw evaluations absorbed)
+        proof, ch = zk.ComposedSumcheck(terms[0]).prove()
+        rp, och = ora.composed_prove(flat)
+        return np.array_equal(proof.round_polys, rp) and np.array_equal(ch, och), ("composed_k2", log_n)
+    s = zk.MultiComposedSumcheckProver.calculate_poly_sum(terms)
+    partial = rng.random() < 0.7
+    fn = zk.MultiComposedSumcheckProver.prove_partial if partial else zk.MultiComposedSumcheckProver.prove
+    proof, ch = fn(terms, s)
+    orps, och = ora.multi_composed_prove(flat, sizes, s, partial=partial)
+    return (proof.to_bytes() == ora.multi_composed_proof_bytes(orps) and np.array_equal(ch, och)), ("multi_k2", n_terms, log_n, partial)
+
+
 _srs = {}
 def case_commit():
     nv = rng.randint(1, 10)
@@ -198,7 +225,7 @@ def case_in_flight():
     return ok, ("in_flight", depth, logs)
 
 
-cases = [case_multifold, case_in_flight, case_open, case_uni_open, case_table_ops, case_sumcheck, case_fold_eval, case_composed, case_multi, case_commit, case_ntt, case_gkr]
+cases = [case_multi_k2, case_multifold, case_in_flight, case_open, case_uni_open, case_table_ops, case_sumcheck, case_fold_eval, case_composed, case_multi, case_commit, case_ntt, case_gkr]
 if len(sys.argv) > 3:
     cases = [c for c in cases if c.__name__ in sys.argv[3:]]
 t0 = time.time()
