@@ -1,13 +1,20 @@
 #!/bin/bash
-# usage (this container, repo root, after `gpurun -- tools/collect_r03.sh; tools/prof_open.sh` merged gpurun_out/r03/): copy what is judged into profiles/r03/
+# usage (this container, repo root, after `gpurun -- tools/collect.sh <round>` merged gpurun_out/<round>/): tools/collect_copy.sh <round>
+# copies what is judged into profiles/<round>/
 set -e
-R=gpurun_out/r03 P=profiles/r03
+N=${1:?round name, e.g. r04}
+R=gpurun_out/$N P=profiles/$N
+mkdir -p $P
 cp $R/stats/runc/*kernel_stats.csv $P/a_bench_kernel_stats.csv
 cp $R/bench_under_rocprof.json $P/a_bench_line_under_rocprof.json
 cp $R/stats_prover/runc/*kernel_stats.csv $P/a2_prover_kernel_stats.csv
 cp $R/bench_prover_under_rocprof.json $P/a2_prover_line_under_rocprof.json
 cp $R/a_bench_line_default_run.json $P/
-cp $R/b_prover_timeline.txt $R/c_proofs_in_flight_timeline.txt $R/open_last_call_trace.txt $P/
+cp $R/b_prover_timeline.txt $R/c_proofs_in_flight_timeline.txt $P/
+cp $R/gkr20/runc/*kernel_stats.csv $P/d_gkr20_kernel_stats.csv
+cp $R/d_gkr20_trace_gaps.txt $R/d_composed_round_stamps.txt $R/d_ab_pipe.txt $P/
+[ -f $R/ubench_fine_gfx950.txt ] && cp $R/ubench_fine_gfx950.txt $P/
+[ -f $R/open_last_call_trace.txt ] && cp $R/open_last_call_trace.txt $P/
 cp $R/pmc_fetch/runc/*counter_collection.csv $P/pmc_fetch_counter_collection.csv
 cp $R/pmc_write/runc/*counter_collection.csv $P/pmc_write_counter_collection.csv
 python tools/pmc_summary.py $P/pmc_fetch_counter_collection.csv $P/pmc_write_counter_collection.csv $P/pmc_traffic.json | grep -i "multifold\|fine_sums\|fold_kernel"
