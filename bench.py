@@ -366,6 +366,20 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
         t_o = sorted(t_open)[len(t_open) // 2]
         extras = {"srs_setup_ms": round(1e3 * t_s, 2), "open": {"ms_per_open": round(1e3 * t_o, 3), "batches": _stats(t_open, 1e3, 3), "proofs": len(proof.proofs),
                   "note": "MultilinearKZG::open (multilinear_kzg.rs:50-88): %d quotient commitments, folded SRS levels cached" % len(proof.proofs)}}
+        # ... and against the level tables (shifted tables of the folded levels, built once per SRS like the commit's table)
+        t_b = time.perf_counter()
+        plain_srs.precompute_open()
+        torch.cuda.synchronize()
+        t_b = time.perf_counter() - t_b
+        proof_t = zk.MultilinearKZG.open(poly, z, plain_srs)
+        assert np.array_equal(proof_t.evaluation, proof.evaluation) and all(a == b for a, b in zip(proof_t.proofs, proof.proofs)), \
+            "openings with and without the level tables differ"
+        t_open = _timed(lambda: zk.MultilinearKZG.open(poly, z, plain_srs), torch, reps=5)
+        t_o = sorted(t_open)[len(t_open) // 2]
+        extras["open_level_tables"] = {"ms_per_open": round(1e3 * t_o, 3), "batches": _stats(t_open, 1e3, 3), "tables_gib": round(plain_srs.level_tables.numel() / 2 ** 30, 2),
+                                       "tables_built_ms": round(1e3 * t_b, 1),
+                                       "note": "the same opening against zkhip_srs_level_tables (TrustedSetup.precompute_open): same proof, checked"}
+        plain_srs.invalidate()                                     # the 1.9 GiB go back before the next leg
     # the same commitments without the table (16 instead of 13 bucket additions per point, 16 bucket reductions)
     com_plain = zk.MultilinearKZG.commitment(poly, plain_srs)
     t_plain = _timed(lambda: zk.MultilinearKZG.commitment(poly, plain_srs), torch, reps=steps)

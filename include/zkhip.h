@@ -503,7 +503,13 @@ int zkhip_srs_univariate_g1(zkhip_ctx *ctx, const uint64_t *h_tau, size_t max_de
  * repeated table is sum_j q_i[j] * S_i[j] with S_i[j] = sum_rep SRS[rep * |q_i| + j]; the S_i ("folded SRS", n - 1
  * points in all) depend on the SRS only:
  *   zkhip_srs_fold_levels : d_out_xy[(n-1)*12], d_out_inf[n-1] <- S_0 (n/2 points), S_1 (n/4), ..., S_{nv-1} (1);
- *   zkhip_kzg_open        : d_folded_* = that array, or NULL to derive it inside the call.
+ *   zkhip_kzg_open        : d_folded_* = that array, or NULL to derive it inside the call;
+ *   zkhip_srs_level_tables: shifted tables 2^(c w) * S_i[j] of the folded levels of at most 2^19 points, each level with a window
+ *                           width c of its own (~log2 of its size), zkhip_srs_level_tables_bytes(n) bytes in all (1.9 GiB at 2^20):
+ *                           built once per SRS like zkhip_srs_precompute's table; with them every round's commitment needs
+ *                           ceil(256 / c) instead of ~ceil(256 / (c - 4)) bucket additions per point, ONE bucket set and a
+ *                           host epilogue of ~20 instead of 255 doublings;
+ *   zkhip_kzg_open_tables : zkhip_kzg_open with those tables (d_level_tables; NULL = zkhip_kzg_open; needs d_folded_inf).
  * Outputs (host): h_evaluation[4]; h_proofs_xy[n_vars*12], h_proofs_inf[n_vars] (affine, as zkhip_kzg_commit).
  * Shape errors as in the reference: n_points != n (multilinear_kzg.rs:36-41), n_eval_points != n_vars
  * (evaluation_form.rs:163-167), n_vars < 2 (`variable_index - 1` underflows at :73) -> ZKHIP_ERR_SHAPE. */
@@ -513,6 +519,13 @@ int zkhip_kzg_open(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint
                    const uint64_t *d_points_xy, const uint8_t *d_points_inf, size_t n_points,
                    const uint64_t *d_folded_xy, const uint8_t *d_folded_inf, uint64_t *h_evaluation,
                    uint64_t *h_proofs_xy, uint8_t *h_proofs_inf);
+size_t zkhip_srs_level_tables_bytes(size_t n_points);
+int zkhip_srs_level_tables(zkhip_ctx *ctx, const uint64_t *d_folded_xy, const uint8_t *d_folded_inf, size_t n_points,
+                           void *d_tables);
+int zkhip_kzg_open_tables(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint64_t *h_points, size_t n_eval_points,
+                          const uint64_t *d_points_xy, const uint8_t *d_points_inf, size_t n_points,
+                          const uint64_t *d_folded_xy, const uint8_t *d_folded_inf, const void *d_level_tables,
+                          uint64_t *h_evaluation, uint64_t *h_proofs_xy, uint8_t *h_proofs_inf);
 /* UnivariateKZGInterface::open (kzg/src/univariate_kzg.rs:60-81): evaluation = poly(z) (dense_univariate.rs:184-196),
  * proof = commitment to the quotient of (poly - z) / (x - z) (divide_with_q_and_r, dense_univariate.rs:88-124) against
  * the first n_coeffs - 1 SRS points.  Evaluation and quotient come from one Horner suffix scan on the device.

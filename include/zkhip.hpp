@@ -436,10 +436,24 @@ class TrustedSetup {                                                            
         return *this;
     }
     const void* table() const { return table_ ? table_->u8() : nullptr; }
+    // folded levels + their shifted tables (zkhip_srs_fold_levels, zkhip_srs_level_tables): built once per SRS, then every `open` uses them
+    TrustedSetup& precompute_open() {
+        if (!level_tables_ && n_ >= 4 && !(n_ & (n_ - 1))) {
+            folded_xy_ = std::make_shared<DeviceBuffer>(96 * (n_ - 1));
+            folded_inf_ = std::make_shared<DeviceBuffer>(n_ - 1);
+            check(zkhip_srs_fold_levels(ctx(), points(), inf(), n_, folded_xy_->u64(), folded_inf_->u8()), "srs_fold_levels");
+            level_tables_ = std::make_shared<DeviceBuffer>(zkhip_srs_level_tables_bytes(n_));
+            check(zkhip_srs_level_tables(ctx(), folded_xy_->u64(), folded_inf_->u8(), n_, level_tables_->u8()), "srs_level_tables");
+        }
+        return *this;
+    }
+    const uint64_t* folded_xy() const { return folded_xy_ ? folded_xy_->u64() : nullptr; }
+    const uint8_t* folded_inf() const { return folded_inf_ ? folded_inf_->u8() : nullptr; }
+    const void* level_tables() const { return level_tables_ ? level_tables_->u8() : nullptr; }
     const uint64_t* points() const { return pts_->u64(); }
     const uint8_t* inf() const { return inf_->u8(); }
     explicit TrustedSetup(size_t n) : pts_(std::make_shared<DeviceBuffer>(96 * n)), inf_(std::make_shared<DeviceBuffer>(n)), n_(n) {}
-    std::shared_ptr<DeviceBuffer> pts_, inf_, table_;
+    std::shared_ptr<DeviceBuffer> pts_, inf_, table_, folded_xy_, folded_inf_, level_tables_;
   private:
     size_t n_;
 };
@@ -476,8 +490,8 @@ struct MultilinearKZG {
         const size_t nv = evaluation_points.size();
         std::vector<uint64_t> xy(12 * (nv ? nv : 1));
         std::vector<uint8_t> inf(nv ? nv : 1);
-        int st = zkhip_kzg_open(ctx(), poly.device(), poly.len(), nv ? evaluation_points[0].l : nullptr, nv, srs.points(), srs.inf(), srs.len(),
-                                nullptr, nullptr, pr.evaluation.l, xy.data(), inf.data());
+        int st = zkhip_kzg_open_tables(ctx(), poly.device(), poly.len(), nv ? evaluation_points[0].l : nullptr, nv, srs.points(), srs.inf(), srs.len(),
+                                       srs.folded_xy(), srs.folded_inf(), srs.level_tables(), pr.evaluation.l, xy.data(), inf.data());
         if (st == ZKHIP_ERR_SHAPE) throw Panic("open: evaluation points / SRS length must match the polynomial (n_vars >= 2)");
         check(st, "kzg_open");
         for (size_t i = 0; i < nv; ++i) {

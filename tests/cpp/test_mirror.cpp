@@ -186,6 +186,12 @@ static void kzg_open_case(const std::vector<Fr>& vals, const std::vector<Fr>& ta
     EXPECT(ora_kzg_open((fr_t*)&ev, want.data(), O(vals), vals.size(), O(z), z.size(), osrs.data(), osrs.size()) == 0);
     EXPECT(proof.evaluation == ev && proof.proofs.size() == tau.size());
     for (size_t i = 0; i < want.size() && i < proof.proofs.size(); ++i) EXPECT(same_point(proof.proofs[i], want[i]));
+    // the same opening against the level tables (TrustedSetup::precompute_open)
+    srs.precompute_open();
+    EXPECT(srs.level_tables() != nullptr);
+    MultilinearKZGProof tabled = MultilinearKZG::open(Multilinear(vals), z, srs);
+    EXPECT(tabled.evaluation == ev && tabled.proofs.size() == tau.size());
+    for (size_t i = 0; i < want.size() && i < tabled.proofs.size(); ++i) EXPECT(same_point(tabled.proofs[i], want[i]));
 }
 TEST(test_kzg_1_open) {   // multilinear_kzg.rs:131-155 (open half; the pairing verifier is out of scope)
     kzg_open_case(F({0, 7, 0, 5, 0, 7, 4, 9}), F({2, 3, 4}), F({5, 9, 6}));

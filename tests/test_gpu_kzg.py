@@ -224,6 +224,69 @@ def test_kzg_open_random_matches_naive_oracle(zk, ora, n_vars):
         _same(zk, got, *_aff(ora, want))
 
 
+# ---- the same openings against the level tables (TrustedSetup.precompute_open: zkhip_srs_level_tables / zkhip_kzg_open_tables) --------
+@pytest.mark.parametrize("vals,tau,z", [
+    ([0, 7, 0, 5, 0, 7, 4, 9], [2, 3, 4], [5, 9, 6]),                                                      # test_kzg_1
+    ([0, 0, 0, 2, 0, 0, 10, 12, 0, -12, 4, -6, 0, -12, 14, 4], [12, 9, 28, 40], [54, 90, 76, 160]),       # test_kzg_2
+])
+def test_kzg_open_level_tables_reference_data(zk, ora, vals, tau, z):
+    srs = zk.TrustedSetup.setup(zk.Fr.from_ints(tau)).precompute_open()
+    assert srs.level_tables is not None
+    proof = zk.MultilinearKZG.open(zk.Multilinear(zk.Fr.from_ints(vals)), zk.Fr.from_ints(z), srs)
+    want_ev, want_proofs = ora.kzg_open(zk.Fr.from_ints(vals), zk.Fr.from_ints(z), ora.kzg_multilinear_srs_g1(zk.Fr.from_ints(tau)))
+    assert np.array_equal(proof.evaluation, want_ev)
+    for got, want in zip(proof.proofs, want_proofs):
+        _same(zk, got, *_aff(ora, want))
+
+
+@pytest.mark.parametrize("n_vars", [2, 3, 5, 8])
+def test_kzg_open_level_tables_random_matches_naive_oracle(zk, ora, n_vars):
+    tau, z = ora.random_fr(n_vars, 2100 + n_vars), ora.random_fr(n_vars, 2200 + n_vars)
+    vals = ora.random_fr(1 << n_vars, 2300 + n_vars)
+    srs = zk.TrustedSetup.setup(tau).precompute_open()
+    proof = zk.MultilinearKZG.open(zk.Multilinear(vals), z, srs)
+    want_ev, want_proofs = ora.kzg_open(vals, z, ora.kzg_multilinear_srs_g1(tau))
+    assert np.array_equal(proof.evaluation, want_ev)
+    for got, want in zip(proof.proofs, want_proofs):
+        _same(zk, got, *_aff(ora, want))
+
+
+@pytest.mark.parametrize("n_vars,kind", [(10, "random"), (13, "random"), (16, "random"), (12, "small"), (12, "equal"), (12, "zero_tau"),
+                                         (12, "minus_one"), (20, "random"), (21, "random")])
+def test_kzg_open_level_tables_agree_with_the_plain_opening(zk, ora, n_vars, kind):
+    """Every proof point of an opening against the level tables equals the one the plain batch (whose own parity is pinned by the oracle
+    tests above and by the exponent identity below) delivers: dense and degenerate quotients (tiny values: sparse top windows; one
+    repeated value: every point of a window in ONE bucket, the heavy-bucket passes; all -1: negative digits throughout), an SRS with
+    points at infinity (tau_0 = 0 zeroes half of it), and 2^21, where the first round is a commit of its own beside the tabled batch."""
+    n = 1 << n_vars
+    tau = ora.random_fr(n_vars, 3100 + n_vars)
+    if kind == "zero_tau":
+        tau = np.ascontiguousarray(tau)
+        tau[0] = zk.Fr.from_int(0)
+    z = ora.random_fr(n_vars, 3200 + n_vars)
+    rng = np.random.default_rng(3300 + n_vars)
+    if kind == "small":
+        vals = zk.Fr.from_ints([int(v) for v in rng.integers(0, 4, n)])
+    elif kind == "equal":
+        # q_i = f(1, .) - f(0, .): a table whose halves differ by one constant gives a first quotient of n/2 equal entries
+        half = ora.random_fr(n // 2, 3400)
+        lo = zk.Fr.to_ints(half)
+        vals = zk.Fr.from_ints(lo + [v + 0x1234567890abcdef1234567890abcdef1234567890abcdef for v in lo])
+    elif kind == "minus_one":
+        vals = zk.Fr.from_ints([0] * (n // 2) + [-1] * (n // 2))
+    else:
+        vals = ora.random_fr(n, 3300 + n_vars)
+    srs = zk.TrustedSetup.setup(tau)
+    plain = zk.TrustedSetup(srs.powers_of_tau_in_g1.clone(), srs.inf.clone())
+    srs.precompute_open()
+    poly = zk.Multilinear(vals)
+    a, b = zk.MultilinearKZG.open(poly, z, srs), zk.MultilinearKZG.open(poly, z, plain)
+    assert plain.level_tables is None and srs.level_tables is not None
+    assert np.array_equal(a.evaluation, b.evaluation)
+    assert len(a.proofs) == n_vars and all(p == q for p, q in zip(a.proofs, b.proofs))
+    assert np.array_equal(a.evaluation, ora.mle_evaluation(np.ascontiguousarray(vals), z))
+
+
 @pytest.mark.parametrize("n_vars", [14, 20])   # 20 = BASELINE config 3's SRS size
 def test_kzg_open_exponent_identity(zk, ora, n_vars):
     """Beyond what the naive oracle can do in seconds: proof_i == Q_i(tau) * G, Q_i the round's quotient evaluated at

@@ -354,35 +354,76 @@ extern "C" int zkhip_kzg_commit_end(zkhip_ctx* c, uint32_t ticket, uint64_t* h_o
 // ---------------------------------------------------------------------------------------
 extern "C" size_t zkhip_srs_table_bytes(size_t n_points) { return n_points * MSM_TABLE_WINDOWS * 128; }
 
-extern "C" int zkhip_srs_precompute(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, size_t n,
-                                    void* d_table) {
-    if (!c || !d_points_xy || !d_table) return ZKHIP_ERR_ARG;
-    if (n == 0) return ZKHIP_OK;
-    if (n * MSM_TABLE_WINDOWS >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;   // entry index + sign bit in 32 bits
-    ZK_TRY(c->activate());
+// windows 0 .. n_windows-1 of c bits over n affine points: table entry w * n + i = 2^(c w) * point i (internal 28-bit-limb layout, 128 bytes);
+// the context's workspace holds one window in XYZZ and affine form meanwhile
+static int build_shift_table(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, size_t n, uint32_t width, uint32_t n_windows,
+                             uint32_t* table, uint32_t n_wide = ~0u /* windows >= n_wide are width - 1 bits */) {
     // workspace: XYZZ of one window (192 n) | affine (96 n) | infinity flags (n)
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_xyzz = 0, o_aff = al(192 * n), o_inf = o_aff + al(96 * n);
     ZK_TRY(c->reserve_ws(o_inf + al(n)));
     char* ws = (char*)c->d_ws;
-    uint32_t* table = (uint32_t*)d_table;
     const unsigned grid = (unsigned)((n + MSM_BLOCK - 1) / MSM_BLOCK);
     hipLaunchKernelGGL(msm_convert_points_kernel, dim3(std::min<unsigned>(grid, 256 * 8)), dim3(MSM_BLOCK), 0, c->stream, d_points_xy, n, table);
     if (d_points_inf) {   // entries of points at infinity: all-zero coordinates (their scalars are skipped by the sort anyway)
         hipLaunchKernelGGL(msm_clear_inf_kernel, dim3(grid), dim3(MSM_BLOCK), 0, c->stream, d_points_inf, n, table);
     }
     const size_t n_threads = (n + SRS_CHUNK - 1) / SRS_CHUNK;
-    for (uint32_t w = 1; w < MSM_TABLE_WINDOWS; ++w) {
+    for (uint32_t w = 1; w < n_windows; ++w) {
         const uint32_t* prev = table + (size_t)(w - 1) * n * 32;
         uint32_t* cur = table + (size_t)w * n * 32;
-        hipLaunchKernelGGL(msm_shift_points_kernel, dim3(grid), dim3(MSM_BLOCK), 0, c->stream, prev, n, MSM_TABLE_C, (uint64_t*)(ws + o_xyzz));
+        hipLaunchKernelGGL(msm_shift_points_kernel, dim3(grid), dim3(MSM_BLOCK), 0, c->stream, prev, n, w - 1 < n_wide ? width : width - 1,
+                           (uint64_t*)(ws + o_xyzz));
         hipLaunchKernelGGL(srs_batch_affine_kernel, dim3((unsigned)((n_threads + SRS_BLOCK - 1) / SRS_BLOCK)), dim3(SRS_BLOCK), 0, c->stream,
                            (const uint64_t*)(ws + o_xyzz), n, (uint64_t*)(ws + o_aff), (uint8_t*)(ws + o_inf));
         hipLaunchKernelGGL(msm_convert_points_kernel, dim3(std::min<unsigned>(grid, 256 * 8)), dim3(MSM_BLOCK), 0, c->stream,
                            (const uint64_t*)(ws + o_aff), n, cur);
     }
     ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_srs_precompute(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, size_t n,
+                                    void* d_table) {
+    if (!c || !d_points_xy || !d_table) return ZKHIP_ERR_ARG;
+    if (n == 0) return ZKHIP_OK;
+    if (n * MSM_TABLE_WINDOWS >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;   // entry index + sign bit in 32 bits
+    ZK_TRY(c->activate());
+    ZK_TRY(build_shift_table(c, d_points_xy, d_points_inf, n, MSM_TABLE_C, MSM_TABLE_WINDOWS, (uint32_t*)d_table));
     ZK_HIP(c, hipStreamSynchronize(c->stream));   // the workspace is reused by the next call
+    return ZKHIP_OK;
+}
+
+// LEVEL TABLES: shifted tables of the folded SRS levels MultilinearKZG::open commits against in ONE batch (the levels of at most
+// OPEN_BATCH_MAX points), each with the window widths of msm_level_table_widths, end to end in level order (msm_geometry.hpp).
+constexpr size_t OPEN_BATCH_MAX_DEFAULT = (size_t)1 << 19;
+static size_t level_tables_first(size_t n_points, size_t* lvl_off) {   // size of the first (largest) level that has a table; *lvl_off = its offset in the folded array
+    size_t h = n_points / 2, off = 0;
+    while (h > OPEN_BATCH_MAX_DEFAULT) { off += h; h /= 2; }
+    if (lvl_off) *lvl_off = off;
+    return h;
+}
+extern "C" size_t zkhip_srs_level_tables_bytes(size_t n_points) {
+    if (n_points < 2 || !is_pow2(n_points)) return 0;
+    size_t entries = 0;
+    const size_t first = level_tables_first(n_points, nullptr);
+    for (size_t h = first; h >= 1; h /= 2) entries += (size_t)msm_level_table_widths(h, 2 * first - 1).W * h;
+    return entries * 128;
+}
+extern "C" int zkhip_srs_level_tables(zkhip_ctx* c, const uint64_t* d_folded_xy, const uint8_t* d_folded_inf, size_t n_points, void* d_tables) {
+    if (!c || !d_folded_xy || !d_folded_inf || !d_tables) return ZKHIP_ERR_ARG;
+    if (n_points < 2 || !is_pow2(n_points)) return ZKHIP_ERR_SHAPE;
+    if (zkhip_srs_level_tables_bytes(n_points) / 128 >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    size_t off = 0, entry = 0;
+    const size_t first = level_tables_first(n_points, &off);
+    for (size_t h = first; h >= 1; h /= 2) {
+        const MsmLevelWidths lw = msm_level_table_widths(h, 2 * first - 1);      // the batch: the levels first, first / 2, ..., 1
+        const uint32_t W = lw.W;
+        ZK_TRY(build_shift_table(c, d_folded_xy + 12 * off, d_folded_inf + off, h, lw.hi, W, (uint32_t*)d_tables + entry * 32, lw.n_hi));
+        off += h;
+        entry += (size_t)W * h;
+    }
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
     return ZKHIP_OK;
 }
 
@@ -481,7 +522,15 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
                               const uint64_t* d_points_xy, const uint8_t* d_points_inf, size_t n_points,
                               const uint64_t* d_folded_xy, const uint8_t* d_folded_inf, uint64_t* h_evaluation,
                               uint64_t* h_proofs_xy, uint8_t* h_proofs_inf) {
+    return zkhip_kzg_open_tables(c, d_evals, n, h_points, n_eval_points, d_points_xy, d_points_inf, n_points, d_folded_xy, d_folded_inf, nullptr,
+                                 h_evaluation, h_proofs_xy, h_proofs_inf);
+}
+extern "C" int zkhip_kzg_open_tables(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_points, size_t n_eval_points,
+                                     const uint64_t* d_points_xy, const uint8_t* d_points_inf, size_t n_points,
+                                     const uint64_t* d_folded_xy, const uint8_t* d_folded_inf, const void* d_level_tables,
+                                     uint64_t* h_evaluation, uint64_t* h_proofs_xy, uint8_t* h_proofs_inf) {
     if (!c || !d_evals || !h_points || !d_points_xy || !h_evaluation || !h_proofs_xy || !h_proofs_inf) return ZKHIP_ERR_ARG;
+    if (d_level_tables && !d_folded_inf) return ZKHIP_ERR_ARG;      // the tables belong to cached folded levels
     if (!is_pow2(n)) return ZKHIP_ERR_SHAPE;
     const uint32_t n_vars = log2_exact(n);
     if (n_eval_points != n_vars) return ZKHIP_ERR_SHAPE;   // evaluation_form.rs:163-167
@@ -517,11 +566,12 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
     // heavy-bucket passes (0.6 ms) and the three reductions ended 0.9 ms after the last accumulate pass.  ZKHIP_OPEN_PIPELINES=1 runs the
     // rounds above 2^14 as pipelines again for an A/B.)
     const bool pipelines = [] { const char* e = std::getenv("ZKHIP_OPEN_PIPELINES"); return e && e[0] == '1'; }();
-    size_t OPEN_BATCH_MAX = pipelines ? (size_t)1 << 14 : (size_t)1 << 19;
+    size_t OPEN_BATCH_MAX = pipelines ? (size_t)1 << 14 : OPEN_BATCH_MAX_DEFAULT;
     if (const char* e = std::getenv("ZKHIP_OPEN_BATCH_LOG")) {   // tuning aid (tools/perf_open.py)
         const int v = std::atoi(e);
         if (v >= 8 && v <= 20) OPEN_BATCH_MAX = (size_t)1 << v;
     }
+    if (OPEN_BATCH_MAX != OPEN_BATCH_MAX_DEFAULT) d_level_tables = nullptr;    // the tables are laid out for the default batch
     // result slot / stream of the single commits (they rotate over the slots); the batch has the last slot
     int NSLOT = pipelines ? 5 : 2;
     if (const char* e = std::getenv("ZKHIP_OPEN_SLOTS")) {   // tuning aid (tools/perf_open.py): fewer single commits beside each other
@@ -570,7 +620,7 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
     }
     {
         size_t used = 0;
-        if (batch.n) ZK_TRY(msm_enqueue(c, nullptr, nullptr, nullptr, lvl_off - batch_first_off, batch, nullptr, 0, 0, 0, nullptr, &used));
+        if (batch.n) ZK_TRY(msm_enqueue(c, nullptr, nullptr, nullptr, lvl_off - batch_first_off, batch, (const uint32_t*)d_level_tables, 0, 0, 0, nullptr, &used));
         ZK_TRY(c->reserve_ws(region_off[NSLOT] + used));
     }
     ZK_TRY(c->ensure_side_streams());
@@ -593,7 +643,7 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
         if (rc == ZKHIP_OK) {
             c->stream = on;                                // msm_enqueue launches on the context's stream
             rc = msm_enqueue(c, d_folded_xy + 12 * batch_first_off, d_folded_inf + batch_first_off, d_q + 4 * batch_first_off,
-                             lvl_off - batch_first_off, batch, nullptr, 0, region_off[NSLOT], sl_batch, &pend[sl_batch], nullptr);
+                             lvl_off - batch_first_off, batch, (const uint32_t*)d_level_tables, 0, region_off[NSLOT], sl_batch, &pend[sl_batch], nullptr);
             c->stream = main_stream;
             if (rc == ZKHIP_OK) pend_round[sl_batch] = (int)batch_first_round;
         }

@@ -32,8 +32,8 @@ constexpr int SORT_MAX_PARTS = 4096;      // partitions of the counting sort's f
 struct MsmWin {
     uint32_t part_base;   // first sort partition of its bucket set
     uint32_t entry_off;   // shifted-SRS table: w * stride, added to the point index (0 otherwise)
-    uint32_t bits;        // byte 0: window width c (digits in [-2^(c-1), 2^(c-1)]); byte 1: part_bits of its bucket set
-    uint32_t pad;
+    uint32_t bits;        // byte 0: window width c (digits in [-2^(c-1), 2^(c-1)]); byte 1: part_bits of its bucket set; byte 2: the low bits of a
+    uint32_t pad;         //   bucket index that level 2 of the sort resolves (set width - 1 - part_bits; the set may be one bit wider than the window)
 };
 struct MsmSet {
     uint32_t bucket_base; // first bucket, a multiple of MSM_SEG
@@ -96,6 +96,31 @@ struct MsmGeometry {
 };
 constexpr uint32_t MSM_TABLE_C = 20;
 constexpr uint32_t MSM_TABLE_WINDOWS = (256 + MSM_TABLE_C - 1) / MSM_TABLE_C;   // 13: twelve full 20-bit windows and a 15-bit top window
+// LEVEL TABLES (the folded SRS levels of MultilinearKZG::open, zkhip_srs_level_tables): a batch of problems, each with a shifted table of
+// its own -- problem j of n_j points has W_j = ceil(256 / c_j) windows of ~c_j = log2(n_j) bits (msm_level_table_widths), ONE bucket set of
+// 2^(c_j - 1) ~ n_j / 2 buckets (as many as its ~17 sets of 2^(lg - 5) buckets without the table) and the entries
+// T_j + w n_j + i = 2^(first bit of window w) * point i, T_j = sum_{k < j} W_k n_k: the tables of the batch's problems lie end to end in problem order.
+// Widths: W = ceil(256 / lg) windows, the low n_hi of them `hi` bits wide and the rest hi - 1, exactly 256 bits in all -- no sparse top window,
+// whose few distinct digits would pile a whole level into a handful of (heavy) buckets.
+struct MsmLevelWidths { uint32_t W, hi, n_hi; };
+inline MsmLevelWidths msm_level_table_widths(size_t nj, size_t batch_total) {
+    int lg = 0;
+    while (((size_t)1 << lg) < nj) ++lg;
+    // measured (tools/sweep_level_delta.sh; ms at delta 0 / -1 / -2 / -3, plain batch in brackets): 2^15 2.04 / 1.61 / 1.46 / 1.30 [1.78],
+    // 2^17 2.18 / 1.98 / 1.70 / 1.64 [1.91], 2^18 2.38 / 2.06 / 1.88 / 2.16 [2.23], 2^19 2.99 / 2.56 / 2.84 / - [3.25], 2^20 4.14 / - [4.97]:
+    // a small opening is as long as its longest bucket lists (wider windows: more buckets, shorter lists), a large one is throughput bound
+    int delta = batch_total < ((size_t)1 << 17) ? -3 : batch_total < ((size_t)1 << 18) ? -2 : batch_total < ((size_t)1 << 19) ? -1 : 0;
+    if (const char* e = std::getenv("ZKHIP_LEVEL_TABLE_DELTA")) {   // tuning aid: widest window log2(n_j) - delta (read when the table is BUILT and when it is used)
+        const int v = std::atoi(e);
+        if (v >= -3 && v <= 4) delta = v;
+    }
+    const uint32_t c = (uint32_t)std::min(20, std::max(8, lg - delta));
+    MsmLevelWidths lw;
+    lw.W = (256 + c - 1) / c;
+    lw.hi = (256 + lw.W - 1) / lw.W;
+    lw.n_hi = 256 - lw.W * (lw.hi - 1);
+    return lw;
+}
 inline int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t table_stride, int delta, MsmGeometry& g);
 inline int msm_build_geometry(const MsmProblems& pr, bool shared, size_t table_stride, MsmGeometry& g);
 inline int msm_build_geometry(const MsmProblems& pr, bool shared, size_t table_stride, MsmGeometry& g) {
@@ -115,6 +140,7 @@ inline int msm_build_geometry(const MsmProblems& pr, bool shared, size_t table_s
 inline int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t table_stride, int delta, MsmGeometry& g) {
     g = MsmGeometry();
     uint32_t max_chain = 1, rc_max = 1;
+    size_t level_entries = 0;
     g.prob_set_first.push_back(0);
     auto add_set = [&](uint32_t c, uint32_t exp) {
         MsmSet s = {};
@@ -147,7 +173,8 @@ inline int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t tabl
         MsmWin w = {};
         w.part_base = s.part_base;
         w.entry_off = entry_off;
-        w.bits = c | (s.bits & 0xff00u);
+        const uint32_t set_c = s.bits & 0xffu, part_bits = (s.bits >> 8) & 0xffu;
+        w.bits = c | (part_bits << 8) | ((set_c - 1 - part_bits) << 16);
         g.wins.push_back(w);
     };
     for (uint32_t j = 0; j < pr.n; ++j) {
@@ -155,7 +182,17 @@ inline int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t tabl
         g.win_first[j] = (uint16_t)g.wins.size();
         uint32_t lg = 0;
         while (((size_t)1 << lg) < nj) ++lg;
-        if (shared) {
+        if (shared && pr.n > 1) {                     // level tables: see msm_level_table_widths
+            const MsmLevelWidths lw = msm_level_table_widths(nj, pr.off[pr.n]);
+            const uint32_t c = lw.hi, W = lw.W;
+            const MsmSet s = add_set(c, 0);
+            if (level_entries + (size_t)W * nj >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;    // entry index + sign bit in 32 bits
+            for (uint32_t w = 0; w < W; ++w)                                                        // + the point's index in the batch
+                add_win(s, w < lw.n_hi ? lw.hi : lw.hi - 1, (uint32_t)(level_entries + (size_t)w * nj - pr.off[j]));
+            level_entries += (size_t)W * nj;
+            g.items += nj * W;
+            max_chain = std::max<uint32_t>(max_chain, (uint32_t)((nj * W + (1u << (c - 1)) - 1) >> (c - 1)));
+        } else if (shared) {
             const MsmSet s = add_set(MSM_TABLE_C, 0);
             for (uint32_t w = 0; w < MSM_TABLE_WINDOWS; ++w) add_win(s, MSM_TABLE_C, (uint32_t)(w * table_stride));
             g.items += nj * MSM_TABLE_WINDOWS;

@@ -116,7 +116,7 @@ __device__ __forceinline__ uint32_t msm_problem_of(const MsmSortTables& t, uint3
 }
 // the partition of a digit: the HIGH part_bits bits of its bucket index (all windows of every geometry are dense, so the partitions of a
 // set fill evenly; level 2 resolves the low <= 8 bits and writes a partition's counts / offsets / sorted run contiguously)
-__device__ __forceinline__ uint32_t msm_win_sub_bits(const uint4& w) { return (w.z & 0xffu) - 1 - ((w.z >> 8) & 0xffu); }   // w = an MsmWin
+__device__ __forceinline__ uint32_t msm_win_sub_bits(const uint4& w) { return (w.z >> 16) & 0xffu; }   // w = an MsmWin
 __device__ __forceinline__ uint32_t msm_partition_of(const uint4& w, uint32_t mag) { return w.x + ((mag - 1) >> msm_win_sub_bits(w)); }
 
 static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_count_kernel(const uint64_t* __restrict__ scalars,
