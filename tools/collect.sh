@@ -25,6 +25,12 @@ make -s -C zk-cryptography_amd/csrc libzkhip_diag.so > /dev/null 2>&1
 (echo "== MultiComposedSumcheckProver::prove_partial, 2 terms of 2 tables, 2^16 entries: per-round in-kernel stamps (us)"; timeout 120 python3 tools/diag_composed.py 16 multi 2>&1 | grep "^round"; echo "== ComposedSumcheck::prove, 2 tables, 2^22 entries"; timeout 120 python3 tools/diag_composed.py 22 2>&1 | grep "^round") > gpurun_out/$R/d_composed_round_stamps.txt
 timeout 300 ./tools/ab_pipe.sh > gpurun_out/$R/d_ab_pipe.txt 2>&1
 [ -x tools/ubench_fine ] && timeout 120 ./tools/ubench_fine > gpurun_out/$R/ubench_fine_gfx950.txt 2>&1
+[ -x tools/ubench_batched_affine ] && timeout 120 ./tools/ubench_batched_affine > gpurun_out/$R/ubench_batched_affine_gfx950.txt 2>&1
+# MultilinearKZG::open: plain batch against the level tables -- per-kernel stats at 2^20, time by size, time by window width
+for m in cached tables; do
+  PERF_OPEN_MODES=$m timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/open_$m -- python3 tools/perf_open.py 20 > gpurun_out/$R/open_$m.log 2>&1 < /dev/null
+done
+(timeout 300 python3 tools/perf_open.py 12 16 18 20 21 22 2>&1 | grep "open\|level\|commitment"; timeout 300 bash tools/sweep_level_delta.sh 16 18 19 2>&1) > gpurun_out/$R/e_open_by_size_and_width.txt
 find gpurun_out/$R -name "*.csv" | head -20
 f=$(ls gpurun_out/$R/stats/*/*kernel_stats.csv | head -1); head -30 "$f" | cut -d, -f1-5 | sed 's/(.*),/",/' | cut -c1-160
 # keep what is small: stats CSVs and counter collections (the kernel traces themselves are large)

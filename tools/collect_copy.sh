@@ -14,7 +14,9 @@ cp $R/b_prover_timeline.txt $R/c_proofs_in_flight_timeline.txt $P/
 cp $R/gkr20/runc/*kernel_stats.csv $P/d_gkr20_kernel_stats.csv
 cp $R/d_gkr20_trace_gaps.txt $R/d_composed_round_stamps.txt $R/d_ab_pipe.txt $P/
 [ -f $R/ubench_fine_gfx950.txt ] && cp $R/ubench_fine_gfx950.txt $P/
-[ -f $R/open_last_call_trace.txt ] && cp $R/open_last_call_trace.txt $P/
+[ -f $R/ubench_batched_affine_gfx950.txt ] && cp $R/ubench_batched_affine_gfx950.txt $P/
+[ -f $R/e_open_by_size_and_width.txt ] && cp $R/e_open_by_size_and_width.txt $P/
+for m in cached tables; do f=$(find $R/open_$m -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $P/e_open_${m}_kernel_stats.csv; done
 cp $R/pmc_fetch/runc/*counter_collection.csv $P/pmc_fetch_counter_collection.csv
 cp $R/pmc_write/runc/*counter_collection.csv $P/pmc_write_counter_collection.csv
 python tools/pmc_summary.py $P/pmc_fetch_counter_collection.csv $P/pmc_write_counter_collection.csv $P/pmc_traffic.json | grep -i "multifold\|fine_sums\|fold_kernel"
