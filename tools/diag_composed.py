@@ -31,3 +31,10 @@ for r in range(log_n):
     print("round %2d  start->close %6.2f  items %5.2f  message %5.2f  schedules %5.2f  hash %5.2f  publish %5.2f  fold %5.2f | since previous round's start %7.2f us"
           % (r, d(6, 0), d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), fold, (s[6] - prev) * tick if prev else 0.0))
     prev = s[6]
+print("cross workgroup (the first one), per round it runs beside: wait | tiles | record + signal | closer's round start -> this workgroup's start (us)")
+for r in range(min(log_n, 32)):
+    s = buf[32 + r].astype(np.int64)
+    if s[1] == 0:
+        continue
+    w = (s[1] - s[0]) * tick if s[0] else float("nan")
+    print("round %2d  wait %6.2f  tiles %6.2f  record %6.2f  | start - closer's start %7.2f" % (r, w, (s[2] - s[1]) * tick, (s[3] - s[2]) * tick, (s[1] - buf[r].astype(np.int64)[6]) * tick))

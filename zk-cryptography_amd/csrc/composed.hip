@@ -107,7 +107,7 @@ struct ComposedRun {
     int cur_buf = 0;         // where the current tables lie: 0 the caller's, 1 the n/2-entry buffer, 2 the n/4-entry buffer
     uint64_t* d_stage_w = nullptr;   // fold weights of a two-round stage (composed_stage.hpp)
     uint64_t* d_pipe_rec[2] = {nullptr, nullptr};   // forms records of the pipelined rounds, alternating
-    static constexpr size_t PIPE_MAX_WGS = 256;
+    static constexpr size_t PIPE_MAX_WGS = 512;     // two per compute unit: all resident when the chip is this prover's alone
     static constexpr size_t PIPE_REC_BYTES = PIPE_MAX_WGS * 9 * CMP_MAX_TERMS * 32;
     uint32_t pipe_records = 0;       // > 0: the tail continues pipelined rounds -- forms records in d_pipe_rec[pipe_parity], tables unfolded
     int pipe_parity = 0;
@@ -456,13 +456,32 @@ struct ComposedRun {
         a.do_close = do_close;
         a.records_in = rec_in; a.n_records_in = n_rec_in; a.records_out = rec_out;
         const size_t tiles = std::max<size_t>(1, (a.cn / 4 + PIPE_TILE - 1) / PIPE_TILE);
-        const uint32_t n_cross = (uint32_t)std::min<size_t>(tiles, PIPE_MAX_WGS);
+        const uint32_t n_cross = (uint32_t)std::min<size_t>(tiles, pipe_wgs());
         const size_t lds = (size_t)3 * n_terms * 4 * PIPE_TILE * 32;
         ZK_TRY(c->allow_big_lds((const void*)composed_pipe_round_kernel, 128 * 1024));
         ProfScope ps(c, "composed_pipe_round", 0.0);
         hipLaunchKernelGGL(composed_pipe_round_kernel, dim3(n_cross + (do_close ? 1 : 0)), dim3(PIPE_BLOCK), lds, c->stream, a);
         *n_rec_out = n_cross;
         return ZKHIP_OK;
+    }
+    // the steady rounds of pipe_mid from the current state on: how many there are
+    uint32_t pipe_steady_rounds() const {
+        size_t cn_ = cn;
+        uint32_t round_ = round, k = 0;
+        while ((cn_ > tail_len || cn_ > pipe_tail_max()) && cn_ >= 8 * PIPE_TILE && n_rounds - round_ >= 2) { cn_ /= 2; ++round_; ++k; }
+        return k;
+    }
+    static size_t pipe_wgs() {         // workgroups that take tiles, at most (ZKHIP_PIPE_WGS: tuning)
+        static const size_t v = [] { const char* e = std::getenv("ZKHIP_PIPE_WGS"); const int x = e ? std::atoi(e) : 0; return x >= 1 && x <= (int)PIPE_MAX_WGS ? (size_t)x : (size_t)256; }();
+        return v;
+    }
+    // one steady round's bookkeeping (what a launch of composed_pipe_round_kernel with fold = 1 leaves behind)
+    void pipe_advance() {
+        for (uint32_t q = 0; q < total; ++q) cur[q] = out_buf(q);
+        for (uint32_t p = 0; p < n_terms; ++p) if (lin_cur[p]) lin_cur[p] = out_buf(meta.lin_tab[p]);
+        cn /= 2; cur_buf = cur_buf == 1 ? 2 : 1;
+        ++round;
+        pipe_parity ^= 1;
     }
     int pipe_mid() {
         // the first round the round-by-round way, with the forms of the NEXT round computed between its two launches
@@ -476,15 +495,12 @@ struct ComposedRun {
         ++round;
         pending = true;                                  // a fold at the new challenge
         // steady state: one launch closes a round and prepares the next one
-        while ((cn > tail_len || cn > pipe_tail_max()) && cn >= 8 * PIPE_TILE && n_rounds - round >= 2) {
+        const uint32_t k = pipe_steady_rounds();
+        for (uint32_t i = 0; i < k; ++i) {
             uint32_t n_out = 0;
             ZK_TRY(pipe_launch(true, 1u, d_pipe_rec[pipe_parity], n_rec, d_pipe_rec[pipe_parity ^ 1], &n_out));
-            for (uint32_t q = 0; q < total; ++q) cur[q] = out_buf(q);
-            for (uint32_t p = 0; p < n_terms; ++p) if (lin_cur[p]) lin_cur[p] = out_buf(meta.lin_tab[p]);
-            cn /= 2; cur_buf = cur_buf == 1 ? 2 : 1;
-            ++round;
+            pipe_advance();
             n_rec = n_out;
-            pipe_parity ^= 1;
         }
         pipe_records = n_rec;
         return ZKHIP_OK;

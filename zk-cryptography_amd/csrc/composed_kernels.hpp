@@ -116,7 +116,9 @@ struct ComposedMeta {
 // (Montgomery form), uploaded by the host once per prove.
 struct ComposedDev {                   // one per context, persistent: a continuation finds the transcript where the last call left it
     Sha256State transcript;
-    uint64_t last_canon[4];            // the most recent challenge as the hash yielded it (canonical): what the pipelined rounds evaluate their forms at (composed_pipe.hpp)
+    uint64_t last_canon[2][4];         // the challenge of round r as the hash yielded it (canonical), in slot r & 1: what the pipelined rounds evaluate
+                                       // their forms at and fold by (composed_pipe.hpp).  Two slots: the workgroup that closes round r writes slot r & 1
+                                       // while the others of the same launch still read round r - 1's
     uint64_t interp[CMP_MAX_K + 1][(CMP_MAX_K + 1) * (CMP_MAX_K + 1)][4];
 };
 struct CloseShared {                   // LDS scratch of close_round
@@ -317,7 +319,7 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
             tr.store(tr_state);
             sh.challenge_canon = c;
 #pragma unroll
-            for (int i = 0; i < Fr::N; ++i) reinterpret_cast<uint32_t*>(st->last_canon)[i] = c.l[i];
+            for (int i = 0; i < Fr::N; ++i) reinterpret_cast<uint32_t*>(st->last_canon[round & 1])[i] = c.l[i];
         }
     }
     __syncthreads();

@@ -312,11 +312,12 @@ __device__ __forceinline__ void pipe_outputs(const PipeShared& ps, const Compose
     if (sl == 32 && ps.prev_valid) store_fr(challenges, ps.prev_round, fr_to_mont_outlined(ps.prev_challenge));
 }
 
-// sums the forms records of n_records workgroups into ps.forms and fetches the challenge they are to be evaluated at (every thread calls)
+// sums the forms records of n_records workgroups into ps.forms and fetches the challenge they are to be evaluated at -- the one of the
+// round before `round`, the round they belong to (every thread calls)
 __device__ __forceinline__ void pipe_reduce_records(CloseShared& sh, PipeShared& ps, const ComposedDev* st, const uint64_t* __restrict__ records,
-                                                    uint32_t n_records, uint32_t n_groups) {
+                                                    uint32_t n_records, uint32_t n_groups, uint32_t round) {
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6, vals = 3 * n_groups;
-    if (tid < 8) sh.challenge_canon.l[tid] = reinterpret_cast<const uint32_t*>(st->last_canon)[tid];
+    if (tid < 8) sh.challenge_canon.l[tid] = reinterpret_cast<const uint32_t*>(st->last_canon[(round - 1) & 1])[tid];
     for (uint32_t v = wave; v < vals; v += n_waves) {
         Fr s = Fr::zero();
         for (uint32_t b = lane; b < n_records; b += 256) {       // four loads in flight per lane
@@ -361,7 +362,7 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_tail_pipe_kernel(T
         if (meta.multi && ca.first && tid == 64) sh.sum_canon = fr_from_mont_outlined(fr_from_arg(ca.sum));   // multi_composed_sumcheck.rs:70
     }
     const uint32_t n_groups = 3 * meta.n_terms;
-    if (n_records_in) pipe_reduce_records(sh, ps, ca.st, records_in, n_records_in, n_groups);
+    if (n_records_in) pipe_reduce_records(sh, ps, ca.st, records_in, n_records_in, n_groups, ca.round);
     __syncthreads();
     uint32_t cn = m, first = ca.first;
     bool have_forms = false, pending_fold = false;
@@ -461,7 +462,7 @@ struct PipeRoundArgs {
     CloseArgs ca;                  // ca.round: the round workgroup 0 closes (do_close)
     MultiTablePtrs tabs;           // per term: in[0], in[1], lin_in = the source tables; out[..] / lin_out = the folded tables (fold)
     size_t cn;                     // entries per table AFTER the fold (= of the source when fold == 0)
-    uint32_t fold;                 // 1: tables = fold(source, challenge ca.st->last_canon); its Montgomery form goes to challenges[fold_round]
+    uint32_t fold;                 // 1: tables = fold(source, challenge of round ca.round - 1); its Montgomery form goes to challenges[fold_round]
     uint32_t fold_round;
     uint32_t do_close;             // workgroup 0 closes round ca.round: 1 = from the forms in records_in; 2 = from the sums themselves (records of
                                    // meta.rec Montgomery values per workgroup, as the round kernels of composed_kernels.hpp leave them: the first
@@ -470,7 +471,131 @@ struct PipeRoundArgs {
     uint32_t n_records_in;
     uint64_t* records_out;         // one record of 9 n_terms forms per cross workgroup
 };
-constexpr uint32_t PIPE_TILE = 64;            // indices j per tile: 4 x 64 entries of every table in LDS
+// indices j per tile: 4 x PIPE_TILE entries of every table in LDS.  A tile is what ONE workgroup takes through both phases in a row:
+// 13.5 us at 64 (two entries to fold per thread, two passes of jobs per wave), 7.7 us at 32 (in-kernel stamps, tools/diag_composed.py) --
+// beside a closing workgroup that needs 12 us.  End to end the two measure the same (tools/ab_tile.sh, same box, three runs each:
+// ComposedSumcheck 2^22 0.565-0.591 / 0.585-0.604 ms, GKR depth 20 10.08-10.12 / 9.97-10.38 ms at 64 / 32).
+#ifndef ZK_PIPE_TILE
+#define ZK_PIPE_TILE 64
+#endif
+constexpr uint32_t PIPE_TILE = ZK_PIPE_TILE;
+static_assert(PIPE_TILE == 16 || PIPE_TILE == 32 || PIPE_TILE == 64, "a job is an aligned segment of a wave");
+
+// The closing half of a round, from sh.evals-free state: ps.forms (from_forms) or the canonical sums e (per thread < meta.rec) are in place.
+// Every thread of the workgroup calls; the challenge ends in sh.challenge_canon, the transcript in trs.
+__device__ __forceinline__ void pipe_close_round(CloseShared& sh, PipeShared& ps, Sha256State& trs, const CloseArgs& ca, uint32_t round, uint32_t first,
+                                                 bool from_forms, const Fr& e) {
+    const uint32_t wave = threadIdx.x >> 6;
+    ZK_STAMP_AT(0, round, 6);
+    ZK_STAMP_AT(0, round, 0);
+    if (wave == 0) {
+        if (from_forms) pipe_items_from_forms(sh, ps, ca.meta, round, ca.round_out);
+        else pipe_items_from_evals(sh, ps, ca.meta, e, round, ca.round_out);
+    }
+    __syncthreads();
+    ZK_STAMP_AT(0, round, 1);
+    pipe_message(sh, ca.meta, &trs, first);
+    __syncthreads();
+    ZK_STAMP_AT(0, round, 2);
+    if (wave == 0) {
+        ZK_STAMP_AT(0, round, 3);
+        pipe_hash_wave(sh, &trs, first);
+        ZK_STAMP_AT(0, round, 4);
+    } else {
+        pipe_schedules(sh);
+        pipe_outputs(ps, ca.meta, ca.round_out, ca.challenges);
+    }
+    __syncthreads();
+    ZK_STAMP_AT(0, round, 5);
+    if (threadIdx.x < 8) reinterpret_cast<uint32_t*>(ca.st->last_canon[round & 1])[threadIdx.x] = sh.challenge_canon.l[threadIdx.x];
+}
+
+// source / destination of every table slot (3 p + {0, 1, 2}: the term's two factors and its additive table; null = no table there)
+struct PipeTileTabs {
+    const uint64_t* src[PIPE_GROUPS];
+    uint64_t* dst[PIPE_GROUPS];
+};
+// One tile of PIPE_TILE indices j: the tile's 4 quarter-block entries of every table into LDS -- folded by cm on the way in and written to
+// dst (fold) -- then the products of the next round's forms, accumulated into ps.raw.  Every thread of the workgroup calls.
+__device__ __forceinline__ void pipe_cross_tile(const PipeTileTabs& tb, uint32_t n_terms, size_t cn, bool fold, const Fr& cm, size_t tile_i,
+                                                uint32_t* tile, PipeShared& ps) {
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t n_slots = 3 * n_terms, n_groups = 3 * n_terms;
+    const size_t q = cn >> 2, j0 = tile_i * PIPE_TILE;
+    const uint32_t J = (uint32_t)((q - j0) < PIPE_TILE ? (q - j0) : PIPE_TILE);
+    __syncthreads();                                                // the previous tile's products are done with the LDS tile
+    // phase 1: the tile of every table, folded on the way in (all loads of a lane are issued before its first product)
+    const uint32_t units = n_slots * 4 * PIPE_TILE;
+    for (uint32_t u0 = tid; u0 < units; u0 += 2 * PIPE_BLOCK) {
+        Fr lo[2], hi[2];
+        bool live[2];
+        uint32_t slot[2], b[2], jj[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t u = u0 + k * PIPE_BLOCK;
+            slot[k] = u / (4 * PIPE_TILE); b[k] = (u / PIPE_TILE) & 3; jj[k] = u & (PIPE_TILE - 1);
+            const uint64_t* src = u < units ? tb.src[slot[k]] : nullptr;
+            live[k] = src != nullptr && jj[k] < J;
+            lo[k] = hi[k] = Fr::zero();
+            if (live[k]) {
+                const size_t x = j0 + jj[k] + (size_t)b[k] * q;
+                lo[k] = load_fr(src, x);
+                if (fold) hi[k] = load_fr(src, x + cn);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t u = u0 + k * PIPE_BLOCK;
+            if (u >= units) continue;
+            Fr v = lo[k];
+            if (live[k] && fold) {
+                v = lo[k] + fr_mul_outlined(cm, hi[k] - lo[k]);
+                store_fr(tb.dst[slot[k]], j0 + jj[k] + (size_t)b[k] * q, v);
+            }
+            lds_store_fr(tile, (slot[k] * 4 + b[k]) * PIPE_TILE + jj[k], v);       // lanes past the table hold zero
+        }
+    }
+    __syncthreads();
+    // phase 2: jobs (kind, group (p, t)) of PIPE_TILE lanes each, 64 / PIPE_TILE of them side by side in a wave: one product per index and a
+    // segment sum each (kind 3: the additive table).  Kind-major numbering: the jobs a wave holds are of one kind when n_groups is even.
+    constexpr uint32_t PACK = 64 / PIPE_TILE;
+    const uint32_t sub = lane / PIPE_TILE, jl = lane & (PIPE_TILE - 1), n_jobs = 4 * n_groups;
+    for (uint32_t job0 = wave * PACK; job0 < n_jobs; job0 += (PIPE_BLOCK / 64) * PACK) {
+        const uint32_t job = job0 + sub;
+        if (job >= n_jobs) continue;
+        const uint32_t kind = job / n_groups, g = job - kind * n_groups, p = g / 3, t = g - 3 * p;
+        if (kind < 3) {
+            const uint32_t* ta = tile + 8 * (size_t)(3 * p) * 4 * PIPE_TILE;
+            const uint32_t* tbb = tile + 8 * (size_t)(3 * p + 1) * 4 * PIPE_TILE;
+            const Fr v = seg_sum_fr(fr_mul_outlined(pipe_operand(ta, PIPE_TILE, t, kind, jl), pipe_operand(tbb, PIPE_TILE, t, kind, jl)), PIPE_TILE);
+            if (jl == PIPE_TILE - 1) ps.raw[g][kind] = ps.raw[g][kind] + v;
+        } else if (tb.src[3 * p + 2] != nullptr) {
+            const uint32_t* tl = tile + 8 * (size_t)(3 * p + 2) * 4 * PIPE_TILE;
+            const FrPair l = pipe_lin(tl, PIPE_TILE, t, jl);
+            const Fr v = seg_sum_fr(l.a, PIPE_TILE), v2 = seg_sum_fr(l.b, PIPE_TILE);
+            if (jl == PIPE_TILE - 1) { ps.raw[g][3] = ps.raw[g][3] + v; ps.raw[g][4] = ps.raw[g][4] + v2; }
+        }
+    }
+}
+// the workgroup's record from ps.raw: F0 canonical, F1 Montgomery, F2 x R^2 (one product for all)
+__device__ __forceinline__ void pipe_write_record(const PipeShared& ps, uint32_t n_groups, uint64_t* __restrict__ records, size_t slot) {
+    const uint32_t tid = threadIdx.x;
+    if (tid < 3 * n_groups) {
+        const uint32_t g = tid / 3, l = tid - 3 * g;
+        const Fr s0 = ps.raw[g][0], sk = ps.raw[g][1], s2 = ps.raw[g][2], l0 = ps.raw[g][3], l1 = ps.raw[g][4];
+        const Fr val = l == 0 ? s0 + l0 : l == 1 ? ((sk - s0) - s2) + l1 : s2;
+        Fr k;
+#pragma unroll
+        for (int i = 0; i < Fr::N; ++i) k.l[i] = l == 0 ? (i == 0 ? 1u : 0u) : l == 1 ? FrParams::r1(i) : FrParams::r2(i);
+        store_fr(records, slot * 3 * n_groups + tid, fr_mul_outlined(val, k));
+    }
+}
+__device__ __forceinline__ Fr pipe_challenge_mont(const ComposedDev* st, uint32_t round) {      // the challenge of `round`, Montgomery form
+    Fr c;
+#pragma unroll
+    for (int i = 0; i < Fr::N; ++i) c.l[i] = reinterpret_cast<const uint32_t*>(st->last_canon[round & 1])[i];
+    return fr_to_mont_outlined(c);
+}
 
 static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(PipeRoundArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
@@ -489,7 +614,7 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(
         const uint32_t first = a.ca.first;
         Fr e = Fr::zero();
         if (a.do_close == 1) {
-            pipe_reduce_records(sh, ps, a.ca.st, a.records_in, a.n_records_in, n_groups);
+            pipe_reduce_records(sh, ps, a.ca.st, a.records_in, a.n_records_in, n_groups, round);
             __syncthreads();
         } else {
             if (meta.multi && first && tid == 64) sh.sum_canon = fr_from_mont_outlined(fr_from_arg(a.ca.sum));   // multi_composed_sumcheck.rs:70
@@ -507,28 +632,7 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(
             __syncthreads();
             if (tid < meta.rec) e = fr_from_mont_outlined(sh.evals[tid]);
         }
-        ZK_STAMP_AT(0, round, 6);
-        ZK_STAMP_AT(0, round, 0);
-        if (wave == 0) {
-            if (a.do_close == 1) pipe_items_from_forms(sh, ps, meta, round, a.ca.round_out);
-            else pipe_items_from_evals(sh, ps, meta, e, round, a.ca.round_out);
-        }
-        __syncthreads();
-        ZK_STAMP_AT(0, round, 1);
-        pipe_message(sh, meta, &trs, first);
-        __syncthreads();
-        ZK_STAMP_AT(0, round, 2);
-        if (wave == 0) {
-            ZK_STAMP_AT(0, round, 3);
-            pipe_hash_wave(sh, &trs, first);
-            ZK_STAMP_AT(0, round, 4);
-        } else {
-            pipe_schedules(sh);
-            pipe_outputs(ps, meta, a.ca.round_out, a.ca.challenges);
-        }
-        __syncthreads();
-        ZK_STAMP_AT(0, round, 5);
-        if (tid < 8) reinterpret_cast<uint32_t*>(a.ca.st->last_canon)[tid] = sh.challenge_canon.l[tid];
+        pipe_close_round(sh, ps, trs, a.ca, round, first, a.do_close == 1, e);
         if (tid < sizeof(Sha256State) / 4)
             reinterpret_cast<uint32_t*>(&a.ca.st->transcript)[tid] = reinterpret_cast<const uint32_t*>(&trs)[tid];
         return;
@@ -539,81 +643,24 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(
     const size_t cn = a.cn, q = cn >> 2;
     Fr cm = Fr::zero();
     if (a.fold) {
-        Fr c;
-#pragma unroll
-        for (int i = 0; i < Fr::N; ++i) c.l[i] = reinterpret_cast<const uint32_t*>(a.ca.st->last_canon)[i];
-        cm = fr_to_mont_outlined(c);
+        cm = pipe_challenge_mont(a.ca.st, a.ca.round - 1);
         if (wg == 0 && tid == 0) store_fr(a.ca.challenges, a.fold_round, cm);           // whoever folds by a challenge files its Montgomery form
     }
     if (tid < n_groups * 5) (&ps.raw[0][0])[tid] = Fr::zero();
-    const uint32_t n_slots = 3 * meta.n_terms;
+    __shared__ PipeTileTabs tb;                                        // (indexed by slot at run time: LDS, not registers)
+    if (tid < PIPE_GROUPS) {
+        const uint32_t p = tid / 3, w = tid - 3 * p;
+        const bool on = p < meta.n_terms;
+        tb.src[tid] = !on ? nullptr : w < 2 ? a.tabs.t[p].in[w] : a.tabs.t[p].lin_in;
+        tb.dst[tid] = !on ? nullptr : w < 2 ? a.tabs.t[p].out[w] : a.tabs.t[p].lin_out;
+    }
     const size_t n_tiles = (q + PIPE_TILE - 1) / PIPE_TILE;
-    for (size_t tile_i = wg; tile_i < n_tiles; tile_i += n_cross) {
-        const size_t j0 = tile_i * PIPE_TILE;
-        const uint32_t J = (uint32_t)((q - j0) < PIPE_TILE ? (q - j0) : PIPE_TILE);
-        __syncthreads();                                                // the previous tile's products are done with the LDS tile
-        // phase 1: the tile of every table, folded on the way in (all loads of a lane are issued before its first product)
-        const uint32_t units = n_slots * 4 * PIPE_TILE;
-        for (uint32_t u0 = tid; u0 < units; u0 += 2 * PIPE_BLOCK) {
-            Fr lo[2], hi[2];
-            bool live[2];
-            uint32_t slot[2], b[2], jj[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const uint32_t u = u0 + k * PIPE_BLOCK;
-                slot[k] = u / (4 * PIPE_TILE); b[k] = (u / PIPE_TILE) & 3; jj[k] = u & (PIPE_TILE - 1);
-                const uint32_t p = slot[k] / 3, w = slot[k] - 3 * p;
-                const uint64_t* src = u < units ? (w < 2 ? a.tabs.t[p].in[w] : a.tabs.t[p].lin_in) : nullptr;
-                live[k] = src != nullptr && jj[k] < J;
-                lo[k] = hi[k] = Fr::zero();
-                if (live[k]) {
-                    const size_t x = j0 + jj[k] + (size_t)b[k] * q;
-                    lo[k] = load_fr(src, x);
-                    if (a.fold) hi[k] = load_fr(src, x + cn);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const uint32_t u = u0 + k * PIPE_BLOCK;
-                if (u >= units) continue;
-                Fr v = lo[k];
-                if (live[k] && a.fold) {
-                    v = lo[k] + fr_mul_outlined(cm, hi[k] - lo[k]);
-                    const uint32_t p = slot[k] / 3, w = slot[k] - 3 * p;
-                    uint64_t* dst = w < 2 ? a.tabs.t[p].out[w] : a.tabs.t[p].lin_out;
-                    store_fr(dst, j0 + jj[k] + (size_t)b[k] * q, v);
-                }
-                lds_store_fr(tile, (slot[k] * 4 + b[k]) * PIPE_TILE + jj[k], v);       // lanes past the table hold zero
-            }
-        }
-        __syncthreads();
-        // phase 2: jobs (group (p, t), kind) spread over all waves: one product per index and a wave sum each (kind 3: the additive table)
-        for (uint32_t job = wave; job < 4 * n_groups; job += PIPE_BLOCK / 64) {
-            const uint32_t g = job >> 2, kind = job & 3, p = g / 3, t = g - 3 * p;
-            if (kind < 3) {
-                const uint32_t* ta = tile + 8 * (size_t)(3 * p) * 4 * PIPE_TILE;
-                const uint32_t* tb = tile + 8 * (size_t)(3 * p + 1) * 4 * PIPE_TILE;
-                const Fr v = seg_sum_fr(fr_mul_outlined(pipe_operand(ta, PIPE_TILE, t, kind, lane), pipe_operand(tb, PIPE_TILE, t, kind, lane)), 64);
-                if (lane == 63) ps.raw[g][kind] = ps.raw[g][kind] + v;
-            } else if (a.tabs.t[p].lin_in != nullptr) {
-                const uint32_t* tl = tile + 8 * (size_t)(3 * p + 2) * 4 * PIPE_TILE;
-                const FrPair l = pipe_lin(tl, PIPE_TILE, t, lane);
-                const Fr v = seg_sum_fr(l.a, 64), v2 = seg_sum_fr(l.b, 64);
-                if (lane == 63) { ps.raw[g][3] = ps.raw[g][3] + v; ps.raw[g][4] = ps.raw[g][4] + v2; }
-            }
-        }
-    }
+    if (wg == 0) ZK_STAMP_AT(0, 32 + (a.ca.round & 31), 1);
+    for (size_t tile_i = wg; tile_i < n_tiles; tile_i += n_cross) pipe_cross_tile(tb, meta.n_terms, cn, a.fold != 0, cm, tile_i, tile, ps);
     __syncthreads();
-    // the workgroup's record: F0 canonical, F1 Montgomery, F2 x R^2 (one product for all)
-    if (tid < 3 * n_groups) {
-        const uint32_t g = tid / 3, l = tid - 3 * g;
-        const Fr s0 = ps.raw[g][0], sk = ps.raw[g][1], s2 = ps.raw[g][2], l0 = ps.raw[g][3], l1 = ps.raw[g][4];
-        const Fr val = l == 0 ? s0 + l0 : l == 1 ? ((sk - s0) - s2) + l1 : s2;
-        Fr k;
-#pragma unroll
-        for (int i = 0; i < Fr::N; ++i) k.l[i] = l == 0 ? (i == 0 ? 1u : 0u) : l == 1 ? FrParams::r1(i) : FrParams::r2(i);
-        store_fr(a.records_out, (size_t)wg * 3 * n_groups + tid, fr_mul_outlined(val, k));
-    }
+    if (wg == 0) ZK_STAMP_AT(0, 32 + (a.ca.round & 31), 2);
+    pipe_write_record(ps, n_groups, a.records_out, wg);
+    if (wg == 0) ZK_STAMP_AT(0, 32 + (a.ca.round & 31), 3);
 }
 
 }  // namespace zk
