@@ -679,7 +679,7 @@ def bench_prediction(args, zk, N, torch, np, dist_mod, exchange):
                                    "streaming rounds shrink 8-fold, the serial rounds and launches do not)"}
     # commit, BASELINE configs[4]: 2^23 points per GPU + one 104-byte all-gather whose result the host reads
     out["commit_2^23_per_gpu"] = {"exchanges": 1, "exchange_us_with_host_wait": round(x8h, 1),
-                                  "note": "t_local = the 2^23-point commit of `msm` run with --msm-log-n 23 (21.9 ms in round 2); predicted = t_local + exchange"}
+                                  "note": "t_local = the 2^23-point commit of `msm` run with --msm-log-n 23 (21.9 ms when last measured); predicted = t_local + exchange"}
     return out
 
 

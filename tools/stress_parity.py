@@ -149,7 +149,12 @@ def case_open():
         _srs[nv] = (zk.TrustedSetup.setup(tau), ora.kzg_multilinear_srs_g1(tau))
     srs, osrs = _srs[nv]
     v, z = ora.random_fr(1 << nv, rng.randrange(1 << 30)), ora.random_fr(nv, rng.randrange(1 << 30))
-    proof = zk.MultilinearKZG.open(zk.Multilinear(v), z, srs, cache_folded_srs=rng.random() < 0.5)
+    mode = rng.random()          # a third each: folded levels derived per call / cached / cached with their shifted tables
+    if mode < 0.33:
+        srs.precompute_open()
+    elif srs.level_tables is not None:
+        srs.invalidate()
+    proof = zk.MultilinearKZG.open(zk.Multilinear(v), z, srs, cache_folded_srs=mode < 0.66)
     want_ev, want_proofs = ora.kzg_open(v, z, osrs)
     ok = np.array_equal(proof.evaluation, want_ev)
     for got, w in zip(proof.proofs, want_proofs):

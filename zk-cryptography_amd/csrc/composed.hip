@@ -535,13 +535,18 @@ struct ComposedRun {
     // the first `rounds` recorded rounds (of this call and the calls it continued) to the host
     static int collect_rounds(zkhip_ctx* c, int multi, uint32_t k0, uint32_t n_rounds, uint32_t* h_lens, uint64_t* h_round_polys,
                               uint64_t* h_challenges) {
-        const uint64_t* d_rp = c->small_u64(ZK_SMALL_ROUNDPOLYS);
+        // ONE copy into pinned memory: the challenges and the recorded rounds are neighbours in the context's small buffer.  (Two copies into
+        // the caller's pageable buffers were two staged, host-blocking transfers behind the last kernel of every proof and GKR layer.)
+        static_assert(ZK_SMALL_ROUNDPOLYS == ZK_SMALL_CHALLENGES + 4 * ZK_MAX_ROUNDS, "challenges | round polynomials, adjacent");
+        static_assert(ZK_PIN_END - ZK_PIN_PROOF >= 4 * ZK_MAX_ROUNDS + 64 * ZK_MAX_ROUNDS, "pinned proof area too small");
+        if (n_rounds > (uint32_t)ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
         const uint64_t* d_ch = c->small_u64(ZK_SMALL_CHALLENGES);
         const uint32_t term_sizes[1] = {k0};
-        std::vector<uint64_t> h_rp(64 * (size_t)n_rounds);
-        ZK_HIP(c, hipMemcpyAsync(h_rp.data(), d_rp, 64 * 8 * (size_t)n_rounds, hipMemcpyDeviceToHost, c->stream));
-        ZK_HIP(c, hipMemcpyAsync(h_challenges, d_ch, 32 * (size_t)n_rounds, hipMemcpyDeviceToHost, c->stream));
+        uint64_t* pin = c->pinned_u64(ZK_PIN_PROOF);
+        ZK_HIP(c, hipMemcpyAsync(pin, d_ch, 8 * (4 * (size_t)ZK_MAX_ROUNDS + 64 * (size_t)n_rounds), hipMemcpyDeviceToHost, c->stream));
         ZK_HIP(c, hipStreamSynchronize(c->stream));
+        std::memcpy(h_challenges, pin, 32 * (size_t)n_rounds);
+        const uint64_t* h_rp = pin + 4 * ZK_MAX_ROUNDS;
         for (uint32_t r = 0; r < n_rounds; ++r) {
             if (!multi) {
                 std::memcpy(h_round_polys + (size_t)r * (term_sizes[0] + 1) * 4, &h_rp[64 * r], (term_sizes[0] + 1) * 32);

@@ -66,7 +66,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void fold_kernel(const uint64_t* 
         const bool has2 = j2 < n_out;
         const size_t i1 = fold_lo_index(j, log_half);
         const size_t i2 = has2 ? fold_lo_index(j2, log_half) : i1;
-        Fr a1 = load_fr(in, i1), b1 = load_fr(in, i1 + half_in);      // (non-temporal loads measured in round 4: 144.2 us either way at 2^24)
+        Fr a1 = load_fr(in, i1), b1 = load_fr(in, i1 + half_in);      // (non-temporal loads measured: 144.2 us either way at 2^24)
         Fr a2 = load_fr(in, i2), b2 = load_fr(in, i2 + half_in);
         Fr o1 = fold_pair(a1, b1, r);
         store_fr(out, j, o1);

@@ -240,7 +240,7 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_sort_scatter_kernel(cons
 // Heavy buckets (pass 4 below walks a bucket with one lane): a bucket holding more than `heavy_min` points is filed as records of
 // <= 2048 points for pass 4b, where a whole workgroup sums a record (<= 8 points per lane, then a tree in LDS), and, when the bucket
 // spans several records, as a tree of <= 256-way sums over the record sums for pass 4c.  With uniform scalars no bucket is heavy.
-constexpr uint32_t MSM_HEAVY_LANE_MAX = 8;                        // points per lane inside a record (32 in rounds 1-3: the pass is a latency chain of that many additions plus the tree)
+constexpr uint32_t MSM_HEAVY_LANE_MAX = 8;                        // points per lane inside a record (32 at first: the pass is a latency chain of that many additions plus the tree)
 constexpr uint32_t MSM_HEAVY_REC = MSM_BLOCK * MSM_HEAVY_LANE_MAX;   // points per record
 constexpr int MSM_HEAVY_LEVELS = 4;                               // 0: records of points; 1..3: 256-way sums of sums
 struct MsmHeavyRec {

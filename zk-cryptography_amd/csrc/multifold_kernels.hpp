@@ -60,7 +60,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void group_sums_kernel(const uint
 // ---- fine block sums for the overlapped plan -------------------------------------------------------------
 // sums[c] = sum of the c-th run of FINE_CHUNK consecutive entries.  A wave owns two adjacent runs (8 loads of 2 KiB in flight per
 // wave); no loop, the grid covers the table (n / (8 FINE_CHUNK) workgroups).
-// Round 4 probes (tools/ubench_fine.hip + tools/ab_fine.sh, 2^24 entries, same box; profiles/r04/NOTES.md): the loads alone take
+// Probes (tools/ubench_fine.hip and in-situ A/Bs, 2^24 entries, same box; profiles/r04/NOTES.md): the loads alone take
 // 82.2-82.5 us non-temporal, 85.9 plain; this kernel 90.3-91.0.  Its two runs half a table apart + non-temporal loads: 87.1-87.7 in
 // isolation, but in the prover the k-variable fold behind it then ran 95 instead of 84 us (it had been finding the tail of THIS pass in
 // the 256 MiB Infinity Cache) and the step did not move.  Four runs per wave, waves permuted by strides of 2^3..2^12 runs: 88-96 us.

@@ -584,7 +584,7 @@ static int launch_fine_sums(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uin
     const size_t blk = n >> lb, n_chunks = n / FINE_CHUNK;
     uint64_t* first = blk == (size_t)FINE_CHUNK ? d_fine : d_chunk;
     {
-        // (measured and dropped in round 3: waves that stay and loop over run pairs with the next pair's loads in flight -- 100-115 us
+        // (measured and dropped: waves that stay and loop over run pairs with the next pair's loads in flight -- 100-115 us
         // against 94-96 us for this one-shot form at 2^24; the loads alone take 81 us, tools/ubench_rows.hip "pieces")
         ProfScope ps(c, "fine_sums", 32.0 * (double)n, stream);
         hipLaunchKernelGGL(fine_sums_kernel, dim3((unsigned)((n_chunks + 7) / 8)), dim3(MLE_BLOCK), 0, stream, d_evals, n_chunks, first);
