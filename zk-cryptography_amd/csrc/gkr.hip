@@ -473,8 +473,9 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
     zkhost::Transcript tr;
     ZK_HIP(c, hipMemsetAsync(d_w0, 0, 64, c->stream));
     ZK_HIP(c, hipMemcpyAsync(d_w0, h_layer_ptrs[0], 32, hipMemcpyDeviceToDevice, c->stream));
-    ZK_HIP(c, hipMemcpyAsync(h_w0, d_w0, 64, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_w0, 64, hipMemcpyDeviceToHost, c->stream));   // (pinned: a copy into the caller's pageable buffer is staged)
     ZK_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(h_w0, c->pinned_u64(ZK_PIN_RES), 64);
     {
         zkhost::Fr one_canon = zkhost::fr_zero();
         one_canon.l[0] = 1;
@@ -490,7 +491,11 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
     }
     std::vector<zkhost::Fr> n_r(1, tr.challenge_fr());               // evaluate_n_challenge_into_field(&w_0_mle.n_vars)
     zkhost::Fr claimed;
-    ZK_TRY(zkhip_mle_evaluation(c, d_w0, 2, n_r[0].l, 1, claimed.l));
+    {   // w_0_mle.evaluation(&n_r) of the two-entry table [w, 0]: w + n_r (0 - w), on the host (no launch, no wait)
+        zkhost::Fr w;
+        std::memcpy(w.l, h_w0, 32);
+        claimed = zkhost::fr_sub(w, zkhost::fr_mul(n_r[0], w));
+    }
 
     zkhost::Fr alpha = zkhost::fr_one(), beta = zkhost::fr_zero();
     std::vector<zkhost::Fr> r_b, r_c;
@@ -621,8 +626,9 @@ extern "C" int zkhip_gkr_prove_sharded(zkhip_circuit* cir, zkhip_comm* comm, con
     zkhost::Transcript tr;
     ZK_HIP(c, hipMemsetAsync(d_w0, 0, 64, c->stream));
     ZK_HIP(c, hipMemcpyAsync(d_w0, h_layer_ptrs[0], 32, hipMemcpyDeviceToDevice, c->stream));
-    ZK_HIP(c, hipMemcpyAsync(h_w0, d_w0, 64, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), d_w0, 64, hipMemcpyDeviceToHost, c->stream));   // (pinned: a copy into the caller's pageable buffer is staged)
     ZK_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(h_w0, c->pinned_u64(ZK_PIN_RES), 64);
     {
         zkhost::Fr one_canon = zkhost::fr_zero();
         one_canon.l[0] = 1;
@@ -638,7 +644,11 @@ extern "C" int zkhip_gkr_prove_sharded(zkhip_circuit* cir, zkhip_comm* comm, con
     }
     std::vector<zkhost::Fr> r_b(1, tr.challenge_fr()), r_c;          // evaluate_n_challenge_into_field(&w_0_mle.n_vars)
     zkhost::Fr claimed;
-    ZK_TRY(zkhip_mle_evaluation(c, d_w0, 2, r_b[0].l, 1, claimed.l));
+    {   // w_0_mle.evaluation(&n_r) of the two-entry table [w, 0]: w + n_r (0 - w), on the host (no launch, no wait)
+        zkhost::Fr w;
+        std::memcpy(w.l, h_w0, 32);
+        claimed = zkhost::fr_sub(w, zkhost::fr_mul(r_b[0], w));
+    }
     zkhost::Fr alpha = zkhost::fr_one(), beta = zkhost::fr_zero();
 
     int rc = ZKHIP_OK;
