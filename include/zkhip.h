@@ -454,6 +454,11 @@ int zkhip_kzg_commit(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t 
  * bucket reduction.  The table depends on the SRS only (built once, ~70 ms at 2^20); zkhip_kzg_commit_table then has the
  * semantics of zkhip_kzg_commit (same group element, same errors).  n * 13 must stay below 2^31. */
 size_t zkhip_srs_table_bytes(size_t n_points);
+/* Content check for a host-side cache of what is derived from an SRS (the table above, the folded levels): the first two and the last
+ * two points with their infinity flags, h_out[52] = 4 x (12 coordinate words, flag) -- one small launch, one copy, ~20 us.  A wrapper
+ * that keeps such caches compares it before every use to catch writes into the SRS buffers that its own bookkeeping cannot see. */
+int zkhip_srs_fingerprint(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t *d_points_inf, size_t n_points,
+                          uint64_t *h_out);
 int zkhip_srs_precompute(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t *d_points_inf, size_t n_points,
                          void *d_table);
 int zkhip_kzg_commit_table(zkhip_ctx *ctx, const void *d_table, const uint8_t *d_points_inf, size_t n_points,

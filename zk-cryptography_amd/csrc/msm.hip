@@ -350,6 +350,30 @@ extern "C" int zkhip_kzg_commit_end(zkhip_ctx* c, uint32_t ticket, uint64_t* h_o
 }
 
 // ---------------------------------------------------------------------------------------
+// SRS fingerprint: the first two and last two points with their infinity flags, in ONE launch and ONE copy
+// ---------------------------------------------------------------------------------------
+static __global__ void srs_fingerprint_kernel(const uint64_t* __restrict__ xy, const uint8_t* __restrict__ inf, size_t n, uint64_t* __restrict__ out) {
+    const uint32_t t = threadIdx.x;                 // 52 threads: 4 points x (12 words + 1 flag)
+    if (t >= 52) return;
+    const uint32_t k = t / 13, w = t - 13 * k;
+    const size_t idx[4] = {(size_t)0, n > 1 ? (size_t)1 : (size_t)0, n > 1 ? n - 2 : (size_t)0, n - 1};
+    out[t] = w < 12 ? xy[12 * idx[k] + w] : (inf ? (uint64_t)inf[idx[k]] : 0);
+}
+extern "C" int zkhip_srs_fingerprint(zkhip_ctx* c, const uint64_t* d_points_xy, const uint8_t* d_points_inf, size_t n_points, uint64_t* h_out) {
+    if (!c || !d_points_xy || !h_out) return ZKHIP_ERR_ARG;
+    if (n_points == 0) { std::memset(h_out, 0, 52 * 8); return ZKHIP_OK; }
+    ZK_TRY(c->activate());
+    if (!c->d_fingerprint) ZK_HIP(c, hipMalloc(&c->d_fingerprint, 512));      // a buffer of its own: commits in flight hold the workspace
+    uint64_t* pin = c->pinned_u64(ZK_PIN_PTS);      // (evaluation points' staging area: no prover runs during this call)
+    static_assert(ZK_PIN_PROOF - ZK_PIN_PTS >= 52, "staging area too small");
+    hipLaunchKernelGGL(srs_fingerprint_kernel, dim3(1), dim3(64), 0, c->stream, d_points_xy, d_points_inf, n_points, (uint64_t*)c->d_fingerprint);
+    ZK_HIP(c, hipMemcpyAsync(pin, c->d_fingerprint, 52 * 8, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(h_out, pin, 52 * 8);
+    return ZKHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // shifted-SRS table: commitments with one bucket set for all windows
 // ---------------------------------------------------------------------------------------
 extern "C" size_t zkhip_srs_table_bytes(size_t n_points) { return n_points * MSM_TABLE_WINDOWS * 128; }

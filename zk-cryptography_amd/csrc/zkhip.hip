@@ -70,6 +70,7 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     if (c->d_aux) hipFree(c->d_aux);
     if (c->d_gen_table) hipFree(c->d_gen_table);
     if (c->d_composed) hipFree(c->d_composed);
+    if (c->d_fingerprint) hipFree(c->d_fingerprint);
     if (c->ntt_state && c->ntt_free) c->ntt_free(c->ntt_state);
     for (int i = 0; i < zkhip_ctx::MSM_SLOTS; ++i) {
         if (c->msm_pin[i]) hipHostFree(c->msm_pin[i]);

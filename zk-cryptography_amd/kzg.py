@@ -101,15 +101,15 @@ class TrustedSetup:
     def _fingerprint(self):
         """Content check for what the stamp cannot see -- writes through raw pointers (a kernel filling the tensors via data_ptr())
         and a new tensor that landed on the same address with the same shape and version: the first and last two points and their
-        infinity flags (one small device->host copy, ~20 us against a >= 1 ms commitment)."""
-        import torch
+        infinity flags (zkhip_srs_fingerprint: one small launch and one copy, ~20 us against a >= 1 ms commitment)."""
         p, i = self.powers_of_tau_in_g1, self.inf
         n = p.shape[0]
         if n == 0:
             return b""
-        idx = sorted({0, min(1, n - 1), max(n - 2, 0), n - 1})
-        sel = torch.tensor(idx, device=p.device)
-        return p.index_select(0, sel).cpu().numpy().tobytes() + i.index_select(0, sel).cpu().numpy().tobytes()
+        out = np.empty(52, dtype=np.uint64)
+        ctx = N.Context.get(p.device.index)
+        N.check(N.lib().zkhip_srs_fingerprint(ctx.handle, N.ptr(p), N.ptr(i), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)), "srs_fingerprint")
+        return out.tobytes()
 
     def invalidate(self):
         """Drops the shifted table and the folded levels (call after writing the SRS through raw pointers; commitments in flight
@@ -305,7 +305,7 @@ class MultilinearKZG:
         if cache_folded_srs and len(srs) == n and n >= 4 and n & (n - 1) == 0:
             fxy, finf = srs.folded()
             fxy_p, finf_p = N.ptr(fxy), N.ptr(finf)
-            tables = srs.level_tables          # present after srs.precompute_open()
+            tables = getattr(srs, "_level_tables", None)       # present after srs.precompute_open(); folded() has just run the cache guard
         else:
             fxy_p = finf_p = None
         st = N.lib().zkhip_kzg_open_tables(ctx.handle, N.ptr(poly.evaluations), C.c_size_t(n), pts.ctypes.data_as(C.c_void_p),
