@@ -46,6 +46,13 @@ static void test_fr() {
         if (it < 4) { std::memset(&a, 0, sizeof a); if (it & 1) ora_fr_from_u64(&b, 1); }       // zero, one
         ora_fr_mul(&w, &a, &b); EXPECT(eq(zkhost::fr_mul(H(a), H(b)), w)); mix(&w, 32);
         ora_fr_add(&w, &a, &b); EXPECT(eq(zkhost::fr_add(H(a), H(b)), w));
+        {   // out of Montgomery form: the reduction-only form against a product by the integer 1, and its big-endian bytes
+            zkhost::Fr one_int = zkhost::fr_zero(); one_int.l[0] = 1;
+            const zkhost::Fr c = zkhost::fr_mul(H(a), one_int), c2 = zkhost::fr_from_mont(H(a));
+            EXPECT(std::memcmp(c.l, c2.l, 32) == 0);
+            uint8_t be[32]; zkhost::fr_mont_to_be(a.l, be);
+            for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) EXPECT(be[8 * i + j] == (uint8_t)(c.l[3 - i] >> (56 - 8 * j)));
+        }
         ora_fr_sub(&w, &a, &b); EXPECT(eq(zkhost::fr_sub(H(a), H(b)), w));
         if (it % 50 == 5 && ora_fr_inv(&w, &a)) { EXPECT(eq(zkhost::fr_inv(H(a)), w)); mix(&w, 32); }
         fr_t u; ora_fr_from_u64(&u, (uint64_t)it * 977); EXPECT(eq(zkhost::fr_from_u64((uint64_t)it * 977), u));

@@ -248,20 +248,13 @@ struct LayerOut {
 // to_bytes of a ComposedSumcheckProof (multi_composed_sumcheck.rs:24-31): per round, per monomial coeff || pow as
 // 32-byte big-endian canonical integers (sparse_univariate.rs:27-34)
 void absorb_proof(zkhost::Transcript& tr, const uint64_t* polys, const uint32_t* lens, uint32_t n_rounds) {
-    zkhost::Fr one_canon = zkhost::fr_zero();
-    one_canon.l[0] = 1;
+    uint8_t be[GKR_MONO * 64];                            // one round's bytes, one update per round
     for (uint32_t r = 0; r < n_rounds; ++r) {
-        for (uint32_t m = 0; m < lens[r]; ++m) {
-            for (int part = 0; part < 2; ++part) {
-                zkhost::Fr v;
-                std::memcpy(v.l, polys + ((size_t)r * GKR_MONO + m) * 8 + 4 * part, 32);
-                const zkhost::Fr c = zkhost::fr_mul(v, one_canon);   // out of Montgomery form
-                uint8_t be[32];
-                for (int i = 0; i < 4; ++i)
-                    for (int j = 0; j < 8; ++j) be[8 * i + j] = (uint8_t)(c.l[3 - i] >> (56 - 8 * j));
-                tr.commit(be, 32);
-            }
-        }
+        const uint32_t n_mono = lens[r] <= (uint32_t)GKR_MONO ? lens[r] : (uint32_t)GKR_MONO;
+        for (uint32_t m = 0; m < n_mono; ++m)
+            for (int part = 0; part < 2; ++part)
+                zkhost::fr_mont_to_be(polys + ((size_t)r * GKR_MONO + m) * 8 + 4 * part, be + 64 * m + 32 * part);
+        tr.commit(be, 64 * (size_t)n_mono);
     }
 }
 

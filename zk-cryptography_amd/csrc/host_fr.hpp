@@ -57,6 +57,25 @@ inline Fr fr_mul(const Fr& a, const Fr& b) {
     if (t[4] || fr_geq_p(t)) fr_sub_p(t);
     Fr r; memcpy(r.l, t, 32); return r;
 }
+// out of Montgomery form: four reduction steps on (a, 0) -- half the products of fr_mul(a, 1); canonical (< r)
+inline Fr fr_from_mont(const Fr& a) {
+    uint64_t t[5] = {a.l[0], a.l[1], a.l[2], a.l[3], 0};
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t m = t[0] * FR_INV;
+        u128 s = (u128)m * FR_P[0] + t[0];
+        uint64_t c = (uint64_t)(s >> 64);
+        for (int j = 1; j < 4; ++j) { s = (u128)m * FR_P[j] + t[j] + c; t[j - 1] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+        t[3] = c;
+    }
+    if (fr_geq_p(t)) fr_sub_p(t);
+    Fr r; memcpy(r.l, t, 32); return r;
+}
+// the canonical integer of a Montgomery-form element as 32 big-endian bytes (Fr::into_bigint().to_bytes_be())
+inline void fr_mont_to_be(const uint64_t* mont, uint8_t* be) {
+    Fr v; memcpy(v.l, mont, 32);
+    const Fr c = fr_from_mont(v);
+    for (int i = 0; i < 4; ++i) { const uint64_t w = __builtin_bswap64(c.l[3 - i]); memcpy(be + 8 * i, &w, 8); }
+}
 inline Fr fr_from_u64(uint64_t v) { Fr c = fr_zero(); c.l[0] = v; Fr r2; memcpy(r2.l, FR_R2, 32); return fr_mul(c, r2); }
 inline Fr fr_inv(const Fr& a) {   // Fermat
     uint64_t e[4]; memcpy(e, FR_P, 32); e[0] -= 2;
