@@ -65,7 +65,12 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_rows_kernel(const u
                                                                   uint64_t* __restrict__ lin_out, uint64_t* __restrict__ mul_out,
                                                                   const uint64_t* __restrict__ v, const uint64_t* __restrict__ vu_ptr,
                                                                   uint64_t* __restrict__ t1, uint64_t* __restrict__ t2,
-                                                                  uint32_t row_stride = 1, uint32_t row_first = 0, uint64_t* __restrict__ v_shard = nullptr) {
+                                                                  uint32_t row_stride = 1, uint32_t row_first = 0, uint64_t* __restrict__ v_shard = nullptr,
+                                                                  const uint64_t* __restrict__ eq_b = nullptr, const uint64_t* __restrict__ eq_c = nullptr,
+                                                                  FrArg alpha_v = FrArg(), FrArg beta_v = FrArg(), uint64_t* __restrict__ wg_out = nullptr) {
+    // eq_b (phase 1 of a single-GPU proof, every gate visited exactly once): the gate weights are formed HERE from the previous layer's two
+    // eq tables -- w_g = alpha eq_g(r_b) + beta eq_g(r_c), the tables that layer built for its own second phase and for w_c -- and
+    // filed in wg_out for phase 2: no weight launches per layer
     const uint32_t j = blockIdx.x * MLE_BLOCK + threadIdx.x;
     if (j >= n_rows) return;
     const uint32_t x = j * row_stride + row_first;
@@ -78,7 +83,13 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_rows_kernel(const u
     Fr a = Fr::zero(), l = Fr::zero(), m = Fr::zero();
     for (uint32_t q = row_off[x]; q < row_off[x + 1]; ++q) {
         const uint32_t g = ids[q];
-        const Fr w = load_fr(wg, g);
+        Fr w;
+        if (eq_b) {
+            w = fr_from_arg(alpha_v) * load_fr(eq_b, g) + fr_from_arg(beta_v) * load_fr(eq_c, g);
+            store_fr(wg_out, g, w);
+        } else {
+            w = load_fr(wg, g);
+        }
         const Fr wf = w * load_fr(factor, other_in[g]);     // phase 1: w_g V[in1];  phase 2: w_g eq_u[in0]
         if (gate_type[g]) m = m + wf;
         else if (phase == 1) { a = a + w; l = l + wf; }
@@ -269,7 +280,7 @@ static void group_gates(const uint32_t* key, size_t n_gates, size_t n_rows, std:
 
 // device scratch of one layer (carved from the context's aux buffer)
 struct LayerScratch {
-    uint64_t *wg, *ha0, *ha1, *hm, *equ, *aa, *am, *t1, *t2;
+    uint64_t *wg, *ha0, *ha1, *hm, *equ, *eqc, *aa, *am, *t1, *t2;   // equ / eqc: eq(r_b) and eq(r_c) of the layer just proved (the next layer's gate weights)
     uint64_t* eqh;                    // halves of the eq tables of wide layers (2 points x GKR_EQ_HALVES entries)
     uint64_t *dot_partials, *evals;   // workgroup shares of <eq, V>; evals[0..4) = V(u) = w_b, evals[4..8) = V(r_c) = w_c
 };
@@ -300,10 +311,14 @@ int layer_prove(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_
     std::memcpy(av.v, alpha.l, 32);
     std::memcpy(bv.v, beta.l, 32);
     const unsigned gw = (unsigned)((w_len + MLE_BLOCK - 1) / MLE_BLOCK);
-    launch_gate_weights(c, n_gates, n_gate_vars, pb, pc, av, bv, two_points, sc.eqh, sc.wg);
+    // gate weights: the first layer's from n_r (host); every other layer's inside its first row pass, from the eq tables of r_b and r_c
+    // that the layer before left in sc.equ / sc.eqc (2^l entries: the gate index has l bits)
+    const bool weights_on_the_fly = two_points && n_gates <= ((size_t)1 << n_gate_vars);
+    if (!weights_on_the_fly) launch_gate_weights(c, n_gates, n_gate_vars, pb, pc, av, bv, two_points, sc.eqh, sc.wg);
     // ---- rounds over b
     hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr0, ld.csr0 + w_len + 1, ld.type, ld.in1, sc.wg, d_w,
-                       (uint32_t)w_len, 1u, sc.ha0, sc.ha1, sc.hm, (const uint64_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr);
+                       (uint32_t)w_len, 1u, sc.ha0, sc.ha1, sc.hm, (const uint64_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr,
+                       1u, 0u, (uint64_t*)nullptr, weights_on_the_fly ? (const uint64_t*)sc.equ : (const uint64_t*)nullptr, (const uint64_t*)sc.eqc, av, bv, sc.wg);
     ZK_HIP(c, hipGetLastError());
     // Everything up to the end of the layer's sumcheck is enqueued without waiting for the host: the rounds over c read the
     // challenges of the rounds over b, V(u) and the eq table from device memory, the two composed-prover calls append to one
@@ -328,8 +343,8 @@ int layer_prove(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_
         const uint64_t* tables[4] = {sc.aa, sc.t1, sc.am, sc.t2};        // [add~(u, c), V(u) + V(c)],  [mul~(u, c), V(u) V(c)]
         ZK_TRY(zk_multi_composed_enqueue(c, tables, sizes, nullptr, 2, w_len, nullptr, 1, s));
     }
-    // w_c = V(r_c), r_c = the second half of the challenges
-    launch_eq_table(c, d_ch + 4 * (size_t)s, s, sc.eqh, sc.equ, d_w, sc.dot_partials, sc.evals + 4);
+    // w_c = V(r_c), r_c = the second half of the challenges (its eq table stays for the next layer's gate weights, beside eq(u) = eq(r_b))
+    launch_eq_table(c, d_ch + 4 * (size_t)s, s, sc.eqh, sc.eqc, d_w, sc.dot_partials, sc.evals + 4);
     ZK_HIP(c, hipGetLastError());
     zkhost::Fr eval_wb, eval_wc;
     ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), sc.evals, 64, hipMemcpyDeviceToHost, c->stream));
@@ -444,12 +459,12 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
     for (uint32_t k = 1; k <= n_layers; ++k)
         if (!is_pow2(h_layer_len[k])) return ZKHIP_ERR_SHAPE;  // Multilinear::new (evaluation_form.rs:16-20)
     ZK_TRY(c->activate());
-    // aux layout: w_0 (2) | eight tables of the widest layer | gate weights
+    // aux layout: w_0 (2) | nine tables of the widest layer | gate weights
     size_t max_w = 0, max_g = 0;
     for (uint32_t l = 0; l < n_layers; ++l) { max_w = std::max(max_w, h_layer_len[l + 1]); max_g = std::max(max_g, cir->layers[l].n_gates); }
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t tb = al(32 * max_w);
-    const size_t o_w0 = 0, o_tab = al(64), o_wg = o_tab + 8 * tb, o_dot = o_wg + al(32 * max_g), o_ev = o_dot + al(32 * (size_t)zk::MLE_MAX_GRID);
+    const size_t o_w0 = 0, o_tab = al(64), o_wg = o_tab + 9 * tb, o_dot = o_wg + al(32 * max_g), o_ev = o_dot + al(32 * (size_t)zk::MLE_MAX_GRID);
     const size_t o_eqh = o_ev + 256;
     ZK_TRY(c->reserve_aux(o_eqh + 32 * 2 * (size_t)zk::GKR_EQ_HALVES));
     char* aux = (char*)c->d_aux;
@@ -457,7 +472,7 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
     LayerScratch sc;
     sc.ha0 = (uint64_t*)(aux + o_tab); sc.ha1 = (uint64_t*)(aux + o_tab + tb); sc.hm = (uint64_t*)(aux + o_tab + 2 * tb);
     sc.equ = (uint64_t*)(aux + o_tab + 3 * tb); sc.aa = (uint64_t*)(aux + o_tab + 4 * tb); sc.am = (uint64_t*)(aux + o_tab + 5 * tb);
-    sc.t1 = (uint64_t*)(aux + o_tab + 6 * tb); sc.t2 = (uint64_t*)(aux + o_tab + 7 * tb);
+    sc.t1 = (uint64_t*)(aux + o_tab + 6 * tb); sc.t2 = (uint64_t*)(aux + o_tab + 7 * tb); sc.eqc = (uint64_t*)(aux + o_tab + 8 * tb);
     sc.wg = (uint64_t*)(aux + o_wg);
     sc.dot_partials = (uint64_t*)(aux + o_dot); sc.evals = (uint64_t*)(aux + o_ev); sc.eqh = (uint64_t*)(aux + o_eqh);
     LayerOut out = {h_sums, h_round_polys, h_wb, h_wc, h_challenges, h_n_rounds, h_round_poly_lens, 2 * n_layers};
