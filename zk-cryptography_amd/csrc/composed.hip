@@ -366,7 +366,11 @@ struct ComposedRun {
         sa.weights_out = d_stage_w;
         {
             ProfScope ps(c, "composed_stage_close", 0.0);
-            hipLaunchKernelGGL(composed_stage_close_kernel, dim3(1), dim3(CST_BLOCK), 0, c->stream, records, sa);
+            // the second round one round ahead of the transcript (composed_pipe.hpp); ZKHIP_PIPE=0 keeps the round-by-round form (same-box A/B)
+            if (pipe_on() && pipe_eligible(meta))
+                hipLaunchKernelGGL(composed_stage_close_pipe_kernel, dim3(1), dim3(PIPE_BLOCK), 0, c->stream, records, sa);
+            else
+                hipLaunchKernelGGL(composed_stage_close_kernel, dim3(1), dim3(CST_BLOCK), 0, c->stream, records, sa);
         }
         first = 0;
         round += 2;

@@ -19,6 +19,7 @@
 // Critical path per round: two products + interpolation + message (~3 us) + the hash, against ~7 us + the hash.
 #pragma once
 #include "composed_kernels.hpp"
+#include "composed_stage.hpp"
 
 namespace zk {
 
@@ -483,8 +484,10 @@ static_assert(PIPE_TILE == 16 || PIPE_TILE == 32 || PIPE_TILE == 64, "a job is a
 
 // The closing half of a round, from sh.evals-free state: ps.forms (from_forms) or the canonical sums e (per thread < meta.rec) are in place.
 // Every thread of the workgroup calls; the challenge ends in sh.challenge_canon, the transcript in trs.
+struct PipeNothing { __device__ __forceinline__ void operator()() const {} };
+template <class Beside = PipeNothing>
 __device__ __forceinline__ void pipe_close_round(CloseShared& sh, PipeShared& ps, Sha256State& trs, const CloseArgs& ca, uint32_t round, uint32_t first,
-                                                 bool from_forms, const Fr& e) {
+                                                 bool from_forms, const Fr& e, Beside beside = Beside()) {
     const uint32_t wave = threadIdx.x >> 6;
     ZK_STAMP_AT(0, round, 6);
     ZK_STAMP_AT(0, round, 0);
@@ -504,6 +507,7 @@ __device__ __forceinline__ void pipe_close_round(CloseShared& sh, PipeShared& ps
     } else {
         pipe_schedules(sh);
         pipe_outputs(ps, ca.meta, ca.round_out, ca.challenges);
+        beside();                                    // (waves 1..: whatever else can be prepared while wave 0 hashes)
     }
     __syncthreads();
     ZK_STAMP_AT(0, round, 5);
@@ -661,6 +665,106 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(
     if (wg == 0) ZK_STAMP_AT(0, 32 + (a.ca.round & 31), 2);
     pipe_write_record(ps, n_groups, a.records_out, wg);
     if (wg == 0) ZK_STAMP_AT(0, 32 + (a.ca.round & 31), 3);
+}
+
+// ---- the serial kernel of a STAGE (two rounds per pass over large tables, composed_stage.hpp) in the same form ---------------------------
+// Round 1 closes from the cross sums; round 2's sums are the cross sums BOUND at round 1's challenge -- quadratics in it whose three
+// coefficients are plain sums of the cross sums (no products):
+//     C'[x][y](r) = C00 + r (C01 + C10 - 2 C00) + r^2 (C00 - C01 - C10 + C11),   C_ab = C[2a + x][2b + y];   L'[x](r) = L[x] + r (L[2 + x] - L[x])
+//     e_0 = C'[0][0] + L'[0],   e_1 = C'[1][1] + L'[1],   e_2 = C'[0][0] - 2 (C'[0][1] + C'[1][0]) + 4 C'[1][1] - L'[0] + 2 L'[1].
+// They are laid out as forms beside round 1's hash, so round 2 starts two products behind it (composed_stage_close_kernel: a bind three
+// products deep, then the sums, then the round-by-round closing: 53 us for the two rounds; here ~35).
+static __global__ __launch_bounds__(PIPE_BLOCK) void composed_stage_close_pipe_kernel(const uint64_t* __restrict__ partials, StageArgs sa) {
+    __shared__ CloseShared sh;
+    __shared__ PipeShared ps;
+    __shared__ Sha256State trs;
+    __shared__ Fr vals[CMP_MAX_TERMS][CST_VALS];
+    __shared__ Fr rsum[PIPE_BLOCK];
+    __shared__ Fr r1m;
+    const CloseArgs& ca = sa.ca;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t P = ca.meta.n_terms, n_vals = P * CST_VALS;
+    if (ca.first != 1 && tid < sizeof(Sha256State) / 4)
+        reinterpret_cast<uint32_t*>(&trs)[tid] = reinterpret_cast<const uint32_t*>(&ca.st->transcript)[tid];
+    if (tid == 0) { ps.prev_valid = 0; ps.out_n = 0; }
+    if (ca.meta.multi && ca.first && tid == 64) sh.sum_canon = fr_from_mont_outlined(fr_from_arg(ca.sum));   // multi_composed_sumcheck.rs:70
+    {   // the records: thread (value v, chunk) sums the records chunk, chunk + n_chunks, ... (eight loads in flight); the chunks are added in LDS
+        const uint32_t n_chunks = PIPE_BLOCK / n_vals, v = tid % n_vals, chunk = tid / n_vals;
+        Fr acc = Fr::zero();
+        if (chunk < n_chunks) {
+            for (uint32_t r0 = chunk; r0 < sa.n_records; r0 += 8 * n_chunks) {
+                Fr x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = r0 + u * n_chunks < sa.n_records ? load_fr(partials, (size_t)(r0 + u * n_chunks) * n_vals + v) : Fr::zero();
+                acc = acc + (((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7])));
+            }
+        }
+        rsum[tid] = acc;
+        __syncthreads();
+        if (tid < n_vals) {
+            Fr t = rsum[tid];
+            for (uint32_t q = 1; q < n_chunks; ++q) t = t + rsum[q * n_vals + tid];
+            vals[tid / CST_VALS][tid % CST_VALS] = t;
+        }
+    }
+    __syncthreads();
+    // ---- round 1: p(0), p(1), p(2) of every term from C and L (as composed_stage_close_kernel), canonical for the transcript
+    Fr e = Fr::zero();
+    if (tid < 3 * P) {
+        const uint32_t p = tid / 3, t = tid % 3;
+        const Fr* C = vals[p];
+        const Fr* L = vals[p] + 16;
+        Fr v;
+        if (t == 0) v = (C[0] + C[5]) + (L[0] + L[1]);
+        else if (t == 1) v = (C[10] + C[15]) + (L[2] + L[3]);
+        else {
+            const Fr ll = C[0] + C[5], hh = C[10] + C[15], lh = (C[2] + C[7]) + (C[8] + C[13]);
+            const Fr hh2 = hh + hh, lh2 = lh + lh;
+            v = (ll + (hh2 + hh2)) - lh2;
+            const Fr lhi = L[2] + L[3];
+            v = v + ((lhi + lhi) - (L[0] + L[1]));
+        }
+        e = fr_from_mont_outlined(v);
+    }
+    // beside round 1's hash (the last wave): the forms of round 2, thread (p, t, k)
+    auto stage_forms = [&]() {
+        const uint32_t u = tid - (PIPE_BLOCK - 64);
+        if (tid < PIPE_BLOCK - 64 || u >= 9 * P) return;
+        const uint32_t p = u / 9, t = (u / 3) % 3, k = u % 3;
+        const Fr* C = vals[p];
+        const Fr* L = vals[p] + 16;
+        auto Q = [&](uint32_t x, uint32_t y) {            // coefficient k of C'[x][y]
+            const Fr c00 = C[4 * x + y], c01 = C[4 * x + 2 + y], c10 = C[4 * (2 + x) + y], c11 = C[4 * (2 + x) + 2 + y];
+            if (k == 0) return c00;
+            const Fr mixed = c01 + c10;
+            return k == 1 ? mixed - (c00 + c00) : (c00 + c11) - mixed;
+        };
+        auto M = [&](uint32_t x) { return k == 0 ? L[x] : k == 1 ? L[2 + x] - L[x] : Fr::zero(); };
+        Fr f;
+        if (t == 0) f = Q(0, 0) + M(0);
+        else if (t == 1) f = Q(1, 1) + M(1);
+        else {
+            const Fr q11 = Q(1, 1), q2 = q11 + q11, mixed = Q(0, 1) + Q(1, 0), m1 = M(1);
+            f = ((Q(0, 0) + (q2 + q2)) - (mixed + mixed)) + ((m1 + m1) - M(0));
+        }
+        Fr kk;
+#pragma unroll
+        for (int i = 0; i < Fr::N; ++i) kk.l[i] = k == 0 ? (i == 0 ? 1u : 0u) : k == 1 ? FrParams::r1(i) : FrParams::r2(i);
+        ps.forms[3 * p + t][k] = fr_mul_outlined(f, kk);      // F0 canonical, F1 Montgomery, F2 x R^2
+    };
+    pipe_close_round(sh, ps, trs, ca, ca.round, ca.first, false, e, stage_forms);
+    if (tid == 0) r1m = fr_to_mont_outlined(sh.challenge_canon);
+    // ---- round 2 from the forms (sh.challenge_canon = round 1's challenge)
+    pipe_close_round(sh, ps, trs, ca, ca.round + 1, 0u, true, Fr::zero());
+    if (tid < 4) {
+        const Fr r2 = fr_to_mont_outlined(sh.challenge_canon), r1v = r1m;
+        const Fr one = Fr::one();
+        const Fr f1 = (tid >> 1) ? r1v : one - r1v, f2 = (tid & 1) ? r2 : one - r2;
+        store_fr(sa.weights_out, tid, (f1 * f2) * fr_mont_2_32());
+        if (tid == 0) { store_fr(ca.challenges, ca.round, r1v); store_fr(ca.challenges, ca.round + 1, r2); }
+    }
+    if (tid < sizeof(Sha256State) / 4)
+        reinterpret_cast<uint32_t*>(&ca.st->transcript)[tid] = reinterpret_cast<const uint32_t*>(&trs)[tid];
 }
 
 }  // namespace zk
