@@ -313,8 +313,11 @@ struct ComposedRun {
     // round kernels + two closing kernels (~13 us each).  With the cross sums on the VALU (16 products per index against 13 for two
     // rounds) it never paid; with them on the matrix cores (composed_cross2_mfma_kernel: 53 us at 2^22 against 113) it pays where the
     // passes are long: measured per stage / per two rounds (tools/prof_composed_k2.py, one term) 156 / 195 us at 2^22, 88 / 81 at 2^20,
-    // 62 / 46 at 2^18; claims of several terms (no unreduced wide kernel in their round form) gain from 2^18 on.  ZKHIP_STAGE=0 / 1
-    // forces it off / on from 2^15 (measurements); the sharded sessions use it wherever their shard allows: there it saves an EXCHANGE.
+    // 62 / 46 at 2^18; claims of several terms (no unreduced wide kernel in their round form) gain from 2^18 on.  With the serial kernel's
+    // second round one round ahead of the transcript (composed_stage_close_pipe_kernel, ~18 us less per stage) one-term claims gain from
+    // 2^18 on as well: ComposedSumcheck at 2^22 0.528 / 0.525 / 0.521 / 0.518 / 0.520 ms with stages from 2^21 / 2^20 / 2^19 / 2^18 / 2^17
+    // (tools/sweep_stage.sh, same box).  ZKHIP_STAGE=0 / 1 forces it off / on from 2^15 (measurements); the sharded sessions use it
+    // wherever their shard allows: there it saves an EXCHANGE.
     bool stage_possible(size_t min_n) const {
         if (pending || cn < min_n || cn < 4 || n_rounds - round < 2) return false;
         for (uint32_t p = 0; p < n_terms; ++p) if (term_sizes[p] != 2) return false;
@@ -324,7 +327,9 @@ struct ComposedRun {
         static const int mode = [] { const char* e = std::getenv("ZKHIP_STAGE"); return e ? std::atoi(e) : -1; }();
         if (mode == 0) return false;
         if (mode == 1) return stage_possible((size_t)1 << 15);
-        return stage_possible(n_terms >= 2 ? (size_t)1 << 18 : (size_t)1 << 21);
+        static const int log1 = [] { const char* e = std::getenv("ZKHIP_STAGE_MIN_LOG_ONE"); const int v = e ? std::atoi(e) : 0; return v >= 12 && v <= 30 ? v : 18; }();     // tuning aids (tools/sweep_stage.sh)
+        static const int logm = [] { const char* e = std::getenv("ZKHIP_STAGE_MIN_LOG_MANY"); const int v = e ? std::atoi(e) : 0; return v >= 12 && v <= 30 ? v : 18; }();
+        return stage_possible(n_terms >= 2 ? (size_t)1 << logm : (size_t)1 << log1);
     }
     MultiTablePtrs stage_tables() const {
         MultiTablePtrs mp = {};
