@@ -24,6 +24,8 @@ f=$(ls gpurun_out/$R/gkr20/*/*kernel_trace.csv | head -1); python3 tools/trace_g
 make -s -C zk-cryptography_amd/csrc libzkhip_diag.so > /dev/null 2>&1
 (echo "== MultiComposedSumcheckProver::prove_partial, 2 terms of 2 tables, 2^16 entries: per-round in-kernel stamps (us)"; timeout 120 python3 tools/diag_composed.py 16 multi 2>&1 | grep "^round"; echo "== ComposedSumcheck::prove, 2 tables, 2^22 entries"; timeout 120 python3 tools/diag_composed.py 22 2>&1 | grep "^round") > gpurun_out/$R/d_composed_round_stamps.txt
 timeout 300 ./tools/ab_pipe.sh > gpurun_out/$R/d_ab_pipe.txt 2>&1
+timeout 400 bash tools/sweep_stage.sh > gpurun_out/$R/d_sweep_stage.txt 2>&1
+timeout 100 python3 tools/perf_fingerprint.py 2>&1 | grep " us" > gpurun_out/$R/e_srs_guard_cost.txt
 [ -x tools/ubench_fine ] && timeout 120 ./tools/ubench_fine > gpurun_out/$R/ubench_fine_gfx950.txt 2>&1
 [ -x tools/ubench_batched_affine ] && timeout 120 ./tools/ubench_batched_affine > gpurun_out/$R/ubench_batched_affine_gfx950.txt 2>&1
 # MultilinearKZG::open: plain batch against the level tables -- per-kernel stats at 2^20, time by size, time by window width

@@ -13,6 +13,8 @@ cp $R/a_bench_line_default_run.json $P/
 cp $R/b_prover_timeline.txt $R/c_proofs_in_flight_timeline.txt $P/
 cp $R/gkr20/runc/*kernel_stats.csv $P/d_gkr20_kernel_stats.csv
 cp $R/d_gkr20_trace_gaps.txt $R/d_composed_round_stamps.txt $R/d_ab_pipe.txt $P/
+[ -f $R/d_sweep_stage.txt ] && cp $R/d_sweep_stage.txt $P/
+[ -f $R/e_srs_guard_cost.txt ] && cp $R/e_srs_guard_cost.txt $P/
 [ -f $R/ubench_fine_gfx950.txt ] && cp $R/ubench_fine_gfx950.txt $P/
 [ -f $R/ubench_batched_affine_gfx950.txt ] && cp $R/ubench_batched_affine_gfx950.txt $P/
 [ -f $R/e_open_by_size_and_width.txt ] && cp $R/e_open_by_size_and_width.txt $P/
