@@ -154,6 +154,9 @@ def bench_exchange(comm, world):
     At world 1 over a one-rank RCCL communicator this is the fixed cost of the call path that every rank count pays."""
     out = {"transport": comm.transport if isinstance(comm.transport, str) else "callback", "world": world,
            "measured": "inside libzkhip: ncclAllGather on the context's stream (zkhip_comm_measure)"}
+    if getattr(comm, "fallback_reason", None):      # the library's RCCL communicator did not come up on every rank: host-staged all-gathers over torch.distributed
+        out["measured"] = "inside libzkhip over the STAGED transport (device -> host -> torch.distributed all_gather -> device)"
+        out["rccl_fallback_reason"] = str(comm.fallback_reason)[:300]
     for nbytes in (64, 8192, 65536):
         b2b, waited = comm.measure(nbytes, 200)
         out["%d_B" % nbytes] = {"back_to_back_us": round(b2b, 2), "with_host_wait_us": round(waited, 2)}

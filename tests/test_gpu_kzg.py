@@ -460,6 +460,15 @@ def test_srs_caches_follow_in_place_edits(zk, ora):
     assert zk.MultilinearKZG.commitment(poly, srs.precompute()) == after   # and a table rebuilt from the edited points agrees
     a, b = zk.MultilinearKZG.open(poly, z, srs), zk.MultilinearKZG.open(poly, z, plain, cache_folded_srs=False)
     assert all(p == q for p, q in zip(a.proofs, b.proofs))
+    # the level tables of `open` follow the same rule
+    srs.precompute_open()
+    assert srs.level_tables is not None
+    srs.powers_of_tau_in_g1[[2, 3]] = srs.powers_of_tau_in_g1[[3, 2]]
+    plain2 = zk.TrustedSetup(srs.powers_of_tau_in_g1.clone(), srs.inf.clone())
+    a, b = zk.MultilinearKZG.open(poly, z, srs), zk.MultilinearKZG.open(poly, z, plain2, cache_folded_srs=False)
+    assert srs.level_tables is None and all(p == q for p, q in zip(a.proofs, b.proofs))
+    a = zk.MultilinearKZG.open(poly, z, srs.precompute_open())
+    assert srs.level_tables is not None and all(p == q for p, q in zip(a.proofs, b.proofs))
 
 
 def test_srs_caches_follow_raw_pointer_writes(zk, ora):

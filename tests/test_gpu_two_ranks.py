@@ -103,3 +103,53 @@ def test_real_ranks_sharing_one_gpu(world):
     for rank, r in sorted(res):
         assert all(r.values()), (rank, r)
     assert len(res) == world
+
+
+def _worker_rccl_pick(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import zk_cryptography_amd as zk
+        from zk_cryptography_amd import _native as N
+        from zk_cryptography_amd import distributed as D
+        torch.cuda.set_device(0)
+        D.Comm._pick_rccl_anyway = True          # what a job on the nccl backend picks: the library's own RCCL communicator
+        comm = D.Comm.get(N.Context.get(0), world, rank, dist, None)
+        full = zk.Fr.random(1 << 16, 777)
+        t = torch.from_numpy(np.ascontiguousarray(D.shard_interleaved(full, rank, world)).view(np.int64)).cuda()
+        s, rp, ch = D.ShardedSumcheck(D.HipSumcheckEngine(t), world, None, dist, comm=comm).prove()
+        sc = zk.Sumcheck(zk.Multilinear(full))
+        sc.poly_sum()
+        proof, wch = sc.prove()
+        ok = bool(np.array_equal(s, proof.sum) and np.array_equal(rp, proof.univariate_poly) and np.array_equal(ch, wch))
+        q.put((rank, {"proof": ok, "transport": comm.transport, "fallback_reason": comm.fallback_reason}))
+        D.Comm.close_all()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_communicator_that_does_not_come_up_falls_back_on_every_rank():
+    """Two ranks on ONE device: the library's RCCL communicator cannot be built (RCCL refuses duplicate devices) or, if a build of RCCL
+    allows it, works.  Either way every rank ends with the SAME transport -- the ranks agree over torch.distributed after a probe
+    all-gather -- and the sharded proof is the single-GPU proof."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_rccl_pick, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    transports = {r["transport"] for _, r in res}
+    assert len(transports) == 1 and transports <= {"rccl", "staged"}, res
+    for _, r in res:
+        assert r["proof"], res
+        assert (r["transport"] == "staged") == (r["fallback_reason"] is not None), res

@@ -29,6 +29,7 @@ class Comm:
     """zkhip_comm (include/zkhip.h): one per (context, group); cached, closed explicitly (Comm.close_all) or never."""
 
     _cache = {}
+    _pick_rccl_anyway = False     # tests: pick the library's RCCL communicator whatever backend torch.distributed runs (the fallback path)
 
     def __init__(self, ctx, world=1, rank=0, dist=None, group=None, transport=None):
         """transport: None = pick ("none" for world 1, "rccl" when `dist` runs the nccl backend, else "staged"); or a callable
@@ -38,8 +39,10 @@ class Comm:
         self.ctx, self.world, self.rank, self.dist, self.group = ctx, world, rank, dist, group
         self.handle = C.c_void_p()
         self.error = None
-        if transport is None:
-            transport = "none" if world == 1 else ("rccl" if _is_nccl(dist, group) else "staged")
+        self.fallback_reason = None          # set when the library's RCCL communicator was picked but did not come up on every rank
+        auto = transport is None
+        if auto:
+            transport = "none" if world == 1 else ("rccl" if (_is_nccl(dist, group) or Comm._pick_rccl_anyway) else "staged")
         self.transport = transport
         lib = N.lib()
         if callable(transport):
@@ -49,18 +52,75 @@ class Comm:
             assert world == 1
             N.check(lib.zkhip_comm_create(ctx.handle, C.c_uint32(0), C.c_uint32(1), None, None, C.byref(self.handle)), "comm_create")
         elif transport == "rccl":
-            uid = np.zeros(128, dtype=np.uint8)
-            if rank == 0:
-                N.check(lib.zkhip_rccl_unique_id(uid.ctypes.data_as(C.c_void_p)), "rccl_unique_id (librccl.so not found?)")
-            if world > 1:
-                box = [uid.tobytes()]
-                dist.broadcast_object_list(box, src=_global_rank(dist, group, 0), group=group)
-                uid = np.frombuffer(box[0], dtype=np.uint8).copy()
-            N.check(lib.zkhip_comm_create_rccl(ctx.handle, uid.ctypes.data_as(C.c_void_p), C.c_uint32(rank), C.c_uint32(world),
-                                               C.byref(self.handle)), "comm_create_rccl")
+            picked = auto and world > 1
+            err = self._create_rccl(lib, raise_errors=not picked)
+            if picked:
+                # The library's own communicator at world > 1: every rank checks it with one small all-gather and the ranks AGREE (over
+                # torch.distributed) before anything depends on it; if any rank failed, all of them fall back to the staged transport.
+                ok = err is None and self._probe()
+                if not self._all_ranks(ok):
+                    self.close()
+                    self.handle = C.c_void_p()
+                    self.transport = "staged"
+                    self.fallback_reason = repr(err) if err is not None else "probe all-gather through the library's RCCL communicator failed on some rank"
+                    self._create_staged(lib)
         else:
-            self._cb = ALL_GATHER_FN(self._staged_all_gather)      # kept alive with the comm
-            N.check(lib.zkhip_comm_create(ctx.handle, C.c_uint32(rank), C.c_uint32(world), self._cb, None, C.byref(self.handle)), "comm_create")
+            self._create_staged(lib)
+
+    def _create_staged(self, lib):
+        self._cb = ALL_GATHER_FN(self._staged_all_gather)      # kept alive with the comm
+        N.check(lib.zkhip_comm_create(self.ctx.handle, C.c_uint32(self.rank), C.c_uint32(self.world), self._cb, None, C.byref(self.handle)), "comm_create")
+
+    def _create_rccl(self, lib, raise_errors):
+        """ncclGetUniqueId on rank 0, its broadcast, ncclCommInitRank on every rank.  -> None or the exception (raise_errors=False)"""
+        try:
+            uid = np.zeros(128, dtype=np.uint8)
+            first = None
+            if self.rank == 0:
+                try:
+                    N.check(lib.zkhip_rccl_unique_id(uid.ctypes.data_as(C.c_void_p)), "rccl_unique_id (librccl.so not found?)")
+                except Exception as e:          # the broadcast below must still happen: the other ranks wait in it
+                    first = e
+            if self.world > 1:
+                box = [uid.tobytes() if first is None else None]
+                self.dist.broadcast_object_list(box, src=_global_rank(self.dist, self.group, 0), group=self.group)
+                if box[0] is None:
+                    raise first or RuntimeError("rank 0 could not create an RCCL unique id")
+                uid = np.frombuffer(box[0], dtype=np.uint8).copy()
+            elif first is not None:
+                raise first
+            N.check(lib.zkhip_comm_create_rccl(self.ctx.handle, uid.ctypes.data_as(C.c_void_p), C.c_uint32(self.rank), C.c_uint32(self.world),
+                                               C.byref(self.handle)), "comm_create_rccl")
+            return None
+        except Exception as e:
+            if raise_errors:
+                raise
+            return e
+
+    def _probe(self):
+        """one 64-byte all-gather through the communicator: rank r sends 64 bytes of value r"""
+        try:
+            import torch
+            dev = getattr(self.ctx, "device", None) or torch.device("cuda")
+            send = torch.full((64,), self.rank, dtype=torch.uint8, device=dev)
+            recv = torch.zeros(64 * self.world, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            st = N.lib().zkhip_comm_all_gather(self.handle, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), C.c_size_t(64))
+            if st != N.ZKHIP_OK:
+                return False
+            got = np.empty(64 * self.world, dtype=np.uint8)
+            N.check(N.lib().zkhip_memcpy_d2h(self.ctx.handle, got.ctypes.data_as(C.c_void_p), C.c_void_p(recv.data_ptr()), C.c_size_t(64 * self.world)), "d2h")
+            return bool(np.array_equal(got, np.repeat(np.arange(self.world, dtype=np.uint8), 64)))
+        except Exception:
+            return False
+
+    def _all_ranks(self, ok):
+        """True iff `ok` on every rank of the group"""
+        import torch
+        dev = "cuda" if _is_nccl(self.dist, self.group) else "cpu"
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()) == 1)
 
     def _staged_all_gather(self, user, d_send, d_recv, nbytes, stream):
         """all-gather through host memory and torch.distributed (payloads are at most a few hundred KiB): waits for the stream"""
