@@ -448,11 +448,12 @@ int zkhip_kzg_commit_sharded(zkhip_comm *comm, const uint64_t *d_points_xy, cons
 int zkhip_kzg_commit(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t *d_points_inf, size_t n_points,
                      const uint64_t *d_scalars, size_t n_scalars, int require_equal_len, uint64_t *h_out_xy,
                      uint8_t *h_out_inf);
-/* Shifted-SRS table: d_table[w * n + i] = 2^(20 w) * point i for the 13 windows w of a 255-bit scalar, in the kernels'
- * internal layout (zkhip_srs_table_bytes(n) = 13 * 128 * n bytes: 1.6 GiB for 2^20 points -- HBM is what this part has).
- * With it the digits of all windows fall into ONE set of 2^19 buckets: 13 n bucket additions instead of 16 n and a single
- * bucket reduction.  The table depends on the SRS only (built once, ~70 ms at 2^20); zkhip_kzg_commit_table then has the
- * semantics of zkhip_kzg_commit (same group element, same errors).  n * 13 must stay below 2^31. */
+/* Shifted-SRS table: d_table[w * n + i] = 2^(first bit of window w) * point i for the W digit windows of a 256-bit scalar, in the
+ * kernels' internal layout (zkhip_srs_table_bytes(n) = W * 128 * n bytes; at 2^20 points W = 13 windows of 20 / 19 bits: 1.6 GiB -- HBM
+ * is what this part has; smaller SRS get windows WIDER than their size, 2^12 points: 18 windows of 15 / 14 bits).  With it the digits
+ * of all windows fall into ONE bucket set: at 2^20 13 n bucket additions instead of 16 n and a single bucket reduction.  The table
+ * depends on the SRS only (built once, ~70 ms at 2^20); zkhip_kzg_commit_table then has the semantics of zkhip_kzg_commit (same group
+ * element, same errors).  n * W must stay below 2^31. */
 size_t zkhip_srs_table_bytes(size_t n_points);
 /* Content check for a host-side cache of what is derived from an SRS (the table above, the folded levels): the first two and the last
  * two points with their infinity flags, h_out[52] = 4 x (12 coordinate words, flag) -- one small launch, one copy, ~20 us.  A wrapper

@@ -30,7 +30,7 @@ using namespace zk;
 //                  lists, so the window is as wide as the sort allows as soon as the bucket reduction is not the larger cost; measured
 //                  with tools/perf_msm.py, ZKHIP_MSM_C sweep: below 2^13 every c ends at the ~1 ms latency floor of the reduction
 //                  passes).  16 x 16 = 256: the top window has 15 significant bits, half full, never sparse.
-//   shifted table: thirteen 20-bit digit windows on ONE bucket set of 2^19 buckets (MSM_TABLE_C).
+//   shifted table: at 2^20 points thirteen digit windows of 20 / 19 bits on ONE bucket set of 2^19 buckets; widths by SRS size (msm_table_widths).
 //   several:       every problem gets a width of its OWN, log2(n_j) - delta bits (lists of 2^delta .. 2^(delta+1) points: the accumulate pass
 //                  takes as long as its longest lists, and every further bit doubles the buckets the reduction passes walk), as w = ceil(256 / c)
 //                  windows of the two widths ceil(256 / w) and one less that add up to exactly 256 -- so no window of any problem is
@@ -288,7 +288,7 @@ extern "C" int zkhip_kzg_commit_begin(zkhip_ctx* c, const uint64_t* d_points_xy,
     if (n_scalars > n_points) return ZKHIP_ERR_INDEX;                          // univariate_kzg.rs:53
     const size_t n = n_scalars;
     if (n == 0 || !d_scalars) return ZKHIP_ERR_ARG;                           // nothing to overlap: use the synchronous call
-    if (n >= ((size_t)1 << 31) || (d_table && n_points * MSM_TABLE_WINDOWS >= ((size_t)1 << 31))) return ZKHIP_ERR_SHAPE;
+    if (n >= ((size_t)1 << 31) || (d_table && n_points * msm_table_widths(n_points).W >= ((size_t)1 << 31))) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
     int slot = -1;
     bool any = false;
@@ -376,7 +376,7 @@ extern "C" int zkhip_srs_fingerprint(zkhip_ctx* c, const uint64_t* d_points_xy, 
 // ---------------------------------------------------------------------------------------
 // shifted-SRS table: commitments with one bucket set for all windows
 // ---------------------------------------------------------------------------------------
-extern "C" size_t zkhip_srs_table_bytes(size_t n_points) { return n_points * MSM_TABLE_WINDOWS * 128; }
+extern "C" size_t zkhip_srs_table_bytes(size_t n_points) { return n_points ? n_points * msm_table_widths(n_points).W * 128 : 0; }
 
 // windows 0 .. n_windows-1 of c bits over n affine points: table entry w * n + i = 2^(c w) * point i (internal 28-bit-limb layout, 128 bytes);
 // the context's workspace holds one window in XYZZ and affine form meanwhile
@@ -410,9 +410,10 @@ extern "C" int zkhip_srs_precompute(zkhip_ctx* c, const uint64_t* d_points_xy, c
                                     void* d_table) {
     if (!c || !d_points_xy || !d_table) return ZKHIP_ERR_ARG;
     if (n == 0) return ZKHIP_OK;
-    if (n * MSM_TABLE_WINDOWS >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;   // entry index + sign bit in 32 bits
+    const MsmLevelWidths lw = msm_table_widths(n);
+    if (n * lw.W >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;   // entry index + sign bit in 32 bits
     ZK_TRY(c->activate());
-    ZK_TRY(build_shift_table(c, d_points_xy, d_points_inf, n, MSM_TABLE_C, MSM_TABLE_WINDOWS, (uint32_t*)d_table));
+    ZK_TRY(build_shift_table(c, d_points_xy, d_points_inf, n, lw.hi, lw.W, (uint32_t*)d_table, lw.n_hi));
     ZK_HIP(c, hipStreamSynchronize(c->stream));   // the workspace is reused by the next call
     return ZKHIP_OK;
 }
@@ -460,7 +461,7 @@ extern "C" int zkhip_kzg_commit_table(zkhip_ctx* c, const void* d_table, const u
     const size_t n = n_scalars;
     if (n == 0) { std::memset(h_out_xy, 0, 96); *h_out_inf = 1; return ZKHIP_OK; }
     if (!d_table || !d_scalars) return ZKHIP_ERR_ARG;
-    if (n_points * MSM_TABLE_WINDOWS >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
+    if (n_points * msm_table_widths(n_points).W >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
     MsmProblems one = {};
     one.n = 1;

@@ -94,8 +94,7 @@ struct MsmGeometry {
     size_t items = 0;                // (point, window) pairs of the pass
     uint32_t heavy_min = 32;
 };
-constexpr uint32_t MSM_TABLE_C = 20;
-constexpr uint32_t MSM_TABLE_WINDOWS = (256 + MSM_TABLE_C - 1) / MSM_TABLE_C;   // 13: twelve full 20-bit windows and a 15-bit top window
+constexpr uint32_t MSM_TABLE_WINDOWS_MAX = 32;    // windows of the narrowest table (8 bits): the bound the size checks use
 // LEVEL TABLES (the folded SRS levels of MultilinearKZG::open, zkhip_srs_level_tables): a batch of problems, each with a shifted table of
 // its own -- problem j of n_j points has W_j = ceil(256 / c_j) windows of ~c_j = log2(n_j) bits (msm_level_table_widths), ONE bucket set of
 // 2^(c_j - 1) ~ n_j / 2 buckets (as many as its ~17 sets of 2^(lg - 5) buckets without the table) and the entries
@@ -121,6 +120,10 @@ inline MsmLevelWidths msm_level_table_widths(size_t nj, size_t batch_total) {
     lw.n_hi = 256 - lw.W * (lw.hi - 1);
     return lw;
 }
+// The shifted-SRS table of ONE commit over n_points points (zkhip_srs_precompute): the same rule -- thirteen windows of 20 / 19 bits on
+// 2^19 buckets at 2^20 points, wider than the size below 2^19 points (a small commit is as long as its longest bucket list and its
+// reduction passes: 2^19 buckets for 2^12 points were a millisecond of empty reduction).
+inline MsmLevelWidths msm_table_widths(size_t n_points) { return msm_level_table_widths(n_points, n_points); }
 inline int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t table_stride, int delta, MsmGeometry& g);
 inline int msm_build_geometry(const MsmProblems& pr, bool shared, size_t table_stride, MsmGeometry& g);
 inline int msm_build_geometry(const MsmProblems& pr, bool shared, size_t table_stride, MsmGeometry& g) {
@@ -192,11 +195,12 @@ inline int msm_build_geometry_at(const MsmProblems& pr, bool shared, size_t tabl
             level_entries += (size_t)W * nj;
             g.items += nj * W;
             max_chain = std::max<uint32_t>(max_chain, (uint32_t)((nj * W + (1u << (c - 1)) - 1) >> (c - 1)));
-        } else if (shared) {
-            const MsmSet s = add_set(MSM_TABLE_C, 0);
-            for (uint32_t w = 0; w < MSM_TABLE_WINDOWS; ++w) add_win(s, MSM_TABLE_C, (uint32_t)(w * table_stride));
-            g.items += nj * MSM_TABLE_WINDOWS;
-            max_chain = std::max<uint32_t>(max_chain, (uint32_t)((nj * MSM_TABLE_WINDOWS + (1u << (MSM_TABLE_C - 1)) - 1) >> (MSM_TABLE_C - 1)));
+        } else if (shared) {                          // ONE problem against the shifted-SRS table of table_stride points (msm_table_widths)
+            const MsmLevelWidths lw = msm_table_widths(table_stride);
+            const MsmSet s = add_set(lw.hi, 0);
+            for (uint32_t w = 0; w < lw.W; ++w) add_win(s, w < lw.n_hi ? lw.hi : lw.hi - 1, (uint32_t)(w * table_stride));
+            g.items += nj * lw.W;
+            max_chain = std::max<uint32_t>(max_chain, (uint32_t)((nj * lw.W + (1u << (lw.hi - 1)) - 1) >> (lw.hi - 1)));
         } else {
             uint32_t w, hi, n_hi;
             if (pr.n == 1) {

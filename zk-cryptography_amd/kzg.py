@@ -135,7 +135,7 @@ class TrustedSetup:
         return getattr(self, "_table", None)
 
     def precompute(self):
-        """Build (once) the shifted-SRS table 2^(20 w) * point for the 13 windows of a scalar: commitments then need
+        """Build (once) the shifted-SRS table 2^(first bit of window w) * point for the digit windows of a scalar (13 at 2^20): commitments then need
         13 instead of 16 bucket additions per point and one bucket reduction (zkhip_srs_precompute); 1.6 GiB at 2^20."""
         self._check_caches()
         if getattr(self, "_table", None) is None:
