@@ -62,7 +62,9 @@ struct zkhip_ctx {
     int last_hip = 0;
     void* d_ws = nullptr;       // large workspace (ping-pong tables, MSM buckets, ...)
     size_t ws_bytes = 0;
-    void* d_fingerprint = nullptr;   // zkhip_srs_fingerprint's 52 words
+    void* d_fingerprint = nullptr;   // zkhip_srs_fingerprint's 52 words, its stream (highest priority) and the event that orders it behind the caller's
+    hipStream_t guard_stream = nullptr;
+    hipEvent_t guard_ev = nullptr;
     void* d_composed = nullptr;      // composed provers: ComposedDev (transcript + interpolation matrices of every degree), uploaded once
     void* d_gen_table = nullptr;   // SRS generation: d * 2^(8w) * G for 32 windows x 255 digits, affine (+ infinity flags); built on first use
     void* ntt_state = nullptr;     // twiddle tables and pass plans of the transforms this context has run (ntt.hip); ntt_free releases them

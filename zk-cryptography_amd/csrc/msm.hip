@@ -364,11 +364,21 @@ extern "C" int zkhip_srs_fingerprint(zkhip_ctx* c, const uint64_t* d_points_xy, 
     if (n_points == 0) { std::memset(h_out, 0, 52 * 8); return ZKHIP_OK; }
     ZK_TRY(c->activate());
     if (!c->d_fingerprint) ZK_HIP(c, hipMalloc(&c->d_fingerprint, 512));      // a buffer of its own: commits in flight hold the workspace
+    if (!c->guard_stream) {
+        // a stream of the highest priority: with commits in flight the one-wave kernel takes the next slot that frees instead of queueing
+        // behind the thousands of workgroups of an accumulate pass (109 us per call on the caller's stream, rocprofv3 of the bench's in-flight leg)
+        int least = 0, greatest = 0;
+        ZK_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        ZK_HIP(c, hipStreamCreateWithPriority(&c->guard_stream, hipStreamNonBlocking, greatest));
+        ZK_HIP(c, hipEventCreateWithFlags(&c->guard_ev, hipEventDisableTiming));
+    }
     uint64_t* pin = c->pinned_u64(ZK_PIN_PTS);      // (evaluation points' staging area: no prover runs during this call)
     static_assert(ZK_PIN_PROOF - ZK_PIN_PTS >= 52, "staging area too small");
-    hipLaunchKernelGGL(srs_fingerprint_kernel, dim3(1), dim3(64), 0, c->stream, d_points_xy, d_points_inf, n_points, (uint64_t*)c->d_fingerprint);
-    ZK_HIP(c, hipMemcpyAsync(pin, c->d_fingerprint, 52 * 8, hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    ZK_HIP(c, hipEventRecord(c->guard_ev, c->stream));                         // behind whatever the caller's stream still does to the SRS
+    ZK_HIP(c, hipStreamWaitEvent(c->guard_stream, c->guard_ev, 0));
+    hipLaunchKernelGGL(srs_fingerprint_kernel, dim3(1), dim3(64), 0, c->guard_stream, d_points_xy, d_points_inf, n_points, (uint64_t*)c->d_fingerprint);
+    ZK_HIP(c, hipMemcpyAsync(pin, c->d_fingerprint, 52 * 8, hipMemcpyDeviceToHost, c->guard_stream));
+    ZK_HIP(c, hipStreamSynchronize(c->guard_stream));
     std::memcpy(h_out, pin, 52 * 8);
     return ZKHIP_OK;
 }

@@ -71,6 +71,8 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     if (c->d_gen_table) hipFree(c->d_gen_table);
     if (c->d_composed) hipFree(c->d_composed);
     if (c->d_fingerprint) hipFree(c->d_fingerprint);
+    if (c->guard_stream) { hipStreamSynchronize(c->guard_stream); hipStreamDestroy(c->guard_stream); }
+    if (c->guard_ev) hipEventDestroy(c->guard_ev);
     if (c->ntt_state && c->ntt_free) c->ntt_free(c->ntt_state);
     for (int i = 0; i < zkhip_ctx::MSM_SLOTS; ++i) {
         if (c->msm_pin[i]) hipHostFree(c->msm_pin[i]);
