@@ -411,7 +411,8 @@ def test_commit_table_reference_data(zk, ora):   # multilinear_kzg.rs:133-148 da
         zk.MultilinearKZG.commitment(zk.Multilinear(zk.Fr.from_ints([1, 2, 3, 4])), srs)
 
 
-@pytest.mark.parametrize("log_n,kind", [(4, "uniform"), (10, "uniform"), (13, "bytes"), (16, "uniform"), (16, "ones"), (17, "uniform")])
+@pytest.mark.parametrize("log_n,kind", [(1, "uniform"), (2, "ones"), (4, "uniform"), (7, "bytes"), (10, "uniform"), (13, "bytes"), (16, "uniform"), (16, "ones"),
+                                        (17, "uniform"), (18, "uniform"), (19, "uniform")])   # the table's window widths change at 2^17, 2^18, 2^19
 def test_commit_table_matches_plain_commit(zk, ora, log_n, kind):
     n = 1 << log_n
     tau = ora.random_fr(log_n, 4100 + log_n)

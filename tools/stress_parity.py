@@ -105,9 +105,13 @@ def case_commit():
     elif kind == "small": v = zk.Fr.from_ints([rng.randrange(0, 300) for _ in range(n)])
     elif kind == "sparse": v = zk.Fr.from_ints([rng.randrange(1 << 200) if rng.random() < 0.1 else 0 for _ in range(n)])
     else: v = zk.Fr.from_ints([zk.Fr.MODULUS - 1] * n)
+    if rng.random() < 0.5:          # half of them against the shifted-SRS table
+        srs.precompute()
+    elif srs.table is not None:
+        srs.invalidate()
     com = zk.MultilinearKZG.commitment(zk.Multilinear(v), srs)
     want = ora.g1_to_affine(ora.kzg_commitment(v, osrs, True))
-    return (bool(want[12]) == com.infinity) and (com.infinity or np.array_equal(com.xy, want[:12])), ("commit", nv, kind)
+    return (bool(want[12]) == com.infinity) and (com.infinity or np.array_equal(com.xy, want[:12])), ("commit", nv, kind, srs.table is not None)
 
 
 def case_ntt():
