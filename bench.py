@@ -400,7 +400,8 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
                         "device to device over RCCL) per commit, summed on every rank" % (n * world, world, world)) if world > 1 else "single GPU",
            "points_per_gpu": n, "exchanges_per_commit": 1 if world > 1 else 0, "commitment_replicated_on_all_ranks": same,
            "srs_table": {"bytes": int(srs._table.numel()), "build_ms": round(1e3 * t_tab, 1),
-                         "note": "2^(20 w) * point for the 13 windows of a scalar; depends on the SRS only, built once, not timed"},
+                         "windows": int(srs._table.numel()) // (128 * n),
+                         "note": "2^(first bit of window w) * point for the digit windows of a scalar (13 of 20 / 19 bits at 2^20 points); depends on the SRS only, built once, not timed"},
            "pipelined": pipelined,
            "extras": extras,
            "without_srs_table": {"value": round(float(n) * steps / dt_plain, 1), "unit": "points/s (this rank)",
@@ -412,14 +413,15 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
                         "algorithmic_bytes_per_launch": "128 B x points (96 B affine point + 32 B scalar)"}}
     # what actually bounds that kernel: issue of v_mad_u64_u32.  One bucket addition = 10 products in the 14 x 28-bit
     # representation = 4060 multiply-adds; a launch adds one point per non-zero digit (13 windows x points with the
-    # shifted-SRS table, all but 2^-20 of them).  Peak = 1024 SIMDs x 64 lanes / 4.9 cycles per wave-instruction x 2.4 GHz as measured by
+    # shifted-SRS table at 2^20 points, all but ~2^-19 of them).  Peak = 1024 SIMDs x 64 lanes / 4.9 cycles per wave-instruction x 2.4 GHz as measured by
     # tools/ubench.hip (profiles/r01/ubench_alu_gfx950.txt).
-    mads = 4060.0 * 13.0 * n * (1.0 - 2.0 ** -20)
+    windows = int(srs._table.numel()) // (128 * n)                      # 13 at 2^20 points (zkhip_srs_table_bytes)
+    mads = 4060.0 * windows * n * (1.0 - 2.0 ** -19)
     peak_tmads = 1024 * 64 / 4.9 * 2.4e9 / 1e12
     out["roofline_alu"] = {"bound": "valu", "kernel": "msm_accumulate_kernel", "achieved": round(mads / (ms * 1e-3) / 1e12, 2),
                            "peak": round(peak_tmads, 2), "unit": "T v_mad_u64_u32 lane-ops/s",
                            "frac": round(mads / (ms * 1e-3) / 1e12 / peak_tmads, 4),
-                           "ops_per_launch": "4060 multiply-adds x 13 windows x points"}
+                           "ops_per_launch": "4060 multiply-adds x %d windows x points" % windows}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as ora
         m = 1 << 14                                                     # bounded sample of the naive reference algorithm (~3.5 s)
