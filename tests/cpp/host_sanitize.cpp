@@ -114,6 +114,18 @@ static bool same_point(const zkhost::Xyzz& p, const g1_jac_t& j) {
     return a.inf == 0 && std::memcmp(xy, a.x.l, 48) == 0 && std::memcmp(xy + 6, a.y.l, 48) == 0;
 }
 static void test_g1() {
+    // Fq inversion (binary extended Euclid) against the oracle's, on random elements, 0, 1, 2, p - 1 and the coordinates of real points
+    for (int it = 0; it < 600; ++it) {
+        uint64_t c[6] = {rng(), rng(), rng(), rng(), rng(), rng() >> 4};   // < 2^380 < p
+        if (it < 6) { std::memset(c, 0, sizeof c); c[0] = (uint64_t)it; }
+        if (it == 6) { static const uint64_t pm1[6] = {0xb9feffffffffaaaaULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL, 0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL}; std::memcpy(c, pm1, 48); }
+        fq_t a, w; ora_fq_from_canonical(&a, c);
+        zkhost::Fq ha; std::memcpy(ha.l, a.l, 48);
+        const zkhost::Fq hi = zkhost::fq_inv(ha);
+        if (ora_fq_inv(&w, &a)) { EXPECT(std::memcmp(hi.l, w.l, 48) == 0); EXPECT(zkhost::fq_eq(zkhost::fq_mul(hi, ha), zkhost::fq_one())); }
+        else EXPECT(zkhost::fq_is_zero(hi));
+        mix(&w, 48);
+    }
     g1_jac_t g; ora_g1_generator(&g);
     std::vector<g1_jac_t> pts(40);
     for (size_t i = 0; i < pts.size(); ++i) { uint64_t k[4] = {rng(), rng(), rng(), rng() >> 2}; ora_g1_mul_bigint(&pts[i], &g, k, 4); }

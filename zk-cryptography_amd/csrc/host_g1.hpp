@@ -62,14 +62,36 @@ inline Fq fq_mul(const Fq& a, const Fq& b) {
     Fq r; memcpy(r.l, t, 48); return r;
 }
 inline Fq fq_sqr(const Fq& a) { return fq_mul(a, a); }
-inline Fq fq_inv(const Fq& a) {   // Fermat: a^(p-2)
-    uint64_t e[6]; memcpy(e, FQ_P, 48); e[0] -= 2;
-    Fq acc = fq_one();
-    for (int i = 383; i >= 0; --i) {
-        acc = fq_sqr(acc);
-        if ((e[i / 64] >> (i % 64)) & 1) acc = fq_mul(acc, a);
+// a^-1 (Montgomery form in, Montgomery form out; 0 -> 0).  Binary extended Euclid on the stored integer a R -- ~2 x 381 steps of shifts
+// and subtractions on six limbs, ~10 us, against 384 squarings + ~190 products (~40 us) for a^(p-2): it ends every commitment's and
+// every opening round's host epilogue -- then one product by R^3 takes (a R)^-1 = a^-1 R^-1 back to a^-1 R.
+inline Fq fq_inv(const Fq& a) {
+    if (fq_is_zero(a)) return a;
+    static const uint64_t R2[6] = {0xf4df1f341c341746ULL, 0x0a76e6a609d104f1ULL, 0x8de5476c4c95b6d5ULL,
+                                   0x67eb88a9939d83c0ULL, 0x9a793e85b519952dULL, 0x11988fe592cae3aaULL};
+    static const Fq R3 = [] { Fq r2; memcpy(r2.l, R2, 48); return fq_mul(r2, r2); }();
+    uint64_t u[6], v[6], x1[6] = {1, 0, 0, 0, 0, 0}, x2[6] = {0, 0, 0, 0, 0, 0};
+    memcpy(u, a.l, 48);
+    memcpy(v, FQ_P, 48);
+    auto is_one = [](const uint64_t* t) { return t[0] == 1 && (t[1] | t[2] | t[3] | t[4] | t[5]) == 0; };
+    auto shr1 = [](uint64_t* t) { for (int i = 0; i < 5; ++i) t[i] = (t[i] >> 1) | (t[i + 1] << 63); t[5] >>= 1; };
+    auto halve = [&](uint64_t* t) {           // t / 2 mod p (t < p: t + p < 2^382)
+        if (t[0] & 1) { uint64_t c = 0; for (int i = 0; i < 6; ++i) { u128 s = (u128)t[i] + FQ_P[i] + c; t[i] = (uint64_t)s; c = (uint64_t)(s >> 64); } }
+        shr1(t);
+    };
+    auto geq = [](const uint64_t* x, const uint64_t* y) { for (int i = 5; i >= 0; --i) { if (x[i] > y[i]) return true; if (x[i] < y[i]) return false; } return true; };
+    auto sub = [](uint64_t* x, const uint64_t* y) { uint64_t br = 0; for (int i = 0; i < 6; ++i) { u128 d = (u128)x[i] - y[i] - br; x[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } return br; };
+    auto submod = [&](uint64_t* x, const uint64_t* y) {
+        if (sub(x, y)) { uint64_t c = 0; for (int i = 0; i < 6; ++i) { u128 s = (u128)x[i] + FQ_P[i] + c; x[i] = (uint64_t)s; c = (uint64_t)(s >> 64); } }
+    };
+    while (!is_one(u) && !is_one(v)) {
+        while (!(u[0] & 1)) { shr1(u); halve(x1); }
+        while (!(v[0] & 1)) { shr1(v); halve(x2); }
+        if (geq(u, v)) { sub(u, v); submod(x1, x2); } else { sub(v, u); submod(x2, x1); }
     }
-    return acc;
+    Fq t;
+    memcpy(t.l, is_one(u) ? x1 : x2, 48);
+    return fq_mul(t, R3);
 }
 
 struct Xyzz { Fq x, y, zz, zzz; };
