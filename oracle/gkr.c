@@ -103,6 +103,7 @@ static int prove_layer(const fr_t *add_bc, const fr_t *mul_bc, const fr_t *w, si
     if (rc != 0) return rc;
     proof->sums[k] = *claimed;
     proof->n_rounds[k] = nv;
+    memcpy(proof->challenges[k], challenges, nv * sizeof(fr_t));
     uint8_t bytes[64 * ORA_SPARSE_MAX];
     for (size_t r = 0; r < nv; ++r) {                            /* transcript.commit(&sumcheck_proof.to_bytes()) */
         size_t nb = ora_sparse_to_bytes(bytes, &proof->round_polys[k][r]);

@@ -540,12 +540,27 @@ GKR_MAX_LAYERS, GKR_MAX_ROUNDS = 20, 40
 class GkrProof(C.Structure):
     _fields_ = [("n_proofs", C.c_size_t), ("sums", C.c_uint64 * (4 * GKR_MAX_LAYERS)), ("n_rounds", C.c_size_t * GKR_MAX_LAYERS),
                 ("round_polys", (Sparse * GKR_MAX_ROUNDS) * GKR_MAX_LAYERS), ("wb", C.c_uint64 * (4 * GKR_MAX_LAYERS)),
-                ("wc", C.c_uint64 * (4 * GKR_MAX_LAYERS)), ("w0", C.c_uint64 * 8)]
+                ("wc", C.c_uint64 * (4 * GKR_MAX_LAYERS)), ("w0", C.c_uint64 * 8),
+                ("challenges", (C.c_uint64 * (4 * GKR_MAX_ROUNDS)) * GKR_MAX_LAYERS)]
+
+    def layer_challenges(self, k):
+        """the challenges prove_partial returned for sumcheck proof k: uint64 [n_rounds, 4]"""
+        return np.array(self.challenges[k][0:4 * self.n_rounds[k]], dtype=np.uint64).reshape(-1, 4)
 
     def layer(self, k):
         """(sum [4], [Sparse per round], wb [4], wc [4]) of sumcheck proof k"""
         return (np.array(self.sums[4 * k:4 * k + 4], dtype=np.uint64), [self.round_polys[k][r] for r in range(self.n_rounds[k])],
                 np.array(self.wb[4 * k:4 * k + 4], dtype=np.uint64), np.array(self.wc[4 * k:4 * k + 4], dtype=np.uint64))
+
+
+    def fields(self):
+        """everything a GKRProof holds, as plain python values (for == between two provers)"""
+        out = [tuple(self.w0[0:8])]
+        for k in range(self.n_proofs):
+            s, rps, wb, wc = self.layer(k)
+            out.append((tuple(int(v) for v in s), tuple(int(v) for v in wb), tuple(int(v) for v in wc), self.layer_challenges(k).tobytes(),
+                        tuple((rp.len, tuple(rp.coeff[0:4 * rp.len]), tuple(rp.pow[0:4 * rp.len])) for rp in rps)))
+        return out
 
 
 def _circuit_args(layers):
@@ -596,6 +611,18 @@ def gkr_prove(layers, evaluation):
     rc = lib().ora_gkr_prove(nl, ng, _p(gt), _p(i0), _p(i1), _p(flat), lens, C.byref(proof))
     if rc != 0:
         raise AssertionError("gkr_prove: shape error %d" % rc)
+    return proof
+
+
+def gkr_prove_sparse(layers, evaluation):
+    """GKRProtocol::prove on sparse containers (gkr_sparse.c): the reference's (b, c)-table prover in O(gates) per round"""
+    nl, ng, gt, i0, i1 = _circuit_args(layers)
+    flat = np.ascontiguousarray(np.concatenate([_fr(e).reshape(-1, 4) for e in evaluation]))
+    lens = (C.c_size_t * len(evaluation))(*[len(e) for e in evaluation])
+    proof = GkrProof()
+    rc = lib().ora_gkr_prove_sparse(nl, ng, _p(gt), _p(i0), _p(i1), _p(flat), lens, C.byref(proof))
+    if rc != 0:
+        raise AssertionError("gkr_prove_sparse: shape error %d" % rc)
     return proof
 
 

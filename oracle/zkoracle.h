@@ -134,6 +134,7 @@ typedef struct {
     ora_sparse_t round_polys[ORA_GKR_MAX_LAYERS][ORA_GKR_MAX_ROUNDS];
     fr_t wb[ORA_GKR_MAX_LAYERS], wc[ORA_GKR_MAX_LAYERS];
     fr_t w0[2];                                                    /* w_0_mle: [output, 0] */
+    fr_t challenges[ORA_GKR_MAX_LAYERS][ORA_GKR_MAX_ROUNDS];       /* what prove_partial returned beside each proof (b then c) */
 } ora_gkr_proof_t;
 size_t ora_gkr_mle_size(size_t layer_index);
 int  ora_circuit_evaluation(size_t n_layers, const size_t *n_gates, const uint8_t *gate_type, const uint32_t *in0,
@@ -142,6 +143,9 @@ int  ora_circuit_add_mult_mle(size_t n_layers, const size_t *n_gates, const uint
                               const uint32_t *in1, size_t layer_index, fr_t *add, fr_t *mul);
 int  ora_gkr_prove(size_t n_layers, const size_t *n_gates, const uint8_t *gate_type, const uint32_t *in0,
                    const uint32_t *in1, const fr_t *layers, const size_t *layer_len, ora_gkr_proof_t *proof);
+/* the same prover on sparse containers (gkr_sparse.c): reaches depth 20, bit-identical to ora_gkr_prove where that runs */
+int  ora_gkr_prove_sparse(size_t n_layers, const size_t *n_gates, const uint8_t *gate_type, const uint32_t *in0,
+                          const uint32_t *in1, const fr_t *layers, const size_t *layer_len, ora_gkr_proof_t *proof);
 int  ora_gkr_verify(size_t n_layers, const size_t *n_gates, const uint8_t *gate_type, const uint32_t *in0,
                     const uint32_t *in1, const fr_t *input, size_t n_input, const ora_gkr_proof_t *proof);
 

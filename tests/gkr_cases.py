@@ -28,3 +28,40 @@ def random_circuit(num_of_layers):
         n_in = 2 ** (li + 1)
         layers.append([(A if li % 2 == 0 else M, (2 * g) % n_in, (2 * g + 1) % n_in) for g in range(2 ** li)])
     return layers
+
+
+def scrambled_circuit(num_of_layers, seed):
+    """Same shape as Circuit::random, but every gate draws its type and both inputs at random: inputs shared between gates
+    (several gates on one (b, c) pair, values read twice), b == c, unused inputs -- what Circuit::random never produces."""
+    import random
+    rng = random.Random(seed)
+    layers = []
+    for li in range(num_of_layers):
+        n_in = 2 ** (li + 1)
+        layers.append([(rng.choice((A, M)), rng.randrange(n_in), rng.randrange(n_in)) for _ in range(2 ** li)])
+    return layers
+
+
+def gkr_proof_mismatches(ora, proof, want):
+    """Field by field: a GKRProof of the HIP prover (zk.GKRProtocol.prove / prove_sharded) against the oracle's
+    (ora.gkr_prove / ora.gkr_prove_sparse) -- w_0, and per layer the claimed sum, ComposedSumcheckProof::to_bytes, the challenges
+    prove_partial returned, w_b and w_c.  Returns the list of what differs (empty = bit-identical)."""
+    import numpy as np
+    bad = []
+    if len(proof.sumcheck_proofs) != want.n_proofs:
+        return ["n_proofs %d != %d" % (len(proof.sumcheck_proofs), want.n_proofs)]
+    w0 = proof.w_0_mle.evaluations
+    w0 = (w0.cpu().numpy() if hasattr(w0, "cpu") else np.asarray(w0)).view(np.uint64).reshape(-1)
+    if [int(v) for v in w0] != list(want.w0[0:8]):
+        bad.append("w_0")
+    for k, sp in enumerate(proof.sumcheck_proofs):
+        w_sum, w_rps, w_wb, w_wc = want.layer(k)
+        if not np.array_equal(sp.sum, w_sum):
+            bad.append("layer %d sum" % k)
+        if sp.to_bytes() != ora.multi_composed_proof_bytes(w_rps):
+            bad.append("layer %d proof bytes" % k)
+        if not np.array_equal(np.asarray(proof._challenges[k]).reshape(-1, 4), want.layer_challenges(k)):
+            bad.append("layer %d challenges" % k)
+        if not (np.array_equal(proof.wb_s[k], w_wb) and np.array_equal(proof.wc_s[k], w_wc)):
+            bad.append("layer %d w_b / w_c" % k)
+    return bad

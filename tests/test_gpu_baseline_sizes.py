@@ -166,7 +166,11 @@ def test_univariate_commit_2_20_identity(zk, ora, table):
 
 
 # ---- configs[3]: Circuit::random(20) --------------------------------------------------------------------------------------
-def test_gkr_depth_20_accepted_and_tamper_rejected(zk, ora):
+def test_gkr_depth_20_bit_exact_accepted_and_tamper_rejected(zk, ora):
+    """configs[3] at its full width: the proof is the sparse-container restatement's of the reference prover (oracle/gkr_sparse.c:
+    w_0, claimed sums, proof bytes, challenges, w_b, w_c of all 20 layers), the sharded prover's sessions yield the same, the
+    restated verifier accepts it and rejects it for another input."""
+    from gkr_cases import gkr_proof_mismatches
     from test_gpu_gkr import _to_oracle_proof
     depth = 20
     layers = random_circuit(depth)
@@ -175,6 +179,11 @@ def test_gkr_depth_20_accepted_and_tamper_rejected(zk, ora):
     ev = circuit.evaluation(inp)
     proof = zk.GKRProtocol.prove(circuit, ev)
     assert len(proof.sumcheck_proofs) == depth and len(proof.sumcheck_proofs[-1].round_polys) == 2 * depth
+    want_ev = ora.circuit_evaluation(layers, inp)
+    assert all(np.array_equal(a.cpu().numpy().view(np.uint64), b) for a, b in zip(ev, want_ev))
+    want = ora.gkr_prove_sparse(layers, want_ev)
+    assert gkr_proof_mismatches(ora, proof, want) == []
+    assert gkr_proof_mismatches(ora, zk.GKRProtocol.prove_sharded(circuit, ev, use_stages=True), want) == []
     op = _to_oracle_proof(zk, ora, proof)
     assert ora.gkr_verify(layers, inp, op)
     bad = inp.copy()

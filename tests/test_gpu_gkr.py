@@ -4,7 +4,7 @@ gkr/src/protocol.rs tests.  The GPU proof must be bit-identical to the oracle's 
 import numpy as np
 import pytest
 
-from gkr_cases import CIRCUIT_2, CIRCUIT_3, GKR_1, GKR_2, random_circuit
+from gkr_cases import CIRCUIT_2, CIRCUIT_3, GKR_1, GKR_2, gkr_proof_mismatches, random_circuit, scrambled_circuit
 
 pytestmark = pytest.mark.gpu
 
@@ -76,6 +76,8 @@ def _check_against_oracle(zk, ora, layers, inp):
         assert np.array_equal(sp.sum, w_sum)
         assert sp.to_bytes() == ora.multi_composed_proof_bytes(w_rps)
         assert np.array_equal(proof.wb_s[k], w_wb) and np.array_equal(proof.wc_s[k], w_wc)
+    assert gkr_proof_mismatches(ora, proof, want) == []
+    assert gkr_proof_mismatches(ora, proof, ora.gkr_prove_sparse(layers, want_ev)) == []
     assert ora.gkr_verify(layers, inp, _to_oracle_proof(zk, ora, proof))
     return proof
 
@@ -153,6 +155,44 @@ def test_gkr_beyond_the_dense_tables(zk, ora, depth):
     bad = inp.copy()
     bad[5, 0] ^= np.uint64(1)
     assert not ora.gkr_verify(layers, bad, op)
+
+
+@pytest.mark.parametrize("depth", [9, 10, 12, 13, 16])
+def test_gkr_bit_exact_beyond_the_dense_tables(zk, ora, depth):
+    """Bit for bit against the reference's layer prover restated on sparse containers (oracle/gkr_sparse.c: the (b, c)-table
+    prover of protocol.rs:61-108 / multi_composed_sumcheck.rs:64-121 in O(gates) per round, pinned on the dense restatement at
+    every depth that one reaches).  At these depths the layers' sumchecks run through the mid-size kernels in their GKR role
+    (rounds one ahead of the transcript, two-round stages, additive table, continued transcript) -- which the restated verifier
+    cannot see: gkr/src/protocol.rs:154-181 never checks a layer's final claim against the wiring for layers >= 2.
+    Depth 20 (BASELINE configs[3]): tests/test_gpu_baseline_sizes.py."""
+    layers = random_circuit(depth)
+    inp = ora.random_fr(2 ** depth, 60 + depth)
+    circuit = zk.Circuit.from_tuples(layers)
+    ev = circuit.evaluation(inp)
+    want_ev = ora.circuit_evaluation(layers, inp)
+    want = ora.gkr_prove_sparse(layers, want_ev)
+    assert gkr_proof_mismatches(ora, zk.GKRProtocol.prove(circuit, ev), want) == []
+    if depth in (9, 12, 16):
+        for stages in (False, True):                              # the sharded prover's sessions, one rank
+            assert gkr_proof_mismatches(ora, zk.GKRProtocol.prove_sharded(circuit, ev, use_stages=stages), want) == []
+
+
+@pytest.mark.parametrize("depth,seed", [(4, 11), (7, 12), (10, 13), (12, 14), (14, 15)])
+def test_gkr_bit_exact_scrambled_wiring(zk, ora, depth, seed):
+    """Gate types mixed inside a layer, inputs shared between gates, b == c, unused inputs (Circuit::random has none of these):
+    CSR rows of uneven length, both product terms live in every layer, zero coefficients that must be dropped per term."""
+    layers = scrambled_circuit(depth, seed)
+    inp = ora.random_fr(2 ** depth, 900 + seed)
+    if seed % 2:
+        inp[1] = 0
+    circuit = zk.Circuit.from_tuples(layers)
+    ev = circuit.evaluation(inp)
+    want_ev = ora.circuit_evaluation(layers, inp)
+    assert all(np.array_equal(_host(a), b) for a, b in zip(ev, want_ev))
+    want = ora.gkr_prove_sparse(layers, want_ev)
+    assert gkr_proof_mismatches(ora, zk.GKRProtocol.prove(circuit, ev), want) == []
+    assert gkr_proof_mismatches(ora, zk.GKRProtocol.prove_sharded(circuit, ev, use_stages=True), want) == []
+    assert ora.gkr_verify(layers, inp, want)
 
 
 def test_gkr_device_circuit_reused_across_inputs(zk, ora):

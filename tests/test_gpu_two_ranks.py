@@ -67,6 +67,13 @@ def _worker(rank, world, port, q):
             ok = ok and all(np.array_equal(a, b) for a, b in zip(got.wb_s, want.wb_s)) and all(np.array_equal(a, b) for a, b in zip(got.wc_s, want.wc_s))
             ok = ok and all(np.array_equal(a, b) for a, b in zip(got._challenges, want._challenges))
             res["gkr_depth_%d" % depth] = bool(ok)
+            if depth < 20 or rank == 0:   # and against the CPU oracle's sparse-container restatement of the reference prover (15 s at depth 20)
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from gkr_cases import gkr_proof_mismatches, random_circuit
+                from oracle import oracle as ora
+                layers = random_circuit(depth)
+                o_ev = ora.circuit_evaluation(layers, zk.Fr.random(2 ** depth, 300 + depth))
+                res["gkr_depth_%d_vs_oracle" % depth] = gkr_proof_mismatches(ora, got, ora.gkr_prove_sparse(layers, o_ev)) == []
         # sharded KZG commit
         tau = zk.Fr.random(12, 7)
         srs = zk.TrustedSetup.setup(tau)

@@ -479,7 +479,7 @@ def test_multilinear_kzg_open_shape_panics(ora):
 
 
 # ---- circuit + GKR: circuit/src/circuit.rs, gkr/src/protocol.rs ---------------------------------------------
-from gkr_cases import CIRCUIT_2, CIRCUIT_3, GKR_1, GKR_2, random_circuit   # noqa: E402
+from gkr_cases import CIRCUIT_2, CIRCUIT_3, GKR_1, GKR_2, random_circuit, scrambled_circuit   # noqa: E402
 
 
 @pytest.mark.parametrize("case", [GKR_1, CIRCUIT_2, CIRCUIT_3])
@@ -526,6 +526,47 @@ def test_gkr_random_circuit_depth_5(ora):   # Circuit::random, gkr/benches
     ev = ora.circuit_evaluation(layers, inp)
     proof = ora.gkr_prove(layers, ev)
     assert ora.gkr_verify(layers, inp, proof)
+
+
+# ---- the sparse-container restatement of the same prover (oracle/gkr_sparse.c) against the dense one ----------------
+@pytest.mark.parametrize("case", [GKR_1, GKR_2, CIRCUIT_3])
+def test_gkr_sparse_prover_is_the_dense_prover_on_reference_circuits(ora, case):   # protocol.rs:209-286, circuit.rs:209-260
+    ev = ora.circuit_evaluation(case["layers"], F(ora, case["input"]))
+    assert ora.gkr_prove_sparse(case["layers"], ev).fields() == ora.gkr_prove(case["layers"], ev).fields()
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_gkr_sparse_prover_is_the_dense_prover_random_circuit(ora, depth):   # Circuit::random (circuit.rs:99-122)
+    layers = random_circuit(depth)
+    ev = ora.circuit_evaluation(layers, ora.random_fr(2 ** depth, 300 + depth))
+    sparse, dense = ora.gkr_prove_sparse(layers, ev), ora.gkr_prove(layers, ev)
+    assert sparse.n_proofs == depth and sparse.fields() == dense.fields()
+
+
+@pytest.mark.parametrize("depth,seed", [(2, 1), (3, 2), (4, 3), (5, 4), (5, 5), (6, 6)])
+def test_gkr_sparse_prover_is_the_dense_prover_scrambled_wiring(ora, depth, seed):
+    """gates of both types in one layer, several gates on one (b, c) pair, b == c: list entries merge and cancel in ways
+    Circuit::random never shows"""
+    layers = scrambled_circuit(depth, seed)
+    inp = ora.random_fr(2 ** depth, 500 + seed)
+    if seed == 5:
+        inp[3] = 0                                                # a zero value: zero products, dropped coefficients
+    ev = ora.circuit_evaluation(layers, inp)
+    sparse, dense = ora.gkr_prove_sparse(layers, ev), ora.gkr_prove(layers, ev)
+    assert sparse.fields() == dense.fields()
+    assert ora.gkr_verify(layers, inp, sparse)
+
+
+def test_gkr_sparse_prover_depth_12_verifies(ora):
+    """beyond the dense tables (2^38 wiring entries): the proof passes the restated verifier and a wrong input fails it"""
+    layers = random_circuit(12)
+    inp = ora.random_fr(2 ** 12, 77)
+    proof = ora.gkr_prove_sparse(layers, ora.circuit_evaluation(layers, inp))
+    assert proof.n_proofs == 12 and proof.n_rounds[11] == 24
+    assert ora.gkr_verify(layers, inp, proof)
+    bad = inp.copy()
+    bad[5, 0] ^= np.uint64(1)
+    assert not ora.gkr_verify(layers, bad, proof)
 
 
 # ---- dense division + UnivariateKZG::open (dense_univariate.rs:88-124, univariate_kzg.rs:60-81) -------------
