@@ -260,6 +260,34 @@ def bench_fold(args, zk, N, poly, torch):
                          "algorithmic_bytes_per_launch": "48 B x table entries (32 n read + 16 n written)"}}
 
 
+def bench_evaluate(args, zk, N, poly, torch):
+    """MultilinearTrait::evaluation (evaluation_form.rs:162-175) of the 2^log_n table at log_n known points: SURVEY 8d's 96 n row
+    (the reference: n folds of a cloned table).  Here ONE pass over the table -- the k-variable fold whose tiles keep the sum of their
+    outputs weighted by the eq table of the remaining points -- so the bytes really moved are 32 (n + n / 2^k), reported beside the
+    algorithmic 96 n."""
+    n = len(poly)
+    pts = zk.Fr.synthetic(args.log_n, SEED_TABLE + 0x778)
+    ctx = N.Context.get()
+    reps = max(3, min(args.steps, 10))
+    ts = _timed(lambda: poly.evaluation(pts), torch, reps=reps)
+    wall = sorted(ts)[len(ts) // 2]
+    N.check(N.lib().zkhip_profile_enable(ctx.handle, 1), "profile_enable")
+    for _ in range(reps):
+        poly.evaluation(pts)
+    ms, cnt, by = _profile(N, ctx, b"multifold_eval")
+    N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
+    moved = by / max(1, cnt)
+    ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"workload": "evaluation of the 2^%d table at %d points (host call: the value comes back)" % (args.log_n, args.log_n),
+            "value": round(n / wall, 1), "unit": "field-evals/s", "ms_per_evaluation": round(1e3 * wall, 4), "batches": _stats(ts, 1e3),
+            "algorithmic_bytes": 96.0 * n, "algorithmic_gbs": round(96.0 * n / wall / 1e9, 1), "algorithmic_frac_of_hbm": round(96.0 * n / wall / 1e9 / HBM_PEAK_GBS, 4),
+            "bytes_moved": moved, "moved_frac_of_hbm": round(moved / wall / 1e9 / HBM_PEAK_GBS, 4) if moved else None,
+            "roofline": {"bound": "hbm", "kernel": "multifold_mfma_kernel<4, 4, true> (the pass; weights and the records' sum are two small launches beside it)",
+                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "launches": cnt,
+                         "avg_launch_us": round(1e3 * ms / max(1, cnt), 2),
+                         "algorithmic_bytes_per_launch": "32 B x (table entries + eq-table entries of the remaining points) read"}}
+
+
 def bench_ntt(args, zk, N, torch):
     """Domain::fft / ifft (domain.rs:108-118) at 2^21 points -- the transform size of a 2^20 x 2^20 product -- and
     UnivariateEval::multiply (evaluation.rs:59-86).  Bound by field products, not HBM: both figures are reported."""
@@ -422,7 +450,7 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
                            "peak": round(peak_tmads, 2), "unit": "T v_mad_u64_u32 lane-ops/s",
                            "frac": round(mads / (ms * 1e-3) / 1e12 / peak_tmads, 4),
                            "ops_per_launch": "4060 multiply-adds x %d windows x points" % windows}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:                         # at N > 1 too: the other ranks wait in the next leg's barrier
         from oracle import oracle as ora
         m = 1 << 14                                                     # bounded sample of the naive reference algorithm (~3.5 s)
         pts = srs.powers_of_tau_in_g1[:m].cpu().numpy().view(np.uint64)
@@ -493,6 +521,39 @@ def bench_composed(args, zk, N, rank, world, barrier, dist, torch, np):
             "entries_per_table_per_gpu": n, "exchanges_per_prove": exch[0] if world > 1 else 0,
             "transcript_replicated_on_all_ranks": same,
             "sharding": "tables sharded by low index bits; two rounds per exchange: one record of 16 cross-block sums (+ 4 block sums) per term and rank all-gathered per stage" if world > 1 else "single GPU"}
+
+
+def bench_composed_shapes(args, zk, N, torch, np):
+    """The reference's OTHER composed bench shapes, one GPU: ComposedSumcheck::prove on a product of FIVE tables
+    (sumcheck/benches/composed_sumcheck_benchmark.rs:33-78) and MultiComposedSumcheckProver::prove_partial on (2 + 3) tables
+    (sumcheck/benches/multi_composed_sumcheck_benchmark.rs:8-54; prove_partial: the variant that does not hash the tables first).
+    SURVEY 8d: 96 K N algorithmic bytes per prover."""
+    out = {}
+    steps = max(2, min(args.steps, 10))
+    for log_n in sorted({20, args.composed_log_n}):
+        n = 1 << log_n
+        tabs = [zk.Multilinear(_synthetic(zk, torch, n, SEED_TABLE + 0x500 + k)) for k in range(5)]
+        poly = zk.ComposedMultilinear(tabs)
+        fn = lambda: zk.ComposedSumcheck(poly).prove()       # noqa: E731
+        fn()
+        ts = _timed(fn, torch, reps=steps)
+        dt = sorted(ts)[len(ts) // 2]
+        out["composed_k5_2^%d" % log_n] = {"workload": "ComposedSumcheck::prove, product of 5 tables of 2^%d entries" % log_n, "ms_per_prove": round(1e3 * dt, 4),
+                                           "batches": _stats(ts, 1e3), "value": round(5 * n / dt, 1), "unit": "field-evals/s (table entries consumed)",
+                                           "algorithmic_bytes": 96.0 * 5 * n, "frac_of_hbm": round(96.0 * 5 * n / dt / 1e9 / HBM_PEAK_GBS, 4)}
+        del tabs, poly
+    n = 1 << 20
+    tabs = [zk.Multilinear(_synthetic(zk, torch, n, SEED_TABLE + 0x520 + k)) for k in range(5)]
+    mpoly = [zk.ComposedMultilinear(tabs[:2]), zk.ComposedMultilinear(tabs[2:])]
+    claimed = zk.MultiComposedSumcheckProver.calculate_poly_sum(mpoly)
+    fn = lambda: zk.MultiComposedSumcheckProver.prove_partial(mpoly, claimed)       # noqa: E731
+    fn()
+    ts = _timed(fn, torch, reps=steps)
+    dt = sorted(ts)[len(ts) // 2]
+    out["multi_composed_2_3_2^20"] = {"workload": "MultiComposedSumcheckProver::prove_partial, (2 + 3) tables of 2^20 entries", "ms_per_prove": round(1e3 * dt, 4),
+                                      "batches": _stats(ts, 1e3), "value": round(5 * n / dt, 1), "unit": "field-evals/s (table entries consumed)",
+                                      "algorithmic_bytes": 96.0 * 5 * n, "frac_of_hbm": round(96.0 * 5 * n / dt / 1e9 / HBM_PEAK_GBS, 4)}
+    return out
 
 
 def bench_gkr(args, zk, N, D, rank, world, barrier, dist, torch, np):
@@ -594,22 +655,50 @@ def bench_strong_and_config4(args, zk, N, rank, world, barrier, dist, torch, np)
                                   "value": round(n_total * args.steps / med, 1), "unit": "field-evals/s", "ms_per_step": round(1e3 * med / args.steps, 4),
                                   "batches": _stats([b / args.steps for b in bs], 1e3), "exchanges_per_prove": ex[0], "scaling": "strong"}
         del shard
+    # (b) ONE SRS for the whole commit: the same tau on every rank, generated whole on every GPU (6 GiB at 2^26, 0.6 s) and cut down to
+    # this rank's points g, g + N, ...; this rank's scalars are entries g, g + N, ... of ONE polynomial p.  Checked once before the
+    # timing: commit == p(tau) * G, with p(tau) = sum_g eq_g(tau_low) * p_g(tau_high) from every rank's evaluation of its shard.
     log_c = args.config4_log_n
-    tau = zk.Fr.synthetic(log_c, SEED_SCALARS + 0x300 + rank)
-    srs = zk.TrustedSetup.setup(tau)
+    log_w = world.bit_length() - 1
+    tau = zk.Fr.synthetic(log_c + log_w, SEED_SCALARS + 0x300)                     # variables 0 .. log_c - 1 index j (high bits), the rest the rank
+    whole = zk.TrustedSetup.setup(tau)
+    srs = zk.TrustedSetup(whole.powers_of_tau_in_g1[rank::world].contiguous(), whole.inf[rank::world].contiguous())
+    del whole
+    torch.cuda.empty_cache()
     srs.precompute()
     poly = zk.Multilinear(_synthetic(zk, torch, 1 << log_c, SEED_SCALARS + 0x310 + rank))
 
     def commit():
         return D.sharded_commit(None, srs.inf, poly.evaluations, comm, table=srs.table)
 
-    commit()
+    com = commit()
+    # the identity
+    R_MOD, to_int = zk.Fr.MODULUS, (lambda a: zk.Fr.to_ints(np.asarray(a, dtype=np.uint64).reshape(1, 4))[0])
+    mine = torch.from_numpy(np.ascontiguousarray(poly.evaluation(tau[:log_c])).view(np.int64).copy()).cuda()
+    every = torch.empty(4 * world, dtype=torch.int64, device="cuda")
+    dist.all_gather_into_tensor(every, mine)
+    vals = every.cpu().numpy().view(np.uint64).reshape(world, 4)
+    t_low = [to_int(t) for t in tau[log_c:]]
+    p_tau = 0
+    for g in range(world):
+        w = 1
+        for i, t in enumerate(t_low):                                               # variable log_c + i <-> bit (log_w - 1 - i) of g
+            w = w * (t if (g >> (log_w - 1 - i)) & 1 else (1 - t)) % R_MOD
+        p_tau = (p_tau + w * to_int(vals[g])) % R_MOD
+    one_var = zk.TrustedSetup.setup(zk.Fr.synthetic(1, SEED_SCALARS + 0x3FF))      # [G (1 - x), G x]: committing [v, v] against it is v * G
+    want = zk.MultilinearKZG.commitment(zk.Multilinear(zk.Fr.from_ints([p_tau, p_tau])), one_var)
+    identity = bool((not com[1]) and (not want.infinity) and np.array_equal(np.asarray(com[0], dtype=np.uint64), want.xy))
+    if not identity:
+        sys.stderr.write("bench.py: rank %d: sharded commit != p(tau) * G on ONE sharded SRS\n" % rank)
+        sys.exit(3)
     bs, com = _batches(commit, 3, barrier, dist, world, torch, min_total=0.2, max_batches=6)
     med = sorted(bs)[len(bs) // 2]
     same = _same_on_all_ranks(dist, torch, np, np.concatenate([np.asarray(com[0], dtype=np.uint64), np.array([1 if com[1] else 0], dtype=np.uint64)]))
-    out["commit_config4_shape"] = {"workload": "multilinear KZG commit of 2^%d evaluations, (scalars, SRS) sharded over %d GPUs: 2^%d points per GPU" % (log_c + world.bit_length() - 1, world, log_c),
+    out["commit_config4_shape"] = {"workload": "multilinear KZG commit of 2^%d evaluations, (scalars, SRS) of ONE commit sharded over %d GPUs: 2^%d points per GPU" % (log_c + log_w, world, log_c),
                                    "value": round(float(1 << log_c) * world * 3 / med, 1), "unit": "points/s", "ms_per_commit": round(1e3 * med / 3, 3),
-                                   "batches": _stats([b / 3 for b in bs], 1e3, 3), "exchanges_per_commit": 1, "commitment_replicated_on_all_ranks": same}
+                                   "batches": _stats([b / 3 for b in bs], 1e3, 3), "exchanges_per_commit": 1, "commitment_replicated_on_all_ranks": same,
+                                   "commit_equals_p_tau_times_G": identity,
+                                   "identity_note": "one SRS (same tau on every rank, rank g holds points g, g + N, ...), p(tau) from every rank's evaluation of its shard, p(tau) * G as a two-entry commit; checked before the timing, exit 3 on mismatch"}
     return out
 
 
@@ -879,15 +968,27 @@ def main():
             src = os.path.relpath(files[-1], ROOT)
             traffic = pmc["multifold"]["hbm_bytes_per_launch"]
             traffic_all = {k: v.get("hbm_bytes_per_launch") for k, v in pmc.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
+            for short, needle in (("fine_sums", "fine_sums_kernel"), ("multifold", "multifold_mfma_kernel<4, 4>"), ("chunk_sums", "chunk_sums_kernel")):
+                hits = [v for k, v in pmc.get("kernels", {}).items() if needle in k and "hbm_bytes_per_launch" in v]
+                if hits and short not in traffic_all:
+                    traffic_all[short] = max(h["hbm_bytes_per_launch"] for h in hits)      # the 2^24-entry launch of the step
             traffic_source = src + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in round %s; not collected in this run)" % src.split(os.sep)[1]
     except Exception:
         traffic = None
     longest = max(per_kernel, key=lambda k: per_kernel[k]["avg_launch_us"]) if per_kernel else None
-    roofline = {"bound": "hbm", "kernel": "multifold_mfma_kernel<4, 4> (k-variable fold of the 2^%d table next to the serial rounds, limb products as int8 MFMA; k = 6 at 2^24 on one GPU)" % args.log_n,
+    # the line's roofline entry = the LONGEST streaming kernel of the step (the dominant one); the others are under per_kernel
+    lk = per_kernel.get(longest) if longest else None
+    if lk is not None:
+        achieved, cnt = lk["achieved"], lk["launches"]
+        ms = lk["avg_launch_us"] * cnt / 1e3
+        if traffic_all and longest in traffic_all:
+            traffic = traffic_all[longest]
+    roofline = {"bound": "hbm", "kernel": lk["kernel"] if lk else "multifold_mfma_kernel<4, 4>",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "launches": cnt, "avg_launch_us": round(1e3 * ms / max(1, cnt), 2),
-                "algorithmic_bytes_per_launch": "32 B x (table entries read + folded entries written), k variables per launch",
+                "algorithmic_bytes_per_launch": lk["bytes_per_launch"] if lk else None,
+                "algorithmic_bytes_note": "fine_sums: 32 B x table entries read; multifold: 32 B x (table entries read + folded entries written), k variables per launch",
                 # every streaming kernel of a step against the same roof, and the step as a whole on the bytes it REALLY moves
                 "per_kernel": per_kernel, "longest_streaming_kernel": longest, "traffic_per_kernel": traffic_all,
                 "step_bytes_moved": step_bytes,
@@ -907,6 +1008,8 @@ def main():
 
     # ---- the single-variable fold (48 n bytes), rank-local
     fold = leg(args.no_fold, bench_fold, args, zk, N, poly, torch)
+    # ---- full evaluation (96 n bytes algorithmic), rank-local
+    evaluate = leg(args.no_fold, bench_evaluate, args, zk, N, poly, torch)
     # ---- second half of BASELINE's metric: MSM points/s of the KZG commit on a 2^20-point SRS per GPU
     msm = None
     if not args.no_msm:
@@ -915,6 +1018,7 @@ def main():
     ntt = leg(args.no_ntt, bench_ntt, args, zk, N, torch)
     # ---- the composed prover (GKR's sumcheck shape) on sharded tables; informational, never part of `value`
     composed = leg(args.no_composed, bench_composed, args, zk, N, rank, world, barrier, dist, torch, np)
+    composed_shapes = leg(args.no_composed or world > 1, bench_composed_shapes, args, zk, N, torch, np)
     gkr = leg(args.no_gkr, bench_gkr, args, zk, N, D, rank, world, barrier, dist, torch, np)
     # ---- PCIe-inclusive figure (never `value`), exchange cost and the N = 8 prediction (N = 1), strong scaling + configs[4] shape (N > 1)
     h2d = leg(args.no_h2d or world > 1, bench_h2d, args, zk, N, table, poly, torch, np)
@@ -934,7 +1038,7 @@ def main():
     # ---- CPU baseline: the oracle's single-threaded restatement of poly_sum + prove, rank 0 only.  Last: the all-cores leg
     # loads every host core, which would disturb the host-side share of the GPU legs above if it ran before them
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:      # at N > 1 too: the other ranks wait in the barrier below
         from oracle import oracle as ora
         cpu_log = min(args.log_n, 24)
         ev = table[: 1 << cpu_log].cpu().numpy().view(np.uint64)
@@ -955,9 +1059,53 @@ def main():
         except Exception as e:
             cpu["all_cores"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    if world > 1:
+        barrier()                        # the ranks that ran no CPU baseline wait here for rank 0
     if rank == 0:
         total_evals = float(n) * world * args.steps
+        if world > 1:                    # which transport the sharded provers ran on, and why if it is not the library's RCCL communicator
+            import ctypes as C
+            ver = C.c_int(0)
+            ok = N.lib().zkhip_rccl_version(C.byref(ver)) == 0
+            exchange = dict(exchange or {})
+            exchange.update({"transport": comm.transport if isinstance(comm.transport, str) else "callback", "fallback_reason": comm.fallback_reason,
+                             "rccl_version": ver.value if ok else None, "torch_nccl_version": list(torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None})
+
+        def g(d, *path):
+            for k in path:
+                if not isinstance(d, dict) or k not in d:
+                    return None
+                d = d[k]
+            return d
+        # every leg's headline figure, flat and FIRST in the line (a record that keeps only the head or the tail of the line keeps these)
+        legs = {"step_ms": round(1e3 * dt / args.steps, 4), "step_hbm_frac": roofline.get("step_hbm_frac"),
+                "pipelined_ms": g(pipelined, "ms_per_step"),
+                "fine_sums_us": g(per_kernel, "fine_sums", "avg_launch_us"), "fine_sums_frac": g(per_kernel, "fine_sums", "frac"),
+                "kfold_us": g(per_kernel, "multifold", "avg_launch_us"), "kfold_frac": g(per_kernel, "multifold", "frac"),
+                "fold_ms": g(fold, "ms_per_fold"), "fold_frac": g(fold, "roofline", "frac"),
+                "evaluate_ms": g(evaluate, "ms_per_evaluation"), "evaluate_frac_96n": g(evaluate, "algorithmic_frac_of_hbm"), "evaluate_pass_frac": g(evaluate, "roofline", "frac"),
+                "msm_ms": g(msm, "ms_per_commit"), "msm_mpoints_s": round(g(msm, "value") / 1e6, 1) if g(msm, "value") else None,
+                "msm_alu_frac": g(msm, "roofline_alu", "frac"), "msm_inflight_ms": g(msm, "pipelined", "ms_per_commit"),
+                "msm_no_table_ms": g(msm, "without_srs_table", "ms_per_commit"),
+                "open_ms": g(msm, "extras", "open", "ms_per_open"), "open_tables_ms": g(msm, "extras", "open_level_tables", "ms_per_open"),
+                "srs_setup_ms": g(msm, "extras", "srs_setup_ms"),
+                "ntt_ms": g(ntt, "ms_per_fft"), "intt_ms": g(ntt, "ms_per_ifft"), "multiply_ms": g(ntt, "ms_per_multiply"), "ntt_alu_frac": g(ntt, "roofline_alu", "frac"),
+                "composed_k2_ms": g(composed, "ms_per_prove"),
+                "composed_k5_2^20_ms": g(composed_shapes, "composed_k5_2^20", "ms_per_prove"), "composed_k5_2^20_frac": g(composed_shapes, "composed_k5_2^20", "frac_of_hbm"),
+                "composed_k5_2^%d_ms" % args.composed_log_n: g(composed_shapes, "composed_k5_2^%d" % args.composed_log_n, "ms_per_prove"),
+                "composed_k5_2^%d_frac" % args.composed_log_n: g(composed_shapes, "composed_k5_2^%d" % args.composed_log_n, "frac_of_hbm"),
+                "multi_composed_2_3_ms": g(composed_shapes, "multi_composed_2_3_2^20", "ms_per_prove"), "multi_composed_2_3_frac": g(composed_shapes, "multi_composed_2_3_2^20", "frac_of_hbm"),
+                "gkr8_ms": g(gkr, "ms_per_proof", "depth_8"), "gkr20_ms": g(gkr, "ms_per_proof", "depth_20"), "gkr20_sharded_ms": g(gkr, "sharded", "ms_per_proof"),
+                "h2d_step_ms": g(h2d, "sumcheck", "ms_per_step"),
+                "cpu_1core_mevals_s": round(g(cpu, "value") / 1e6, 2) if g(cpu, "value") else None,
+                "cpu_msm_1core_points_s": g(msm, "cpu_baseline", "value"),
+                "strong_ms": g(multi, "sumcheck_strong", "ms_per_step"), "config4_commit_ms": g(multi, "commit_config4_shape", "ms_per_commit"),
+                "transport": g(exchange, "transport") if world > 1 else None}
+        if composed_shapes is not None and composed is not None:
+            composed = dict(composed)
+            composed["other_shapes"] = composed_shapes
         out = {
+            "legs": legs,
             "metric": "field-evals/s (sumcheck 2^%d) + MSM points/s (KZG 2^%d) per BASELINE.json; value = the sumcheck prover's "
                       "field-evals/s, the MSM half is under \"msm\"" % (args.log_n, args.msm_log_n),
             "value": round(total_evals / dt, 1),
@@ -986,6 +1134,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "fold": fold,
+            "evaluate": evaluate,
             "msm": msm,
             "ntt": ntt,
             "composed": composed,

@@ -379,11 +379,17 @@ int zkhip_mc_abort(zkhip_mc_state *st);
  *                           overrides the name) and creates an RCCL communicator from a 128-byte unique id: rank 0 calls
  *                           zkhip_rccl_unique_id, the host distributes the id to all ranks by any means, every rank calls
  *                           zkhip_comm_create_rccl (collective, like ncclCommInitRank).
- * world must be a power of two (the tables have 2^n entries).  A comm is used by one host thread at a time, like its context. */
+ * world must be a power of two (the tables have 2^n entries).  A comm is used by one host thread at a time, like its context.
+ * ERRORS ARE LOCAL: the sharded entry points are collective calls, and a rank that returns an error before an exchange (bad
+ * arguments, out of memory, a HIP error) does not tell its peers -- they wait in that exchange like the ranks of any collective whose
+ * member left.  Hosts validate arguments identically on every rank (all the shape checks depend only on values every rank holds) and
+ * treat a non-zero status at world > 1 as fatal for the job (bench.py: non-zero exit, the launcher ends the other ranks).
+ * zkhip_rccl_version: ncclGetVersion of the RCCL the library resolved (major * 10000 + minor * 100 + patch), ZKHIP_ERR_HIP if none. */
 typedef int (*zkhip_all_gather_fn)(void *user, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
 typedef struct zkhip_comm zkhip_comm;
 int zkhip_comm_create(zkhip_ctx *ctx, uint32_t rank, uint32_t world, zkhip_all_gather_fn fn, void *user, zkhip_comm **out);
 int zkhip_rccl_unique_id(uint8_t *h_id128);
+int zkhip_rccl_version(int *version);
 int zkhip_comm_create_rccl(zkhip_ctx *ctx, const uint8_t *h_id128, uint32_t rank, uint32_t world, zkhip_comm **out);
 int zkhip_comm_destroy(zkhip_comm *comm);
 /* one exchange as the provers issue them (d_recv: world * bytes_per_rank); cumulative counters of this comm */

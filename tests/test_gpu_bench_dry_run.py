@@ -35,6 +35,9 @@ def test_bench_multi_rank_dry_run(world):
     mg = d["multi_gpu"]                                       # strong scaling of the headline + the configs[4]-shaped commit
     assert mg["sumcheck_strong"]["scaling"] == "strong" and mg["sumcheck_strong"]["value"] > 0 and mg["sumcheck_strong"]["exchanges_per_prove"] >= 1
     assert mg["commit_config4_shape"]["commitment_replicated_on_all_ranks"] is True and mg["commit_config4_shape"]["value"] > 0
+    assert mg["commit_config4_shape"]["commit_equals_p_tau_times_G"] is True        # ONE SRS sharded over the ranks, identity checked before the timing
+    assert list(d)[0] == "legs" and d["legs"]["step_ms"] == d["ms_per_step"] and d["legs"]["config4_commit_ms"] > 0 and d["legs"]["gkr20_ms"] > 0
+    assert d["exchange"]["transport"] in ("staged", "rccl", "callback") and "fallback_reason" in d["exchange"] and "rccl_version" in d["exchange"]
     assert d["batches"]["n"] >= 3 and d["batches"]["min"] <= d["ms_per_step"] <= d["batches"]["max"]
     sh = d["gkr"]["sharded"]
     assert sh["proof_equals_single_gpu_proof"] is True and sh["proof_replicated_on_all_ranks"] is True and sh["exchanges_per_proof"] > 0

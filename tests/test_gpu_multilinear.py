@@ -105,12 +105,36 @@ def test_fold_edge_field_values(zk, ora):
         assert np.array_equal(zk.Multilinear(a).partial_evaluation(r, 0).to_numpy(), ora.mle_partial_evaluation(a, r, 0))
 
 
-@pytest.mark.parametrize("log_n", [1, 3, 10, 11, 12, 17])
+@pytest.mark.parametrize("log_n", [1, 3, 10, 11, 12, 13, 16, 17, 18, 19, 20, 21, 22])
 def test_evaluation_matches_oracle(zk, ora, log_n):
+    """sizes either side of 2^17, where `evaluation` turns into ONE pass over the table (the k-variable fold whose tiles keep only the
+    sum of their outputs weighted by the eq table of the remaining points: zkhip_mle_evaluation)"""
     n = 1 << log_n
     a = ora.random_fr(n, 200 + log_n)
     pts = ora.random_fr(log_n, 9)
     assert np.array_equal(zk.Multilinear(a).evaluation(pts), ora.mle_evaluation(a, pts))
+
+
+@pytest.mark.parametrize("log_n", [17, 19])
+def test_evaluation_one_pass_edge_values(zk, ora, log_n):
+    """the one-pass form at boolean points (weights 0 / 1: returns the table entry), at points 0, 1, r - 1 mixed with random ones, on
+    tables of extreme entries (0, r - 1), and against the chain of folds that partial_evaluations takes"""
+    n = 1 << log_n
+    a = ora.random_fr(n, 300 + log_n)
+    a[::3] = 0
+    a[1::7] = F(zk, [R - 1])[0]
+    poly = zk.Multilinear(a)
+    for j in (0, n - 1, 0x15A5A % n):
+        pt = ora.fr_from_ints([(j >> (log_n - 1 - k)) & 1 for k in range(log_n)])
+        assert np.array_equal(poly.evaluation(pt), a[j])
+    rnd = ora.random_fr(log_n, 31)
+    for special in (0, 1, R - 1):
+        pts = rnd.copy()
+        pts[0] = pts[7] = pts[8] = pts[log_n - 1] = F(zk, [special])[0]      # leading, either side of the pass's split, last
+        want = ora.mle_evaluation(a, pts)
+        assert np.array_equal(poly.evaluation(pts), want)
+        chain = poly.partial_evaluations(pts, [0] * log_n)                  # the same folds, table by table
+        assert np.array_equal(chain.to_numpy().reshape(-1, 4)[0], want)
 
 
 def test_partial_evaluations_matches_oracle(zk, ora):

@@ -160,3 +160,113 @@ def test_rccl_communicator_that_does_not_come_up_falls_back_on_every_rank():
     for _, r in res:
         assert r["proof"], res
         assert (r["transport"] == "staged") == (r["fallback_reason"] is not None), res
+
+
+def _worker_nccl_like(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import zk_cryptography_amd as zk
+        from zk_cryptography_amd import _native as N
+        from zk_cryptography_amd import distributed as D
+        torch.cuda.set_device(0)
+
+        class NcclLike:
+            """What distributed.Comm sees of a job on the nccl backend: get_backend() says "nccl" and every tensor collective REFUSES CPU
+            tensors the way ProcessGroupNCCL does.  (Underneath the bytes travel over gloo: two ranks share this box's one GPU.)"""
+            ReduceOp = dist.ReduceOp
+            cuda_collectives = 0
+
+            def get_backend(self, group=None):
+                return "nccl"
+
+            def get_rank(self, group=None):
+                return dist.get_rank(group)
+
+            def get_global_rank(self, group, r):
+                return dist.get_global_rank(group, r)
+
+            def broadcast_object_list(self, box, src=0, group=None):
+                dist.broadcast_object_list(box, src=src, group=group)
+
+            def _need_cuda(self, *ts):
+                if not all(t.is_cuda for t in ts):
+                    raise RuntimeError("No backend type associated with device type cpu")
+                NcclLike.cuda_collectives += 1
+
+            def all_reduce(self, t, op=None, group=None):
+                self._need_cuda(t)
+                c = t.cpu()
+                dist.all_reduce(c, op=op, group=group)
+                t.copy_(c)
+
+            def all_gather_into_tensor(self, out, inp, group=None):
+                self._need_cuda(out, inp)
+                c = out.cpu()
+                dist.all_gather_into_tensor(c, inp.cpu(), group=group)
+                out.copy_(c)
+
+        shim = NcclLike()
+        ctx = N.Context.get(0)
+        full = zk.Fr.random(1 << 16, 778)
+        sc = zk.Sumcheck(zk.Multilinear(full))
+        sc.poly_sum()
+        proof, wch = sc.prove()
+        res = {}
+        # (1) what such a job does by itself: picks the library's RCCL communicator, probes it, agrees, falls back together if needed
+        comm = D.Comm.get(ctx, world, rank, shim, None)
+        res["picked"] = comm.transport
+        res["picked_reason"] = comm.fallback_reason
+        # (2) the staged transport itself on the nccl-like group, whatever (1) ended with
+        staged = comm if comm.transport == "staged" else D.Comm(ctx, world, rank, shim, None, transport="staged")
+        before = NcclLike.cuda_collectives
+        t = torch.from_numpy(np.ascontiguousarray(D.shard_interleaved(full, rank, world)).view(np.int64)).cuda()
+        s, rp, ch = D.ShardedSumcheck(D.HipSumcheckEngine(t), world, None, shim, comm=staged).prove()
+        res["proof"] = bool(np.array_equal(s, proof.sum) and np.array_equal(rp, proof.univariate_poly) and np.array_equal(ch, wch))
+        res["exchanges_on_cuda_tensors"] = NcclLike.cuda_collectives - before
+        # a sharded commit through it as well (one exchange of 128-byte records)
+        tau = zk.Fr.random(10, 17)
+        srs = zk.TrustedSetup.setup(tau)
+        scal = zk.Fr.random(1 << 10, 18)
+        want = zk.MultilinearKZG.commitment(zk.Multilinear(scal), srs)
+        xy, inf = D.sharded_commit(srs.powers_of_tau_in_g1[rank::world].contiguous(), srs.inf[rank::world].contiguous(),
+                                   torch.from_numpy(np.ascontiguousarray(D.shard_interleaved(scal, rank, world)).view(np.int64)).cuda(), staged)
+        res["commit"] = bool((not inf) and np.array_equal(xy, want.xy))
+        # closing a context closes its communicators; a later Comm.get on a new context never hands out a dead one
+        n_before = len(D.Comm._cache)
+        ctx.destroy()
+        res["comms_closed_with_context"] = (not staged.handle) and (not comm.handle) and len(D.Comm._cache) < max(n_before, 1)
+        ctx2 = N.Context.get(0)
+        res["fresh_context"] = ctx2 is not ctx and bool(ctx2.handle)
+        q.put((rank, res))
+        D.Comm.close_all()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_staged_transport_on_a_group_that_only_takes_cuda_tensors():
+    """The transport of last resort must work where it is needed: on an nccl process group (no CPU backend).  A shim that reports the
+    nccl backend and rejects CPU tensors in every collective stands in for it on this one-GPU box: the auto-picked communicator
+    ends the same on both ranks, and the staged transport -- forced if RCCL happened to come up -- proves and commits bit-exactly
+    while every exchange it made went through CUDA tensors."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_nccl_like, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len({r["picked"] for _, r in res}) == 1, res
+    for _, r in res:
+        assert r["picked"] in ("rccl", "staged") and (r["picked"] == "staged") == (r["picked_reason"] is not None), res
+        assert r["proof"] and r["commit"] and r["exchanges_on_cuda_tensors"] >= 3, res
+        assert r["comms_closed_with_context"] and r["fresh_context"], res

@@ -72,9 +72,10 @@ def check(status, what=""):
 class Context:
     """One libzkhip context per (host thread, device), enqueueing on torch's current stream (include/zkhip.h: "one context per
     host thread; contexts are independent" -- the mirror classes reach theirs through Context.get, so two Python threads that prove
-    at once never share one)."""
+    at once never share one).  The per-thread table is thread-LOCAL storage: it goes away with its thread (a thread identifier can
+    be reused by a later thread; a context must not be), and a context nobody refers to any more is destroyed."""
 
-    _instances = {}
+    _tls = threading.local()
 
     def __init__(self, device_index):
         import torch
@@ -83,6 +84,7 @@ class Context:
         self.torch = torch
         self.device = torch.device("cuda", device_index)
         self.handle = C.c_void_p()
+        self._comms = []                 # distributed.Comm objects created on this context: closed before the context goes
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
             check(lib().zkhip_ctx_create(C.byref(self.handle), C.c_int(device_index), C.c_void_p(stream)), "ctx_create")
@@ -93,21 +95,34 @@ class Context:
         import torch
         if device_index is None:
             device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
-        key = (threading.get_ident(), device_index)
-        ctx = cls._instances.get(key)
-        if ctx is None:
-            ctx = cls._instances[key] = Context(device_index)
+        table = cls._tls.__dict__.setdefault("contexts", {})
+        ctx = table.get(device_index)
+        if ctx is None or not ctx.handle:
+            ctx = table[device_index] = Context(device_index)
         ctx.sync_stream()
         return ctx
 
     def destroy(self):
-        """zkhip_ctx_destroy: waits for the context's streams and returns every buffer it holds"""
+        """zkhip_ctx_destroy: closes the communicators created on this context (a zkhip_comm refers to its context), waits for the
+        context's streams and returns every buffer it holds"""
         if self.handle:
+            for m in list(self._comms):
+                m.close()
             h, self.handle = self.handle, None
-            for k, v in list(Context._instances.items()):
+            table = Context._tls.__dict__.get("contexts", {})
+            for k, v in list(table.items()):
                 if v is self:
-                    del Context._instances[k]
+                    del table[k]
             check(lib().zkhip_ctx_destroy(h), "ctx_destroy")
+
+    def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():      # interpreter shutdown: the HIP runtime may already be gone; the process ends anyway
+            return
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
     def sync_stream(self):
         s = self.torch.cuda.current_stream(self.device).cuda_stream

@@ -441,6 +441,45 @@ static __global__ __launch_bounds__(MLE_BLOCK) void eq_weights_kernel(PtsArg pts
     store_fr(out, b, w);
 }
 
+// The two weight tables of an evaluation in one pass (zkhip_mle_evaluation): lanes [0, 2^k1) -> w1 = the fold weights of the first k1
+// points (with the factor 2^32, as above); lanes [2^k1, 2^k1 + 2^k2) -> w2 = the plain eq table of the remaining k2 points (Montgomery
+// form, no factor: it multiplies finished outputs).
+static __global__ __launch_bounds__(MLE_BLOCK) void eval_weights_kernel(PtsArg pts, uint32_t k1, uint32_t k2, uint64_t* __restrict__ w1,
+                                                                        uint64_t* __restrict__ w2) {
+    size_t b = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x;
+    const bool second = b >= ((size_t)1 << k1);
+    if (second) b -= (size_t)1 << k1;
+    const uint32_t k = second ? k2 : k1, first = second ? k1 : 0;
+    if (b >= ((size_t)1 << k)) return;
+    Fr w = Fr::one();
+    if (!second) {
+        constexpr uint32_t c[8] = {0xcaaf6b13u, 0x355094eau, 0x69a568efu, 0xf6b10cb3u, 0x40cc3869u, 0xe2c926a6u, 0xed269aadu, 0x736a6d3bu};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w.l[i] = c[i];
+    }
+    const Fr one = Fr::one();
+    for (uint32_t i = 0; i < k; ++i) {
+        Fr r = fr_from_pts(pts, first + i);
+        if (!((b >> (k - 1 - i)) & 1)) r = one - r;
+        w = w * r;
+    }
+    store_fr(second ? w2 : w1, b, w);
+}
+// out[0] = sum of n records (the tiles' shares of an evaluation)
+static __global__ __launch_bounds__(MLE_BLOCK) void sum_records_kernel(const uint64_t* __restrict__ records, uint32_t n, uint64_t* __restrict__ out) {
+    __shared__ Fr red[MLE_BLOCK / 64];
+    Fr s = Fr::zero();
+    for (uint32_t i = threadIdx.x; i < n; i += 4 * MLE_BLOCK) {
+        Fr v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (i + u * MLE_BLOCK < n) ? load_fr(records, i + u * MLE_BLOCK) : Fr::zero();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s = s + v[u];
+    }
+    s = block_reduce_fr(s, red);
+    if (threadIdx.x == 0) store_fr(out, 0, s);
+}
+
 // ---- the k-variable fold -------------------------------------------------------------------------------
 // out[j] = sum_{b < 2^k} w[b] * in[b*m + j], j < m.
 // A wave covers G consecutive outputs x (64/G) term groups; a workgroup's S = blockDim/64 waves split the 2^k terms

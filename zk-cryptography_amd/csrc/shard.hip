@@ -27,6 +27,7 @@ struct Rccl {
     int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
     bool ok = false;
 };
 constexpr int RCCL_UINT8 = 1;                          // ncclUint8
@@ -46,6 +47,7 @@ Rccl& rccl() {
         q.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(q.lib, "ncclCommInitRank");
         q.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(q.lib, "ncclAllGather");
         q.CommDestroy = (int (*)(void*))dlsym(q.lib, "ncclCommDestroy");
+        q.GetVersion = (int (*)(int*))dlsym(q.lib, "ncclGetVersion");
         q.ok = q.GetUniqueId && q.CommInitRank && q.AllGather && q.CommDestroy;
         return q;
     }();
@@ -108,6 +110,11 @@ extern "C" int zkhip_rccl_unique_id(uint8_t* h_id128) {
     RcclId id;
     if (rccl().GetUniqueId(&id) != 0) return ZKHIP_ERR_HIP;
     std::memcpy(h_id128, id.internal, 128);
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_rccl_version(int* version) {
+    if (!version) return ZKHIP_ERR_ARG;
+    if (!rccl().ok || !rccl().GetVersion || rccl().GetVersion(version) != 0) return ZKHIP_ERR_HIP;
     return ZKHIP_OK;
 }
 extern "C" int zkhip_comm_create_rccl(zkhip_ctx* c, const uint8_t* h_id128, uint32_t rank, uint32_t world, zkhip_comm** out) {

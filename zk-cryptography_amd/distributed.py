@@ -28,7 +28,7 @@ ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_siz
 class Comm:
     """zkhip_comm (include/zkhip.h): one per (context, group); cached, closed explicitly (Comm.close_all) or never."""
 
-    _cache = {}
+    _cache = []
     _pick_rccl_anyway = False     # tests: pick the library's RCCL communicator whatever backend torch.distributed runs (the fallback path)
 
     def __init__(self, ctx, world=1, rank=0, dist=None, group=None, transport=None):
@@ -55,17 +55,24 @@ class Comm:
             picked = auto and world > 1
             err = self._create_rccl(lib, raise_errors=not picked)
             if picked:
-                # The library's own communicator at world > 1: every rank checks it with one small all-gather and the ranks AGREE (over
-                # torch.distributed) before anything depends on it; if any rank failed, all of them fall back to the staged transport.
-                ok = err is None and self._probe()
-                if not self._all_ranks(ok):
+                # The library's own communicator at world > 1.  The ranks AGREE (over torch.distributed) twice before anything depends
+                # on it: first that every rank CREATED its communicator -- a rank that did not must not leave its peers alone in the
+                # probe's all-gather --, then that one small all-gather through it delivered every rank's bytes to every rank.  If
+                # either answer is no on any rank, all of them fall back to the staged transport.
+                created = self._all_ranks(err is None)
+                ok = created and self._all_ranks(self._probe())
+                if not ok:
                     self.close()
                     self.handle = C.c_void_p()
                     self.transport = "staged"
-                    self.fallback_reason = repr(err) if err is not None else "probe all-gather through the library's RCCL communicator failed on some rank"
+                    self.fallback_reason = (repr(err) if err is not None else
+                                            ("the library's RCCL communicator could not be created on another rank" if not created else
+                                             "probe all-gather through the library's RCCL communicator failed on some rank"))
                     self._create_staged(lib)
         else:
             self._create_staged(lib)
+        if self.handle:
+            ctx._comms.append(self)
 
     def _create_staged(self, lib):
         self._cb = ALL_GATHER_FN(self._staged_all_gather)      # kept alive with the comm
@@ -123,14 +130,23 @@ class Comm:
         return bool(int(t.item()) == 1)
 
     def _staged_all_gather(self, user, d_send, d_recv, nbytes, stream):
-        """all-gather through host memory and torch.distributed (payloads are at most a few hundred KiB): waits for the stream"""
+        """all-gather through host memory and torch.distributed (payloads are at most a few hundred KiB): waits for the stream.
+        The collective itself runs on tensors the group's backend accepts: an nccl group has no CPU backend, so there the staged
+        bytes go up into CUDA tensors of torch's own, through torch's all-gather, and come down again (this is the transport of
+        last resort of a job whose library-side RCCL communicator did not come up -- correct first, 3 copies more)."""
         try:
             import torch
             lib = N.lib()
             send = torch.empty(nbytes, dtype=torch.uint8)
-            recv = torch.empty(nbytes * self.world, dtype=torch.uint8)
             N.check(lib.zkhip_memcpy_d2h(self.ctx.handle, C.c_void_p(send.data_ptr()), C.c_void_p(d_send), C.c_size_t(nbytes)), "d2h")
-            self.dist.all_gather_into_tensor(recv, send, group=self.group)
+            if _is_nccl(self.dist, self.group):
+                dev = getattr(self.ctx, "device", None) or torch.device("cuda")
+                recv_d = torch.empty(nbytes * self.world, dtype=torch.uint8, device=dev)
+                self.dist.all_gather_into_tensor(recv_d, send.to(dev), group=self.group)
+                recv = recv_d.cpu()                                  # waits for the collective
+            else:
+                recv = torch.empty(nbytes * self.world, dtype=torch.uint8)
+                self.dist.all_gather_into_tensor(recv, send, group=self.group)
             N.check(lib.zkhip_memcpy_h2d(self.ctx.handle, C.c_void_p(d_recv), C.c_void_p(recv.data_ptr()), C.c_size_t(nbytes * self.world)), "h2d")
             return 0
         except BaseException as e:      # never unwind through the C frames
@@ -141,10 +157,12 @@ class Comm:
     def get(cls, ctx, world=1, rank=None, dist=None, group=None):
         if rank is None:
             rank = dist.get_rank(group) if (world > 1 and dist is not None) else 0
-        key = (id(ctx), world, rank, id(dist) if world > 1 else 0, id(group) if world > 1 else 0)
-        m = cls._cache.get(key)
-        if m is None:
-            m = cls._cache[key] = Comm(ctx, world, rank, dist, group)
+        # the cache holds the objects themselves and compares with `is`: an id() can be reused by a later context or group
+        for m in cls._cache:
+            if m.handle and m.ctx is ctx and m.world == world and m.rank == rank and (world == 1 or (m.dist is dist and m.group is group)):
+                return m
+        m = Comm(ctx, world, rank, dist, group)
+        cls._cache.append(m)
         return m
 
     def stats(self):
@@ -169,12 +187,16 @@ class Comm:
         if self.handle:
             h, self.handle = self.handle, None
             N.lib().zkhip_comm_destroy(h)
+        if self in self.ctx._comms:
+            self.ctx._comms.remove(self)
+        if self in Comm._cache:
+            Comm._cache.remove(self)
 
     @classmethod
     def close_all(cls):
-        for m in list(cls._cache.values()):
+        for m in list(cls._cache):
             m.close()
-        cls._cache.clear()
+        del cls._cache[:]
 
 
 def _is_nccl(dist, group):
