@@ -6,6 +6,7 @@ stream and torch.distributed; it is plumbing only -- all arithmetic happens in l
 import ctypes as C
 import os
 import subprocess
+import sys
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -116,7 +117,6 @@ class Context:
             check(lib().zkhip_ctx_destroy(h), "ctx_destroy")
 
     def __del__(self):
-        import sys
         if sys is None or sys.is_finalizing():      # interpreter shutdown: the HIP runtime may already be gone; the process ends anyway
             return
         try:

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -36,6 +37,22 @@ static void launch_round(zkhip_ctx* c, bool fold, const TablePtrs& tp, size_t n,
                 hipLaunchKernelGGL((composed_round_kernel<K, false, true>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
         }
         return;
+    }
+    if constexpr (K >= 3) {   // three to five tables: the coefficient form (ZKHIP_ROUND_COEFF=0: the evaluation form, for A/B runs)
+        static const bool coeff = [] { const char* e = std::getenv("ZKHIP_ROUND_COEFF"); return !e || std::atoi(e) != 0; }();
+        // waves per SIMD the register allocation aims at: 2 = no spills, 3 = a few spilled words (ZKHIP_ROUND_COEFF_OCC, A/B runs)
+        static const int occ = [] { const char* e = std::getenv("ZKHIP_ROUND_COEFF_OCC"); return e && std::atoi(e) == 2 ? 2 : 3; }();
+        if (coeff) {
+            if (fold && occ == 3)
+                hipLaunchKernelGGL((composed_round_coeff_kernel<K, true, 3>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
+            else if (fold)
+                hipLaunchKernelGGL((composed_round_coeff_kernel<K, true, 2>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
+            else if (occ == 3)
+                hipLaunchKernelGGL((composed_round_coeff_kernel<K, false, 3>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
+            else
+                hipLaunchKernelGGL((composed_round_coeff_kernel<K, false, 2>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
+            return;
+        }
     }
     if (fold)
         hipLaunchKernelGGL((composed_round_kernel<K, true, false>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
@@ -254,6 +271,7 @@ struct ComposedRun {
         bool same_k = n_terms > 1;
         for (uint32_t p = 1; p < n_terms; ++p) same_k = same_k && term_sizes[p] == term_sizes[0];
         for (uint32_t p = 0; p < n_terms; ++p) if (lin_cur[p] && term_sizes[p] > 2) same_k = false;
+        if (term_sizes[0] >= 3) same_k = false;     // three and more tables: one launch per term, in coefficient form (composed_round_coeff_kernel)
         same_k = same_k || split;
         MultiTablePtrs mp = {};
         for (uint32_t p = 0; p < n_terms; ++p) {
@@ -591,7 +609,14 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
         if (run.stage_ok()) { ZK_TRY(run.stage()); continue; }
         if (run.pipe_mid_ok()) {                 // one launch per round, one round ahead, down to the LDS tail
             ZK_TRY(run.pipe_mid());
-            if (run.pipe_records && run.cn <= run.tail_len) { ZK_TRY(run.tail_after_pipe()); break; }
+            // pipe_mid() ends with the tables still unfolded at the last closed round's challenge and that challenge's Montgomery form
+            // not yet in d_ch: only tail_after_pipe() continues from there.  It runs down to the LDS tail by construction (tail_len >=
+            // 256 >= the steady loop's exit); if a change of constants ever broke that, fail here rather than fold by an unwritten value.
+            if (run.pipe_records) {
+                if (run.cn > run.tail_len) return ZKHIP_ERR_ARG;
+                ZK_TRY(run.tail_after_pipe());
+                break;
+            }
             continue;
         }
         int grid = 0;
@@ -622,7 +647,14 @@ int zk_multi_composed_enqueue(zkhip_ctx* c, const uint64_t* const* ptrs, const u
         if (run.stage_ok()) { ZK_TRY(run.stage()); continue; }
         if (run.pipe_mid_ok()) {                 // one launch per round, one round ahead, down to the LDS tail
             ZK_TRY(run.pipe_mid());
-            if (run.pipe_records && run.cn <= run.tail_len) { ZK_TRY(run.tail_after_pipe()); break; }
+            // pipe_mid() ends with the tables still unfolded at the last closed round's challenge and that challenge's Montgomery form
+            // not yet in d_ch: only tail_after_pipe() continues from there.  It runs down to the LDS tail by construction (tail_len >=
+            // 256 >= the steady loop's exit); if a change of constants ever broke that, fail here rather than fold by an unwritten value.
+            if (run.pipe_records) {
+                if (run.cn > run.tail_len) return ZKHIP_ERR_ARG;
+                ZK_TRY(run.tail_after_pipe());
+                break;
+            }
             continue;
         }
         int grid = 0;

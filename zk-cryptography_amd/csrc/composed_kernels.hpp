@@ -390,6 +390,118 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TableP
     }
 }
 
+// x * t for a small constant t (0..5) by additions
+template <int T>
+__device__ __forceinline__ Fr fr_mul_small(const Fr& x) {
+    if constexpr (T == 0) return Fr::zero();
+    else if constexpr (T == 1) return x;
+    else if constexpr (T == 2) return x + x;
+    else if constexpr (T == 3) { const Fr d = x + x; return d + x; }
+    else if constexpr (T == 4) { const Fr d = x + x; return d + d; }
+    else { const Fr d = x + x; const Fr q = d + d; return q + x; }
+}
+// p(T) = sum_i c[i] T^i (Horner), T = 0..5
+template <int K, int T>
+__device__ __forceinline__ Fr eval_small(const Fr (&c)[K + 1]) {
+    Fr e = c[K];
+#pragma unroll
+    for (int i = K - 1; i >= 0; --i) e = fr_mul_small<T>(e) + c[i];
+    return e;
+}
+
+// One round of one product term of K >= 3 tables (no additive table), in COEFFICIENT form.
+// composed_round_kernel keeps, per lane, every table's value and difference alive while it walks t = 0..K (2 K field elements)
+// beside the K + 1 sums: at K = 4, 5 that is every register a lane can have (256, one wave per SIMD: nothing hides a load).  Here
+// the tables are taken ONE AT A TIME: prod_k (lo_k + X d_k) grows as a polynomial in X, c(X) <- c(X) (lo + X d), and the last
+// table's step adds straight into the K + 1 sums of COEFFICIENTS.  2 (k + 1) products for table k >= 1 -- K (K + 1) - 2 per index
+// against (K + 1)(K - 1) -- but K + (K + 1) + 2 live elements instead of 3 K + 1, three waves per SIMD at K = 5.  The record this
+// kernel writes is the same as composed_round_kernel's: the round's EVALUATIONS at t = 0..K, p(t) = sum_i S_i t^i from the
+// workgroup's coefficient sums (exact field arithmetic: the same canonical values).
+// table KK of the term (every index a compile-time constant: the coefficients stay in registers), then the next one
+template <int K, bool FOLD, int KK>
+__device__ __forceinline__ void coeff_table(const TablePtrs& tp, size_t j, size_t h, size_t q, const Fr& r, Fr (&c)[K], Fr (&sums)[K + 1]) {
+    Fr lo, hi;
+    if constexpr (FOLD) {
+        const Fr a0 = load_fr(tp.in[KK], j), b0 = load_fr(tp.in[KK], j + h);
+        lo = fold_pair(a0, b0, r);
+        store_fr(tp.out[KK], j, lo);
+        const Fr a1 = load_fr(tp.in[KK], j + q), b1 = load_fr(tp.in[KK], j + h + q);
+        hi = fold_pair(a1, b1, r);
+        store_fr(tp.out[KK], j + q, hi);
+    } else {
+        lo = load_fr(tp.in[KK], j);
+        hi = load_fr(tp.in[KK], j + h);
+    }
+    const Fr d = hi - lo;
+    if constexpr (KK == 0) {
+        c[0] = lo;
+        c[1] = d;
+    } else if constexpr (KK < K - 1) {
+        c[KK + 1] = c[KK] * d;
+#pragma unroll
+        for (int i = KK; i >= 1; --i) c[i] = c[i] * lo + c[i - 1] * d;
+        c[0] = c[0] * lo;
+    } else {
+        sums[K] = sums[K] + c[K - 1] * d;
+#pragma unroll
+        for (int i = K - 1; i >= 1; --i) sums[i] = sums[i] + (c[i] * lo + c[i - 1] * d);
+        sums[0] = sums[0] + c[0] * lo;
+    }
+    if constexpr (KK + 1 < K) coeff_table<K, FOLD, KK + 1>(tp, j, h, q, r, c, sums);
+}
+template <int K, bool FOLD, int OCC>
+static __global__ __launch_bounds__(MLE_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) void composed_round_coeff_kernel(TablePtrs tp, size_t n, const uint64_t* __restrict__ r_ptr,
+                                                                         uint32_t rec, uint32_t rec_off, uint64_t* __restrict__ partials) {
+    static_assert(K >= 3 && K <= CMP_MAX_K, "coefficient form: three to five tables");
+    __shared__ Fr red[(K + 1) * (MLE_BLOCK / 64)];
+    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
+    Fr sums[K + 1];
+#pragma unroll
+    for (int t = 0; t <= K; ++t) sums[t] = Fr::zero();
+    const size_t h = n >> 1, q = n >> 2;
+    Fr r = Fr::zero();
+    if (FOLD) {
+        r = load_fr(r_ptr, 0);
+        if (q == 0 && blockIdx.x == 0 && threadIdx.x == 0) {          // n == 2: the fold leaves one entry per table, no pair to sum over
+#pragma unroll
+            for (int k = 0; k < K; ++k) store_fr(tp.out[k], 0, fold_pair(load_fr(tp.in[k], 0), load_fr(tp.in[k], 1), r));
+        }
+    }
+    const size_t cnt = FOLD ? q : h;
+    for (size_t j = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; j < cnt; j += stride) {
+        Fr c[K];                                                        // coefficients of the product of the tables taken so far
+        coeff_table<K, FOLD, 0>(tp, j, h, q, r, c, sums);
+    }
+    // the workgroup's coefficient sums, then lane t of the first wave turns them into the evaluation at t
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = MLE_BLOCK / 64;
+#pragma unroll
+    for (int i = 0; i <= K; ++i) {
+        const Fr w = wave_reduce_fr(sums[i]);
+        if (lane == 0) red[i * NW + wave] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x <= K) {
+        Fr s[K + 1];
+#pragma unroll
+        for (int i = 0; i <= K; ++i) {
+            s[i] = red[i * NW];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) s[i] = s[i] + red[i * NW + w];
+        }
+        Fr e;
+        switch (threadIdx.x) {
+            case 0: e = eval_small<K, 0>(s); break;
+            case 1: e = eval_small<K, 1>(s); break;
+            case 2: e = eval_small<K, 2>(s); break;
+            case 3: e = eval_small<K, 3>(s); break;
+            case 4: e = eval_small<K, 4>(s); break;
+            default: e = eval_small<K, 5>(s); break;
+        }
+        store_fr(partials, (size_t)blockIdx.x * rec + rec_off + threadIdx.x, e);
+    }
+}
+
 // The K = 2 round of ONE term without additive table on LARGE tables (>= CMP_WIDE_MIN_WORK pairs): the round polynomial
 // p(t) = sum_j (lo0 + t d0)(lo1 + t d1) is fixed by E0 = sum lo0 lo1, E1 = sum hi0 hi1 and D = sum d0 d1 (p(2) = 2 E1 - E0 + 2 D),
 // and the three sums of products are accumulated UNREDUCED (wide_acc.hpp): a pair costs 3 x (64 mads + carries) instead of 3

@@ -109,10 +109,16 @@ inline MsmLevelWidths msm_level_table_widths(size_t nj, size_t batch_total) {
     // 2^17 2.18 / 1.98 / 1.70 / 1.64 [1.91], 2^18 2.38 / 2.06 / 1.88 / 2.16 [2.23], 2^19 2.99 / 2.56 / 2.84 / - [3.25], 2^20 4.14 / - [4.97]:
     // a small opening is as long as its longest bucket lists (wider windows: more buckets, shorter lists), a large one is throughput bound
     int delta = batch_total < ((size_t)1 << 17) ? -3 : batch_total < ((size_t)1 << 18) ? -2 : batch_total < ((size_t)1 << 19) ? -1 : 0;
-    if (const char* e = std::getenv("ZKHIP_LEVEL_TABLE_DELTA")) {   // tuning aid: widest window log2(n_j) - delta (read when the table is BUILT and when it is used)
+    // tuning aid: widest window log2(n_j) - delta.  Read ONCE per process: the layout of a table (W, hi, n_hi) is a function of the sizes
+    // and of this value, and the table carries no header -- a value that changed between the build of a table and its use would
+    // silently address it wrongly.  (Tables are not portable between processes that run with different values.)
+    static const int env_delta = [] {
+        const char* e = std::getenv("ZKHIP_LEVEL_TABLE_DELTA");
+        if (!e) return 99;
         const int v = std::atoi(e);
-        if (v >= -3 && v <= 4) delta = v;
-    }
+        return v >= -3 && v <= 4 ? v : 99;
+    }();
+    if (env_delta != 99) delta = env_delta;
     const uint32_t c = (uint32_t)std::min(20, std::max(8, lg - delta));
     MsmLevelWidths lw;
     lw.W = (256 + c - 1) / c;
