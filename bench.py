@@ -263,7 +263,7 @@ def bench_fold(args, zk, N, poly, torch):
 def bench_evaluate(args, zk, N, poly, torch):
     """MultilinearTrait::evaluation (evaluation_form.rs:162-175) of the 2^log_n table at log_n known points: SURVEY 8d's 96 n row
     (the reference: n folds of a cloned table).  Here ONE pass over the table -- the k-variable fold whose tiles keep the sum of their
-    outputs weighted by the eq table of the remaining points -- so the bytes really moved are 32 (n + n / 2^k), reported beside the
+    outputs weighted by the eq table of the remaining points -- so the bytes really moved are 32 n, reported beside the
     algorithmic 96 n."""
     n = len(poly)
     pts = zk.Fr.synthetic(args.log_n, SEED_TABLE + 0x778)
@@ -285,7 +285,7 @@ def bench_evaluate(args, zk, N, poly, torch):
             "roofline": {"bound": "hbm", "kernel": "multifold_mfma_kernel<4, 4, true> (the pass; weights and the records' sum are two small launches beside it)",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "launches": cnt,
                          "avg_launch_us": round(1e3 * ms / max(1, cnt), 2),
-                         "algorithmic_bytes_per_launch": "32 B x (table entries + eq-table entries of the remaining points) read"}}
+                         "algorithmic_bytes_per_launch": "32 B x table entries read"}}
 
 
 def bench_ntt(args, zk, N, torch):

@@ -268,5 +268,5 @@ def test_staged_transport_on_a_group_that_only_takes_cuda_tensors():
     assert len({r["picked"] for _, r in res}) == 1, res
     for _, r in res:
         assert r["picked"] in ("rccl", "staged") and (r["picked"] == "staged") == (r["picked_reason"] is not None), res
-        assert r["proof"] and r["commit"] and r["exchanges_on_cuda_tensors"] >= 3, res
+        assert r["proof"] and r["commit"] and r["exchanges_on_cuda_tensors"] >= 2, res
         assert r["comms_closed_with_context"] and r["fresh_context"], res

@@ -1,6 +1,6 @@
 """Diagnostic only: where a round of the composed / multi-composed prover spends its time (libzkhip_diag.so, -DZK_STAMPS; s_memtime
 ticks of the 2.4 GHz core clock printed in microseconds).  Per round: [sums or record reduction] | items (interpolation, canonical
-forms) | message | schedules | hash | challenge + publish | fold.   usage: python tools/diag_composed.py [log_n] [multi]"""
+forms) | message | schedules | hash | challenge + publish | fold.   usage: python tools/diag_composed.py [log_n] [multi | k3 | k4 | k5]"""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,10 +8,14 @@ from zk_cryptography_amd import _native as N
 N.LIB_PATH = os.path.join(N.CSRC, "libzkhip_diag.so")
 import zk_cryptography_amd as zk
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 22
-multi = len(sys.argv) > 2
+multi = len(sys.argv) > 2 and sys.argv[2] == "multi"
+kk = int(sys.argv[2][1:]) if len(sys.argv) > 2 and sys.argv[2][0] == "k" else 2
 n = 1 << log_n
-tabs = [zk.Multilinear(torch.randint(0, 2 ** 62, (n, 4), dtype=torch.int64, device="cuda")) for _ in range(4)]
-if multi:
+tabs = [zk.Multilinear(torch.randint(0, 2 ** 62, (n, 4), dtype=torch.int64, device="cuda")) for _ in range(max(4, kk))]
+if kk > 2:
+    cs = zk.ComposedSumcheck(zk.ComposedMultilinear(tabs[:kk]))
+    run = lambda: cs.prove()
+elif multi:
     poly = [zk.ComposedMultilinear(tabs[:2]), zk.ComposedMultilinear(tabs[2:])]
     claimed = zk.MultiComposedSumcheckProver.calculate_poly_sum(poly)
     run = lambda: zk.MultiComposedSumcheckProver.prove_partial(poly, claimed)

@@ -38,22 +38,6 @@ static void launch_round(zkhip_ctx* c, bool fold, const TablePtrs& tp, size_t n,
         }
         return;
     }
-    if constexpr (K >= 3) {   // three to five tables: the coefficient form (ZKHIP_ROUND_COEFF=0: the evaluation form, for A/B runs)
-        static const bool coeff = [] { const char* e = std::getenv("ZKHIP_ROUND_COEFF"); return !e || std::atoi(e) != 0; }();
-        // waves per SIMD the register allocation aims at: 2 = no spills, 3 = a few spilled words (ZKHIP_ROUND_COEFF_OCC, A/B runs)
-        static const int occ = [] { const char* e = std::getenv("ZKHIP_ROUND_COEFF_OCC"); return e && std::atoi(e) == 2 ? 2 : 3; }();
-        if (coeff) {
-            if (fold && occ == 3)
-                hipLaunchKernelGGL((composed_round_coeff_kernel<K, true, 3>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
-            else if (fold)
-                hipLaunchKernelGGL((composed_round_coeff_kernel<K, true, 2>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
-            else if (occ == 3)
-                hipLaunchKernelGGL((composed_round_coeff_kernel<K, false, 3>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
-            else
-                hipLaunchKernelGGL((composed_round_coeff_kernel<K, false, 2>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
-            return;
-        }
-    }
     if (fold)
         hipLaunchKernelGGL((composed_round_kernel<K, true, false>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
     else
@@ -263,7 +247,17 @@ struct ComposedRun {
         // two terms per claim, measured no better with fewer).  ZKHIP_ROUND_GRID overrides (diagnostics).
         static const int grid_env = [] { const char* e = std::getenv("ZKHIP_ROUND_GRID"); return e ? std::atoi(e) : 0; }();
         const int grid_cap = grid_env > 0 ? grid_env : n_terms == 1 ? 512 : (int)MLE_MAX_GRID;
-        const int grid = split ? (int)((4 * work + MLE_BLOCK - 1) / MLE_BLOCK)
+        // small folding rounds with a term of three and more tables: K + 1 lanes per output pair (composed_round_tsplit_kernel), ONE pass
+        // per workgroup -- the grid is sized for the widest such term and every term of the round uses it (the records of a round
+        // are per workgroup).  ZKHIP_ROUND_TSPLIT=0: off (A/B runs).
+        static const bool tsplit_on = [] { const char* e = std::getenv("ZKHIP_ROUND_TSPLIT"); return !e || std::atoi(e) != 0; }();
+        uint32_t k_wide = 0;
+        bool any_lin = false;
+        for (uint32_t p = 0; p < n_terms; ++p) { k_wide = std::max(k_wide, term_sizes[p]); any_lin = any_lin || lin_cur[p] != nullptr; }
+        const bool tsplit = tsplit_on && fold && k_wide >= 3 && !any_lin && work >= 1 && work <= CMP_TSPLIT_MAX;
+        const size_t tsplit_per_wg = (size_t)(MLE_BLOCK / 64) * (64 / (k_wide + 1));
+        const int grid = tsplit ? (int)std::min<size_t>(MLE_MAX_GRID, (work + tsplit_per_wg - 1) / tsplit_per_wg)
+                         : split ? (int)((4 * work + MLE_BLOCK - 1) / MLE_BLOCK)
                          : wide ? (int)std::min<size_t>(MLE_MAX_GRID, std::max<size_t>(256, work / (MLE_BLOCK * per_lane)))
                          : std::min(grid_cap, mle_grid(work ? work : 1));
         uint32_t off = 0;
@@ -271,9 +265,10 @@ struct ComposedRun {
         bool same_k = n_terms > 1;
         for (uint32_t p = 1; p < n_terms; ++p) same_k = same_k && term_sizes[p] == term_sizes[0];
         for (uint32_t p = 0; p < n_terms; ++p) if (lin_cur[p] && term_sizes[p] > 2) same_k = false;
-        if (term_sizes[0] >= 3) same_k = false;     // three and more tables: one launch per term, in coefficient form (composed_round_coeff_kernel)
+        if (tsplit) same_k = false;     // K + 1 lanes per pair, every term in one launch (composed_round_tsplit_kernel) below
         same_k = same_k || split;
         MultiTablePtrs mp = {};
+        TsplitTerms ts = {};
         for (uint32_t p = 0; p < n_terms; ++p) {
             TablePtrs tp = {};
             // ping-pong: a fold writes into the buffer the current tables do not lie in (out_buf)
@@ -285,7 +280,11 @@ struct ComposedRun {
                 tp.lin_in = lin_cur[p];
                 tp.lin_out = out_buf(meta.lin_tab[p]);
             }
-            if (same_k) {
+            if (tsplit) {
+                ts.t[p] = tp;
+                ts.rec_off[p] = meta.rec_off[p];
+                ts.k[p] = term_sizes[p];
+            } else if (same_k) {
                 mp.t[p] = tp;
                 mp.rec_off[p] = meta.rec_off[p];
             } else {
@@ -302,6 +301,10 @@ struct ComposedRun {
             if (fold) for (uint32_t q = 0; q < term_sizes[p]; ++q) cur[off + q] = tp.out[q];
             if (fold && lin_cur[p]) lin_cur[p] = tp.lin_out;
             off += term_sizes[p];
+        }
+        if (tsplit) {
+            ProfScope ps(c, "composed_round", 0.0);
+            hipLaunchKernelGGL(composed_round_tsplit_kernel, dim3(grid, n_terms), dim3(MLE_BLOCK), 0, c->stream, ts, cn, prev_challenge(), meta.rec, d_partials);
         }
         if (same_k) {
             ProfScope ps(c, "composed_round", 0.0);

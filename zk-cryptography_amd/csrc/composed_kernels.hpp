@@ -33,6 +33,19 @@ struct TablePtrs {
     const uint64_t* lin_in;
     uint64_t* lin_out;
 };
+__device__ __forceinline__ Fr lds_load_fr(const uint32_t* base, uint32_t idx) {
+    const uint4* p = reinterpret_cast<const uint4*>(base + 8 * idx);
+    uint4 a = p[0], b = p[1];
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void lds_store_fr(uint32_t* base, uint32_t idx, const Fr& v) {
+    uint4* p = reinterpret_cast<uint4*>(base + 8 * idx);
+    p[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    p[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
 // evaluations at t = 0..K of lo + t (hi - lo), added into sums[0..K]
 template <int K>
 __device__ __forceinline__ void accumulate_linear_evals(const Fr& lo, const Fr& hi, Fr (&sums)[K + 1]) {
@@ -46,20 +59,64 @@ __device__ __forceinline__ void accumulate_linear_evals(const Fr& lo, const Fr& 
 }
 
 // evaluations at t = 0..K of prod_k (lo_k + t*(hi_k - lo_k)), added into sums[0..K]
+// K <= 2: a table's value at integer t by repeated addition of d = hi - lo, K - 1 products per t.
+// K >= 3: the tables are taken in PAIRS.  A(t) = (lo_0 + t d_0)(lo_1 + t d_1) is a quadratic: A(0) = lo_0 lo_1, A(1) = hi_0 hi_1 and
+// its leading coefficient d_0 d_1 -- three products -- give every A(t) by second differences (A(t+1) - A(t) grows by 2 d_0 d_1 per
+// step: two additions per point).  K = 3: 3 + 4 products per index instead of 8; K = 4: 3 + 3 + 5 = 11 instead of 15; K = 5:
+// 3 + 3 + 6 + 6 = 18 instead of 24.  These rounds are bound by the issue of multiply-adds (one product ~ 330 VALU instructions),
+// not by memory: fewer products is the only lever.  Exact field arithmetic: the same canonical sums.
+struct QuadEvals {          // a quadratic's values at t = 0, 1, 2, ...: cur = A(t), diff = A(t + 1) - A(t), dd = the second difference
+    Fr cur, diff, dd;
+    __device__ __forceinline__ QuadEvals(const Fr& lo0, const Fr& hi0, const Fr& lo1, const Fr& hi1) {
+        const Fr a0 = lo0 * lo1, a1 = hi0 * hi1, lead = (hi0 - lo0) * (hi1 - lo1);
+        cur = a0;
+        diff = a1 - a0;
+        dd = lead + lead;
+    }
+    __device__ __forceinline__ void step() { cur = cur + diff; diff = diff + dd; }
+};
 template <int K>
 __device__ __forceinline__ void accumulate_round_evals(const Fr (&lo)[K], const Fr (&hi)[K], Fr (&sums)[K + 1]) {
-    Fr v[K], d[K];
+    if constexpr (K <= 2) {
+        Fr v[K], d[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) { v[k] = lo[k]; d[k] = hi[k] - lo[k]; }
+        for (int k = 0; k < K; ++k) { v[k] = lo[k]; d[k] = hi[k] - lo[k]; }
 #pragma unroll
-    for (int t = 0; t <= K; ++t) {
-        Fr prod = v[0];
+        for (int t = 0; t <= K; ++t) {
+            Fr prod = v[0];
 #pragma unroll
-        for (int k = 1; k < K; ++k) prod = prod * v[k];
-        sums[t] = sums[t] + prod;
-        if (t < K) {
+            for (int k = 1; k < K; ++k) prod = prod * v[k];
+            sums[t] = sums[t] + prod;
+            if (t < K) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) v[k] = v[k] + d[k];
+                for (int k = 0; k < K; ++k) v[k] = v[k] + d[k];
+            }
+        }
+    } else if constexpr (K == 3) {
+        QuadEvals a(lo[0], hi[0], lo[1], hi[1]);
+        Fr v = lo[2];
+        const Fr d = hi[2] - lo[2];
+#pragma unroll
+        for (int t = 0; t <= K; ++t) {
+            sums[t] = sums[t] + a.cur * v;
+            if (t < K) { a.step(); v = v + d; }
+        }
+    } else if constexpr (K == 4) {
+        QuadEvals a(lo[0], hi[0], lo[1], hi[1]), b(lo[2], hi[2], lo[3], hi[3]);
+#pragma unroll
+        for (int t = 0; t <= K; ++t) {
+            sums[t] = sums[t] + a.cur * b.cur;
+            if (t < K) { a.step(); b.step(); }
+        }
+    } else {
+        static_assert(K == 5, "product terms have at most five tables");
+        QuadEvals a(lo[0], hi[0], lo[1], hi[1]), b(lo[2], hi[2], lo[3], hi[3]);
+        Fr v = lo[4];
+        const Fr d = hi[4] - lo[4];
+#pragma unroll
+        for (int t = 0; t <= K; ++t) {
+            sums[t] = sums[t] + (a.cur * b.cur) * v;
+            if (t < K) { a.step(); b.step(); v = v + d; }
         }
     }
 }
@@ -334,8 +391,63 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
 // Per workgroup, the K+1 sums go to partials[(block * rec + rec_off + t)]; composed_close_kernel sums the records
 // and closes the round.  (Closing inside this kernel by the last workgroup to finish was measured and dropped: on
 // eight XCDs with private L2s the agent-scope release every workgroup then needs costs more than a launch.)
+// (lo, hi) of table k at output pair j: the entries themselves (first round) or the fold at r of the four entries behind them,
+// written back on the way
+template <bool FOLD>
+__device__ __forceinline__ void round_pair(const TablePtrs& tp, int k, size_t j, size_t h, size_t q, const Fr& r, Fr& lo, Fr& hi) {
+    if constexpr (FOLD) {
+        const Fr a0 = load_fr(tp.in[k], j), b0 = load_fr(tp.in[k], j + h), a1 = load_fr(tp.in[k], j + q), b1 = load_fr(tp.in[k], j + h + q);
+        lo = fold_pair(a0, b0, r);
+        hi = fold_pair(a1, b1, r);
+        store_fr(tp.out[k], j, lo);
+        store_fr(tp.out[k], j + q, hi);
+    } else {
+        lo = load_fr(tp.in[k], j);
+        hi = load_fr(tp.in[k], j + h);
+    }
+}
+// accumulate_round_evals for K >= 3 with the tables taken from memory two at a time: a pair of tables is consumed into its quadratic
+// before the next pair is loaded (all K tables in registers at once is what held these kernels at one wave per SIMD)
+template <int K, bool FOLD>
+__device__ __forceinline__ void accumulate_round_evals_streamed(const TablePtrs& tp, size_t j, size_t h, size_t q, const Fr& r, Fr (&sums)[K + 1]) {
+    static_assert(K >= 3 && K <= 5, "pairs of tables");
+    Fr l0, h0, l1, h1;
+    round_pair<FOLD>(tp, 0, j, h, q, r, l0, h0);
+    round_pair<FOLD>(tp, 1, j, h, q, r, l1, h1);
+    QuadEvals a(l0, h0, l1, h1);
+    if constexpr (K == 3) {
+        round_pair<FOLD>(tp, 2, j, h, q, r, l0, h0);
+        Fr v = l0;
+        const Fr d = h0 - l0;
+#pragma unroll
+        for (int t = 0; t <= K; ++t) {
+            sums[t] = sums[t] + a.cur * v;
+            if (t < K) { a.step(); v = v + d; }
+        }
+    } else {
+        round_pair<FOLD>(tp, 2, j, h, q, r, l0, h0);
+        round_pair<FOLD>(tp, 3, j, h, q, r, l1, h1);
+        QuadEvals b(l0, h0, l1, h1);
+        if constexpr (K == 4) {
+#pragma unroll
+            for (int t = 0; t <= K; ++t) {
+                sums[t] = sums[t] + a.cur * b.cur;
+                if (t < K) { a.step(); b.step(); }
+            }
+        } else {
+            round_pair<FOLD>(tp, 4, j, h, q, r, l0, h0);
+            Fr v = l0;
+            const Fr d = h0 - l0;
+#pragma unroll
+            for (int t = 0; t <= K; ++t) {
+                sums[t] = sums[t] + (a.cur * b.cur) * v;
+                if (t < K) { a.step(); b.step(); v = v + d; }
+            }
+        }
+    }
+}
 template <int K, bool FOLD, bool LIN>
-static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TablePtrs tp, size_t n, const uint64_t* __restrict__ r_ptr,
+static __global__ __launch_bounds__(MLE_BLOCK) __attribute__((amdgpu_waves_per_eu(K >= 4 ? 2 : 1))) void composed_round_kernel(TablePtrs tp, size_t n, const uint64_t* __restrict__ r_ptr,
                                                                    uint32_t rec, uint32_t rec_off,
                                                                    uint64_t* __restrict__ partials) {
     __shared__ Fr red[MLE_BLOCK / 64];
@@ -354,33 +466,41 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TableP
             }
         }
         for (size_t j = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; j < q; j += stride) {
-            Fr lo[K], hi[K];
+            if constexpr (K >= 3 && !LIN) {
+                accumulate_round_evals_streamed<K, true>(tp, j, h, q, r, sums);
+            } else {
+                Fr lo[K], hi[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                Fr a0 = load_fr(tp.in[k], j), a1 = load_fr(tp.in[k], j + q);
-                Fr b0 = load_fr(tp.in[k], j + h), b1 = load_fr(tp.in[k], j + h + q);
-                lo[k] = fold_pair(a0, b0, r);
-                hi[k] = fold_pair(a1, b1, r);
-                store_fr(tp.out[k], j, lo[k]);
-                store_fr(tp.out[k], j + q, hi[k]);
-            }
-            accumulate_round_evals<K>(lo, hi, sums);
-            if (LIN) {
-                const Fr llo = fold_pair(load_fr(tp.lin_in, j), load_fr(tp.lin_in, j + h), r);
-                const Fr lhi = fold_pair(load_fr(tp.lin_in, j + q), load_fr(tp.lin_in, j + h + q), r);
-                store_fr(tp.lin_out, j, llo);
-                store_fr(tp.lin_out, j + q, lhi);
-                accumulate_linear_evals<K>(llo, lhi, sums);
+                for (int k = 0; k < K; ++k) {
+                    Fr a0 = load_fr(tp.in[k], j), a1 = load_fr(tp.in[k], j + q);
+                    Fr b0 = load_fr(tp.in[k], j + h), b1 = load_fr(tp.in[k], j + h + q);
+                    lo[k] = fold_pair(a0, b0, r);
+                    hi[k] = fold_pair(a1, b1, r);
+                    store_fr(tp.out[k], j, lo[k]);
+                    store_fr(tp.out[k], j + q, hi[k]);
+                }
+                accumulate_round_evals<K>(lo, hi, sums);
+                if (LIN) {
+                    const Fr llo = fold_pair(load_fr(tp.lin_in, j), load_fr(tp.lin_in, j + h), r);
+                    const Fr lhi = fold_pair(load_fr(tp.lin_in, j + q), load_fr(tp.lin_in, j + h + q), r);
+                    store_fr(tp.lin_out, j, llo);
+                    store_fr(tp.lin_out, j + q, lhi);
+                    accumulate_linear_evals<K>(llo, lhi, sums);
+                }
             }
         }
     } else {
         const size_t h = n >> 1;
         for (size_t j = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; j < h; j += stride) {
-            Fr lo[K], hi[K];
+            if constexpr (K >= 3 && !LIN) {
+                accumulate_round_evals_streamed<K, false>(tp, j, h, 0, Fr::zero(), sums);
+            } else {
+                Fr lo[K], hi[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) { lo[k] = load_fr(tp.in[k], j); hi[k] = load_fr(tp.in[k], j + h); }
-            accumulate_round_evals<K>(lo, hi, sums);
-            if (LIN) accumulate_linear_evals<K>(load_fr(tp.lin_in, j), load_fr(tp.lin_in, j + h), sums);
+                for (int k = 0; k < K; ++k) { lo[k] = load_fr(tp.in[k], j); hi[k] = load_fr(tp.in[k], j + h); }
+                accumulate_round_evals<K>(lo, hi, sums);
+                if (LIN) accumulate_linear_evals<K>(load_fr(tp.lin_in, j), load_fr(tp.lin_in, j + h), sums);
+            }
         }
     }
 #pragma unroll
@@ -390,115 +510,79 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_kernel(TableP
     }
 }
 
-// x * t for a small constant t (0..5) by additions
-template <int T>
-__device__ __forceinline__ Fr fr_mul_small(const Fr& x) {
-    if constexpr (T == 0) return Fr::zero();
-    else if constexpr (T == 1) return x;
-    else if constexpr (T == 2) return x + x;
-    else if constexpr (T == 3) { const Fr d = x + x; return d + x; }
-    else if constexpr (T == 4) { const Fr d = x + x; return d + d; }
-    else { const Fr d = x + x; const Fr q = d + d; return q + x; }
-}
-// p(T) = sum_i c[i] T^i (Horner), T = 0..5
-template <int K, int T>
-__device__ __forceinline__ Fr eval_small(const Fr (&c)[K + 1]) {
-    Fr e = c[K];
-#pragma unroll
-    for (int i = K - 1; i >= 0; --i) e = fr_mul_small<T>(e) + c[i];
-    return e;
-}
-
-// One round of one product term of K >= 3 tables (no additive table), in COEFFICIENT form.
-// composed_round_kernel keeps, per lane, every table's value and difference alive while it walks t = 0..K (2 K field elements)
-// beside the K + 1 sums: at K = 4, 5 that is every register a lane can have (256, one wave per SIMD: nothing hides a load).  Here
-// the tables are taken ONE AT A TIME: prod_k (lo_k + X d_k) grows as a polynomial in X, c(X) <- c(X) (lo + X d), and the last
-// table's step adds straight into the K + 1 sums of COEFFICIENTS.  2 (k + 1) products for table k >= 1 -- K (K + 1) - 2 per index
-// against (K + 1)(K - 1) -- but K + (K + 1) + 2 live elements instead of 3 K + 1, three waves per SIMD at K = 5.  The record this
-// kernel writes is the same as composed_round_kernel's: the round's EVALUATIONS at t = 0..K, p(t) = sum_i S_i t^i from the
-// workgroup's coefficient sums (exact field arithmetic: the same canonical values).
-// table KK of the term (every index a compile-time constant: the coefficients stay in registers), then the next one
-template <int K, bool FOLD, int KK>
-__device__ __forceinline__ void coeff_table(const TablePtrs& tp, size_t j, size_t h, size_t q, const Fr& r, Fr (&c)[K], Fr (&sums)[K + 1]) {
-    Fr lo, hi;
-    if constexpr (FOLD) {
-        const Fr a0 = load_fr(tp.in[KK], j), b0 = load_fr(tp.in[KK], j + h);
-        lo = fold_pair(a0, b0, r);
-        store_fr(tp.out[KK], j, lo);
-        const Fr a1 = load_fr(tp.in[KK], j + q), b1 = load_fr(tp.in[KK], j + h + q);
-        hi = fold_pair(a1, b1, r);
-        store_fr(tp.out[KK], j + q, hi);
-    } else {
-        lo = load_fr(tp.in[KK], j);
-        hi = load_fr(tp.in[KK], j + h);
-    }
-    const Fr d = hi - lo;
-    if constexpr (KK == 0) {
-        c[0] = lo;
-        c[1] = d;
-    } else if constexpr (KK < K - 1) {
-        c[KK + 1] = c[KK] * d;
-#pragma unroll
-        for (int i = KK; i >= 1; --i) c[i] = c[i] * lo + c[i - 1] * d;
-        c[0] = c[0] * lo;
-    } else {
-        sums[K] = sums[K] + c[K - 1] * d;
-#pragma unroll
-        for (int i = K - 1; i >= 1; --i) sums[i] = sums[i] + (c[i] * lo + c[i - 1] * d);
-        sums[0] = sums[0] + c[0] * lo;
-    }
-    if constexpr (KK + 1 < K) coeff_table<K, FOLD, KK + 1>(tp, j, h, q, r, c, sums);
-}
-template <int K, bool FOLD, int OCC>
-static __global__ __launch_bounds__(MLE_BLOCK) __attribute__((amdgpu_waves_per_eu(OCC))) void composed_round_coeff_kernel(TablePtrs tp, size_t n, const uint64_t* __restrict__ r_ptr,
-                                                                         uint32_t rec, uint32_t rec_off, uint64_t* __restrict__ partials) {
-    static_assert(K >= 3 && K <= CMP_MAX_K, "coefficient form: three to five tables");
-    __shared__ Fr red[(K + 1) * (MLE_BLOCK / 64)];
-    const size_t stride = (size_t)gridDim.x * MLE_BLOCK;
-    Fr sums[K + 1];
-#pragma unroll
-    for (int t = 0; t <= K; ++t) sums[t] = Fr::zero();
-    const size_t h = n >> 1, q = n >> 2;
-    Fr r = Fr::zero();
-    if (FOLD) {
-        r = load_fr(r_ptr, 0);
-        if (q == 0 && blockIdx.x == 0 && threadIdx.x == 0) {          // n == 2: the fold leaves one entry per table, no pair to sum over
-#pragma unroll
-            for (int k = 0; k < K; ++k) store_fr(tp.out[k], 0, fold_pair(load_fr(tp.in[k], 0), load_fr(tp.in[k], 1), r));
-        }
-    }
-    const size_t cnt = FOLD ? q : h;
-    for (size_t j = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x; j < cnt; j += stride) {
-        Fr c[K];                                                        // coefficients of the product of the tables taken so far
-        coeff_table<K, FOLD, 0>(tp, j, h, q, r, c, sums);
-    }
-    // the workgroup's coefficient sums, then lane t of the first wave turns them into the evaluation at t
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// The folding round for SMALL tables of claims with a term of K >= 3 tables (<= CMP_TSPLIT_MAX output pairs): K + 1 LANES per output
+// pair, every term of the claim in ONE launch (blockIdx.y = term; K is a run-time value per term).
+// With one lane per pair such a round is 2 K + (K + 1)(K - 1) Montgomery products one after another on every lane -- 34 at K = 5,
+// ~26 us on a lone wave, whatever the size of the tables -- and a chip with 1024 SIMDs has nothing else to do.  Here lane t of a
+// group first folds table t (lanes 0..K-1: two products), the group exchanges the folded values through LDS, and then lane t
+// evaluates the product at ITS point t: K - 1 products.  6 products deep instead of 34; a third more work in total, so only below
+// the size where one lane per pair is latency.  Same values, same record layout as composed_round_kernel.
+constexpr size_t CMP_TSPLIT_MAX = 65536;
+struct TsplitTerms {
+    TablePtrs t[CMP_MAX_TERMS];
+    uint32_t rec_off[CMP_MAX_TERMS];
+    uint32_t k[CMP_MAX_TERMS];
+};
+static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_tsplit_kernel(TsplitTerms mp, size_t n, const uint64_t* __restrict__ r_ptr,
+                                                                          uint32_t rec, uint64_t* __restrict__ partials) {
     constexpr int NW = MLE_BLOCK / 64;
-#pragma unroll
-    for (int i = 0; i <= K; ++i) {
-        const Fr w = wave_reduce_fr(sums[i]);
-        if (lane == 0) red[i * NW + wave] = w;
+    constexpr int XCH = 104;                                             // (64 / (K + 1)) K 2 field elements per wave, largest at K = 5 (100)
+    __shared__ __attribute__((aligned(16))) uint32_t xch[NW * XCH * 8];   // folded (lo, hi) of every table of every group
+    __shared__ __attribute__((aligned(16))) uint32_t part[NW * 64 * 8];   // every lane's sum
+    const TablePtrs& tp = mp.t[blockIdx.y];
+    const uint32_t K = mp.k[blockIdx.y], rec_off = mp.rec_off[blockIdx.y];
+    const uint32_t G = K + 1, GPW = 64 / G;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t g = lane / G, t = lane - g * G;
+    const bool active = g < GPW;
+    const size_t h = n >> 1, q = n >> 2;
+    const Fr r = load_fr(r_ptr, 0);
+    // this lane's table in the folding phase (lanes t < K)
+    const uint64_t* in = tp.in[0];
+    uint64_t* out = tp.out[0];
+    for (uint32_t k = 1; k < K; ++k) if (t == k) { in = tp.in[k]; out = tp.out[k]; }
+    if (q == 0 && blockIdx.x == 0 && lane < K && wave == 0)          // n == 2: one entry per table is left, no pair to sum over
+        store_fr(out, 0, fold_pair(load_fr(in, 0), load_fr(in, 1), r));
+    Fr sum = Fr::zero();
+    const size_t per_wg = (size_t)NW * GPW;
+    uint32_t* my = xch + ((size_t)wave * XCH + (size_t)(active ? g : 0) * K * 2) * 8;
+    for (size_t base = (size_t)blockIdx.x * per_wg; base < q; base += (size_t)gridDim.x * per_wg) {    // uniform per workgroup
+        const size_t j = base + (size_t)wave * GPW + g;
+        const bool valid = active && j < q;
+        if (valid && t < K) {                                           // lane t folds table t
+            const Fr a0 = load_fr(in, j), b0 = load_fr(in, j + h), a1 = load_fr(in, j + q), b1 = load_fr(in, j + h + q);
+            const Fr lo = fold_pair(a0, b0, r), hi = fold_pair(a1, b1, r);
+            store_fr(out, j, lo);
+            store_fr(out, j + q, hi);
+            lds_store_fr(my, 2 * t, lo);
+            lds_store_fr(my, 2 * t + 1, hi);
+        }
+        __syncthreads();
+        if (valid) {                                                    // lane t evaluates prod_k (lo_k + t d_k)
+            Fr prod = Fr::zero();
+            for (uint32_t k = 0; k < K; ++k) {
+                const Fr lo = lds_load_fr(my, 2 * k), hi = lds_load_fr(my, 2 * k + 1);
+                // v = hi + (t - 1) d for t >= 1: the bits of t - 1 select d, 2 d, 4 d
+                const Fr d = hi - lo, d2 = d + d, d4 = d2 + d2;
+                const uint32_t e = t - 1;                               // t = 0: unused
+                Fr v = hi;
+                v = v + ((e & 1u) ? d : Fr::zero());
+                v = v + ((e & 2u) ? d2 : Fr::zero());
+                v = v + ((e & 4u) ? d4 : Fr::zero());
+                if (t == 0) v = lo;
+                prod = k == 0 ? v : prod * v;
+            }
+            sum = sum + prod;
+        }
+        __syncthreads();                                                // before the next pass overwrites the exchange area
     }
+    lds_store_fr(part, threadIdx.x, active ? sum : Fr::zero());
     __syncthreads();
-    if (threadIdx.x <= K) {
-        Fr s[K + 1];
-#pragma unroll
-        for (int i = 0; i <= K; ++i) {
-            s[i] = red[i * NW];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) s[i] = s[i] + red[i * NW + w];
-        }
-        Fr e;
-        switch (threadIdx.x) {
-            case 0: e = eval_small<K, 0>(s); break;
-            case 1: e = eval_small<K, 1>(s); break;
-            case 2: e = eval_small<K, 2>(s); break;
-            case 3: e = eval_small<K, 3>(s); break;
-            case 4: e = eval_small<K, 4>(s); break;
-            default: e = eval_small<K, 5>(s); break;
-        }
-        store_fr(partials, (size_t)blockIdx.x * rec + rec_off + threadIdx.x, e);
+    if (threadIdx.x <= K) {                                             // thread t: the sum over every group of every wave
+        Fr s = Fr::zero();
+        for (uint32_t w = 0; w < (uint32_t)NW; ++w)
+            for (uint32_t gg = 0; gg < GPW; ++gg) s = s + lds_load_fr(part, w * 64 + gg * G + threadIdx.x);
+        store_fr(partials, (size_t)blockIdx.x * rec + rec_off + threadIdx.x, s);
     }
 }
 
@@ -776,19 +860,6 @@ inline uint32_t composed_tail_len(uint32_t total_tables) {   // entries per tabl
     while (2 * m * total_tables <= CMP_TAIL_ENTRIES) m *= 2;
     return m;
 }
-__device__ __forceinline__ Fr lds_load_fr(const uint32_t* base, uint32_t idx) {
-    const uint4* p = reinterpret_cast<const uint4*>(base + 8 * idx);
-    uint4 a = p[0], b = p[1];
-    Fr r;
-    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    return r;
-}
-__device__ __forceinline__ void lds_store_fr(uint32_t* base, uint32_t idx, const Fr& v) {
-    uint4* p = reinterpret_cast<uint4*>(base + 8 * idx);
-    p[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-    p[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
-}
 // one term: per-wave sums of the K+1 evaluations over the pairs (j, j + cn/2) of its K tables (table k at tab + k * m)
 template <int K>
 __device__ __forceinline__ void tail_term_sums(const uint32_t* tab, const uint32_t* lin /* the term's additive table or nullptr */,
@@ -866,36 +937,45 @@ static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(Ta
         // Late rounds (all pairs fit one wave): wave w computes evaluation w of the record -- one point t of one term -- for
         // every pair and reduces it, so the critical path is K - 1 products and ONE wave reduction instead of all (K + 1) points
         // of all terms one after another on the same lanes.  Field arithmetic is exact: same sums.
-        if ((cn >> 1) <= 64 && ca.meta.rec <= CMP_TAIL_BLOCK / 64) {
+        // Terms of three and more tables take this form from 256 pairs on (a few pairs per lane: K - 1 products each, against
+        // (K + 1)(K - 1) per pair with one lane per pair: 24 at K = 5, ~16 us of a round).
+        const bool wide_terms = ca.meta.k[0] >= 3 || (ca.meta.n_terms > 1 && ca.meta.k[1] >= 3);
+        if ((cn >> 1) <= (wide_terms ? 256u : 64u) && ca.meta.rec <= CMP_TAIL_BLOCK / 64) {
             const uint32_t half = cn >> 1, lane = threadIdx.x & 63;
             if (wave < ca.meta.rec) {
                 uint32_t p = 0, q0w = 0;
                 while (p + 1 < ca.meta.n_terms && wave >= ca.meta.rec_off[p + 1]) { q0w += ca.meta.k[p]; ++p; }
                 const uint32_t t = wave - ca.meta.rec_off[p], K = ca.meta.k[p];
                 Fr s = Fr::zero();
-                if (lane < half) {
+                for (uint32_t j = lane; j < half; j += 64) {
+                    Fr pr = Fr::zero();
                     for (uint32_t k = 0; k < K; ++k) {
-                        const Fr lo = lds_load_fr(tab, (q0w + k) * m + lane), hi = lds_load_fr(tab, (q0w + k) * m + lane + half);
+                        const Fr lo = lds_load_fr(tab, (q0w + k) * m + j), hi = lds_load_fr(tab, (q0w + k) * m + j + half);
                         Fr v = t == 0 ? lo : hi;
                         if (t >= 2) {
                             const Fr d = hi - lo;
                             for (uint32_t i = 1; i < t; ++i) v = v + d;
                         }
-                        s = k == 0 ? v : fr_mul_outlined(s, v);
+                        pr = k == 0 ? v : fr_mul_outlined(pr, v);
                     }
                     if (ca.meta.lin_tab[p] != ~0u) {
                         const uint32_t lq = ca.meta.lin_tab[p];
-                        const Fr lo = lds_load_fr(tab, lq * m + lane), hi = lds_load_fr(tab, lq * m + lane + half);
+                        const Fr lo = lds_load_fr(tab, lq * m + j), hi = lds_load_fr(tab, lq * m + j + half);
                         Fr v = t == 0 ? lo : hi;
                         if (t >= 2) {
                             const Fr d = hi - lo;
                             for (uint32_t i = 1; i < t; ++i) v = v + d;
                         }
-                        s = s + v;
+                        pr = pr + v;
                     }
+                    s = s + pr;
                 }
-                // lanes >= half hold zero: log2(half) shuffle steps instead of six
-                for (uint32_t dd = half > 1 ? (1u << (31 - __builtin_clz(half - 1))) : 0; dd >= 1; dd >>= 1) s = s + shfl_down_fr(s, (int)dd);
+                if (half >= 64) {
+                    s = wave_reduce_fr(s);
+                } else {
+                    // lanes >= half hold zero: log2(half) shuffle steps instead of six
+                    for (uint32_t dd = half > 1 ? (1u << (31 - __builtin_clz(half - 1))) : 0; dd >= 1; dd >>= 1) s = s + shfl_down_fr(s, (int)dd);
+                }
                 if (lane == 0) sh.evals[wave] = s;
             }
             __syncthreads();

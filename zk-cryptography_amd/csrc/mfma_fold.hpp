@@ -59,15 +59,16 @@ __device__ __forceinline__ mf_v4i mfm_signed(mf_v4i a) {
 // several tiles per wave as one long stream measured 4.6-5.4 TB/s either way, so a wave takes ONE tile).
 // Host contract: 2^k is a multiple of 2 DEPTH.
 // WSUM (MultilinearTrait::evaluation with every point known, evaluation_form.rs:162-175): the folded table is not written; tile T's
-// record is sum_j out_weights[j] * out[j] over its 64 outputs -- with out_weights = the eq table of the REMAINING points the records
-// add up to the evaluation, so the whole evaluation is this one pass over the table (plus 32 m bytes of weights read instead of
-// 32 m bytes of outputs written: the same traffic as the fold).
+// record is sum_j eq[j] * out[j] over its 64 outputs -- with eq = the eq table of the REMAINING points (kept as the two factors of
+// an outer product, eval_weights_kernel) the records add up to the evaluation, so the whole evaluation is this one pass over the
+// table: 32 n bytes read, nothing written but m / 64 records.
 template <int WAVES, int DEPTH, bool WSUM = false>
 static __global__ __launch_bounds__(64 * WAVES) void multifold_mfma_kernel(const uint64_t* __restrict__ in, size_t m, uint32_t k,
                                                                           const uint64_t* __restrict__ weights,
                                                                           uint64_t* __restrict__ out,
                                                                           uint64_t* __restrict__ partials, uint32_t rot,
-                                                                          const uint64_t* __restrict__ out_weights = nullptr) {
+                                                                          const uint64_t* __restrict__ out_wa = nullptr,
+                                                                          const uint64_t* __restrict__ out_wb = nullptr, uint32_t out_s = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];   // mfm_lds_bytes(min(2^k, MFM_CHUNK)) (host)
     uint32_t* qd = reinterpret_cast<uint32_t*>(zk_dyn_lds);
     const unsigned char* q_lds = zk_dyn_lds;                        // plane 0 = the unshifted strings
@@ -201,7 +202,10 @@ static __global__ __launch_bounds__(64 * WAVES) void multifold_mfma_kernel(const
     x[16] = (uint32_t)carry;
     x[17] = 0;
     Fr o = wide_redc(x);
-    if constexpr (WSUM) o = o * load_fr(out_weights, tile * 64 + lane);
+    if constexpr (WSUM) {                                            // eq[j] of the remaining points = wa[j >> s] * wb[j & (2^s - 1)]
+        const size_t j = tile * 64 + lane;
+        o = o * (load_fr(out_wa, j >> out_s) * load_fr(out_wb, j & (((size_t)1 << out_s) - 1)));
+    }
     else store_fr(out, tile * 64 + lane, o);
     const Fr s = wave_reduce_fr(o);
     if (lane == 0) store_fr(partials, tile, s);

@@ -441,21 +441,29 @@ static __global__ __launch_bounds__(MLE_BLOCK) void eq_weights_kernel(PtsArg pts
     store_fr(out, b, w);
 }
 
-// The two weight tables of an evaluation in one pass (zkhip_mle_evaluation): lanes [0, 2^k1) -> w1 = the fold weights of the first k1
-// points (with the factor 2^32, as above); lanes [2^k1, 2^k1 + 2^k2) -> w2 = the plain eq table of the remaining k2 points (Montgomery
-// form, no factor: it multiplies finished outputs).
-static __global__ __launch_bounds__(MLE_BLOCK) void eval_weights_kernel(PtsArg pts, uint32_t k1, uint32_t k2, uint64_t* __restrict__ w1,
-                                                                        uint64_t* __restrict__ w2) {
+// The weight tables of an evaluation in one pass (zkhip_mle_evaluation), one lane per entry:
+//   w1[b], b < 2^k1       the fold weights of the first k1 points (with the factor 2^32, as above);
+//   wa[x], x < 2^(k2 - s) and wb[y], y < 2^s: the plain eq tables (Montgomery form, no factor) of the next k2 - s and the last s
+//   points -- the eq table of all k2 remaining points is their outer product, eq[x * 2^s + y] = wa[x] * wb[y], formed where it is
+//   used (one product per output): at most max(k1, k2 - s, s) products one after another here instead of k2.
+static __global__ __launch_bounds__(MLE_BLOCK) void eval_weights_kernel(PtsArg pts, uint32_t k1, uint32_t k2, uint32_t s, uint64_t* __restrict__ w1,
+                                                                        uint64_t* __restrict__ wa, uint64_t* __restrict__ wb) {
     size_t b = (size_t)blockIdx.x * MLE_BLOCK + threadIdx.x;
-    const bool second = b >= ((size_t)1 << k1);
-    if (second) b -= (size_t)1 << k1;
-    const uint32_t k = second ? k2 : k1, first = second ? k1 : 0;
-    if (b >= ((size_t)1 << k)) return;
+    const size_t n1 = (size_t)1 << k1, na = (size_t)1 << (k2 - s), nb = (size_t)1 << s;
+    uint32_t k, first;
+    uint64_t* out;
     Fr w = Fr::one();
-    if (!second) {
+    if (b < n1) {
+        k = k1; first = 0; out = w1;
         constexpr uint32_t c[8] = {0xcaaf6b13u, 0x355094eau, 0x69a568efu, 0xf6b10cb3u, 0x40cc3869u, 0xe2c926a6u, 0xed269aadu, 0x736a6d3bu};
 #pragma unroll
         for (int i = 0; i < 8; ++i) w.l[i] = c[i];
+    } else if (b < n1 + na) {
+        b -= n1; k = k2 - s; first = k1; out = wa;
+    } else if (b < n1 + na + nb) {
+        b -= n1 + na; k = s; first = k1 + k2 - s; out = wb;
+    } else {
+        return;
     }
     const Fr one = Fr::one();
     for (uint32_t i = 0; i < k; ++i) {
@@ -463,7 +471,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void eval_weights_kernel(PtsArg p
         if (!((b >> (k - 1 - i)) & 1)) r = one - r;
         w = w * r;
     }
-    store_fr(second ? w2 : w1, b, w);
+    store_fr(out, b, w);
 }
 // out[0] = sum of n records (the tiles' shares of an evaluation)
 static __global__ __launch_bounds__(MLE_BLOCK) void sum_records_kernel(const uint64_t* __restrict__ records, uint32_t n, uint64_t* __restrict__ out) {

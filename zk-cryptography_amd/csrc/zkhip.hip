@@ -327,24 +327,25 @@ extern "C" int zkhip_mle_evaluation(zkhip_ctx* c, const uint64_t* d_evals, size_
     if (one_pass && log_n >= 17) {
         // Every point is known before the first launch, so the evaluation is ONE pass over the table: with k1 leading variables per
         // output, p(r) = sum_j eq_j(r[k1..]) * (sum_b eq_b(r[..k1]) * T[b * m + j]) -- the k1-variable fold on the matrix cores
-        // whose tiles weight their 64 outputs with the eq table of the remaining points and keep only that sum (32 n + 32 m bytes
-        // read, nothing written but m / 64 records), then the records' sum.  Three launches: both weight tables, the pass, the sum.
-        const uint32_t k1 = std::min<uint32_t>(MF_MAX_LOGK, log_n - 13), k2 = log_n - k1;
-        const size_t m = n >> k1, tiles = m / 64;
-        ZK_TRY(c->reserve_ws((256 + m + tiles + 16) * 32));
+        // whose tiles weight their 64 outputs with the eq table of the remaining points and keep only that sum (32 n bytes read,
+        // nothing written but m / 64 records), then the records' sum.  Three launches: the weight tables, the pass, the sum.
+        const uint32_t k1 = std::min<uint32_t>(MF_MAX_LOGK, log_n - 13), k2 = log_n - k1, s2 = k2 / 2;
+        const size_t m = n >> k1, tiles = m / 64, na = (size_t)1 << (k2 - s2), nb = (size_t)1 << s2;
+        ZK_TRY(c->reserve_ws((256 + na + nb + tiles + 16) * 32));
         uint64_t* d_w1 = (uint64_t*)c->d_ws;
-        uint64_t* d_w2 = d_w1 + 4 * 256;
-        uint64_t* d_rec = d_w2 + 4 * m;
+        uint64_t* d_wa = d_w1 + 4 * 256;
+        uint64_t* d_wb = d_wa + 4 * na;
+        uint64_t* d_rec = d_wb + 4 * nb;
         PtsArg pa = {};
         std::memcpy(pa.v, h_pts, 32 * n_pts);
-        const size_t lanes = ((size_t)1 << k1) + m;
-        hipLaunchKernelGGL(eval_weights_kernel, dim3((unsigned)((lanes + MLE_BLOCK - 1) / MLE_BLOCK)), dim3(MLE_BLOCK), 0, c->stream, pa, k1, k2, d_w1, d_w2);
+        const size_t lanes = ((size_t)1 << k1) + na + nb;
+        hipLaunchKernelGGL(eval_weights_kernel, dim3((unsigned)((lanes + MLE_BLOCK - 1) / MLE_BLOCK)), dim3(MLE_BLOCK), 0, c->stream, pa, k1, k2, s2, d_w1, d_wa, d_wb);
         {
-            ProfScope ps(c, "multifold_eval", 32.0 * (double)n + 32.0 * (double)m);
+            ProfScope ps(c, "multifold_eval", 32.0 * (double)n);
             const size_t q_bytes = mfm_lds_bytes(std::min<uint32_t>(1u << k1, (uint32_t)MFM_CHUNK));
             if (q_bytes > 64 * 1024) ZK_TRY(c->allow_big_lds((const void*)multifold_mfma_kernel<4, 4, true>, 158 * 1024));
             hipLaunchKernelGGL((multifold_mfma_kernel<4, 4, true>), dim3((unsigned)(tiles / 4)), dim3(256), q_bytes, c->stream, d_evals, m, k1,
-                               (const uint64_t*)d_w1, (uint64_t*)nullptr, d_rec, 1u, (const uint64_t*)d_w2);
+                               (const uint64_t*)d_w1, (uint64_t*)nullptr, d_rec, 1u, (const uint64_t*)d_wa, (const uint64_t*)d_wb, s2);
         }
         hipLaunchKernelGGL(sum_records_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, (const uint64_t*)d_rec, (uint32_t)tiles, d_res);
         ZK_HIP(c, hipGetLastError());
