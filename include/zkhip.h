@@ -456,7 +456,8 @@ int zkhip_kzg_commit(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t 
                      uint8_t *h_out_inf);
 /* Shifted-SRS table: d_table[w * n + i] = 2^(first bit of window w) * point i for the W digit windows of a 256-bit scalar, in the
  * kernels' internal layout (zkhip_srs_table_bytes(n) = W * 128 * n bytes; at 2^20 points W = 13 windows of 20 / 19 bits: 1.6 GiB -- HBM
- * is what this part has; smaller SRS get windows WIDER than their size, 2^12 points: 18 windows of 15 / 14 bits).  With it the digits
+ * is what this part has; smaller SRS get windows WIDER than their size, 2^12 points: 18 windows of 15 / 14 bits; commits of at most 2^12 scalars against a
+ * table take a short path without sort or buckets -- one plain sum per digit bit, two launches: 0.42 ms at 2^8 against 0.65).  With it the digits
  * of all windows fall into ONE bucket set: at 2^20 13 n bucket additions instead of 16 n and a single bucket reduction.  The table
  * depends on the SRS only (built once, ~70 ms at 2^20); zkhip_kzg_commit_table then has the semantics of zkhip_kzg_commit (same group
  * element, same errors).  n * W must stay below 2^31.  A table has no header: its layout (W and the two window widths) is a function

@@ -454,10 +454,13 @@ def test_srs_caches_follow_in_place_edits(zk, ora):
     before = zk.MultilinearKZG.commitment(poly, srs)
     z = ora.random_fr(8, 323)
     zk.MultilinearKZG.open(poly, z, srs)                                   # caches the folded levels too
+    stale = srs.table
+    assert stale is not None
     srs.powers_of_tau_in_g1[[0, 1]] = srs.powers_of_tau_in_g1[[1, 0]]      # in place: the first two points swapped
     plain = zk.TrustedSetup(srs.powers_of_tau_in_g1.clone(), srs.inf.clone())
-    after = zk.MultilinearKZG.commitment(poly, srs)                        # plain path now: the stale table was dropped
-    assert srs.table is None and not (after == before) and after == zk.MultilinearKZG.commitment(poly, plain)
+    assert srs.table is None                                               # the stale table was dropped ...
+    after = zk.MultilinearKZG.commitment(poly, srs)                        # ... (a small SRS builds a fresh one on its next commitment)
+    assert srs.table is not stale and not (after == before) and after == zk.MultilinearKZG.commitment(poly, plain)
     assert zk.MultilinearKZG.commitment(poly, srs.precompute()) == after   # and a table rebuilt from the edited points agrees
     a, b = zk.MultilinearKZG.open(poly, z, srs), zk.MultilinearKZG.open(poly, z, plain, cache_folded_srs=False)
     assert all(p == q for p, q in zip(a.proofs, b.proofs))
@@ -488,9 +491,11 @@ def test_srs_caches_follow_raw_pointer_writes(zk, ora):
     N.check(N.lib().zkhip_memcpy_h2d(ctx.handle, C.c_void_p(srs.powers_of_tau_in_g1.data_ptr()), swapped.ctypes.data_as(C.c_void_p),
                                      C.c_size_t(swapped.nbytes)), "memcpy")
     assert srs.powers_of_tau_in_g1._version == version                     # torch saw nothing
+    stale = srs._table
     plain = zk.TrustedSetup(srs.powers_of_tau_in_g1.clone(), srs.inf.clone())
-    after = zk.MultilinearKZG.commitment(poly, srs)
-    assert srs.table is None and not (after == before) and after == zk.MultilinearKZG.commitment(poly, plain)
+    assert srs.table is None                                               # the fingerprint did: the stale table was dropped ...
+    after = zk.MultilinearKZG.commitment(poly, srs)                        # ... (a small SRS builds a fresh one on its next commitment)
+    assert srs.table is not stale and not (after == before) and after == zk.MultilinearKZG.commitment(poly, plain)
     srs.precompute()
     assert srs.table is not None
     srs.invalidate()

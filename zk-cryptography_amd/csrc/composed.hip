@@ -113,6 +113,9 @@ struct ComposedRun {
     uint32_t pipe_records = 0;       // > 0: the tail continues pipelined rounds -- forms records in d_pipe_rec[pipe_parity], tables unfolded
     int pipe_parity = 0;
     FrArg sum_arg = {};      // the claimed sum, passed to the closing kernels by value
+    const uint64_t* sum_dev = nullptr;   // ... or read by them from device memory (gkr.hip: the kernel before computed it)
+    OuterPub outer = {};     // an outer transcript fed beside the rounds (composed_kernels.hpp): every closing launch gets a hasher workgroup
+    unsigned extra_wg() const { return outer.dev ? 1u : 0u; }
 
     // n = entries per table held here, n_rounds = rounds of the whole sumcheck (log2 n, more when other ranks hold shards)
     int setup(zkhip_ctx* ctx, const uint64_t* const* ptrs, const uint32_t* sizes, uint32_t nt, size_t n_entries, uint32_t rounds,
@@ -227,6 +230,7 @@ struct ComposedRun {
     CloseArgs close_args() const {
         CloseArgs ca = {};
         ca.meta = meta; ca.st = st; ca.round = out_base + round; ca.first = first; ca.round_out = d_rp; ca.challenges = d_ch; ca.sum = sum_arg;
+        ca.sum_dev = sum_dev; ca.outer = outer;
         return ca;
     }
     // The round on tables too large for one workgroup's LDS, first part: one launch per term (fold at the previous
@@ -394,9 +398,9 @@ struct ComposedRun {
             ProfScope ps(c, "composed_stage_close", 0.0);
             // the second round one round ahead of the transcript (composed_pipe.hpp); ZKHIP_PIPE=0 keeps the round-by-round form (same-box A/B)
             if (pipe_on() && pipe_eligible(meta))
-                hipLaunchKernelGGL(composed_stage_close_pipe_kernel, dim3(1), dim3(PIPE_BLOCK), 0, c->stream, records, sa);
+                hipLaunchKernelGGL(composed_stage_close_pipe_kernel, dim3(1 + extra_wg()), dim3(PIPE_BLOCK), 0, c->stream, records, sa);
             else
-                hipLaunchKernelGGL(composed_stage_close_kernel, dim3(1), dim3(CST_BLOCK), 0, c->stream, records, sa);
+                hipLaunchKernelGGL(composed_stage_close_kernel, dim3(1 + extra_wg()), dim3(CST_BLOCK), 0, c->stream, records, sa);
         }
         first = 0;
         round += 2;
@@ -422,7 +426,7 @@ struct ComposedRun {
     }
     // second part: sum the records (the workgroups' here, the ranks' in the sharded protocol) and close the round
     void close(const uint64_t* records, uint32_t n_records) {
-        hipLaunchKernelGGL(composed_close_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, records, n_records, close_args());
+        hipLaunchKernelGGL(composed_close_kernel, dim3(1 + extra_wg()), dim3(MLE_BLOCK), 0, c->stream, records, n_records, close_args());
         first = 0;
         ++round;
         pending = true;
@@ -435,11 +439,11 @@ struct ComposedRun {
         // transcript (composed_pipe.hpp).  ZKHIP_PIPE=0 keeps the round-by-round tail (same-box A/B).
         if (pipe_on() && pipe_eligible(meta)) {
             ZK_TRY(c->allow_big_lds((const void*)composed_tail_pipe_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
-            hipLaunchKernelGGL(composed_tail_pipe_kernel, dim3(1), dim3(PIPE_BLOCK), (size_t)total_all * m * 32, c->stream, tt, total_all, m,
+            hipLaunchKernelGGL(composed_tail_pipe_kernel, dim3(1 + extra_wg()), dim3(PIPE_BLOCK), (size_t)total_all * m * 32, c->stream, tt, total_all, m,
                                fold ? 1u : 0u, fold ? prev_challenge() : nullptr, close_args(), n_rounds - round, (const uint64_t*)nullptr, 0u, pipe_max_q());
         } else {
             ZK_TRY(c->allow_big_lds((const void*)composed_tail_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
-            hipLaunchKernelGGL(composed_tail_kernel, dim3(1), dim3(CMP_TAIL_BLOCK), (size_t)total_all * m * 32, c->stream, tt, total_all, m,
+            hipLaunchKernelGGL(composed_tail_kernel, dim3(1 + extra_wg()), dim3(CMP_TAIL_BLOCK), (size_t)total_all * m * 32, c->stream, tt, total_all, m,
                                fold ? 1u : 0u, fold ? prev_challenge() : nullptr, close_args(), n_rounds - round);
         }
         round = n_rounds;
@@ -490,7 +494,7 @@ struct ComposedRun {
         const size_t lds = (size_t)3 * n_terms * 4 * PIPE_TILE * 32;
         ZK_TRY(c->allow_big_lds((const void*)composed_pipe_round_kernel, 128 * 1024));
         ProfScope ps(c, "composed_pipe_round", 0.0);
-        hipLaunchKernelGGL(composed_pipe_round_kernel, dim3(n_cross + (do_close ? 1 : 0)), dim3(PIPE_BLOCK), lds, c->stream, a);
+        hipLaunchKernelGGL(composed_pipe_round_kernel, dim3(n_cross + (do_close ? 1 + extra_wg() : 0)), dim3(PIPE_BLOCK), lds, c->stream, a);
         *n_rec_out = n_cross;
         return ZKHIP_OK;
     }
@@ -539,7 +543,7 @@ struct ComposedRun {
     int tail_after_pipe() {
         ZK_TRY(c->allow_big_lds((const void*)composed_tail_pipe_kernel, (size_t)CMP_TAIL_ENTRIES * 32));
         ProfScope ps(c, "composed_tail", 0.0);
-        hipLaunchKernelGGL(composed_tail_pipe_kernel, dim3(1), dim3(PIPE_BLOCK), (size_t)total_all * cn * 32, c->stream, current_tables(), total_all,
+        hipLaunchKernelGGL(composed_tail_pipe_kernel, dim3(1 + extra_wg()), dim3(PIPE_BLOCK), (size_t)total_all * cn * 32, c->stream, current_tables(), total_all,
                            (uint32_t)cn, 0u, (const uint64_t*)nullptr, close_args(), n_rounds - round, (const uint64_t*)d_pipe_rec[pipe_parity], pipe_records, pipe_max_q());
         pipe_records = 0;
         round = n_rounds;
@@ -632,9 +636,12 @@ static int composed_prove_impl(zkhip_ctx* c, const uint64_t* const* ptrs, const 
 // Internal entries for gkr.hip (same shared object; not part of the C ABI): the two halves of prove_partial.  A caller chains the
 // calls of ONE sumcheck on the device -- `cont` continues the transcript, `out_base` appends to the rounds already recorded --
 // and reads all rounds back once (zk_multi_composed_collect), so nothing between the calls waits for the host.
+// ex (nullable): the claimed sum from device memory instead of h_sum, an outer transcript to feed, and where the rounds and challenges
+// are recorded instead of the context's small buffer (a caller that enqueues several sumchecks before it reads any of them back)
+static_assert(CMP_OUTER_ROUNDS >= ZK_MAX_ROUNDS, "one ring slot per round");
 int zk_multi_composed_enqueue(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes, const uint64_t* const* lin_ptrs,
-                              uint32_t n_terms, size_t n, const uint64_t* h_sum, int cont, uint32_t out_base) {
-    if (!c || !ptrs || !term_sizes || n_terms == 0 || n_terms > CMP_MAX_TERMS || (!h_sum && !cont)) return ZKHIP_ERR_ARG;
+                              uint32_t n_terms, size_t n, const uint64_t* h_sum, int cont, uint32_t out_base, const ZkMcExtra* ex) {
+    if (!c || !ptrs || !term_sizes || n_terms == 0 || n_terms > CMP_MAX_TERMS || (!h_sum && !cont && !(ex && ex->d_sum))) return ZKHIP_ERR_ARG;
     if (!is_pow2(n) || n < 2) return ZKHIP_ERR_SHAPE;
     const uint32_t n_vars = log2_exact(n);
     if (out_base + n_vars > ZK_MAX_ROUNDS) return ZKHIP_ERR_SHAPE;
@@ -642,6 +649,13 @@ int zk_multi_composed_enqueue(zkhip_ctx* c, const uint64_t* const* ptrs, const u
     ComposedRun run;
     ZK_TRY(run.setup(c, ptrs, term_sizes, n_terms, n, n_vars, 1, h_sum, 1, lin_ptrs, cont));
     run.out_base = out_base;
+    if (ex) {
+        run.sum_dev = ex->d_sum;
+        run.outer.dev = (OuterDev*)ex->outer;
+        run.outer.token = ex->token;
+        if (ex->d_round_polys) run.d_rp = ex->d_round_polys;
+        if (ex->d_challenges) run.d_ch = ex->d_challenges;
+    }
     while (run.round < n_vars) {
         if (run.after() <= run.tail_len) {
             ZK_TRY(run.tail(run.current_tables(), (uint32_t)run.after(), run.folds()));

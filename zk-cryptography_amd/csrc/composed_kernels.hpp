@@ -16,6 +16,7 @@
 #include "mle_kernels.hpp"
 #include "stamps.hpp"
 #include "wide_acc.hpp"
+#include "outer_transcript.hpp"
 
 namespace zk {
 
@@ -194,6 +195,118 @@ struct CloseShared {                   // LDS scratch of close_round
     uint32_t n_blocks;
 };
 
+// ---- an OUTER transcript fed beside the rounds ---------------------------------------------------------------------------------
+// GKRProtocol::prove absorbs every layer's ComposedSumcheckProof::to_bytes() into its own transcript (gkr/src/protocol.rs:91,
+// gkr/src/utils.rs:38) and draws alpha, beta from it (:104-105): the same item bytes the rounds' own transcript absorbs, in a second
+// hash chain.  On the host that was one synchronisation per layer.  Here every closing kernel is launched with ONE MORE workgroup, the
+// hasher: the wave that closes a round publishes its items (canonical coefficient, power) in a ring in global memory and raises the
+// round's flag (release, agent scope, by a wave that is not on the round's critical path); the hasher waits for the flag (acquire),
+// absorbs the items into the outer state -- which lives in global memory between kernels, like the rounds' own transcript -- and ends
+// with the kernel.  Its ~2 us per 64-byte item run beside the rounds' own hash of the same bytes.
+static_assert(CMP_OUTER_MONO == CMP_MAX_MONO, "the ring holds a whole round polynomial");
+struct CloseArgs {
+    ComposedMeta meta;
+    ComposedDev* st;
+    FrArg sum;                          // the claimed sum (absorbed in the first round of a multi-composed proof) ...
+    const uint64_t* sum_dev;            // ... or, when not null, where it lies in device memory (the kernel before computed it)
+    uint32_t round, first;
+    uint64_t* round_out;
+    uint64_t* challenges;
+    OuterPub outer;
+};
+__device__ __forceinline__ Fr close_claimed_sum(const CloseArgs& ca) { return ca.sum_dev ? load_fr(ca.sum_dev, 0) : fr_from_arg(ca.sum); }
+// one whole wave, after the round's items are in sh (canon, pow_of, n_items) and a barrier has made them visible to it.
+// One row = 64 words = one agent-scope store per lane, then the flag behind a release fence at agent scope (the reader may run on
+// another XCD, behind another L2).
+__device__ __forceinline__ void outer_publish(const OuterPub& op, const CloseShared& sh, uint32_t round) {
+    if (!op.dev) return;
+    const uint32_t lane = threadIdx.x & 63, n = sh.n_items;
+    uint32_t* it = op.dev->items[round];
+    uint32_t v = n;
+    if (lane >= 1) {
+        const uint32_t w = lane - 1, i = w / 9, o = w - 9 * i;
+        v = i < n ? (o < 8 ? sh.canon[i].l[o] : sh.pow_of[i]) : 0u;
+    }
+    __hip_atomic_store(&it[lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // release at agent scope: the row before the flag, for a reader on another XCD.  (The write-back this implies runs on a wave that
+    // has nothing else to do while wave 0 hashes; measured: no difference to a relaxed flag -- which two boxes of four processes
+    // sharing one GPU showed to be not enough.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_store(&op.dev->flag[round], op.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The hasher workgroup (every thread of it calls; >= 128 threads): absorbs rounds [first_round, first_round + n_rounds) as they are
+// published.  transcript.commit(&sumcheck_proof.to_bytes()): per round, per monomial coeff || pow as 32-byte big-endian integers
+// (multi_composed_sumcheck.rs:24-31, sparse_univariate.rs:27-34) -- 64 bytes per monomial, so a round of n monomials is exactly n
+// blocks whatever is pending (the pending part is 0 or 32 bytes and stays so).  Like the rounds' own hash: the waves beside wave 0
+// compute the message schedules of all blocks side by side, wave 0 runs the state rounds only (~1.7 us per block).
+struct OuterShared {
+    uint32_t row[64];
+    uint32_t msg[16 * CMP_OUTER_MONO];
+    uint32_t kw[64 * CMP_OUTER_MONO];
+    uint32_t buf[8];
+    uint32_t fill_words, n, ok;
+};
+__device__ __forceinline__ uint32_t outer_stream_word(const uint32_t* row, uint32_t x) {      // word x of the round's item bytes
+    const uint32_t i = x >> 4, o = x & 15;
+    return o < 8 ? row[1 + 9 * i + (7 - o)] : (o == 15 ? row[1 + 9 * i + 8] : 0u);
+}
+__device__ __noinline__ void outer_absorb_rounds(OuterPub op, uint32_t first_round, uint32_t n_rounds) {
+    __shared__ OuterShared os;
+    static_assert(1 + CMP_OUTER_MONO * 9 == 64, "a round's row is one word per lane");
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, n_sched = (blockDim.x >> 6) - 1;
+    uint32_t h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = op.dev->state.h[i];
+    uint64_t len = op.dev->state.len;
+    if (tid < 8) os.buf[tid] = op.dev->state.buf[tid];
+    if (tid == 0) os.fill_words = op.dev->state.fill >> 2;
+    __syncthreads();
+    for (uint32_t r = first_round; r < first_round + n_rounds; ++r) {
+        if (wave == 0) {
+            uint32_t spins = 0;
+            bool ok = true;
+            while (__hip_atomic_load(&op.dev->flag[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != op.token) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 25)) { ok = false; break; }     // seconds: something upstream failed; say so instead of hanging the stream
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the row after the flag
+            const uint32_t mine = ok ? __hip_atomic_load(&op.dev->items[r][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            os.row[tid] = mine;
+            if (tid == 0) { os.ok = ok ? 1u : 0u; os.n = mine < (uint32_t)CMP_OUTER_MONO ? mine : (uint32_t)CMP_OUTER_MONO; }
+        }
+        __syncthreads();
+        if (!os.ok) {
+            if (tid == 0) op.dev->error = 1 + r;
+            break;
+        }
+        const uint32_t n = os.n, fill = os.fill_words;
+        for (uint32_t t = tid; t < 16 * n; t += blockDim.x) {
+            const uint32_t b = t >> 4, k = t & 15;
+            uint32_t v;
+            if (fill == 0) v = outer_stream_word(os.row, t);
+            else v = k < 8 ? (b == 0 ? os.buf[k] : outer_stream_word(os.row, 16 * (b - 1) + 8 + k)) : outer_stream_word(os.row, 16 * b + (k - 8));
+            os.msg[t] = v;
+        }
+        __syncthreads();
+        if (wave >= 1) {
+            for (uint32_t b = wave - 1; b < n; b += n_sched) sha256_schedule_block(os.msg + 16 * b, os.kw + 64 * b);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (uint32_t b = 0; b < n; ++b) sha256_rounds_block(h, os.kw + 64 * b);
+            if (fill != 0 && n > 0 && tid < 8) os.buf[tid] = outer_stream_word(os.row, 16 * (n - 1) + 8 + tid);
+        }
+        len += 64ull * n;
+        __syncthreads();
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) op.dev->state.h[i] = h[i];
+        op.dev->state.len = len;
+    }
+    if (tid < 8) op.dev->state.buf[tid] = os.buf[tid];      // (fill is unchanged: whole 64-byte items only)
+}
+
 // Closes a round with the whole workgroup (>= 64 threads; every thread must call): sh.evals hold the sums.
 // Builds the round polynomial, absorbs it, derives the challenge (left in sh.challenge_canon and, in Montgomery form, challenges[round]).
 //   first: 1 = the transcript is started here (ComposedSumcheck: nothing absorbed before, composed_sumcheck.rs:33;
@@ -223,10 +336,12 @@ __device__ __forceinline__ void close_preload(CloseShared& sh, const ComposedMet
 // form goes to challenges[round] without anyone waiting for the conversion.
 struct NoShadow { __device__ __forceinline__ void operator()(uint32_t, uint32_t) const {} };
 template <class Shadow = NoShadow>
-__device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta& meta, ComposedDev* st, const FrArg& claimed_sum, Sha256State* tr_state,
-                                            uint32_t round, uint32_t first, uint64_t* __restrict__ round_out,
-                                            uint64_t* __restrict__ challenges, const Shadow& shadow = Shadow()) {
-    uint64_t* out = round_out + 64 * (size_t)round;
+__device__ __forceinline__ void close_round(CloseShared& sh, const CloseArgs& ca, Sha256State* tr_state,
+                                            uint32_t round, uint32_t first, const Shadow& shadow = Shadow()) {
+    const ComposedMeta& meta = ca.meta;
+    ComposedDev* st = ca.st;
+    uint64_t* __restrict__ challenges = ca.challenges;
+    uint64_t* out = ca.round_out + 64 * (size_t)round;
     const uint32_t tid = threadIdx.x;
     ZK_STAMP_AT(0, round, 0);
     if (!meta.multi) {
@@ -305,7 +420,7 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
             if (tid == 0) { sh.n_items = (uint32_t)__popcll(mask); out[0] = (uint64_t)__popcll(mask); }
         }
     }
-    if (meta.multi && first && tid == 64) sh.sum_canon = fr_from_mont_outlined(fr_from_arg(claimed_sum));   // multi_composed_sumcheck.rs:70
+    if (meta.multi && first && tid == 64) sh.sum_canon = fr_from_mont_outlined(close_claimed_sum(ca));   // multi_composed_sumcheck.rs:70
     __syncthreads();
     ZK_STAMP_AT(0, round, 1);
     // ---- the round's message, padded (FiatShamirTranscript: commit ... then challenge = finalize, fiat_shamir.rs:17-25):
@@ -348,6 +463,7 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const ComposedMeta&
             for (int j = 0; j < 16; ++j) w[j] = sh.msg[16 * b + j];
             sha256_schedule_to_lds(w, sh.kw + 64 * b, &sh.kw_ready[b], 0u, b == 0 ? 1u : 0u);
         }
+        if (wave == n_sched - 1) outer_publish(ca.outer, sh, round);      // the last wave: the one with the fewest schedules
         shadow(tid - 64, blockDim.x - 64);
     } else {
         uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
@@ -756,17 +872,10 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_round_split2_kernel
     }
 }
 
-struct CloseArgs {
-    ComposedMeta meta;
-    ComposedDev* st;
-    FrArg sum;                          // the claimed sum (absorbed in the first round of a multi-composed proof)
-    uint32_t round, first;
-    uint64_t* round_out;
-    uint64_t* challenges;
-};
 // sums the n_partials workgroup records of a round (wave w takes the values v = w, w + 4, ...) and closes it
 static __global__ __launch_bounds__(MLE_BLOCK) void composed_close_kernel(const uint64_t* __restrict__ partials, uint32_t n_partials,
                                                                    CloseArgs ca) {
+    if (ca.outer.dev && blockIdx.x == gridDim.x - 1) { outer_absorb_rounds(ca.outer, ca.round, 1); return; }   // the hasher workgroup
     __shared__ CloseShared sh;
     __shared__ Sha256State trs;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -799,7 +908,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void composed_close_kernel(const 
         }
     }
     __syncthreads();
-    close_round(sh, ca.meta, ca.st, ca.sum, &trs, ca.round, ca.first, ca.round_out, ca.challenges);
+    close_round(sh, ca, &trs, ca.round, ca.first);
     if (threadIdx.x < sizeof(Sha256State) / 4)
         reinterpret_cast<uint32_t*>(&ca.st->transcript)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&trs)[threadIdx.x];
 }
@@ -911,6 +1020,7 @@ __device__ __forceinline__ void tail_fold(uint32_t* tab, uint32_t total, uint32_
 static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(TailTables tt, uint32_t total, uint32_t m, uint32_t load_fold,
                                                                        const uint64_t* __restrict__ r_ptr, CloseArgs ca,
                                                                        uint32_t n_rounds) {
+    if (ca.outer.dev && blockIdx.x == gridDim.x - 1) { outer_absorb_rounds(ca.outer, ca.round, n_rounds); return; }   // the hasher workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
     uint32_t* tab = reinterpret_cast<uint32_t*>(zk_dyn_lds);   // total tables x m elements
     __shared__ CloseShared sh;
@@ -979,7 +1089,7 @@ static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(Ta
                 if (lane == 0) sh.evals[wave] = s;
             }
             __syncthreads();
-            close_round(sh, ca.meta, ca.st, ca.sum, &trs, round, first, ca.round_out, ca.challenges, TailShadow{tab, total, m, cn == 2 ? 0u : half});
+            close_round(sh, ca, &trs, round, first, TailShadow{tab, total, m, cn == 2 ? 0u : half});
             first = 0;
             if (cn == 2) break;
             tail_fold(tab, total, m, half, sh.challenge_canon);
@@ -1009,7 +1119,7 @@ static __global__ __launch_bounds__(CMP_TAIL_BLOCK) void composed_tail_kernel(Ta
         }
         __syncthreads();
         const uint32_t half = cn >> 1;
-        close_round(sh, ca.meta, ca.st, ca.sum, &trs, round, first, ca.round_out, ca.challenges, TailShadow{tab, total, m, cn == 2 ? 0u : half});
+        close_round(sh, ca, &trs, round, first, TailShadow{tab, total, m, cn == 2 ? 0u : half});
         first = 0;
         if (cn == 2) break;   // the fold after the last round has no consumer
         tail_fold(tab, total, m, half, sh.challenge_canon);

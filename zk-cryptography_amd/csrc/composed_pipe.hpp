@@ -340,6 +340,7 @@ __device__ __forceinline__ void pipe_reduce_records(CloseShared& sh, PipeShared&
 static __global__ __launch_bounds__(PIPE_BLOCK) void composed_tail_pipe_kernel(TailTables tt, uint32_t total, uint32_t m, uint32_t load_fold,
                                                                          const uint64_t* __restrict__ r_ptr, CloseArgs ca, uint32_t n_rounds,
                                                                          const uint64_t* __restrict__ records_in, uint32_t n_records_in, uint32_t max_q) {
+    if (ca.outer.dev && blockIdx.x == gridDim.x - 1) { outer_absorb_rounds(ca.outer, ca.round, n_rounds); return; }   // the hasher workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
     uint32_t* tab = reinterpret_cast<uint32_t*>(zk_dyn_lds);   // total tables x m elements
     __shared__ CloseShared sh;
@@ -360,7 +361,7 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_tail_pipe_kernel(T
         if (tid < sizeof(Sha256State) / 4)
             reinterpret_cast<uint32_t*>(&trs)[tid] = reinterpret_cast<const uint32_t*>(&ca.st->transcript)[tid];
         if (tid == 0) { ps.prev_valid = 0; ps.out_n = 0; }
-        if (meta.multi && ca.first && tid == 64) sh.sum_canon = fr_from_mont_outlined(fr_from_arg(ca.sum));   // multi_composed_sumcheck.rs:70
+        if (meta.multi && ca.first && tid == 64) sh.sum_canon = fr_from_mont_outlined(close_claimed_sum(ca));   // multi_composed_sumcheck.rs:70
     }
     const uint32_t n_groups = 3 * meta.n_terms;
     if (n_records_in) pipe_reduce_records(sh, ps, ca.st, records_in, n_records_in, n_groups, ca.round);
@@ -426,6 +427,7 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_tail_pipe_kernel(T
             ZK_STAMP_AT(0, round, 4);
         } else {
             pipe_schedules(sh);
+            if (wave == PIPE_OUT_WAVE) outer_publish(ca.outer, sh, round);
             pipe_outputs(ps, meta, ca.round_out, ca.challenges);
             if (make_forms) {
                 // the tables of this round are folded (above) -- their four quarter blocks give the next round's forms in THIS round's challenge
@@ -506,6 +508,7 @@ __device__ __forceinline__ void pipe_close_round(CloseShared& sh, PipeShared& ps
         ZK_STAMP_AT(0, round, 4);
     } else {
         pipe_schedules(sh);
+        if (wave == PIPE_OUT_WAVE) outer_publish(ca.outer, sh, round);   // (the wave without a schedule in the common shapes)
         pipe_outputs(ps, ca.meta, ca.round_out, ca.challenges);
         beside();                                    // (waves 1..: whatever else can be prepared while wave 0 hashes)
     }
@@ -602,6 +605,9 @@ __device__ __forceinline__ Fr pipe_challenge_mont(const ComposedDev* st, uint32_
 }
 
 static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(PipeRoundArgs a) {
+    // the hasher workgroup (the last one, when an outer transcript is fed and this launch closes a round)
+    const uint32_t n_outer = (a.ca.outer.dev && a.do_close) ? 1u : 0u;
+    if (n_outer && blockIdx.x == gridDim.x - 1) { outer_absorb_rounds(a.ca.outer, a.ca.round, 1); return; }
     extern __shared__ __attribute__((aligned(16))) unsigned char zk_dyn_lds[];
     __shared__ CloseShared sh;
     __shared__ PipeShared ps;
@@ -621,7 +627,7 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(
             pipe_reduce_records(sh, ps, a.ca.st, a.records_in, a.n_records_in, n_groups, round);
             __syncthreads();
         } else {
-            if (meta.multi && first && tid == 64) sh.sum_canon = fr_from_mont_outlined(fr_from_arg(a.ca.sum));   // multi_composed_sumcheck.rs:70
+            if (meta.multi && first && tid == 64) sh.sum_canon = fr_from_mont_outlined(close_claimed_sum(a.ca));   // multi_composed_sumcheck.rs:70
             for (uint32_t v = wave; v < meta.rec; v += PIPE_BLOCK / 64) {
                 Fr s = Fr::zero();
                 for (uint32_t b = lane; b < a.n_records_in; b += 256) {
@@ -643,7 +649,7 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(
     }
     // ---- the other workgroups: fold the tables (or take them as they are) and compute the forms of the round after the one being closed
     uint32_t* tile = reinterpret_cast<uint32_t*>(zk_dyn_lds);          // [slot][4 blocks][PIPE_TILE] field elements; slot 3 p + {0, 1, 2}
-    const uint32_t n_close = a.do_close ? 1u : 0u, wg = blockIdx.x - n_close, n_cross = gridDim.x - n_close;
+    const uint32_t n_close = a.do_close ? 1u : 0u, wg = blockIdx.x - n_close, n_cross = gridDim.x - n_close - n_outer;
     const size_t cn = a.cn, q = cn >> 2;
     Fr cm = Fr::zero();
     if (a.fold) {
@@ -675,6 +681,7 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(
 // They are laid out as forms beside round 1's hash, so round 2 starts two products behind it (composed_stage_close_kernel: a bind three
 // products deep, then the sums, then the round-by-round closing: 53 us for the two rounds; here ~35).
 static __global__ __launch_bounds__(PIPE_BLOCK) void composed_stage_close_pipe_kernel(const uint64_t* __restrict__ partials, StageArgs sa) {
+    if (sa.ca.outer.dev && blockIdx.x == gridDim.x - 1) { outer_absorb_rounds(sa.ca.outer, sa.ca.round, 2); return; }   // the hasher workgroup
     __shared__ CloseShared sh;
     __shared__ PipeShared ps;
     __shared__ Sha256State trs;
@@ -687,7 +694,7 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_stage_close_pipe_k
     if (ca.first != 1 && tid < sizeof(Sha256State) / 4)
         reinterpret_cast<uint32_t*>(&trs)[tid] = reinterpret_cast<const uint32_t*>(&ca.st->transcript)[tid];
     if (tid == 0) { ps.prev_valid = 0; ps.out_n = 0; }
-    if (ca.meta.multi && ca.first && tid == 64) sh.sum_canon = fr_from_mont_outlined(fr_from_arg(ca.sum));   // multi_composed_sumcheck.rs:70
+    if (ca.meta.multi && ca.first && tid == 64) sh.sum_canon = fr_from_mont_outlined(close_claimed_sum(ca));   // multi_composed_sumcheck.rs:70
     {   // the records: thread (value v, chunk) sums the records chunk, chunk + n_chunks, ... (eight loads in flight); the chunks are added in LDS
         const uint32_t n_chunks = PIPE_BLOCK / n_vals, v = tid % n_vals, chunk = tid / n_vals;
         Fr acc = Fr::zero();

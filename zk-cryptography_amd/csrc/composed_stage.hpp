@@ -259,6 +259,7 @@ struct StageArgs {
 };
 // Sums the workgroup (or rank) records and runs the two rounds.
 static __global__ __launch_bounds__(CST_BLOCK) void composed_stage_close_kernel(const uint64_t* __restrict__ partials, StageArgs sa) {
+    if (sa.ca.outer.dev && blockIdx.x == gridDim.x - 1) { outer_absorb_rounds(sa.ca.outer, sa.ca.round, 2); return; }   // the hasher workgroup
     __shared__ CloseShared sh;
     __shared__ Sha256State trs;
     __shared__ Fr vals[CMP_MAX_TERMS][CST_VALS];
@@ -312,7 +313,7 @@ static __global__ __launch_bounds__(CST_BLOCK) void composed_stage_close_kernel(
         sh.evals[ca.meta.rec_off[p] + e] = v;
     }
     __syncthreads();
-    close_round(sh, ca.meta, ca.st, ca.sum, &trs, ca.round, ca.first, ca.round_out, ca.challenges);
+    close_round(sh, ca, &trs, ca.round, ca.first);
     // ---- bind the first variable.  A lone wave pays ~0.9 us per product whatever the dependencies, so the bind is laid out THREE products
     // deep instead of seven: every lane converts the challenge for itself, lane (p, i, a, b) multiplies l_a(r1) l_b(r1) and then its one
     // entry of C (or L), and the four (two) partial products of a bound value are added from LDS.
@@ -357,7 +358,7 @@ static __global__ __launch_bounds__(CST_BLOCK) void composed_stage_close_kernel(
         sh.evals[ca.meta.rec_off[p] + e] = v;
     }
     __syncthreads();
-    close_round(sh, ca.meta, ca.st, ca.sum, &trs, ca.round + 1, 0u, ca.round_out, ca.challenges);
+    close_round(sh, ca, &trs, ca.round + 1, 0u);
     if (tid < 4) {
         const Fr r2 = fr_to_mont_outlined(sh.challenge_canon), r1v = r1m;
         const Fr one = Fr::one();

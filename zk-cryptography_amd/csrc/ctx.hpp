@@ -70,6 +70,7 @@ struct zkhip_ctx {
     void* ntt_state = nullptr;     // twiddle tables and pass plans of the transforms this context has run (ntt.hip); ntt_free releases them
     void (*ntt_free)(void*) = nullptr;
     void* d_aux = nullptr;      // second grow-only buffer for entry points that call others which own d_ws (kzg_open)
+    uint32_t outer_token = 0;   // sessions that feed an outer transcript (composed_kernels.hpp): a value no earlier session's flags hold
     size_t aux_bytes = 0;
     // pinned result buffers + events for commits whose host epilogue is deferred (msm_enqueue / msm_finish), and the side
     // streams on which MultilinearKZG::open runs its per-round commits next to each other

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -16,6 +17,7 @@
 #include "host_util.hpp"
 #include "host_fr.hpp"
 #include "mle_kernels.hpp"
+#include "outer_transcript.hpp"
 #include "shard.hpp"
 
 // ---- a layer's sumcheck in time linear in its width -------------------------------------------------------------
@@ -67,7 +69,9 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_rows_kernel(const u
                                                                   uint64_t* __restrict__ t1, uint64_t* __restrict__ t2,
                                                                   uint32_t row_stride = 1, uint32_t row_first = 0, uint64_t* __restrict__ v_shard = nullptr,
                                                                   const uint64_t* __restrict__ eq_b = nullptr, const uint64_t* __restrict__ eq_c = nullptr,
-                                                                  FrArg alpha_v = FrArg(), FrArg beta_v = FrArg(), uint64_t* __restrict__ wg_out = nullptr) {
+                                                                  FrArg alpha_v = FrArg(), FrArg beta_v = FrArg(), uint64_t* __restrict__ wg_out = nullptr,
+                                                                  const uint64_t* __restrict__ ab_dev = nullptr) {
+    // ab_dev (not null): alpha and beta lie in device memory (entries 0 and 1), where gkr_layer_finish_kernel left them
     // eq_b (phase 1 of a single-GPU proof, every gate visited exactly once): the gate weights are formed HERE from the previous layer's two
     // eq tables -- w_g = alpha eq_g(r_b) + beta eq_g(r_c), the tables that layer built for its own second phase and for w_c -- and
     // filed in wg_out for phase 2: no weight launches per layer
@@ -85,7 +89,8 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_rows_kernel(const u
         const uint32_t g = ids[q];
         Fr w;
         if (eq_b) {
-            w = fr_from_arg(alpha_v) * load_fr(eq_b, g) + fr_from_arg(beta_v) * load_fr(eq_c, g);
+            const Fr al = ab_dev ? load_fr(ab_dev, 0) : fr_from_arg(alpha_v), be = ab_dev ? load_fr(ab_dev, 1) : fr_from_arg(beta_v);
+            w = al * load_fr(eq_b, g) + be * load_fr(eq_c, g);
             store_fr(wg_out, g, w);
         } else {
             w = load_fr(wg, g);
@@ -206,6 +211,28 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_dot_finish_kernel(const 
     s = block_reduce_fr(s, red);
     if (threadIdx.x == 0) store_fr(out, 0, s);
 }
+// The end of a layer with the outer transcript on the device (composed_kernels.hpp "an OUTER transcript"): every round of the layer's
+// sumcheck has been absorbed by the hasher workgroups; alpha, beta = two challenges (protocol.rs:104-105), the next claim
+// alpha w_b + beta w_c (:107), all left in device memory for the next layer's first kernels -- no host round trip per layer.
+// next: alpha | beta | claimed (4 u64 each); evals: w_b | w_c.  One wave.
+static __global__ __launch_bounds__(64) void gkr_layer_finish_kernel(OuterDev* __restrict__ outer, const uint64_t* __restrict__ evals,
+                                                                     uint64_t* __restrict__ next, uint64_t* __restrict__ wb_out,
+                                                                     uint64_t* __restrict__ wc_out, uint64_t* __restrict__ sum_out) {
+    Transcript tr;
+    tr.load(&outer->state);
+    const Fr alpha = tr.challenge_fr(), beta = tr.challenge_fr();
+    const Fr wb = load_fr(evals, 0), wc = load_fr(evals, 1);
+    const Fr claimed = fr_mul_outlined(alpha, wb) + fr_mul_outlined(beta, wc);
+    if (threadIdx.x == 0) {
+        tr.store(&outer->state);
+        store_fr(next, 0, alpha);
+        store_fr(next, 1, beta);
+        store_fr(next, 2, claimed);
+        store_fr(wb_out, 0, wb);
+        store_fr(wc_out, 0, wc);
+        if (sum_out) store_fr(sum_out, 0, claimed);
+    }
+}
 // eq_x(u) for all x < 2^n_vars, u in device memory; with d_v also <eq(u), v> -> d_dot (one value), summed from the table
 // kernel's per-workgroup shares (d_partials: MLE_MAX_GRID entries of scratch)
 static void launch_eq_table(zkhip_ctx* c, const uint64_t* d_u, uint32_t n_vars, uint64_t* d_halves, uint64_t* d_out,
@@ -242,7 +269,7 @@ static void launch_gate_weights(zkhip_ctx* c, size_t n_gates, uint32_t n_gate_va
 }  // namespace zk
 
 int zk_multi_composed_enqueue(zkhip_ctx* c, const uint64_t* const* ptrs, const uint32_t* term_sizes, const uint64_t* const* lin_ptrs,
-                              uint32_t n_terms, size_t n, const uint64_t* h_sum, int cont, uint32_t out_base);   // composed.hip
+                              uint32_t n_terms, size_t n, const uint64_t* h_sum, int cont, uint32_t out_base, const ZkMcExtra* ex = nullptr);   // composed.hip
 int zk_multi_composed_collect(zkhip_ctx* c, uint32_t n_rounds, uint32_t* h_lens, uint64_t* h_round_polys, uint64_t* h_challenges);
 const uint64_t* zk_composed_challenges_dev(zkhip_ctx* c);
 
@@ -367,6 +394,75 @@ int layer_prove(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_
     return ZKHIP_OK;
 }
 
+
+// ---- the same layer with the OUTER transcript on the device: nothing here waits for the host --------------------------------------------
+// What a layer needs from the one before -- alpha, beta, the claimed sum -- lies in device memory (d_next: alpha | beta | claimed, left
+// by gkr_layer_finish_kernel; layer one takes them by value: 1, 0 and w_0(n_r)), its rounds are recorded in the proof arena instead of
+// the context's small buffer (ar_ch | ar_rp: the layer's slice), and every closing kernel feeds the outer transcript (ex.outer).
+struct DeviceTranscript {
+    zk::OuterDev* outer;
+    uint64_t* next;          // alpha | beta | claimed
+    uint64_t *sums, *wb, *wc;   // per layer, 4 u64 each
+    uint64_t* arena;         // per layer: challenges (4 x ZK_MAX_ROUNDS) | round polynomials (64 x ZK_MAX_ROUNDS)
+    static constexpr size_t LAYER_U64 = (size_t)(4 + 64) * ZK_MAX_ROUNDS;
+};
+int layer_enqueue_device(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_w, size_t w_len, const LayerScratch& sc,
+                         const DeviceTranscript& dt, const zkhost::Fr& claimed0, const zkhost::Fr& n_r, uint32_t stride) {
+    using namespace zk;
+    const size_t n_gates = ld.n_gates;
+    const uint32_t s = log2_exact(w_len);
+    const uint32_t n_gate_vars = l == 0 ? 1u : l;
+    const bool two_points = l > 0;
+    if (s != l + 1 || w_len != ld.w_len || 2 * s > stride || s < 1) return ZKHIP_ERR_SHAPE;
+    if (ld.bad_label) return ZKHIP_ERR_INDEX;
+    if (two_points && n_gates > ((size_t)1 << n_gate_vars)) return ZKHIP_ERR_SHAPE;      // (gate g has l index bits: zkhip_circuit_create flags anything else)
+    const unsigned gw = (unsigned)((w_len + MLE_BLOCK - 1) / MLE_BLOCK);
+    FrArg av = {}, bv = {};
+    if (!two_points) {
+        PtsArg pb = {}, pc = {};
+        std::memcpy(pb.v, n_r.l, 32);
+        const zkhost::Fr one = zkhost::fr_one();
+        std::memcpy(av.v, one.l, 32);
+        launch_gate_weights(c, n_gates, n_gate_vars, pb, pc, av, bv, false, sc.eqh, sc.wg);
+    }
+    hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr0, ld.csr0 + w_len + 1, ld.type, ld.in1, sc.wg, d_w,
+                       (uint32_t)w_len, 1u, sc.ha0, sc.ha1, sc.hm, (const uint64_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr,
+                       1u, 0u, (uint64_t*)nullptr, two_points ? (const uint64_t*)sc.equ : (const uint64_t*)nullptr, (const uint64_t*)sc.eqc, av, bv, sc.wg,
+                       two_points ? (const uint64_t*)dt.next : (const uint64_t*)nullptr);
+    ZK_HIP(c, hipGetLastError());
+    uint64_t* ar_ch = dt.arena + (size_t)l * DeviceTranscript::LAYER_U64;
+    uint64_t* ar_rp = ar_ch + 4 * (size_t)ZK_MAX_ROUNDS;
+    ZkMcExtra ex = {};
+    ex.d_sum = two_points ? dt.next + 8 : nullptr;
+    ex.outer = dt.outer;
+    ex.d_round_polys = ar_rp;
+    ex.d_challenges = ar_ch;
+    const uint32_t sizes[2] = {2, 2};
+    {
+        const uint64_t* tables[4] = {sc.ha0, d_w, sc.hm, d_w};          // [Ha0, V] + Ha1,  [Hm, V]
+        const uint64_t* lin[2] = {sc.ha1, nullptr};
+        ex.token = ++c->outer_token;
+        ZK_TRY(zk_multi_composed_enqueue(c, tables, sizes, lin, 2, w_len, two_points ? nullptr : claimed0.l, 0, 0, &ex));
+    }
+    // ---- rounds over c, b at u = the challenges just recorded (in the arena)
+    launch_eq_table(c, ar_ch, s, sc.eqh, sc.equ, d_w, sc.dot_partials, sc.evals);
+    hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr1, ld.csr1 + w_len + 1, ld.type, ld.in0, sc.wg, sc.equ,
+                       (uint32_t)w_len, 2u, sc.aa, (uint64_t*)nullptr, sc.am, d_w, (const uint64_t*)sc.evals, sc.t1, sc.t2);
+    ZK_HIP(c, hipGetLastError());
+    {
+        const uint64_t* tables[4] = {sc.aa, sc.t1, sc.am, sc.t2};
+        ex.d_sum = nullptr;
+        ex.token = ++c->outer_token;
+        ZK_TRY(zk_multi_composed_enqueue(c, tables, sizes, nullptr, 2, w_len, nullptr, 1, s, &ex));
+    }
+    launch_eq_table(c, ar_ch + 4 * (size_t)s, s, sc.eqh, sc.eqc, d_w, sc.dot_partials, sc.evals + 4);     // w_c = V(r_c); eq(r_c) stays for the next layer
+    // alpha, beta, the next claim; w_b, w_c and the next layer's claimed sum into the per-layer arrays
+    hipLaunchKernelGGL(gkr_layer_finish_kernel, dim3(1), dim3(64), 0, c->stream, dt.outer, (const uint64_t*)sc.evals, dt.next, dt.wb + 4 * (size_t)l,
+                       dt.wc + 4 * (size_t)l, dt.sums + 4 * (size_t)(l + 1));
+    ZK_HIP(c, hipGetLastError());
+    return ZKHIP_OK;
+}
+
 }  // namespace
 
 // ---- device-resident circuit ---------------------------------------------------------------------------------------
@@ -466,7 +562,10 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
     const size_t tb = al(32 * max_w);
     const size_t o_w0 = 0, o_tab = al(64), o_wg = o_tab + 9 * tb, o_dot = o_wg + al(32 * max_g), o_ev = o_dot + al(32 * (size_t)zk::MLE_MAX_GRID);
     const size_t o_eqh = o_ev + 256;
-    ZK_TRY(c->reserve_aux(o_eqh + 32 * 2 * (size_t)zk::GKR_EQ_HALVES));
+    // (+ the device transcript's block behind it, below: outer state, alpha | beta | claim, per-layer sums / w_b / w_c, the proof arena)
+    const size_t dt_bytes = al(sizeof(zk::OuterDev)) + 256 + al(32 * ((size_t)n_layers + 1)) + 2 * al(32 * (size_t)n_layers) +
+                            al(8 * (size_t)(4 + 64) * ZK_MAX_ROUNDS * n_layers);
+    ZK_TRY(c->reserve_aux(o_eqh + al(32 * 2 * (size_t)zk::GKR_EQ_HALVES) + dt_bytes));
     char* aux = (char*)c->d_aux;
     uint64_t* d_w0 = (uint64_t*)(aux + o_w0);
     LayerScratch sc;
@@ -505,6 +604,74 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
         claimed = zkhost::fr_sub(w, zkhost::fr_mul(n_r[0], w));
     }
 
+    // The outer transcript on the device (default): every layer is enqueued behind the one before, alpha / beta / the claims travel
+    // through device memory, the proof is read back ONCE.  ZKHIP_GKR_HOST_TRANSCRIPT=1 keeps the host transcript (one synchronisation
+    // per layer; same proof, for A/B runs); the pipelined closing kernels are what feed the device transcript, so ZKHIP_PIPE=0 does too.
+    static const bool host_transcript = [] {
+        const char* e = std::getenv("ZKHIP_GKR_HOST_TRANSCRIPT");
+        const char* p = std::getenv("ZKHIP_PIPE");
+        return (e && std::atoi(e) != 0) || (p && std::atoi(p) == 0);
+    }();
+    if (!host_transcript) {
+        const uint32_t stride = 2 * n_layers;
+        // device block behind the layer scratch: outer state | next | sums (n_layers + 1) | w_b | w_c | arena
+        const size_t o_outer = o_eqh + al(32 * 2 * (size_t)zk::GKR_EQ_HALVES), o_next = o_outer + al(sizeof(zk::OuterDev)), o_sums = o_next + 256;
+        const size_t o_wb = o_sums + al(32 * ((size_t)n_layers + 1)), o_wc = o_wb + al(32 * (size_t)n_layers), o_arena = o_wc + al(32 * (size_t)n_layers);
+        const size_t arena_bytes = 8 * DeviceTranscript::LAYER_U64 * n_layers;     // (all inside the reservation above: dt_bytes)
+        DeviceTranscript dt;
+        dt.outer = (zk::OuterDev*)(aux + o_outer);
+        dt.next = (uint64_t*)(aux + o_next);
+        dt.sums = (uint64_t*)(aux + o_sums);
+        dt.wb = (uint64_t*)(aux + o_wb);
+        dt.wc = (uint64_t*)(aux + o_wc);
+        dt.arena = (uint64_t*)(aux + o_arena);
+        // the outer transcript as the host leaves it after n_r: a fresh hasher that has absorbed the 32-byte digest
+        {
+            zk::Sha256State* hs = (zk::Sha256State*)c->pinned_u64(ZK_PIN_RES);
+            std::memset(hs, 0, sizeof(*hs));
+            std::memcpy(hs->h, tr.hasher.h, 32);
+            const uint32_t fill = (uint32_t)(tr.hasher.len % 64);
+            for (uint32_t i = 0; i < fill / 4; ++i)
+                hs->buf[i] = ((uint32_t)tr.hasher.buf[4 * i] << 24) | ((uint32_t)tr.hasher.buf[4 * i + 1] << 16) | ((uint32_t)tr.hasher.buf[4 * i + 2] << 8) | tr.hasher.buf[4 * i + 3];
+            hs->fill = fill;
+            hs->len = tr.hasher.len;
+            ZK_HIP(c, hipMemcpyAsync(&dt.outer->state, hs, sizeof(*hs), hipMemcpyHostToDevice, c->stream));
+            ZK_HIP(c, hipMemsetAsync(&dt.outer->error, 0, 4, c->stream));
+            ZK_HIP(c, hipMemcpyAsync(dt.sums, claimed.l, 32, hipMemcpyHostToDevice, c->stream));     // (pageable source: copied before the call returns)
+            ZK_HIP(c, hipStreamSynchronize(c->stream));                  // the pinned staging words are reused below
+        }
+        for (uint32_t li = 1; li <= n_layers; ++li)
+            ZK_TRY(layer_enqueue_device(c, cir->layers[li - 1], li - 1, h_layer_ptrs[li], h_layer_len[li], sc, dt, claimed, n_r[0], stride));
+        // ---- the whole proof back in one go
+        const size_t pin_bytes = arena_bytes + 32 * ((size_t)n_layers + 1) + 64 * (size_t)n_layers + 16;
+        ZK_TRY(c->reserve_msm_pin(0, pin_bytes));
+        char* pin = (char*)c->msm_pin[0];
+        ZK_HIP(c, hipMemcpyAsync(pin, dt.arena, arena_bytes, hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(c, hipMemcpyAsync(pin + arena_bytes, dt.sums, 32 * ((size_t)n_layers + 1), hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(c, hipMemcpyAsync(pin + arena_bytes + 32 * ((size_t)n_layers + 1), dt.wb, 32 * (size_t)n_layers, hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(c, hipMemcpyAsync(pin + arena_bytes + 32 * ((size_t)n_layers + 1) + 32 * (size_t)n_layers, dt.wc, 32 * (size_t)n_layers, hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(c, hipMemcpyAsync(pin + pin_bytes - 16, &dt.outer->error, 4, hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(c, hipStreamSynchronize(c->stream));
+        if (*(const uint32_t*)(pin + pin_bytes - 16) != 0) return ZKHIP_ERR_HIP;         // a hasher gave up waiting for a round (see OuterDev::error)
+        const uint64_t* h_arena = (const uint64_t*)pin;
+        for (uint32_t k = 0; k < n_layers; ++k) {
+            const uint32_t nv = 2 * (k + 1);
+            const uint64_t* ch = h_arena + (size_t)k * DeviceTranscript::LAYER_U64;
+            const uint64_t* rp = ch + 4 * (size_t)ZK_MAX_ROUNDS;
+            if (h_challenges) std::memcpy(h_challenges + (size_t)k * stride * 4, ch, 32 * (size_t)nv);
+            uint64_t* polys = h_round_polys + (size_t)k * stride * GKR_MONO * 8;
+            uint32_t* lens = h_round_poly_lens + (size_t)k * stride;
+            for (uint32_t r = 0; r < nv; ++r) {
+                lens[r] = (uint32_t)rp[64 * r];
+                std::memcpy(polys + (size_t)r * GKR_MONO * 8, &rp[64 * r + 8], GKR_MONO * 64);
+            }
+            h_n_rounds[k] = nv;
+        }
+        std::memcpy(h_sums, pin + arena_bytes, 32 * (size_t)n_layers);
+        std::memcpy(h_wb, pin + arena_bytes + 32 * ((size_t)n_layers + 1), 32 * (size_t)n_layers);
+        std::memcpy(h_wc, pin + arena_bytes + 32 * ((size_t)n_layers + 1) + 32 * (size_t)n_layers, 32 * (size_t)n_layers);
+        return ZKHIP_OK;
+    }
     zkhost::Fr alpha = zkhost::fr_one(), beta = zkhost::fr_zero();
     std::vector<zkhost::Fr> r_b, r_c;
     // layer one (gkr/src/utils.rs:12-56): the wiring of layer 0 with its gate variable fixed at n_r

@@ -8,6 +8,14 @@ static inline uint32_t log2_exact(size_t n) {
     return k;
 }
 static inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+// optional arguments of zk_multi_composed_enqueue (composed.hip; internal, used by gkr.hip): see there
+struct ZkMcExtra {
+    const uint64_t* d_sum;        // the claimed sum, in device memory
+    void* outer;                  // OuterDev* (composed_kernels.hpp): an outer transcript fed beside the rounds
+    uint32_t token;               // the value the rounds' flags are raised to
+    uint64_t* d_round_polys;      // 64 u64 per round, instead of the context's small buffer
+    uint64_t* d_challenges;       // 4 u64 per round
+};
 
 #ifdef __cplusplus
 #include <atomic>

@@ -462,6 +462,42 @@ extern "C" int zkhip_srs_level_tables(zkhip_ctx* c, const uint64_t* d_folded_xy,
     return ZKHIP_OK;
 }
 
+// Commits of at most MSM_SMALL_MAX scalars against a shifted-SRS table: the plane sums of msm_kernels.hpp "commits of a few thousand
+// points" -- two launches, one copy, a host epilogue of <= 20 doublings.  ZKHIP_MSM_SMALL=0 keeps the bucket pipeline (A/B runs).
+constexpr size_t MSM_SMALL_MAX = 4096;
+static int msm_commit_small(zkhip_ctx* c, const uint32_t* d_table, size_t stride, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n,
+                            uint64_t* h_out_xy, uint8_t* h_out_inf) {
+    const MsmLevelWidths lw = msm_table_widths(stride);
+    MsmSmallArgs a = {};
+    a.table = d_table; a.scalars = d_scalars; a.inf = d_inf;
+    a.n = (uint32_t)n; a.stride = (uint32_t)stride; a.W = lw.W; a.hi = lw.hi; a.n_hi = lw.n_hi;
+    a.planes = lw.hi;                                              // |digit| <= 2^(hi - 1): bits 0 .. hi - 1
+    const size_t pairs = n * lw.W, chunks = (pairs + 63) / 64;
+    a.n_slots = (uint32_t)std::max<size_t>(1, std::min<size_t>(chunks, 2048 / a.planes));     // ~2 waves per SIMD in all
+    const size_t part_bytes = (size_t)a.planes * a.n_slots * 256, terms_bytes = (size_t)a.planes * 192;
+    ZK_TRY(c->reserve_ws(part_bytes + 256 + terms_bytes));
+    a.partials = (uint32_t*)c->d_ws;
+    a.terms = (uint64_t*)((char*)c->d_ws + ((part_bytes + 255) & ~(size_t)255));
+    {
+        ProfScope ps(c, "msm_small", 128.0 * (double)n);
+        hipLaunchKernelGGL(msm_small_planes_kernel, dim3(a.n_slots, a.planes), dim3(64), 0, c->stream, a);
+        hipLaunchKernelGGL(msm_small_reduce_kernel, dim3(a.planes), dim3(64), 0, c->stream, a);
+    }
+    ZK_HIP(c, hipGetLastError());
+    ZK_TRY(c->reserve_msm_pin(0, terms_bytes));
+    ZK_HIP(c, hipMemcpyAsync(c->msm_pin[0], a.terms, terms_bytes, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<zkhost::Xyzz> pts(a.planes);
+    std::vector<uint32_t> exps(a.planes);
+    for (uint32_t t = 0; t < a.planes; ++t) {
+        std::memcpy(&pts[t], (const char*)c->msm_pin[0] + 192 * (size_t)t, 192);
+        exps[t] = t;
+    }
+    const zkhost::Xyzz res = zkhost::weighted_sum_pow2(pts, exps);
+    *h_out_inf = zkhost::xyzz_to_affine(res, h_out_xy) ? 0 : 1;
+    return ZKHIP_OK;
+}
+
 extern "C" int zkhip_kzg_commit_table(zkhip_ctx* c, const void* d_table, const uint8_t* d_points_inf, size_t n_points,
                                       const uint64_t* d_scalars, size_t n_scalars, int require_equal_len, uint64_t* h_out_xy,
                                       uint8_t* h_out_inf) {
@@ -473,6 +509,8 @@ extern "C" int zkhip_kzg_commit_table(zkhip_ctx* c, const void* d_table, const u
     if (!d_table || !d_scalars) return ZKHIP_ERR_ARG;
     if (n_points * msm_table_widths(n_points).W >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
+    static const bool small_on = [] { const char* e = std::getenv("ZKHIP_MSM_SMALL"); return !e || std::atoi(e) != 0; }();
+    if (small_on && n <= MSM_SMALL_MAX) return msm_commit_small(c, (const uint32_t*)d_table, n_points, d_points_inf, d_scalars, n, h_out_xy, h_out_inf);
     MsmProblems one = {};
     one.n = 1;
     one.off[1] = (uint32_t)n;

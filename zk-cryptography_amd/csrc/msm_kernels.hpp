@@ -597,6 +597,56 @@ static __global__ __launch_bounds__(64) void msm_rowcol_terms_kernel(const uint3
     }
 }
 
+// ---- commits of a few thousand points against the shifted-SRS table: no sort, no buckets ------------------------------------------
+// The bucket pipeline above is ~17 launches and, behind the accumulate pass, two reduction passes with chains of 16 + ~8 group
+// additions one after another: 0.65 ms for 2^8 points, 0.9 ms for 2^12, whatever the chip could do beside (a group addition is 10-14
+// Fq products in sequence on a lane: 11-17 us).  With the table every (point, window) pair is a point T[w n + i] of its own with a
+// signed digit d, and  sum d T = sum_t 2^t ( sum over the pairs whose |d| has bit t of +-T ):  one PLANE per digit bit, each a plain
+// sum.  msm_small_planes_kernel: one wave per (slot, plane) -- a lane adds the pairs of its stride whose digit has the bit (mixed
+// additions), the wave sums its lanes by a tree in registers; msm_small_reduce_kernel: one wave per plane sums the slots' partial
+// sums the same way and converts.  ~2 log2(64) + pairs-per-lane additions deep, two launches; the host epilogue is the weighted sum
+// of <= 20 plane sums (one doubling and one addition each).  Same group element, so the same affine commitment.
+struct MsmSmallArgs {
+    const uint32_t* table;       // [w * stride + i]: 2^(first bit of window w) * point i, affine, 28-bit limbs
+    const uint64_t* scalars;     // n, Montgomery
+    const uint8_t* inf;          // n flags or nullptr
+    uint32_t* partials;          // [plane * n_slots + slot], XYZZ
+    uint64_t* terms;             // [plane], XYZZ in the arkworks layout (4 x 48 B)
+    uint32_t n, stride, W, hi, n_hi, n_slots, planes;
+};
+static __global__ __launch_bounds__(64) void msm_small_planes_kernel(MsmSmallArgs a) {
+    const uint32_t slot = blockIdx.x, plane = blockIdx.y, lane = threadIdx.x;
+    const uint32_t pairs = a.n * a.W, lanes_total = a.n_slots * 64;
+    G1XyzzU acc = G1XyzzU::identity();
+    for (uint32_t p = slot * 64 + lane; p < pairs; p += lanes_total) {
+        const uint32_t w = p / a.n, i = p - w * a.n;
+        if (a.inf && a.inf[i]) continue;
+        DigitStream ds(load_fr(a.scalars, i).from_mont());
+        int32_t d = 0;
+        for (uint32_t v = 0; v <= w; ++v) d = ds.next(v < a.n_hi ? a.hi : a.hi - 1);
+        const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+        if ((mag >> plane) & 1u) g1u_madd(acc, load_affine_u(a.table, (size_t)w * a.stride + i), d < 0);
+    }
+    msm_wave_tree_sum(acc, 64);
+    if (lane == 0) store_xyzz_u(a.partials, (size_t)plane * a.n_slots + slot, acc);
+}
+static __global__ __launch_bounds__(64) void msm_small_reduce_kernel(MsmSmallArgs a) {
+    const uint32_t plane = blockIdx.x, lane = threadIdx.x;
+    G1XyzzU acc = G1XyzzU::identity();
+    for (uint32_t s = lane; s < a.n_slots; s += 64) {
+        const G1XyzzU v = load_xyzz_u(a.partials, (size_t)plane * a.n_slots + s);
+        g1u_add(acc, v);
+    }
+    msm_wave_tree_sum(acc, 64);
+    if (lane == 0) {
+        uint64_t* o = a.terms + 24 * (size_t)plane;
+        store_fq(o, fqu_to_ark(acc.x));
+        store_fq(o + 6, fqu_to_ark(acc.y));
+        store_fq(o + 12, fqu_to_ark(acc.zz));
+        store_fq(o + 18, fqu_to_ark(acc.zzz));
+    }
+}
+
 // ---- shifted-SRS table (zkhip_srs_precompute) -------------------------------------------------------------
 static __global__ __launch_bounds__(MSM_BLOCK) void msm_clear_inf_kernel(const uint8_t* __restrict__ inf, size_t n, uint32_t* __restrict__ table) {
     const size_t i = (size_t)blockIdx.x * MSM_BLOCK + threadIdx.x;

@@ -134,6 +134,16 @@ class TrustedSetup:
         self._check_caches()
         return getattr(self, "_table", None)
 
+    SMALL_SRS = 4096      # zkhip_kzg_commit_table's short path (no sort, no buckets) serves commits of at most this many scalars
+
+    def table_for(self, n_scalars):
+        """the table a commitment of n_scalars coefficients should use: a SMALL SRS builds its table on first use (a few ms, a few
+        MiB, once per SRS) -- the short commits of plonk-style callers then take two launches instead of the bucket pipeline"""
+        t = self.table
+        if t is None and 0 < n_scalars <= TrustedSetup.SMALL_SRS and 0 < len(self) <= TrustedSetup.SMALL_SRS:
+            t = self.precompute().table
+        return t
+
     def precompute(self):
         """Build (once) the shifted-SRS table 2^(first bit of window w) * point for the digit windows of a scalar (13 at 2^20): commitments then need
         13 instead of 16 bucket additions per point and one bucket reduction (zkhip_srs_precompute); 1.6 GiB at 2^20."""
@@ -282,7 +292,7 @@ class MultilinearKZG:
     def commitment(poly, srs):
         """MultilinearKZGInterface::commitment (multilinear_kzg.rs:33-48)"""
         assert isinstance(poly, Multilinear)
-        return _commit(srs.powers_of_tau_in_g1, srs.inf, len(srs), poly.evaluations, len(poly), True, srs.table)
+        return _commit(srs.powers_of_tau_in_g1, srs.inf, len(srs), poly.evaluations, len(poly), True, srs.table_for(len(poly)))
 
     @staticmethod
     def commitment_begin(poly, srs):
@@ -355,4 +365,4 @@ class UnivariateKZG:
         """UnivariateKZGInterface::commitment (univariate_kzg.rs:37-58): no length assert; a polynomial longer
         than the SRS indexes out of bounds (IndexError), exactly what the unregistered bench would hit."""
         assert isinstance(poly, DenseUnivariatePolynomial)
-        return _commit(srs.powers_of_tau_in_g1, srs.inf, len(srs), poly.coefficients, len(poly), False, srs.table)
+        return _commit(srs.powers_of_tau_in_g1, srs.inf, len(srs), poly.coefficients, len(poly), False, srs.table_for(len(poly)))
