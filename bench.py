@@ -278,13 +278,21 @@ def bench_evaluate(args, zk, N, poly, torch):
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
     moved = by / max(1, cnt)
     ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic = None
+    try:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "pmc_traffic.json")))
+        if files and args.log_n == 24:
+            traffic = json.load(open(files[-1])).get("multifold_eval", {}).get("hbm_bytes_per_launch")
+    except Exception:
+        traffic = None
     return {"workload": "evaluation of the 2^%d table at %d points (host call: the value comes back)" % (args.log_n, args.log_n),
             "value": round(n / wall, 1), "unit": "field-evals/s", "ms_per_evaluation": round(1e3 * wall, 4), "batches": _stats(ts, 1e3),
             "algorithmic_bytes": 96.0 * n, "algorithmic_gbs": round(96.0 * n / wall / 1e9, 1), "algorithmic_frac_of_hbm": round(96.0 * n / wall / 1e9 / HBM_PEAK_GBS, 4),
             "bytes_moved": moved, "moved_frac_of_hbm": round(moved / wall / 1e9 / HBM_PEAK_GBS, 4) if moved else None,
             "roofline": {"bound": "hbm", "kernel": "multifold_mfma_kernel<4, 4, true> (the pass; weights and the records' sum are two small launches beside it)",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "launches": cnt,
-                         "avg_launch_us": round(1e3 * ms / max(1, cnt), 2),
+                         "avg_launch_us": round(1e3 * ms / max(1, cnt), 2), "traffic": traffic,
                          "algorithmic_bytes_per_launch": "32 B x table entries read"}}
 
 
@@ -411,6 +419,18 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
                                        "tables_built_ms": round(1e3 * t_b, 1),
                                        "note": "the same opening against zkhip_srs_level_tables (TrustedSetup.precompute_open): same proof, checked"}
         plain_srs.invalidate()                                     # the 1.9 GiB go back before the next leg
+    # commits of short polynomials (the reference's kzg bench size 2^8, kzg/benches/multilinear_kzg_benchmark.rs:10-43; plonk's callers):
+    # an SRS of <= 2^12 points builds its table on first use and its commits take the short path (no sort, no buckets)
+    small = None
+    if world == 1:
+        small = {}
+        for lg in (8, 12):
+            s_srs = zk.TrustedSetup.setup(zk.Fr.synthetic(lg, SEED_SCALARS + 0x400 + lg))
+            s_poly = zk.Multilinear(_synthetic(zk, torch, 1 << lg, SEED_SCALARS + 0x410 + lg))
+            zk.MultilinearKZG.commitment(s_poly, s_srs)
+            ts_ = _timed(lambda: zk.MultilinearKZG.commitment(s_poly, s_srs), torch, reps=10)
+            small["2^%d" % lg] = {"ms_per_commit": round(1e3 * sorted(ts_)[len(ts_) // 2], 4), "batches": _stats(ts_, 1e3)}
+        small["note"] = "MultilinearKZG::commitment on a 2^8 / 2^12-point SRS (table built on first use): one plain sum per digit bit, two launches"
     # the same commitments without the table (16 instead of 13 bucket additions per point, 16 bucket reductions)
     com_plain = zk.MultilinearKZG.commitment(poly, plain_srs)
     t_plain = _timed(lambda: zk.MultilinearKZG.commitment(poly, plain_srs), torch, reps=steps)
@@ -431,6 +451,7 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
                          "windows": int(srs._table.numel()) // (128 * n),
                          "note": "2^(first bit of window w) * point for the digit windows of a scalar (13 of 20 / 19 bits at 2^20 points); depends on the SRS only, built once, not timed"},
            "pipelined": pipelined,
+           "small_commits": small,
            "extras": extras,
            "without_srs_table": {"value": round(float(n) * steps / dt_plain, 1), "unit": "points/s (this rank)",
                                  "ms_per_commit": round(1e3 * dt_plain / steps, 3)},
@@ -560,6 +581,8 @@ def bench_gkr(args, zk, N, D, rank, world, barrier, dist, torch, np):
     """GKRProtocol::prove (gkr/src/protocol.rs:21-117) on Circuit::random(depth) -- the reference's gkr bench shape at depth 8,
     BASELINE configs[3]'s width 2^20 at depth 20.  Replicas only: every rank proves its own circuit."""
     out = {"workload": "GKRProtocol::prove on Circuit::random(depth), evaluation resident in HBM, circuit resident (zkhip_circuit)",
+           "outer_transcript": "host (ZKHIP_GKR_HOST_TRANSCRIPT / ZKHIP_PIPE=0)" if (os.environ.get("ZKHIP_GKR_HOST_TRANSCRIPT", "0") not in ("", "0") or os.environ.get("ZKHIP_PIPE") == "0")
+                               else "device: a hasher workgroup beside every closing kernel, no host round trip per layer",
            "replicas": world, "ms_per_proof": {}}
     for depth in (8, 20):
         circuit = zk.Circuit.random(depth)
@@ -968,7 +991,7 @@ def main():
             src = os.path.relpath(files[-1], ROOT)
             traffic = pmc["multifold"]["hbm_bytes_per_launch"]
             traffic_all = {k: v.get("hbm_bytes_per_launch") for k, v in pmc.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
-            for short, needle in (("fine_sums", "fine_sums_kernel"), ("multifold", "multifold_mfma_kernel<4, 4>"), ("chunk_sums", "chunk_sums_kernel")):
+            for short, needle in (("fine_sums", "fine_sums_kernel"), ("chunk_sums", "chunk_sums_kernel")):
                 hits = [v for k, v in pmc.get("kernels", {}).items() if needle in k and "hbm_bytes_per_launch" in v]
                 if hits and short not in traffic_all:
                     traffic_all[short] = max(h["hbm_bytes_per_launch"] for h in hits)      # the 2^24-entry launch of the step
@@ -1087,6 +1110,7 @@ def main():
                 "msm_ms": g(msm, "ms_per_commit"), "msm_mpoints_s": round(g(msm, "value") / 1e6, 1) if g(msm, "value") else None,
                 "msm_alu_frac": g(msm, "roofline_alu", "frac"), "msm_inflight_ms": g(msm, "pipelined", "ms_per_commit"),
                 "msm_no_table_ms": g(msm, "without_srs_table", "ms_per_commit"),
+                "commit_2^8_ms": g(msm, "small_commits", "2^8", "ms_per_commit"), "commit_2^12_ms": g(msm, "small_commits", "2^12", "ms_per_commit"),
                 "open_ms": g(msm, "extras", "open", "ms_per_open"), "open_tables_ms": g(msm, "extras", "open_level_tables", "ms_per_open"),
                 "srs_setup_ms": g(msm, "extras", "srs_setup_ms"),
                 "ntt_ms": g(ntt, "ms_per_fft"), "intt_ms": g(ntt, "ms_per_ifft"), "multiply_ms": g(ntt, "ms_per_multiply"), "ntt_alu_frac": g(ntt, "roofline_alu", "frac"),

@@ -24,6 +24,13 @@ f=$(ls gpurun_out/$R/gkr20/*/*kernel_trace.csv | head -1); python3 tools/trace_g
 make -s -C zk-cryptography_amd/csrc libzkhip_diag.so > /dev/null 2>&1
 (echo "== MultiComposedSumcheckProver::prove_partial, 2 terms of 2 tables, 2^16 entries: per-round in-kernel stamps (us)"; timeout 120 python3 tools/diag_composed.py 16 multi 2>&1 | grep "^round"; echo "== ComposedSumcheck::prove, 2 tables, 2^22 entries"; timeout 120 python3 tools/diag_composed.py 22 2>&1 | grep "^round") > gpurun_out/$R/d_composed_round_stamps.txt
 timeout 300 ./tools/ab_pipe.sh > gpurun_out/$R/d_ab_pipe.txt 2>&1
+# round 5: evaluation as one pass, terms of 3-5 tables, short commits, the GKR outer transcript on the device
+timeout 100 python3 tools/timeline_any.py eval24 eval20 2>&1 | grep -v "amdgpu.ids" > gpurun_out/$R/b_evaluation_timeline.txt
+timeout 300 python3 tools/timeline_any.py k5_22 k5_20 m23_20 k3_20 k4_20 2>&1 | grep -v "amdgpu.ids" > gpurun_out/$R/d_k5_timelines.txt
+(echo "== ComposedSumcheck::prove, 5 tables, 2^20 entries: per-round in-kernel stamps (us)"; timeout 120 python3 tools/diag_composed.py 20 k5 2>&1 | grep "^round") > gpurun_out/$R/d_k5_round_stamps.txt
+(timeout 200 python3 tools/timeline_any.py commitT8 commitT10 commitT12 2>&1 | grep -v "amdgpu.ids"; echo "== ZKHIP_MSM_SMALL=0: the bucket pipeline on the same inputs"; ZKHIP_MSM_SMALL=0 timeout 200 python3 tools/timeline_any.py commitT8 commitT12 2>&1 | grep -v "amdgpu.ids") > gpurun_out/$R/e_small_commit_timelines.txt
+(for rep in 1 2; do for d in 8 20; do echo "depth $d, outer transcript on the device: $(timeout 100 python3 tools/gkr_run.py $d 2>&1 | grep 'ms per')"; echo "depth $d, outer transcript on the host:   $(ZKHIP_GKR_HOST_TRANSCRIPT=1 timeout 100 python3 tools/gkr_run.py $d 2>&1 | grep 'ms per')"; done; done) > gpurun_out/$R/d_ab_gkr_transcript.txt
+f=$(ls gpurun_out/$R/gkr20/*/*kernel_trace.csv | head -1); python3 tools/trace_seq.py $f 9.3 0 > gpurun_out/$R/d_gkr20_kernel_sequence.txt 2>&1
 timeout 400 bash tools/sweep_stage.sh > gpurun_out/$R/d_sweep_stage.txt 2>&1
 timeout 100 python3 tools/perf_fingerprint.py 2>&1 | grep " us" > gpurun_out/$R/e_srs_guard_cost.txt
 [ -x tools/ubench_fine ] && timeout 120 ./tools/ubench_fine > gpurun_out/$R/ubench_fine_gfx950.txt 2>&1

@@ -14,6 +14,7 @@ cp $R/b_prover_timeline.txt $R/c_proofs_in_flight_timeline.txt $P/
 cp $R/gkr20/runc/*kernel_stats.csv $P/d_gkr20_kernel_stats.csv
 cp $R/d_gkr20_trace_gaps.txt $R/d_composed_round_stamps.txt $R/d_ab_pipe.txt $P/
 [ -f $R/d_sweep_stage.txt ] && cp $R/d_sweep_stage.txt $P/
+for f in b_evaluation_timeline.txt d_k5_timelines.txt d_k5_round_stamps.txt e_small_commit_timelines.txt d_ab_gkr_transcript.txt d_gkr20_kernel_sequence.txt; do [ -f $R/$f ] && cp $R/$f $P/; done
 [ -f $R/e_srs_guard_cost.txt ] && cp $R/e_srs_guard_cost.txt $P/
 [ -f $R/ubench_fine_gfx950.txt ] && cp $R/ubench_fine_gfx950.txt $P/
 [ -f $R/ubench_batched_affine_gfx950.txt ] && cp $R/ubench_batched_affine_gfx950.txt $P/
