@@ -433,6 +433,46 @@ def test_commit_table_matches_plain_commit(zk, ora, log_n, kind):
         _same(zk, b, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), p_tau)))
 
 
+@pytest.mark.parametrize("n_points,n_scalars,kind", [
+    (1, 1, "uniform"), (2, 2, "uniform"), (8, 8, "zeros"), (8, 8, "minus_one"), (64, 64, "uniform"), (256, 256, "uniform"), (256, 256, "ones"),
+    (256, 100, "uniform"), (300, 300, "bytes"), (1024, 1024, "uniform"), (2048, 1000, "bits"), (4096, 4096, "uniform"), (4096, 4095, "minus_one"),
+    (4096, 1, "uniform")])
+def test_short_commits_cross_the_bucket_pipeline(zk, ora, n_points, n_scalars, kind):
+    """zkhip_kzg_commit_table's short path (<= 2^12 scalars: one plain sum per digit bit, csrc/msm.hip msm_commit_small) against the
+    bucket pipeline on the plain SRS (zkhip_kzg_commit: sort, buckets, reductions -- no table, no short path) on the same inputs:
+    univariate SRS with n_scalars <= n_points (the table's stride is the SRS size), a point at infinity in the SRS, scalars of every
+    kind; the naive oracle as a third opinion where it is quick."""
+    from zk_cryptography_amd import kzg as K
+    srs = zk.UnivariateKZG.generate_srs(zk.Fr.from_int(3 + n_points), n_points - 1)
+    assert len(srs) == n_points
+    if n_points >= 8:
+        srs.inf[5] = 1                                       # a point at infinity: both paths must skip it
+        srs.invalidate()
+    table = zk.TrustedSetup(srs.powers_of_tau_in_g1, srs.inf).precompute().table
+    rng = np.random.default_rng(n_points * 7 + n_scalars)
+    if kind == "uniform":
+        sc = ora.random_fr(n_scalars, 5100 + n_scalars)
+    elif kind == "zeros":
+        sc = zk.Fr.from_ints([0] * n_scalars)
+    elif kind == "ones":
+        sc = zk.Fr.from_ints([1] * n_scalars)
+    elif kind == "minus_one":
+        sc = zk.Fr.from_ints([R - 1] * n_scalars)
+    elif kind == "bits":
+        sc = zk.Fr.from_ints([int(v) for v in rng.integers(0, 2, n_scalars)])
+    else:
+        sc = zk.Fr.from_ints([int(v) for v in rng.integers(0, 256, n_scalars)])
+    d_sc = zk.DenseUnivariatePolynomial(sc).coefficients
+    short = K._commit(srs.powers_of_tau_in_g1, srs.inf, n_points, d_sc, n_scalars, False, table)
+    buckets = K._commit(srs.powers_of_tau_in_g1, srs.inf, n_points, d_sc, n_scalars, False, None)
+    assert short == buckets
+    if n_scalars <= 300:
+        jac = ora.kzg_univariate_srs_g1(zk.Fr.from_int(3 + n_points), n_points - 1).reshape(-1, 18).copy()
+        if n_points >= 8:
+            jac[5] = ora.g1_identity()
+        _same(zk, short, *_aff(ora, ora.kzg_commitment(sc, jac, False)))
+
+
 def test_commit_table_with_identity_points_and_short_polynomial(zk, ora):
     tau = zk.Fr.from_ints([0, 1, 2, 3])     # SRS with points at infinity (kzg benches' tau)
     plain = zk.TrustedSetup.setup(tau)

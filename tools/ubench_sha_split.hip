@@ -1,0 +1,80 @@
+// ubench_sha_split.hip -- SHA-256 state rounds on a lone wave: the 14-instruction round (sha256_rounds_block) against the
+// six-lane form (sha256_rounds_block_split, csrc/transcript.hpp), same chained blocks; digests compared, time per block.
+// Build: hipcc -O3 --offload-arch=gfx950 -I zk-cryptography_amd/csrc -o tools/ubench_sha_split tools/ubench_sha_split.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include "transcript.hpp"
+using namespace zk;
+
+template <bool SPLIT> __global__ void chain_kernel(const uint32_t* blocks, int n_blocks, int reps, uint32_t* out) {
+    __shared__ uint32_t kw[64 * 8];
+    // schedules of up to 8 blocks (all lanes compute the same; lane 0 writes)
+    for (int b = 0; b < n_blocks; ++b) sha256_schedule_block(blocks + 16 * b, kw + 64 * b);
+    __syncthreads();
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    if (SPLIT) {
+        ShaSplit sp;
+        sp.init();
+        uint32_t hs[4];
+        sp.split(h, hs);
+        for (int r = 0; r < reps; ++r)
+            for (int b = 0; b < n_blocks; ++b) sha256_rounds_block_split(sp, hs, kw + 64 * b);
+        sp.join(hs, h);
+    } else {
+        for (int r = 0; r < reps; ++r)
+            for (int b = 0; b < n_blocks; ++b) sha256_rounds_block(h, kw + 64 * b);
+    }
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) out[i] = h[i];
+}
+
+static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+static void host_compress(uint32_t h[8], const uint32_t* blk) {
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe,
+        0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7,
+        0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b,
+        0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+        0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i) w[i] = blk[i];
+    for (int i = 16; i < 64; ++i) w[i] = w[i - 16] + (rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] + (rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10));
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; ++i) {
+        uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+        uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+int main() {
+    const int nb = 4, reps = 2000;
+    uint32_t hb[16 * nb];
+    uint32_t x = 12345;
+    for (int i = 0; i < 16 * nb; ++i) { x = x * 1664525u + 1013904223u; hb[i] = x; }
+    uint32_t want[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    for (int r = 0; r < reps; ++r)
+        for (int b = 0; b < nb; ++b) host_compress(want, hb + 16 * b);
+    uint32_t *d_blk, *d_out;
+    hipMalloc(&d_blk, sizeof hb); hipMalloc(&d_out, 64);
+    hipMemcpy(d_blk, hb, sizeof hb, hipMemcpyHostToDevice);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    int bad = 0;
+    for (int split = 0; split < 2; ++split) {
+        for (int pass = 0; pass < 2; ++pass) {
+            hipEventRecord(a);
+            if (split) hipLaunchKernelGGL(chain_kernel<true>, dim3(1), dim3(64), 0, 0, d_blk, nb, reps, d_out);
+            else hipLaunchKernelGGL(chain_kernel<false>, dim3(1), dim3(64), 0, 0, d_blk, nb, reps, d_out);
+            hipEventRecord(b); hipEventSynchronize(b);
+        }
+        float ms = 0; hipEventElapsedTime(&ms, a, b);
+        uint32_t got[8]; hipMemcpy(got, d_out, 32, hipMemcpyDeviceToHost);
+        bool same = true;
+        for (int i = 0; i < 8; ++i) same = same && got[i] == want[i];
+        bad += !same;
+        std::printf("%-34s %7.3f us per block   digest %s\n", split ? "six-lane rounds (9 instr / round)" : "one-lane rounds (14 instr / round)", 1e3 * ms / (reps * nb), same ? "matches the host's" : "DIFFERS");
+    }
+    return bad;
+}

@@ -293,7 +293,12 @@ __device__ __noinline__ void outer_absorb_rounds(OuterPub op, uint32_t first_rou
         }
         __syncthreads();
         if (wave == 0) {
-            for (uint32_t b = 0; b < n; ++b) sha256_rounds_block(h, os.kw + 64 * b);
+            ShaSplit sp;
+            sp.init();
+            uint32_t hs[4];
+            sp.split(h, hs);
+            for (uint32_t b = 0; b < n; ++b) sha256_rounds_block_split(sp, hs, os.kw + 64 * b);
+            sp.join(hs, h);
             if (fill != 0 && n > 0 && tid < 8) os.buf[tid] = outer_stream_word(os.row, 16 * (n - 1) + 8 + tid);
         }
         len += 64ull * n;
@@ -474,11 +479,7 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const CloseArgs& ca
         const uint32_t n_blocks = sh.n_blocks;
         // block 0 chunk by chunk; the later blocks' schedules (1.8 us each, started together with block 0's) are complete when the
         // hash reaches them: one wait, then the plain rounds
-        sha256_compress_kw(h, sh.msg, sh.kw, &sh.kw_ready[0], 0u);
-        for (uint32_t b = 1; b < n_blocks; ++b) {
-            sha256_wait_flag(&sh.kw_ready[b], 4u);
-            sha256_rounds_block(h, sh.kw + 64 * b);
-        }
+        sha256_message_split(h, sh.msg, sh.kw, sh.kw_ready, n_blocks);
         ZK_STAMP_AT(0, round, 4);
         Fr c;                                                   // from_be_bytes_mod_order (fiat_shamir.rs:27-29)
 #pragma unroll

@@ -271,11 +271,7 @@ __device__ __forceinline__ void pipe_hash_wave(CloseShared& sh, Sha256State* tr_
         for (int i = 0; i < 8; ++i) h[i] = tr_state->h[i];
     }
     const uint32_t n_blocks = sh.n_blocks;
-    sha256_compress_kw(h, sh.msg, sh.kw, &sh.kw_ready[0], 0u);
-    for (uint32_t b = 1; b < n_blocks; ++b) {
-        sha256_wait_flag(&sh.kw_ready[b], 4u);
-        sha256_rounds_block(h, sh.kw + 64 * b);
-    }
+    sha256_message_split(h, sh.msg, sh.kw, sh.kw_ready, n_blocks);
     Fr c;                                                   // from_be_bytes_mod_order (fiat_shamir.rs:27-29)
 #pragma unroll
     for (int i = 0; i < 8; ++i) c.l[i] = h[7 - i];

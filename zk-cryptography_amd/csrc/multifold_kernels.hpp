@@ -311,9 +311,14 @@ static __global__ __launch_bounds__(SMALL_BLOCK) void sumcheck_small_kernel(Smal
             const uint32_t* pre = dig_sh + 8 * ((it + 1) & 1);
 #pragma unroll
             for (int i = 0; i < 8; ++i) { blk[i] = pre[i]; blk[8 + i] = lo.l[7 - i]; }
-            sha256_compress_kw(h, blk, kw1, flags, 4 * it);          // uni_poly.to_bytes()  sumcheck.rs:42
+            ShaSplit sp;                                              // the state rounds on six lanes (transcript.hpp)
+            sp.init();
+            uint32_t hs[4];
+            sp.split(h, hs);
+            sha256_compress_kw_split(sp, hs, blk, kw1, flags, 4 * it);          // uni_poly.to_bytes()  sumcheck.rs:42
             ZK_STAMP_AT(0, round, 1);
-            sha256_compress_kw(h, nullptr, kw2, flags + 1, 4 * it);  // challenge()  :46
+            sha256_compress_kw_split(sp, hs, nullptr, kw2, flags + 1, 4 * it);  // challenge()  :46
+            sp.join(hs, h);
             ZK_STAMP_AT(0, round, 2);
 #pragma unroll
             for (int i = 0; i < 8; ++i) digest[i] = h[i];

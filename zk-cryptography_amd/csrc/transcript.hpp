@@ -210,6 +210,137 @@ __device__ __forceinline__ void sha256_rounds_block(uint32_t (&h)[8], const uint
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
 
+// ---- state rounds on SIX lanes ------------------------------------------------------------------------------------
+// A lone wave pays for INSTRUCTIONS (4-6 cycles each whatever the dependencies), and a round above is 14 of them: six
+// rotates, two xor3, Ch, Maj, four additions.  Its two halves -- Sigma1(e) + Ch(e, f, g) + h + kw and Sigma0(a) + Maj(a, b, c) --
+// have the same shape, and the three rotates of a Sigma are one instruction with a per-lane amount.  So the state lives on
+// six lanes of every row of 16: lanes 0, 1, 2 hold (e, f, g, h) and rotate by 6, 11, 25; lanes 4, 5, 6 hold (a, b, c, d)
+// and rotate by 2, 13, 22.  One round:
+//     x  = rotr(R0, s)                                  one v_alignbit, the lane's own amount
+//     p  = R0 ^ (R2 & m)                                m = 0 on the e lanes, ~0 on the a lanes
+//     F  = p ? R1 : R2 (bitwise)                        Ch(e, f, g) on the e lanes; Ch(a ^ c, b, c) = Maj(a, b, c) on the a lanes
+//     Sg = x ^ x' ^ x''                                 two v_xor with a quad permutation (DPP): every lane of a triple gets the Sigma
+//     T  = Sg + F + q                                   q = h + kw on the e lanes (kept one round ahead), 0 on the a lanes
+//     e' = T + d (d from the lane four up), a' = T + T (T of the lane four down): two bank-masked DPP additions
+// = 9 instructions, ~41 cycles instead of ~74.  The DPP reads observe the two wait states the ISA asks for after a VALU write
+// of the register they read (x: p and F in between; T: the e-lane addition and the next q in between).
+struct ShaSplit {
+    uint32_t s, m;
+    __device__ __forceinline__ void init() {
+        const uint32_t l = threadIdx.x & 7;
+        const bool a_lane = (l & 4) != 0;
+        const uint32_t k = l & 3;
+        s = a_lane ? (k == 0 ? 2u : k == 1 ? 13u : 22u) : (k == 0 ? 6u : k == 1 ? 11u : 25u);
+        m = a_lane ? 0xFFFFFFFFu : 0u;
+    }
+    // h[0..7] (the same on every lane) -> R0..R3 of this lane's half
+    __device__ __forceinline__ void split(const uint32_t (&h)[8], uint32_t (&hs)[4]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hs[i] = m ? h[i] : h[4 + i];
+    }
+    __device__ __forceinline__ void join(const uint32_t (&hs)[4], uint32_t (&h)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h[i] = __builtin_amdgcn_readlane(hs[i], 4);
+            h[4 + i] = __builtin_amdgcn_readlane(hs[i], 0);
+        }
+    }
+};
+// One asm statement per 16 rounds (between separate statements the compiler puts an s_nop of its own).  R3 <- the new R0;
+// afterwards the roles are (R3, R0, R1, R2).  KWN: kw of the NEXT round (q runs one round ahead).
+#define ZK_SHA_SPLIT_RND_HEAD(R0, R1, R2, R3)                                                          \
+    "v_alignbit_b32 %[x], %[" #R0 "], %[" #R0 "], %[s]\n\t"                                            \
+    "v_bitop3_b32 %[p], %[" #R0 "], %[" #R2 "], %[m] bitop3:0x78\n\t"                                  \
+    "v_bitop3_b32 %[f], %[p], %[" #R1 "], %[" #R2 "] bitop3:0xca\n\t"                                  \
+    "v_xor_b32_dpp %[t], %[x], %[x] quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n\t"                \
+    "v_xor_b32_dpp %[t], %[x], %[t] quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n\t"                \
+    "v_add3_u32 %[f], %[t], %[f], %[q]\n\t"                                                            \
+    "v_add_u32_dpp %[" #R3 "], %[" #R3 "], %[f] row_shl:4 row_mask:0xf bank_mask:0x1\n\t"
+#define ZK_SHA_SPLIT_RND(R0, R1, R2, R3, KWN)                                                          \
+    ZK_SHA_SPLIT_RND_HEAD(R0, R1, R2, R3)                                                              \
+    "v_add_u32_dpp %[q], %[" #R2 "], %[" #KWN "] quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x1\n\t"   \
+    "v_add_u32_dpp %[" #R3 "], %[f], %[f] row_shr:4 row_mask:0xf bank_mask:0x2\n\t"
+// the last round of a chunk has no next kw at hand: a wait state in q's place
+#define ZK_SHA_SPLIT_RND_LAST(R0, R1, R2, R3)                                                          \
+    ZK_SHA_SPLIT_RND_HEAD(R0, R1, R2, R3)                                                              \
+    "s_nop 0\n\t"                                                                                      \
+    "v_add_u32_dpp %[" #R3 "], %[f], %[f] row_shr:4 row_mask:0xf bank_mask:0x2\n\t"
+// q of the chunk's first round: h + kw on the e lanes (bank 0 of every row); the a lanes keep their 0
+#define ZK_SHA_SPLIT_16ROUNDS(V)                                                                       \
+    asm volatile("s_nop 1\n\t"                                                                         \
+                 "v_add_u32_dpp %[q], %[r3], %[k0] quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x1\n\t" \
+                 ZK_SHA_SPLIT_RND(r0, r1, r2, r3, k1) ZK_SHA_SPLIT_RND(r3, r0, r1, r2, k2)             \
+                 ZK_SHA_SPLIT_RND(r2, r3, r0, r1, k3) ZK_SHA_SPLIT_RND(r1, r2, r3, r0, k4)             \
+                 ZK_SHA_SPLIT_RND(r0, r1, r2, r3, k5) ZK_SHA_SPLIT_RND(r3, r0, r1, r2, k6)             \
+                 ZK_SHA_SPLIT_RND(r2, r3, r0, r1, k7) ZK_SHA_SPLIT_RND(r1, r2, r3, r0, k8)             \
+                 ZK_SHA_SPLIT_RND(r0, r1, r2, r3, k9) ZK_SHA_SPLIT_RND(r3, r0, r1, r2, k10)            \
+                 ZK_SHA_SPLIT_RND(r2, r3, r0, r1, k11) ZK_SHA_SPLIT_RND(r1, r2, r3, r0, k12)           \
+                 ZK_SHA_SPLIT_RND(r0, r1, r2, r3, k13) ZK_SHA_SPLIT_RND(r3, r0, r1, r2, k14)           \
+                 ZK_SHA_SPLIT_RND(r2, r3, r0, r1, k15) ZK_SHA_SPLIT_RND_LAST(r1, r2, r3, r0)           \
+                 : [r0] "+v"(r0), [r1] "+v"(r1), [r2] "+v"(r2), [r3] "+v"(r3), [q] "+v"(q), [x] "=&v"(x_), [p] "=&v"(p_),  \
+                   [f] "=&v"(f_), [t] "=&v"(t_)                                                        \
+                 : [s] "v"(sp.s), [m] "v"(sp.m), [k0] "v"(V[0]), [k1] "v"(V[1]), [k2] "v"(V[2]), [k3] "v"(V[3]), [k4] "v"(V[4]),   \
+                   [k5] "v"(V[5]), [k6] "v"(V[6]), [k7] "v"(V[7]), [k8] "v"(V[8]), [k9] "v"(V[9]), [k10] "v"(V[10]),               \
+                   [k11] "v"(V[11]), [k12] "v"(V[12]), [k13] "v"(V[13]), [k14] "v"(V[14]), [k15] "v"(V[15]));
+// state rounds of one block on the split state hs (sha256_rounds_block's counterpart): every lane of the wave runs it.
+// The kw chunks are read one chunk ahead of the rounds that use them (two register sets, no copies).
+__device__ __forceinline__ void sha256_rounds_block_split(const ShaSplit& sp, uint32_t (&hs)[4], const uint32_t* __restrict__ kw) {
+    uint32_t r0 = hs[0], r1 = hs[1], r2 = hs[2], r3 = hs[3];
+    uint32_t q = 0, x_, p_, f_, t_;
+    uint32_t va[16], vb[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) va[j] = kw[j];
+#pragma unroll 1
+    for (int half = 0; half < 64; half += 32) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) vb[j] = kw[half + 16 + j];
+        ZK_SHA_SPLIT_16ROUNDS(va)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) va[j] = kw[((half + 32) & 63) + j];   // the second time round: chunk 0 again, unused
+        ZK_SHA_SPLIT_16ROUNDS(vb)
+    }
+    hs[0] += r0; hs[1] += r1; hs[2] += r2; hs[3] += r3;
+}
+// sha256_compress_kw's counterpart: rounds 0..15 from `blk` when given (else from kw chunk 0), 16..63 from the chunks as they arrive
+__device__ __forceinline__ void sha256_compress_kw_split(const ShaSplit& sp, uint32_t (&hs)[4], const uint32_t* blk /* 16 words or nullptr */,
+                                                      const uint32_t* __restrict__ kw, volatile uint32_t* flag, uint32_t flag_base) {
+    uint32_t r0 = hs[0], r1 = hs[1], r2 = hs[2], r3 = hs[3];
+    uint32_t q = 0, x_, p_, f_, t_;
+    uint32_t v[16];
+    if (blk) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = SHA256_K[j] + blk[j];
+    } else {
+        sha256_wait_flag(flag, flag_base + 1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = kw[j];
+    }
+    ZK_SHA_SPLIT_16ROUNDS(v)
+#pragma unroll 1
+    for (int base = 16; base < 64; base += 16) {
+        sha256_wait_flag(flag, flag_base + 1 + base / 16);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = kw[base + j];
+        ZK_SHA_SPLIT_16ROUNDS(v)
+    }
+    hs[0] += r0; hs[1] += r1; hs[2] += r2; hs[3] += r3;
+}
+// A whole padded message whose schedules other waves publish (block 0 chunk by chunk from its second chunk on, the later blocks
+// complete when the hash reaches them): the closing kernels' hash wave.  h: in the initial value / out the digest, on every lane.
+__device__ __forceinline__ void sha256_message_split(uint32_t (&h)[8], const uint32_t* msg, const uint32_t* kw, volatile uint32_t* kw_ready,
+                                                  uint32_t n_blocks) {
+    ShaSplit sp;
+    sp.init();
+    uint32_t hs[4];
+    sp.split(h, hs);
+    sha256_compress_kw_split(sp, hs, msg, kw, &kw_ready[0], 0u);
+    for (uint32_t b = 1; b < n_blocks; ++b) {
+        sha256_wait_flag(&kw_ready[b], 4u);
+        sha256_rounds_block_split(sp, hs, kw + 64 * b);
+    }
+    sp.join(hs, h);
+}
+
 // Out-of-line Montgomery product for the single-wave control paths (keeps those kernels small).
 __device__ __noinline__ Fr fr_mul_outlined(Fr a, Fr b) { return a * b; }   // by value: arguments travel in registers, not through scratch
 // Montgomery form -> canonical integer (into_bigint): the reduction half of a product only (x * 1 has no
