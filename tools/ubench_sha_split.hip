@@ -9,8 +9,17 @@ using namespace zk;
 
 template <bool SPLIT> __global__ void chain_kernel(const uint32_t* blocks, int n_blocks, int reps, uint32_t* out) {
     __shared__ uint32_t kw[64 * 8];
-    // schedules of up to 8 blocks (all lanes compute the same; lane 0 writes)
-    for (int b = 0; b < n_blocks; ++b) sha256_schedule_block(blocks + 16 * b, kw + 64 * b);
+    // schedules of up to 8 blocks: SPLIT: a block per row of 16 lanes (sha256_schedule_rows_to_lds); else one after another
+    if (SPLIT) {
+        for (int b0 = 0; b0 < n_blocks; b0 += 4) {
+            const int b = b0 + (threadIdx.x >> 4);
+            const bool active = b < n_blocks;
+            const int bb = active ? b : b0;
+            sha256_schedule_rows_to_lds(blocks[16 * bb + (threadIdx.x & 15)], kw + 64 * bb, nullptr, 0u, 0u, active);
+        }
+    } else {
+        for (int b = 0; b < n_blocks; ++b) sha256_schedule_block(blocks + 16 * b, kw + 64 * b);
+    }
     __syncthreads();
     uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
     if (SPLIT) {
@@ -25,6 +34,33 @@ template <bool SPLIT> __global__ void chain_kernel(const uint32_t* blocks, int n
         for (int r = 0; r < reps; ++r)
             for (int b = 0; b < n_blocks; ++b) sha256_rounds_block(h, kw + 64 * b);
     }
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) out[i] = h[i];
+}
+
+// the schedules alone: `reps` times the schedules of four blocks, serial (one block after another) or a block per row
+template <bool ROWS> __global__ void schedule_kernel(const uint32_t* blocks, int reps, uint32_t* out) {
+    __shared__ uint32_t kw[64 * 4];
+    uint32_t acc = 0;
+    for (int r = 0; r < reps; ++r) {
+        if (ROWS) sha256_schedule_rows_to_lds(blocks[threadIdx.x] + acc, kw + 64 * (threadIdx.x >> 4), nullptr, 0u, 0u, true);
+        else sha256_schedule_block(blocks, kw);
+        acc += kw[63];
+    }
+    if (threadIdx.x == 0) out[8] = acc;
+}
+
+// the closing kernels' hash wave as it is called there: sha256_message_split on four blocks whose schedules are complete
+__global__ void message_kernel(const uint32_t* blocks, int reps, uint32_t* out) {
+    __shared__ uint32_t kw[64 * 4];
+    __shared__ uint32_t msg[16 * 4];
+    __shared__ uint32_t ready[4];
+    sha256_schedule_rows_to_lds(blocks[threadIdx.x], kw + 64 * (threadIdx.x >> 4), nullptr, 0u, 0u, true);
+    msg[threadIdx.x] = blocks[threadIdx.x];
+    if (threadIdx.x < 4) ready[threadIdx.x] = 4;
+    __syncthreads();
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    for (int r = 0; r < reps; ++r) sha256_message_split(h, msg, kw, ready, 4);
     if (threadIdx.x == 0)
         for (int i = 0; i < 8; ++i) out[i] = h[i];
 }
@@ -75,6 +111,29 @@ int main() {
         for (int i = 0; i < 8; ++i) same = same && got[i] == want[i];
         bad += !same;
         std::printf("%-34s %7.3f us per block   digest %s\n", split ? "six-lane rounds (9 instr / round)" : "one-lane rounds (14 instr / round)", 1e3 * ms / (reps * nb), same ? "matches the host's" : "DIFFERS");
+    }
+    for (int rows = 0; rows < 2; ++rows) {
+        for (int pass = 0; pass < 2; ++pass) {
+            hipEventRecord(a);
+            if (rows) hipLaunchKernelGGL(schedule_kernel<true>, dim3(1), dim3(64), 0, 0, d_blk, reps, d_out);
+            else hipLaunchKernelGGL(schedule_kernel<false>, dim3(1), dim3(64), 0, 0, d_blk, reps, d_out);
+            hipEventRecord(b); hipEventSynchronize(b);
+        }
+        float ms = 0; hipEventElapsedTime(&ms, a, b);
+        std::printf("%-34s %7.3f us per call\n", rows ? "schedules of 4 blocks, one per row" : "schedule of 1 block, serial", 1e3 * ms / reps);
+    }
+    {
+        for (int pass = 0; pass < 2; ++pass) {
+            hipEventRecord(a);
+            hipLaunchKernelGGL(message_kernel, dim3(1), dim3(64), 0, 0, d_blk, reps, d_out);
+            hipEventRecord(b); hipEventSynchronize(b);
+        }
+        float ms = 0; hipEventElapsedTime(&ms, a, b);
+        uint32_t got[8]; hipMemcpy(got, d_out, 32, hipMemcpyDeviceToHost);
+        bool same = true;
+        for (int i = 0; i < 8; ++i) same = same && got[i] == want[i];
+        bad += !same;
+        std::printf("%-34s %7.3f us per message of 4 blocks   digest %s\n", "sha256_message_split", 1e3 * ms / reps, same ? "matches the host's" : "DIFFERS");
     }
     return bad;
 }

@@ -289,7 +289,12 @@ __device__ __noinline__ void outer_absorb_rounds(OuterPub op, uint32_t first_rou
         }
         __syncthreads();
         if (wave >= 1) {
-            for (uint32_t b = wave - 1; b < n; b += n_sched) sha256_schedule_block(os.msg + 16 * b, os.kw + 64 * b);
+            for (uint32_t b0 = 4 * (wave - 1); b0 < n; b0 += 4 * n_sched) {
+                const uint32_t b = b0 + ((tid >> 4) & 3);
+                const bool active = b < n;
+                const uint32_t bb = active ? b : b0;
+                sha256_schedule_rows_to_lds(os.msg[16 * bb + (tid & 15)], os.kw + 64 * bb, nullptr, 0u, 0u, active);
+            }
         }
         __syncthreads();
         if (wave == 0) {
@@ -462,11 +467,11 @@ __device__ __forceinline__ void close_round(CloseShared& sh, const CloseArgs& ca
     ZK_STAMP_AT(0, round, 3);
     if (tid >= 64) {
         const uint32_t wave = (tid >> 6) - 1, n_sched = (blockDim.x >> 6) - 1;
-        for (uint32_t b = wave; b < sh.n_blocks; b += n_sched) {
-            uint32_t w[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) w[j] = sh.msg[16 * b + j];
-            sha256_schedule_to_lds(w, sh.kw + 64 * b, &sh.kw_ready[b], 0u, b == 0 ? 1u : 0u);
+        for (uint32_t b0 = 4 * wave; b0 < sh.n_blocks; b0 += 4 * n_sched) {    // a block per row of 16 lanes (sha256_schedule_rows_to_lds)
+            const uint32_t b = b0 + ((tid >> 4) & 3);
+            const bool active = b < sh.n_blocks;
+            const uint32_t bb = active ? b : b0;
+            sha256_schedule_rows_to_lds(sh.msg[16 * bb + (tid & 15)], sh.kw + 64 * bb, &sh.kw_ready[bb], 0u, bb == 0 ? 1u : 0u, active);
         }
         if (wave == n_sched - 1) outer_publish(ca.outer, sh, round);      // the last wave: the one with the fewest schedules
         shadow(tid - 64, blockDim.x - 64);

@@ -288,11 +288,11 @@ __device__ __forceinline__ void pipe_hash_wave(CloseShared& sh, Sha256State* tr_
 // Waves 1..: the message schedules (one block per wave, round robin)
 __device__ __forceinline__ void pipe_schedules(CloseShared& sh) {
     const uint32_t wave = (threadIdx.x >> 6) - 1, n_sched = (blockDim.x >> 6) - 1;
-    for (uint32_t b = wave; b < sh.n_blocks; b += n_sched) {
-        uint32_t w[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) w[j] = sh.msg[16 * b + j];
-        sha256_schedule_to_lds(w, sh.kw + 64 * b, &sh.kw_ready[b], 0u, b == 0 ? 1u : 0u);
+    for (uint32_t b0 = 4 * wave; b0 < sh.n_blocks; b0 += 4 * n_sched) {    // a block per row of 16 lanes
+        const uint32_t b = b0 + ((threadIdx.x >> 4) & 3);
+        const bool active = b < sh.n_blocks;
+        const uint32_t bb = active ? b : b0;
+        sha256_schedule_rows_to_lds(sh.msg[16 * bb + (threadIdx.x & 15)], sh.kw + 64 * bb, &sh.kw_ready[bb], 0u, bb == 0 ? 1u : 0u, active);
     }
 }
 // Beside the hash (lanes of waves 1..): the Montgomery copies the caller reads back -- the round's items and the previous challenge
@@ -518,10 +518,18 @@ struct PipeTileTabs {
     const uint64_t* src[PIPE_GROUPS];
     uint64_t* dst[PIPE_GROUPS];
 };
+__device__ __forceinline__ Fr pipe_challenge_mont(const ComposedDev* st, uint32_t round) {      // the challenge of `round`, Montgomery form
+    Fr c;
+#pragma unroll
+    for (int i = 0; i < Fr::N; ++i) c.l[i] = reinterpret_cast<const uint32_t*>(st->last_canon[round & 1])[i];
+    return fr_to_mont_outlined(c);
+}
 // One tile of PIPE_TILE indices j: the tile's 4 quarter-block entries of every table into LDS -- folded by cm on the way in and written to
 // dst (fold) -- then the products of the next round's forms, accumulated into ps.raw.  Every thread of the workgroup calls.
-__device__ __forceinline__ void pipe_cross_tile(const PipeTileTabs& tb, uint32_t n_terms, size_t cn, bool fold, const Fr& cm, size_t tile_i,
-                                                uint32_t* tile, PipeShared& ps) {
+// cm_src != nullptr: cm is still to be fetched (the challenge of round cm_round, canonical in the context) -- it is, AFTER the tile's loads
+// are issued: the loads do not depend on it, and its own load and conversion run in their shadow (~1 us per launch).
+__device__ __forceinline__ void pipe_cross_tile(const PipeTileTabs& tb, uint32_t n_terms, size_t cn, bool fold, Fr& cm, const ComposedDev*& cm_src,
+                                                uint32_t cm_round, size_t tile_i, uint32_t* tile, PipeShared& ps) {
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t n_slots = 3 * n_terms, n_groups = 3 * n_terms;
     const size_t q = cn >> 2, j0 = tile_i * PIPE_TILE;
@@ -546,6 +554,7 @@ __device__ __forceinline__ void pipe_cross_tile(const PipeTileTabs& tb, uint32_t
                 if (fold) hi[k] = load_fr(src, x + cn);
             }
         }
+        if (cm_src) { cm = pipe_challenge_mont(cm_src, cm_round); cm_src = nullptr; }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const uint32_t u = u0 + k * PIPE_BLOCK;
@@ -592,12 +601,6 @@ __device__ __forceinline__ void pipe_write_record(const PipeShared& ps, uint32_t
         for (int i = 0; i < Fr::N; ++i) k.l[i] = l == 0 ? (i == 0 ? 1u : 0u) : l == 1 ? FrParams::r1(i) : FrParams::r2(i);
         store_fr(records, slot * 3 * n_groups + tid, fr_mul_outlined(val, k));
     }
-}
-__device__ __forceinline__ Fr pipe_challenge_mont(const ComposedDev* st, uint32_t round) {      // the challenge of `round`, Montgomery form
-    Fr c;
-#pragma unroll
-    for (int i = 0; i < Fr::N; ++i) c.l[i] = reinterpret_cast<const uint32_t*>(st->last_canon[round & 1])[i];
-    return fr_to_mont_outlined(c);
 }
 
 static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(PipeRoundArgs a) {
@@ -648,10 +651,7 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(
     const uint32_t n_close = a.do_close ? 1u : 0u, wg = blockIdx.x - n_close, n_cross = gridDim.x - n_close - n_outer;
     const size_t cn = a.cn, q = cn >> 2;
     Fr cm = Fr::zero();
-    if (a.fold) {
-        cm = pipe_challenge_mont(a.ca.st, a.ca.round - 1);
-        if (wg == 0 && tid == 0) store_fr(a.ca.challenges, a.fold_round, cm);           // whoever folds by a challenge files its Montgomery form
-    }
+    const ComposedDev* cm_src = a.fold ? a.ca.st : nullptr;            // fetched inside the first tile, behind its loads
     if (tid < n_groups * 5) (&ps.raw[0][0])[tid] = Fr::zero();
     __shared__ PipeTileTabs tb;                                        // (indexed by slot at run time: LDS, not registers)
     if (tid < PIPE_GROUPS) {
@@ -662,7 +662,12 @@ static __global__ __launch_bounds__(PIPE_BLOCK) void composed_pipe_round_kernel(
     }
     const size_t n_tiles = (q + PIPE_TILE - 1) / PIPE_TILE;
     if (wg == 0) ZK_STAMP_AT(0, 32 + (a.ca.round & 31), 1);
-    for (size_t tile_i = wg; tile_i < n_tiles; tile_i += n_cross) pipe_cross_tile(tb, meta.n_terms, cn, a.fold != 0, cm, tile_i, tile, ps);
+    for (size_t tile_i = wg; tile_i < n_tiles; tile_i += n_cross)
+        pipe_cross_tile(tb, meta.n_terms, cn, a.fold != 0, cm, cm_src, a.ca.round - 1, tile_i, tile, ps);
+    if (a.fold && wg == 0 && tid == 0) {                                // whoever folds by a challenge files its Montgomery form
+        if (cm_src) cm = pipe_challenge_mont(cm_src, a.ca.round - 1);
+        store_fr(a.ca.challenges, a.fold_round, cm);
+    }
     __syncthreads();
     if (wg == 0) ZK_STAMP_AT(0, 32 + (a.ca.round & 31), 2);
     pipe_write_record(ps, n_groups, a.records_out, wg);

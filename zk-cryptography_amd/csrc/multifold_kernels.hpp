@@ -276,26 +276,26 @@ static __global__ __launch_bounds__(SMALL_BLOCK) void sumcheck_small_kernel(Smal
     uint32_t depth = a.log_n, round = a.round0, n_w = 1;
     ZK_STAMP_AT(0, 40 + a.round0, 1);                   // prologue done
     // schedules of round 0 (waves 1 and 2)
+    // (a word per lane: lane i of every row holds word i of the block -- sha256_schedule_rows_to_lds)
+    const uint32_t word = threadIdx.x & 15;
     auto schedule_block1 = [&](const uint32_t* prefix, const Fr& lo_c, uint32_t it) {
-        uint32_t w[16];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { w[i] = prefix[i]; w[8 + i] = lo_c.l[7 - i]; }
-        sha256_schedule_to_lds(w, kw1, flags, 4 * it, 1);
+        const uint32_t w = word < 8 ? prefix[word] : fr_limb_by_lane(lo_c, 15 - word);
+        sha256_schedule_rows_to_lds(w, kw1, flags, 4 * it, 1, threadIdx.x < 64 + 16);
     };
     auto schedule_block2 = [&](const Fr& hi_c, uint32_t it) {
-        uint32_t w[16];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { w[i] = hi_c.l[7 - i]; w[8 + i] = 0; }
-        w[8] = 0x80000000u;
-        w[15] = 96 * 8;
-        sha256_schedule_to_lds(w, kw2, flags + 1, 4 * it, 0);
+        const uint32_t w = word < 8 ? fr_limb_by_lane(hi_c, 7 - word) : (word == 8 ? 0x80000000u : word == 15 ? 96u * 8u : 0u);
+        sha256_schedule_rows_to_lds(w, kw2, flags + 1, 4 * it, 0, threadIdx.x < 128 + 16);
     };
     if (a.n_rounds) {
         if (wave == 1) schedule_block1(dig_sh + 8, lo, 0);
         if (wave == 2) schedule_block2(hi, 0);
     }
     uint32_t digest[8];
-    constexpr uint32_t FIRST_HELPER = 192, N_HELPERS = SMALL_BLOCK - FIRST_HELPER;
+    // Waves 3, 5, 6, 7 fold the trees and the weights.  Wave 4 sits on the transcript wave's SIMD (waves go round the four SIMDs),
+    // where every instruction it issues is one the hash waits for: it only records the round's outputs, which nobody in this
+    // kernel reads, and at the lowest priority.
+    constexpr uint32_t FIRST_HELPER = 192, N_HELPERS = SMALL_BLOCK - FIRST_HELPER - 64, OUT_WAVE = 4;
+    if (wave == OUT_WAVE) __builtin_amdgcn_s_setprio(0);
     for (uint32_t it = 0; it < a.n_rounds; ++it) {
         Fr* told = (it & 1) ? tree1 : tree0;
         Fr* tnew = (it & 1) ? tree0 : tree1;
@@ -357,8 +357,8 @@ static __global__ __launch_bounds__(SMALL_BLOCK) void sumcheck_small_kernel(Smal
             }
         } else {
             const Fr r = fr_to_mont_outlined(c);       // every helper wave converts for itself (no extra sync)
-            const uint32_t helper = threadIdx.x - FIRST_HELPER;
-            if (helper == 0) {   // outputs of this round, in Montgomery form as the reference holds them
+            const uint32_t helper = wave == OUT_WAVE ? N_HELPERS : wave < OUT_WAVE ? threadIdx.x - FIRST_HELPER : threadIdx.x - FIRST_HELPER - 64;
+            if (threadIdx.x == 64 * OUT_WAVE) {   // outputs of this round, in Montgomery form as the reference holds them
                 Fr lo_m = told[2].to_mont(), hi_m = told[3].to_mont();
                 if (absorb_sum) {
                     Fr sum_m = (a.first == 2) ? fr_from_arg(a.claimed) : (a.first == 3) ? load_fr(a.d_claimed, 0) : lo_m + hi_m;
@@ -375,7 +375,7 @@ static __global__ __launch_bounds__(SMALL_BLOCK) void sumcheck_small_kernel(Smal
                 }
             }
             const uint32_t nodes = 1u << (depth - 1);   // the new tree has nodes 1 .. 2*nodes - 1
-            if (helper >= N_HELPERS - 2 && depth >= 3) {
+            if (helper >= N_HELPERS - 2 && helper < N_HELPERS && depth >= 3) {
                 // the last two lanes of the last helper wave: new level 2 pair (q, q+2) and the product wave 0 will need next round
                 const uint32_t q = 4 + (helper - (N_HELPERS - 2));
                 Fr va = told[q + 4] + r * (told[q + 8] - told[q + 4]);           // new[q],   p = 4
@@ -384,13 +384,13 @@ static __global__ __launch_bounds__(SMALL_BLOCK) void sumcheck_small_kernel(Smal
                 tnew[q + 2] = vb;
                 enew[helper - (N_HELPERS - 2)] = (vb - va).to_mont();
             }
-            for (uint32_t q = 1 + helper; q < 2 * nodes; q += N_HELPERS) {
+            for (uint32_t q = 1 + helper; q < 2 * nodes && helper < N_HELPERS; q += N_HELPERS) {
                 if (depth >= 3 && q >= 4 && q < 8) continue;                     // done above
                 const uint32_t p = 1u << (31 - __builtin_clz(q));
                 tnew[q] = told[q + p] + r * (told[q + 2 * p] - told[q + p]);
             }
             if (a.weights_out) {   // eq weights: the index gains the new variable as its least significant bit
-                for (uint32_t b = helper; b < n_w; b += N_HELPERS) {
+                for (uint32_t b = helper; b < n_w && helper < N_HELPERS; b += N_HELPERS) {
                     Fr w1v = wold[b] * r;
                     wnew[2 * b + 1] = w1v;
                     wnew[2 * b] = wold[b] - w1v;

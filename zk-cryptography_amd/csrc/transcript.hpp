@@ -210,6 +210,67 @@ __device__ __forceinline__ void sha256_rounds_block(uint32_t (&h)[8], const uint
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
 
+// ---- message schedule on the sixteen lanes of a row -------------------------------------------------------------
+// The serial forms above spend ~12 instructions per schedule word on a wave that pays per instruction: 1.75 us per block, more
+// than the six-lane state rounds below need for it.  Here lane i of a row of 16 holds word i of a chunk of 16, and
+//     w[t] = w[t-16] + s0(w[t-15]) + w[t-7] + s1(w[t-2])
+// is evaluated for the whole chunk at once: the terms that come from the previous chunk (w[t-16]; s0(w[t-15]) for i < 15; w[t-7] for
+// i < 7; s1(w[t-2]) for i < 2) with three DPP additions, the others by iteration -- after step k lanes 0 .. 2k+1 hold their final
+// words (s1 reaches two lanes back, w[t-7] seven: both are final by then), so seven steps of six instructions finish the chunk;
+// lane 15's s0(w[t-15]) is s0 of the new chunk's word 0, final after the first step and added once.  ~65 instructions per chunk
+// instead of ~200, and the four rows of a wave take four blocks side by side.
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_row0(uint32_t v) {     // lanes without a source read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+// c.l[j] with a per-lane j in 0..7 (a message word of this lane out of an element every lane holds)
+__device__ __forceinline__ uint32_t fr_limb_by_lane(const Fr& c, uint32_t j) {
+    uint32_t v = c.l[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v = (j == (uint32_t)k) ? c.l[k] : v;
+    return v;
+}
+__device__ __forceinline__ uint32_t sha_s0(uint32_t x) { return xor3(rotr32(x, 7), rotr32(x, 18), x >> 3); }
+__device__ __forceinline__ uint32_t sha_s1(uint32_t x) { return xor3(rotr32(x, 17), rotr32(x, 19), x >> 10); }
+// w: this lane's word of the previous chunk -> its word of the next one.  Every lane of the wave runs it (rows are independent).
+__device__ __forceinline__ uint32_t sha256_schedule_chunk_rows(uint32_t wp) {
+    constexpr int SHL = 0x100, SHR = 0x110, ROR = 0x120;
+    const uint32_t lane15 = ((threadIdx.x & 15) == 15) ? 0xFFFFFFFFu : 0u;
+    uint32_t base = wp + dpp_row0<SHL + 1>(sha_s0(wp));
+    base += dpp_row0<SHL + 9>(wp);
+    base += dpp_row0<SHL + 14>(sha_s1(wp));
+    uint32_t w2 = 0, w1 = base;                        // steps k - 2 and k - 1 (step 0 is `base` itself: lanes 0, 1 final)
+    base += dpp_row0<ROR + 15>(sha_s0(w1)) & lane15;   // lane 15 reads lane 0
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const uint32_t t = base + dpp_row0<SHR + 7>(w2);
+        const uint32_t w0 = t + dpp_row0<SHR + 2>(sha_s1(w1));
+        w2 = w1;
+        w1 = w0;
+    }
+    return w1;
+}
+// The schedule of this row's block, published chunk by chunk like sha256_schedule_to_lds: `w` is lane i's message word i (rows of a
+// wave: up to four blocks), kw / flag this row's (flag == nullptr: no counter, the caller synchronises); rows with active == false
+// compute along and publish nothing.
+__device__ __forceinline__ void sha256_schedule_rows_to_lds(uint32_t w, uint32_t* __restrict__ kw, volatile uint32_t* flag, uint32_t flag_base,
+                                                         uint32_t first_chunk, bool active) {
+    const uint32_t i = threadIdx.x & 15;
+    if (first_chunk == 0 && active) {
+        kw[i] = SHA256_K[i] + w;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the data before the counter
+        if (flag && i == 0) *flag = flag_base + 1;
+    }
+#pragma unroll 1
+    for (int base = 16; base < 64; base += 16) {
+        w = sha256_schedule_chunk_rows(w);
+        if (active) {
+            kw[base + i] = SHA256_K[base + i] + w;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (flag && i == 0) *flag = flag_base + 1 + base / 16;
+        }
+    }
+}
+
 // ---- state rounds on SIX lanes ------------------------------------------------------------------------------------
 // A lone wave pays for INSTRUCTIONS (4-6 cycles each whatever the dependencies), and a round above is 14 of them: six
 // rotates, two xor3, Ch, Maj, four additions.  Its two halves -- Sigma1(e) + Ch(e, f, g) + h + kw and Sigma0(a) + Maj(a, b, c) --
@@ -301,28 +362,31 @@ __device__ __forceinline__ void sha256_rounds_block_split(const ShaSplit& sp, ui
     }
     hs[0] += r0; hs[1] += r1; hs[2] += r2; hs[3] += r3;
 }
-// sha256_compress_kw's counterpart: rounds 0..15 from `blk` when given (else from kw chunk 0), 16..63 from the chunks as they arrive
+// sha256_compress_kw's counterpart.  With `blk`: rounds 0..15 from the message words while the schedule wave works (a chunk of
+// it takes 0.2 us, sixteen rounds 0.3), chunk 1 when its counter says so, chunks 2 and 3 together (they are ready by then: one
+// wait, one load latency).  Without: the whole schedule was published before the hash came here -- one wait, then the plain rounds.
 __device__ __forceinline__ void sha256_compress_kw_split(const ShaSplit& sp, uint32_t (&hs)[4], const uint32_t* blk /* 16 words or nullptr */,
                                                       const uint32_t* __restrict__ kw, volatile uint32_t* flag, uint32_t flag_base) {
+    if (!blk) {
+        sha256_wait_flag(flag, flag_base + 4);
+        sha256_rounds_block_split(sp, hs, kw);
+        return;
+    }
     uint32_t r0 = hs[0], r1 = hs[1], r2 = hs[2], r3 = hs[3];
     uint32_t q = 0, x_, p_, f_, t_;
-    uint32_t v[16];
-    if (blk) {
+    uint32_t va[16], vb[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = SHA256_K[j] + blk[j];
-    } else {
-        sha256_wait_flag(flag, flag_base + 1);
+    for (int j = 0; j < 16; ++j) va[j] = SHA256_K[j] + blk[j];
+    ZK_SHA_SPLIT_16ROUNDS(va)
+    sha256_wait_flag(flag, flag_base + 2);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = kw[j];
-    }
-    ZK_SHA_SPLIT_16ROUNDS(v)
-#pragma unroll 1
-    for (int base = 16; base < 64; base += 16) {
-        sha256_wait_flag(flag, flag_base + 1 + base / 16);
+    for (int j = 0; j < 16; ++j) va[j] = kw[16 + j];
+    ZK_SHA_SPLIT_16ROUNDS(va)
+    sha256_wait_flag(flag, flag_base + 4);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = kw[base + j];
-        ZK_SHA_SPLIT_16ROUNDS(v)
-    }
+    for (int j = 0; j < 16; ++j) { va[j] = kw[32 + j]; vb[j] = kw[48 + j]; }
+    ZK_SHA_SPLIT_16ROUNDS(va)
+    ZK_SHA_SPLIT_16ROUNDS(vb)
     hs[0] += r0; hs[1] += r1; hs[2] += r2; hs[3] += r3;
 }
 // A whole padded message whose schedules other waves publish (block 0 chunk by chunk from its second chunk on, the later blocks
