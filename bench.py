@@ -441,6 +441,9 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
     zk.MultilinearKZG.commitment(poly, srs)
     ms, cnt, by = _profile(N, ctx, b"msm_accumulate")
     N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
+    short_path = ms <= 0.0          # at most 2^12 scalars per rank (dry runs): zkhip_kzg_commit_table's short path, no accumulate pass to price
+    if short_path:
+        ms, by = float("nan"), 0
     out = {"metric": "MSM points/s (KZG commit, 2^%d-point SRS per GPU)" % log_n,
            "value": round(float(n) * world * steps / dt, 1), "unit": "points/s", "ms_per_commit": round(1e3 * dt / steps, 3),
            "steps": steps, "batches": _stats([b_ / steps for b_ in commit_batches], 1e3, 3),
@@ -467,7 +470,11 @@ def bench_msm(args, zk, N, rank, world, barrier, dist, torch, np):
     windows = int(srs._table.numel()) // (128 * n)                      # 13 at 2^20 points (zkhip_srs_table_bytes)
     mads = 4060.0 * windows * n * (1.0 - 2.0 ** -19)
     peak_tmads = 1024 * 64 / 4.9 * 2.4e9 / 1e12
-    out["roofline_alu"] = {"bound": "valu", "kernel": "msm_accumulate_kernel", "achieved": round(mads / (ms * 1e-3) / 1e12, 2),
+    if short_path:
+        out["roofline"] = out["roofline_alu"] = None
+        out["note_short_path"] = "commits of at most 2^12 scalars take the short path (no bucket accumulation): no accumulate-pass roofline at this size"
+    else:
+      out["roofline_alu"] = {"bound": "valu", "kernel": "msm_accumulate_kernel", "achieved": round(mads / (ms * 1e-3) / 1e12, 2),
                            "peak": round(peak_tmads, 2), "unit": "T v_mad_u64_u32 lane-ops/s",
                            "frac": round(mads / (ms * 1e-3) / 1e12 / peak_tmads, 4),
                            "ops_per_launch": "4060 multiply-adds x %d windows x points" % windows}
