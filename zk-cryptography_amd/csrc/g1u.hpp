@@ -122,4 +122,58 @@ __device__ __forceinline__ void g1u_add(G1XyzzU& acc, const G1XyzzU& q) {
     acc.x = x3; acc.y = y3; acc.zz = zz3; acc.zzz = zzz3;
 }
 
+// ---- one addition on FOUR lanes -----------------------------------------------------------------------------------
+// The trees that end every reduction (msm_wave_tree_sum) add ever fewer pairs, and a wave pays an addition's ~7 k instructions for a
+// level however few of its lanes still take part.  add-2008-s is four products deep with up to four independent products per
+// level:   { X1 ZZ2, X2 ZZ1, Y1 ZZZ2, Y2 ZZZ1 }   { P^2, R^2, ZZ1 ZZ2, ZZZ1 ZZZ2 }   { P PP, U1 PP, (ZZ1 ZZ2) PP }   { R (Q - X3), S1 PPP, (ZZZ1 ZZZ2) PPP }
+// so the four lanes of a quad, holding the same two points, each take one product of a level (operands picked by the lane's role,
+// results handed round the quad by DPP): 4 products + ~1 k instructions of selects, moves and lazy additions instead of 14 products.
+template <int K> __device__ __forceinline__ FqU fqu_quad_bcast(const FqU& v) {          // lane K of the quad's value, on all four
+    FqU r;
+#pragma unroll
+    for (int i = 0; i < FqU::N; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], K * 0x55, 0xf, 0xf, false);
+    return r;
+}
+__device__ __forceinline__ FqU fqu_sel4(uint32_t role, const FqU& a0, const FqU& a1, const FqU& a2, const FqU& a3) {
+    FqU r;
+#pragma unroll
+    for (int i = 0; i < FqU::N; ++i) {
+        const uint32_t lo = role & 1 ? a1.l[i] : a0.l[i], hi = role & 1 ? a3.l[i] : a2.l[i];
+        r.l[i] = role & 2 ? hi : lo;
+    }
+    return r;
+}
+// a + b on every lane of a quad whose four lanes hold the same a, b (any quad of a wave; all 64 lanes call).  Complete like g1u_add;
+// same formulas, same bounds on the stored coordinates.
+__device__ __forceinline__ G1XyzzU g1u_add_quad(const G1XyzzU& a, const G1XyzzU& b) {
+    const uint32_t role = threadIdx.x & 3;
+    const bool a_id = a.is_identity(), b_id = b.is_identity();
+    // level 1: u1 = X1 ZZ2 | u2 = X2 ZZ1 | s1 = Y1 ZZZ2 | s2 = Y2 ZZZ1
+    const FqU m1 = fqu_mul(fqu_sel4(role, a.x, b.x, a.y, b.y), fqu_sel4(role, b.zz, a.zz, b.zzz, a.zzz));
+    const FqU u1 = fqu_quad_bcast<0>(m1), u2 = fqu_quad_bcast<1>(m1), s1 = fqu_quad_bcast<2>(m1), s2 = fqu_quad_bcast<3>(m1);
+    const FqU p = fqu_sub<4>(u2, u1);                       // < 6p
+    const FqU r = fqu_sub<4>(s2, s1);
+    if (!a_id && !b_id && fqu_is_zero_mod_p(p)) {          // the same point or inverse points (quad-uniform: the four lanes hold the same values)
+        if (fqu_is_zero_mod_p(r)) return g1u_double(a);
+        return G1XyzzU::identity();
+    }
+    // level 2: pp = P^2 | rr = R^2 | zz12 = ZZ1 ZZ2 | zzz12 = ZZZ1 ZZZ2
+    const FqU m2 = fqu_mul(fqu_sel4(role, p, r, a.zz, a.zzz), fqu_sel4(role, p, r, b.zz, b.zzz));
+    const FqU pp = fqu_quad_bcast<0>(m2), rr = fqu_quad_bcast<1>(m2);
+    // level 3: ppp = P PP | qq = U1 PP | zz3 = zz12 PP | (idle: zzz12 carried along)
+    const FqU m3 = fqu_mul(fqu_sel4(role, p, u1, m2, m2), pp);
+    const FqU ppp = fqu_quad_bcast<0>(m3), qq = fqu_quad_bcast<1>(m3);
+    const FqU x3 = fqu_sub<8>(fqu_sub<4>(rr, ppp), fqu_dbl(qq));          // < 14p
+    // level 4: r (qq - x3) | s1 ppp | (idle) | zzz3 = zzz12 ppp
+    const FqU m4 = fqu_mul(fqu_sel4(role, r, s1, r, m2), fqu_sel4(role, fqu_sub<16>(qq, x3), ppp, ppp, ppp));
+    G1XyzzU o;
+    o.x = x3;
+    o.y = fqu_sub<4>(fqu_quad_bcast<0>(m4), fqu_quad_bcast<1>(m4));      // < 6p
+    o.zz = fqu_quad_bcast<2>(m3);
+    o.zzz = fqu_quad_bcast<3>(m4);
+    if (b_id) return a;
+    if (a_id) return b;
+    return o;
+}
+
 }  // namespace zk

@@ -428,11 +428,44 @@ __device__ __forceinline__ G1XyzzU msm_shfl_down(const G1XyzzU& v, uint32_t d) {
     }
     return o;
 }
-__device__ __forceinline__ void msm_wave_tree_sum(G1XyzzU& acc, uint32_t width) {
+__device__ __forceinline__ G1XyzzU msm_shfl(const G1XyzzU& v, uint32_t src_lane) {
+    G1XyzzU o;
+#pragma unroll
+    for (int i = 0; i < FqU::N; ++i) {
+        o.x.l[i] = __shfl(v.x.l[i], src_lane, 64);
+        o.y.l[i] = __shfl(v.y.l[i], src_lane, 64);
+        o.zz.l[i] = __shfl(v.zz.l[i], src_lane, 64);
+        o.zzz.l[i] = __shfl(v.zzz.l[i], src_lane, 64);
+    }
+    return o;
+}
+__device__ __forceinline__ void msm_wave_tree_sum_lanes(G1XyzzU& acc, uint32_t width) {      // a lane per pair: one full addition per level
     const uint32_t pos = threadIdx.x & (width - 1);
     for (uint32_t d = width >> 1; d >= 1; d >>= 1) {
         G1XyzzU o = msm_shfl_down(acc, d);
         if (pos < d) g1u_add(acc, o);
+    }
+}
+// The same with a QUAD of lanes per pair (g1u_add_quad: an addition in ~2.6 k instructions instead of ~7 k): a level of P pairs is
+// ceil(P / 16) passes -- the pairs' operands gathered onto their quads by ds_bpermute, the sums scattered back to the pairs' first
+// lanes.  A 64-lane tree: 2 + 1 + 1 + 1 + 1 + 1 passes instead of six full additions.  The wave must be 64 lanes, all of them calling.
+__device__ __forceinline__ void msm_wave_tree_sum(G1XyzzU& acc, uint32_t width) {
+    const uint32_t lane = threadIdx.x & 63, quad = lane >> 2, pos = lane & (width - 1), line = lane / width, lines = 64 / width;
+    for (uint32_t d = width >> 1, ld = 31 - __builtin_clz(width >> 1); d >= 1; d >>= 1, --ld) {
+        const uint32_t pairs = lines * d;                  // pair t = (line, pos < d): lanes line * width + pos and ... + d
+        const uint32_t my_t = line * d + pos;              // the pair this lane is the first lane of (when pos < d)
+        for (uint32_t t0 = 0; t0 < pairs; t0 += 16) {
+            const uint32_t t = t0 + quad;
+            const bool live = t < pairs;
+            const uint32_t la = live ? (t >> ld) * width + (t & (d - 1)) : lane;
+            G1XyzzU a = msm_shfl(acc, la), b = msm_shfl(acc, live ? la + d : lane);
+            if (!live) b = G1XyzzU::identity();            // an idle quad: a + 0, nobody reads it
+            const G1XyzzU s = g1u_add_quad(a, b);
+            const bool mine = pos < d && my_t >= t0 && my_t < t0 + 16;
+            const G1XyzzU got = msm_shfl(s, mine ? 4 * (my_t - t0) : lane);
+            if (mine) acc = got;
+        }
+        if (d == 1) break;
     }
 }
 
