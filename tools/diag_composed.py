@@ -5,7 +5,7 @@ import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from zk_cryptography_amd import _native as N
-N.LIB_PATH = os.path.join(N.CSRC, "libzkhip_diag.so")
+N.LIB_PATH = os.environ.get("ZKHIP_DIAG_LIB") or os.path.join(N.CSRC, "libzkhip_diag.so")
 import zk_cryptography_amd as zk
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 multi = len(sys.argv) > 2 and sys.argv[2] == "multi"
