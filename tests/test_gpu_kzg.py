@@ -134,6 +134,27 @@ def test_commit_duplicate_and_inverse_points(zk, ora):
     _same(zk, com, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), 192)))
 
 
+@pytest.mark.parametrize("n", [64, 256, 1024])
+def test_commit_duplicate_and_inverse_points_every_pipeline(zk, ora, n):
+    """The same degenerate inputs through the bucket pipeline on the plain SRS, the bucket pipeline on the table (ZKHIP_MSM_SMALL has no
+    say over zkhip_kzg_commit) and the short path: equal points meet in every tree level (the doubling branch of the four-lane
+    addition, csrc/g1u.hpp g1u_add_quad) and cancel (its identity branch)."""
+    from zk_cryptography_amd import kzg as K
+    g = ora.g1_batch_to_affine(np.stack([ora.g1_generator()] * n))
+    srs = zk.TrustedSetup(g[:, :12], g[:, 12].astype(np.uint8))
+    table = srs.precompute().table
+    for ints, want in (([5] * (n // 2) + [R - 5] * (n // 2), None), ([3] * n, 3 * n), ([1, 2] * (n // 2), 3 * (n // 2)),
+                       ([7] + [0] * (n - 1), 7), ([R - 1] * n, (R - 1) * n % R)):
+        sc = zk.DenseUnivariatePolynomial(zk.Fr.from_ints(ints)).coefficients
+        plain = K._commit(srs.powers_of_tau_in_g1, srs.inf, n, sc, n, True, None)
+        short = K._commit(srs.powers_of_tau_in_g1, srs.inf, n, sc, n, True, table)
+        assert plain == short
+        if want is None:
+            assert plain.infinity
+        else:
+            _same(zk, plain, *_aff(ora, ora.g1_mul_int(ora.g1_generator(), want)))
+
+
 @pytest.mark.parametrize("log_n", [4, 8, 10, 12])
 def test_commit_random_matches_naive_oracle(zk, ora, log_n):
     n = 1 << log_n
