@@ -57,26 +57,32 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_weights_kernel(uint
 // rows of a CSR grouping of the gates by one of their inputs: row_off[x] .. row_off[x+1] index `ids` (gate numbers).
 // phase 1 (rows = in0):  add_out[x] = sum_{add} w_g (Ha0),  lin_out[x] = sum_{add} w_g V[in1] (Ha1),  mul_out[x] = sum_{mul} w_g V[in1] (Hm)
 // phase 2 (rows = in1):  add_out[x] = sum_{add} w_g eq_u[in0] (Aa),  mul_out[x] = sum_{mul} w_g eq_u[in0] (Am);  lin_out unused
-// A rank of a sharded proof builds only ITS rows: lane j takes row x = j * row_stride + row_first and writes entry j of the outputs
-// (row_stride = world, row_first = rank: the rank-interleaved shard the sumcheck sweeps); v_shard (phase 1, optional) receives V[x].
-// What the rows GATHER from -- the gate weights, V, eq(u) -- is indexed by arbitrary wires and stays whole on every rank.
-static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_rows_kernel(const uint32_t* __restrict__ row_off, const uint32_t* __restrict__ ids,
-                                                                  const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ other_in,
-                                                                  const uint64_t* __restrict__ wg, const uint64_t* __restrict__ factor,
-                                                                  uint32_t n_rows, uint32_t phase, uint64_t* __restrict__ add_out,
-                                                                  uint64_t* __restrict__ lin_out, uint64_t* __restrict__ mul_out,
-                                                                  const uint64_t* __restrict__ v, const uint64_t* __restrict__ vu_ptr,
-                                                                  uint64_t* __restrict__ t1, uint64_t* __restrict__ t2,
-                                                                  uint32_t row_stride = 1, uint32_t row_first = 0, uint64_t* __restrict__ v_shard = nullptr,
-                                                                  const uint64_t* __restrict__ eq_b = nullptr, const uint64_t* __restrict__ eq_c = nullptr,
-                                                                  FrArg alpha_v = FrArg(), FrArg beta_v = FrArg(), uint64_t* __restrict__ wg_out = nullptr,
-                                                                  const uint64_t* __restrict__ ab_dev = nullptr) {
-    // ab_dev (not null): alpha and beta lie in device memory (entries 0 and 1), where gkr_layer_finish_kernel left them
-    // eq_b (phase 1 of a single-GPU proof, every gate visited exactly once): the gate weights are formed HERE from the previous layer's two
-    // eq tables -- w_g = alpha eq_g(r_b) + beta eq_g(r_c), the tables that layer built for its own second phase and for w_c -- and
-    // filed in wg_out for phase 2: no weight launches per layer
-    const uint32_t j = blockIdx.x * MLE_BLOCK + threadIdx.x;
-    if (j >= n_rows) return;
+// one row (every argument as gkr_gate_rows_kernel's)
+struct GateRowsArgs {
+    const uint32_t *row_off, *ids;
+    const uint8_t* gate_type;
+    const uint32_t* other_in;
+    const uint64_t *wg, *factor;
+    uint32_t n_rows, phase;
+    uint64_t *add_out, *lin_out, *mul_out;
+    const uint64_t *v, *vu_ptr;
+    uint64_t *t1, *t2;
+    uint32_t row_stride, row_first;
+    uint64_t* v_shard;
+    const uint64_t *eq_b, *eq_c;
+    FrArg alpha_v, beta_v;
+    uint64_t* wg_out;
+    const uint64_t* ab_dev;
+};
+__device__ __forceinline__ void gkr_gate_row(const GateRowsArgs& ga, uint32_t j) {
+    const uint32_t* __restrict__ row_off = ga.row_off; const uint32_t* __restrict__ ids = ga.ids;
+    const uint8_t* __restrict__ gate_type = ga.gate_type; const uint32_t* __restrict__ other_in = ga.other_in;
+    const uint64_t* __restrict__ wg = ga.wg; const uint64_t* __restrict__ factor = ga.factor;
+    const uint32_t phase = ga.phase, row_stride = ga.row_stride, row_first = ga.row_first;
+    uint64_t* add_out = ga.add_out; uint64_t* lin_out = ga.lin_out; uint64_t* mul_out = ga.mul_out;
+    const uint64_t* v = ga.v; const uint64_t* vu_ptr = ga.vu_ptr; uint64_t* t1 = ga.t1; uint64_t* t2 = ga.t2; uint64_t* v_shard = ga.v_shard;
+    const uint64_t* eq_b = ga.eq_b; const uint64_t* eq_c = ga.eq_c; const FrArg& alpha_v = ga.alpha_v; const FrArg& beta_v = ga.beta_v;
+    uint64_t* wg_out = ga.wg_out; const uint64_t* ab_dev = ga.ab_dev;
     const uint32_t x = j * row_stride + row_first;
     if (t1) {   // phase 2 also lays out the other factor of each term (one launch less per layer): t1[c] = V(u) + V[c], t2[c] = V(u) V[c]
         const Fr vu = load_fr(vu_ptr, 0), vx = load_fr(v, x);
@@ -103,6 +109,30 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_rows_kernel(const u
     store_fr(add_out, j, a);
     if (phase == 1) store_fr(lin_out, j, l);
     store_fr(mul_out, j, m);
+}
+// A rank of a sharded proof builds only ITS rows: lane j takes row x = j * row_stride + row_first and writes entry j of the outputs
+// (row_stride = world, row_first = rank: the rank-interleaved shard the sumcheck sweeps); v_shard (phase 1, optional) receives V[x].
+// What the rows GATHER from -- the gate weights, V, eq(u) -- is indexed by arbitrary wires and stays whole on every rank.
+static __global__ __launch_bounds__(MLE_BLOCK) void gkr_gate_rows_kernel(const uint32_t* __restrict__ row_off, const uint32_t* __restrict__ ids,
+                                                                  const uint8_t* __restrict__ gate_type, const uint32_t* __restrict__ other_in,
+                                                                  const uint64_t* __restrict__ wg, const uint64_t* __restrict__ factor,
+                                                                  uint32_t n_rows, uint32_t phase, uint64_t* __restrict__ add_out,
+                                                                  uint64_t* __restrict__ lin_out, uint64_t* __restrict__ mul_out,
+                                                                  const uint64_t* __restrict__ v, const uint64_t* __restrict__ vu_ptr,
+                                                                  uint64_t* __restrict__ t1, uint64_t* __restrict__ t2,
+                                                                  uint32_t row_stride = 1, uint32_t row_first = 0, uint64_t* __restrict__ v_shard = nullptr,
+                                                                  const uint64_t* __restrict__ eq_b = nullptr, const uint64_t* __restrict__ eq_c = nullptr,
+                                                                  FrArg alpha_v = FrArg(), FrArg beta_v = FrArg(), uint64_t* __restrict__ wg_out = nullptr,
+                                                                  const uint64_t* __restrict__ ab_dev = nullptr) {
+    // ab_dev (not null): alpha and beta lie in device memory (entries 0 and 1), where gkr_layer_finish_kernel left them
+    // eq_b (phase 1 of a single-GPU proof, every gate visited exactly once): the gate weights are formed HERE from the previous layer's two
+    // eq tables -- w_g = alpha eq_g(r_b) + beta eq_g(r_c), the tables that layer built for its own second phase and for w_c -- and
+    // filed in wg_out for phase 2: no weight launches per layer
+    const uint32_t j = blockIdx.x * MLE_BLOCK + threadIdx.x;
+    if (j >= n_rows) return;
+    const GateRowsArgs a = {row_off, ids, gate_type, other_in, wg, factor, n_rows, phase, add_out, lin_out, mul_out, v, vu_ptr, t1, t2,
+                            row_stride, row_first, v_shard, eq_b, eq_c, alpha_v, beta_v, wg_out, ab_dev};
+    gkr_gate_row(a, j);
 }
 // eq_x(u) over n_vars index bits, MSB first (the b side of the wiring at the phase-1 challenges).  The points are read from
 // DEVICE memory -- where the sumcheck that produced them left them -- so the host never waits for them.
@@ -215,23 +245,73 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_dot_finish_kernel(const 
 // sumcheck has been absorbed by the hasher workgroups; alpha, beta = two challenges (protocol.rs:104-105), the next claim
 // alpha w_b + beta w_c (:107), all left in device memory for the next layer's first kernels -- no host round trip per layer.
 // next: alpha | beta | claimed (4 u64 each); evals: w_b | w_c.  One wave.
-static __global__ __launch_bounds__(64) void gkr_layer_finish_kernel(OuterDev* __restrict__ outer, const uint64_t* __restrict__ evals,
-                                                                     uint64_t* __restrict__ next, uint64_t* __restrict__ wb_out,
-                                                                     uint64_t* __restrict__ wc_out, uint64_t* __restrict__ sum_out) {
-    Transcript tr;
-    tr.load(&outer->state);
-    const Fr alpha = tr.challenge_fr(), beta = tr.challenge_fr();
-    const Fr wb = load_fr(evals, 0), wc = load_fr(evals, 1);
-    const Fr claimed = fr_mul_outlined(alpha, wb) + fr_mul_outlined(beta, wc);
-    if (threadIdx.x == 0) {
-        tr.store(&outer->state);
-        store_fr(next, 0, alpha);
-        store_fr(next, 1, beta);
-        store_fr(next, 2, claimed);
-        store_fr(wb_out, 0, wb);
-        store_fr(wc_out, 0, wc);
-        if (sum_out) store_fr(sum_out, 0, claimed);
+// ---- layers of at most GKR_SMALL_ROWS rows: their small launches, fused ---------------------------------------------------------------
+// A layer is gate rows | rounds over b | eq(u), w_b | gate rows | rounds over c | eq(r_c), w_c | alpha, beta: on a small layer every launch
+// between the sumchecks is a single workgroup that lives ~5 us whatever it does, so eq(u) + w_b + the second phase's rows are ONE
+// launch, and eq(r_c) + w_c + alpha, beta + the NEXT layer's first rows another: 3 launches per layer instead of 6 (depth 8: 1.37 ->
+// 1.2x ms).  The same device code as the kernels they replace, a barrier between the steps (one workgroup: what a step stored is
+// visible to the next).
+constexpr uint32_t GKR_SMALL_ROWS = 1024;
+__device__ __forceinline__ void gkr_eq_table_block(const uint64_t* __restrict__ u, uint32_t n_vars, uint64_t* __restrict__ out,
+                                                   const uint64_t* __restrict__ v, uint64_t* __restrict__ dot_out, Fr* red) {
+    const size_t n = (size_t)1 << n_vars;
+    const Fr one = Fr::one();
+    Fr dot = Fr::zero();
+    for (size_t i = threadIdx.x; i < n; i += MLE_BLOCK) {
+        Fr acc = one;
+        for (uint32_t j = 0; j < n_vars; ++j) {
+            const Fr t = load_fr(u, j);
+            acc = acc * (((i >> (n_vars - 1 - j)) & 1) ? t : one - t);
+        }
+        store_fr(out, i, acc);
+        dot = dot + acc * load_fr(v, i);
     }
+    dot = block_reduce_fr(dot, red);
+    if (threadIdx.x == 0) store_fr(dot_out, 0, dot);
+}
+static __global__ __launch_bounds__(MLE_BLOCK) void gkr_small_mid_kernel(const uint64_t* __restrict__ u, uint32_t n_vars, uint64_t* __restrict__ eq_out,
+                                                                  const uint64_t* __restrict__ v, uint64_t* __restrict__ dot_out, GateRowsArgs rows) {
+    __shared__ Fr red[MLE_BLOCK / 64];
+    gkr_eq_table_block(u, n_vars, eq_out, v, dot_out, red);
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < rows.n_rows; j += MLE_BLOCK) gkr_gate_row(rows, j);
+}
+struct LayerFinishArgs {
+    OuterDev* outer;
+    const uint64_t* evals;
+    uint64_t *next, *wb_out, *wc_out, *sum_out;
+};
+__device__ __forceinline__ void gkr_layer_finish_wave(const LayerFinishArgs& f, uint32_t* lds /* 64 words */) {        // one wave, all of its lanes
+    Transcript tr;
+    tr.load(&f.outer->state);
+    const Fr alpha = tr.challenge_fr_wave(lds), beta = tr.challenge_fr_wave(lds);
+    const Fr wb = load_fr(f.evals, 0), wc = load_fr(f.evals, 1);
+    const Fr claimed = fr_mul_outlined(alpha, wb) + fr_mul_outlined(beta, wc);
+    if ((threadIdx.x & 63) == 0) {
+        tr.store(&f.outer->state);
+        store_fr(f.next, 0, alpha);
+        store_fr(f.next, 1, beta);
+        store_fr(f.next, 2, claimed);
+        store_fr(f.wb_out, 0, wb);
+        store_fr(f.wc_out, 0, wc);
+        if (f.sum_out) store_fr(f.sum_out, 0, claimed);
+    }
+}
+static __global__ __launch_bounds__(64) void gkr_layer_finish_kernel(LayerFinishArgs fin) {
+    __shared__ uint32_t kw[64];
+    gkr_layer_finish_wave(fin, kw);
+}
+static __global__ __launch_bounds__(MLE_BLOCK) void gkr_small_end_kernel(const uint64_t* __restrict__ u, uint32_t n_vars, uint64_t* __restrict__ eq_out,
+                                                                  const uint64_t* __restrict__ v, uint64_t* __restrict__ dot_out, LayerFinishArgs fin,
+                                                                  uint32_t with_rows, GateRowsArgs rows) {
+    __shared__ Fr red[MLE_BLOCK / 64];
+    __shared__ uint32_t kw[64];
+    gkr_eq_table_block(u, n_vars, eq_out, v, dot_out, red);
+    __syncthreads();
+    if (threadIdx.x < 64) gkr_layer_finish_wave(fin, kw);
+    if (!with_rows) return;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < rows.n_rows; j += MLE_BLOCK) gkr_gate_row(rows, j);
 }
 // eq_x(u) for all x < 2^n_vars, u in device memory; with d_v also <eq(u), v> -> d_dot (one value), summed from the table
 // kernel's per-workgroup shares (d_partials: MLE_MAX_GRID entries of scratch)
@@ -406,8 +486,11 @@ struct DeviceTranscript {
     uint64_t* arena;         // per layer: challenges (4 x ZK_MAX_ROUNDS) | round polynomials (64 x ZK_MAX_ROUNDS)
     static constexpr size_t LAYER_U64 = (size_t)(4 + 64) * ZK_MAX_ROUNDS;
 };
+// rows1_done: this layer's first rows were built by the layer before (gkr_small_end_kernel); next / d_w_next / w_len_next: the layer after
+// this one (null: none), whose first rows this layer's last launch builds when both are small -- *next_rows1_done says so.
 int layer_enqueue_device(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_w, size_t w_len, const LayerScratch& sc,
-                         const DeviceTranscript& dt, const zkhost::Fr& claimed0, const zkhost::Fr& n_r, uint32_t stride) {
+                         const DeviceTranscript& dt, const zkhost::Fr& claimed0, const zkhost::Fr& n_r, uint32_t stride, bool rows1_done,
+                         const LayerDev* next, const uint64_t* d_w_next, size_t w_len_next, bool* next_rows1_done) {
     using namespace zk;
     const size_t n_gates = ld.n_gates;
     const uint32_t s = log2_exact(w_len);
@@ -425,11 +508,24 @@ int layer_enqueue_device(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uin
         std::memcpy(av.v, one.l, 32);
         launch_gate_weights(c, n_gates, n_gate_vars, pb, pc, av, bv, false, sc.eqh, sc.wg);
     }
-    hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr0, ld.csr0 + w_len + 1, ld.type, ld.in1, sc.wg, d_w,
-                       (uint32_t)w_len, 1u, sc.ha0, sc.ha1, sc.hm, (const uint64_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr,
-                       1u, 0u, (uint64_t*)nullptr, two_points ? (const uint64_t*)sc.equ : (const uint64_t*)nullptr, (const uint64_t*)sc.eqc, av, bv, sc.wg,
-                       two_points ? (const uint64_t*)dt.next : (const uint64_t*)nullptr);
-    ZK_HIP(c, hipGetLastError());
+    static const bool fuse_small = [] { const char* e = std::getenv("ZKHIP_GKR_FUSE_SMALL"); return !e || std::atoi(e) != 0; }();
+    const bool small = fuse_small && w_len <= GKR_SMALL_ROWS;
+    auto rows1_args = [&](const LayerDev& L, const uint64_t* V, size_t rows, bool two) {       // the first rows of layer L (every gate once: the weights are formed there)
+        GateRowsArgs ra = {};
+        ra.row_off = L.csr0; ra.ids = L.csr0 + rows + 1; ra.gate_type = L.type; ra.other_in = L.in1; ra.wg = sc.wg; ra.factor = V;
+        ra.n_rows = (uint32_t)rows; ra.phase = 1u; ra.add_out = sc.ha0; ra.lin_out = sc.ha1; ra.mul_out = sc.hm;
+        ra.row_stride = 1u; ra.row_first = 0u;
+        ra.eq_b = two ? (const uint64_t*)sc.equ : nullptr; ra.eq_c = sc.eqc; ra.alpha_v = av; ra.beta_v = bv; ra.wg_out = sc.wg;
+        ra.ab_dev = two ? (const uint64_t*)dt.next : nullptr;
+        return ra;
+    };
+    if (!rows1_done) {
+        const GateRowsArgs ra = rows1_args(ld, d_w, w_len, two_points);
+        hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ra.row_off, ra.ids, ra.gate_type, ra.other_in, ra.wg, ra.factor,
+                           ra.n_rows, 1u, ra.add_out, ra.lin_out, ra.mul_out, (const uint64_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                           (uint64_t*)nullptr, 1u, 0u, (uint64_t*)nullptr, ra.eq_b, ra.eq_c, av, bv, ra.wg_out, ra.ab_dev);
+        ZK_HIP(c, hipGetLastError());
+    }
     uint64_t* ar_ch = dt.arena + (size_t)l * DeviceTranscript::LAYER_U64;
     uint64_t* ar_rp = ar_ch + 4 * (size_t)ZK_MAX_ROUNDS;
     ZkMcExtra ex = {};
@@ -445,9 +541,17 @@ int layer_enqueue_device(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uin
         ZK_TRY(zk_multi_composed_enqueue(c, tables, sizes, lin, 2, w_len, two_points ? nullptr : claimed0.l, 0, 0, &ex));
     }
     // ---- rounds over c, b at u = the challenges just recorded (in the arena)
-    launch_eq_table(c, ar_ch, s, sc.eqh, sc.equ, d_w, sc.dot_partials, sc.evals);
-    hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr1, ld.csr1 + w_len + 1, ld.type, ld.in0, sc.wg, sc.equ,
-                       (uint32_t)w_len, 2u, sc.aa, (uint64_t*)nullptr, sc.am, d_w, (const uint64_t*)sc.evals, sc.t1, sc.t2);
+    if (small) {                                           // eq(u), w_b and the second rows: one workgroup, one launch
+        GateRowsArgs ra = {};
+        ra.row_off = ld.csr1; ra.ids = ld.csr1 + w_len + 1; ra.gate_type = ld.type; ra.other_in = ld.in0; ra.wg = sc.wg; ra.factor = sc.equ;
+        ra.n_rows = (uint32_t)w_len; ra.phase = 2u; ra.add_out = sc.aa; ra.mul_out = sc.am; ra.v = d_w; ra.vu_ptr = sc.evals; ra.t1 = sc.t1; ra.t2 = sc.t2;
+        ra.row_stride = 1u;
+        hipLaunchKernelGGL(gkr_small_mid_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, (const uint64_t*)ar_ch, s, sc.equ, d_w, sc.evals, ra);
+    } else {
+        launch_eq_table(c, ar_ch, s, sc.eqh, sc.equ, d_w, sc.dot_partials, sc.evals);
+        hipLaunchKernelGGL(gkr_gate_rows_kernel, dim3(gw), dim3(MLE_BLOCK), 0, c->stream, ld.csr1, ld.csr1 + w_len + 1, ld.type, ld.in0, sc.wg, sc.equ,
+                           (uint32_t)w_len, 2u, sc.aa, (uint64_t*)nullptr, sc.am, d_w, (const uint64_t*)sc.evals, sc.t1, sc.t2);
+    }
     ZK_HIP(c, hipGetLastError());
     {
         const uint64_t* tables[4] = {sc.aa, sc.t1, sc.am, sc.t2};
@@ -455,10 +559,20 @@ int layer_enqueue_device(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uin
         ex.token = ++c->outer_token;
         ZK_TRY(zk_multi_composed_enqueue(c, tables, sizes, nullptr, 2, w_len, nullptr, 1, s, &ex));
     }
-    launch_eq_table(c, ar_ch + 4 * (size_t)s, s, sc.eqh, sc.eqc, d_w, sc.dot_partials, sc.evals + 4);     // w_c = V(r_c); eq(r_c) stays for the next layer
-    // alpha, beta, the next claim; w_b, w_c and the next layer's claimed sum into the per-layer arrays
-    hipLaunchKernelGGL(gkr_layer_finish_kernel, dim3(1), dim3(64), 0, c->stream, dt.outer, (const uint64_t*)sc.evals, dt.next, dt.wb + 4 * (size_t)l,
-                       dt.wc + 4 * (size_t)l, dt.sums + 4 * (size_t)(l + 1));
+    // w_c = V(r_c) (eq(r_c) stays for the next layer); alpha, beta, the next claim; w_b, w_c and the next layer's claimed sum into the per-layer arrays
+    const LayerFinishArgs fin = {dt.outer, sc.evals, dt.next, dt.wb + 4 * (size_t)l, dt.wc + 4 * (size_t)l, dt.sums + 4 * (size_t)(l + 1)};
+    *next_rows1_done = false;
+    if (small) {                                           // ... and the next layer's first rows, if that layer is small too
+        const bool with_rows = next && w_len_next <= GKR_SMALL_ROWS && !next->bad_label && w_len_next == next->w_len && w_len_next == 2 * w_len &&
+                               next->n_gates <= ((size_t)1 << (l + 1));      // (what the next call checks before it would launch them itself)
+        const GateRowsArgs ra = with_rows ? rows1_args(*next, d_w_next, w_len_next, true) : GateRowsArgs();
+        hipLaunchKernelGGL(gkr_small_end_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, (const uint64_t*)(ar_ch + 4 * (size_t)s), s, sc.eqc, d_w, sc.evals + 4,
+                           fin, with_rows ? 1u : 0u, ra);
+        *next_rows1_done = with_rows;
+    } else {
+        launch_eq_table(c, ar_ch + 4 * (size_t)s, s, sc.eqh, sc.eqc, d_w, sc.dot_partials, sc.evals + 4);
+        hipLaunchKernelGGL(gkr_layer_finish_kernel, dim3(1), dim3(64), 0, c->stream, fin);
+    }
     ZK_HIP(c, hipGetLastError());
     return ZKHIP_OK;
 }
@@ -635,24 +749,32 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
                 hs->buf[i] = ((uint32_t)tr.hasher.buf[4 * i] << 24) | ((uint32_t)tr.hasher.buf[4 * i + 1] << 16) | ((uint32_t)tr.hasher.buf[4 * i + 2] << 8) | tr.hasher.buf[4 * i + 3];
             hs->fill = fill;
             hs->len = tr.hasher.len;
-            ZK_HIP(c, hipMemcpyAsync(&dt.outer->state, hs, sizeof(*hs), hipMemcpyHostToDevice, c->stream));
-            ZK_HIP(c, hipMemsetAsync(&dt.outer->error, 0, 4, c->stream));
+            static_assert(offsetof(zk::OuterDev, error) == sizeof(zk::Sha256State), "state | error: one copy");
+            *(uint32_t*)(hs + 1) = 0u;                                   // OuterDev::error
+            ZK_HIP(c, hipMemcpyAsync(&dt.outer->state, hs, sizeof(*hs) + 4, hipMemcpyHostToDevice, c->stream));
             ZK_HIP(c, hipMemcpyAsync(dt.sums, claimed.l, 32, hipMemcpyHostToDevice, c->stream));     // (pageable source: copied before the call returns)
             ZK_HIP(c, hipStreamSynchronize(c->stream));                  // the pinned staging words are reused below
         }
-        for (uint32_t li = 1; li <= n_layers; ++li)
-            ZK_TRY(layer_enqueue_device(c, cir->layers[li - 1], li - 1, h_layer_ptrs[li], h_layer_len[li], sc, dt, claimed, n_r[0], stride));
-        // ---- the whole proof back in one go
-        const size_t pin_bytes = arena_bytes + 32 * ((size_t)n_layers + 1) + 64 * (size_t)n_layers + 16;
+        bool rows1_done = false;
+        for (uint32_t li = 1; li <= n_layers; ++li) {
+            const bool has_next = li < n_layers;
+            bool next_done = false;
+            ZK_TRY(layer_enqueue_device(c, cir->layers[li - 1], li - 1, h_layer_ptrs[li], h_layer_len[li], sc, dt, claimed, n_r[0], stride, rows1_done,
+                                        has_next ? &cir->layers[li] : nullptr, has_next ? h_layer_ptrs[li + 1] : nullptr, has_next ? h_layer_len[li + 1] : 0,
+                                        &next_done));
+            rows1_done = next_done;
+        }
+        // ---- the whole proof back in ONE copy: outer state (its error word) | next | sums | w_b | w_c | arena are neighbours on the device
+        const size_t pin_bytes = o_arena + arena_bytes - o_outer;
         ZK_TRY(c->reserve_msm_pin(0, pin_bytes));
-        char* pin = (char*)c->msm_pin[0];
-        ZK_HIP(c, hipMemcpyAsync(pin, dt.arena, arena_bytes, hipMemcpyDeviceToHost, c->stream));
-        ZK_HIP(c, hipMemcpyAsync(pin + arena_bytes, dt.sums, 32 * ((size_t)n_layers + 1), hipMemcpyDeviceToHost, c->stream));
-        ZK_HIP(c, hipMemcpyAsync(pin + arena_bytes + 32 * ((size_t)n_layers + 1), dt.wb, 32 * (size_t)n_layers, hipMemcpyDeviceToHost, c->stream));
-        ZK_HIP(c, hipMemcpyAsync(pin + arena_bytes + 32 * ((size_t)n_layers + 1) + 32 * (size_t)n_layers, dt.wc, 32 * (size_t)n_layers, hipMemcpyDeviceToHost, c->stream));
-        ZK_HIP(c, hipMemcpyAsync(pin + pin_bytes - 16, &dt.outer->error, 4, hipMemcpyDeviceToHost, c->stream));
+        char* pin0 = (char*)c->msm_pin[0];
+        ZK_HIP(c, hipMemcpyAsync(pin0, aux + o_outer, pin_bytes, hipMemcpyDeviceToHost, c->stream));
         ZK_HIP(c, hipStreamSynchronize(c->stream));
-        if (*(const uint32_t*)(pin + pin_bytes - 16) != 0) return ZKHIP_ERR_HIP;         // a hasher gave up waiting for a round (see OuterDev::error)
+        if (((const zk::OuterDev*)pin0)->error != 0) return ZKHIP_ERR_HIP;         // a hasher gave up waiting for a round (see OuterDev::error)
+        const char* pin = pin0 + (o_arena - o_outer);
+        const char* pin_sums = pin0 + (o_sums - o_outer);
+        const char* pin_wb = pin0 + (o_wb - o_outer);
+        const char* pin_wc = pin0 + (o_wc - o_outer);
         const uint64_t* h_arena = (const uint64_t*)pin;
         for (uint32_t k = 0; k < n_layers; ++k) {
             const uint32_t nv = 2 * (k + 1);
@@ -667,9 +789,9 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
             }
             h_n_rounds[k] = nv;
         }
-        std::memcpy(h_sums, pin + arena_bytes, 32 * (size_t)n_layers);
-        std::memcpy(h_wb, pin + arena_bytes + 32 * ((size_t)n_layers + 1), 32 * (size_t)n_layers);
-        std::memcpy(h_wc, pin + arena_bytes + 32 * ((size_t)n_layers + 1) + 32 * (size_t)n_layers, 32 * (size_t)n_layers);
+        std::memcpy(h_sums, pin_sums, 32 * (size_t)n_layers);
+        std::memcpy(h_wb, pin_wb, 32 * (size_t)n_layers);
+        std::memcpy(h_wc, pin_wc, 32 * (size_t)n_layers);
         return ZKHIP_OK;
     }
     zkhost::Fr alpha = zkhost::fr_one(), beta = zkhost::fr_zero();

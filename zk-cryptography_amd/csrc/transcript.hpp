@@ -405,6 +405,24 @@ __device__ __forceinline__ void sha256_message_split(uint32_t (&h)[8], const uin
     sp.join(hs, h);
 }
 
+// One compression by a whole wave (every lane holds the same h and blk): the schedule on the sixteen lanes of row 0, the state rounds on
+// six -- ~1.9 us instead of the ~3.2 us of sha256_compress on one lane.  lds: 64 words of scratch nobody else touches.
+__device__ __forceinline__ void sha256_compress_wave(uint32_t (&h)[8], const uint32_t (&blk)[16], uint32_t* lds) {
+    const uint32_t i = threadIdx.x & 15;
+    uint32_t w = blk[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) w = i == (uint32_t)k ? blk[k] : w;
+    sha256_schedule_rows_to_lds(w, lds, nullptr, 0u, 0u, (threadIdx.x & 63) < 16);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // lanes read what other lanes of the wave wrote
+    ShaSplit sp;
+    sp.init();
+    uint32_t hs[4];
+    sp.split(h, hs);
+    sha256_rounds_block_split(sp, hs, lds);
+    sp.join(hs, h);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (the scratch is rewritten by the next call)
+}
+
 // Out-of-line Montgomery product for the single-wave control paths (keeps those kernels small).
 __device__ __noinline__ Fr fr_mul_outlined(Fr a, Fr b) { return a * b; }   // by value: arguments travel in registers, not through scratch
 // Montgomery form -> canonical integer (into_bigint): the reduction half of a product only (x * 1 has no
@@ -536,6 +554,33 @@ struct Transcript {
         return v;
     }
     __device__ __forceinline__ Fr challenge_fr() { return fr_to_mont_outlined(challenge_canonical()); }
+    // the same by a whole wave (sha256_compress_wave; every lane of the wave calls with the same state; lds: 64 words of scratch)
+    __device__ __forceinline__ Fr challenge_fr_wave(uint32_t* lds) {
+        const uint64_t bits = len * 8;
+        if (fill_words == 0) {
+            buf[0] = 0x80000000u;
+#pragma unroll
+            for (int i = 1; i < 14; ++i) buf[i] = 0;
+        } else {   // 8 words pending
+            buf[8] = 0x80000000u;
+#pragma unroll
+            for (int i = 9; i < 14; ++i) buf[i] = 0;
+        }
+        buf[14] = (uint32_t)(bits >> 32);
+        buf[15] = (uint32_t)bits;
+        sha256_compress_wave(h, buf, lds);
+        uint32_t d[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = h[i];
+        init();
+        commit_words8(d);                                        // 8 words pending: no compression
+        Fr v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v.l[i] = d[7 - i];
+        v.reduce_once();
+        v.reduce_once();
+        return fr_to_mont_outlined(v);
+    }
 };
 
 }  // namespace zk
