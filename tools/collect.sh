@@ -33,6 +33,10 @@ timeout 300 python3 tools/timeline_any.py k5_22 k5_20 m23_20 k3_20 k4_20 2>&1 | 
 f=$(ls gpurun_out/$R/gkr20/*/*kernel_trace.csv | head -1); python3 tools/trace_seq.py $f 9.3 0 > gpurun_out/$R/d_gkr20_kernel_sequence.txt 2>&1
 timeout 400 bash tools/sweep_stage.sh > gpurun_out/$R/d_sweep_stage.txt 2>&1
 timeout 100 python3 tools/perf_fingerprint.py 2>&1 | grep " us" > gpurun_out/$R/e_srs_guard_cost.txt
+[ -x tools/ubench_salu ] && timeout 120 ./tools/ubench_salu > gpurun_out/$R/ubench_salu_gfx950.txt 2>&1
+[ -x tools/ubench_sha_split ] && timeout 120 ./tools/ubench_sha_split > gpurun_out/$R/ubench_sha_split_gfx950.txt 2>&1
+(for rep in 1 2; do for d in 8 20; do echo "depth $d, small launches fused:   $(timeout 100 python3 tools/gkr_run.py $d 2>&1 | grep 'ms per')"; echo "depth $d, small launches separate: $(ZKHIP_GKR_FUSE_SMALL=0 timeout 100 python3 tools/gkr_run.py $d 2>&1 | grep 'ms per')"; done; done) > gpurun_out/$R/d_ab_gkr_fused_small.txt
+(timeout 120 python3 tools/diag_small.py 24 2>&1 | grep "^round\|^kernel") > gpurun_out/$R/b_sumcheck_small_round_stamps.txt
 [ -x tools/ubench_fine ] && timeout 120 ./tools/ubench_fine > gpurun_out/$R/ubench_fine_gfx950.txt 2>&1
 [ -x tools/ubench_batched_affine ] && timeout 120 ./tools/ubench_batched_affine > gpurun_out/$R/ubench_batched_affine_gfx950.txt 2>&1
 # MultilinearKZG::open: plain batch against the level tables -- per-kernel stats at 2^20, time by size, time by window width

@@ -16,6 +16,7 @@ cp $R/d_gkr20_trace_gaps.txt $R/d_composed_round_stamps.txt $R/d_ab_pipe.txt $P/
 [ -f $R/d_sweep_stage.txt ] && cp $R/d_sweep_stage.txt $P/
 for f in b_evaluation_timeline.txt d_k5_timelines.txt d_k5_round_stamps.txt e_small_commit_timelines.txt d_ab_gkr_transcript.txt d_gkr20_kernel_sequence.txt; do [ -f $R/$f ] && cp $R/$f $P/; done
 [ -f $R/e_srs_guard_cost.txt ] && cp $R/e_srs_guard_cost.txt $P/
+for f in ubench_salu_gfx950.txt ubench_sha_split_gfx950.txt d_ab_gkr_fused_small.txt b_sumcheck_small_round_stamps.txt; do [ -f $R/$f ] && cp $R/$f $P/; done
 [ -f $R/ubench_fine_gfx950.txt ] && cp $R/ubench_fine_gfx950.txt $P/
 [ -f $R/ubench_batched_affine_gfx950.txt ] && cp $R/ubench_batched_affine_gfx950.txt $P/
 [ -f $R/e_open_by_size_and_width.txt ] && cp $R/e_open_by_size_and_width.txt $P/
