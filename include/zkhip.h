@@ -119,6 +119,14 @@ int zkhip_mle_add_to_back(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, uin
 /* Multilinear::to_bytes (:54-62): 32 big-endian canonical bytes per element into d_out_bytes[32 n] */
 int zkhip_mle_to_bytes(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, uint8_t *d_out_bytes);
 
+/* ---- FiatShamirTranscript (transcripts/fiat-shamir/src/fiat_shamir.rs:10-40) ----------------------------------
+ * Every prover here keeps its transcript on the device; this entry runs the same device code on bytes of the caller's choice, so that
+ * the hash itself can be held against an independent SHA-256.  A transcript that has just answered a challenge() holds a fresh
+ * hasher that absorbed the 32-byte digest (:21-25): h_prefix32 = that digest (NULL: FiatShamirTranscript::new()); then
+ * commit(h_bytes[0 .. n)) (:17-19) and challenge() -> h_digest32, the 32 bytes evaluate_challenge_into_field reduces (:27-29).
+ * One wave: the message schedule on the sixteen lanes of a row, the state rounds on six (csrc/transcript.hpp). */
+int zkhip_transcript_challenge(zkhip_ctx *ctx, const uint8_t *h_prefix32, const uint8_t *h_bytes, size_t n, uint8_t *h_digest32);
+
 /* ---- layered circuit: the GKR prover's table builders (circuit/src/circuit.rs) ----------------------------
  * Gates arrive as host arrays (h_gate_type: 0 = Add, 1 = Mul; h_in0 / h_in1: input labels); values stay in HBM.
  *   zkhip_circuit_layer_eval   one step of Circuit::evaluation (:31-57): d_out[g] = d_in[in0[g]] (+|*) d_in[in1[g]];

@@ -19,5 +19,5 @@ from zk_cryptography_amd.composed import (ComposedMultilinear, ComposedSumcheck,
                                           MultiComposedSumcheckProof, MultiComposedSumcheckProver,
                                           SparseUnivariatePolynomial)
 from zk_cryptography_amd.univariate import Domain, UnivariateEval  # noqa: F401
-from zk_cryptography_amd.gkr import (Circuit, CircuitLayer, FiatShamirTranscript, Gate, GKRProof, GKRProtocol,  # noqa: F401
+from zk_cryptography_amd.gkr import (Circuit, CircuitLayer, DeviceFiatShamirTranscript, FiatShamirTranscript, Gate, GKRProof, GKRProtocol,  # noqa: F401
                                      SuccintGKRProof, SuccintGKRProtocol)

@@ -1330,6 +1330,52 @@ extern "C" int zkhip_sc_abort(zkhip_sc_state* st) {
     return rc;
 }
 
+// ---- FiatShamirTranscript on bytes of the caller's choice (the device hash held against an independent SHA-256) ----
+namespace zk {
+static __global__ __launch_bounds__(64) void transcript_blocks_kernel(const uint32_t* __restrict__ blocks, uint32_t n_blocks, uint32_t* __restrict__ digest) {
+    __shared__ uint32_t kw[64];
+    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        uint32_t blk[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) blk[j] = blocks[16 * (size_t)b + j];
+        sha256_compress_wave(h, blk, kw);
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) digest[i] = h[i];
+    }
+}
+}  // namespace zk
+extern "C" int zkhip_transcript_challenge(zkhip_ctx* c, const uint8_t* h_prefix32, const uint8_t* h_bytes, size_t n, uint8_t* h_digest32) {
+    if (!c || !h_digest32 || (n && !h_bytes)) return ZKHIP_ERR_ARG;
+    if (n >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
+    ZK_TRY(c->activate());
+    // the padded message as big-endian words (FIPS 180-4 5.1.1): prefix || bytes || 0x80 || 0 ... || bit length
+    const size_t len = (h_prefix32 ? 32 : 0) + n, n_blocks = (len + 9 + 63) / 64;
+    std::vector<uint8_t> msg(64 * n_blocks, 0);
+    if (h_prefix32) std::memcpy(msg.data(), h_prefix32, 32);
+    if (n) std::memcpy(msg.data() + (h_prefix32 ? 32 : 0), h_bytes, n);
+    msg[len] = 0x80;
+    const uint64_t bits = 8 * (uint64_t)len;
+    for (int i = 0; i < 8; ++i) msg[64 * n_blocks - 1 - i] = (uint8_t)(bits >> (8 * i));
+    std::vector<uint32_t> words(16 * n_blocks);
+    for (size_t w = 0; w < words.size(); ++w)
+        words[w] = ((uint32_t)msg[4 * w] << 24) | ((uint32_t)msg[4 * w + 1] << 16) | ((uint32_t)msg[4 * w + 2] << 8) | msg[4 * w + 3];
+    ZK_TRY(c->reserve_ws(4 * words.size() + 64));
+    uint32_t* d_words = (uint32_t*)c->d_ws;
+    uint32_t* d_digest = d_words + words.size();
+    ZK_HIP(c, hipMemcpyAsync(d_words, words.data(), 4 * words.size(), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(zk::transcript_blocks_kernel, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)d_words, (uint32_t)n_blocks, d_digest);
+    ZK_HIP(c, hipGetLastError());
+    uint32_t out[8];
+    ZK_HIP(c, hipMemcpyAsync(out, d_digest, 32, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j) h_digest32[4 * i + j] = (uint8_t)(out[i] >> (24 - 8 * j));
+    return ZKHIP_OK;
+}
+
 #ifdef ZK_STAMPS
 extern "C" int zkhip_debug_read_stamps(zkhip_ctx* c, unsigned long long* h_out /*64*8*/) {
     ZK_HIP(c, hipStreamSynchronize(c->stream));

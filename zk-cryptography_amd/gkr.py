@@ -171,6 +171,36 @@ class FiatShamirTranscript:
         return np.stack([self.evaluate_challenge_into_field() for _ in range(n)]) if n else np.zeros((0, 4), dtype=np.uint64)
 
 
+class DeviceFiatShamirTranscript:
+    """The same transcript with its hash on the GPU (zkhip_transcript_challenge: the device code every prover's transcript runs --
+    schedule on the sixteen lanes of a row, state rounds on six), for holding that hash against an independent SHA-256.  commit()
+    gathers bytes on the host; challenge() hashes `digest of the previous challenge || committed bytes` on the device."""
+
+    def __init__(self, device=None):
+        self._prefix = None
+        self._pending = bytearray()
+        self._ctx = N.Context.get(device)
+
+    def commit(self, new_data):
+        self._pending += bytes(new_data)
+
+    def challenge(self):
+        data = bytes(self._pending)
+        out = (C.c_uint8 * 32)()
+        pre = (C.c_uint8 * 32).from_buffer_copy(self._prefix) if self._prefix is not None else None
+        buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+        N.check(N.lib().zkhip_transcript_challenge(self._ctx.handle, pre, buf, C.c_size_t(len(data)), out), "transcript_challenge")
+        self._prefix = bytes(out)
+        self._pending = bytearray()
+        return self._prefix
+
+    def evaluate_challenge_into_field(self):
+        return Fr.from_int(int.from_bytes(self.challenge(), "big") % R_MOD)
+
+    def evaluate_n_challenge_into_field(self, n):
+        return np.stack([self.evaluate_challenge_into_field() for _ in range(n)]) if n else np.zeros((0, 4), dtype=np.uint64)
+
+
 class GKRProof:
     """gkr/src/protocol.rs:10-15"""
 
