@@ -143,8 +143,8 @@ int zkhip_circuit_add_mult_mle(zkhip_ctx *ctx, const uint8_t *h_gate_type, const
 /* GKRProtocol::prove (gkr/src/protocol.rs:21-117 with gkr/src/utils.rs:8-56) in one call, every table in HBM.  The dense
  * wiring tables of Circuit::add_mult_mle (2^(3 l + 2) entries) and the dense (b, c) tables of a layer's sumcheck
  * (2^(2 l + 2) entries) are not built: the layer prover sums over the gates and works on tables as wide as the layer
- * (rounds over b, then over c), giving the proof of the dense prover bit for bit.  2 * n_layers <= 40
- * rounds per layer proof, i.e. circuits up to depth 20 / width 2^20.  The prover's own transcript (protocol.rs:25: every layer's
+ * (rounds over b, then over c), giving the proof of the dense prover bit for bit.  2 * n_layers <= 48
+ * rounds per layer proof, i.e. circuits up to depth 24 / width 2^24.  The prover's own transcript (protocol.rs:25: every layer's
  * proof bytes, then alpha and beta) runs on the DEVICE beside the rounds: the call enqueues all layers behind each other and
  * waits once, for the whole proof (ZKHIP_GKR_HOST_TRANSCRIPT=1 or ZKHIP_PIPE=0: the transcript on the host, one wait per layer;
  * the same proof).

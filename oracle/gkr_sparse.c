@@ -38,10 +38,13 @@
 #include <string.h>
 
 /* ---- sp_t: non-zero entries of a table ------------------------------------------------------------------------ */
-typedef struct { uint64_t *pos; fr_t *val; size_t len; uint64_t n; } sp_t;
+/* positions and table sizes as 128-bit integers: the wiring table of layer l has 2^(3l + 2) entries -- 2^65 at depth 22 */
+typedef unsigned __int128 pos_t;
+#define POS_MAX (~(pos_t)0)
+typedef struct { pos_t *pos; fr_t *val; size_t len; pos_t n; } sp_t;
 
-static int sp_alloc(sp_t *t, size_t cap, uint64_t n) {
-    t->pos = (uint64_t *)malloc((cap ? cap : 1) * sizeof(uint64_t));
+static int sp_alloc(sp_t *t, size_t cap, pos_t n) {
+    t->pos = (pos_t *)malloc((cap ? cap : 1) * sizeof(pos_t));
     t->val = (fr_t *)malloc((cap ? cap : 1) * sizeof(fr_t));
     t->len = 0;
     t->n = n;
@@ -52,7 +55,7 @@ static void sp_free(sp_t *t) { free(t->pos); free(t->val); t->pos = NULL; t->val
 /* partial_evaluation(r, 0) (evaluation_form.rs:123-141 with utils.rs:26-53 at variable_index 0: pairs (i, i + n/2)) */
 static int sp_fold(sp_t *t, const fr_t *r) {
     if (t->n < 2) return -1;
-    const uint64_t half = t->n / 2;
+    const pos_t half = t->n / 2;
     size_t m = 0;
     while (m < t->len && t->pos[m] < half) ++m;                  /* entries [0, m) lie in the lower half */
     sp_t o;
@@ -63,8 +66,8 @@ static int sp_fold(sp_t *t, const fr_t *r) {
     ora_fr_sub(&one_minus_r, &one, r);
     size_t i = 0, j = m;
     while (i < m || j < t->len) {
-        const uint64_t pi = i < m ? t->pos[i] : UINT64_MAX, pj = j < t->len ? t->pos[j] - half : UINT64_MAX;
-        const uint64_t p = pi < pj ? pi : pj;
+        const pos_t pi = i < m ? t->pos[i] : POS_MAX, pj = j < t->len ? t->pos[j] - half : POS_MAX;
+        const pos_t p = pi < pj ? pi : pj;
         const fr_t *y1 = &zero, *y2 = &zero;
         if (pi == p) y1 = &t->val[i++];
         if (pj == p) y2 = &t->val[j++];
@@ -83,7 +86,7 @@ static int sp_fold(sp_t *t, const fr_t *r) {
 /* partial_evaluations(points, [0; k]) (evaluation_form.rs:143-159) of a copy */
 static int sp_folds(sp_t *out, const sp_t *in, const fr_t *pts, size_t k) {
     if (sp_alloc(out, in->len, in->n) != 0) return -1;
-    memcpy(out->pos, in->pos, in->len * sizeof(uint64_t));
+    memcpy(out->pos, in->pos, in->len * sizeof(pos_t));
     memcpy(out->val, in->val, in->len * sizeof(fr_t));
     out->len = in->len;
     for (size_t i = 0; i < k; ++i)
@@ -96,8 +99,8 @@ static int sp_scale_add(sp_t *out, const sp_t *a, const fr_t *alpha, const sp_t 
     if (a->n != b->n || sp_alloc(out, a->len + b->len, a->n) != 0) return -1;
     size_t i = 0, j = 0;
     while (i < a->len || j < b->len) {
-        const uint64_t pi = i < a->len ? a->pos[i] : UINT64_MAX, pj = j < b->len ? b->pos[j] : UINT64_MAX;
-        const uint64_t p = pi < pj ? pi : pj;
+        const pos_t pi = i < a->len ? a->pos[i] : POS_MAX, pj = j < b->len ? b->pos[j] : POS_MAX;
+        const pos_t p = pi < pj ? pi : pj;
         fr_t x, y;
         ora_fr_zero(&x);
         ora_fr_zero(&y);
@@ -127,8 +130,8 @@ static int ds_init(ds_t *d, const fr_t *w, size_t w_len, int mul) {
 static void ds_free(ds_t *d) { free(d->u); free(d->v); free(d->scratch); }
 
 /* entry x of the table: evaluation_form.rs:33-35 / :46-48 (self.evaluations[i] (+|*) rhs.evaluations[j] at i*len + j) */
-static void ds_at(fr_t *o, const ds_t *d, uint64_t x) {
-    const fr_t *a = &d->u[x / d->nv], *b = &d->v[x % d->nv];
+static void ds_at(fr_t *o, const ds_t *d, pos_t x) {
+    const fr_t *a = &d->u[(size_t)(x / d->nv)], *b = &d->v[(size_t)(x % d->nv)];
     if (d->mul) ora_fr_mul(o, a, b); else ora_fr_add(o, a, b);
 }
 
@@ -149,7 +152,7 @@ static int ds_fold(ds_t *d, const fr_t *r) {
  * = sum over j < n/2 of A_i[j] * S_i[j] with X_i[j] = i*X[j + n/2] + (1 - i)*X[j]; terms with A_i[j] = 0 for every i
  * (both paired entries of A absent) are zero and skipped.  X_{i+1} = X_i + (X[j + n/2] - X[j]). */
 static void term_round_evals(fr_t ev[3], const sp_t *a, const ds_t *s) {
-    const uint64_t half = a->n / 2;
+    const pos_t half = a->n / 2;
     size_t m = 0;
     while (m < a->len && a->pos[m] < half) ++m;
     fr_t zero;
@@ -157,8 +160,8 @@ static void term_round_evals(fr_t ev[3], const sp_t *a, const ds_t *s) {
     for (int t = 0; t < 3; ++t) ora_fr_zero(&ev[t]);
     size_t i = 0, j = m;
     while (i < m || j < a->len) {
-        const uint64_t pi = i < m ? a->pos[i] : UINT64_MAX, pj = j < a->len ? a->pos[j] - half : UINT64_MAX;
-        const uint64_t p = pi < pj ? pi : pj;
+        const pos_t pi = i < m ? a->pos[i] : POS_MAX, pj = j < a->len ? a->pos[j] - half : POS_MAX;
+        const pos_t p = pi < pj ? pi : pj;
         const fr_t *a1 = &zero, *a2 = &zero;
         if (pi == p) a1 = &a->val[i++];
         if (pj == p) a2 = &a->val[j++];
@@ -214,19 +217,19 @@ static int prove_partial_sparse(sp_t *a_add, ds_t *s_add, sp_t *a_mul, ds_t *s_m
 }
 
 /* ---- the layers -------------------------------------------------------------------------------------------------- */
-static int cmp_u64(const void *a, const void *b) {
-    const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+static int cmp_pos(const void *a, const void *b) {
+    const pos_t x = *(const pos_t *)a, y = *(const pos_t *)b;
     return x < y ? -1 : x > y;
 }
 
 /* Circuit::add_mult_mle (circuit.rs:59-97): the positions set to one, ascending, once each */
 static int wiring_sparse(sp_t *add, sp_t *mul, size_t layer_index, size_t n_gates, const uint8_t *gate_type,
                          const uint32_t *in0, const uint32_t *in1) {
-    const uint64_t size = ora_gkr_mle_size(layer_index);
+    const pos_t size = (pos_t)1 << (layer_index == 0 ? 3 : 3 * layer_index + 2);      /* ora_gkr_mle_size (circuit/src/utils.rs:1-10), past 64 bits */
     if (sp_alloc(add, n_gates, size) != 0 || sp_alloc(mul, n_gates, size) != 0) return -1;
     for (size_t g = 0; g < n_gates; ++g) {
         /* circuit/src/utils.rs:12-25, as gkr.c's wiring_index */
-        const uint64_t idx = ((uint64_t)g << (2 * (layer_index + 1))) | ((uint64_t)in0[g] << (layer_index + 1)) | in1[g];
+        const pos_t idx = ((pos_t)g << (2 * (layer_index + 1))) | ((pos_t)in0[g] << (layer_index + 1)) | in1[g];
         if (idx >= size) return -1;
         sp_t *t = gate_type[g] == 0 ? add : mul;
         t->pos[t->len++] = idx;
@@ -234,7 +237,7 @@ static int wiring_sparse(sp_t *add, sp_t *mul, size_t layer_index, size_t n_gate
     sp_t *both[2] = {add, mul};
     for (int k = 0; k < 2; ++k) {
         sp_t *t = both[k];
-        qsort(t->pos, t->len, sizeof(uint64_t), cmp_u64);
+        qsort(t->pos, t->len, sizeof(pos_t), cmp_pos);
         size_t o = 0;
         for (size_t i = 0; i < t->len; ++i)
             if (o == 0 || t->pos[o - 1] != t->pos[i]) t->pos[o++] = t->pos[i];
@@ -244,9 +247,9 @@ static int wiring_sparse(sp_t *add, sp_t *mul, size_t layer_index, size_t n_gate
     return 0;
 }
 
-static size_t log2_exact_sz(uint64_t n) {
+static size_t log2_exact_sz(pos_t n) {
     size_t k = 0;
-    while (((uint64_t)1 << k) < n) ++k;
+    while (((pos_t)1 << k) < n) ++k;
     return k;
 }
 
@@ -289,9 +292,9 @@ int ora_gkr_prove_sparse(size_t n_layers, const size_t *n_gates, const uint8_t *
             if (sp_folds(&t1, &mul, r_b, r_len) != 0 || sp_folds(&t2, &mul, r_c, r_len) != 0) goto done;
             if (sp_scale_add(&a_mul, &t1, &alpha, &t2, &beta) != 0) goto done;
         }
-        if (a_add.n != (uint64_t)w_len * w_len || a_mul.n != a_add.n) goto done;   /* ComposedMultilinear::new asserts equal n_vars */
+        if (a_add.n != (pos_t)w_len * w_len || a_mul.n != a_add.n) goto done;   /* ComposedMultilinear::new asserts equal n_vars */
         const size_t nv = log2_exact_sz(a_add.n);
-        if (((uint64_t)1 << nv) != a_add.n || nv > ORA_GKR_MAX_ROUNDS) goto done;
+        if (((pos_t)1 << nv) != a_add.n || nv > ORA_GKR_MAX_ROUNDS) goto done;
         if (ds_init(&s_add, w, w_len, 0) != 0 || ds_init(&s_mul, w, w_len, 1) != 0) goto done;   /* wb.add_distinct(&wc), wb.mul_distinct(&wc) */
         if (prove_partial_sparse(&a_add, &s_add, &a_mul, &s_mul, nv, &claimed, proof->round_polys[k], challenges) != 0) goto done;
         proof->sums[k] = claimed;

@@ -534,7 +534,7 @@ def msm_pippenger(scalars, pts_affine):
 
 
 # ---- circuit + GKR (gkr.c) ---------------------------------------------------------------------
-GKR_MAX_LAYERS, GKR_MAX_ROUNDS = 20, 40
+GKR_MAX_LAYERS, GKR_MAX_ROUNDS = 24, 48
 
 
 class GkrProof(C.Structure):

@@ -125,8 +125,8 @@ int  ora_multi_composed_verify(const fr_t *tables, const size_t *term_sizes, siz
 /* ---- GKR (gkr/src/protocol.rs, gkr/src/utils.rs) over the layered circuit (circuit/src/circuit.rs) ----------
  * A circuit travels as flat arrays: n_gates[l] gates in layer l (layer 0 = output), then per gate (layers
  * concatenated) gate_type (0 = Add, 1 = Mul) and the two input labels. */
-#define ORA_GKR_MAX_LAYERS 20
-#define ORA_GKR_MAX_ROUNDS 40
+#define ORA_GKR_MAX_LAYERS 24
+#define ORA_GKR_MAX_ROUNDS 48
 typedef struct {
     size_t n_proofs;
     fr_t sums[ORA_GKR_MAX_LAYERS];                                 /* ComposedSumcheckProof::sum */

@@ -189,3 +189,39 @@ def test_gkr_depth_20_bit_exact_accepted_and_tamper_rejected(zk, ora):
     bad = inp.copy()
     bad[12345, 0] ^= np.uint64(1)
     assert not ora.gkr_verify(layers, bad, op)
+
+
+@pytest.mark.parametrize("depth", [22])
+def test_gkr_beyond_depth_20(zk, ora, depth):
+    """Headroom above configs[3]: a last layer of 2^22 gates (44 sumcheck rounds per layer proof; the limit is depth 24, 48 rounds), bit
+    for bit the sparse-container restatement's proof -- every layer's sums, proof bytes, challenges, w_b, w_c.  (The restatement keeps
+    positions in 128 bits: that layer's wiring table has 2^65 entries.  Depth 21 was checked the same way when the limit moved.)"""
+    from gkr_cases import gkr_proof_mismatches
+    layers = random_circuit(depth)
+    inp = ora.random_fr(1 << depth, 0x5EED00002100 + depth)
+    circuit = zk.Circuit.from_tuples(layers)
+    ev = circuit.evaluation(inp)
+    proof = zk.GKRProtocol.prove(circuit, ev)
+    assert len(proof.sumcheck_proofs) == depth and len(proof.sumcheck_proofs[-1].round_polys) == 2 * depth
+    want_ev = ora.circuit_evaluation(layers, inp)
+    assert all(np.array_equal(a.cpu().numpy().view(np.uint64), b) for a, b in zip(ev, want_ev))
+    want = ora.gkr_prove_sparse(layers, want_ev)
+    assert gkr_proof_mismatches(ora, proof, want) == []
+
+
+def test_gkr_depth_24_two_provers_agree(zk, ora):
+    """The deepest circuit the library takes (2^24 gates in the last layer, 48 rounds): the single-call prover (outer transcript on the
+    device) and the sharded prover's sessions at world 1 (transcript on the host, stage passes) yield the same proof; the oracle's
+    restatement would take minutes here and is held against both at depth 21 / 22 above."""
+    depth = 24
+    layers = random_circuit(depth)
+    circuit = zk.Circuit.from_tuples(layers)
+    ev = circuit.evaluation(zk.Fr.synthetic(1 << depth, 0x5EED00002124))
+    a = zk.GKRProtocol.prove(circuit, ev)
+    b = zk.GKRProtocol.prove_sharded(circuit, ev, use_stages=True)
+    assert len(a.sumcheck_proofs) == depth and len(a.sumcheck_proofs[-1].round_polys) == 2 * depth
+    for k in range(depth):
+        pa, pb = a.sumcheck_proofs[k], b.sumcheck_proofs[k]
+        assert np.array_equal(pa.sum, pb.sum) and pa.to_bytes() == pb.to_bytes(), k
+        assert np.array_equal(a.wb_s[k], b.wb_s[k]) and np.array_equal(a.wc_s[k], b.wc_s[k]), k
+

@@ -56,9 +56,10 @@ def test_composed_limits(zk):
 
 
 def test_gkr_depth_limit(zk):
-    """2 * n_layers <= 40 sumcheck rounds per layer proof: depth 21 is refused with the shape status before any work."""
+    """2 * n_layers <= 48 sumcheck rounds per layer proof: depth 25 is refused with the shape status before any work (depth 21 .. 24:
+    tests/test_gpu_baseline_sizes.py::test_gkr_beyond_depth_20)."""
     from zk_cryptography_amd import _native as N
-    n_layers = 21
+    n_layers = 25
     n_gates = (C.c_size_t * n_layers)(*[1] * n_layers)
     gt = (C.c_uint8 * n_layers)()
     z = (C.c_uint32 * n_layers)()

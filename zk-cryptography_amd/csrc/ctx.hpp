@@ -12,7 +12,7 @@
 #include "../../include/zkhip.h"
 #include "host_util.hpp"
 
-#define ZK_MAX_ROUNDS 40          /* tables up to 2^40 entries: far beyond 288 GB */
+#define ZK_MAX_ROUNDS 48          /* rounds of one sumcheck: tables of 2^48 entries are far beyond 288 GB; a GKR layer of width 2^24 takes 2 x 24 */
 #define ZK_MAX_PARTIALS 4096      /* (lo, hi) pairs: >= the largest grid any reducing kernel uses */
 
 // fixed carve-up of the small device scratch (offsets in uint64_t units)

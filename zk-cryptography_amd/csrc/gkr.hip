@@ -163,16 +163,17 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_table_kernel(const ui
 // one product per entry after a tiny kernel for the halves (exact arithmetic: the same field elements).  blockIdx.y selects
 // the point (gate weights take two, scaled by alpha / beta through their hi halves); the points come from device memory
 // (u_dev, the challenges a sumcheck left there) or by value.
-constexpr uint32_t GKR_EQ_LO = 10;
-constexpr uint32_t GKR_EQ_HALVES = 2u << GKR_EQ_LO;        // entries reserved per point: hi (<= 2^10) then lo (2^10)
+constexpr uint32_t GKR_EQ_LO = 12;                         // (n_vars <= 2 GKR_EQ_LO = 24: the widest layer of a depth-24 circuit)
+constexpr uint32_t GKR_EQ_HALVES = 2u << GKR_EQ_LO;        // entries reserved per point: hi (<= 2^12) then lo (2^12)
 // A lone wave pays 0.9 us per product and 2 us per dependent load, so an entry is NOT built as a chain over its index bits
 // (10 loads + 10 products: 28 us per launch): the points are fetched once into LDS with their complements, each half is split
-// again into two parts of <= 5 bits whose <= 32-entry tables 128 lanes build (5 products deep), and an entry is one product of two
-// part entries -- 6-7 products deep in all.  Every workgroup rebuilds the part tables (they are tiny).
+// again into two parts of <= 6 bits whose <= 64-entry tables the 256 lanes build (6 products deep), and an entry is one product of two
+// part entries -- 7-8 products deep in all.  Every workgroup rebuilds the part tables (they are tiny).
 static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_halves_kernel(const uint64_t* __restrict__ u_dev, PtsArg p0, PtsArg p1, uint32_t n_vars,
                                                                   FrArg scale0, FrArg scale1, uint32_t scaled, uint64_t* __restrict__ out) {
     __shared__ Fr fac[2 * GKR_EQ_LO + 2][2];   // [variable][bit]: 1 - t, t
-    __shared__ Fr part[2][2][32];              // [half: hi, lo][part: leading bits, trailing bits][index]
+    __shared__ Fr part[2][2][64];              // [half: hi, lo][part: leading bits, trailing bits][index]
+    static_assert(MLE_BLOCK == 256 && GKR_EQ_LO <= 12, "four part tables of <= 64 entries, a lane each");
     const uint32_t n_lo = GKR_EQ_LO, n_hi = n_vars - n_lo, pt = blockIdx.y, tid = threadIdx.x;
     {
         // by-value points are read with a UNIFORM index (scalar loads from the kernel arguments): indexing them by lane would put
@@ -193,8 +194,8 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_halves_kernel(const u
     }
     __syncthreads();
     // part tables: half h covers the variables [first, first + cnt), its part 0 the leading cnt - cnt/2 of them
-    if (tid < 128) {
-        const uint32_t hh = tid >> 6, pp = (tid >> 5) & 1, idx = tid & 31;
+    {
+        const uint32_t hh = tid >> 7, pp = (tid >> 6) & 1, idx = tid & 63;
         const uint32_t first = hh ? n_hi : 0, cnt = hh ? n_lo : n_hi;
         const uint32_t nb = cnt / 2, na = cnt - nb;                    // bits of part 0 / part 1
         const uint32_t bits = pp ? nb : na, v0 = first + (pp ? na : 0);
@@ -213,7 +214,7 @@ static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_halves_kernel(const u
     const Fr v = part[is_hi ? 0 : 1][0][idx >> nb] * part[is_hi ? 0 : 1][1][idx & ((1u << nb) - 1)];
     store_fr(out, (size_t)pt * GKR_EQ_HALVES + (is_hi ? idx : (GKR_EQ_HALVES >> 1) + idx), v);
 }
-// out[x] = sum over the n_points points of hi[x >> 10] * lo[x & 1023]
+// out[x] = sum over the n_points points of hi[x >> GKR_EQ_LO] * lo[x & (2^GKR_EQ_LO - 1)]
 static __global__ __launch_bounds__(MLE_BLOCK) void gkr_eq_expand_kernel(const uint64_t* __restrict__ halves, uint32_t n_points, size_t n,
                                                                   uint64_t* __restrict__ out, const uint64_t* __restrict__ v,
                                                                   uint64_t* __restrict__ partials) {

@@ -23,7 +23,7 @@ constexpr int TAIL_N = 1 << TAIL_LOG;
 // Small host-side parameters travel as kernel arguments (captured at launch), never through a shared staging
 // buffer: entry points return before the stream has run, so a staging slot could be overwritten by the next call.
 struct FrArg { uint64_t v[4]; };
-struct PtsArg { uint64_t v[4 * 40]; };   // up to ZK_MAX_ROUNDS points
+struct PtsArg { uint64_t v[4 * 48]; };   // up to ZK_MAX_ROUNDS points
 __device__ __forceinline__ Fr fr_from_arg(const FrArg& a) {
     Fr r;
 #pragma unroll

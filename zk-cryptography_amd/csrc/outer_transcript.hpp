@@ -6,7 +6,7 @@
 
 namespace zk {
 
-constexpr int CMP_OUTER_ROUNDS = 40;    // >= ZK_MAX_ROUNDS (composed.hip asserts it)
+constexpr int CMP_OUTER_ROUNDS = 48;    // >= ZK_MAX_ROUNDS (composed.hip asserts it)
 constexpr int CMP_OUTER_MONO = 7;       // = CMP_MAX_MONO: monomials of a round polynomial
 struct OuterDev {                       // device-resident, one per proof in flight
     Sha256State state;                  // the outer transcript between kernels
