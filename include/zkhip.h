@@ -535,7 +535,9 @@ int zkhip_srs_univariate_g1(zkhip_ctx *ctx, const uint64_t *h_tau, size_t max_de
  *                           built once per SRS like zkhip_srs_precompute's table; with them every round's commitment needs
  *                           ceil(256 / c) instead of ~ceil(256 / (c - 4)) bucket additions per point, ONE bucket set and a
  *                           host epilogue of ~20 instead of 255 doublings;
- *   zkhip_kzg_open_tables : zkhip_kzg_open with those tables (d_level_tables; NULL = zkhip_kzg_open; needs d_folded_inf).
+ *   zkhip_kzg_open_tables : zkhip_kzg_open with those tables (d_level_tables; NULL = zkhip_kzg_open; needs d_folded_inf).  Openings of at
+ *                           most 2^12 entries take every round's quotient commit on the short path of zkhip_kzg_commit_table (one plain
+ *                           sum per digit bit, two launches for all rounds); zkhip_srs_level_tables builds such an SRS's tables in a few ms.
  * Outputs (host): h_evaluation[4]; h_proofs_xy[n_vars*12], h_proofs_inf[n_vars] (affine, as zkhip_kzg_commit).
  * Shape errors as in the reference: n_points != n (multilinear_kzg.rs:36-41), n_eval_points != n_vars
  * (evaluation_form.rs:163-167), n_vars < 2 (`variable_index - 1` underflows at :73) -> ZKHIP_ERR_SHAPE. */

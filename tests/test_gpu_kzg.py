@@ -301,7 +301,8 @@ def test_kzg_open_level_tables_agree_with_the_plain_opening(zk, ora, n_vars, kin
     plain = zk.TrustedSetup(srs.powers_of_tau_in_g1.clone(), srs.inf.clone())
     srs.precompute_open()
     poly = zk.Multilinear(vals)
-    a, b = zk.MultilinearKZG.open(poly, z, srs), zk.MultilinearKZG.open(poly, z, plain)
+    # (an SRS of at most 2^12 points would build its level tables on first use: the plain side then folds per call, which keeps it on the bucket pipeline)
+    a, b = zk.MultilinearKZG.open(poly, z, srs), zk.MultilinearKZG.open(poly, z, plain, cache_folded_srs=n > zk.TrustedSetup.SMALL_SRS)
     assert plain.level_tables is None and srs.level_tables is not None
     assert np.array_equal(a.evaluation, b.evaluation)
     assert len(a.proofs) == n_vars and all(p == q for p, q in zip(a.proofs, b.proofs))
@@ -530,8 +531,10 @@ def test_srs_caches_follow_in_place_edits(zk, ora):
     assert srs.level_tables is not None
     srs.powers_of_tau_in_g1[[2, 3]] = srs.powers_of_tau_in_g1[[3, 2]]
     plain2 = zk.TrustedSetup(srs.powers_of_tau_in_g1.clone(), srs.inf.clone())
+    stale_levels = srs._level_tables
+    assert srs.level_tables is None                                        # the stale level tables were dropped ...
     a, b = zk.MultilinearKZG.open(poly, z, srs), zk.MultilinearKZG.open(poly, z, plain2, cache_folded_srs=False)
-    assert srs.level_tables is None and all(p == q for p, q in zip(a.proofs, b.proofs))
+    assert srs.level_tables is not stale_levels and all(p == q for p, q in zip(a.proofs, b.proofs))   # ... (a small SRS builds fresh ones on its next opening)
     a = zk.MultilinearKZG.open(poly, z, srs.precompute_open())
     assert srs.level_tables is not None and all(p == q for p, q in zip(a.proofs, b.proofs))
 

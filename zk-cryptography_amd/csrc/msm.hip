@@ -431,6 +431,7 @@ extern "C" int zkhip_srs_precompute(zkhip_ctx* c, const uint64_t* d_points_xy, c
 // LEVEL TABLES: shifted tables of the folded SRS levels MultilinearKZG::open commits against in ONE batch (the levels of at most
 // OPEN_BATCH_MAX points), each with the window widths of msm_level_table_widths, end to end in level order (msm_geometry.hpp).
 constexpr size_t OPEN_BATCH_MAX_DEFAULT = (size_t)1 << 19;
+constexpr size_t MSM_SMALL_MAX = 4096;          // commits / openings of at most this many scalars take the short path (msm_small_batch)
 static size_t level_tables_first(size_t n_points, size_t* lvl_off) {   // size of the first (largest) level that has a table; *lvl_off = its offset in the folded array
     size_t h = n_points / 2, off = 0;
     while (h > OPEN_BATCH_MAX_DEFAULT) { off += h; h /= 2; }
@@ -451,6 +452,38 @@ extern "C" int zkhip_srs_level_tables(zkhip_ctx* c, const uint64_t* d_folded_xy,
     ZK_TRY(c->activate());
     size_t off = 0, entry = 0;
     const size_t first = level_tables_first(n_points, &off);
+    if (n_points <= MSM_SMALL_MAX) {
+        // a small SRS: every level in one go (msm_small_level_windows_kernel) -- a few ms instead of 0.3-0.4 s, so that a small opening can
+        // build its tables on first use
+        MsmSmallTabArgs a = {};
+        for (size_t h = first; h >= 1; h /= 2) {
+            const MsmLevelWidths lw = msm_level_table_widths(h, 2 * first - 1);
+            const uint32_t j = a.n_levels++;
+            a.h[j] = (uint32_t)h; a.pt_off[j] = a.total_points; a.tab_off[j] = (uint32_t)entry; a.W[j] = lw.W; a.hi[j] = lw.hi; a.n_hi[j] = lw.n_hi;
+            a.total_points += (uint32_t)h;
+            entry += (size_t)lw.W * h;
+        }
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t o_pts = 0, o_xyzz = al(128 * (size_t)a.total_points), o_aff = o_xyzz + al(192 * entry), o_inf = o_aff + al(96 * entry);
+        ZK_TRY(c->reserve_ws(o_inf + al(entry)));
+        char* ws = (char*)c->d_ws;
+        uint32_t* d_pts = (uint32_t*)(ws + o_pts);
+        hipLaunchKernelGGL(msm_convert_points_kernel, dim3((a.total_points + MSM_BLOCK - 1) / MSM_BLOCK), dim3(MSM_BLOCK), 0, c->stream, d_folded_xy + 12 * off,
+                           (size_t)a.total_points, d_pts);
+        hipLaunchKernelGGL(msm_clear_inf_kernel, dim3((a.total_points + MSM_BLOCK - 1) / MSM_BLOCK), dim3(MSM_BLOCK), 0, c->stream, d_folded_inf + off,
+                           (size_t)a.total_points, d_pts);
+        hipLaunchKernelGGL(msm_small_level_windows_kernel, dim3((a.total_points + 63) / 64), dim3(64), 0, c->stream, a, (const uint32_t*)d_pts, (uint64_t*)(ws + o_xyzz));
+        const size_t n_threads = (entry + SRS_CHUNK - 1) / SRS_CHUNK;
+        hipLaunchKernelGGL(srs_batch_affine_kernel, dim3((unsigned)((n_threads + SRS_BLOCK - 1) / SRS_BLOCK)), dim3(SRS_BLOCK), 0, c->stream,
+                           (const uint64_t*)(ws + o_xyzz), entry, (uint64_t*)(ws + o_aff), (uint8_t*)(ws + o_inf));
+        const unsigned grid = (unsigned)((entry + MSM_BLOCK - 1) / MSM_BLOCK);
+        hipLaunchKernelGGL(msm_convert_points_kernel, dim3(std::min<unsigned>(grid, 256 * 8)), dim3(MSM_BLOCK), 0, c->stream, (const uint64_t*)(ws + o_aff), entry,
+                           (uint32_t*)d_tables);
+        hipLaunchKernelGGL(msm_clear_inf_kernel, dim3(grid), dim3(MSM_BLOCK), 0, c->stream, (const uint8_t*)(ws + o_inf), entry, (uint32_t*)d_tables);
+        ZK_HIP(c, hipGetLastError());
+        ZK_HIP(c, hipStreamSynchronize(c->stream));
+        return ZKHIP_OK;
+    }
     for (size_t h = first; h >= 1; h /= 2) {
         const MsmLevelWidths lw = msm_level_table_widths(h, 2 * first - 1);      // the batch: the levels first, first / 2, ..., 1
         const uint32_t W = lw.W;
@@ -464,38 +497,69 @@ extern "C" int zkhip_srs_level_tables(zkhip_ctx* c, const uint64_t* d_folded_xy,
 
 // Commits of at most MSM_SMALL_MAX scalars against a shifted-SRS table: the plane sums of msm_kernels.hpp "commits of a few thousand
 // points" -- two launches, one copy, a host epilogue of <= 20 doublings.  ZKHIP_MSM_SMALL=0 keeps the bucket pipeline (A/B runs).
-constexpr size_t MSM_SMALL_MAX = 4096;
-static int msm_commit_small(zkhip_ctx* c, const uint32_t* d_table, size_t stride, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n,
-                            uint64_t* h_out_xy, uint8_t* h_out_inf) {
-    const MsmLevelWidths lw = msm_table_widths(stride);
+// problem j: n[j] scalars from sc_off[j] on against the table at tab_off[j] (entries) of stride[j] points with the widths lw[j]; results
+// h_out_xy[12 j], h_out_inf[j]
+struct MsmSmallProblem { size_t n, stride, tab_off, sc_off; MsmLevelWidths lw; };
+static int msm_small_batch(zkhip_ctx* c, const uint32_t* d_table, const uint8_t* d_inf, const uint64_t* d_scalars, const MsmSmallProblem* pr,
+                           uint32_t nprob, uint64_t* h_out_xy, uint8_t* h_out_inf) {
+    if (nprob == 0 || nprob > (uint32_t)MSM_SMALL_PROBS) return ZKHIP_ERR_SHAPE;
     MsmSmallArgs a = {};
-    a.table = d_table; a.scalars = d_scalars; a.inf = d_inf;
-    a.n = (uint32_t)n; a.stride = (uint32_t)stride; a.W = lw.W; a.hi = lw.hi; a.n_hi = lw.n_hi;
-    a.planes = lw.hi;                                              // |digit| <= 2^(hi - 1): bits 0 .. hi - 1
-    const size_t pairs = n * lw.W, chunks = (pairs + 63) / 64;
-    a.n_slots = (uint32_t)std::max<size_t>(1, std::min<size_t>(chunks, 2048 / a.planes));     // ~2 waves per SIMD in all
-    const size_t part_bytes = (size_t)a.planes * a.n_slots * 256, terms_bytes = (size_t)a.planes * 192;
+    a.table = d_table; a.scalars = d_scalars; a.inf = d_inf; a.nprob = nprob;
+    size_t total_pairs = 0;
+    for (uint32_t j = 0; j < nprob; ++j) {
+        a.n[j] = (uint32_t)pr[j].n; a.stride[j] = (uint32_t)pr[j].stride; a.W[j] = pr[j].lw.W; a.hi[j] = pr[j].lw.hi; a.n_hi[j] = pr[j].lw.n_hi;
+        a.tab_off[j] = (uint32_t)pr[j].tab_off; a.sc_off[j] = (uint32_t)pr[j].sc_off;
+        a.planes = std::max(a.planes, pr[j].lw.hi);
+        total_pairs += pr[j].n * pr[j].lw.W;
+    }
+    // ~2 waves per SIMD in all, dealt to the problems by their share of the pairs (at least one slot each, at most a wave per 64 pairs)
+    const size_t budget = std::max<size_t>(1, 2048 / a.planes);
+    for (uint32_t j = 0; j < nprob; ++j) {
+        const size_t pairs = pr[j].n * pr[j].lw.W, chunks = (pairs + 63) / 64;
+        const size_t share = total_pairs ? (budget * pairs + total_pairs - 1) / total_pairs : 1;
+        a.slot_first[j + 1] = a.slot_first[j] + (uint32_t)std::max<size_t>(1, std::min(chunks, share));
+    }
+    a.total_slots = a.slot_first[nprob];
+    const size_t part_bytes = (size_t)a.planes * a.total_slots * 256, terms_bytes = (size_t)nprob * a.planes * 192;
     ZK_TRY(c->reserve_ws(part_bytes + 256 + terms_bytes));
     a.partials = (uint32_t*)c->d_ws;
     a.terms = (uint64_t*)((char*)c->d_ws + ((part_bytes + 255) & ~(size_t)255));
     {
-        ProfScope ps(c, "msm_small", 128.0 * (double)n);
-        hipLaunchKernelGGL(msm_small_planes_kernel, dim3(a.n_slots, a.planes), dim3(64), 0, c->stream, a);
-        hipLaunchKernelGGL(msm_small_reduce_kernel, dim3(a.planes), dim3(64), 0, c->stream, a);
+        ProfScope ps(c, "msm_small", 128.0 * (double)total_pairs / std::max<uint32_t>(1, a.W[0]));
+        hipLaunchKernelGGL(msm_small_planes_kernel, dim3(a.total_slots, a.planes), dim3(64), 0, c->stream, a);
+        hipLaunchKernelGGL(msm_small_reduce_kernel, dim3(a.planes, nprob), dim3(64), 0, c->stream, a);
     }
     ZK_HIP(c, hipGetLastError());
     ZK_TRY(c->reserve_msm_pin(0, terms_bytes));
     ZK_HIP(c, hipMemcpyAsync(c->msm_pin[0], a.terms, terms_bytes, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
-    std::vector<zkhost::Xyzz> pts(a.planes);
-    std::vector<uint32_t> exps(a.planes);
-    for (uint32_t t = 0; t < a.planes; ++t) {
-        std::memcpy(&pts[t], (const char*)c->msm_pin[0] + 192 * (size_t)t, 192);
-        exps[t] = t;
+    const char* pin = (const char*)c->msm_pin[0];
+    auto finish = [&](uint32_t j) {                                  // the weighted sum of a problem's plane sums: <= 20 doublings
+        std::vector<zkhost::Xyzz> pts(a.hi[j]);
+        std::vector<uint32_t> exps(a.hi[j]);
+        for (uint32_t t = 0; t < a.hi[j]; ++t) {
+            std::memcpy(&pts[t], pin + 192 * ((size_t)j * a.planes + t), 192);
+            exps[t] = t;
+        }
+        const zkhost::Xyzz res = zkhost::weighted_sum_pow2(pts, exps);
+        h_out_inf[j] = zkhost::xyzz_to_affine(res, h_out_xy + 12 * (size_t)j) ? 0 : 1;
+    };
+    ZkHostPool* pool = nprob > 1 ? c->pool() : nullptr;
+    if (!pool) {
+        for (uint32_t j = 0; j < nprob; ++j) finish(j);
+    } else {
+        pool->run(nprob, [&](unsigned j) { finish(j); });
     }
-    const zkhost::Xyzz res = zkhost::weighted_sum_pow2(pts, exps);
-    *h_out_inf = zkhost::xyzz_to_affine(res, h_out_xy) ? 0 : 1;
     return ZKHIP_OK;
+}
+static int msm_commit_small(zkhip_ctx* c, const uint32_t* d_table, size_t stride, const uint8_t* d_inf, const uint64_t* d_scalars, size_t n,
+                            uint64_t* h_out_xy, uint8_t* h_out_inf) {
+    const MsmSmallProblem one = {n, stride, 0, 0, msm_table_widths(stride)};
+    return msm_small_batch(c, d_table, d_inf, d_scalars, &one, 1, h_out_xy, h_out_inf);
+}
+static bool msm_small_on() {
+    static const bool on = [] { const char* e = std::getenv("ZKHIP_MSM_SMALL"); return !e || std::atoi(e) != 0; }();
+    return on;
 }
 
 extern "C" int zkhip_kzg_commit_table(zkhip_ctx* c, const void* d_table, const uint8_t* d_points_inf, size_t n_points,
@@ -509,8 +573,7 @@ extern "C" int zkhip_kzg_commit_table(zkhip_ctx* c, const void* d_table, const u
     if (!d_table || !d_scalars) return ZKHIP_ERR_ARG;
     if (n_points * msm_table_widths(n_points).W >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
-    static const bool small_on = [] { const char* e = std::getenv("ZKHIP_MSM_SMALL"); return !e || std::atoi(e) != 0; }();
-    if (small_on && n <= MSM_SMALL_MAX) return msm_commit_small(c, (const uint32_t*)d_table, n_points, d_points_inf, d_scalars, n, h_out_xy, h_out_inf);
+    if (msm_small_on() && n <= MSM_SMALL_MAX) return msm_commit_small(c, (const uint32_t*)d_table, n_points, d_points_inf, d_scalars, n, h_out_xy, h_out_inf);
     MsmProblems one = {};
     one.n = 1;
     one.off[1] = (uint32_t)n;
@@ -677,6 +740,25 @@ extern "C" int zkhip_kzg_open_tables(zkhip_ctx* c, const uint64_t* d_evals, size
         cn = h;
     }
     ZK_HIP(c, hipGetLastError());
+    if (d_level_tables && large.empty() && batch.n && batch.n <= (uint32_t)MSM_SMALL_PROBS && n <= MSM_SMALL_MAX && msm_small_on()) {
+        // a small opening against its level tables: every round's quotient commit is a plain sum per digit bit (msm_small_batch) --
+        // two launches for all rounds instead of the bucket pipeline's seventeen (0.96 -> 0.6x ms at 2^12)
+        MsmSmallProblem sp[MSM_SMALL_PROBS];
+        const size_t total = batch.off[batch.n];
+        size_t entry = 0;
+        for (uint32_t j = 0; j < batch.n; ++j) {
+            const size_t h = batch.off[j + 1] - batch.off[j];
+            const MsmLevelWidths lw = msm_level_table_widths(h, total);          // as zkhip_srs_level_tables laid the level out
+            sp[j] = {h, h, entry, batch_first_off + batch.off[j], lw};
+            entry += (size_t)lw.W * h;
+        }
+        ZK_TRY(msm_small_batch(c, (const uint32_t*)d_level_tables, d_folded_inf, d_q, sp, batch.n, h_proofs_xy + 12 * (size_t)batch_first_round,
+                               h_proofs_inf + batch_first_round));
+        ZK_HIP(c, hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), cur, 32, hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(c, hipStreamSynchronize(c->stream));
+        std::memcpy(h_evaluation, c->pinned_u64(ZK_PIN_RES), 32);
+        return ZKHIP_OK;
+    }
     // workspace: region k (k < NSLOT) is sized for the k-th single commit and reused by the commits k + NSLOT, k + 2 NSLOT, ... (each
     // half the size of its predecessor in the region or less); the batch has a region of its own.  Reserved once, up front: a
     // commit that grew the workspace later would move it under the commits in flight.

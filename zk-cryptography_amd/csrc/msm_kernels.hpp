@@ -640,40 +640,51 @@ static __global__ __launch_bounds__(64) void msm_rowcol_terms_kernel(const uint3
 // sums the same way and converts.  Two launches, each a few mixed / full additions per lane and a 64-lane tree whose additions run on
 // quads of lanes (msm_wave_tree_sum: 7 passes of ~3 k instructions); the host epilogue is the weighted sum of <= 20 plane sums (one
 // doubling and one addition each).  Same group element, so the same affine commitment.  0.245 ms at 2^8, 0.47 ms at 2^12.
+// A BATCH of such commits (the rounds of a small MultilinearKZG::open against their level tables) takes the same two launches: the
+// slots are dealt to the problems in proportion to their pairs, a problem's planes are its own digit width.
+constexpr int MSM_SMALL_PROBS = 16;
 struct MsmSmallArgs {
-    const uint32_t* table;       // [w * stride + i]: 2^(first bit of window w) * point i, affine, 28-bit limbs
-    const uint64_t* scalars;     // n, Montgomery
-    const uint8_t* inf;          // n flags or nullptr
-    uint32_t* partials;          // [plane * n_slots + slot], XYZZ
-    uint64_t* terms;             // [plane], XYZZ in the arkworks layout (4 x 48 B)
-    uint32_t n, stride, W, hi, n_hi, n_slots, planes;
+    const uint32_t* table;       // problem j: [tab_off[j] + w * stride[j] + i]: 2^(first bit of window w) * point i, affine, 28-bit limbs
+    const uint64_t* scalars;     // problem j: n[j] of them from sc_off[j] on, Montgomery
+    const uint8_t* inf;          // flags of the points (indexed like the scalars) or nullptr
+    uint32_t* partials;          // [plane * total_slots + slot], XYZZ
+    uint64_t* terms;             // [j * planes + plane], XYZZ in the arkworks layout (4 x 48 B)
+    uint32_t nprob, planes, total_slots;
+    uint32_t n[MSM_SMALL_PROBS], stride[MSM_SMALL_PROBS], W[MSM_SMALL_PROBS], hi[MSM_SMALL_PROBS], n_hi[MSM_SMALL_PROBS];
+    uint32_t tab_off[MSM_SMALL_PROBS], sc_off[MSM_SMALL_PROBS], slot_first[MSM_SMALL_PROBS + 1];
 };
 static __global__ __launch_bounds__(64) void msm_small_planes_kernel(MsmSmallArgs a) {
     const uint32_t slot = blockIdx.x, plane = blockIdx.y, lane = threadIdx.x;
-    const uint32_t pairs = a.n * a.W, lanes_total = a.n_slots * 64;
+    uint32_t j = 0;
+    while (j + 1 < a.nprob && slot >= a.slot_first[j + 1]) ++j;
+    if (plane >= a.hi[j]) return;                                   // |digit| <= 2^(hi - 1): bits 0 .. hi - 1
+    const uint32_t n = a.n[j], pairs = n * a.W[j], s = slot - a.slot_first[j], lanes_total = (a.slot_first[j + 1] - a.slot_first[j]) * 64;
+    const uint32_t hi = a.hi[j], n_hi = a.n_hi[j];
     G1XyzzU acc = G1XyzzU::identity();
-    for (uint32_t p = slot * 64 + lane; p < pairs; p += lanes_total) {
-        const uint32_t w = p / a.n, i = p - w * a.n;
-        if (a.inf && a.inf[i]) continue;
-        DigitStream ds(load_fr(a.scalars, i).from_mont());
+    for (uint32_t p = s * 64 + lane; p < pairs; p += lanes_total) {
+        const uint32_t w = p / n, i = p - w * n;
+        if (a.inf && a.inf[a.sc_off[j] + i]) continue;
+        DigitStream ds(load_fr(a.scalars, (size_t)a.sc_off[j] + i).from_mont());
         int32_t d = 0;
-        for (uint32_t v = 0; v <= w; ++v) d = ds.next(v < a.n_hi ? a.hi : a.hi - 1);
+        for (uint32_t v = 0; v <= w; ++v) d = ds.next(v < n_hi ? hi : hi - 1);
         const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-        if ((mag >> plane) & 1u) g1u_madd(acc, load_affine_u(a.table, (size_t)w * a.stride + i), d < 0);
+        if ((mag >> plane) & 1u) g1u_madd(acc, load_affine_u(a.table, (size_t)a.tab_off[j] + (size_t)w * a.stride[j] + i), d < 0);
     }
     msm_wave_tree_sum(acc, 64);
-    if (lane == 0) store_xyzz_u(a.partials, (size_t)plane * a.n_slots + slot, acc);
+    if (lane == 0) store_xyzz_u(a.partials, (size_t)plane * a.total_slots + slot, acc);
 }
 static __global__ __launch_bounds__(64) void msm_small_reduce_kernel(MsmSmallArgs a) {
-    const uint32_t plane = blockIdx.x, lane = threadIdx.x;
+    const uint32_t plane = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+    if (plane >= a.hi[j]) return;
+    const uint32_t s0 = a.slot_first[j], ns = a.slot_first[j + 1] - s0;
     G1XyzzU acc = G1XyzzU::identity();
-    for (uint32_t s = lane; s < a.n_slots; s += 64) {
-        const G1XyzzU v = load_xyzz_u(a.partials, (size_t)plane * a.n_slots + s);
+    for (uint32_t s = lane; s < ns; s += 64) {
+        const G1XyzzU v = load_xyzz_u(a.partials, (size_t)plane * a.total_slots + s0 + s);
         g1u_add(acc, v);
     }
     msm_wave_tree_sum(acc, 64);
     if (lane == 0) {
-        uint64_t* o = a.terms + 24 * (size_t)plane;
+        uint64_t* o = a.terms + 24 * ((size_t)j * a.planes + plane);
         store_fq(o, fqu_to_ark(acc.x));
         store_fq(o + 6, fqu_to_ark(acc.y));
         store_fq(o + 12, fqu_to_ark(acc.zz));
@@ -707,6 +718,39 @@ static __global__ __launch_bounds__(MSM_BLOCK) void msm_shift_points_kernel(cons
     store_fq(o + 6, fqu_to_ark(acc.y));
     store_fq(o + 12, fqu_to_ark(acc.zz));
     store_fq(o + 18, fqu_to_ark(acc.zzz));
+}
+
+// ---- level tables of a SMALL SRS in one go (zkhip_srs_level_tables, n <= 2^12) ----------------------------------------------------------
+// The window-by-window build (shift, batched affine conversion, layout conversion: three launches per window, ~30 windows per level,
+// a dozen levels) is latency from end to end: 0.3-0.4 s for a table of a few MiB.  Here a lane owns a point of a level and walks its
+// windows itself (all the doublings of a point: ~256, ~2 ms), every window's XYZZ goes to ONE batched affine conversion.
+struct MsmSmallTabArgs {
+    uint32_t n_levels, total_points;
+    uint32_t h[MSM_SMALL_PROBS], pt_off[MSM_SMALL_PROBS], tab_off[MSM_SMALL_PROBS], W[MSM_SMALL_PROBS], hi[MSM_SMALL_PROBS], n_hi[MSM_SMALL_PROBS];
+};
+static __global__ __launch_bounds__(64) void msm_small_level_windows_kernel(MsmSmallTabArgs a, const uint32_t* __restrict__ points_u /* the levels' points, internal affine layout, in level order */,
+                                                                     uint64_t* __restrict__ out_xyzz /* [table entry] */) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= a.total_points) return;
+    uint32_t j = 0;
+    while (j + 1 < a.n_levels && t >= a.pt_off[j + 1]) ++j;
+    const uint32_t i = t - a.pt_off[j], h = a.h[j];
+    const G1AffineU p = load_affine_u(points_u, t);
+    const bool zero = p.x.all_zero() && p.y.all_zero();
+    G1XyzzU acc;
+    acc.x = p.x; acc.y = p.y; acc.zz = zero ? FqU::zero() : FqU::one(); acc.zzz = acc.zz;
+    for (uint32_t w = 0; w < a.W[j]; ++w) {
+        if (w) {
+            const uint32_t width = w - 1 < a.n_hi[j] ? a.hi[j] : a.hi[j] - 1;       // the window before this one
+            if (w == 1 && !zero) { acc = g1u_double_affine(p); for (uint32_t k = 1; k < width; ++k) acc = g1u_double(acc); }
+            else for (uint32_t k = 0; k < width; ++k) acc = g1u_double(acc);
+        }
+        uint64_t* o = out_xyzz + 24 * ((size_t)a.tab_off[j] + (size_t)w * h + i);
+        store_fq(o, fqu_to_ark(acc.x));
+        store_fq(o + 6, fqu_to_ark(acc.y));
+        store_fq(o + 12, fqu_to_ark(acc.zz));
+        store_fq(o + 18, fqu_to_ark(acc.zzz));
+    }
 }
 
 }  // namespace zk

@@ -316,6 +316,8 @@ class MultilinearKZG:
             fxy, finf = srs.folded()
             fxy_p, finf_p = N.ptr(fxy), N.ptr(finf)
             tables = getattr(srs, "_level_tables", None)       # present after srs.precompute_open(); folded() has just run the cache guard
+            if tables is None and n <= TrustedSetup.SMALL_SRS:  # a small SRS builds them on first use (a few ms): its openings take the
+                tables = srs.precompute_open()._level_tables    # short path, two launches for all rounds (zkhip_kzg_open_tables)
         else:
             fxy_p = finf_p = None
         st = N.lib().zkhip_kzg_open_tables(ctx.handle, N.ptr(poly.evaluations), C.c_size_t(n), pts.ctypes.data_as(C.c_void_p),
