@@ -65,6 +65,45 @@ __global__ void message_kernel(const uint32_t* blocks, int reps, uint32_t* out) 
         for (int i = 0; i < 8; ++i) out[i] = h[i];
 }
 
+// ... and beside eleven other waves of its workgroup (as in the closing kernels): idle, multiplying field elements, or streaming LDS
+template <int OTHERS> __global__ __launch_bounds__(768) void message_beside_kernel(const uint32_t* blocks, int reps, uint32_t* out) {
+    __shared__ uint32_t kw[64 * 4];
+    __shared__ uint32_t msg[16 * 4];
+    __shared__ uint32_t ready[4];
+    __shared__ uint32_t traffic[8192];
+    __shared__ volatile uint32_t done;
+    if (threadIdx.x < 64) {
+        sha256_schedule_rows_to_lds(blocks[threadIdx.x], kw + 64 * (threadIdx.x >> 4), nullptr, 0u, 0u, true);
+        msg[threadIdx.x] = blocks[threadIdx.x];
+        if (threadIdx.x < 4) ready[threadIdx.x] = 4;
+        if (threadIdx.x == 0) done = 0;
+    }
+    for (uint32_t i = threadIdx.x; i < 8192; i += 768) traffic[i] = i * 2654435761u;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+        for (int r = 0; r < reps; ++r) sha256_message_split(h, msg, kw, ready, 4);
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < 8; ++i) out[i] = h[i];
+            done = 1;
+        }
+    } else {
+        Fr a = Fr::one(), b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b.l[i] = traffic[(threadIdx.x + i) & 8191] | 1u;
+        uint32_t x = threadIdx.x;
+        while (!done) {
+            if (OTHERS == 0) __builtin_amdgcn_s_sleep(8);
+            if (OTHERS == 1 || OTHERS == 3) a = fr_mul_outlined(a, b);
+            if (OTHERS == 2 || OTHERS == 3) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { x = traffic[x & 8191] + k; traffic[(x >> 7) & 8191] = x; }
+            }
+        }
+        if (a.l[0] == 0x12345678u && x == 77u) out[20] = a.l[1];
+    }
+}
+
 static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 static void host_compress(uint32_t h[8], const uint32_t* blk) {
     static const uint32_t K[64] = {
@@ -134,6 +173,20 @@ int main() {
         for (int i = 0; i < 8; ++i) same = same && got[i] == want[i];
         bad += !same;
         std::printf("%-34s %7.3f us per message of 4 blocks   digest %s\n", "sha256_message_split", 1e3 * ms / reps, same ? "matches the host's" : "DIFFERS");
+    }
+    for (int others = 0; others < 4; ++others) {
+        const int r2 = 400;
+        for (int pass = 0; pass < 2; ++pass) {
+            hipEventRecord(a);
+            if (others == 0) hipLaunchKernelGGL(message_beside_kernel<0>, dim3(1), dim3(768), 0, 0, d_blk, r2, d_out);
+            if (others == 1) hipLaunchKernelGGL(message_beside_kernel<1>, dim3(1), dim3(768), 0, 0, d_blk, r2, d_out);
+            if (others == 2) hipLaunchKernelGGL(message_beside_kernel<2>, dim3(1), dim3(768), 0, 0, d_blk, r2, d_out);
+            if (others == 3) hipLaunchKernelGGL(message_beside_kernel<3>, dim3(1), dim3(768), 0, 0, d_blk, r2, d_out);
+            hipEventRecord(b); hipEventSynchronize(b);
+        }
+        float ms = 0; hipEventElapsedTime(&ms, a, b);
+        const char* what[4] = {"asleep", "multiplying field elements", "streaming LDS", "multiplying and streaming LDS"};
+        std::printf("sha256_message_split beside 11 waves %-30s %7.3f us per message of 4 blocks\n", what[others], 1e3 * ms / r2);
     }
     return bad;
 }
