@@ -227,6 +227,30 @@ static __global__ __launch_bounds__(MLE_BLOCK) void open_step_kernel(const uint6
     }
 }
 
+// All rounds of a SMALL opening (n <= 2^12) in one launch: a single workgroup walks the rounds, the remainders ping-pong between the
+// two scratch tables exactly as the per-round launches leave them (round i reads `in` / ping / pong, writes quotients at their level's
+// offset and the remainder to ping (i even) or pong (i odd)); a barrier between rounds -- one workgroup: what it stored is visible to it.
+static __global__ __launch_bounds__(MLE_BLOCK) void open_steps_small_kernel(const uint64_t* __restrict__ in, uint32_t n, PtsArg z_pts, uint32_t n_rounds,
+                                                                     uint64_t* __restrict__ quotients, uint64_t* ping, uint64_t* pong) {
+    const uint64_t* cur = in;
+    uint32_t cn = n, off = 0;
+    for (uint32_t i = 0; i < n_rounds; ++i) {
+        const Fr z = fr_from_pts(z_pts, i);
+        uint64_t* rem = (i & 1) ? pong : ping;
+        const uint32_t h = cn >> 1;
+        for (uint32_t j = threadIdx.x; j < h; j += MLE_BLOCK) {
+            const Fr lo = load_fr(cur, j), hi = load_fr(cur, (size_t)j + h);
+            const Fr d = hi - lo;
+            store_fr(quotients, (size_t)off + j, d);
+            store_fr(rem, j, lo + z * d);
+        }
+        __syncthreads();
+        off += h;
+        cur = rem;
+        cn = h;
+    }
+}
+
 // ---- Horner suffix scan: UnivariateKZG::open ---------------------------------------------------------------
 // V_i = sum_{j >= i} c_j z^(j-i)  (V_i = c_i + z V_{i+1}, V_n = 0).  V_0 = p(z) is DenseUnivariatePolynomial::evaluate
 // (dense_univariate.rs:184-196) and V_1 .. V_{n-1} are the coefficients of the quotient (p(x) - k) / (x - z) for any

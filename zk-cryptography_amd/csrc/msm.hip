@@ -722,11 +722,20 @@ extern "C" int zkhip_kzg_open_tables(zkhip_ctx* c, const uint64_t* d_evals, size
     uint32_t batch_first_round = 0;
     struct Large { uint32_t round; size_t off, h; };
     std::vector<Large> large;
+    // (a small opening against its tables -- the short path below -- takes all its rounds in ONE launch: a dozen 5 us launches otherwise)
+    const bool small_open = d_level_tables && n <= MSM_SMALL_MAX && OPEN_BATCH_MAX == OPEN_BATCH_MAX_DEFAULT && msm_small_on() && n_vars <= (uint32_t)ZK_MAX_ROUNDS;
+    if (small_open) {
+        PtsArg zp = {};
+        std::memcpy(zp.v, h_points, 32 * (size_t)n_vars);
+        hipLaunchKernelGGL(open_steps_small_kernel, dim3(1), dim3(MLE_BLOCK), 0, c->stream, d_evals, (uint32_t)n, zp, n_vars, d_q, (uint64_t*)(aux + o_ping),
+                           (uint64_t*)(aux + o_pong));
+    }
     for (uint32_t i = 0; i < n_vars; ++i) {
         FrArg z = {};
         std::memcpy(z.v, h_points + 4 * (size_t)i, 32);
         uint64_t* rem = (uint64_t*)(aux + ((i & 1) ? o_pong : o_ping));
-        hipLaunchKernelGGL(open_step_kernel, dim3(mle_grid_stream(cn / 2)), dim3(MLE_BLOCK), 0, c->stream, cur, cn, z, d_q + 4 * lvl_off, rem);
+        if (!small_open)
+            hipLaunchKernelGGL(open_step_kernel, dim3(mle_grid_stream(cn / 2)), dim3(MLE_BLOCK), 0, c->stream, cur, cn, z, d_q + 4 * lvl_off, rem);
         const size_t h = cn / 2;   // |q_i| = |S_i|
         if (h > OPEN_BATCH_MAX) {
             large.push_back({i, lvl_off, h});
@@ -740,7 +749,7 @@ extern "C" int zkhip_kzg_open_tables(zkhip_ctx* c, const uint64_t* d_evals, size
         cn = h;
     }
     ZK_HIP(c, hipGetLastError());
-    if (d_level_tables && large.empty() && batch.n && batch.n <= (uint32_t)MSM_SMALL_PROBS && n <= MSM_SMALL_MAX && msm_small_on()) {
+    if (small_open && large.empty() && batch.n && batch.n <= (uint32_t)MSM_SMALL_PROBS) {
         // a small opening against its level tables: every round's quotient commit is a plain sum per digit bit (msm_small_batch) --
         // two launches for all rounds instead of the bucket pipeline's seventeen (0.96 -> 0.6x ms at 2^12)
         MsmSmallProblem sp[MSM_SMALL_PROBS];
