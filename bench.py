@@ -605,6 +605,35 @@ def bench_gkr(args, zk, N, D, rank, world, barrier, dist, torch, np):
         dt = sorted(bs)[len(bs) // 2] / reps
         out["ms_per_proof"]["depth_%d" % depth] = round(1e3 * dt, 3)
         out.setdefault("batches", {})["depth_%d" % depth] = _stats([b_ / reps for b_ in bs], 1e3, 3)
+        if world == 1 and not args.no_pipelined:
+            # informational: the same proofs from several host threads at once -- a context (and a stream) per thread, ONE Circuit (a device
+            # copy per context).  A proof keeps one workgroup busy most of the time, so independent proofs share the chip.
+            import threading
+            want = [p_.to_bytes() for p_ in zk.GKRProtocol.prove(circuit, ev).sumcheck_proofs]
+            flight = {}
+            for n_thr in (4, 8):
+                per, spans, ok = 4, [None] * n_thr, [True] * n_thr
+                gate = threading.Barrier(n_thr)
+
+                def work(k):
+                    with torch.cuda.stream(torch.cuda.Stream()):
+                        zk.GKRProtocol.prove(circuit, ev)
+                        torch.cuda.synchronize()
+                        gate.wait()
+                        t1 = time.perf_counter()
+                        for _ in range(per):
+                            pr = zk.GKRProtocol.prove(circuit, ev)
+                        spans[k] = (t1, time.perf_counter())
+                        ok[k] = [p_.to_bytes() for p_ in pr.sumcheck_proofs] == want
+                ths = [threading.Thread(target=work, args=(k,)) for k in range(n_thr)]
+                for t_ in ths: t_.start()
+                for t_ in ths: t_.join()
+                assert all(ok), "proofs from concurrent threads differ from the synchronous proof"
+                flight[str(n_thr)] = round(1e3 * (max(b_ for _, b_ in spans) - min(a_ for a_, _ in spans)) / (n_thr * per), 3)
+            out.setdefault("threads_in_flight", {})["depth_%d" % depth] = flight
+            out["threads_in_flight"]["note"] = ("ms per proof with 4 / 8 host threads proving at once (a zkhip context and a stream each, one Circuit); "
+                                                "every proof equal to the synchronous one (asserted).  How far the proofs overlap depends on how the threads' streams fall on "
+                                                "the four hardware queues: a fresh process (tools/gkr_threads.py) reaches 2.6 ms per depth-20 proof with 8 threads")
     # BASELINE configs[3]: ONE depth-20 proof with every layer's sumcheck sharded over the ranks (GKRProtocol.prove_sharded:
     # the layer tables are built on every rank, the rounds over b and c run on shards with one record all-gathered per round)
     # next to the replicated figure above -- whichever is faster is the answer to "should GKR shard at this width"
@@ -1132,7 +1161,8 @@ def main():
                 "composed_k5_2^%d_ms" % args.composed_log_n: g(composed_shapes, "composed_k5_2^%d" % args.composed_log_n, "ms_per_prove"),
                 "composed_k5_2^%d_frac" % args.composed_log_n: g(composed_shapes, "composed_k5_2^%d" % args.composed_log_n, "frac_of_hbm"),
                 "multi_composed_2_3_ms": g(composed_shapes, "multi_composed_2_3_2^20", "ms_per_prove"), "multi_composed_2_3_frac": g(composed_shapes, "multi_composed_2_3_2^20", "frac_of_hbm"),
-                "gkr8_ms": g(gkr, "ms_per_proof", "depth_8"), "gkr20_ms": g(gkr, "ms_per_proof", "depth_20"), "gkr20_sharded_ms": g(gkr, "sharded", "ms_per_proof"),
+                "gkr8_ms": g(gkr, "ms_per_proof", "depth_8"), "gkr20_ms": g(gkr, "ms_per_proof", "depth_20"),
+                "gkr8_8_threads_ms": g(gkr, "threads_in_flight", "depth_8", "8"), "gkr20_8_threads_ms": g(gkr, "threads_in_flight", "depth_20", "8"), "gkr20_sharded_ms": g(gkr, "sharded", "ms_per_proof"),
                 "h2d_step_ms": g(h2d, "sumcheck", "ms_per_step"),
                 "cpu_1core_mevals_s": round(g(cpu, "value") / 1e6, 2) if g(cpu, "value") else None,
                 "cpu_msm_1core_points_s": g(msm, "cpu_baseline", "value"),

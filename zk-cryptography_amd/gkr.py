@@ -8,6 +8,7 @@ is host-side in the reference and out of scope; tests check proofs wi
 """
 import ctypes as C
 import hashlib
+import threading
 
 import numpy as np
 
@@ -219,6 +220,9 @@ def _fadd(a, b):
     return Fr.from_int((Fr.to_ints(a)[0] + Fr.to_ints(b)[0]) % R_MOD)
 
 
+_DEVICE_CIRCUITS_LOCK = threading.Lock()      # guards the per-Circuit lists of device copies (GKRProtocol._device_circuit)
+
+
 class _DeviceCircuit:
     """zkhip_circuit handle (include/zkhip.h): the circuit's gate arrays and CSR groupings resident in HBM."""
 
@@ -304,11 +308,21 @@ class GKRProtocol:
         (identity, not id(): no address reuse) and their gate lists' mutation counters."""
         shape = [len(layer.layer) for layer in circuit.layers]
         stamp = circuit._stamp()
-        dev = getattr(circuit, "_device", None)
-        if dev is None or dev.shape != shape or dev.ctx is not ctx or len(dev.stamp) != len(stamp) or \
-                any(a[0] is not b[0] or a[1] is not b[1] or a[2] != b[2] for a, b in zip(dev.stamp, stamp)):
-            dev = circuit._device = _DeviceCircuit(ctx, circuit, shape)
-            dev.stamp = stamp
+
+        def fresh(dev):
+            return dev.shape == shape and len(dev.stamp) == len(stamp) and \
+                all(a[0] is b[0] and a[1] is b[1] and a[2] == b[2] for a, b in zip(dev.stamp, stamp))
+        # one device copy per CONTEXT (contexts are per host thread: several threads may prove one Circuit at once, each on its own
+        # stream); copies of an older circuit state are dropped
+        with _DEVICE_CIRCUITS_LOCK:
+            devs = [d for d in getattr(circuit, "_devices", ()) if d.ctx.handle and fresh(d)]
+            dev = next((d for d in devs if d.ctx is ctx), None)
+            if dev is None:
+                dev = _DeviceCircuit(ctx, circuit, shape)
+                dev.stamp = stamp
+                devs.append(dev)
+            circuit._devices = devs
+            circuit._device = dev                  # (the copy of the last call: what the tests look at)
         return dev
 
     @staticmethod
