@@ -185,6 +185,37 @@ def test_threads_as_ranks_run_the_in_library_sharded_provers(zk, ora, world):
     assert len(set(exchanges)) == 1 and exchanges[0] > 10                  # every rank took part in every exchange
 
 
+@pytest.mark.parametrize("n_threads", [4])
+def test_threads_prove_one_circuit_at_once_each_on_its_own_stream(zk, ora, n_threads):
+    """Several host threads, a context and a stream each, prove ONE Circuit object at the same time (how a prover gets GKR throughput:
+    tools/gkr_threads.py): the mirror keeps a device copy of the circuit per context, every proof is the synchronous one."""
+    import torch
+    depth = 7
+    circuit = zk.Circuit.random(depth)
+    inp = ora.random_fr(2 ** depth, 9100)
+    ev = circuit.evaluation(inp)
+    want = [p.to_bytes() for p in zk.GKRProtocol.prove(circuit, ev).sumcheck_proofs]
+    got, errors, gate = [None] * n_threads, [], threading.Barrier(n_threads)
+
+    def work(k):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                gate.wait()
+                for _ in range(6):
+                    pr = zk.GKRProtocol.prove(circuit, ev)
+                    assert [p.to_bytes() for p in pr.sumcheck_proofs] == want
+                got[k] = True
+        except BaseException as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors and all(got), errors
+    assert len(circuit._devices) == n_threads + 1            # the main thread's copy and one per worker context
+
+
 def test_soak_create_destroy_and_aborted_sessions_return_all_memory(zk, ora):
     """2000 cycles each of context create / destroy (with work in between), zkhip_sc_begin / _abort, zkhip_mc_begin / _abort,
     commit_begin / _end and comm create / destroy: free device memory before = after (hipMemGetInfo), and the context still proves."""
