@@ -632,8 +632,8 @@ def bench_gkr(args, zk, N, D, rank, world, barrier, dist, torch, np):
                 flight[str(n_thr)] = round(1e3 * (max(b_ for _, b_ in spans) - min(a_ for a_, _ in spans)) / (n_thr * per), 3)
             out.setdefault("threads_in_flight", {})["depth_%d" % depth] = flight
             out["threads_in_flight"]["note"] = ("ms per proof with 4 / 8 host threads proving at once (a zkhip context and a stream each, one Circuit); "
-                                                "every proof equal to the synchronous one (asserted).  How far the proofs overlap depends on how the threads' streams fall on "
-                                                "the four hardware queues: a fresh process (tools/gkr_threads.py) reaches 2.6 ms per depth-20 proof with 8 threads")
+                                                "every proof equal to the synchronous one (asserted).  The bound is the process's kernel-launch rate (~430 launches per depth-20 proof): "
+                                                "a fresh process (tools/gkr_threads.py) reaches 2.6 ms per depth-20 proof with 8 threads")
     # BASELINE configs[3]: ONE depth-20 proof with every layer's sumcheck sharded over the ranks (GKRProtocol.prove_sharded:
     # the layer tables are built on every rank, the rounds over b and c run on shards with one record all-gathered per round)
     # next to the replicated figure above -- whichever is faster is the answer to "should GKR shard at this width"
