@@ -605,35 +605,21 @@ def bench_gkr(args, zk, N, D, rank, world, barrier, dist, torch, np):
         dt = sorted(bs)[len(bs) // 2] / reps
         out["ms_per_proof"]["depth_%d" % depth] = round(1e3 * dt, 3)
         out.setdefault("batches", {})["depth_%d" % depth] = _stats([b_ / reps for b_ in bs], 1e3, 3)
-        if world == 1 and not args.no_pipelined:
-            # informational: the same proofs from several host threads at once -- a context (and a stream) per thread, ONE Circuit (a device
-            # copy per context).  A proof keeps one workgroup busy most of the time, so independent proofs share the chip.
-            import threading
-            want = [p_.to_bytes() for p_ in zk.GKRProtocol.prove(circuit, ev).sumcheck_proofs]
-            flight = {}
-            for n_thr in (4, 8):
-                per, spans, ok = 4, [None] * n_thr, [True] * n_thr
-                gate = threading.Barrier(n_thr)
-
-                def work(k):
-                    with torch.cuda.stream(torch.cuda.Stream()):
-                        zk.GKRProtocol.prove(circuit, ev)
-                        torch.cuda.synchronize()
-                        gate.wait()
-                        t1 = time.perf_counter()
-                        for _ in range(per):
-                            pr = zk.GKRProtocol.prove(circuit, ev)
-                        spans[k] = (t1, time.perf_counter())
-                        ok[k] = [p_.to_bytes() for p_ in pr.sumcheck_proofs] == want
-                ths = [threading.Thread(target=work, args=(k,)) for k in range(n_thr)]
-                for t_ in ths: t_.start()
-                for t_ in ths: t_.join()
-                assert all(ok), "proofs from concurrent threads differ from the synchronous proof"
-                flight[str(n_thr)] = round(1e3 * (max(b_ for _, b_ in spans) - min(a_ for a_, _ in spans)) / (n_thr * per), 3)
-            out.setdefault("threads_in_flight", {})["depth_%d" % depth] = flight
-            out["threads_in_flight"]["note"] = ("ms per proof with 4 / 8 host threads proving at once (a zkhip context and a stream each, one Circuit); "
-                                                "every proof equal to the synchronous one (asserted).  The bound is the process's kernel-launch rate (~430 launches per depth-20 proof): "
-                                                "a fresh process (tools/gkr_threads.py) reaches 2.6 ms per depth-20 proof with 8 threads")
+    if world == 1 and not args.no_gkr_threads:
+        # informational: independent proofs from several host threads at once -- a context and a stream per thread, ONE Circuit (a device copy
+        # per context).  A proof keeps one workgroup busy most of the time, so independent proofs share the chip; what bounds them is the
+        # process's kernel-launch rate (~430 launches per depth-20 proof).  Measured in a child process of its own (tools/gkr_threads.py: the
+        # same library, no other leg's streams and contexts beside it; every thread's proofs compared with a synchronous one there).
+        try:
+            import subprocess
+            kid = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "gkr_threads.py"), "--json", "8:8", "20:4,8"],
+                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+            lines = [l_ for l_ in kid.stdout.decode().splitlines() if l_.startswith("{")]
+            out["threads_in_flight"] = json.loads(lines[-1]) if kid.returncode == 0 and lines else {"error": "child exited with %d" % kid.returncode}
+        except Exception as e:      # noqa: BLE001 -- an informational leg never fails the bench
+            out["threads_in_flight"] = {"error": repr(e)}
+        out["threads_in_flight"]["note"] = ("ms per proof with 4 / 8 host threads proving at once (a zkhip context and a stream each, one Circuit), in a process "
+                                            "of its own; every proof equal to the synchronous one (asserted there)")
     # BASELINE configs[3]: ONE depth-20 proof with every layer's sumcheck sharded over the ranks (GKRProtocol.prove_sharded:
     # the layer tables are built on every rank, the rounds over b and c run on shards with one record all-gathered per round)
     # next to the replicated figure above -- whichever is faster is the answer to "should GKR shard at this width"
@@ -858,6 +844,7 @@ def main():
     ap.add_argument("--no-fold", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="diagnostic: run the sharded prover protocol even on one GPU")
     ap.add_argument("--no-h2d", action="store_true")
+    ap.add_argument("--no-gkr-threads", action="store_true", help="skip the GKR proofs-from-several-threads leg")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the proofs-in-flight leg (profiling: keeps the kernel averages those of the synchronous steps)")
     ap.add_argument("--config4-log-n", type=int, default=23, help="N > 1: log2 of the per-GPU points of the configs[4]-shaped commit (2^26 over 8 = 2^23)")
     ap.add_argument("--no-exchange", action="store_true", help="skip the exchange-cost measurement and the N = 8 prediction")
