@@ -612,7 +612,7 @@ def bench_gkr(args, zk, N, D, rank, world, barrier, dist, torch, np):
         # same library, no other leg's streams and contexts beside it; every thread's proofs compared with a synchronous one there).
         try:
             import subprocess
-            kid = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "gkr_threads.py"), "--json", "8:8", "20:4,8"],
+            kid = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "gkr_threads.py"), "--json", "20:4,8"],
                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
             lines = [l_ for l_ in kid.stdout.decode().splitlines() if l_.startswith("{")]
             out["threads_in_flight"] = json.loads(lines[-1]) if kid.returncode == 0 and lines else {"error": "child exited with %d" % kid.returncode}
@@ -1149,7 +1149,7 @@ def main():
                 "composed_k5_2^%d_frac" % args.composed_log_n: g(composed_shapes, "composed_k5_2^%d" % args.composed_log_n, "frac_of_hbm"),
                 "multi_composed_2_3_ms": g(composed_shapes, "multi_composed_2_3_2^20", "ms_per_prove"), "multi_composed_2_3_frac": g(composed_shapes, "multi_composed_2_3_2^20", "frac_of_hbm"),
                 "gkr8_ms": g(gkr, "ms_per_proof", "depth_8"), "gkr20_ms": g(gkr, "ms_per_proof", "depth_20"),
-                "gkr8_8_threads_ms": g(gkr, "threads_in_flight", "depth_8", "8"), "gkr20_8_threads_ms": g(gkr, "threads_in_flight", "depth_20", "8"), "gkr20_sharded_ms": g(gkr, "sharded", "ms_per_proof"),
+                "gkr20_8_threads_ms": g(gkr, "threads_in_flight", "depth_20", "8"), "gkr20_sharded_ms": g(gkr, "sharded", "ms_per_proof"),
                 "h2d_step_ms": g(h2d, "sumcheck", "ms_per_step"),
                 "cpu_1core_mevals_s": round(g(cpu, "value") / 1e6, 2) if g(cpu, "value") else None,
                 "cpu_msm_1core_points_s": g(msm, "cpu_baseline", "value"),
