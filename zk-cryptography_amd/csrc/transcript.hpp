@@ -3,7 +3,8 @@
 // Replaces transcripts/fiat-shamir/src/fiat_shamir.rs:10-40 (SHA-256 hash chain:
 // commit = update; challenge = finalize, reset, re-seed with the digest;
 // evaluate_challenge_into_field = from_be_bytes_mod_order) so that the sumcheck
-// round loop never leaves the GPU between rounds.  One lane runs it; the state
+// round loop never leaves the GPU between rounds.  One WAVE runs it -- the state
+// rounds on six of its lanes, the message schedule on sixteen (below) -- and the state
 // lives in global memory between kernels.
 #pragma once
 #include "fp.hpp"
