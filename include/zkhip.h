@@ -204,8 +204,8 @@ int zkhip_gkr_layer_tables_sharded(zkhip_circuit *circuit, uint32_t layer, const
 int zkhip_sumcheck_plan_log_blocks(size_t n);
 int zkhip_mle_block_sums(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, uint32_t log_blocks, uint64_t *d_out,
                          uint64_t *h_total);
-/* The same block sums with the TOTAL deferred where it would cost a launch of its own (the fine granularity of 2^19..2^24-entry
- * tables): zkhip_sumcheck_prove with both claimed-sum arguments NULL absorbs the true sum out of its own sum tree, so a
+/* The same block sums with the TOTAL deferred where it would cost a launch of its own (the fine granularity of 2^24-entry
+ * tables, the overlapped plan): zkhip_sumcheck_prove with both claimed-sum arguments NULL absorbs the true sum out of its own sum tree, so a
  * poly_sum() whose caller proves next need not compute it; zkhip_mle_block_sums_total (two small launches + a copy) delivers it
  * to d_block_sums + 4 * 2^log_blocks and h_total[4] when the caller wants to read `self.sum` first. */
 int zkhip_mle_block_sums_deferred(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, uint32_t log_blocks, uint64_t *d_out);

@@ -140,18 +140,18 @@ def test_proofs_in_flight_without_poly_sum_and_same_table(zk, ora):
     assert np.array_equal(proof.univariate_poly, rp) and np.array_equal(ch, och)
 
 
-@pytest.mark.parametrize("log_n", [19, 21])
+@pytest.mark.parametrize("log_n", [21, 24])
 def test_poly_sum_with_the_total_deferred(zk, ora, log_n):
-    """Tables of 2^19..2^24 entries: poly_sum() leaves the total to prove()'s own sum tree (zkhip_mle_block_sums_deferred).  The
-    proof absorbs the true sum either way, `sum` read before or after the proof is the true sum, and a sum the caller overrides
-    is absorbed as given."""
+    """Tables of 2^24 entries (the overlapped plan; the stage plan below that since round 5: tools/step_sizes.py): poly_sum() leaves the
+    total to prove()'s own sum tree (zkhip_mle_block_sums_deferred).  The proof absorbs the true sum either way, `sum` read before or
+    after the proof is the true sum, and a sum the caller overrides is absorbed as given -- at 2^21 (total computed by poly_sum) too."""
     evals = ora.random_fr(1 << log_n, 7100 + log_n)
     ws, wrp, wch = ora.sumcheck_prove(evals)
     poly = zk.Multilinear(evals)
     sc = zk.Sumcheck(poly)
     sc.poly_sum()
-    assert sc._sum_deferred
-    proof, ch = sc.prove()                                   # the total never computed by poly_sum
+    assert sc._sum_deferred == (log_n == 24)
+    proof, ch = sc.prove()                                   # (2^24: the total never computed by poly_sum)
     assert np.array_equal(proof.sum, ws) and np.array_equal(proof.univariate_poly, wrp) and np.array_equal(ch, wch)
     assert np.array_equal(sc.sum, ws)                        # ... and delivered on demand
     sc2 = zk.Sumcheck(poly)

@@ -519,14 +519,23 @@ static inline uint32_t stage_k(size_t cur_n) {
     if (k > MF_MAX_LOGK) k = MF_MAX_LOGK;
     return k;                                                  // >= 3 here
 }
-// Overlapped plan (tables of 2^19 .. 2^24 entries).  Identity (1) of multifold_kernels.hpp applied twice: with FINE block
+// Overlapped plan (tables of 2^24 entries; measured against the stage plan at every size with the rounds at 4.5 us, tools/step_sizes.py:
+// 2^19 192 / 158 us, 2^20 201 / 171, 2^21 216 / 199, 2^22 230 / 218, 2^23 259 / 253, 2^24 322 / 347 -- only where the fold is long
+// enough to hide ten rounds does running them beside it pay for the two extra launches).  Identity (1) of multifold_kernels.hpp applied twice: with FINE block
 // sums B_g (2^g blocks of 256 entries, g = lg - 8) the first k1 rounds run on B_k1 (grouped B_g) and the next k2 = g - k1
 // rounds on fold_k1(B_g; r_1..r_k1) -- a table of 2^k2 <= 1024 entries -- so rounds k1+1 .. g need the first k1 challenges
 // but NOT the folded big table.  The streaming k1-variable fold of the big table therefore runs on a side stream next to
 // the serial kernel of those rounds and is joined before the fold by the next k2 variables.  k2 is as large as the serial
 // kernel takes (10), so that the fold starts as early as possible: 2^24 = 6 rounds | fold (100 us) next to 10 rounds | 8
 // rounds.  Same values as the round-by-round loop, bit for bit.
-static inline bool overlapped_plan(size_t n) { return is_pow2(n) && n >= ((size_t)1 << 19) && n <= ((size_t)1 << 24); }
+static inline uint32_t overlapped_min_log() {       // (ZKHIP_OVERLAP_MIN_LOG: tuning aid, read once)
+    static const uint32_t v = [] { const char* e = std::getenv("ZKHIP_OVERLAP_MIN_LOG"); const int x = e ? std::atoi(e) : 0; return x >= 19 && x <= 25 ? (uint32_t)x : 24u; }();
+    return v;
+}
+static inline bool overlapped_plan(size_t n) { return is_pow2(n) && n >= ((size_t)1 << overlapped_min_log()) && n <= ((size_t)1 << 24); }
+// A rank's SHARD takes the overlapped stage over the whole range it was built for: there it is also the form with the fewest exchanges
+// (three per proof), which is what counts over the fabric.
+static inline bool overlapped_shard(size_t n) { return is_pow2(n) && n >= ((size_t)1 << 19) && n <= ((size_t)1 << 24); }
 static inline uint32_t overlapped_k2(size_t n) { return std::min<uint32_t>(TREE_MAX_LOG, log2_exact(n) - 8 - 3); }
 extern "C" int zkhip_sumcheck_plan_log_blocks(size_t n) {
     if (!is_pow2(n)) return 0;
@@ -1107,7 +1116,7 @@ extern "C" int zkhip_sc_stage_fold(zkhip_sc_state* st) {
 extern "C" int zkhip_sc_overlap_plan(zkhip_sc_state* st, uint32_t world, uint32_t* k1, uint32_t* k2, uint32_t* mid_entries) {
     if (!st || !k1 || !k2 || !mid_entries || !is_pow2(world)) return ZKHIP_ERR_ARG;
     *k1 = *k2 = *mid_entries = 0;
-    if (st->round != 0 || st->stage_idx != 0 || st->ov_phase != 0 || !overlapped_plan(st->cn)) return ZKHIP_OK;
+    if (st->round != 0 || st->stage_idx != 0 || st->ov_phase != 0 || !overlapped_shard(st->cn)) return ZKHIP_OK;
     if ((size_t)256 * world > (size_t)zkhip_sc_tail_capacity()) return ZKHIP_OK;      // the gathered 256-entry tables must fit the tail
     const uint32_t g = log2_exact(st->cn) - 8;
     st->ov_k2 = overlapped_k2(st->cn);
