@@ -938,7 +938,7 @@ def main():
     if world == 1 and not args.force_sharded and not args.no_pipelined:
         # several tables, proved round robin with up to `depth` proofs in flight: every ticket has its own streams and buffers
         # (zkhip_ctx::ProofLane), so the streaming passes of one table's proof run while the transcript rounds of the others hash
-        n_tab = 4
+        n_tab = 8
         polys = [poly] + [zk.Multilinear(_synthetic(zk, torch, n, SEED_TABLE + 16 * rank + 8 + t)) for t in range(1, n_tab)]
         want = [res]
         for pl in polys[1:]:
@@ -959,7 +959,7 @@ def main():
             return got
 
         by_depth = {}
-        for depth in (2, 3, 4):
+        for depth in (2, 3, 4, 6, 8):
             in_flight(2 * depth, depth)         # the lanes' streams and buffers come into being on first use
             runs, total = [], 0.0
             while total < MIN_LEG_SECONDS / 2 and len(runs) < 40:

@@ -39,8 +39,11 @@ typedef enum {
     ZKHIP_ERR_INDEX = -3,    /* out-of-bounds index panic in the reference */
     ZKHIP_ERR_ARG = -4,      /* null pointer / unsupported argument */
     ZKHIP_ERR_NOMEM = -5,
-    ZKHIP_ERR_BUSY = -6      /* the context's workspace backs a live split-phase session (zkhip_sc_* / zkhip_mc_*):
+    ZKHIP_ERR_BUSY = -6,     /* the context's workspace backs a live split-phase session (zkhip_sc_* / zkhip_mc_*):
                                 finish or abort it first, or use another context */
+    ZKHIP_ERR_PEER = -7,     /* a sharded prover: ANOTHER rank failed (its record arrived poisoned); this rank's outputs are void */
+    ZKHIP_ERR_TIMEOUT = -8   /* a device-side wait gave up (the GKR prover's outer-transcript hasher did not see a round's items:
+                                its workgroup and the one that publishes them were not resident together) */
 } zkhip_status;
 
 typedef struct zkhip_ctx zkhip_ctx;
@@ -225,7 +228,7 @@ int zkhip_sumcheck_prove(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, cons
                          uint64_t *h_round_polys, uint64_t *h_challenges);
 
 /* Sumcheck::prove in flight: begin enqueues the whole proof (same inputs as zkhip_sumcheck_prove) and returns a ticket, end
- * waits for that proof and delivers the same outputs (all-NULL outputs abandon it).  Up to four proofs may be in flight.  Each
+ * waits for that proof and delivers the same outputs (all-NULL outputs abandon it).  Up to eight proofs may be in flight.  Each
  * runs on streams, workspace and scratch of its own behind what the caller's stream held at `begin`, so the streaming passes
  * of one proof (and the zkhip_mle_block_sums of the next table, on the caller's stream) overlap the transcript rounds of the
  * others; `end` orders the caller's stream behind the proof again.  The table, its block sums and a device-resident claimed sum
@@ -391,10 +394,17 @@ int zkhip_mc_abort(zkhip_mc_state *st);
  *                           zkhip_rccl_unique_id, the host distributes the id to all ranks by any means, every rank calls
  *                           zkhip_comm_create_rccl (collective, like ncclCommInitRank).
  * world must be a power of two (the tables have 2^n entries).  A comm is used by one host thread at a time, like its context.
- * ERRORS ARE LOCAL: the sharded entry points are collective calls, and a rank that returns an error before an exchange (bad
- * arguments, out of memory, a HIP error) does not tell its peers -- they wait in that exchange like the ranks of any collective whose
- * member left.  Hosts validate arguments identically on every rank (all the shape checks depend only on values every rank holds) and
- * treat a non-zero status at world > 1 as fatal for the job (bench.py: non-zero exit, the launcher ends the other ranks).
+ * A FAILING RANK DOES NOT HANG ITS PEERS (csrc/shard_protocol.hpp).  The sharded entry points are collective calls; a rank whose step
+ * fails for a reason of its own -- out of memory, a busy workspace, a HIP error, at begin or between two exchanges -- stays in the
+ * protocol: it skips its compute and enters every remaining exchange with a POISON record (first element all ones, which no field
+ * element is; the buffers for that are set aside when the comm is created), then returns its own error.  Behind every gather one tiny
+ * kernel looks at the first element of each rank's record and raises a sticky host-mapped flag; the healthy ranks read it where they
+ * wait for the GPU anyway -- the end of the proof, the end of each GKR layer -- and return ZKHIP_ERR_PEER (their outputs are void).
+ * zkhip_kzg_commit_sharded carries a status word in its one 128-byte record.  A call that collects nothing (zkhip_mc_prove_sharded
+ * with all-NULL outputs) leaves the flag for the next collecting call on the comm.  Not covered: a process that dies, and argument /
+ * shape errors, which depend only on values every rank holds and return at once on all of them.
+ * zkhip_comm_inject_failure: test hook -- the next protocol run on this comm fails with `status` in front of its exchange number
+ * exchange_index (0-based), as if a compute step had; exchange_index < 0 disarms.
  * zkhip_rccl_version: ncclGetVersion of the RCCL the library resolved (major * 10000 + minor * 100 + patch), ZKHIP_ERR_HIP if none. */
 typedef int (*zkhip_all_gather_fn)(void *user, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
 typedef struct zkhip_comm zkhip_comm;
@@ -406,6 +416,7 @@ int zkhip_comm_destroy(zkhip_comm *comm);
 /* one exchange as the provers issue them (d_recv: world * bytes_per_rank); cumulative counters of this comm */
 int zkhip_comm_all_gather(zkhip_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank);
 int zkhip_comm_stats(zkhip_comm *comm, uint64_t *exchanges, uint64_t *bytes_sent);
+int zkhip_comm_inject_failure(zkhip_comm *comm, int exchange_index, int status);
 /* the in-library cost of an exchange: `iters` all-gathers of bytes_per_rank back to back (one wait at the end), then `iters` with
  * the host waiting for each -- microseconds per exchange (what bench.py reports as `exchange`) */
 int zkhip_comm_measure(zkhip_comm *comm, size_t bytes_per_rank, uint32_t iters, double *us_back_to_back, double *us_host_wait);

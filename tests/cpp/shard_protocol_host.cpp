@@ -12,11 +12,11 @@ struct zkshard_sc_callbacks {
     size_t (*local_len)(void);
     int (*use_stages)(void);
     uint32_t (*tail_capacity)(void);
-    int (*overlap_plan)(uint32_t world, uint32_t* k1, uint32_t* k2, uint32_t* mid);
+    int (*overlap_plan)(uint32_t world, size_t n_local, uint32_t* k1, uint32_t* k2, uint32_t* mid, int failed);
     int (*overlap_sums)(uint64_t* out, size_t n);
     int (*overlap_rounds1)(const uint64_t* g, uint32_t world, const uint64_t* claimed, uint64_t* mid_out, uint32_t mid);
     int (*overlap_rounds2)(const uint64_t* g, uint32_t world, uint32_t mid);
-    int (*stage_plan)(uint32_t world, uint32_t* k);
+    int (*stage_plan)(uint32_t world, size_t n_local, uint32_t* k, int failed);
     int (*stage_block_sums)(uint64_t* out, size_t n);
     int (*stage_absorb)(const uint64_t* g, uint32_t world, const uint64_t* claimed, size_t n);
     int (*stage_fold)(void);
@@ -32,7 +32,7 @@ struct zkshard_mc_callbacks {
     uint32_t (*tail_capacity)(void);
     uint32_t (*record_len)(void);
     uint32_t (*table_count)(void);
-    int (*stage_record_len)(uint32_t* vals);
+    int (*stage_record_len)(uint32_t world, size_t n_local, uint32_t* vals, int failed);
     int (*stage_sums)(uint64_t* out, uint32_t vals);
     int (*stage_absorb)(const uint64_t* g, uint32_t world, uint32_t vals);
     int (*round_sums)(uint64_t* out, uint32_t rec);
@@ -60,24 +60,47 @@ struct HostBuffers {
         return 0;
     }
 };
+// The host end of an exchange sees the gathered bytes: immediate() -- a poisoned record is reported as ERR_PEER right behind the gather
+// and every rank, the failed one included, leaves the protocol there (shard_protocol.hpp, "a failing rank must not hang its peers").
 template <class CB>
 struct HostComm {
     const CB* cb;
     uint32_t w;
+    int inject_at, inject_rc;
+    std::vector<uint64_t> p_send, p_recv;
     uint32_t world() const { return w; }
     bool passthrough() const { return w == 1; }
+    bool immediate() const { return true; }
+    int inject(uint32_t idx) {
+        if (inject_at < 0 || (uint32_t)inject_at != idx) return 0;
+        inject_at = -1;
+        return inject_rc;
+    }
     int all_gather(const void* send, void* recv, size_t bytes) { return cb->all_gather(send, recv, bytes); }
+    int poison(size_t elems, const uint64_t** send, uint64_t** recv) {
+        p_send.assign(4 * (elems ? elems : 1), 0);
+        for (int q = 0; q < 4; ++q) p_send[q] = ~(uint64_t)0;        // the first element all ones: no field element
+        p_recv.assign(4 * (elems ? elems : 1) * w, 0);
+        *send = p_send.data();
+        *recv = p_recv.data();
+        return 0;
+    }
+    int check(const uint64_t* gathered, size_t elems) {
+        for (uint32_t g = 0; g < w; ++g)
+            if (gathered[4 * elems * g + 3] == ~(uint64_t)0) return zkshard::ERR_PEER;
+        return 0;
+    }
 };
 struct ScEngine : HostBuffers {
     const zkshard_sc_callbacks* cb;
     size_t local_len() { return cb->local_len(); }
     bool use_stages() { return cb->use_stages() != 0; }
     uint32_t tail_capacity() { return cb->tail_capacity(); }
-    int overlap_plan(uint32_t world, uint32_t* k1, uint32_t* k2, uint32_t* mid) { return cb->overlap_plan(world, k1, k2, mid); }
+    int overlap_plan(uint32_t world, size_t n_local, uint32_t* k1, uint32_t* k2, uint32_t* mid, bool failed) { return cb->overlap_plan(world, n_local, k1, k2, mid, failed ? 1 : 0); }
     int overlap_sums(uint64_t* out, size_t n) { return cb->overlap_sums(out, n); }
     int overlap_rounds1(const uint64_t* g, uint32_t world, const uint64_t* claimed, uint64_t* mid_out, uint32_t mid) { return cb->overlap_rounds1(g, world, claimed, mid_out, mid); }
     int overlap_rounds2(const uint64_t* g, uint32_t world, uint32_t mid) { return cb->overlap_rounds2(g, world, mid); }
-    int stage_plan(uint32_t world, uint32_t* k) { return cb->stage_plan(world, k); }
+    int stage_plan(uint32_t world, size_t n_local, uint32_t* k, bool failed) { return cb->stage_plan(world, n_local, k, failed ? 1 : 0); }
     int stage_block_sums(uint64_t* out, size_t n) { return cb->stage_block_sums(out, n); }
     int stage_absorb(const uint64_t* g, uint32_t world, const uint64_t* claimed, size_t n) { return cb->stage_absorb(g, world, claimed, n); }
     int stage_fold() { return cb->stage_fold(); }
@@ -93,7 +116,7 @@ struct McEngine : HostBuffers {
     uint32_t tail_capacity() { return cb->tail_capacity(); }
     uint32_t record_len() { return cb->record_len(); }
     uint32_t table_count() { return cb->table_count(); }
-    int stage_record_len(uint32_t* vals) { return cb->stage_record_len(vals); }
+    int stage_record_len(uint32_t world, size_t n_local, uint32_t* vals, bool failed) { return cb->stage_record_len(world, n_local, vals, failed ? 1 : 0); }
     int stage_sums(uint64_t* out, uint32_t vals) { return cb->stage_sums(out, vals); }
     int stage_absorb(const uint64_t* g, uint32_t world, uint32_t vals) { return cb->stage_absorb(g, world, vals); }
     int round_sums(uint64_t* out, uint32_t rec) { return cb->round_sums(out, rec); }
@@ -103,15 +126,17 @@ struct McEngine : HostBuffers {
 };
 }  // namespace
 
-extern "C" int zkshard_host_sumcheck(const zkshard_sc_callbacks* cb, uint32_t world, const uint64_t* claimed, uint32_t* exchanges) {
+// inject_at >= 0: this rank fails with inject_rc in front of exchange inject_at (the test hook of the library's zkhip_comm_inject_failure)
+extern "C" int zkshard_host_sumcheck(const zkshard_sc_callbacks* cb, uint32_t world, const uint64_t* claimed, uint32_t* exchanges, int inject_at,
+                                     int inject_rc) {
     ScEngine e;
     e.cb = cb;
-    HostComm<zkshard_sc_callbacks> comm{cb, world};
+    HostComm<zkshard_sc_callbacks> comm{cb, world, inject_at, inject_rc, {}, {}};
     return zkshard::sumcheck_prove(e, comm, claimed, exchanges);
 }
-extern "C" int zkshard_host_composed(const zkshard_mc_callbacks* cb, uint32_t world, int use_stages, uint32_t* exchanges) {
+extern "C" int zkshard_host_composed(const zkshard_mc_callbacks* cb, uint32_t world, int use_stages, uint32_t* exchanges, int inject_at, int inject_rc) {
     McEngine e;
     e.cb = cb;
-    HostComm<zkshard_mc_callbacks> comm{cb, world};
+    HostComm<zkshard_mc_callbacks> comm{cb, world, inject_at, inject_rc, {}, {}};
     return zkshard::composed_prove(e, comm, use_stages != 0, exchanges);
 }

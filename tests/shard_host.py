@@ -62,11 +62,11 @@ def _all_gather_cb(dist, world, guard):
 
 
 SC_FIELDS = [("local_len", C.CFUNCTYPE(C.c_size_t)), ("use_stages", C.CFUNCTYPE(C.c_int)), ("tail_capacity", C.CFUNCTYPE(C.c_uint32)),
-             ("overlap_plan", C.CFUNCTYPE(C.c_int, C.c_uint32, u32p, u32p, u32p)),
+             ("overlap_plan", C.CFUNCTYPE(C.c_int, C.c_uint32, C.c_size_t, u32p, u32p, u32p, C.c_int)),
              ("overlap_sums", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t)),
              ("overlap_rounds1", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32)),
              ("overlap_rounds2", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32)),
-             ("stage_plan", C.CFUNCTYPE(C.c_int, C.c_uint32, u32p)),
+             ("stage_plan", C.CFUNCTYPE(C.c_int, C.c_uint32, C.c_size_t, u32p, C.c_int)),
              ("stage_block_sums", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t)),
              ("stage_absorb", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t)),
              ("stage_fold", C.CFUNCTYPE(C.c_int)),
@@ -84,7 +84,7 @@ class ScCallbacks(C.Structure):
 
 MC_FIELDS = [("local_len", C.CFUNCTYPE(C.c_size_t)), ("tail_capacity", C.CFUNCTYPE(C.c_uint32)), ("record_len", C.CFUNCTYPE(C.c_uint32)),
              ("table_count", C.CFUNCTYPE(C.c_uint32)),
-             ("stage_record_len", C.CFUNCTYPE(C.c_int, u32p)),
+             ("stage_record_len", C.CFUNCTYPE(C.c_int, C.c_uint32, C.c_size_t, u32p, C.c_int)),
              ("stage_sums", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32)),
              ("stage_absorb", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32)),
              ("round_sums", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32)),
@@ -98,21 +98,33 @@ class McCallbacks(C.Structure):
     _fields_ = MC_FIELDS
 
 
-def prove_sumcheck(so, e, world, dist, claimed_sum=None):
+ERR_PEER = -7
+
+
+class RankFailed(Exception):
+    """the protocol returned a status: .rc (ERR_PEER on the healthy ranks, the injected status on the failed one), .exchanges"""
+
+    def __init__(self, rc, exchanges):
+        super().__init__("protocol status %d after %d exchanges" % (rc, exchanges))
+        self.rc, self.exchanges = rc, exchanges
+
+
+def prove_sumcheck(so, e, world, dist, claimed_sum=None, inject=None):
     """zkshard::sumcheck_prove over checker engine `e` (the interface of tests/test_distributed_cpu.OracleSumcheckEngine);
-    returns (engine.finish(total rounds), exchanges)."""
+    returns (engine.finish(total rounds), exchanges).  inject = (exchange index, status): this rank fails there (raises RankFailed,
+    as every other rank does with ERR_PEER).  The plan callbacks take the protocol's n_local: they are called after a failure too."""
     lib = C.CDLL(so)
     g = _Guard()
     total_rounds = (e.local_len() * world).bit_length() - 1
     st = {}
 
-    def overlap_plan(w, k1, k2, mid):
-        plan = e.overlap_plan(w) if hasattr(e, "overlap_plan") else None
+    def overlap_plan(w, n_local, k1, k2, mid, failed):
+        plan = e.overlap_plan(w, n_local) if hasattr(e, "overlap_plan") else None
         k1[0], k2[0], mid[0] = plan if plan else (0, 0, 0)
         st["k1"], st["k2"] = k1[0], k2[0]
 
-    def stage_plan(w, k):
-        k[0] = e.stage_plan(w) if hasattr(e, "stage_plan") else 0
+    def stage_plan(w, n_local, k, failed):
+        k[0] = e.stage_plan(w, n_local) if hasattr(e, "stage_plan") else 0
 
     fns = {
         "local_len": (lambda: e.local_len(), 0),
@@ -144,22 +156,26 @@ def prove_sumcheck(so, e, world, dist, claimed_sum=None):
         setattr(cb, name, f)
     ex = C.c_uint32(0)
     cs = np.ascontiguousarray(claimed_sum, dtype=np.uint64) if claimed_sum is not None else None
-    rc = lib.zkshard_host_sumcheck(C.byref(cb), C.c_uint32(world), cs.ctypes.data_as(C.c_void_p) if cs is not None else None, C.byref(ex))
+    inj_at, inj_rc = inject if inject is not None else (-1, 0)
+    rc = lib.zkshard_host_sumcheck(C.byref(cb), C.c_uint32(world), cs.ctypes.data_as(C.c_void_p) if cs is not None else None, C.byref(ex),
+                                   C.c_int(inj_at), C.c_int(inj_rc))
     if g.error is not None:
         raise g.error
-    assert rc == 0, rc
+    if rc != 0:
+        raise RankFailed(rc, ex.value)
     return e.finish(total_rounds), ex.value
 
 
-def prove_composed(so, e, world, dist, use_stages=None):
-    """zkshard::composed_prove over checker engine `e` (the interface of OracleComposedEngine); use_stages None = world > 1."""
+def prove_composed(so, e, world, dist, use_stages=None, inject=None):
+    """zkshard::composed_prove over checker engine `e` (the interface of OracleComposedEngine); use_stages None = world > 1.
+    inject as prove_sumcheck."""
     lib = C.CDLL(so)
     g = _Guard()
     total_rounds = (e.local_len() * world).bit_length() - 1
     nt = e.table_count()
 
-    def stage_record_len(vals):
-        vals[0] = e.stage_record_len() if hasattr(e, "stage_record_len") else 0
+    def stage_record_len(w, n_local, vals, failed):
+        vals[0] = e.stage_record_len(n_local) if hasattr(e, "stage_record_len") else 0
 
     fns = {
         "local_len": (lambda: e.local_len(), 0),
@@ -186,8 +202,10 @@ def prove_composed(so, e, world, dist, use_stages=None):
         setattr(cb, name, f)
     ex = C.c_uint32(0)
     stages = (world > 1) if use_stages is None else bool(use_stages)
-    rc = lib.zkshard_host_composed(C.byref(cb), C.c_uint32(world), C.c_int(1 if stages else 0), C.byref(ex))
+    inj_at, inj_rc = inject if inject is not None else (-1, 0)
+    rc = lib.zkshard_host_composed(C.byref(cb), C.c_uint32(world), C.c_int(1 if stages else 0), C.byref(ex), C.c_int(inj_at), C.c_int(inj_rc))
     if g.error is not None:
         raise g.error
-    assert rc == 0, (rc, nt)
+    if rc != 0:
+        raise RankFailed(rc, ex.value)
     return e.finish(total_rounds), ex.value

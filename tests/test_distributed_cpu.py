@@ -69,11 +69,13 @@ class OracleSumcheckEngine:
         out.copy_(torch.from_numpy(self.cur.view(np.int64)))
 
     # ---- stage form: one exchange per k rounds
-    def stage_plan(self, world):
-        n_glob = self.cur.shape[0] * world
+    # the plans are pure functions of (world, entries per shard): the protocol also calls them on a rank that has failed
+    def stage_plan(self, world, n_local=None):
+        n_local = self.cur.shape[0] if n_local is None else n_local
+        n_glob = n_local * world
         if not self.use_stages or n_glob <= self.cap:
             return 0
-        k = min(3, (n_glob // self.cap).bit_length() - 1, self.cur.shape[0].bit_length() - 1)
+        k = min(3, (n_glob // self.cap).bit_length() - 1, n_local.bit_length() - 1)
         self.k = k
         return k
 
@@ -113,9 +115,9 @@ class OracleSumcheckEngine:
         m = tab.shape[0] // blocks
         return np.stack([self.ora.mle_sum(tab[b * m:(b + 1) * m]) for b in range(blocks)])
 
-    def overlap_plan(self, world):
-        L = self.cur.shape[0].bit_length() - 1
-        if not self.overlap or self.rps or L < 3:
+    def overlap_plan(self, world, n_local=None):
+        L = (self.cur.shape[0] if n_local is None else n_local).bit_length() - 1
+        if not self.overlap or L < 3:
             return None
         self.k1 = max(1, (L - 1) // 2)
         self.k2 = L - 1 - self.k1
@@ -259,9 +261,11 @@ class OracleComposedEngine:
 
     # ---- two rounds per exchange (zkhip_mc_stage_*): the record is, per term, C[a][b] = sum_j A[a][j] B[b][j] over the four blocks
     # of the next two variables (16 values, index 4 a + b) and 4 block sums of an additive table (none here: zeros)
-    def stage_record_len(self):
-        if self.pending is not None or self.terms[0].shape[1] < 4 or any(t.shape[0] != 2 for t in self.terms):
+    def stage_record_len(self, n_local=None):
+        n_local = self.terms[0].shape[1] if n_local is None else n_local
+        if n_local < 4 or any(t.shape[0] != 2 for t in self.terms):
             return 0
+        assert self.pending is None or n_local != self.terms[0].shape[1]     # (no fold is pending inside the protocol's stage loop)
         return 20 * len(self.terms)
 
     def stage_sums(self, out):
@@ -414,3 +418,69 @@ def test_sharded_composed_protocol_gloo(world, log_n, tmp_path):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(r, True, True) for r in range(world)]
+
+
+# ---- a failing rank must not hang its peers (csrc/shard_protocol.hpp) ---------------------------------------------------------
+def _failure_worker(rank, world, port, log_n, q, so):
+    """Every protocol form, a failure injected on one rank in front of EVERY exchange index in turn: the failed rank returns its own
+    status, every other rank ERR_PEER, all of them right behind the poisoned exchange -- and the next proof on the same group is right."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as ora
+        from zk_cryptography_amd import distributed as D
+        import shard_host as H
+        NOMEM = -5
+        n = 1 << log_n
+        full = ora.random_fr(n, 515)
+        shard = D.shard_interleaved(full, rank, world)
+        want = ora.sumcheck_prove(full)
+        full2 = np.stack([ora.random_fr(n, 616 + k) for k in range(2)])
+        shard2 = np.stack([D.shard_interleaved(full2[k], rank, world) for k in range(2)])
+        want2 = ora.composed_prove(full2)
+        forms = [("sumcheck stages", lambda inj: H.prove_sumcheck(so, OracleSumcheckEngine(ora, shard, True, False), world, dist, inject=inj)),
+                 ("sumcheck rounds", lambda inj: H.prove_sumcheck(so, OracleSumcheckEngine(ora, shard, False, False), world, dist, inject=inj)),
+                 ("sumcheck overlapped", lambda inj: H.prove_sumcheck(so, OracleSumcheckEngine(ora, shard, True, True), world, dist, inject=inj)),
+                 ("composed stages", lambda inj: H.prove_composed(so, OracleComposedEngine(ora, [shard2], False), world, dist, use_stages=True, inject=inj)),
+                 ("composed rounds", lambda inj: H.prove_composed(so, OracleComposedEngine(ora, [shard2], False), world, dist, use_stages=False, inject=inj))]
+        bad = []
+        cases = 0
+        for name, run in forms:
+            _, n_ex = run(None)
+            for idx in range(n_ex):
+                failing = idx % world
+                try:
+                    run((idx, NOMEM) if rank == failing else None)
+                    bad.append((name, idx, "no status"))
+                except H.RankFailed as e:
+                    if e.rc != (NOMEM if rank == failing else H.ERR_PEER) or e.exchanges != idx + 1:
+                        bad.append((name, idx, e.rc, e.exchanges))
+                cases += 1
+            # the group is still in step: a healthy proof right behind the failures
+            res, _ = run(None)
+            w = want if name.startswith("sumcheck") else want2
+            if not all(np.array_equal(a, b) for a, b in zip(res, w)):
+                bad.append((name, "proof after failures differs"))
+        q.put((rank, bad, cases))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log_n", [(2, 6), (4, 6)])
+def test_failing_rank_does_not_hang_its_peers_gloo(world, log_n, tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + world * 3 + log_n
+    so = H.build(tmp_path)
+    procs = [ctx.Process(target=_failure_worker, args=(r, world, port, log_n, q, so)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [b for _, b, _ in res] == [[]] * world, res
+    assert all(c >= 10 for _, _, c in res)          # every exchange index of five protocol forms

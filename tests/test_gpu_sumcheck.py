@@ -90,9 +90,9 @@ def test_prove_2_24_self_consistency(zk, ora):
     assert zk.Fr.to_ints(poly.evaluation(ch)) == [claim]
 
 
-@pytest.mark.parametrize("depth", [2, 4])
+@pytest.mark.parametrize("depth", [2, 4, 8])
 def test_proofs_in_flight_match_synchronous_proofs(zk, ora, depth):
-    """zkhip_sumcheck_prove_begin / _end: up to four proofs in flight on lanes of their own (streams, workspace, scratch),
+    """zkhip_sumcheck_prove_begin / _end: up to eight proofs in flight on lanes of their own (streams, workspace, scratch),
     different tables and sizes -- overlapped and generic plans side by side -- each equal to the oracle's."""
     from zk_cryptography_amd import _native as N
     tables = [ora.random_fr(1 << log_n, 5100 + log_n) for log_n in (20, 12, 21, 3, 19, 20, 22, 9)]
@@ -109,16 +109,16 @@ def test_proofs_in_flight_match_synchronous_proofs(zk, ora, depth):
         pending = []
     for (proof, ch), (s, rp, och) in zip(got, want + want):
         assert np.array_equal(proof.sum, s) and np.array_equal(proof.univariate_poly, rp) and np.array_equal(ch, och)
-    # a fifth proof in flight and a synchronous prove are refused while four are pending
-    scs = [zk.Sumcheck(zk.Multilinear(t)) for t in tables[:5]]
-    held = [sc.prove_begin() for sc in scs[:4]]
+    # a ninth proof in flight and a synchronous prove are refused while eight are pending
+    scs = [zk.Sumcheck(zk.Multilinear(t)) for t in tables + tables[:1]]
+    held = [sc.prove_begin() for sc in scs[:8]]
     with pytest.raises(N.ZkhipError):
-        scs[4].prove_begin()
+        scs[8].prove_begin()
     with pytest.raises(N.ZkhipError):
-        scs[4].prove()
+        scs[8].prove()
     held[0].wait()
     del held
-    scs[4].prove()                             # every ticket is free again
+    scs[8].prove()                             # every ticket is free again
 
 
 def test_proofs_in_flight_without_poly_sum_and_same_table(zk, ora):

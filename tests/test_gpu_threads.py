@@ -277,3 +277,126 @@ def test_soak_create_destroy_and_aborted_sessions_return_all_memory(zk, ora):
     proof, ch = s.prove()
     ws, wrp, wch = ora.sumcheck_prove(ev)
     assert np.array_equal(proof.sum, ws) and np.array_equal(proof.univariate_poly, wrp) and np.array_equal(ch, wch)
+
+
+# ---- a failing rank must not hang its peers (include/zkhip.h, csrc/shard_protocol.hpp) -----------------------------------------------
+@pytest.mark.parametrize("world", [2, 4])
+def test_failing_rank_reports_through_the_exchange_and_nobody_hangs(zk, ora, world):
+    """Threads as ranks, real concurrent exchanges.  One rank fails in front of exchange i -- for EVERY i of the sumcheck and
+    multi-composed protocols, two places of the GKR prover and the commit's one exchange -- or fails at begin (a busy workspace: no
+    session at all).  That rank gets its own status, every other rank ZkhipPeerError, nobody waits for ever, and the next proof on the
+    same communicators is bit-exact again."""
+    import torch
+    from zk_cryptography_amd import _native as N
+    from zk_cryptography_amd import distributed as D
+    xch = BarrierExchange(world)
+    full = zk.Fr.random(1 << 21, 6150)                                   # shards of 2^20 / 2^19: the overlapped stage, 3 exchanges
+    sc = zk.Sumcheck(zk.Multilinear(full))
+    sc.poly_sum()
+    want_sc, want_ch = sc.prove()
+    tabs = [zk.Fr.random(1 << 15, 6160 + k) for k in range(4)]
+    poly = [zk.ComposedMultilinear([zk.Multilinear(tabs[0]), zk.Multilinear(tabs[1])]),
+            zk.ComposedMultilinear([zk.Multilinear(tabs[2]), zk.Multilinear(tabs[3])])]
+    claimed = zk.MultiComposedSumcheckProver.calculate_poly_sum(poly)
+    want_mc, want_mc_ch = zk.MultiComposedSumcheckProver.prove_partial(poly, claimed)
+    want_mc = [p.monomials() for p in want_mc.round_polys]
+    depth = 10
+    gkr_in = zk.Fr.random(2 ** depth, 6170)
+    circuit = zk.Circuit.random(depth)
+    want_gkr = zk.GKRProtocol.prove(circuit, circuit.evaluation(gkr_in))
+    srs = zk.TrustedSetup.setup(zk.Fr.random(10, 6180))
+    scal = zk.Fr.random(1 << 10, 6181)
+    want_c = zk.MultilinearKZG.commitment(zk.Multilinear(scal), srs)
+    srs_xy, srs_inf = srs.powers_of_tau_in_g1.cpu(), srs.inf.cpu()
+    torch.cuda.synchronize()
+    seen = [[] for _ in range(world)]
+
+    def body(rank):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            ctx = N.Context.get(0)
+            cb, err = xch.callback(ctx, rank)
+            comm = D.Comm(ctx, world, rank, transport=cb)
+
+            def cuda(a):
+                return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+            shard = cuda(full[rank::world])
+            sh = [cuda(t[rank::world]) for t in tabs]
+            my_circuit = zk.Circuit.random(depth)
+            my_ev = my_circuit.evaluation(gkr_in)
+            pts, pinf, psc = srs_xy[rank::world].contiguous().cuda(), srs_inf[rank::world].contiguous().cuda(), cuda(scal[rank::world])
+
+            def prove_sc():
+                e = D.ShardedSumcheck(D.HipSumcheckEngine(shard), world, comm=comm)
+                s, rp, ch = e.prove()
+                assert np.array_equal(s, want_sc.sum) and np.array_equal(rp, want_sc.univariate_poly) and np.array_equal(ch, want_ch)
+                return e.exchanges
+
+            def prove_mc():
+                e = D.ShardedComposedSumcheck(D.HipComposedEngine([sh[:2], sh[2:]], world, multi=True, claimed_sum=claimed), world, comm=comm)
+                rps, ch = e.prove()
+                assert [zk.SparseUnivariatePolynomial(c_, p_).monomials() for c_, p_ in rps] == want_mc and np.array_equal(ch, want_mc_ch)
+                return e.exchanges
+
+            def prove_gkr():
+                got = zk.GKRProtocol.prove_sharded(my_circuit, my_ev, world, rank, comm=comm)
+                assert all(a.to_bytes() == b.to_bytes() for a, b in zip(got.sumcheck_proofs, want_gkr.sumcheck_proofs))
+                return 2
+
+            def commit():
+                xy, inf = D.sharded_commit(pts, pinf, psc, comm)
+                assert (not inf) and np.array_equal(xy, want_c.xy)
+                return 1
+
+            def expect_failure(run, failing, arm):
+                """`arm()` on the failing rank makes its next run fail; every rank must come back with the right status"""
+                if rank == failing:
+                    arm()
+                try:
+                    run()
+                    seen[rank].append("no status")
+                except N.ZkhipPeerError:
+                    seen[rank].append("peer" if rank != failing else "WRONG: the failed rank saw ERR_PEER")
+                except N.ZkhipError as e:
+                    seen[rank].append("own %d" % e.status if rank == failing else "WRONG: status %r on a healthy rank" % e.status)
+
+            try:
+                for run in (prove_sc, prove_mc, prove_gkr, commit):
+                    n_ex = run()                                             # healthy first: how many exchanges there are to fail in front of
+                    for idx in range(n_ex):
+                        expect_failure(run, idx % world, lambda idx=idx: comm.inject_failure(idx, N.ERR_NOMEM))
+                    run()                                                    # and healthy again, on the same communicators
+                # a failure at BEGIN: the rank's workspace is lent to another session, zkhip_mc_begin gives ZKHIP_ERR_BUSY -- no session,
+                # the whole exchange schedule is walked from the shapes alone
+                hold = []
+
+                def lend_workspace():
+                    st = C.c_void_p()
+                    N.check(N.lib().zkhip_sc_begin(ctx.handle, N.ptr(shard), C.c_size_t(shard.shape[0]), C.byref(st)), "sc_begin")
+                    hold.append(st)
+
+                def mc_one_call():
+                    ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in sh])
+                    n_rounds = 15
+                    lens, rp, ch = np.zeros(n_rounds, np.uint32), np.zeros((n_rounds, 7, 2, 4), np.uint64), np.zeros((n_rounds, 4), np.uint64)
+                    p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+                    comm.check(N.lib().zkhip_multi_composed_prove_sharded(comm.handle, ptrs, (C.c_uint32 * 2)(2, 2), C.c_uint32(2), C.c_size_t(sh[0].shape[0]),
+                                                                          p(np.ascontiguousarray(claimed)), C.c_int(-1), p(lens), p(rp), p(ch), None), "mc_sharded")
+                    assert np.array_equal(ch, want_mc_ch)
+                expect_failure(mc_one_call, world - 1, lend_workspace)
+                for st in hold:
+                    N.check(N.lib().zkhip_sc_abort(st), "sc_abort")
+                mc_one_call()
+            finally:
+                if err:
+                    raise err[0]
+                comm.close()
+
+    _run_threads(world, body)
+    # every injected case: exactly one rank with its own status (-5; -6 for the busy begin), everybody else "peer"
+    n_cases = len(seen[0])
+    assert n_cases >= 3 + 3 + 2 + 1 + 1 and all(len(s) == n_cases for s in seen)   # every exchange of the sumcheck (3) and multi-composed protocols, 2 in GKR, commit, busy begin
+    for k in range(n_cases):
+        col = [seen[r][k] for r in range(world)]
+        assert col.count("peer") == world - 1, (k, col)
+        assert [c for c in col if c != "peer"][0] in ("own -5", "own -6"), (k, col)

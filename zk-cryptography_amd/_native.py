@@ -13,11 +13,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libzkhip.so")
 
-ZKHIP_OK, ERR_HIP, ERR_SHAPE, ERR_INDEX, ERR_ARG, ERR_NOMEM, ERR_BUSY = 0, -1, -2, -3, -4, -5, -6
+ZKHIP_OK, ERR_HIP, ERR_SHAPE, ERR_INDEX, ERR_ARG, ERR_NOMEM, ERR_BUSY, ERR_PEER, ERR_TIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 
 class ZkhipError(RuntimeError):
-    pass
+    def __init__(self, msg, status=None):
+        super().__init__(msg)
+        self.status = status
+
+
+class ZkhipPeerError(ZkhipError):
+    """a sharded prover: ANOTHER rank failed and said so through the exchange (ZKHIP_ERR_PEER); this rank's outputs are void"""
 
 
 def build(force=False):
@@ -67,7 +73,7 @@ def check(status, what=""):
         raise AssertionError("%s: %s" % (what, msg))      # the reference panics (assert!/assert_eq!)
     if status == ERR_INDEX:
         raise IndexError("%s: %s" % (what, msg))
-    raise ZkhipError("%s: %s (status %d)" % (what, msg, status))
+    raise (ZkhipPeerError if status == ERR_PEER else ZkhipError)("%s: %s (status %d)" % (what, msg, status), status)
 
 
 class Context:

@@ -721,12 +721,41 @@ extern "C" int zkhip_multi_composed_prove(zkhip_ctx* c, const uint64_t* const* p
 // ---------------------------------------------------------------------------------------
 // split-phase session: the same prover with its tables sharded over several GPUs (include/zkhip.h, zkhip_mc_*)
 // ---------------------------------------------------------------------------------------
+// The exchange shape of a session from its term sizes alone (what ComposedRun::setup derives): a rank that failed before it had a
+// session still walks the protocol's exchange schedule with it (shard_protocol.hpp, "a failing rank must not hang its peers").
+int zk_mc_shape(const uint32_t* sizes, uint32_t n_terms, uint32_t n_lin, uint32_t* rec, uint32_t* n_tables, uint32_t* tail_len, uint32_t* stage_vals) {
+    if (!sizes || n_terms == 0 || n_terms > CMP_MAX_TERMS) return ZKHIP_ERR_ARG;
+    uint32_t r = 0, total = 0;
+    bool pairs = true;
+    for (uint32_t p = 0; p < n_terms; ++p) {
+        if (sizes[p] < 1 || sizes[p] > CMP_MAX_K) return ZKHIP_ERR_ARG;
+        r += sizes[p] + 1;
+        total += sizes[p];
+        pairs = pairs && sizes[p] == 2;
+    }
+    if (r > CMP_MAX_REC) return ZKHIP_ERR_ARG;
+    if (rec) *rec = r;
+    if (n_tables) *n_tables = total + n_lin;
+    if (tail_len) *tail_len = composed_tail_len(total + n_lin);
+    if (stage_vals) *stage_vals = pairs ? n_terms * (uint32_t)CST_VALS : 0u;
+    return ZKHIP_OK;
+}
+
 struct zkhip_mc_state {
     ComposedRun run;
     uint32_t world = 1;
     int sums_pending = 0;        // which record is out and not absorbed yet: 0 none, 1 a round record (zkhip_mc_round_sums), 2 a stage record
     size_t pending_cn = 0;       // entries per table when that record was taken (the matching absorb must find the session where it left it)
 };
+
+// the shape of a live session (what zk_mc_shape gives for its arguments) and its current entries per table
+int zk_mc_state_shape(zkhip_mc_state* s, uint32_t* rec, uint32_t* n_tables, uint32_t* tail_len, uint32_t* stage_vals, size_t* n_local) {
+    if (!s) return ZKHIP_ERR_ARG;
+    const ComposedRun& run = s->run;
+    ZK_TRY(zk_mc_shape(run.term_sizes, run.n_terms, run.total_all - run.total, rec, n_tables, tail_len, stage_vals));
+    if (n_local) *n_local = run.after();
+    return ZKHIP_OK;
+}
 
 extern "C" int zkhip_mc_begin_ex(zkhip_ctx* c, const uint64_t* const* d_local_tables, const uint32_t* term_sizes, uint32_t n_terms,
                                  const uint64_t* const* d_local_lin, size_t n_local, uint32_t world, int multi, const uint64_t* h_sum,

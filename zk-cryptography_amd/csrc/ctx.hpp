@@ -103,7 +103,7 @@ struct zkhip_ctx {
     }
     // coarse block sums left by zkhip_mle_block_sums for the prover's first rounds: a ring (canonical, then Montgomery: 64 KiB
     // each; more entries than proofs in flight), so that the sums of a table whose proof is in flight survive the poly_sum() of the next tables
-    static constexpr int COARSE_RING = 8;
+    static constexpr int COARSE_RING = 16;
     void* d_coarse[COARSE_RING] = {};
     const void* coarse_of[COARSE_RING] = {}; size_t coarse_n[COARSE_RING] = {}; uint32_t coarse_k1[COARSE_RING] = {};
     int coarse_owner[COARSE_RING] = {};     // result slot + 1 of the proof that still reads the entry (0: nobody): such an entry is never handed out
@@ -132,7 +132,7 @@ struct zkhip_ctx {
         void* ws = nullptr; size_t ws_bytes = 0;
         void* small = nullptr;
     };
-    static constexpr int PROOF_SLOTS = 4;      // proofs in flight (measured at 2^24: 2 / 3 / 4 in flight, see bench.py `pipelined`)
+    static constexpr int PROOF_SLOTS = 8;      // proofs in flight (measured at 2^24: 2 / 3 / 4 / 6 / 8 in flight, see bench.py `pipelined`)
     ProofLane lanes[PROOF_SLOTS];
     int ensure_lane(int k, size_t ws_need) {
         ProofLane& L = lanes[k];

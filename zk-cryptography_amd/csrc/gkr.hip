@@ -750,9 +750,14 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
                 hs->buf[i] = ((uint32_t)tr.hasher.buf[4 * i] << 24) | ((uint32_t)tr.hasher.buf[4 * i + 1] << 16) | ((uint32_t)tr.hasher.buf[4 * i + 2] << 8) | tr.hasher.buf[4 * i + 3];
             hs->fill = fill;
             hs->len = tr.hasher.len;
-            static_assert(offsetof(zk::OuterDev, error) == sizeof(zk::Sha256State), "state | error: one copy");
-            *(uint32_t*)(hs + 1) = 0u;                                   // OuterDev::error
-            ZK_HIP(c, hipMemcpyAsync(&dt.outer->state, hs, sizeof(*hs) + 4, hipMemcpyHostToDevice, c->stream));
+            // state | error | flags in ONE copy.  The flags MUST be cleared per proof: d_aux is uninitialised memory that an earlier
+            // context (tokens restart at 1 per context) or a freed table of small integers may have left holding this proof's token --
+            // a hasher would then absorb stale items without waiting and the proof would be silently wrong.  Tokens are never 0.
+            static_assert(offsetof(zk::OuterDev, error) == sizeof(zk::Sha256State), "state | error | flags: one copy");
+            constexpr size_t head_bytes = offsetof(zk::OuterDev, items);
+            static_assert(head_bytes <= 8 * (ZK_PIN_PTS - ZK_PIN_RES), "the staging slot holds the head of OuterDev");
+            std::memset((char*)hs + sizeof(*hs), 0, head_bytes - sizeof(*hs));   // OuterDev::error, pad_, flag[]
+            ZK_HIP(c, hipMemcpyAsync(&dt.outer->state, hs, head_bytes, hipMemcpyHostToDevice, c->stream));
             ZK_HIP(c, hipMemcpyAsync(dt.sums, claimed.l, 32, hipMemcpyHostToDevice, c->stream));     // (pageable source: copied before the call returns)
             ZK_HIP(c, hipStreamSynchronize(c->stream));                  // the pinned staging words are reused below
         }
@@ -771,7 +776,10 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
         char* pin0 = (char*)c->msm_pin[0];
         ZK_HIP(c, hipMemcpyAsync(pin0, aux + o_outer, pin_bytes, hipMemcpyDeviceToHost, c->stream));
         ZK_HIP(c, hipStreamSynchronize(c->stream));
-        if (((const zk::OuterDev*)pin0)->error != 0) return ZKHIP_ERR_HIP;         // a hasher gave up waiting for a round (see OuterDev::error)
+        // a hasher gave up waiting for a round's items (OuterDev::error = 1 + round).  The hasher is the LAST workgroup of a closing launch and
+        // the publisher its workgroup 0: both are resident as long as the grid is at most what the chip holds beside other work -- a
+        // residency assumption, hence a status of its own (not a device fault); the outer state is void
+        if (((const zk::OuterDev*)pin0)->error != 0) return ZKHIP_ERR_TIMEOUT;
         const char* pin = pin0 + (o_arena - o_outer);
         const char* pin_sums = pin0 + (o_sums - o_outer);
         const char* pin_wb = pin0 + (o_wb - o_outer);
@@ -949,7 +957,31 @@ extern "C" int zkhip_gkr_prove_sharded(zkhip_circuit* cir, zkhip_comm* comm, con
     }
     zkhost::Fr alpha = zkhost::fr_one(), beta = zkhost::fr_zero();
 
+    // A rank that fails must not hang its peers (shard_protocol.hpp): it enters every exchange the healthy ranks still make, with poison
+    // records, up to the end of the first layer that has any; the healthy ranks read the sticky flag where they wait for the GPU anyway
+    // (the end of each layer) and return ZKHIP_ERR_PEER there.  sessions_left: how many of layer li_from's two sessions are still to come.
+    auto walk_failed = [&](uint32_t li_from, int sessions_left, int fail_rc) {
+        for (uint32_t li = li_from; li <= n_layers; ++li, sessions_left = 2) {
+            const size_t w_len = h_layer_len[li];
+            if (w_len < 2 * (size_t)world || world == 1) continue;              // a narrow layer runs whole on every rank: no exchange
+            const uint32_t sizes[2] = {2, 2};
+            const bool stages = use_stages >= 0 ? use_stages != 0 : true;
+            for (int sess = 2 - sessions_left; sess < 2; ++sess) {
+                zkshard::HipMcEngine e{nullptr, comm};
+                if (e.shape(sizes, 2, sess == 0 ? 1u : 0u, w_len / world) != ZKHIP_OK) return;
+                uint32_t ex = 0;
+                (void)zkshard::composed_prove(e, *comm, stages, &ex, fail_rc);
+                n_ex += ex;
+            }
+            break;                                                                // the peers look at the flag behind this layer
+        }
+        (void)c->wait_stream();
+        (void)comm->take_peer_failure();
+    };
     int rc = ZKHIP_OK;
+    uint32_t fail_layer = 0;     // where this rank failed: the layer, and how many of its sessions the peers still run
+    int fail_sessions_left = 0;
+#define GKR_FAIL(sessions_left) { fail_layer = li; fail_sessions_left = (sessions_left); break; }
     for (uint32_t li = 1; li <= n_layers && rc == ZKHIP_OK; ++li) {   // layer one (gkr/src/utils.rs:12-56), then protocol.rs:64-108
         const uint32_t l = li - 1, k = li - 1;
         const uint64_t* V = h_layer_ptrs[li];
@@ -967,40 +999,42 @@ extern "C" int zkhip_gkr_prove_sharded(zkhip_circuit* cir, zkhip_comm* comm, con
         const TablesScratch ts = carve_tables_scratch(aux + o_scr, ld.n_gates, w_len);
         const uint32_t sizes[2] = {2, 2};
         // ---- rounds over b on this rank's rows of [Ha0, V] + Ha1, [Hm, V]
-        if ((rc = layer_tables_enqueue(cir, l, V, w_len, r_b[0].l, two_points ? r_c[0].l : nullptr, alpha.l, beta.l, 0, w, rk, tab, ts)) != ZKHIP_OK) break;
+        if ((rc = layer_tables_enqueue(cir, l, V, w_len, r_b[0].l, two_points ? r_c[0].l : nullptr, alpha.l, beta.l, 0, w, rk, tab, ts)) != ZKHIP_OK) GKR_FAIL(2)
         const uint64_t* v_sh = w > 1 ? tab[3] : V;
         {
             const uint64_t* tables[4] = {tab[0], v_sh, tab[2], v_sh};
             const uint64_t* lin[2] = {tab[1], nullptr};
             zkhip_mc_state* st = nullptr;
-            if ((rc = zkhip_mc_begin_ex(c, tables, sizes, 2, lin, rows, w, 1, claimed.l, 0, 0, &st)) != ZKHIP_OK) break;
+            if ((rc = zkhip_mc_begin_ex(c, tables, sizes, 2, lin, rows, w, 1, claimed.l, 0, 0, &st)) != ZKHIP_OK) GKR_FAIL(2)
             uint32_t ex = 0;
             rc = zkhip_mc_prove_sharded(st, cm, stages ? 1 : 0, nullptr, nullptr, nullptr, &ex);   // recorded on the device; releases the session
             n_ex += ex;
-            if (rc != ZKHIP_OK) break;
+            if (rc != ZKHIP_OK) GKR_FAIL(1)                                     // (its own remaining exchanges were walked inside)
         }
         // ---- rounds over c, b at u = the challenges just recorded: rows of [Aa, V(u) + V], [Am, V(u) V]; V(u) = w_b stays on the device
-        if ((rc = layer_tables_enqueue(cir, l, V, w_len, r_b[0].l, two_points ? r_c[0].l : nullptr, alpha.l, beta.l, 1, w, rk, tab + 4, ts)) != ZKHIP_OK) break;
+        if ((rc = layer_tables_enqueue(cir, l, V, w_len, r_b[0].l, two_points ? r_c[0].l : nullptr, alpha.l, beta.l, 1, w, rk, tab + 4, ts)) != ZKHIP_OK) GKR_FAIL(1)
         uint64_t* polys = h_round_polys + (size_t)k * stride * GKR_MONO * 8;
         uint32_t* lens = h_round_poly_lens + (size_t)k * stride;
         std::vector<uint64_t> challenges(4 * (size_t)(2 * s));
         {
             const uint64_t* tables[4] = {tab[4], tab[5], tab[6], tab[7]};
             zkhip_mc_state* st = nullptr;
-            if ((rc = zkhip_mc_begin_ex(c, tables, sizes, 2, nullptr, rows, w, 1, nullptr, 1, s, &st)) != ZKHIP_OK) break;
+            if ((rc = zkhip_mc_begin_ex(c, tables, sizes, 2, nullptr, rows, w, 1, nullptr, 1, s, &st)) != ZKHIP_OK) GKR_FAIL(1)
             zkshard::HipMcEngine e{st, cm};
+            if ((rc = e.shape_of_session()) != ZKHIP_OK) { zkhip_mc_abort(st); GKR_FAIL(1) }
             uint32_t ex = 0;
             rc = zkshard::composed_prove(e, *cm, stages, &ex);
             n_ex += ex;
-            if (rc != ZKHIP_OK) { zkhip_mc_abort(st); break; }
+            if (rc != ZKHIP_OK) { zkhip_mc_abort(st); GKR_FAIL(0) }
             // w_c = V(r_c), r_c = the second half of the challenges: enqueued behind the rounds, read back with them
             zk::launch_eq_table(c, zk_composed_challenges_dev(c) + 4 * (size_t)s, s, ts.eqh, ts.equ, V, ts.dot_partials, ts.evals + 4);
             if (hipGetLastError() != hipSuccess || hipMemcpyAsync(c->pinned_u64(ZK_PIN_RES), ts.evals, 64, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
                 zkhip_mc_abort(st);
                 rc = ZKHIP_ERR_HIP;
-                break;
+                GKR_FAIL(0)
             }
-            if ((rc = zkhip_mc_finish(st, lens, polys, challenges.data())) != ZKHIP_OK) break;   // all 2 s rounds; synchronises the stream
+            if ((rc = zkhip_mc_finish(st, lens, polys, challenges.data())) != ZKHIP_OK) GKR_FAIL(0)   // all 2 s rounds; synchronises the stream
+            if (comm->take_peer_failure()) { rc = ZKHIP_ERR_PEER; break; }     // a peer's poison record in one of this layer's exchanges: every healthy rank stops here
         }
         zkhost::Fr eval_wb, eval_wc;
         std::memcpy(eval_wb.l, c->pinned_u64(ZK_PIN_RES), 32);
@@ -1019,6 +1053,8 @@ extern "C" int zkhip_gkr_prove_sharded(zkhip_circuit* cir, zkhip_comm* comm, con
         beta = tr.challenge_fr();
         claimed = zkhost::fr_add(zkhost::fr_mul(alpha, eval_wb), zkhost::fr_mul(beta, eval_wc));
     }
+#undef GKR_FAIL
+    if (fail_layer) walk_failed(fail_sessions_left ? fail_layer : fail_layer + 1, fail_sessions_left ? fail_sessions_left : 2, rc);
     if (exchanges) *exchanges = n_ex;
     return rc;
 }

@@ -36,6 +36,8 @@ extern "C" const char* zkhip_status_string(int s) {
         case ZKHIP_ERR_ARG: return "invalid argument";
         case ZKHIP_ERR_NOMEM: return "out of memory";
         case ZKHIP_ERR_BUSY: return "workspace lent to a live split-phase session";
+        case ZKHIP_ERR_PEER: return "another rank of the sharded prover failed";
+        case ZKHIP_ERR_TIMEOUT: return "a device-side wait gave up";
         default: return "unknown";
     }
 }
@@ -919,7 +921,7 @@ extern "C" int zkhip_sumcheck_prove(zkhip_ctx* c, const uint64_t* d_evals, size_
     return sumcheck_collect(c, 0, n_vars, h_sum, h_round_polys, h_challenges);
 }
 // Sumcheck::prove in flight: begin enqueues the whole proof and returns a ticket, end waits for it and delivers the outputs of
-// zkhip_sumcheck_prove.  Up to four proofs of tables with >= 2 entries may be in flight, each on streams and buffers of its own
+// zkhip_sumcheck_prove.  Up to eight proofs of tables with >= 2 entries may be in flight, each on streams and buffers of its own
 // (zkhip_ctx::ProofLane): the streaming passes of one run while the transcript rounds of the others hash.
 extern "C" int zkhip_sumcheck_prove_begin(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_claimed_sum,
                                           const uint64_t* d_claimed_sum, const uint64_t* d_block_sums, uint32_t log_blocks,
@@ -1027,15 +1029,17 @@ extern "C" int zkhip_sc_begin(zkhip_ctx* c, const uint64_t* d_local, size_t n_lo
 }
 
 // ---- stage form -------------------------------------------------------------------------------------
-extern "C" int zkhip_sc_stage_plan(zkhip_sc_state* st, uint32_t world, uint32_t* k_out) {
-    if (!st || !k_out || !is_pow2(world)) return ZKHIP_ERR_ARG;
+// The plans are PURE functions of (entries per shard, world): a rank that failed -- possibly before it had a state at all -- still
+// walks the exchange schedule of the protocol with them (shard_protocol.hpp, "a failing rank must not hang its peers").
+int zk_sc_plan_stage(size_t cn, uint32_t world, uint32_t* k_out) {
+    if (!k_out || !is_pow2(world) || !is_pow2(cn)) return ZKHIP_ERR_ARG;
     uint32_t k;
     if (world == 1) {
-        k = stage_k(st->cn);                    // the single-GPU plan
+        k = stage_k(cn);                        // the single-GPU plan
     } else {
         // Every stage costs an exchange: use as few as the kernels allow (<= MF_CAP_LOGK variables per stage, the
         // gathered tail takes zkhip_sc_tail_capacity() entries) and spread the variables evenly over them.
-        const uint32_t lg = log2_exact(st->cn * world);
+        const uint32_t lg = log2_exact(cn * world);
         const uint32_t tail_log = log2_exact((size_t)zkhip_sc_tail_capacity());
         if (lg <= tail_log) k = 0;
         else {
@@ -1044,8 +1048,15 @@ extern "C" int zkhip_sc_stage_plan(zkhip_sc_state* st, uint32_t world, uint32_t*
             k = std::max<uint32_t>((need + stages - 1) / stages, 3);   // a stage folds at least 3 variables (overshooting the tail size is fine)
         }
     }
-    while (k && (st->cn >> k) < 16) --k;       // the local k-variable fold needs >= 16 outputs per workgroup
+    while (k && (cn >> k) < 16) --k;           // the local k-variable fold needs >= 16 outputs per workgroup
     if (k < 3) k = 0;                           // too little left: gather the tables and finish replicated
+    *k_out = k;
+    return ZKHIP_OK;
+}
+extern "C" int zkhip_sc_stage_plan(zkhip_sc_state* st, uint32_t world, uint32_t* k_out) {
+    if (!st || !k_out || !is_pow2(world)) return ZKHIP_ERR_ARG;
+    uint32_t k = 0;
+    ZK_TRY(zk_sc_plan_stage(st->cn, world, &k));
     st->stage_k_cur = k;
     st->stage_world = world;
     *k_out = k;
@@ -1113,19 +1124,29 @@ extern "C" int zkhip_sc_stage_fold(zkhip_sc_state* st) {
 // while the k1-variable fold of the shard runs on the context's fold stream; after the k2 rounds the fold's output is folded
 // by the k2 variables into a 256-entry local table (gathered by the caller for the last rounds).  Three exchanges in all,
 // as in the plain stage form, with the big fold hidden behind the second one and the serial kernel of the k2 rounds.
+int zk_sc_plan_overlap(size_t cn, uint32_t world, uint32_t* k1, uint32_t* k2, uint32_t* mid_entries, uint32_t* ny_out) {
+    if (!k1 || !k2 || !mid_entries || !is_pow2(world)) return ZKHIP_ERR_ARG;
+    *k1 = *k2 = *mid_entries = 0;
+    if (ny_out) *ny_out = 0;
+    if (!overlapped_shard(cn)) return ZKHIP_OK;
+    if ((size_t)256 * world > (size_t)zkhip_sc_tail_capacity()) return ZKHIP_OK;      // the gathered 256-entry tables must fit the tail
+    const uint32_t g = log2_exact(cn) - 8;
+    const uint32_t ov_k2 = overlapped_k2(cn), ov_k1 = g - ov_k2;
+    BlockfoldShape sh;
+    if (!blockfold_shape(1u << ov_k2, ov_k1, &sh)) return ZKHIP_ERR_SHAPE;
+    *k1 = ov_k1; *k2 = ov_k2; *mid_entries = sh.ny << ov_k2;
+    if (ny_out) *ny_out = sh.ny;
+    return ZKHIP_OK;
+}
 extern "C" int zkhip_sc_overlap_plan(zkhip_sc_state* st, uint32_t world, uint32_t* k1, uint32_t* k2, uint32_t* mid_entries) {
     if (!st || !k1 || !k2 || !mid_entries || !is_pow2(world)) return ZKHIP_ERR_ARG;
     *k1 = *k2 = *mid_entries = 0;
-    if (st->round != 0 || st->stage_idx != 0 || st->ov_phase != 0 || !overlapped_shard(st->cn)) return ZKHIP_OK;
-    if ((size_t)256 * world > (size_t)zkhip_sc_tail_capacity()) return ZKHIP_OK;      // the gathered 256-entry tables must fit the tail
-    const uint32_t g = log2_exact(st->cn) - 8;
-    st->ov_k2 = overlapped_k2(st->cn);
-    st->ov_k1 = g - st->ov_k2;
-    BlockfoldShape sh;
-    if (!blockfold_shape(1u << st->ov_k2, st->ov_k1, &sh)) return ZKHIP_ERR_SHAPE;
-    st->ov_ny1 = sh.ny;
+    if (st->round != 0 || st->stage_idx != 0 || st->ov_phase != 0) return ZKHIP_OK;
+    uint32_t ny = 0;
+    ZK_TRY(zk_sc_plan_overlap(st->cn, world, k1, k2, mid_entries, &ny));
+    if (!*k1) return ZKHIP_OK;
+    st->ov_k1 = *k1; st->ov_k2 = *k2; st->ov_ny1 = ny;
     st->stage_world = world;
-    *k1 = st->ov_k1; *k2 = st->ov_k2; *mid_entries = sh.ny << st->ov_k2;
     return ZKHIP_OK;
 }
 // d_out: the 2^k1 coarse block sums of the local shard (canonical integers; they add up across ranks all the same)

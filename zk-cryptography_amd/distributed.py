@@ -176,6 +176,10 @@ class Comm:
         N.check(N.lib().zkhip_comm_measure(self.handle, C.c_size_t(nbytes), C.c_uint32(iters), C.byref(a), C.byref(b)), "comm_measure")
         return a.value, b.value
 
+    def inject_failure(self, exchange_index, status=N.ERR_NOMEM):
+        """test hook (zkhip_comm_inject_failure): the next protocol run on this comm fails on THIS rank in front of that exchange"""
+        N.check(N.lib().zkhip_comm_inject_failure(self.handle, C.c_int(exchange_index), C.c_int(status)), "comm_inject_failure")
+
     def check(self, status, what):
         """N.check, re-raising what a staged exchange caught inside its callback"""
         if status != N.ZKHIP_OK and self.error is not None:
