@@ -1010,7 +1010,7 @@ def main():
     # HBM bytes per launch from the PMC counters: separate rocprofv3 --pmc passes of this command, committed under profiles/rNN
     # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); the NEWEST round's file is read and named -- a file constant of that
     # round's build, labelled as such, not a counter of this run
-    traffic, traffic_source, traffic_all = None, None, None
+    traffic, traffic_source, traffic_all, traffic_age = None, None, None, None
     try:
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "pmc_traffic.json")))
@@ -1024,6 +1024,16 @@ def main():
                 if hits and short not in traffic_all:
                     traffic_all[short] = max(h["hbm_bytes_per_launch"] for h in hits)      # the 2^24-entry launch of the step
             traffic_source = src + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in round %s; not collected in this run)" % src.split(os.sep)[1]
+            # how old is that constant?  The file carries a fingerprint of the streaming kernels' sources it was collected with (tools/pmc_summary.py);
+            # compared with the tree this run comes from -- a rebuilt kernel must not silently keep the old ratio (tools/collect.sh refreshes it)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from pmc_summary import kernel_sources_fingerprint
+            now_fp, then_fp = kernel_sources_fingerprint(ROOT), pmc.get("kernel_sources_sha16")
+            traffic_age = {"collected_with_kernel_sources_sha16": then_fp, "this_run_kernel_sources_sha16": now_fp,
+                           "stale": (then_fp != now_fp) if then_fp else None,
+                           "note": ("the PMC file predates the fingerprint: age unknown" if not then_fp else
+                                    "same kernel sources as the PMC passes" if then_fp == now_fp else
+                                    "the streaming kernels' sources CHANGED since the PMC passes: re-collect (tools/collect.sh)")}
     except Exception:
         traffic = None
     longest = max(per_kernel, key=lambda k: per_kernel[k]["avg_launch_us"]) if per_kernel else None
@@ -1036,7 +1046,7 @@ def main():
             traffic = traffic_all[longest]
     roofline = {"bound": "hbm", "kernel": lk["kernel"] if lk else "multifold_mfma_kernel<4, 4>",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "traffic_age": traffic_age,
                 "launches": cnt, "avg_launch_us": round(1e3 * ms / max(1, cnt), 2),
                 "algorithmic_bytes_per_launch": lk["bytes_per_launch"] if lk else None,
                 "algorithmic_bytes_note": "fine_sums: 32 B x table entries read; multifold: 32 B x (table entries read + folded entries written), k variables per launch",

@@ -482,9 +482,12 @@ int zkhip_kzg_commit(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t 
  * table take a short path without sort or buckets -- one plain sum per digit bit, two launches: 0.42 ms at 2^8 against 0.65).  With it the digits
  * of all windows fall into ONE bucket set: at 2^20 13 n bucket additions instead of 16 n and a single bucket reduction.  The table
  * depends on the SRS only (built once, ~70 ms at 2^20); zkhip_kzg_commit_table then has the semantics of zkhip_kzg_commit (same group
- * element, same errors).  n * W must stay below 2^31.  A table has no header: its layout (W and the two window widths) is a function
- * of n_points alone -- and of the tuning variable ZKHIP_LEVEL_TABLE_DELTA, which the library reads ONCE per process -- so a table is
- * valid for the n_points it was built for, in processes that run with the same value (the default everywhere but in tools/). */
+ * element, same errors).  n * W must stay below 2^31.  A table begins with a 128-byte HEADER (magic, kind, n_points, window widths,
+ * entries; included in zkhip_srs_table_bytes / zkhip_srs_level_tables_bytes): its layout is a function of n_points and of the tuning
+ * variable ZKHIP_LEVEL_TABLE_DELTA (read once per process), and every entry point that takes a table compares the header with the
+ * geometry it is about to address the table with -- a table built for another size, of the other kind, by a process that ran with
+ * another value, or a buffer that is no table -> ZKHIP_ERR_ARG instead of a wrong commitment.  (One 128-byte read the first time a
+ * context sees a (table, size) pair, remembered until a table is built at that address again.) */
 size_t zkhip_srs_table_bytes(size_t n_points);
 /* Content check for a host-side cache of what is derived from an SRS (the table above, the folded levels): the first two and the last
  * two points with their infinity flags, h_out[52] = 4 x (12 coordinate words, flag) -- one small launch, one copy, ~20 us.  A wrapper

@@ -271,3 +271,25 @@ def test_gate_replaced_in_place_proves_the_edited_circuit(zk, ora):
     again = zk.GKRProtocol.prove(circuit, circuit.evaluation(inp))
     fresh2 = zk.Circuit.from_tuples([[(g.gate_type, g.inputs[0], g.inputs[1]) for g in layer.layer] for layer in circuit.layers])
     assert [p.to_bytes() for p in again.sumcheck_proofs] == [p.to_bytes() for p in zk.GKRProtocol.prove(fresh2, fresh2.evaluation(inp)).sumcheck_proofs]
+
+
+def test_gkr_fresh_context_in_a_destroyed_ones_memory(zk, ora):
+    """A context is destroyed and the next one -- whose scratch may be the very memory the old one proved in, outer-transcript ring flags
+    and all, with session tokens that restart at 1 -- proves ANOTHER input of the same shape: every proof bit-exact and accepted by the
+    restated verifier (the flags are cleared per proof; a stale flag equal to the live token would let the hasher absorb the previous
+    proof's round items)."""
+    from zk_cryptography_amd import _native as N
+    for depth in (8, 5):
+        layers = random_circuit(depth)
+        for seed in range(4):
+            _check_against_oracle(zk, ora, layers, ora.random_fr(2 ** depth, 8800 + 10 * depth + seed))
+            N.Context.get(0).destroy()                   # the next proof runs on a fresh context (Context.get creates it)
+    # an explicitly destroyed context takes its device circuits with it: nothing dereferences the freed context later
+    circuit = zk.Circuit.from_tuples(random_circuit(4))
+    inp = ora.random_fr(16, 8899)
+    zk.GKRProtocol.prove(circuit, circuit.evaluation(inp))
+    dev = circuit._device
+    N.Context.get(0).destroy()
+    assert not dev.alive() and not dev.handle
+    del dev
+    _check_against_oracle(zk, ora, random_circuit(4), inp)

@@ -113,3 +113,49 @@ def test_workspace_is_busy_while_a_session_is_live(zk, ora):
     eng = D.HipSumcheckEngine(t)
     del eng
     sc.prove()
+
+
+def test_tables_carry_a_header_that_is_checked_against_the_geometry(zk, ora):
+    """A shifted-SRS table / the level tables begin with a 128-byte header (magic, kind, points, window widths): handed to an entry point
+    that would address them with another geometry they are refused (ZKHIP_ERR_ARG) instead of giving a wrong commitment."""
+    import torch
+    from zk_cryptography_amd import _native as N
+    lib = N.lib()
+    lib.zkhip_srs_table_bytes.restype = C.c_size_t
+    lib.zkhip_srs_level_tables_bytes.restype = C.c_size_t
+    srs10 = zk.TrustedSetup.setup(ora.random_fr(10, 4501)).precompute().precompute_open()
+    srs9 = zk.TrustedSetup.setup(ora.random_fr(9, 4502)).precompute()
+    ctx = N.Context.get(0)
+    sc = torch.from_numpy(ora.random_fr(1 << 10, 4503).view(np.int64)).cuda()
+    xy, inf = np.zeros(12, np.uint64), C.c_uint8(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+
+    def commit(table, srs, n_points, n_scalars):
+        return lib.zkhip_kzg_commit_table(ctx.handle, N.ptr(table), N.ptr(srs.inf), C.c_size_t(n_points), N.ptr(sc), C.c_size_t(n_scalars), C.c_int(0), p(xy), C.byref(inf))
+    assert commit(srs10._table, srs10, 1 << 10, 1 << 10) == N.ZKHIP_OK
+    want = zk.MultilinearKZG.commitment(zk.Multilinear(sc), zk.TrustedSetup(srs10.powers_of_tau_in_g1, srs10.inf))      # no table: the bucket pipeline on the points
+    assert np.array_equal(xy, want.xy)
+    assert commit(srs10._table, srs10, 1 << 9, 1 << 9) == N.ERR_ARG              # a table built for 2^10 points addressed as one of 2^9
+    assert commit(srs9._table, srs10, 1 << 10, 1 << 10) == N.ERR_ARG             # ... and the other way round (the header is read, nothing behind it)
+    assert commit(srs10._level_tables, srs10, 1 << 10, 1 << 10) == N.ERR_ARG     # level tables are not a shifted-SRS table
+    junk = torch.zeros(lib.zkhip_srs_table_bytes(C.c_size_t(1 << 10)), dtype=torch.uint8, device="cuda")
+    assert commit(junk, srs10, 1 << 10, 1 << 10) == N.ERR_ARG                    # no table at all
+    tk = C.c_uint32(0)
+    assert lib.zkhip_kzg_commit_begin(ctx.handle, None, N.ptr(srs9._table), N.ptr(srs10.inf), C.c_size_t(1 << 10), N.ptr(sc), C.c_size_t(1 << 10), C.c_int(0),
+                                      C.byref(tk)) == N.ERR_ARG
+    # openings: the shifted-SRS table where the level tables belong
+    ev = torch.from_numpy(ora.random_fr(1 << 10, 4504).view(np.int64)).cuda()
+    z = ora.random_fr(10, 4505)
+    fxy, finf = srs10.folded()
+    h_ev, pxy, pinf = np.zeros(4, np.uint64), np.zeros((10, 12), np.uint64), np.zeros(10, np.uint8)
+
+    def open_with(tables):
+        return lib.zkhip_kzg_open_tables(ctx.handle, N.ptr(ev), C.c_size_t(1 << 10), p(z), C.c_size_t(10), N.ptr(srs10.powers_of_tau_in_g1), N.ptr(srs10.inf),
+                                         C.c_size_t(1 << 10), N.ptr(fxy), N.ptr(finf), N.ptr(tables), p(h_ev), p(pxy), p(pinf))
+    assert open_with(srs10._level_tables) == N.ZKHIP_OK
+    assert np.array_equal(h_ev, ora.mle_evaluation(ev.cpu().numpy().view(np.uint64), z))
+    assert open_with(srs10._table) == N.ERR_ARG
+    # a table REBUILT at the same address for another size is checked again, not remembered
+    N.check(lib.zkhip_srs_precompute(ctx.handle, N.ptr(srs9.powers_of_tau_in_g1), N.ptr(srs9.inf), C.c_size_t(1 << 9), N.ptr(srs10._table)), "precompute")
+    assert commit(srs10._table, srs10, 1 << 10, 1 << 10) == N.ERR_ARG
+    assert commit(srs10._table, srs9, 1 << 9, 1 << 9) == N.ZKHIP_OK

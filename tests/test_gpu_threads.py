@@ -213,7 +213,10 @@ def test_threads_prove_one_circuit_at_once_each_on_its_own_stream(zk, ora, n_thr
     for t in ths:
         t.join()
     assert not errors and all(got), errors
-    assert len(circuit._devices) == n_threads + 1            # the main thread's copy and one per worker context
+    assert len(circuit._devices) == n_threads + 1            # the main thread's copy and one per worker context ...
+    assert sum(d.alive() for d in circuit._devices) >= 1     # ... whose contexts (and device copies) went with their threads; the Circuit kept none of them alive
+    zk.GKRProtocol.prove(circuit, ev)                        # the next proof drops the dead entries
+    assert all(d.alive() for d in circuit._devices)
 
 
 def test_soak_create_destroy_and_aborted_sessions_return_all_memory(zk, ora):

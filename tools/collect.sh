@@ -6,10 +6,12 @@
 R=${1:?round name, e.g. r04}
 mkdir -p gpurun_out/$R
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-P="--steps 3 --warmup 1 --no-cpu-baseline --no-msm --no-composed --no-gkr --no-ntt --no-h2d --no-exchange --no-pipelined"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -- python3 bench.py --no-cpu-baseline > gpurun_out/$R/bench_under_rocprof.json 2> gpurun_out/$R/stats.err
+# (--no-gkr-threads in every profiled run: that leg's child process would inherit the profiler's preload and its 4 / 8-thread proofs would
+# land in the kernel averages the roofline object is checked against)
+P="--steps 3 --warmup 1 --no-cpu-baseline --no-msm --no-composed --no-gkr --no-ntt --no-h2d --no-exchange --no-pipelined --no-gkr-threads"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -- python3 bench.py --no-cpu-baseline --no-gkr-threads > gpurun_out/$R/bench_under_rocprof.json 2> gpurun_out/$R/stats.err
 # the prover leg alone (no proofs in flight, whose overlapped kernels run longer): the averages the roofline object is checked against
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats_prover -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-msm --no-composed --no-gkr --no-ntt --no-h2d --no-exchange --no-pipelined > gpurun_out/$R/bench_prover_under_rocprof.json 2> gpurun_out/$R/stats_prover.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats_prover -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-msm --no-composed --no-gkr --no-ntt --no-h2d --no-exchange --no-pipelined --no-gkr-threads > gpurun_out/$R/bench_prover_under_rocprof.json 2> gpurun_out/$R/stats_prover.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/pmc_fetch -- python3 bench.py $P > /dev/null 2> gpurun_out/$R/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/pmc_write -- python3 bench.py $P > /dev/null 2> gpurun_out/$R/pmc_write.err
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/$R/pmc_sq_ntt -- python3 tools/perf_ntt.py 21 > gpurun_out/$R/pmc_sq_ntt.txt 2>&1

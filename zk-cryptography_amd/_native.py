@@ -92,6 +92,7 @@ class Context:
         self.device = torch.device("cuda", device_index)
         self.handle = C.c_void_p()
         self._comms = []                 # distributed.Comm objects created on this context: closed before the context goes
+        self._circuits = []              # gkr._DeviceCircuit objects (zkhip_circuit handles refer to their context): destroyed first, too
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
             check(lib().zkhip_ctx_create(C.byref(self.handle), C.c_int(device_index), C.c_void_p(stream)), "ctx_create")
@@ -110,11 +111,13 @@ class Context:
         return ctx
 
     def destroy(self):
-        """zkhip_ctx_destroy: closes the communicators created on this context (a zkhip_comm refers to its context), waits for the
+        """zkhip_ctx_destroy: closes the communicators and device circuits created on this context (both refer to it), waits for the
         context's streams and returns every buffer it holds"""
         if self.handle:
             for m in list(self._comms):
                 m.close()
+            for d in list(self._circuits):
+                d.close()
             h, self.handle = self.handle, None
             table = Context._tls.__dict__.get("contexts", {})
             for k, v in list(table.items()):

@@ -115,6 +115,11 @@ struct ComposedRun {
     FrArg sum_arg = {};      // the claimed sum, passed to the closing kernels by value
     const uint64_t* sum_dev = nullptr;   // ... or read by them from device memory (gkr.hip: the kernel before computed it)
     OuterPub outer = {};     // an outer transcript fed beside the rounds (composed_kernels.hpp): every closing launch gets a hasher workgroup
+    // RESIDENCY ASSUMPTION of every launch that adds extra_wg(): the hasher is the LAST workgroup of the grid and spin-waits (with a
+    // time-out -> OuterDev::error -> ZKHIP_ERR_TIMEOUT) for a flag the closing workgroup of the SAME grid raises, so both must be resident
+    // at once.  They are: the closer is dispatched first (workgroup 0 of a one- or two-workgroup grid; in composed_pipe_round_kernel the
+    // closing workgroup comes behind at most PIPE_MAX_WGS = 2 x 256 tile workgroups that never wait for anything), and a grid of at most
+    // 514 workgroups of <= 1024 lanes is less than the chip holds.  Other processes' kernels can delay the closer, not evict it.
     unsigned extra_wg() const { return outer.dev ? 1u : 0u; }
 
     // n = entries per table held here, n_rounds = rounds of the whole sumcheck (log2 n, more when other ranks hold shards)

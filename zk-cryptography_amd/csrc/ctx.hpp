@@ -187,6 +187,17 @@ struct zkhip_ctx {
         }
         return host_pool;
     }
+    // shifted-SRS / level tables whose header has been compared with the geometry of (kind, n_points) on this context (msm.hip table_check)
+    struct TableOk { const void* p = nullptr; size_t n = 0; uint32_t kind = 0; };
+    static constexpr int TABLE_OK_SLOTS = 16;
+    TableOk table_ok[TABLE_OK_SLOTS];
+    int table_ok_next = 0;
+    bool table_checked(const void* p, size_t n, uint32_t kind, bool remember) {
+        for (const auto& t : table_ok) if (t.p == p && t.n == n && t.kind == kind) return true;
+        if (remember) { table_ok[table_ok_next] = TableOk{p, n, kind}; table_ok_next = (table_ok_next + 1) % TABLE_OK_SLOTS; }
+        return false;
+    }
+    void table_forget(const void* p) { for (auto& t : table_ok) if (t.p == p) t = TableOk{}; }      // a table is being (re)built at p
     bool ws_lent = false;       // the workspace currently backs a split-phase prover state or commits in flight
     // commits in flight (zkhip_kzg_commit_begin / _end): two slots, each with a region of the workspace, a side stream and a
     // pinned result buffer of its own; `async_pend` is an MsmPending allocated by msm.hip

@@ -274,22 +274,87 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
     return msm_commit(c, d_points_xy, d_points_inf, d_scalars, n, h_out_xy, h_out_inf);
 }
 
+// A table begins with a 128-byte HEADER (magic, kind, the number of points it was built for, its window widths, its number of entries):
+// the layout of a table is a function of its size AND of a tuning variable read once per process (msm_level_table_widths), the kernels address
+// it blindly, and a table built for another size -- or by a process that ran with another value -- would give a silently wrong commitment.
+// zkhip_kzg_commit_table / _commit_begin / zkhip_kzg_open_tables compare the header with the geometry they are about to use (one 128-byte read
+// the first time a (table, size) pair is seen on a context, remembered after that) -> ZKHIP_ERR_ARG on a mismatch.
+constexpr size_t ZK_TABLE_HEADER_BYTES = 128;
+constexpr uint64_t ZK_TABLE_MAGIC = 0x31304c42544b5a00ull;       // "\0ZKTBL01"
+enum : uint32_t { ZK_TABLE_SHIFTED_SRS = 1, ZK_TABLE_LEVELS = 2 };
+struct ZkTableHeader {
+    uint64_t magic;
+    uint32_t kind, version;
+    uint64_t n_points, entries;
+    uint32_t W, hi, n_hi;          // the widths of the (first, largest) table
+    uint32_t widths_hash;          // FNV-1a over (h, W, hi, n_hi) of every level (level tables)
+    uint8_t pad_[ZK_TABLE_HEADER_BYTES - 48];
+};
+static_assert(sizeof(ZkTableHeader) == ZK_TABLE_HEADER_BYTES, "one 128-byte entry in front of the table");
+static size_t level_tables_first(size_t n_points, size_t* lvl_off);
+static ZkTableHeader table_header_for(uint32_t kind, size_t n_points) {
+    ZkTableHeader h;
+    std::memset(&h, 0, sizeof(h));
+    h.magic = ZK_TABLE_MAGIC; h.kind = kind; h.version = 1; h.n_points = n_points;
+    uint32_t fnv = 2166136261u;
+    auto mix = [&](uint32_t v) { for (int b = 0; b < 4; ++b) { fnv ^= (v >> (8 * b)) & 0xffu; fnv *= 16777619u; } };
+    if (kind == ZK_TABLE_SHIFTED_SRS) {
+        const MsmLevelWidths lw = msm_table_widths(n_points);
+        h.W = lw.W; h.hi = lw.hi; h.n_hi = lw.n_hi; h.entries = (uint64_t)lw.W * n_points;
+        mix((uint32_t)n_points); mix(lw.W); mix(lw.hi); mix(lw.n_hi);
+    } else {
+        const size_t first = level_tables_first(n_points, nullptr);
+        for (size_t q = first; q >= 1; q /= 2) {
+            const MsmLevelWidths lw = msm_level_table_widths(q, 2 * first - 1);
+            if (q == first) { h.W = lw.W; h.hi = lw.hi; h.n_hi = lw.n_hi; }
+            h.entries += (uint64_t)lw.W * q;
+            mix((uint32_t)q); mix(lw.W); mix(lw.hi); mix(lw.n_hi);
+        }
+    }
+    h.widths_hash = fnv;
+    return h;
+}
+static int table_write_header(zkhip_ctx* c, void* d_table, uint32_t kind, size_t n_points) {
+    const ZkTableHeader h = table_header_for(kind, n_points);
+    ZK_HIP(c, hipMemcpy(d_table, &h, sizeof(h), hipMemcpyHostToDevice));      // (once per SRS; synchronous)
+    c->table_checked(d_table, n_points, kind, true);
+    return ZKHIP_OK;
+}
+// -> the table proper (behind the header), or nullptr with *rc set
+static const uint32_t* table_check(zkhip_ctx* c, const void* d_table, uint32_t kind, size_t n_points, int* rc) {
+    *rc = ZKHIP_OK;
+    if (!c->table_checked(d_table, n_points, kind, false)) {
+        ZkTableHeader got;
+        if (hipMemcpy(&got, d_table, sizeof(got), hipMemcpyDeviceToHost) != hipSuccess) { *rc = ZKHIP_ERR_HIP; return nullptr; }
+        const ZkTableHeader want = table_header_for(kind, n_points);
+        if (std::memcmp(&got, &want, 48) != 0) { *rc = ZKHIP_ERR_ARG; return nullptr; }     // not a table, another kind, another size, other widths
+        c->table_checked(d_table, n_points, kind, true);
+    }
+    return (const uint32_t*)((const char*)d_table + ZK_TABLE_HEADER_BYTES);
+}
+
 // ---------------------------------------------------------------------------------------
 // commits in flight: a commit is a throughput-bound accumulate pass followed by latency-bound reduction passes (chains of
 // ~25 us point additions on a mostly idle chip) and a host epilogue; a prover that commits several polynomials in a row
 // hides the latter behind the next commits' accumulate passes.  Three slots (2 / 3 / 4 in flight: 3.03 / 2.91 / 2.98 ms per 2^20-point
 // commit; the accumulate pass and the sort are throughput work, only the reductions and the epilogue hide); same results as the synchronous calls.
 // ---------------------------------------------------------------------------------------
-extern "C" int zkhip_kzg_commit_begin(zkhip_ctx* c, const uint64_t* d_points_xy, const void* d_table, const uint8_t* d_points_inf,
+extern "C" int zkhip_kzg_commit_begin(zkhip_ctx* c, const uint64_t* d_points_xy, const void* d_table_with_header, const uint8_t* d_points_inf,
                                       size_t n_points, const uint64_t* d_scalars, size_t n_scalars, int require_equal_len,
                                       uint32_t* ticket) {
-    if (!c || !ticket || (!d_points_xy == !d_table)) return ZKHIP_ERR_ARG;
+    if (!c || !ticket || (!d_points_xy == !d_table_with_header)) return ZKHIP_ERR_ARG;
     if (require_equal_len && n_points != n_scalars) return ZKHIP_ERR_SHAPE;   // multilinear_kzg.rs:36-41
     if (n_scalars > n_points) return ZKHIP_ERR_INDEX;                          // univariate_kzg.rs:53
     const size_t n = n_scalars;
     if (n == 0 || !d_scalars) return ZKHIP_ERR_ARG;                           // nothing to overlap: use the synchronous call
-    if (n >= ((size_t)1 << 31) || (d_table && n_points * msm_table_widths(n_points).W >= ((size_t)1 << 31))) return ZKHIP_ERR_SHAPE;
+    if (n >= ((size_t)1 << 31) || (d_table_with_header && n_points * msm_table_widths(n_points).W >= ((size_t)1 << 31))) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
+    const uint32_t* d_table = nullptr;
+    if (d_table_with_header) {
+        int trc = ZKHIP_OK;
+        d_table = table_check(c, d_table_with_header, ZK_TABLE_SHIFTED_SRS, n_points, &trc);       // built for THESE n_points, with the widths used below?
+        if (!d_table) return trc;
+    }
     int slot = -1;
     bool any = false;
     for (int k = zkhip_ctx::ASYNC_SLOTS - 1; k >= 0; --k) { if (!c->async_pend[k]) slot = k; else any = true; }
@@ -386,7 +451,7 @@ extern "C" int zkhip_srs_fingerprint(zkhip_ctx* c, const uint64_t* d_points_xy, 
 // ---------------------------------------------------------------------------------------
 // shifted-SRS table: commitments with one bucket set for all windows
 // ---------------------------------------------------------------------------------------
-extern "C" size_t zkhip_srs_table_bytes(size_t n_points) { return n_points ? n_points * msm_table_widths(n_points).W * 128 : 0; }
+extern "C" size_t zkhip_srs_table_bytes(size_t n_points) { return n_points ? ZK_TABLE_HEADER_BYTES + n_points * msm_table_widths(n_points).W * 128 : 0; }
 
 // windows 0 .. n_windows-1 of c bits over n affine points: table entry w * n + i = 2^(c w) * point i (internal 28-bit-limb layout, 128 bytes);
 // the context's workspace holds one window in XYZZ and affine form meanwhile
@@ -423,9 +488,10 @@ extern "C" int zkhip_srs_precompute(zkhip_ctx* c, const uint64_t* d_points_xy, c
     const MsmLevelWidths lw = msm_table_widths(n);
     if (n * lw.W >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;   // entry index + sign bit in 32 bits
     ZK_TRY(c->activate());
-    ZK_TRY(build_shift_table(c, d_points_xy, d_points_inf, n, lw.hi, lw.W, (uint32_t*)d_table, lw.n_hi));
+    c->table_forget(d_table);
+    ZK_TRY(build_shift_table(c, d_points_xy, d_points_inf, n, lw.hi, lw.W, (uint32_t*)((char*)d_table + ZK_TABLE_HEADER_BYTES), lw.n_hi));
     ZK_HIP(c, hipStreamSynchronize(c->stream));   // the workspace is reused by the next call
-    return ZKHIP_OK;
+    return table_write_header(c, d_table, ZK_TABLE_SHIFTED_SRS, n);      // last: a table whose build failed carries no valid header
 }
 
 // LEVEL TABLES: shifted tables of the folded SRS levels MultilinearKZG::open commits against in ONE batch (the levels of at most
@@ -443,13 +509,15 @@ extern "C" size_t zkhip_srs_level_tables_bytes(size_t n_points) {
     size_t entries = 0;
     const size_t first = level_tables_first(n_points, nullptr);
     for (size_t h = first; h >= 1; h /= 2) entries += (size_t)msm_level_table_widths(h, 2 * first - 1).W * h;
-    return entries * 128;
+    return ZK_TABLE_HEADER_BYTES + entries * 128;
 }
-extern "C" int zkhip_srs_level_tables(zkhip_ctx* c, const uint64_t* d_folded_xy, const uint8_t* d_folded_inf, size_t n_points, void* d_tables) {
-    if (!c || !d_folded_xy || !d_folded_inf || !d_tables) return ZKHIP_ERR_ARG;
+extern "C" int zkhip_srs_level_tables(zkhip_ctx* c, const uint64_t* d_folded_xy, const uint8_t* d_folded_inf, size_t n_points, void* d_tables_with_header) {
+    if (!c || !d_folded_xy || !d_folded_inf || !d_tables_with_header) return ZKHIP_ERR_ARG;
     if (n_points < 2 || !is_pow2(n_points)) return ZKHIP_ERR_SHAPE;
     if (zkhip_srs_level_tables_bytes(n_points) / 128 >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
+    c->table_forget(d_tables_with_header);
+    void* d_tables = (char*)d_tables_with_header + ZK_TABLE_HEADER_BYTES;
     size_t off = 0, entry = 0;
     const size_t first = level_tables_first(n_points, &off);
     if (n_points <= MSM_SMALL_MAX) {
@@ -482,7 +550,7 @@ extern "C" int zkhip_srs_level_tables(zkhip_ctx* c, const uint64_t* d_folded_xy,
         hipLaunchKernelGGL(msm_clear_inf_kernel, dim3(grid), dim3(MSM_BLOCK), 0, c->stream, (const uint8_t*)(ws + o_inf), entry, (uint32_t*)d_tables);
         ZK_HIP(c, hipGetLastError());
         ZK_HIP(c, hipStreamSynchronize(c->stream));
-        return ZKHIP_OK;
+        return table_write_header(c, d_tables_with_header, ZK_TABLE_LEVELS, n_points);
     }
     for (size_t h = first; h >= 1; h /= 2) {
         const MsmLevelWidths lw = msm_level_table_widths(h, 2 * first - 1);      // the batch: the levels first, first / 2, ..., 1
@@ -492,7 +560,7 @@ extern "C" int zkhip_srs_level_tables(zkhip_ctx* c, const uint64_t* d_folded_xy,
         entry += (size_t)W * h;
     }
     ZK_HIP(c, hipStreamSynchronize(c->stream));
-    return ZKHIP_OK;
+    return table_write_header(c, d_tables_with_header, ZK_TABLE_LEVELS, n_points);
 }
 
 // Commits of at most MSM_SMALL_MAX scalars against a shifted-SRS table: the plane sums of msm_kernels.hpp "commits of a few thousand
@@ -562,7 +630,7 @@ static bool msm_small_on() {
     return on;
 }
 
-extern "C" int zkhip_kzg_commit_table(zkhip_ctx* c, const void* d_table, const uint8_t* d_points_inf, size_t n_points,
+extern "C" int zkhip_kzg_commit_table(zkhip_ctx* c, const void* d_table_with_header, const uint8_t* d_points_inf, size_t n_points,
                                       const uint64_t* d_scalars, size_t n_scalars, int require_equal_len, uint64_t* h_out_xy,
                                       uint8_t* h_out_inf) {
     if (!c || !h_out_xy || !h_out_inf) return ZKHIP_ERR_ARG;
@@ -570,9 +638,12 @@ extern "C" int zkhip_kzg_commit_table(zkhip_ctx* c, const void* d_table, const u
     if (n_scalars > n_points) return ZKHIP_ERR_INDEX;                          // univariate_kzg.rs:53
     const size_t n = n_scalars;
     if (n == 0) { std::memset(h_out_xy, 0, 96); *h_out_inf = 1; return ZKHIP_OK; }
-    if (!d_table || !d_scalars) return ZKHIP_ERR_ARG;
+    if (!d_table_with_header || !d_scalars) return ZKHIP_ERR_ARG;
     if (n_points * msm_table_widths(n_points).W >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
+    int trc = ZKHIP_OK;
+    const uint32_t* d_table = table_check(c, d_table_with_header, ZK_TABLE_SHIFTED_SRS, n_points, &trc);     // built for THESE n_points, with the widths used below?
+    if (!d_table) return trc;
     if (msm_small_on() && n <= MSM_SMALL_MAX) return msm_commit_small(c, (const uint32_t*)d_table, n_points, d_points_inf, d_scalars, n, h_out_xy, h_out_inf);
     MsmProblems one = {};
     one.n = 1;
@@ -663,10 +734,10 @@ extern "C" int zkhip_kzg_open(zkhip_ctx* c, const uint64_t* d_evals, size_t n, c
 }
 extern "C" int zkhip_kzg_open_tables(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_points, size_t n_eval_points,
                                      const uint64_t* d_points_xy, const uint8_t* d_points_inf, size_t n_points,
-                                     const uint64_t* d_folded_xy, const uint8_t* d_folded_inf, const void* d_level_tables,
+                                     const uint64_t* d_folded_xy, const uint8_t* d_folded_inf, const void* d_level_tables_with_header,
                                      uint64_t* h_evaluation, uint64_t* h_proofs_xy, uint8_t* h_proofs_inf) {
     if (!c || !d_evals || !h_points || !d_points_xy || !h_evaluation || !h_proofs_xy || !h_proofs_inf) return ZKHIP_ERR_ARG;
-    if (d_level_tables && !d_folded_inf) return ZKHIP_ERR_ARG;      // the tables belong to cached folded levels
+    if (d_level_tables_with_header && !d_folded_inf) return ZKHIP_ERR_ARG;      // the tables belong to cached folded levels
     if (!is_pow2(n)) return ZKHIP_ERR_SHAPE;
     const uint32_t n_vars = log2_exact(n);
     if (n_eval_points != n_vars) return ZKHIP_ERR_SHAPE;   // evaluation_form.rs:163-167
@@ -675,6 +746,12 @@ extern "C" int zkhip_kzg_open_tables(zkhip_ctx* c, const uint64_t* d_evals, size
     if (n >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
     if ((d_folded_xy == nullptr) != (d_folded_inf == nullptr)) return ZKHIP_ERR_ARG;
     ZK_TRY(c->activate());
+    const void* d_level_tables = nullptr;
+    if (d_level_tables_with_header) {
+        int trc = ZKHIP_OK;
+        d_level_tables = table_check(c, d_level_tables_with_header, ZK_TABLE_LEVELS, n_points, &trc);   // the level tables of an SRS of THIS size, with the widths used below?
+        if (!d_level_tables) return trc;
+    }
     // aux layout: quotients of all rounds (n - 1, laid out like the folded SRS) | remainder ping (n/2) | pong (n/4) |
     // [folded SRS xy, inf]
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };

@@ -2,9 +2,11 @@
 
 Mirrors circuit/src/circuit.rs:8-122, circuit/src/gate.rs, gkr/src/utils.rs:8-56 and gkr/src/protocol.rs:10-117: the
 caller of the hot path (wiring tables -> folds at r_b / r_c -> outer sum / product of the layer values -> the
-multi-composed sumcheck prover -> evaluations of w at b and c).  The outer Fiat-Shamir transcript absorbs a few hundred
-bytes per layer and runs on the host (hashlib); every table operation is a HIP kernel behind the C ABI.  The verifier
-is host-side in the reference and out of scope; tests check proofs with the oracle's restated verifier.
+multi-composed sumcheck prover -> evaluations of w at b and c).  GKRProtocol.prove is ONE C-ABI call: every table operation, every
+sumcheck and the outer Fiat-Shamir transcript (a few hundred bytes per layer, absorbed by a hasher workgroup beside the closing kernels,
+csrc/gkr.hip) run on the device; only prove_stepwise -- the mirror that makes one call per reference line -- keeps its outer transcript
+on the host (hashlib).  The verifier is host-side in the reference and out of scope; tests check proofs with the oracle's
+restated verifier.
 """
 import ctypes as C
 import hashlib
@@ -224,25 +226,45 @@ _DEVICE_CIRCUITS_LOCK = threading.Lock()      # guards the per-Circuit lists of 
 
 
 class _DeviceCircuit:
-    """zkhip_circuit handle (include/zkhip.h): the circuit's gate arrays and CSR groupings resident in HBM."""
+    """zkhip_circuit handle (include/zkhip.h): the circuit's gate arrays and CSR groupings resident in HBM.  The CONTEXT owns it
+    (Context._circuits; a zkhip_circuit refers to its zkhip_ctx, so Context.destroy() destroys it first); the Circuit only lists it and
+    refers to the context weakly -- a worker thread's context, with its workspace, goes when the thread does, not when the Circuit does."""
 
     def __init__(self, ctx, circuit, shape):
+        import weakref
         arrays = [layer._arrays() for layer in circuit.layers]
         gt = np.concatenate([a[0] for a in arrays])
         i0 = np.concatenate([a[1] for a in arrays])
         i1 = np.concatenate([a[2] for a in arrays])
-        self.ctx, self.shape = ctx, shape
+        self._ctx, self.shape = weakref.ref(ctx), shape
         self.handle = C.c_void_p()
         p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
         st = N.lib().zkhip_circuit_create(ctx.handle, C.c_uint32(len(shape)), (C.c_size_t * len(shape))(*shape), p(gt), p(i0), p(i1),
                                           C.byref(self.handle))
         N.check(st, "circuit_create")
+        ctx._circuits.append(self)
+
+    @property
+    def ctx(self):
+        return self._ctx()
+
+    def alive(self):
+        ctx = self._ctx()
+        return bool(self.handle) and ctx is not None and bool(ctx.handle)
+
+    def close(self):
+        """zkhip_circuit_destroy; called by Context.destroy() BEFORE the context goes (the handle dereferences it)"""
+        h, self.handle = self.handle, None
+        if h:
+            N.lib().zkhip_circuit_destroy(h)
+        ctx = self._ctx()
+        if ctx is not None and self in ctx._circuits:
+            ctx._circuits.remove(self)
 
     def __del__(self):
         try:
-            if self.handle:
-                N.lib().zkhip_circuit_destroy(self.handle)
-                self.handle = None
+            if self.alive():
+                self.close()
         except Exception:
             pass
 
@@ -315,7 +337,11 @@ class GKRProtocol:
         # one device copy per CONTEXT (contexts are per host thread: several threads may prove one Circuit at once, each on its own
         # stream); copies of an older circuit state are dropped
         with _DEVICE_CIRCUITS_LOCK:
-            devs = [d for d in getattr(circuit, "_devices", ()) if d.ctx.handle and fresh(d)]
+            old = list(getattr(circuit, "_devices", ()))
+            devs = [d for d in old if d.alive() and fresh(d)]
+            for d in old:
+                if d.alive() and not fresh(d):
+                    d.close()                      # a copy of an older circuit state: give its device memory back now
             dev = next((d for d in devs if d.ctx is ctx), None)
             if dev is None:
                 dev = _DeviceCircuit(ctx, circuit, shape)
