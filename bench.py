@@ -606,20 +606,30 @@ def bench_gkr(args, zk, N, D, rank, world, barrier, dist, torch, np):
         out["ms_per_proof"]["depth_%d" % depth] = round(1e3 * dt, 3)
         out.setdefault("batches", {})["depth_%d" % depth] = _stats([b_ / reps for b_ in bs], 1e3, 3)
     if world == 1 and not args.no_gkr_threads:
-        # informational: independent proofs from several host threads at once -- a context and a stream per thread, ONE Circuit (a device copy
-        # per context).  A proof keeps one workgroup busy most of the time, so independent proofs share the chip; what bounds them is the
-        # process's kernel-launch rate (~430 launches per depth-20 proof).  Measured in a child process of its own (tools/gkr_threads.py: the
-        # same library, no other leg's streams and contexts beside it; every thread's proofs compared with a synchronous one there).
+        # independent proofs of one circuit from ONE C-ABI call (zkhip_gkr_prove_batch, gkr/benches/gkr_benchmark.rs:11-27 proves input after
+        # input): the library runs them side by side on its internal lanes (streams, scratch and transcript state of their own; the launch
+        # chains enqueued by the context's host pool) -- a proof keeps one workgroup busy most of the time, so throughput comes from independent
+        # proofs.  Every proof is compared with the synchronous one.
+        out["batch"] = {"note": "zkhip_gkr_prove_batch: B independent proofs of one circuit from one call from one host thread; ms per proof; every proof "
+                                "equal to GKRProtocol.prove's (asserted)", "ms_per_proof": {}}
         try:
-            import subprocess
-            kid = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "gkr_threads.py"), "--json", "20:4,8"],
-                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
-            lines = [l_ for l_ in kid.stdout.decode().splitlines() if l_.startswith("{")]
-            out["threads_in_flight"] = json.loads(lines[-1]) if kid.returncode == 0 and lines else {"error": "child exited with %d" % kid.returncode}
-        except Exception as e:      # noqa: BLE001 -- an informational leg never fails the bench
-            out["threads_in_flight"] = {"error": repr(e)}
-        out["threads_in_flight"]["note"] = ("ms per proof with 4 / 8 host threads proving at once (a zkhip context and a stream each, one Circuit), in a process "
-                                            "of its own; every proof equal to the synchronous one (asserted there)")
+            for depth, B_list in ((8, (8, 32)), (20, (4, 8))):
+                circuit = zk.Circuit.random(depth)
+                evs = [circuit.evaluation(zk.Fr.synthetic(2 ** depth, SEED_GKR + 100 + b)) for b in range(max(B_list))]
+                want = [[sp.to_bytes() for sp in zk.GKRProtocol.prove(circuit, ev).sumcheck_proofs] for ev in evs[:2]]
+                for B in B_list:
+                    got = zk.GKRProtocol.prove_batch(circuit, evs[:B])
+                    assert [[sp.to_bytes() for sp in pr.sumcheck_proofs] for pr in got[:2]] == want, "batched and synchronous proofs differ"
+                    ts = []
+                    for _ in range(5 if depth <= 8 else 3):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        zk.GKRProtocol.prove_batch(circuit, evs[:B])
+                        ts.append((time.perf_counter() - t0) / B)
+                    out["batch"]["ms_per_proof"].setdefault("depth_%d" % depth, {})[str(B)] = round(1e3 * sorted(ts)[len(ts) // 2], 3)
+                del evs, circuit
+        except Exception as e:      # noqa: BLE001 -- reported, not fatal for the other legs
+            out["batch"]["error"] = repr(e)
     # BASELINE configs[3]: ONE depth-20 proof with every layer's sumcheck sharded over the ranks (GKRProtocol.prove_sharded:
     # the layer tables are built on every rank, the rounds over b and c run on shards with one record all-gathered per round)
     # next to the replicated figure above -- whichever is faster is the answer to "should GKR shard at this width"
@@ -844,7 +854,7 @@ def main():
     ap.add_argument("--no-fold", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="diagnostic: run the sharded prover protocol even on one GPU")
     ap.add_argument("--no-h2d", action="store_true")
-    ap.add_argument("--no-gkr-threads", action="store_true", help="skip the GKR proofs-from-several-threads leg")
+    ap.add_argument("--no-gkr-threads", action="store_true", help="skip the GKR batch leg (zkhip_gkr_prove_batch: B proofs of one circuit side by side)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the proofs-in-flight leg (profiling: keeps the kernel averages those of the synchronous steps)")
     ap.add_argument("--config4-log-n", type=int, default=23, help="N > 1: log2 of the per-GPU points of the configs[4]-shaped commit (2^26 over 8 = 2^23)")
     ap.add_argument("--no-exchange", action="store_true", help="skip the exchange-cost measurement and the N = 8 prediction")
@@ -1159,7 +1169,8 @@ def main():
                 "composed_k5_2^%d_frac" % args.composed_log_n: g(composed_shapes, "composed_k5_2^%d" % args.composed_log_n, "frac_of_hbm"),
                 "multi_composed_2_3_ms": g(composed_shapes, "multi_composed_2_3_2^20", "ms_per_prove"), "multi_composed_2_3_frac": g(composed_shapes, "multi_composed_2_3_2^20", "frac_of_hbm"),
                 "gkr8_ms": g(gkr, "ms_per_proof", "depth_8"), "gkr20_ms": g(gkr, "ms_per_proof", "depth_20"),
-                "gkr20_8_threads_ms": g(gkr, "threads_in_flight", "depth_20", "8"), "gkr20_sharded_ms": g(gkr, "sharded", "ms_per_proof"),
+                "gkr8_batch8_ms": g(gkr, "batch", "ms_per_proof", "depth_8", "8"), "gkr8_batch32_ms": g(gkr, "batch", "ms_per_proof", "depth_8", "32"),
+                "gkr20_batch8_ms": g(gkr, "batch", "ms_per_proof", "depth_20", "8"), "gkr20_sharded_ms": g(gkr, "sharded", "ms_per_proof"),
                 "h2d_step_ms": g(h2d, "sumcheck", "ms_per_step"),
                 "cpu_1core_mevals_s": round(g(cpu, "value") / 1e6, 2) if g(cpu, "value") else None,
                 "cpu_msm_1core_points_s": g(msm, "cpu_baseline", "value"),

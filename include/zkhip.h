@@ -178,6 +178,17 @@ void zkhip_circuit_destroy(zkhip_circuit *circuit);
 int zkhip_gkr_prove_circuit(zkhip_circuit *circuit, const uint64_t *const *h_layer_ptrs, const size_t *h_layer_len,
                             uint64_t *h_sums, uint32_t *h_n_rounds, uint32_t *h_round_poly_lens, uint64_t *h_round_polys,
                             uint64_t *h_wb, uint64_t *h_wc, uint64_t *h_w0, uint64_t *h_challenges);
+/* n_proofs independent proofs of one circuit in ONE call (gkr/benches/gkr_benchmark.rs:11-27 proves input after input): proof b reads
+ * h_layer_ptrs[b * (n_layers + 1) ..] (the layer lengths are the circuit's: h_layer_len[n_layers + 1], shared) and writes its outputs at
+ * b times the per-proof sizes of zkhip_gkr_prove_circuit's arrays (h_sums 4 L, h_n_rounds L, h_round_poly_lens 2 L^2, h_round_polys
+ * 2 L^2 * 7 * 8, h_wb / h_wc 4 L, h_w0 8, h_challenges 2 L^2 * 4, L = n_layers; h_challenges and h_status may be NULL).  The proofs run side
+ * by side on up to max_lanes (0 = 8, the most) internal lanes -- streams, scratch and transcript state of their own, created on first use
+ * and kept with the context -- and their launch chains are enqueued by the context's host pool: a proof is a chain of a few hundred small
+ * dependent kernels, so its throughput comes from independent proofs (depth 20: 8.4 ms alone, ~2.5 ms per proof eight at a time).  Every
+ * proof equals the one zkhip_gkr_prove_circuit makes.  Returns the first non-zero status (h_status[b]: each proof's own). */
+int zkhip_gkr_prove_batch(zkhip_circuit *circuit, uint32_t n_proofs, uint32_t max_lanes, const uint64_t *const *h_layer_ptrs,
+                          const size_t *h_layer_len, uint64_t *h_sums, uint32_t *h_n_rounds, uint32_t *h_round_poly_lens,
+                          uint64_t *h_round_polys, uint64_t *h_wb, uint64_t *h_wc, uint64_t *h_w0, uint64_t *h_challenges, int *h_status);
 /* The tables of one layer's sumcheck in the linear-time form, for a caller that runs the sumcheck itself --
  * the sharded prover shards these tables over the ranks (zkhip_mc_begin_ex) instead of calling zkhip_gkr_prove_circuit.
  * Layer `layer` (0 = output layer) of a device-resident circuit, d_w = the layer's input values (w_len = 2^(layer+1)).
@@ -486,8 +497,9 @@ int zkhip_kzg_commit(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t 
  * entries; included in zkhip_srs_table_bytes / zkhip_srs_level_tables_bytes): its layout is a function of n_points and of the tuning
  * variable ZKHIP_LEVEL_TABLE_DELTA (read once per process), and every entry point that takes a table compares the header with the
  * geometry it is about to address the table with -- a table built for another size, of the other kind, by a process that ran with
- * another value, or a buffer that is no table -> ZKHIP_ERR_ARG instead of a wrong commitment.  (One 128-byte read the first time a
- * context sees a (table, size) pair, remembered until a table is built at that address again.) */
+ * another value, or a buffer that is no table -> ZKHIP_ERR_ARG instead of a wrong commitment.  (One 128-byte read the first time the
+ * process sees a (table, size) pair, remembered until a table is built at that address again; a buffer the library did not build,
+ * placed at a remembered address, is not read again.) */
 size_t zkhip_srs_table_bytes(size_t n_points);
 /* Content check for a host-side cache of what is derived from an SRS (the table above, the folded levels): the first two and the last
  * two points with their infinity flags, h_out[52] = 4 x (12 coordinate words, flag) -- one small launch, one copy, ~20 us.  A wrapper

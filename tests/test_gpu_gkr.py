@@ -293,3 +293,22 @@ def test_gkr_fresh_context_in_a_destroyed_ones_memory(zk, ora):
     assert not dev.alive() and not dev.handle
     del dev
     _check_against_oracle(zk, ora, random_circuit(4), inp)
+
+
+@pytest.mark.parametrize("depth,n_proofs,lanes", [(6, 5, 0), (9, 16, 8), (12, 3, 2), (4, 1, 0)])
+def test_gkr_prove_batch_equals_the_single_proofs(zk, ora, depth, n_proofs, lanes):
+    """zkhip_gkr_prove_batch: n independent proofs of one circuit from ONE call (internal lanes; gkr/benches/gkr_benchmark.rs:11-27) -- every
+    proof bit-identical to the oracle's and to GKRProtocol.prove's, whatever the number of lanes; a second batch reuses the lanes."""
+    layers = random_circuit(depth) if depth != 9 else scrambled_circuit(depth, 77)
+    circuit = zk.Circuit.from_tuples(layers)
+    inputs = [ora.random_fr(2 ** depth, 9300 + 31 * depth + b) for b in range(n_proofs)]
+    evs = [circuit.evaluation(inp) for inp in inputs]
+    for rep in range(2):
+        proofs = zk.GKRProtocol.prove_batch(circuit, evs, max_lanes=lanes)
+        assert len(proofs) == n_proofs
+        for inp, ev, proof in zip(inputs, evs, proofs):
+            want = ora.gkr_prove_sparse(layers, ora.circuit_evaluation(layers, inp))
+            assert gkr_proof_mismatches(ora, proof, want) == []
+    single = zk.GKRProtocol.prove(circuit, evs[-1])
+    assert [sp.to_bytes() for sp in single.sumcheck_proofs] == [sp.to_bytes() for sp in proofs[-1].sumcheck_proofs]
+    assert zk.GKRProtocol.prove_batch(circuit, []) == []

@@ -123,6 +123,7 @@ def test_tables_carry_a_header_that_is_checked_against_the_geometry(zk, ora):
     lib = N.lib()
     lib.zkhip_srs_table_bytes.restype = C.c_size_t
     lib.zkhip_srs_level_tables_bytes.restype = C.c_size_t
+    junk = torch.zeros(lib.zkhip_srs_table_bytes(C.c_size_t(1 << 10)), dtype=torch.uint8, device="cuda")   # (first: an address no table has been seen at)
     srs10 = zk.TrustedSetup.setup(ora.random_fr(10, 4501)).precompute().precompute_open()
     srs9 = zk.TrustedSetup.setup(ora.random_fr(9, 4502)).precompute()
     ctx = N.Context.get(0)
@@ -138,7 +139,6 @@ def test_tables_carry_a_header_that_is_checked_against_the_geometry(zk, ora):
     assert commit(srs10._table, srs10, 1 << 9, 1 << 9) == N.ERR_ARG              # a table built for 2^10 points addressed as one of 2^9
     assert commit(srs9._table, srs10, 1 << 10, 1 << 10) == N.ERR_ARG             # ... and the other way round (the header is read, nothing behind it)
     assert commit(srs10._level_tables, srs10, 1 << 10, 1 << 10) == N.ERR_ARG     # level tables are not a shifted-SRS table
-    junk = torch.zeros(lib.zkhip_srs_table_bytes(C.c_size_t(1 << 10)), dtype=torch.uint8, device="cuda")
     assert commit(junk, srs10, 1 << 10, 1 << 10) == N.ERR_ARG                    # no table at all
     tk = C.c_uint32(0)
     assert lib.zkhip_kzg_commit_begin(ctx.handle, None, N.ptr(srs9._table), N.ptr(srs10.inf), C.c_size_t(1 << 10), N.ptr(sc), C.c_size_t(1 << 10), C.c_int(0),

@@ -187,17 +187,15 @@ struct zkhip_ctx {
         }
         return host_pool;
     }
-    // shifted-SRS / level tables whose header has been compared with the geometry of (kind, n_points) on this context (msm.hip table_check)
-    struct TableOk { const void* p = nullptr; size_t n = 0; uint32_t kind = 0; };
-    static constexpr int TABLE_OK_SLOTS = 16;
-    TableOk table_ok[TABLE_OK_SLOTS];
-    int table_ok_next = 0;
-    bool table_checked(const void* p, size_t n, uint32_t kind, bool remember) {
-        for (const auto& t : table_ok) if (t.p == p && t.n == n && t.kind == kind) return true;
-        if (remember) { table_ok[table_ok_next] = TableOk{p, n, kind}; table_ok_next = (table_ok_next + 1) % TABLE_OK_SLOTS; }
-        return false;
-    }
-    void table_forget(const void* p) { for (auto& t : table_ok) if (t.p == p) t = TableOk{}; }      // a table is being (re)built at p
+    std::vector<zkhip_ctx*> gkr_lanes;   // child contexts of zkhip_gkr_prove_batch (a stream, scratch and transcript state each), destroyed with this one
+    // a lane replays a circuit's launch chain as a HIP graph (gkr.hip): its own copy of the layer values + the graph and the addresses it holds
+    bool gkr_lane = false;
+    void* d_gkr_in = nullptr; size_t gkr_in_bytes = 0;
+    struct GkrGraph {
+        void* exec = nullptr;                       // hipGraphExec_t
+        const void *cir = nullptr, *aux = nullptr, *in = nullptr, *ws = nullptr, *pin = nullptr, *composed = nullptr;
+        const void *warm_cir = nullptr, *warm_aux = nullptr, *warm_ws = nullptr;      // a plain proof of this circuit has run here (allocations made)
+    } gkr_graph;
     bool ws_lent = false;       // the workspace currently backs a split-phase prover state or commits in flight
     // commits in flight (zkhip_kzg_commit_begin / _end): two slots, each with a region of the workspace, a side stream and a
     // pinned result buffer of its own; `async_pend` is an MsmPending allocated by msm.hip

@@ -489,9 +489,11 @@ struct DeviceTranscript {
 };
 // rows1_done: this layer's first rows were built by the layer before (gkr_small_end_kernel); next / d_w_next / w_len_next: the layer after
 // this one (null: none), whose first rows this layer's last launch builds when both are small -- *next_rows1_done says so.
+// replayable (zkhip_gkr_prove_batch's lanes replay the launch chain as a HIP graph): nothing of this proof may travel BY VALUE in a kernel
+// argument -- layer one then reads its claimed sum from dt.sums and finds its gate weights (1 - n_r, n_r) uploaded in sc.wg.
 int layer_enqueue_device(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uint64_t* d_w, size_t w_len, const LayerScratch& sc,
                          const DeviceTranscript& dt, const zkhost::Fr& claimed0, const zkhost::Fr& n_r, uint32_t stride, bool rows1_done,
-                         const LayerDev* next, const uint64_t* d_w_next, size_t w_len_next, bool* next_rows1_done) {
+                         const LayerDev* next, const uint64_t* d_w_next, size_t w_len_next, bool* next_rows1_done, bool replayable = false) {
     using namespace zk;
     const size_t n_gates = ld.n_gates;
     const uint32_t s = log2_exact(w_len);
@@ -507,7 +509,8 @@ int layer_enqueue_device(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uin
         std::memcpy(pb.v, n_r.l, 32);
         const zkhost::Fr one = zkhost::fr_one();
         std::memcpy(av.v, one.l, 32);
-        launch_gate_weights(c, n_gates, n_gate_vars, pb, pc, av, bv, false, sc.eqh, sc.wg);
+        if (!replayable) launch_gate_weights(c, n_gates, n_gate_vars, pb, pc, av, bv, false, sc.eqh, sc.wg);
+        else if (n_gates > 2) return ZKHIP_ERR_SHAPE;       // (one gate variable: the caller uploaded at most two weights)
     }
     static const bool fuse_small = [] { const char* e = std::getenv("ZKHIP_GKR_FUSE_SMALL"); return !e || std::atoi(e) != 0; }();
     const bool small = fuse_small && w_len <= GKR_SMALL_ROWS;
@@ -530,7 +533,7 @@ int layer_enqueue_device(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uin
     uint64_t* ar_ch = dt.arena + (size_t)l * DeviceTranscript::LAYER_U64;
     uint64_t* ar_rp = ar_ch + 4 * (size_t)ZK_MAX_ROUNDS;
     ZkMcExtra ex = {};
-    ex.d_sum = two_points ? dt.next + 8 : nullptr;
+    ex.d_sum = two_points ? dt.next + 8 : replayable ? dt.sums : nullptr;
     ex.outer = dt.outer;
     ex.d_round_polys = ar_rp;
     ex.d_challenges = ar_ch;
@@ -539,7 +542,7 @@ int layer_enqueue_device(zkhip_ctx* c, const LayerDev& ld, uint32_t l, const uin
         const uint64_t* tables[4] = {sc.ha0, d_w, sc.hm, d_w};          // [Ha0, V] + Ha1,  [Hm, V]
         const uint64_t* lin[2] = {sc.ha1, nullptr};
         ex.token = ++c->outer_token;
-        ZK_TRY(zk_multi_composed_enqueue(c, tables, sizes, lin, 2, w_len, two_points ? nullptr : claimed0.l, 0, 0, &ex));
+        ZK_TRY(zk_multi_composed_enqueue(c, tables, sizes, lin, 2, w_len, two_points || replayable ? nullptr : claimed0.l, 0, 0, &ex));
     }
     // ---- rounds over c, b at u = the challenges just recorded (in the arena)
     if (small) {                                           // eq(u), w_b and the second rows: one workgroup, one launch
@@ -590,6 +593,15 @@ struct zkhip_circuit {
 
 extern "C" void zkhip_circuit_destroy(zkhip_circuit* cir) {
     if (!cir) return;
+    if (cir->c) {       // the graphs the batch lanes recorded for this circuit hold its addresses (and another circuit may get this very address)
+        for (zkhip_ctx* lane : cir->c->gkr_lanes) {
+            zkhip_ctx::GkrGraph& gg = lane->gkr_graph;
+            if (gg.cir == cir || gg.warm_cir == cir) {
+                if (gg.exec) { (void)hipStreamSynchronize(lane->stream); (void)hipGraphExecDestroy((hipGraphExec_t)gg.exec); }
+                gg = zkhip_ctx::GkrGraph();
+            }
+        }
+    }
     if (cir->d_mem && cir->c && cir->c->activate() == ZKHIP_OK) (void)hipFree(cir->d_mem);
     delete cir;
 }
@@ -659,17 +671,43 @@ extern "C" int zkhip_circuit_create(zkhip_ctx* c, uint32_t n_layers, const size_
     return ZKHIP_OK;
 }
 
-extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const* h_layer_ptrs, const size_t* h_layer_len, uint64_t* h_sums,
-                                       uint32_t* h_n_rounds, uint32_t* h_round_poly_lens, uint64_t* h_round_polys, uint64_t* h_wb,
-                                       uint64_t* h_wc, uint64_t* h_w0, uint64_t* h_challenges) {
-    if (!cir || !h_layer_ptrs || !h_layer_len || !h_sums || !h_n_rounds || !h_round_poly_lens || !h_round_polys || !h_wb || !h_wc || !h_w0)
-        return ZKHIP_ERR_ARG;
-    zkhip_ctx* c = cir->c;
+// GKRProtocol::prove of `cir` on context c -- the circuit's own, or a lane of zkhip_gkr_prove_batch (the circuit's device arrays are
+// read-only here: any context of the same device may prove it, each with its own stream, scratch and transcript state)
+static int gkr_prove_circuit_on(zkhip_ctx* c, zkhip_circuit* cir, const uint64_t* const* h_layer_ptrs, const size_t* h_layer_len, uint64_t* h_sums,
+                                uint32_t* h_n_rounds, uint32_t* h_round_poly_lens, uint64_t* h_round_polys, uint64_t* h_wb,
+                                uint64_t* h_wc, uint64_t* h_w0, uint64_t* h_challenges) {
     const uint32_t n_layers = cir->n_layers;
     if (h_layer_len[0] != 1) return ZKHIP_ERR_SHAPE;              // w_0 = [output.., 0] must have 2^k entries; the wiring of layer 0 has one gate bit
     for (uint32_t k = 1; k <= n_layers; ++k)
         if (!is_pow2(h_layer_len[k])) return ZKHIP_ERR_SHAPE;  // Multilinear::new (evaluation_form.rs:16-20)
     ZK_TRY(c->activate());
+    // A lane of zkhip_gkr_prove_batch REPLAYS the proof's launch chain as a HIP graph (one hipGraphLaunch instead of 130-400 launches of
+    // 3-5 us of host time each: with eight chains side by side the process's launch rate was the bound, tools/perf_gkr_batch.py).  A graph
+    // holds addresses: the layer values are first copied to a buffer of the lane's own, so that every proof of the circuit on this lane is
+    // the same chain on the same memory.  (ZKHIP_GKR_GRAPH=0: plain launches.)
+    static const bool graph_env = [] { const char* e = std::getenv("ZKHIP_GKR_GRAPH"); return !e || std::atoi(e) != 0; }();
+    const bool lane = c->gkr_lane && graph_env && !c->profiling;
+    std::vector<const uint64_t*> staged;
+    if (lane) {
+        size_t total = 0;
+        for (uint32_t k = 0; k <= n_layers; ++k) total += h_layer_len[k];
+        if (32 * total > c->gkr_in_bytes) {
+            ZK_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->d_gkr_in) (void)hipFree(c->d_gkr_in);
+            c->d_gkr_in = nullptr; c->gkr_in_bytes = 0;
+            if (hipMalloc(&c->d_gkr_in, 32 * total) != hipSuccess) return ZKHIP_ERR_NOMEM;
+            c->gkr_in_bytes = 32 * total;
+        }
+        staged.resize(n_layers + 1);
+        size_t off = 0;
+        for (uint32_t k = 0; k <= n_layers; ++k) {
+            uint64_t* dst = (uint64_t*)c->d_gkr_in + 4 * off;
+            ZK_HIP(c, hipMemcpyAsync(dst, h_layer_ptrs[k], 32 * h_layer_len[k], hipMemcpyDeviceToDevice, c->stream));
+            staged[k] = dst;
+            off += h_layer_len[k];
+        }
+        h_layer_ptrs = staged.data();
+    }
     // aux layout: w_0 (2) | nine tables of the widest layer | gate weights
     size_t max_w = 0, max_g = 0;
     for (uint32_t l = 0; l < n_layers; ++l) { max_w = std::max(max_w, h_layer_len[l + 1]); max_g = std::max(max_g, cir->layers[l].n_gates); }
@@ -759,22 +797,59 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
             std::memset((char*)hs + sizeof(*hs), 0, head_bytes - sizeof(*hs));   // OuterDev::error, pad_, flag[]
             ZK_HIP(c, hipMemcpyAsync(&dt.outer->state, hs, head_bytes, hipMemcpyHostToDevice, c->stream));
             ZK_HIP(c, hipMemcpyAsync(dt.sums, claimed.l, 32, hipMemcpyHostToDevice, c->stream));     // (pageable source: copied before the call returns)
+            if (lane) {     // layer one's gate weights (1 - n_r, n_r): what gkr_gate_weights_kernel computes from n_r passed by value
+                const zkhost::Fr w2[2] = {zkhost::fr_sub(zkhost::fr_one(), n_r[0]), n_r[0]};
+                ZK_HIP(c, hipMemcpyAsync(sc.wg, w2[0].l, 32 * std::min<size_t>(2, std::max<size_t>(1, cir->layers[0].n_gates)), hipMemcpyHostToDevice, c->stream));
+            }
             ZK_HIP(c, hipStreamSynchronize(c->stream));                  // the pinned staging words are reused below
-        }
-        bool rows1_done = false;
-        for (uint32_t li = 1; li <= n_layers; ++li) {
-            const bool has_next = li < n_layers;
-            bool next_done = false;
-            ZK_TRY(layer_enqueue_device(c, cir->layers[li - 1], li - 1, h_layer_ptrs[li], h_layer_len[li], sc, dt, claimed, n_r[0], stride, rows1_done,
-                                        has_next ? &cir->layers[li] : nullptr, has_next ? h_layer_ptrs[li + 1] : nullptr, has_next ? h_layer_len[li + 1] : 0,
-                                        &next_done));
-            rows1_done = next_done;
         }
         // ---- the whole proof back in ONE copy: outer state (its error word) | next | sums | w_b | w_c | arena are neighbours on the device
         const size_t pin_bytes = o_arena + arena_bytes - o_outer;
         ZK_TRY(c->reserve_msm_pin(0, pin_bytes));
         char* pin0 = (char*)c->msm_pin[0];
-        ZK_HIP(c, hipMemcpyAsync(pin0, aux + o_outer, pin_bytes, hipMemcpyDeviceToHost, c->stream));
+        auto enqueue_chain = [&](bool replayable) -> int {
+            bool rows1_done = false;
+            for (uint32_t li = 1; li <= n_layers; ++li) {
+                const bool has_next = li < n_layers;
+                bool next_done = false;
+                ZK_TRY(layer_enqueue_device(c, cir->layers[li - 1], li - 1, h_layer_ptrs[li], h_layer_len[li], sc, dt, claimed, n_r[0], stride, rows1_done,
+                                            has_next ? &cir->layers[li] : nullptr, has_next ? h_layer_ptrs[li + 1] : nullptr, has_next ? h_layer_len[li + 1] : 0,
+                                            &next_done, replayable));
+                rows1_done = next_done;
+            }
+            ZK_HIP(c, hipMemcpyAsync(pin0, aux + o_outer, pin_bytes, hipMemcpyDeviceToHost, c->stream));
+            return ZKHIP_OK;
+        };
+        // the graph of this (circuit, lane): valid while every buffer the chain touches is where it was when it was recorded
+        zkhip_ctx::GkrGraph& gg = c->gkr_graph;
+        const bool same = lane && gg.exec && gg.cir == cir && gg.aux == c->d_aux && gg.in == c->d_gkr_in && gg.ws == c->d_ws && gg.pin == c->msm_pin[0] &&
+                          gg.composed == c->d_composed;
+        if (lane && gg.exec && !same) { (void)hipGraphExecDestroy((hipGraphExec_t)gg.exec); gg = zkhip_ctx::GkrGraph(); }
+        if (lane && gg.exec) {
+            ZK_HIP(c, hipGraphLaunch((hipGraphExec_t)gg.exec, c->stream));
+        } else if (lane && gg.warm_cir == cir && gg.warm_aux == c->d_aux && gg.warm_ws == c->d_ws) {
+            // the second proof of this circuit on the lane (the first one, launched plainly, made every allocation): record, instantiate, launch
+            hipGraph_t graph = nullptr;
+            ZK_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            const int crc = enqueue_chain(true);
+            const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
+            if (crc != ZKHIP_OK || ee != hipSuccess || !graph) {
+                if (graph) (void)hipGraphDestroy(graph);
+                gg.warm_cir = nullptr;                                   // not recordable here: plain launches from now on
+                if (crc != ZKHIP_OK) return crc;
+                ZK_TRY(enqueue_chain(false));
+            } else {
+                hipGraphExec_t exec = nullptr;
+                const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ie != hipSuccess || !exec) { c->last_hip = (int)ie; return ZKHIP_ERR_HIP; }
+                gg.exec = exec; gg.cir = cir; gg.aux = c->d_aux; gg.in = c->d_gkr_in; gg.ws = c->d_ws; gg.pin = c->msm_pin[0]; gg.composed = c->d_composed;
+                ZK_HIP(c, hipGraphLaunch(exec, c->stream));
+            }
+        } else {
+            ZK_TRY(enqueue_chain(lane));      // (a lane's plain chain is the replayable one too: the same kernels, the same bits)
+            if (lane) { gg.warm_cir = cir; gg.warm_aux = c->d_aux; gg.warm_ws = c->d_ws; }
+        }
         ZK_HIP(c, hipStreamSynchronize(c->stream));
         // a hasher gave up waiting for a round's items (OuterDev::error = 1 + round).  The hasher is the LAST workgroup of a closing launch and
         // the publisher its workgroup 0: both are resident as long as the grid is at most what the chip holds beside other work -- a
@@ -813,6 +888,69 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
         ZK_TRY(layer_prove(c, cir->layers[l], l, h_layer_ptrs[li], h_layer_len[li], sc, claimed, tr, out, li - 1, alpha, beta, r_b, r_c, true));
     }
     return ZKHIP_OK;
+}
+
+extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const* h_layer_ptrs, const size_t* h_layer_len, uint64_t* h_sums,
+                                       uint32_t* h_n_rounds, uint32_t* h_round_poly_lens, uint64_t* h_round_polys, uint64_t* h_wb,
+                                       uint64_t* h_wc, uint64_t* h_w0, uint64_t* h_challenges) {
+    if (!cir || !h_layer_ptrs || !h_layer_len || !h_sums || !h_n_rounds || !h_round_poly_lens || !h_round_polys || !h_wb || !h_wc || !h_w0)
+        return ZKHIP_ERR_ARG;
+    return gkr_prove_circuit_on(cir->c, cir, h_layer_ptrs, h_layer_len, h_sums, h_n_rounds, h_round_poly_lens, h_round_polys, h_wb, h_wc, h_w0, h_challenges);
+}
+
+// n_proofs independent proofs of ONE circuit (one GKRProtocol::prove per input: gkr/benches/gkr_benchmark.rs:11-27 proves in a loop) from one
+// call.  A proof is a chain of ~130 (depth 8) to ~400 (depth 20) small dependent kernels that keeps one workgroup busy most of the time, so
+// throughput comes from independent proofs side by side: the context owns up to GKR_BATCH_LANES child contexts -- a stream, scratch,
+// workspace and transcript state each, like a host thread's context -- proof b runs on lane b mod lanes, and the lanes' launch chains are
+// enqueued by the context's host pool (the calling thread takes part), because at 3-5 us of host time per launch ONE thread cannot feed
+// eight such chains.  Every proof is the one zkhip_gkr_prove_circuit makes, bit for bit.
+constexpr uint32_t GKR_BATCH_LANES = 8;
+extern "C" int zkhip_gkr_prove_batch(zkhip_circuit* cir, uint32_t n_proofs, uint32_t max_lanes, const uint64_t* const* h_layer_ptrs,
+                                     const size_t* h_layer_len, uint64_t* h_sums, uint32_t* h_n_rounds, uint32_t* h_round_poly_lens,
+                                     uint64_t* h_round_polys, uint64_t* h_wb, uint64_t* h_wc, uint64_t* h_w0, uint64_t* h_challenges, int* h_status) {
+    if (!cir || !h_layer_ptrs || !h_layer_len || !h_sums || !h_n_rounds || !h_round_poly_lens || !h_round_polys || !h_wb || !h_wc || !h_w0)
+        return ZKHIP_ERR_ARG;
+    if (n_proofs == 0) return ZKHIP_OK;
+    zkhip_ctx* c = cir->c;
+    ZK_TRY(c->activate());
+    const uint32_t nl = cir->n_layers, stride = 2 * nl;
+    const uint32_t lanes = std::min<uint32_t>(n_proofs, std::min<uint32_t>(max_lanes ? max_lanes : GKR_BATCH_LANES, GKR_BATCH_LANES));
+    while (c->gkr_lanes.size() < lanes) {
+        zkhip_ctx* lc = nullptr;
+        ZK_TRY(zkhip_ctx_create(&lc, c->device, nullptr));
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { zkhip_ctx_destroy(lc); return ZKHIP_ERR_HIP; }
+        lc->stream = s;
+        lc->own_stream = true;
+        lc->gkr_lane = true;
+        c->gkr_lanes.push_back(lc);
+    }
+    // the lanes start behind what the caller's stream holds now (the layer values may still be on their way there)
+    if (!c->done_ev && hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
+    ZK_HIP(c, hipEventRecord(c->done_ev, c->stream));
+    for (uint32_t l = 0; l < lanes; ++l) ZK_HIP(c, hipStreamWaitEvent(c->gkr_lanes[l]->stream, c->done_ev, 0));
+    std::vector<int> rcs(n_proofs, ZKHIP_OK);
+    const size_t o_sums = 4 * (size_t)nl, o_rounds = nl, o_lens = (size_t)nl * stride, o_polys = (size_t)nl * stride * GKR_MONO * 8, o_ch = (size_t)nl * stride * 4;
+    auto lane_work = [&](unsigned l) {
+        zkhip_ctx* lc = c->gkr_lanes[l];
+        for (uint32_t b = l; b < n_proofs; b += lanes) {
+            rcs[b] = lc->activate();
+            if (rcs[b] != ZKHIP_OK) continue;
+            rcs[b] = gkr_prove_circuit_on(lc, cir, h_layer_ptrs + (size_t)b * (nl + 1), h_layer_len, h_sums + b * o_sums, h_n_rounds + b * o_rounds,
+                                          h_round_poly_lens + b * o_lens, h_round_polys + b * o_polys, h_wb + b * o_sums, h_wc + b * o_sums, h_w0 + 8 * (size_t)b,
+                                          h_challenges ? h_challenges + b * o_ch : nullptr);
+            if (rcs[b] == ZKHIP_ERR_HIP) c->last_hip = lc->last_hip;
+        }
+    };
+    ZkHostPool* pool = lanes > 1 ? c->pool() : nullptr;
+    if (pool) pool->run(lanes, lane_work);
+    else lane_work(0);
+    int rc = ZKHIP_OK;
+    for (uint32_t b = 0; b < n_proofs; ++b) {
+        if (h_status) h_status[b] = rcs[b];
+        if (rc == ZKHIP_OK && rcs[b] != ZKHIP_OK) rc = rcs[b];
+    }
+    return rc;
 }
 
 // The layer's linear-size sumcheck tables for a rank of a sharded proof (world = 1, rank = 0: the whole tables).  phase 0: d_out =

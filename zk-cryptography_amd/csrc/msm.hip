@@ -278,7 +278,8 @@ extern "C" int zkhip_kzg_commit(zkhip_ctx* c, const uint64_t* d_points_xy, const
 // the layout of a table is a function of its size AND of a tuning variable read once per process (msm_level_table_widths), the kernels address
 // it blindly, and a table built for another size -- or by a process that ran with another value -- would give a silently wrong commitment.
 // zkhip_kzg_commit_table / _commit_begin / zkhip_kzg_open_tables compare the header with the geometry they are about to use (one 128-byte read
-// the first time a (table, size) pair is seen on a context, remembered after that) -> ZKHIP_ERR_ARG on a mismatch.
+// the first time a (table, size) pair is seen in the process, remembered until a table is built at that address again) -> ZKHIP_ERR_ARG on a
+// mismatch.  (Not re-read: a buffer the library did not build, placed at a remembered address.)
 constexpr size_t ZK_TABLE_HEADER_BYTES = 128;
 constexpr uint64_t ZK_TABLE_MAGIC = 0x31304c42544b5a00ull;       // "\0ZKTBL01"
 enum : uint32_t { ZK_TABLE_SHIFTED_SRS = 1, ZK_TABLE_LEVELS = 2 };
@@ -291,6 +292,27 @@ struct ZkTableHeader {
     uint8_t pad_[ZK_TABLE_HEADER_BYTES - 48];
 };
 static_assert(sizeof(ZkTableHeader) == ZK_TABLE_HEADER_BYTES, "one 128-byte entry in front of the table");
+// tables whose header has been compared with the geometry of (kind, n_points): one list per PROCESS (contexts are per thread and share
+// SRS objects), forgotten whenever a table is built at that address again
+namespace {
+struct TableOk { const void* p; size_t n; uint32_t kind; int device; };
+std::mutex g_table_ok_mutex;
+std::vector<TableOk> g_table_ok;
+bool table_remembered(const zkhip_ctx* c, const void* p, size_t n, uint32_t kind) {
+    std::lock_guard<std::mutex> lk(g_table_ok_mutex);
+    for (const auto& t : g_table_ok) if (t.p == p && t.n == n && t.kind == kind && t.device == c->device) return true;
+    return false;
+}
+void table_remember(const zkhip_ctx* c, const void* p, size_t n, uint32_t kind) {
+    std::lock_guard<std::mutex> lk(g_table_ok_mutex);
+    if (g_table_ok.size() >= 64) g_table_ok.erase(g_table_ok.begin());
+    g_table_ok.push_back(TableOk{p, n, kind, c->device});
+}
+void table_forget(const zkhip_ctx* c, const void* p) {
+    std::lock_guard<std::mutex> lk(g_table_ok_mutex);
+    for (size_t i = g_table_ok.size(); i-- > 0;) if (g_table_ok[i].p == p && g_table_ok[i].device == c->device) g_table_ok.erase(g_table_ok.begin() + i);
+}
+}  // namespace
 static size_t level_tables_first(size_t n_points, size_t* lvl_off);
 static ZkTableHeader table_header_for(uint32_t kind, size_t n_points) {
     ZkTableHeader h;
@@ -317,18 +339,18 @@ static ZkTableHeader table_header_for(uint32_t kind, size_t n_points) {
 static int table_write_header(zkhip_ctx* c, void* d_table, uint32_t kind, size_t n_points) {
     const ZkTableHeader h = table_header_for(kind, n_points);
     ZK_HIP(c, hipMemcpy(d_table, &h, sizeof(h), hipMemcpyHostToDevice));      // (once per SRS; synchronous)
-    c->table_checked(d_table, n_points, kind, true);
+    table_remember(c, d_table, n_points, kind);
     return ZKHIP_OK;
 }
 // -> the table proper (behind the header), or nullptr with *rc set
 static const uint32_t* table_check(zkhip_ctx* c, const void* d_table, uint32_t kind, size_t n_points, int* rc) {
     *rc = ZKHIP_OK;
-    if (!c->table_checked(d_table, n_points, kind, false)) {
+    if (!table_remembered(c, d_table, n_points, kind)) {
         ZkTableHeader got;
         if (hipMemcpy(&got, d_table, sizeof(got), hipMemcpyDeviceToHost) != hipSuccess) { *rc = ZKHIP_ERR_HIP; return nullptr; }
         const ZkTableHeader want = table_header_for(kind, n_points);
         if (std::memcmp(&got, &want, 48) != 0) { *rc = ZKHIP_ERR_ARG; return nullptr; }     // not a table, another kind, another size, other widths
-        c->table_checked(d_table, n_points, kind, true);
+        table_remember(c, d_table, n_points, kind);
     }
     return (const uint32_t*)((const char*)d_table + ZK_TABLE_HEADER_BYTES);
 }
@@ -488,7 +510,7 @@ extern "C" int zkhip_srs_precompute(zkhip_ctx* c, const uint64_t* d_points_xy, c
     const MsmLevelWidths lw = msm_table_widths(n);
     if (n * lw.W >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;   // entry index + sign bit in 32 bits
     ZK_TRY(c->activate());
-    c->table_forget(d_table);
+    table_forget(c, d_table);
     ZK_TRY(build_shift_table(c, d_points_xy, d_points_inf, n, lw.hi, lw.W, (uint32_t*)((char*)d_table + ZK_TABLE_HEADER_BYTES), lw.n_hi));
     ZK_HIP(c, hipStreamSynchronize(c->stream));   // the workspace is reused by the next call
     return table_write_header(c, d_table, ZK_TABLE_SHIFTED_SRS, n);      // last: a table whose build failed carries no valid header
@@ -516,7 +538,7 @@ extern "C" int zkhip_srs_level_tables(zkhip_ctx* c, const uint64_t* d_folded_xy,
     if (n_points < 2 || !is_pow2(n_points)) return ZKHIP_ERR_SHAPE;
     if (zkhip_srs_level_tables_bytes(n_points) / 128 >= ((size_t)1 << 31)) return ZKHIP_ERR_SHAPE;
     ZK_TRY(c->activate());
-    c->table_forget(d_tables_with_header);
+    table_forget(c, d_tables_with_header);
     void* d_tables = (char*)d_tables_with_header + ZK_TABLE_HEADER_BYTES;
     size_t off = 0, entry = 0;
     const size_t first = level_tables_first(n_points, &off);

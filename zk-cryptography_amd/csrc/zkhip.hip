@@ -61,8 +61,13 @@ extern "C" int zkhip_ctx_create(zkhip_ctx** out, int device, void* stream) {
 extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     if (!c) return ZKHIP_ERR_ARG;
     hipSetDevice(c->device);
+    for (zkhip_ctx* lane : c->gkr_lanes) zkhip_ctx_destroy(lane);      // zkhip_gkr_prove_batch's lanes
+    c->gkr_lanes.clear();
+    hipSetDevice(c->device);
     for (int k = 0; k < zkhip_ctx::ASYNC_SLOTS; ++k) if (c->async_pend[k]) zkhip_kzg_commit_end(c, (uint32_t)k, nullptr, nullptr);   // commits never collected
     hipStreamSynchronize(c->stream);
+    if (c->gkr_graph.exec) (void)hipGraphExecDestroy((hipGraphExec_t)c->gkr_graph.exec);
+    if (c->d_gkr_in) (void)hipFree(c->d_gkr_in);
     // proofs still in flight write their results into the pinned slots from their lanes' streams: drain every stream of the context first
     if (c->fold_stream) hipStreamSynchronize(c->fold_stream);
     for (auto& L : c->lanes) { if (L.serial) hipStreamSynchronize(L.serial); if (L.fold) hipStreamSynchronize(L.fold); }

@@ -323,6 +323,44 @@ class GKRProtocol:
         return proof
 
     @staticmethod
+    def prove_batch(circuit, circuit_evaluations, max_lanes=0):
+        """One GKRProtocol::prove per entry of circuit_evaluations (each as Circuit.evaluation returns it) in ONE C-ABI call,
+        zkhip_gkr_prove_batch: the proofs run side by side on the context's internal lanes (a proof is a chain of small dependent
+        kernels; gkr/benches/gkr_benchmark.rs:11-27 proves input after input).  Returns the proofs GKRProtocol.prove would, in order."""
+        from zk_cryptography_amd.composed import MAX_MONO, MultiComposedSumcheckProof
+        nl, B = len(circuit.layers), len(circuit_evaluations)
+        if B == 0:
+            return []
+        tables = [[t.contiguous() for t in ev] for ev in circuit_evaluations]
+        assert all(len(ev) == nl + 1 for ev in tables)
+        lens0 = [t.shape[0] for t in tables[0]]
+        assert all([t.shape[0] for t in ev] == lens0 for ev in tables), "one circuit: every evaluation has the same layer sizes"
+        ptrs = (C.c_void_p * (B * (nl + 1)))(*[t.data_ptr() for ev in tables for t in ev])
+        lens = (C.c_size_t * (nl + 1))(*lens0)
+        stride = 2 * nl
+        sums = np.zeros((B, nl, 4), dtype=np.uint64)
+        n_rounds = np.zeros((B, nl), dtype=np.uint32)
+        rp_lens = np.zeros((B, nl, stride), dtype=np.uint32)
+        rps = np.zeros((B, nl, stride, MAX_MONO, 2, 4), dtype=np.uint64)
+        wb, wc = np.zeros((B, nl, 4), dtype=np.uint64), np.zeros((B, nl, 4), dtype=np.uint64)
+        w0 = np.zeros((B, 2, 4), dtype=np.uint64)
+        chal = np.zeros((B, nl, stride, 4), dtype=np.uint64)
+        status = np.zeros(B, dtype=np.int32)
+        ctx = N.Context.get(tables[0][0].device.index)
+        dev = GKRProtocol._device_circuit(circuit, ctx)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        st = N.lib().zkhip_gkr_prove_batch(dev.handle, C.c_uint32(B), C.c_uint32(max_lanes), ptrs, lens, p(sums), p(n_rounds), p(rp_lens), p(rps), p(wb), p(wc),
+                                           p(w0), p(chal), p(status))
+        N.check(st, "gkr_prove_batch: every layer must hold a power-of-two number of values, 2^l gates in layer l")
+        out = []
+        for b in range(B):
+            proofs = [MultiComposedSumcheckProof.from_packed(rps[b, k, : n_rounds[b, k]], rp_lens[b, k, : n_rounds[b, k]], sums[b, k]) for k in range(nl)]
+            proof = GKRProof(proofs, list(wb[b]), list(wc[b]), Multilinear(w0[b]))
+            proof._challenges = [chal[b, k, : n_rounds[b, k]] for k in range(nl)]
+            out.append(proof)
+        return out
+
+    @staticmethod
     def _device_circuit(circuit, ctx):
         """The circuit resident in HBM (zkhip_circuit): gate arrays and their groupings validated, built and uploaded once per
         Circuit STATE -- gates are immutable and every layer's gate list counts its mutations, so a gate replaced in place proves the edited circuit
