@@ -140,6 +140,9 @@ struct zkhip_ctx {
             int least = 0, greatest = 0;
             if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return ZKHIP_ERR_HIP;
             if (hipStreamCreateWithPriority(&L.serial, hipStreamNonBlocking, greatest) != hipSuccess) return ZKHIP_ERR_HIP;
+            // (measured and dropped, profiles/r06/NOTES.md: lanes 4..7 with their serial stream at normal instead of high priority, or their fold
+            // stream at normal instead of low -- a hardware queue to itself for every stream of up to six proofs: 0.27-0.32 ms per proof in
+            // flight instead of 0.23; here the priorities do real work, the serial kernels must get in front of every fold)
             if (hipStreamCreateWithPriority(&L.fold, hipStreamNonBlocking, least) != hipSuccess) return ZKHIP_ERR_HIP;
             if (hipEventCreateWithFlags(&L.begin_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
             if (hipEventCreateWithFlags(&L.fork_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;

@@ -904,7 +904,7 @@ extern "C" int zkhip_gkr_prove_circuit(zkhip_circuit* cir, const uint64_t* const
 // workspace and transcript state each, like a host thread's context -- proof b runs on lane b mod lanes, and the lanes' launch chains are
 // enqueued by the context's host pool (the calling thread takes part), because at 3-5 us of host time per launch ONE thread cannot feed
 // eight such chains.  Every proof is the one zkhip_gkr_prove_circuit makes, bit for bit.
-constexpr uint32_t GKR_BATCH_LANES = 8;
+constexpr uint32_t GKR_BATCH_LANES = 12;
 extern "C" int zkhip_gkr_prove_batch(zkhip_circuit* cir, uint32_t n_proofs, uint32_t max_lanes, const uint64_t* const* h_layer_ptrs,
                                      const size_t* h_layer_len, uint64_t* h_sums, uint32_t* h_n_rounds, uint32_t* h_round_poly_lens,
                                      uint64_t* h_round_polys, uint64_t* h_wb, uint64_t* h_wc, uint64_t* h_w0, uint64_t* h_challenges, int* h_status) {
@@ -914,12 +914,21 @@ extern "C" int zkhip_gkr_prove_batch(zkhip_circuit* cir, uint32_t n_proofs, uint
     zkhip_ctx* c = cir->c;
     ZK_TRY(c->activate());
     const uint32_t nl = cir->n_layers, stride = 2 * nl;
-    const uint32_t lanes = std::min<uint32_t>(n_proofs, std::min<uint32_t>(max_lanes ? max_lanes : GKR_BATCH_LANES, GKR_BATCH_LANES));
+    const uint32_t lanes = std::min<uint32_t>(n_proofs, std::min<uint32_t>(max_lanes ? max_lanes : 8u, GKR_BATCH_LANES));
     while (c->gkr_lanes.size() < lanes) {
         zkhip_ctx* lc = nullptr;
         ZK_TRY(zkhip_ctx_create(&lc, c->device, nullptr));
+        // The lanes' streams are spread over the three stream priorities: the runtime keeps a pool of hardware queues PER PRIORITY (four each
+        // by default), and two streams that share a hardware queue take turns in it at a cost -- measured on depth-8 proofs: a queue with
+        // one chain is 86 % busy, a queue with two 51 % (profiles/r06/e_gkr_batch_kernel_stats.txt).  All lanes do the same work, so
+        // what the priorities order is only who goes first.
         hipStream_t s = nullptr;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { zkhip_ctx_destroy(lc); return ZKHIP_ERR_HIP; }
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { zkhip_ctx_destroy(lc); return ZKHIP_ERR_HIP; }
+        static const bool spread = [] { const char* e = std::getenv("ZKHIP_GKR_LANE_PRIO"); return !e || std::atoi(e) != 0; }();
+        const int span = least - greatest + 1;                    // (numerically lower = higher priority)
+        const int prio = spread && span > 1 ? greatest + (int)(c->gkr_lanes.size() % (size_t)span) : 0;
+        if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio) != hipSuccess) { zkhip_ctx_destroy(lc); return ZKHIP_ERR_HIP; }
         lc->stream = s;
         lc->own_stream = true;
         lc->gkr_lane = true;
