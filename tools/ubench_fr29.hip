@@ -26,7 +26,7 @@ constexpr uint32_t MASK = (1u << 29) - 1;
 struct E { uint32_t l[9]; };
 // r in 29-bit limbs, and -r^-1 mod 2^29
 __host__ __device__ constexpr uint32_t P29(int i) {
-    constexpr uint32_t p[9] = {0x00000001u, 0x1ffffff8u, 0x001fffffu, 0x1a402fffu, 0x1c0553bdu, 0x04d80809u, 0x03a9ccceu, 0x14ca675fu, 0x0073eda7u};
+    constexpr uint32_t p[9] = {0x00000001u, 0x1ffffff8u, 0x1f96ffbfu, 0x1b4805ffu, 0x1d80553bu, 0x0c0404d0u, 0x1520cce7u, 0x0a6533afu, 0x0073eda7u};
     return p[i];
 }
 constexpr uint32_t NINV29 = 0x1fffffffu;     // r = 1 mod 2^29 ... -1/r = -1 mod 2^29
@@ -91,11 +91,11 @@ __host__ __device__ inline E add(const E& a, const E& b) {
 }
 // a - b + 4 r with every limb of the constant large enough that no limb underflows (b normalised, < 2 r)
 __host__ __device__ inline E sub4(const E& a, const E& b) {
-    // 4 r = sum c_i 2^(29 i) with c_i >= 2^29 for i < 8: borrow 2^29 from the limb above
+    // 4 r = sum c_i 2^(29 i) with c_i >= 2^30 - 2 > b_i for i < 8: every limb lends 2^30 = 2 x 2^29 to the one below (a_i + c_i < 2^32)
     E r;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const uint32_t c = 4u * P29(i) + (i < 8 ? (1u << 31) : 0u) - (i > 0 ? 4u : 0u);
+        const uint32_t c = 4u * P29(i) + (i < 8 ? (1u << 30) : 0u) - (i > 0 ? 2u : 0u);
         r.l[i] = a.l[i] + c - b.l[i];
     }
     return r;
@@ -108,40 +108,35 @@ static bool selftest() {
     std::mt19937_64 rng(12345);
     Fr r2, one = fr_one();
     std::memcpy(r2.l, FR_R2, 32);
-    // 2^261 mod r in value form: (2^5 as a canonical integer) x R ... fr_from_u64(32) = 32 R; times R again via r2: we want the INTEGER c with
-    // mont'(x, c) = x: c = 2^261 mod r.  fr_from_mont(fr_from_u64(32)) = 32 (canonical); 2^261 = 32 * 2^256 = canonical form of the Montgomery residue fr_from_u64(32).
-    const Fr c261 = fr_from_u64(32);                     // its limbs ARE the integer 32 * 2^256 mod r = 2^261 mod r
+    // zkhost::fr_mul(a, b) = a b 2^-256 mod r on the INTEGERS its arguments' limbs spell.  c517 = 2^517 mod r: fr_mul(w, c517) = w 2^261 mod r.
+    const Fr c517 = fr_mul(r2, fr_from_u64(32));         // 2^512 * (32 * 2^256) * 2^-256
     for (int it = 0; it < 200000; ++it) {
         Fr x, w;
         for (int i = 0; i < 4; ++i) { x.l[i] = rng(); w.l[i] = rng(); }
         x.l[3] &= 0x3fffffffffffffffULL; w.l[3] &= 0x3fffffffffffffffULL;
-        // reduce both below r through the library's arithmetic (value forms)
-        x = fr_mul(x, one); w = fr_mul(w, one);
-        // w29 = w * 2^261 mod r as an integer: mont(w, c261 * R) ... simplest: integer(w) * 2^261 = mont(w, X) with X = 2^261 * 2^256 -> use two steps
-        const Fr w261 = fr_mul(fr_mul(w, c261), r2);      // (w c261 / R) r2 / R = w c261 mod r as integers
+        x = fr_mul(x, one); w = fr_mul(w, one);          // below r
+        const Fr w261 = fr_mul(w, c517);
         uint32_t xw[8], ww[8];
         std::memcpy(xw, x.l, 32); std::memcpy(ww, w261.l, 32);
-        fr29::E xe = fr29::unpack(xw), we = fr29::unpack(ww);
-        fr29::E pe = fr29::mul(xe, we);                   // = x w (integers) mod r, lazily (< 2 r)
-        uint32_t pw[8];
-        fr29::pack(pe, pw);
-        Fr got;
-        std::memcpy(got.l, pw, 32);
-        got = fr_mul(got, fr_mul(one, r2));               // canonicalise: times R / R
-        const Fr want = fr_mul(fr_mul(x, w), r2);         // x w / R * R^2 / R = x w
-        if (std::memcmp(got.l, want.l, 32) != 0) { std::printf("SELFTEST FAILED at %d\n", it); return false; }
-        // lazy add / sub feeding a product: (x + x w) and (x - x w + 4 r)
+        const fr29::E xe = fr29::unpack(xw), we = fr29::unpack(ww);
+        auto canon = [&](const fr29::E& e) {              // the lazy result (< 2^256) mod r
+            uint32_t pw[8];
+            fr29::pack(e, pw);
+            Fr g;
+            std::memcpy(g.l, pw, 32);
+            return fr_mul(g, one);
+        };
+        const fr29::E pe = fr29::mul(xe, we);             // = x w 2^261 2^-261 = x w (mod r), < 2 r
+        const Fr xw_int = fr_mul(fr_mul(x, w), r2);       // the integer x w mod r
+        if (std::memcmp(canon(pe).l, xw_int.l, 32) != 0) { std::printf("SELFTEST FAILED at %d\n", it); return false; }
+        // lazy add / sub feeding a product: (x + x w) w and (x - x w + 4 r) w
         fr29::E s = fr29::add(xe, pe), d = fr29::sub4(xe, pe);
         fr29::normalise(s); fr29::normalise(d);
-        uint32_t sw[8], dw[8];
-        fr29::E ps = fr29::mul(s, we), pd = fr29::mul(d, we);
-        fr29::pack(ps, sw); fr29::pack(pd, dw);
-        Fr gs, gd;
-        std::memcpy(gs.l, sw, 32); std::memcpy(gd.l, dw, 32);
-        gs = fr_mul(gs, fr_mul(one, r2)); gd = fr_mul(gd, fr_mul(one, r2));
-        const Fr xw_v = want;
-        const Fr ws = fr_mul(fr_mul(fr_add(x, xw_v), w), r2), wd = fr_mul(fr_mul(fr_sub(x, xw_v), w), r2);
-        if (std::memcmp(gs.l, ws.l, 32) != 0 || std::memcmp(gd.l, wd.l, 32) != 0) { std::printf("SELFTEST (lazy add/sub) FAILED at %d\n", it); return false; }
+        const Fr ws = fr_mul(fr_mul(fr_add(x, xw_int), w), r2), wd = fr_mul(fr_mul(fr_sub(x, xw_int), w), r2);
+        if (std::memcmp(canon(fr29::mul(s, we)).l, ws.l, 32) != 0 || std::memcmp(canon(fr29::mul(d, we)).l, wd.l, 32) != 0) {
+            std::printf("SELFTEST (lazy add / sub) FAILED at %d\n", it);
+            return false;
+        }
     }
     std::printf("SELFTEST OK: 9 x 29-bit Montgomery product, lazy add / sub, 200000 random cases against csrc/host_fr.hpp\n");
     return true;
