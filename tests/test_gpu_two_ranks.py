@@ -270,3 +270,12 @@ def test_staged_transport_on_a_group_that_only_takes_cuda_tensors():
         assert r["picked"] in ("rccl", "staged") and (r["picked"] == "staged") == (r["picked_reason"] is not None), res
         assert r["proof"] and r["commit"] and r["exchanges_on_cuda_tensors"] >= 2, res
         assert r["comms_closed_with_context"] and r["fresh_context"], res
+
+
+def test_soak_four_processes_one_gpu_device_transcript_and_sharded_gkr():
+    """tools/soak_ranks.py, short form: four processes share the GPU and prove the same circuit again and again -- the device-resident outer
+    transcript (whose hasher reads another workgroup's round items from behind another L2: the agent-scope release of round 5) and the
+    sharded prover; every proof of every repeat on every rank identical.  (The 50-repeat form is run per round: profiles/r06/NOTES.md.)"""
+    import subprocess
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_ranks.py"), "4", "6", "9,14"], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "ALL IDENTICAL" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
