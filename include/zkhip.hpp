@@ -25,8 +25,12 @@ namespace zkc {
 
 struct Panic : std::runtime_error { using std::runtime_error::runtime_error; };
 
+// a sharded prover: ANOTHER rank failed and said so through the exchange (ZKHIP_ERR_PEER); this rank's outputs are void
+struct PeerFailed : Panic { using Panic::Panic; };
+
 inline void check(int st, const char* what) {
     if (st == ZKHIP_OK) return;
+    if (st == ZKHIP_ERR_PEER) throw PeerFailed(std::string(what) + ": " + zkhip_status_string(st));
     throw Panic(std::string(what) + ": " + zkhip_status_string(st));
 }
 
@@ -601,6 +605,11 @@ class DeviceCircuit {
         if (st == ZKHIP_ERR_SHAPE) throw Panic("Number of evaluations must be a power of 2");
         if (st == ZKHIP_ERR_INDEX) throw std::out_of_range("index out of bounds: gate input");
         check(st, "gkr_prove");
+        return unpack(nl, sums.data(), n_rounds.data(), lens.data(), rps.data(), wb.data(), wc.data(), w0.data());
+    }
+    // the C ABI's packed proof (zkhip_gkr_prove_circuit's arrays) -> GKRProof
+    static GKRProof unpack(uint32_t nl, const Fr* sums, const uint32_t* n_rounds, const uint32_t* lens, const uint64_t* rps, const Fr* wb, const Fr* wc, const Fr* w0) {
+        const uint32_t stride = 2 * nl;
         GKRProof proof;
         for (uint32_t k = 0; k < nl; ++k) {
             MultiComposedSumcheckProof sp;
@@ -617,9 +626,35 @@ class DeviceCircuit {
             }
             proof.sumcheck_proofs.push_back(sp);
         }
-        proof.wb_s = wb; proof.wc_s = wc; proof.w_0_mle = w0;
+        proof.wb_s.assign(wb, wb + nl); proof.wc_s.assign(wc, wc + nl); proof.w_0_mle.assign(w0, w0 + 2);
         return proof;
     }
+  public:
+    // one GKRProtocol::prove per evaluation in ONE call (zkhip_gkr_prove_batch: the proofs run side by side on the context's internal lanes;
+    // gkr/benches/gkr_benchmark.rs:11-27 proves input after input); every proof equals prove()'s
+    std::vector<GKRProof> prove_batch(const std::vector<Circuit::Evaluation>& evs, uint32_t max_lanes = 0) const {
+        const uint32_t nl = n_layers_, stride = 2 * nl, B = (uint32_t)evs.size();
+        if (!B) return {};
+        std::vector<const uint64_t*> ptrs;
+        for (auto& ev : evs) {
+            if (ev.tables.size() != (size_t)nl + 1 || ev.lens != evs[0].lens) throw Panic("circuit evaluation does not match the circuit");
+            for (auto& t : ev.tables) ptrs.push_back(t->u64());
+        }
+        std::vector<Fr> sums((size_t)B * nl), wb((size_t)B * nl), wc((size_t)B * nl), w0((size_t)B * 2);
+        std::vector<uint32_t> n_rounds((size_t)B * nl), lens((size_t)B * nl * stride);
+        std::vector<uint64_t> rps((size_t)B * nl * stride * 7 * 8);
+        const int st = zkhip_gkr_prove_batch(handle_, B, max_lanes, ptrs.data(), evs[0].lens.data(), sums[0].l, n_rounds.data(), lens.data(), rps.data(), wb[0].l, wc[0].l,
+                                             w0[0].l, nullptr, nullptr);
+        if (st == ZKHIP_ERR_SHAPE) throw Panic("Number of evaluations must be a power of 2");
+        if (st == ZKHIP_ERR_INDEX) throw std::out_of_range("index out of bounds: gate input");
+        check(st, "gkr_prove_batch");
+        std::vector<GKRProof> out;
+        for (uint32_t b = 0; b < B; ++b)
+            out.push_back(unpack(nl, &sums[(size_t)b * nl], &n_rounds[(size_t)b * nl], &lens[(size_t)b * nl * stride], &rps[(size_t)b * nl * stride * 7 * 8],
+                                 &wb[(size_t)b * nl], &wc[(size_t)b * nl], &w0[(size_t)b * 2]));
+        return out;
+    }
+  private:
     uint32_t n_layers_;
     zkhip_circuit* handle_ = nullptr;
 };

@@ -307,6 +307,22 @@ TEST(test_gkr_device_circuit_reused) {   // one resident circuit, two inputs: ea
         for (size_t k = 0; k < a.sumcheck_proofs.size(); ++k) EXPECT(a.sumcheck_proofs[k].to_bytes() == b.sumcheck_proofs[k].to_bytes());
     }
 }
+TEST(test_gkr_prove_batch) {   // gkr/benches/gkr_benchmark.rs:11-27: many inputs, one circuit -- one call, every proof the single prover's
+    Circuit c = make_circuit({{{0, 0, 1}}, {{1, 0, 1}, {0, 2, 3}}, {{0, 0, 1}, {1, 2, 3}, {1, 4, 5}, {1, 6, 7}}});
+    DeviceCircuit dc(c);
+    std::vector<Circuit::Evaluation> evs;
+    for (uint64_t seed = 21; seed < 21 + 11; ++seed) evs.push_back(c.evaluation(random_fr(8, seed)));
+    for (int rep = 0; rep < 2; ++rep) {             // the second batch replays the lanes' recorded launch chains
+        std::vector<GKRProof> got = dc.prove_batch(evs, rep ? 3 : 0);
+        EXPECT(got.size() == evs.size());
+        for (size_t b = 0; b < got.size(); ++b) {
+            GKRProof want = dc.prove(evs[b]);
+            EXPECT(got[b].wb_s == want.wb_s && got[b].wc_s == want.wc_s && got[b].w_0_mle == want.w_0_mle && got[b].sumcheck_proofs.size() == want.sumcheck_proofs.size());
+            for (size_t k = 0; k < want.sumcheck_proofs.size(); ++k) EXPECT(got[b].sumcheck_proofs[k].to_bytes() == want.sumcheck_proofs[k].to_bytes());
+        }
+    }
+    EXPECT(dc.prove_batch({}).empty());
+}
 // ---- the sharded provers through the C ABI's one-call entry points (include/zkhip.h): ranks = host threads with a context each,
 // the all-gather a barrier + a shared host buffer.  Every rank must return the single-GPU prover's proof of the WHOLE input.
 namespace {
