@@ -213,8 +213,9 @@ def test_threads_prove_one_circuit_at_once_each_on_its_own_stream(zk, ora, n_thr
     for t in ths:
         t.join()
     assert not errors and all(got), errors
-    assert len(circuit._devices) == n_threads + 1            # the main thread's copy and one per worker context ...
-    assert sum(d.alive() for d in circuit._devices) >= 1     # ... whose contexts (and device copies) went with their threads; the Circuit kept none of them alive
+    # the main thread's copy and one per worker context -- whose contexts (and device copies) go with their threads: the Circuit keeps none of
+    # them alive, and a worker that arrives late already drops the copies of those that have finished
+    assert 1 <= len(circuit._devices) <= n_threads + 1 and sum(d.alive() for d in circuit._devices) >= 1
     zk.GKRProtocol.prove(circuit, ev)                        # the next proof drops the dead entries
     assert all(d.alive() for d in circuit._devices)
 
