@@ -153,7 +153,8 @@ def bench_exchange(comm, world):
     pattern: an exchange is followed by more enqueues, never by a host wait -- and, as the upper bound, with the host waiting for each.
     At world 1 over a one-rank RCCL communicator this is the fixed cost of the call path that every rank count pays."""
     out = {"transport": comm.transport if isinstance(comm.transport, str) else "callback", "world": world,
-           "measured": "inside libzkhip: ncclAllGather on the context's stream (zkhip_comm_measure)"}
+           "measured": "inside libzkhip: ncclAllGather on the context's stream + the one-workgroup look at every rank's record for a failed rank's "
+                       "poison mark behind it (zkhip_comm_measure: an exchange as the protocols issue it)"}
     if getattr(comm, "fallback_reason", None):      # the library's RCCL communicator did not come up on every rank: host-staged all-gathers over torch.distributed
         out["measured"] = "inside libzkhip over the STAGED transport (device -> host -> torch.distributed all_gather -> device)"
         out["rccl_fallback_reason"] = str(comm.fallback_reason)[:300]
@@ -197,6 +198,21 @@ def selftest(zk, np, torch, N, D, comm, rank, world, dist, same_on_all_ranks):
     xy, inf = D.sharded_commit(srs.powers_of_tau_in_g1[rank::world].contiguous(), srs.inf[rank::world].contiguous(),
                                torch.from_numpy(np.ascontiguousarray(scal[rank::world]).view(np.int64)).cuda(), comm)
     res["commit_2^12"] = bool((not inf) and np.array_equal(xy, wc.xy) and same_on_all_ranks(np.asarray(xy, dtype=np.uint64)))
+    if os.environ.get("ZKHIP_SELFTEST_FAILURE_INJECTION", "0") not in ("", "0") and world > 1:
+        # opt-in (it has run over gloo and with threads as ranks, never over a real multi-rank RCCL communicator): the last rank fails in front
+        # of the second exchange of a sharded sumcheck -- it must get its own status, every other rank ZKHIP_ERR_PEER, nobody may hang, and
+        # the next proof on the same communicator must be right again
+        if rank == world - 1:
+            comm.inject_failure(1, N.ERR_NOMEM)
+        try:
+            D.ShardedSumcheck(D.HipSumcheckEngine(shard), world, comm=comm).prove()
+            outcome = "no status"
+        except N.ZkhipPeerError:
+            outcome = "peer"
+        except N.ZkhipError as e:
+            outcome = "own %d" % e.status
+        s_, rp_, ch_ = D.ShardedSumcheck(D.HipSumcheckEngine(shard), world, comm=comm).prove()
+        res["failure_injection"] = bool(outcome == ("own %d" % N.ERR_NOMEM if rank == world - 1 else "peer") and np.array_equal(ch_, want_ch))
     return res
 
 

@@ -215,17 +215,22 @@ extern "C" int zkhip_comm_measure(zkhip_comm* m, size_t bytes, uint32_t iters, d
     if (!send || !recv) return ZKHIP_ERR_NOMEM;
     ZK_HIP(c, hipMemsetAsync(send, 0, bytes, c->stream));
     const uint64_t ex0 = m->n_exchanges, by0 = m->n_bytes;
-    for (int w = 0; w < 3; ++w) ZK_TRY(m->all_gather(send, recv, bytes));             // warm-up (first use sets up RCCL's channels)
+    // an exchange as the protocols issue it: the all-gather and, behind it, the look at every rank's record for the poison mark
+    // (shard_protocol.hpp gather(): one tiny kernel; nothing where there is no transport)
+    const size_t elems = (bytes + 31) / 32;
+    auto exchange = [&]() -> int { ZK_TRY(m->all_gather(send, recv, bytes)); return m->check(recv, elems); };
+    for (int w = 0; w < 3; ++w) ZK_TRY(exchange());             // warm-up (first use sets up RCCL's channels)
     ZK_TRY(c->wait_stream());
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
-    for (uint32_t i = 0; i < iters; ++i) ZK_TRY(m->all_gather(send, recv, bytes));
+    for (uint32_t i = 0; i < iters; ++i) ZK_TRY(exchange());
     ZK_TRY(c->wait_stream());
     *us_b2b = std::chrono::duration<double, std::micro>(clk::now() - t0).count() / iters;
     t0 = clk::now();
-    for (uint32_t i = 0; i < iters; ++i) { ZK_TRY(m->all_gather(send, recv, bytes)); ZK_TRY(c->wait_stream()); }
+    for (uint32_t i = 0; i < iters; ++i) { ZK_TRY(exchange()); ZK_TRY(c->wait_stream()); }
     *us_wait = std::chrono::duration<double, std::micro>(clk::now() - t0).count() / iters;
     m->n_exchanges = ex0; m->n_bytes = by0;                                         // a measurement, not a prover's traffic
+    (void)m->take_peer_failure();
     return ZKHIP_OK;
 }
 
