@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_bench_multi_rank_dry_run(world):
-    env = dict(os.environ, ZKHIP_BENCH_ONE_GPU="1")
+    env = dict(os.environ, ZKHIP_BENCH_ONE_GPU="1", ZKHIP_SELFTEST_FAILURE_INJECTION="1")   # + the self-test's opt-in case: one rank fails, nobody hangs
     port = 29800 + (os.getpid() % 1000) + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
@@ -45,5 +45,6 @@ def test_bench_multi_rank_dry_run(world):
     st = [l for l in out.stderr.decode().splitlines() if l.startswith("bench.py selftest: ")]
     assert len(st) == 1
     st = json.loads(st[0][len("bench.py selftest: "):])
-    assert st["n_gpus"] == world and all(st["sharded_provers_match_single_gpu_and_rank_0"].values()) and len(st["sharded_provers_match_single_gpu_and_rank_0"]) == 4
+    assert st["n_gpus"] == world and all(st["sharded_provers_match_single_gpu_and_rank_0"].values()) and len(st["sharded_provers_match_single_gpu_and_rank_0"]) == 5
+    assert st["sharded_provers_match_single_gpu_and_rank_0"]["failure_injection"] is True
     assert st["exchange"]["64_B"]["back_to_back_us"] > 0 and d["exchange"]["64_B"]["back_to_back_us"] > 0
