@@ -146,6 +146,30 @@ def case_gkr():
     return ok, ("gkr", depth)
 
 
+def case_gkr_batch():
+    """zkhip_gkr_prove_batch: several inputs of one random circuit in one call (lanes, replayed launch chains) against the oracle, proof by proof;
+    the circuit changes from case to case, so the lanes' recorded graphs are dropped and re-recorded all the time"""
+    from gkr_cases import A, M
+    depth = rng.randint(1, 6 + BIG // 2)
+    layers = []
+    for li in range(depth):
+        n_in = 2 ** (li + 1)
+        layers.append([(rng.choice((A, M)), rng.randrange(n_in), rng.randrange(n_in)) for _ in range(2 ** li)])
+    layers[0] = layers[0][:1]
+    circuit = zk.Circuit.from_tuples(layers)
+    inputs = [ora.random_fr(2 ** depth, rng.randrange(1 << 30)) for _ in range(rng.randint(1, 20))]
+    ok = True
+    for rep in range(rng.randint(1, 2)):
+        proofs = zk.GKRProtocol.prove_batch(circuit, [circuit.evaluation(i) for i in inputs], max_lanes=rng.choice([0, 1, 3, 8, 12]))
+        for inp, proof in zip(inputs, proofs):
+            want = ora.gkr_prove(layers, ora.circuit_evaluation(layers, inp))
+            for k, sp in enumerate(proof.sumcheck_proofs):
+                w_sum, w_rps, w_wb, w_wc = want.layer(k)
+                ok = ok and np.array_equal(sp.sum, w_sum) and sp.to_bytes() == ora.multi_composed_proof_bytes(w_rps)
+                ok = ok and np.array_equal(proof.wb_s[k], w_wb) and np.array_equal(proof.wc_s[k], w_wc)
+    return ok, ("gkr_batch", depth, len(inputs))
+
+
 def case_open():
     nv = rng.randint(2, 5)
     if nv not in _srs:
@@ -217,9 +241,9 @@ def case_multifold():
 
 
 def case_in_flight():
-    """up to four Sumcheck proofs in flight on lanes of their own, tables of mixed sizes"""
-    depth = rng.randint(2, 4)
-    logs = [rng.choice([3, 9, 12, 18, 19, 20, 21]) for _ in range(rng.randint(2, 6))]
+    """up to eight Sumcheck proofs in flight on lanes of their own, tables of mixed sizes"""
+    depth = rng.randint(2, 8)
+    logs = [rng.choice([3, 9, 12, 18, 19, 20, 21]) for _ in range(rng.randint(2, 10))]
     tabs = [ora.random_fr(1 << l, rng.randrange(1 << 30)) for l in logs]
     pend, got = [], []
     for t in tabs:
@@ -234,7 +258,7 @@ def case_in_flight():
     return ok, ("in_flight", depth, logs)
 
 
-cases = [case_multi_k2, case_multifold, case_in_flight, case_open, case_uni_open, case_table_ops, case_sumcheck, case_fold_eval, case_composed, case_multi, case_commit, case_ntt, case_gkr]
+cases = [case_multi_k2, case_multifold, case_in_flight, case_open, case_uni_open, case_table_ops, case_sumcheck, case_fold_eval, case_composed, case_multi, case_commit, case_ntt, case_gkr, case_gkr_batch]
 if len(sys.argv) > 3:
     cases = [c for c in cases if c.__name__ in sys.argv[3:]]
 t0 = time.time()

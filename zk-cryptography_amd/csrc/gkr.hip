@@ -829,15 +829,19 @@ static int gkr_prove_circuit_on(zkhip_ctx* c, zkhip_circuit* cir, const uint64_t
             ZK_HIP(c, hipGraphLaunch((hipGraphExec_t)gg.exec, c->stream));
         } else if (lane && gg.warm_cir == cir && gg.warm_aux == c->d_aux && gg.warm_ws == c->d_ws) {
             // the second proof of this circuit on the lane (the first one, launched plainly, made every allocation): record, instantiate, launch
+            // Relaxed mode: the recorded region is kernel launches and one copy; the OTHER lanes' threads allocate, free and synchronise at the
+            // same time (a capture in the stricter modes was invalidated by them: hipErrorStreamCaptureInvalidated, tools/stress_parity.py)
             hipGraph_t graph = nullptr;
-            ZK_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            ZK_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
             const int crc = enqueue_chain(true);
             const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
             if (crc != ZKHIP_OK || ee != hipSuccess || !graph) {
+                // not recordable here (whatever the reason): nothing was launched; forget the attempt and launch this proof plainly -- a real
+                // error (a shape, a launch failure) comes back from there
                 if (graph) (void)hipGraphDestroy(graph);
-                gg.warm_cir = nullptr;                                   // not recordable here: plain launches from now on
-                if (crc != ZKHIP_OK) return crc;
-                ZK_TRY(enqueue_chain(false));
+                (void)hipGetLastError();
+                gg.warm_cir = nullptr;
+                ZK_TRY(enqueue_chain(true));
             } else {
                 hipGraphExec_t exec = nullptr;
                 const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);

@@ -351,6 +351,8 @@ class GKRProtocol:
         p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
         st = N.lib().zkhip_gkr_prove_batch(dev.handle, C.c_uint32(B), C.c_uint32(max_lanes), ptrs, lens, p(sums), p(n_rounds), p(rp_lens), p(rps), p(wb), p(wc),
                                            p(w0), p(chal), p(status))
+        if st == N.ERR_HIP:
+            raise N.ZkhipError("gkr_prove_batch: HIP runtime error (hipError %d); per-proof statuses %s" % (N.lib().zkhip_last_hip_error(ctx.handle), status.tolist()), st)
         N.check(st, "gkr_prove_batch: every layer must hold a power-of-two number of values, 2^l gates in layer l")
         out = []
         for b in range(B):
