@@ -629,21 +629,37 @@ def bench_gkr(args, zk, N, D, rank, world, barrier, dist, torch, np):
         out["batch"] = {"note": "zkhip_gkr_prove_batch: B independent proofs of one circuit from one call from one host thread; ms per proof; every proof "
                                 "equal to GKRProtocol.prove's (asserted)", "ms_per_proof": {}}
         try:
+            import ctypes as C
+            from zk_cryptography_amd.gkr import GKRProtocol as _G
+            p_ = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
             for depth, B_list in ((8, (8, 32)), (20, (4, 8))):
                 circuit = zk.Circuit.random(depth)
                 evs = [circuit.evaluation(zk.Fr.synthetic(2 ** depth, SEED_GKR + 100 + b)) for b in range(max(B_list))]
                 want = [[sp.to_bytes() for sp in zk.GKRProtocol.prove(circuit, ev).sumcheck_proofs] for ev in evs[:2]]
+                dev = _G._device_circuit(circuit, N.Context.get())
+                nl, stride = depth, 2 * depth
                 for B in B_list:
                     got = zk.GKRProtocol.prove_batch(circuit, evs[:B])
                     assert [[sp.to_bytes() for sp in pr.sumcheck_proofs] for pr in got[:2]] == want, "batched and synchronous proofs differ"
-                    ts = []
+                    # the C call itself, outputs preallocated once (what a Rust host pays); the Python mirror's per-proof unpacking beside it
+                    ptrs = (C.c_void_p * (B * (nl + 1)))(*[t.data_ptr() for ev in evs[:B] for t in ev])
+                    lens = (C.c_size_t * (nl + 1))(*[t.shape[0] for t in evs[0]])
+                    o = [np.zeros((B, nl, 4), np.uint64), np.zeros((B, nl), np.uint32), np.zeros((B, nl, stride), np.uint32), np.zeros((B, nl, stride, 7, 2, 4), np.uint64),
+                         np.zeros((B, nl, 4), np.uint64), np.zeros((B, nl, 4), np.uint64), np.zeros((B, 2, 4), np.uint64)]
+                    call = lambda: N.check(N.lib().zkhip_gkr_prove_batch(dev.handle, C.c_uint32(B), C.c_uint32(0), ptrs, lens, *[p_(a) for a in o], None, None), "gkr_prove_batch")   # noqa: E731
+                    call()
+                    ts, tm = [], []
                     for _ in range(5 if depth <= 8 else 3):
                         torch.cuda.synchronize()
                         t0 = time.perf_counter()
-                        zk.GKRProtocol.prove_batch(circuit, evs[:B])
+                        call()
                         ts.append((time.perf_counter() - t0) / B)
+                        t0 = time.perf_counter()
+                        zk.GKRProtocol.prove_batch(circuit, evs[:B])
+                        tm.append((time.perf_counter() - t0) / B)
                     out["batch"]["ms_per_proof"].setdefault("depth_%d" % depth, {})[str(B)] = round(1e3 * sorted(ts)[len(ts) // 2], 3)
-                del evs, circuit
+                    out["batch"].setdefault("ms_per_proof_python_mirror", {}).setdefault("depth_%d" % depth, {})[str(B)] = round(1e3 * sorted(tm)[len(tm) // 2], 3)
+                del evs, circuit, dev
         except Exception as e:      # noqa: BLE001 -- reported, not fatal for the other legs
             out["batch"]["error"] = repr(e)
     # BASELINE configs[3]: ONE depth-20 proof with every layer's sumcheck sharded over the ranks (GKRProtocol.prove_sharded:
@@ -1113,7 +1129,20 @@ def main():
     if not args.no_exchange and world == 1:
         # one rank: the call path's fixed cost over a ONE-RANK RCCL communicator of the library's own (librccl resolved at run time)
         try:
-            rc1 = D.Comm(N.Context.get(), 1, 0, transport="rccl")
+            # (RCCL prints a version banner on STDOUT when its first communicator comes up: stdout carries ONE JSON line, so the banner goes to stderr)
+            sys.stdout.flush()
+            _fd1 = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                rc1 = D.Comm(N.Context.get(), 1, 0, transport="rccl")
+            finally:
+                try:
+                    import ctypes as _C
+                    _C.CDLL(None).fflush(None)          # the banner sits in the C library's stdio buffer: out with it while fd 1 is stderr
+                except Exception:                        # noqa: BLE001
+                    pass
+                os.dup2(_fd1, 1)
+                os.close(_fd1)
             exchange = bench_exchange(rc1, 1)
             rc1.close()
         except Exception as e:
