@@ -140,6 +140,69 @@ def test_proofs_in_flight_without_poly_sum_and_same_table(zk, ora):
     assert np.array_equal(proof.univariate_poly, rp) and np.array_equal(ch, och)
 
 
+def test_proofs_in_flight_at_2_24_keep_their_folds_on_the_callers_stream(zk):
+    """From the third proof in flight on, the big fold of an overlapped-plan proof (2^24 entries) is held back and enqueued on the caller's
+    stream behind the next tables' sums passes (zkhip_ctx::deferred).  Every way the held-back half can be flushed -- by the next begin, by
+    wait() in order, out of order and of a proof that still holds it, by a synchronize of the context, by dropping the ticket -- must
+    deliver the synchronous prove()'s proof, bit for bit."""
+    import torch
+    from zk_cryptography_amd import _native as N
+    g = torch.Generator(device="cuda")
+    g.manual_seed(2424)
+    polys = [zk.Multilinear(torch.randint(0, 2 ** 62, (1 << 24, 4), dtype=torch.int64, device="cuda", generator=g)) for _ in range(5)]
+    want = []
+    for pl in polys:
+        sc = zk.Sumcheck(pl)
+        sc.poly_sum()
+        want.append(sc.prove())
+
+    def same(got, j):
+        (proof, ch), (wproof, wch) = got, want[j]
+        return np.array_equal(proof.sum, wproof.sum) and np.array_equal(proof.univariate_poly, wproof.univariate_poly) and np.array_equal(ch, wch)
+
+    def begin(j):
+        sc = zk.Sumcheck(polys[j])
+        sc.poly_sum()
+        return sc.prove_begin()
+
+    for depth in (3, 4, 5, 6, 8):                                  # the pipeline of bench.py's `pipelined` leg, filled and drained
+        pend = []
+        for i in range(2 * depth + 3):
+            pend.append((i % 5, begin(i % 5)))
+            if len(pend) == depth:
+                j, h = pend.pop(0)
+                assert same(h.wait(), j), (depth, i)
+        for j, h in pend:
+            assert same(h.wait(), j), depth
+    hs = [begin(j) for j in range(5)]                             # collected youngest first: the first wait() flushes every half held back
+    for j in reversed(range(5)):
+        assert same(hs[j].wait(), j)
+    hs = [begin(j) for j in range(4)]
+    assert same(hs[3].wait(), 3) and same(hs[0].wait(), 0)         # ... and from the middle
+    assert same(hs[2].wait(), 2) and same(hs[1].wait(), 1)
+    hs = [begin(j) for j in range(5)]
+    N.Context.get().synchronize()                                  # drains the caller's stream: nothing may stay behind
+    torch.cuda.synchronize()
+    for j in range(5):
+        assert same(hs[j].wait(), j)
+    hs = [begin(j) for j in range(5)]                             # tickets dropped uncollected: waited out, lanes and slots free again
+    del hs
+    sc = zk.Sumcheck(polys[1])
+    sc.poly_sum()
+    assert same(sc.prove(), 1)
+
+
+def test_proofs_in_flight_with_the_overlapped_plan_at_small_sizes():
+    """The in-flight tests above once more in a process where the overlapped plan starts at 2^19 (ZKHIP_OVERLAP_MIN_LOG) instead of 2^24:
+    overlapped, stage and serial plans side by side in one pipeline, folds held back on the caller's stream, against the oracle."""
+    import os, subprocess, sys
+    env = dict(os.environ, ZKHIP_OVERLAP_MIN_LOG="19")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k",
+                          "test_proofs_in_flight_match_synchronous_proofs or test_proofs_in_flight_without_poly_sum_and_same_table or test_prove_matches_oracle_random"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert out.returncode == 0, out.stdout.decode()[-3000:]
+
+
 @pytest.mark.parametrize("log_n", [21, 24])
 def test_poly_sum_with_the_total_deferred(zk, ora, log_n):
     """Tables of 2^24 entries (the overlapped plan; the stage plan below that since round 5: tools/step_sizes.py): poly_sum() leaves the

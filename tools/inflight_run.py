@@ -1,0 +1,30 @@
+"""Sumcheck proofs IN FLIGHT, nothing else: `proofs` proofs of 2^log_n entries over 8 tables round robin with up to `depth` in flight (the loop of
+bench.py's `pipelined` leg), no library events -- the program to put under `rocprofv3 --kernel-trace` (tools/trace_passes.py reads the trace).
+usage: python tools/inflight_run.py [log_n] [depth] [proofs]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import zk_cryptography_amd as zk
+log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+depth = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+proofs = int(sys.argv[3]) if len(sys.argv) > 3 else 48
+mixed = os.environ.get("INFLIGHT_MIXED") == "1"        # tables 3 and 7 half as long: which proof a pass belongs to shows in its grid size
+polys = [zk.Multilinear(torch.randint(0, 2 ** 62, (1 << (log_n - (1 if mixed and t % 4 == 3 else 0)), 4), dtype=torch.int64, device="cuda")) for t in range(max(8, depth))]
+
+
+def run(k):
+    pend = []
+    for i in range(k):
+        sc = zk.Sumcheck(polys[i % len(polys)]); sc.poly_sum()
+        pend.append(sc.prove_begin())
+        if len(pend) == depth:
+            pend.pop(0).wait()
+    for h in pend:
+        h.wait()
+    torch.cuda.synchronize()
+
+
+run(2 * depth)
+for _ in range(3):
+    t0 = time.perf_counter(); run(proofs); dt = time.perf_counter() - t0
+    print("depth %d: %.1f us per proof (%d proofs)" % (depth, dt / proofs * 1e6, proofs))

@@ -4,6 +4,8 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <deque>
+#include <functional>
 #include <memory>
 #include <new>
 #include <set>
@@ -123,27 +125,68 @@ struct zkhip_ctx {
     void release_coarse(int proof_slot) {
         for (int k = 0; k < COARSE_RING; ++k) if (coarse_owner[k] == proof_slot + 1) coarse_owner[k] = 0;
     }
-    // Sumcheck::prove in flight (zkhip_sumcheck_prove_begin): every ticket has a LANE of its own -- a serial stream, a low-priority
-    // fold stream, events, workspace and small scratch -- so that the streaming passes of one proof run while the transcript rounds
-    // of the other hash (the synchronous call keeps the caller's stream and the context's buffers)
+    // Sumcheck::prove in flight (zkhip_sumcheck_prove_begin): every ticket has a LANE of its own -- events, workspace and small scratch, a
+    // high-priority serial stream and a low-priority fold stream -- so that the streaming passes of one proof run while the transcript rounds
+    // of the others hash (the synchronous call keeps the caller's stream and the context's buffers).  Lanes k and k + 4 -- four proofs apart,
+    // the older one is done when the younger one begins -- share their two streams: the runtime serves all streams of one priority from four
+    // hardware queues, and two streams that take turns in one queue wait for each other's kernels (profiles/r06/NOTES.md section 7: with six
+    // serial streams on four queues the first rounds of a proof stood behind another lane's 100 us serial kernel)
     struct ProofLane {
         hipStream_t serial = nullptr, fold = nullptr;
+        bool borrowed = false;                  // the streams are those of lane k - 4
         hipEvent_t begin_ev = nullptr, fork_ev = nullptr, serial_ev = nullptr;
         void* ws = nullptr; size_t ws_bytes = 0;
         void* small = nullptr;
     };
-    static constexpr int PROOF_SLOTS = 8;      // proofs in flight (measured at 2^24: 2 / 3 / 4 / 6 / 8 in flight, see bench.py `pipelined`)
+    static constexpr int PROOF_SLOTS = 8;      // proofs in flight (measured at 2^24 with 2 .. 12, see bench.py `pipelined`; nothing is gained beyond 8)
+    static constexpr int LANE_STREAMS = 4;     // = the hardware queues of one stream priority
     ProofLane lanes[PROOF_SLOTS];
+    // With three or more proofs in flight the big fold of a proof is NOT enqueued when the proof begins: it goes onto the CALLER's stream --
+    // where poly_sum() puts every table's sums pass -- behind the sums passes of the next one to three tables, so that ONE stream carries
+    // all streaming passes back to back (two passes side by side take 2.5 x as long as one, not 2 x) and never waits for a proof's first
+    // rounds.  `deferred` holds those second halves, oldest first; they are enqueued by the next zkhip_sumcheck_prove_begin, by
+    // zkhip_sumcheck_prove_end of that proof (or of a younger one), and by everything that drains or replaces the caller's stream.
+    std::deque<std::pair<int, std::function<int()>>> deferred;      // (proof slot, what is left to enqueue)
+    int deferred_rc[PROOF_SLOTS] = {};                              // a second half that could not be enqueued: reported by prove_end of that proof
+    // enqueue the oldest entries until `keep` are left, or -- until_slot >= 0 -- until that proof's entry has gone (nothing if it has already)
+    int flush_deferred(size_t keep = 0, int until_slot = -1) {
+        if (until_slot >= 0) {
+            bool there = false;
+            for (auto& d : deferred) there = there || d.first == until_slot;
+            if (!there) return ZKHIP_OK;
+        }
+        int rc = ZKHIP_OK;
+        while (deferred.size() > keep) {
+            const int slot = deferred.front().first;
+            std::function<int()> f = std::move(deferred.front().second);
+            deferred.pop_front();
+            const int r = f();
+            if (r != ZKHIP_OK) { deferred_rc[slot] = r; if (rc == ZKHIP_OK) rc = r; }
+            if (slot == until_slot) break;
+        }
+        return rc;
+    }
+    int ensure_lane_streams(int k) {
+        ProofLane& L = lanes[k];
+        if (L.serial) return ZKHIP_OK;
+        if (k >= LANE_STREAMS) {
+            const int rc = ensure_lane_streams(k - LANE_STREAMS);
+            if (rc != ZKHIP_OK) return rc;
+            L.serial = lanes[k - LANE_STREAMS].serial; L.fold = lanes[k - LANE_STREAMS].fold; L.borrowed = true;
+            return ZKHIP_OK;
+        }
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return ZKHIP_ERR_HIP;
+        if (hipStreamCreateWithPriority(&L.serial, hipStreamNonBlocking, greatest) != hipSuccess) return ZKHIP_ERR_HIP;
+        // (measured and dropped, profiles/r06/NOTES.md: some lanes' serial stream at normal instead of high priority, or their fold stream at
+        // normal instead of low: 0.27-0.32 ms per proof in flight instead of 0.23; the serial kernels must get in front of every streaming pass)
+        if (hipStreamCreateWithPriority(&L.fold, hipStreamNonBlocking, least) != hipSuccess) return ZKHIP_ERR_HIP;
+        return ZKHIP_OK;
+    }
     int ensure_lane(int k, size_t ws_need) {
         ProofLane& L = lanes[k];
-        if (!L.serial) {
-            int least = 0, greatest = 0;
-            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return ZKHIP_ERR_HIP;
-            if (hipStreamCreateWithPriority(&L.serial, hipStreamNonBlocking, greatest) != hipSuccess) return ZKHIP_ERR_HIP;
-            // (measured and dropped, profiles/r06/NOTES.md: lanes 4..7 with their serial stream at normal instead of high priority, or their fold
-            // stream at normal instead of low -- a hardware queue to itself for every stream of up to six proofs: 0.27-0.32 ms per proof in
-            // flight instead of 0.23; here the priorities do real work, the serial kernels must get in front of every fold)
-            if (hipStreamCreateWithPriority(&L.fold, hipStreamNonBlocking, least) != hipSuccess) return ZKHIP_ERR_HIP;
+        { const int rc = ensure_lane_streams(k); if (rc != ZKHIP_OK) return rc; }
+        if (!L.small) {
             if (hipEventCreateWithFlags(&L.begin_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
             if (hipEventCreateWithFlags(&L.fork_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
             if (hipEventCreateWithFlags(&L.serial_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;

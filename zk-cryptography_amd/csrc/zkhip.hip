@@ -65,6 +65,7 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     c->gkr_lanes.clear();
     hipSetDevice(c->device);
     for (int k = 0; k < zkhip_ctx::ASYNC_SLOTS; ++k) if (c->async_pend[k]) zkhip_kzg_commit_end(c, (uint32_t)k, nullptr, nullptr);   // commits never collected
+    (void)c->flush_deferred();
     hipStreamSynchronize(c->stream);
     if (c->gkr_graph.exec) (void)hipGraphExecDestroy((hipGraphExec_t)c->gkr_graph.exec);
     if (c->d_gkr_in) (void)hipFree(c->d_gkr_in);
@@ -97,8 +98,8 @@ extern "C" int zkhip_ctx_destroy(zkhip_ctx* c) {
     if (c->fold_stream) hipStreamDestroy(c->fold_stream);
     for (int k = 0; k < zkhip_ctx::COARSE_RING; ++k) if (c->d_coarse[k]) hipFree(c->d_coarse[k]);
     for (auto& L : c->lanes) {
-        if (L.serial) hipStreamDestroy(L.serial);
-        if (L.fold) hipStreamDestroy(L.fold);
+        if (L.serial && !L.borrowed) hipStreamDestroy(L.serial);
+        if (L.fold && !L.borrowed) hipStreamDestroy(L.fold);
         if (L.begin_ev) hipEventDestroy(L.begin_ev);
         if (L.fork_ev) hipEventDestroy(L.fork_ev);
         if (L.serial_ev) hipEventDestroy(L.serial_ev);
@@ -120,6 +121,7 @@ extern "C" int zkhip_ctx_set_stream(zkhip_ctx* c, void* stream) {
     // Several entry points return before their kernels have run, and they share the context's scratch buffers: work
     // enqueued on the new stream must come after what is still queued on the old one.
     ZK_TRY(c->activate());
+    (void)c->flush_deferred();                  // proofs in flight finish on the stream they began on (a failure is reported by their prove_end)
     ZK_TRY(c->ensure_side_streams());
     ZK_HIP(c, hipEventRecord(c->fork_ev, c->stream));
     ZK_HIP(c, hipStreamWaitEvent((hipStream_t)stream, c->fork_ev, 0));
@@ -128,6 +130,7 @@ extern "C" int zkhip_ctx_set_stream(zkhip_ctx* c, void* stream) {
 }
 extern "C" int zkhip_ctx_synchronize(zkhip_ctx* c) {
     if (!c) return ZKHIP_ERR_ARG;
+    (void)c->flush_deferred();
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     return ZKHIP_OK;
 }
@@ -734,7 +737,7 @@ static int block_sums_impl(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uint
 // `lane` < 0: on the caller's stream with the context's buffers (the synchronous call); otherwise on the private streams and buffers of
 // c->lanes[lane], behind everything the caller's stream holds at this moment
 static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, const uint64_t* h_claimed_sum,
-                            const uint64_t* d_claimed_sum, const uint64_t* d_block_sums, uint32_t log_blocks, int slot, int lane) {
+                            const uint64_t* d_claimed_sum, const uint64_t* d_block_sums, uint32_t log_blocks, int slot, int lane, int in_flight = 1) {
     const uint32_t n_vars = log2_exact(n);
     const bool overlap = overlapped_plan(n);
     // workspace: stage tables (n/4 + n/16 + ...; overlapped: n / 2^k1 <= n/8), partial sums, fold weights, and for the
@@ -823,11 +826,38 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
         uint32_t ny = 0;
         ZK_TRY(launch_blockfold(c, S, fine, 1u << k2, k1, d_w, d_p1, &ny));
         ZK_HIP(c, hipEventRecord(fork_ev, S));
-        ZK_HIP(c, hipStreamWaitEvent(F, fork_ev, 0));
-        ZK_TRY(launch_multifold(c, F, d_evals, n, k1, d_w, tabA, partA, &n_parts));
         SmallArgs b = {};
         b.src = d_p1; b.group = ny; b.stride = 1u << k2; b.canon = 1; b.log_n = k2; b.n_rounds = k2; b.round0 = k1; b.first = 0;
         b.weights_out = d_w2; b.final_out = nullptr;
+        if (lane >= 0 && in_flight >= 3) {
+            // Three or more proofs in flight: the streaming passes of ALL of them on ONE stream, the caller's -- where poly_sum() puts the sums
+            // passes already.  The big fold and what follows it are enqueued LATER (zkhip_ctx::deferred), behind the sums passes of the next
+            // one to three tables, so that the caller's stream never stands waiting for this proof's first rounds; the serial kernel of
+            // rounds k1+1 .. g goes out now, the last stage follows the fold on the serial stream.  Measured at 2^24 (profiles/r06/NOTES.md
+            // section 7): 0.207 ms per proof with eight in flight against 0.233 with a fold stream per lane.
+            ZK_TRY(launch_small(c, b, st, d_rp, d_ch, 156 * 1024, S));
+            hipEvent_t fold_ev = serial_ev;
+            c->deferred_rc[slot] = ZKHIP_OK;
+            c->deferred.emplace_back(slot, [=]() -> int {
+                uint32_t np2 = 0, ny2 = 0;
+                ZK_HIP(c, hipStreamWaitEvent(c->stream, fork_ev, 0));
+                ZK_TRY(launch_multifold(c, c->stream, d_evals, n, k1, d_w, tabA, partA, &np2));
+                ZK_HIP(c, hipEventRecord(fold_ev, c->stream));
+                ZK_HIP(c, hipStreamWaitEvent(S, fold_ev, 0));
+                ZK_TRY(launch_blockfold(c, S, tabA, 256, k2, d_w2, d_p2, &ny2));
+                SmallArgs t = {};
+                t.src = d_p2; t.group = ny2; t.stride = 256; t.canon = 1; t.log_n = 8; t.n_rounds = 8; t.round0 = g; t.first = 0;
+                t.weights_out = nullptr; t.final_out = d_fin; t.host_delta = host_delta;
+                ZK_TRY(launch_small(c, t, st, d_rp, d_ch, 0, S));
+                ZK_HIP(c, hipEventRecord(c->proof_ev[slot], S));
+                return ZKHIP_OK;
+            });
+            // how many second halves stay back: enough sums passes in front of a fold that its proof's first rounds are over when its turn
+            // comes (1-3 tables), few enough that the host, which stops at its depth, still has passes queued (depth 3 / 4: 1, 5: 2, 6+: 3)
+            return c->flush_deferred((size_t)std::min(3, std::max(1, in_flight - 3)));
+        }
+        ZK_HIP(c, hipStreamWaitEvent(F, fork_ev, 0));
+        ZK_TRY(launch_multifold(c, F, d_evals, n, k1, d_w, tabA, partA, &n_parts));
         ZK_TRY(launch_small(c, b, st, d_rp, d_ch, 156 * 1024, S));
         // join ON THE FOLD STREAM: the serial kernel ends well before the big fold, so its event is long set when the fold
         // ends and the last stage follows the fold in stream order (joining on the caller's stream left the chip idle for the
@@ -937,7 +967,9 @@ extern "C" int zkhip_sumcheck_prove_begin(zkhip_ctx* c, const uint64_t* d_evals,
     for (int k = 0; k < zkhip_ctx::PROOF_SLOTS; ++k) if (!c->proof_pending[k]) { slot = k; break; }
     if (slot < 0) return ZKHIP_ERR_BUSY;
     ZK_TRY(c->activate());
-    ZK_TRY(sumcheck_enqueue(c, d_evals, n, h_claimed_sum, d_claimed_sum, d_block_sums, log_blocks, slot, slot));
+    int in_flight = 1;
+    for (int k = 0; k < zkhip_ctx::PROOF_SLOTS; ++k) in_flight += c->proof_pending[k] != 0;
+    ZK_TRY(sumcheck_enqueue(c, d_evals, n, h_claimed_sum, d_claimed_sum, d_block_sums, log_blocks, slot, slot, in_flight));
     c->proof_pending[slot] = log2_exact(n);
     *ticket = (uint32_t)slot;
     return ZKHIP_OK;
@@ -946,6 +978,16 @@ extern "C" int zkhip_sumcheck_prove_end(zkhip_ctx* c, uint32_t ticket, uint64_t*
     if (!c || ticket >= (uint32_t)zkhip_ctx::PROOF_SLOTS || !c->proof_pending[ticket]) return ZKHIP_ERR_ARG;
     const uint32_t n_vars = c->proof_pending[ticket];
     int rc = c->activate();
+    if (rc == ZKHIP_OK) {
+        (void)c->flush_deferred(0, (int)ticket);          // the proof's second half, if it is still held back (and those of the older proofs in front of it)
+        rc = c->deferred_rc[ticket];
+        c->deferred_rc[ticket] = ZKHIP_OK;
+        if (rc != ZKHIP_OK) {                   // the proof never got its last stage: drain what did get out, there is nothing to collect
+            (void)hipStreamSynchronize(c->lanes[ticket].serial);
+            (void)hipStreamSynchronize(c->stream);
+            c->release_coarse((int)ticket);
+        }
+    }
     if (rc == ZKHIP_OK) {
         if (h_sum && h_round_polys && h_challenges) rc = sumcheck_collect(c, (int)ticket, n_vars, h_sum, h_round_polys, h_challenges);
         else { rc = c->wait_event(c->proof_ev[ticket]); c->release_coarse((int)ticket); }   // abandoned: just wait it out
