@@ -639,7 +639,15 @@ static int launch_fine_sums(zkhip_ctx* c, const uint64_t* d_evals, size_t n, uin
         // (measured and dropped: waves that stay and loop over run pairs with the next pair's loads in flight -- 100-115 us
         // against 94-96 us for this one-shot form at 2^24; the loads alone take 81 us, tools/ubench_rows.hip "pieces")
         ProfScope ps(c, "fine_sums", 32.0 * (double)n, stream);
-        hipLaunchKernelGGL(fine_sums_kernel, dim3((unsigned)((n_chunks + 7) / 8)), dim3(MLE_BLOCK), 0, stream, d_evals, n_chunks, first);
+        // TWO workgroups (8 waves) per CU, through an LDS request the kernel never touches: with all the waves its registers allow
+        // (6 per SIMD) the pass keeps ~48 MiB of loads in flight -- no faster (93 us against 90-91 us with two workgroups per CU, one:
+        // 123 us), and every other kernel's loads queue behind them: the first rounds and small folds of the proofs in flight beside
+        // it took 50-150 us instead of 10-40, 0.212 against 0.201 ms per proof (profiles/r06/NOTES.md section 7).
+        // ZKHIP_FINE_LDS=<bytes> overrides (diagnostics; 0 = no cap).
+        static const long fine_lds = [] { const char* e = getenv("ZKHIP_FINE_LDS"); return e ? atol(e) : 79872L; }();
+        const size_t lds = (size_t)std::min<long>(std::max<long>(fine_lds, 0), 158 * 1024);
+        if (lds > 64 * 1024) ZK_TRY(c->allow_big_lds((const void*)fine_sums_kernel, 158 * 1024));
+        hipLaunchKernelGGL(fine_sums_kernel, dim3((unsigned)((n_chunks + 7) / 8)), dim3(MLE_BLOCK), lds, stream, d_evals, n_chunks, first);
     }
     if (first != d_fine)
         hipLaunchKernelGGL(group_sums_wg_kernel, dim3(1u << lb), dim3(MLE_BLOCK), 0, stream, first, (uint32_t)(blk / FINE_CHUNK), d_fine, (uint64_t*)nullptr);
