@@ -25,6 +25,7 @@ def run(k):
 
 
 run(2 * depth)
-for _ in range(3):
-    t0 = time.perf_counter(); run(proofs); dt = time.perf_counter() - t0
-    print("depth %d: %.1f us per proof (%d proofs)" % (depth, dt / proofs * 1e6, proofs))
+res = []
+for _ in range(5):
+    t0 = time.perf_counter(); run(proofs); res.append((time.perf_counter() - t0) / proofs * 1e6)
+print("depth %d: %.1f us per proof (median of 5 runs of %d proofs; %s)" % (depth, sorted(res)[2], proofs, " ".join("%.1f" % r for r in res)))

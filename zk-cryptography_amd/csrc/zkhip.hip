@@ -574,7 +574,8 @@ static int launch_multifold(zkhip_ctx* c, hipStream_t stream, const uint64_t* cu
     uint32_t out_per_wg;
     // diagnostics: ZKHIP_MF=0 keeps the VALU form for an A/B on the same box (tools/ab_multifold.sh); ZKHIP_MF=r (1..9) sets the rotation of
     // the term order (tile T starts at term r * T mod 2^k; the default 1 -- 3 and 5 measured the same, 0 = every wave at term 0: 108 vs 112 us
-    // before the aligned planes); ZKHIP_MF_OCC=n caps the workgroups per CU through the LDS request (1: 95 us, 2 = the register limit: 84 us)
+    // before the aligned planes); ZKHIP_MF_OCC=n caps the workgroups per CU through the LDS request (all 1024 workgroups are resident at once as it is, 4 per CU; capped at 2 per CU
+    // or with 36-78 KiB requested per workgroup the pass takes the same 83-85 us, alone and beside the proofs in flight: round 6)
     static const int mf_cfg = [] { const char* e = getenv("ZKHIP_MF"); return e ? atoi(e) : 1; }();
     if (m >= 8192 && k >= 4 && mf_cfg != 0) {   // streaming shape, limb products on the matrix cores (mfma_fold.hpp)
         out_per_wg = 64;
