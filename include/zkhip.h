@@ -246,7 +246,13 @@ int zkhip_sumcheck_prove(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, cons
  * of one proof (and the zkhip_mle_block_sums of the next table, on the caller's stream) overlap the transcript rounds of the
  * others; `end` orders the caller's stream behind the proof again.  The table, its block sums and a device-resident claimed sum
  * must stay untouched between begin and end.  While a proof is in flight zkhip_sumcheck_prove returns ZKHIP_ERR_BUSY (the
- * result slots are taken). */
+ * result slots are taken).
+ * From the third proof in flight on, tables of >= 2^24 entries: `begin` enqueues the proof's first half only.  The big fold goes onto
+ * the CALLER's stream -- so that one stream carries every streaming pass of every proof back to back -- and is enqueued by a later
+ * `begin` (behind the block sums of the next one to three tables), by `end` of that proof or of a younger one, by
+ * zkhip_ctx_synchronize, zkhip_ctx_set_stream (on the old stream) and zkhip_ctx_destroy.  A caller that begins proofs and then only
+ * waits on its own stream therefore must call `end` (or zkhip_ctx_synchronize) for them to complete; a second half that cannot be
+ * enqueued is reported by `end` of its proof. */
 int zkhip_sumcheck_prove_begin(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, const uint64_t *h_claimed_sum,
                                const uint64_t *d_claimed_sum, const uint64_t *d_block_sums, uint32_t log_blocks, uint32_t *ticket);
 int zkhip_sumcheck_prove_end(zkhip_ctx *ctx, uint32_t ticket, uint64_t *h_sum, uint64_t *h_round_polys, uint64_t *h_challenges);
