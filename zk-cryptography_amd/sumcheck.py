@@ -113,8 +113,9 @@ class Sumcheck:
 
     def prove_begin(self):
         """The same proof, in flight (zkhip_sumcheck_prove_begin): -> PendingProof; .wait() yields what prove() returns.  At most
-        four per context, each on streams and buffers of its own: a prover with several tables begins the next proofs before it
-        collects the previous ones, and their streaming passes overlap the others' transcript rounds.  The table and its block
+        eight per context, each on buffers of its own: a prover with several tables begins the next proofs before it
+        collects the previous ones, and their streaming passes overlap the others' transcript rounds (from the third proof in flight
+        on, part of a proof is enqueued by a later prove_begin() / wait(): every PendingProof must be waited for or dropped).  The table and its block
         sums (poly_sum() of the SAME Multilinear) must stay untouched until wait()."""
         if len(self.poly) < 2:
             raise AssertionError("prove_begin needs a table of at least two entries")
