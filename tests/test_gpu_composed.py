@@ -81,7 +81,7 @@ def test_sum_check_proof(zk, ora, tables):   # composed_sumcheck.rs:143-241
 
 
 @pytest.mark.parametrize("k,log_n", [(1, 1), (2, 5), (2, 12), (3, 9), (5, 8), (5, 13), (4, 10),
-                                     (2, 20), (3, 18), (2, 21), (2, 22)])   # the last four: grids above the workgroup cap (grid-stride rounds); (2, 21) / (2, 22): one / two rounds on the unreduced K = 2 sums
+                                     (2, 20), (3, 18), (2, 21), (2, 22), (5, 20)])   # (2, 20) .. (2, 22): grids above the workgroup cap (grid-stride rounds); (2, 21) / (2, 22): one / two rounds on the unreduced K = 2 sums; (5, 20): the first round's last factor on the matrix cores (composed_dot.hpp), four steps per workgroup
 def test_composed_prove_random(zk, ora, k, log_n):   # benches: 2 and 5 tables (composed_sumcheck_benchmark.rs)
     t = np.stack([ora.random_fr(1 << log_n, 900 + 10 * k + q) for q in range(k)])
     poly = zk.ComposedMultilinear(list(t))
@@ -179,3 +179,20 @@ def test_multi_composed_zero_coefficient_semantics(zk, ora):
     _check_multi(zk, ora, [[a], [neg_a]], True)
     _check_multi(zk, ora, [[const], [a]], True)
     _check_multi(zk, ora, [[const, const], [neg_a]], False)
+
+
+@pytest.mark.parametrize("grid", [None, "2"])
+def test_five_table_rounds_on_the_matrix_cores_at_every_size(grid):
+    """composed_round_dot_kernel (K = 5: the last factor of every index as a byte GEMM, csrc/composed_dot.hpp) serves rounds of >= 2^18
+    output pairs by default.  Here the prover tests above run once more in a process where it takes every round of >= 256 pairs
+    (ZKHIP_ROUND_DOT_MIN_LOG=8), first and folding rounds, one step per workgroup and -- with two workgroups per round -- up to eight:
+    bit-identical to the oracle and the golden vectors."""
+    import os, subprocess, sys
+    env = dict(os.environ, ZKHIP_ROUND_DOT_MIN_LOG="8")
+    if grid:
+        env["ZKHIP_ROUND_GRID"] = grid
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_composed.py"), os.path.join(here, "test_golden.py"), "-m", "gpu", "-x", "-q",
+                          "-k", "(test_composed_prove_random and 5-) or test_multi_composed_random or test_hip_path_reproduces_golden or test_sum_check_proof"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    assert out.returncode == 0, out.stdout.decode()[-3000:]

@@ -14,6 +14,7 @@
 #include "host_util.hpp"
 #include "composed_kernels.hpp"
 #include "composed_stage.hpp"
+#include "composed_dot.hpp"
 #include "composed_pipe.hpp"
 #include "host_fr.hpp"
 
@@ -37,6 +38,30 @@ static void launch_round(zkhip_ctx* c, bool fold, const TablePtrs& tp, size_t n,
                 hipLaunchKernelGGL((composed_round_kernel<K, false, true>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
         }
         return;
+    }
+    if constexpr (K == 5) {
+        // large rounds: the last factor as a dot product on the matrix cores (composed_dot.hpp).  Measured (K = 5, one term, 512 workgroups,
+        // profiles/r06/NOTES.md section 8): the first round 397 -> 293 us at 2^22 and 111 -> 92 us at 2^20; folding rounds 323 -> 303 us with
+        // 2^20 output pairs, 172 -> 165 with 2^19, a draw with 2^18 -- so from 2^18 pairs on in the first round, 2^19 in the folding ones.
+        // (K = 3, built and measured the same way: 7 -> 3 products in the first round, but its rounds at 2^20 are 35-55 us long and the staging,
+        // the barriers and the closing reduction cost more than the products saved: 56 -> 67 us.  Not instantiated.)
+        // ZKHIP_ROUND_DOT=0 keeps the vector form (A/B runs), ZKHIP_ROUND_DOT_MIN_LOG=<l> moves both thresholds (tests: the small sizes too).
+        static const int dot_min_log = [] {
+            const char* on = std::getenv("ZKHIP_ROUND_DOT");
+            if (on && std::atoi(on) == 0) return 64;
+            const char* e = std::getenv("ZKHIP_ROUND_DOT_MIN_LOG");
+            return e ? -std::max(8, std::atoi(e)) : 18;
+        }();
+        const size_t work = fold ? n / 4 : n / 2;
+        const int min_log = dot_min_log < 0 ? -dot_min_log : dot_min_log + (fold ? 1 : 0);
+        const size_t per_wg = (work + (size_t)grid * CDT_ROWS - 1) / ((size_t)grid * CDT_ROWS) * CDT_ROWS;
+        if (min_log < 64 && work >= ((size_t)1 << min_log) && per_wg <= CDT_MAX_PER_WG) {
+            if (fold)
+                hipLaunchKernelGGL((composed_round_dot_kernel<K, true>), dim3(grid), dim3(CDT_ROWS), cdt_lds_bytes(K), c->stream, tp, n, r, rec, rec_off, partials);
+            else
+                hipLaunchKernelGGL((composed_round_dot_kernel<K, false>), dim3(grid), dim3(CDT_ROWS), cdt_lds_bytes(K), c->stream, tp, n, r, rec, rec_off, partials);
+            return;
+        }
     }
     if (fold)
         hipLaunchKernelGGL((composed_round_kernel<K, true, false>), dim3(grid), dim3(MLE_BLOCK), 0, c->stream, tp, n, r, rec, rec_off, partials);
