@@ -39,13 +39,47 @@ __device__ __forceinline__ void cdt_store_row(unsigned char* p, const Fr& v) {
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
+// The entries of table 0 (and, in the first round, table 1) behind output pair j, loaded ONE STEP AHEAD: all four waves of a workgroup load, compute and wait in step,
+// so nothing but the other workgroup of the CU hides a load issued at the top of a step -- these are issued before the MFMA phase of the
+// previous step and arrive under it (the other tables are loaded under the products of the first quadratic).
+template <bool FOLD>
+struct CdtAhead {
+    static constexpr int TABLES = FOLD ? 1 : 2;     // a folding round has four entries per table and 238 registers in use: one table ahead (two spill)
+    Fr e[FOLD ? 4 : 4];        // per table: FOLD a0, b0, a1, b1 (in[j], in[j + h], in[j + q], in[j + h + q]); else lo, hi
+    __device__ __forceinline__ void load(const TablePtrs& tp, size_t j, size_t h, size_t q) {
+#pragma unroll
+        for (int k = 0; k < TABLES; ++k) {
+            if constexpr (FOLD) {
+                e[4 * k] = load_fr(tp.in[k], j); e[4 * k + 1] = load_fr(tp.in[k], j + h);
+                e[4 * k + 2] = load_fr(tp.in[k], j + q); e[4 * k + 3] = load_fr(tp.in[k], j + h + q);
+            } else {
+                e[2 * k] = load_fr(tp.in[k], j); e[2 * k + 1] = load_fr(tp.in[k], j + h);
+            }
+        }
+    }
+    // (lo, hi) of table k: the entries themselves, or their fold at r written back on the way (round_pair)
+    __device__ __forceinline__ void pair(const TablePtrs& tp, int k, size_t j, size_t q, const Fr& r, Fr& lo, Fr& hi) const {
+        if constexpr (FOLD) {
+            lo = fold_pair(e[4 * k], e[4 * k + 1], r);
+            hi = fold_pair(e[4 * k + 2], e[4 * k + 3], r);
+            store_fr(tp.out[k], j, lo);
+            store_fr(tp.out[k], j + q, hi);
+        } else {
+            lo = e[2 * k];
+            hi = e[2 * k + 1];
+        }
+    }
+};
+
 // the values of output pair j: Q_t (t < K) into plane t of stage_a, (l, d) of the last table into stage_b -- each at this lane's row
 template <int K, bool FOLD>
-__device__ __forceinline__ void cdt_stage_values(const TablePtrs& tp, size_t j, size_t h, size_t q, const Fr& r, unsigned char* row_a, unsigned char* row_b) {
+__device__ __forceinline__ void cdt_stage_values(const TablePtrs& tp, const CdtAhead<FOLD>& first, size_t j, size_t h, size_t q, const Fr& r,
+                                                 unsigned char* row_a, unsigned char* row_b) {
     static_assert(K == 5, "two quadratics and a linear last factor");
     Fr l0, h0, l1, h1;
-    round_pair<FOLD>(tp, 0, j, h, q, r, l0, h0);
-    round_pair<FOLD>(tp, 1, j, h, q, r, l1, h1);
+    first.pair(tp, 0, j, q, r, l0, h0);
+    if constexpr (CdtAhead<FOLD>::TABLES == 2) first.pair(tp, 1, j, q, r, l1, h1);
+    else round_pair<FOLD>(tp, 1, j, h, q, r, l1, h1);
     QuadEvals a(l0, h0, l1, h1);
     round_pair<FOLD>(tp, 2, j, h, q, r, l0, h0);
     round_pair<FOLD>(tp, 3, j, h, q, r, l1, h1);
@@ -116,17 +150,23 @@ static __global__ __launch_bounds__(CDT_ROWS) __attribute__((amdgpu_waves_per_eu
     const uint32_t op_a = (uint32_t)(uintptr_t)(stage_a + wave * CDT_PLANE) + in_tile;
     const uint32_t op_b = (uint32_t)(uintptr_t)stage_b + in_tile;
     const uint32_t op_x = (uint32_t)(uintptr_t)(stage_a + 4 * CDT_PLANE) + in_tile;
+    CdtAhead<FOLD> ahead;
+    {
+        const size_t j = (size_t)blockIdx.x * CDT_ROWS + tid;
+        if (j < work) ahead.load(tp, j, h, q);
+    }
     for (uint32_t it = 0; it < iters; ++it) {
         const size_t j = (size_t)it * stride + (size_t)blockIdx.x * CDT_ROWS + tid;
         unsigned char* row_a = stage_a + tid * 32;
         unsigned char* row_b = stage_b + tid * 32;
-        if (j < work) cdt_stage_values<K, FOLD>(tp, j, h, q, r, row_a, row_b);
+        if (j < work) cdt_stage_values<K, FOLD>(tp, ahead, j, h, q, r, row_a, row_b);
         else {
 #pragma unroll
             for (int t = 0; t < NP; ++t) cdt_store_row(row_a + t * CDT_PLANE, Fr::zero());
             cdt_store_row(row_b, Fr::zero());
             cdt_store_row(row_b + CDT_PLANE, Fr::zero());
         }
+        if (it + 1 < iters && j + stride < work) ahead.load(tp, j + stride, h, q);       // the next step's first two tables, under the MFMA phase
         __syncthreads();                     // the 256 rows are staged
         {
             CdtOps cur, nxt;
