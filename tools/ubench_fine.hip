@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -164,6 +165,37 @@ int main() {
     run("4 runs n/4 apart, nontemporal", [&] { k_fine4<true, 1><<<g4, 256>>>(d_in, n_chunks, d_out); }, true);
     run("loads only, 2 adjacent runs, plain", [&] { k_loads<false><<<g2, 256>>>(d_in, n_chunks, d_out); }, false);
     run("loads only, 2 adjacent runs, nontemporal", [&] { k_loads<true><<<g2, 256>>>(d_in, n_chunks, d_out); }, false);
+    // ---- round 6: the same variants with the workgroups per CU capped through an LDS request the kernels never touch (fine_sums needs 40
+    // registers: eight workgroups per CU without a cap)
+    for (size_t lds : {(size_t)79872, (size_t)53248, (size_t)40960}) {
+        CHK(hipFuncSetAttribute((const void*)k_fine2<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        CHK(hipFuncSetAttribute((const void*)k_fine2<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        CHK(hipFuncSetAttribute((const void*)k_fine2<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        CHK(hipFuncSetAttribute((const void*)k_fine2<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        CHK(hipFuncSetAttribute((const void*)k_fine4<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        CHK(hipFuncSetAttribute((const void*)k_fine4<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        CHK(hipFuncSetAttribute((const void*)k_loads<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        CHK(hipFuncSetAttribute((const void*)k_loads<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        char nm[160];
+        const int per_cu = (int)(160 * 1024 / lds);
+        snprintf(nm, sizeof nm, "%d workgroups per CU: 2 adjacent runs per wave, plain", per_cu);
+        run(nm, [&] { k_fine2<false, 0><<<g2, 256, lds>>>(d_in, n_chunks, 0, d_out); }, true);
+        snprintf(nm, sizeof nm, "%d workgroups per CU: 2 adjacent runs per wave, nontemporal", per_cu);
+        run(nm, [&] { k_fine2<true, 0><<<g2, 256, lds>>>(d_in, n_chunks, 0, d_out); }, true);
+        snprintf(nm, sizeof nm, "%d workgroups per CU: 2 runs n/2 apart, plain", per_cu);
+        run(nm, [&] { k_fine2<false, 1><<<g2, 256, lds>>>(d_in, n_chunks, 0, d_out); }, true);
+        snprintf(nm, sizeof nm, "%d workgroups per CU: 2 runs n/2 apart, nontemporal", per_cu);
+        run(nm, [&] { k_fine2<true, 1><<<g2, 256, lds>>>(d_in, n_chunks, 0, d_out); }, true);
+        snprintf(nm, sizeof nm, "%d workgroups per CU: 4 adjacent runs per wave, nontemporal", per_cu);
+        run(nm, [&] { k_fine4<true, 0><<<g4, 256, lds>>>(d_in, n_chunks, d_out); }, true);
+        snprintf(nm, sizeof nm, "%d workgroups per CU: 4 runs n/4 apart, nontemporal", per_cu);
+        run(nm, [&] { k_fine4<true, 1><<<g4, 256, lds>>>(d_in, n_chunks, d_out); }, true);
+        snprintf(nm, sizeof nm, "%d workgroups per CU: loads only, plain", per_cu);
+        run(nm, [&] { k_loads<false><<<g2, 256, lds>>>(d_in, n_chunks, d_out); }, false);
+        snprintf(nm, sizeof nm, "%d workgroups per CU: loads only, nontemporal", per_cu);
+        run(nm, [&] { k_loads<true><<<g2, 256, lds>>>(d_in, n_chunks, d_out); }, false);
+    }
+    if (getenv("UBENCH_FINE_NO_SWEEP")) return 0;
     // ---- does a pass that walks the table in the OPPOSITE direction of the pass before it find the tail of that pass in the 256 MiB
     // Infinity Cache?  Pairs of sweeps (up, up) against (up, down), per pair; and a single sweep over a table that fits the cache.
     for (int nt = 0; nt < 2; ++nt) {
