@@ -589,7 +589,10 @@ def bench_composed_shapes(args, zk, N, torch, np):
         dt = sorted(ts)[len(ts) // 2]
         out["composed_k5_2^%d" % log_n] = {"workload": "ComposedSumcheck::prove, product of 5 tables of 2^%d entries" % log_n, "ms_per_prove": round(1e3 * dt, 4),
                                            "batches": _stats(ts, 1e3), "value": round(5 * n / dt, 1), "unit": "field-evals/s (table entries consumed)",
-                                           "algorithmic_bytes": 96.0 * 5 * n, "frac_of_hbm": round(96.0 * 5 * n / dt / 1e9 / HBM_PEAK_GBS, 4)}
+                                           "algorithmic_bytes": 96.0 * 5 * n, "frac_of_hbm": round(96.0 * 5 * n / dt / 1e9 / HBM_PEAK_GBS, 4),
+                                           "large_rounds": "composed_round_dot_kernel (csrc/composed_dot.hpp): the last factor of every index as an int8 GEMM on the matrix cores "
+                                                           "(first round from 2^18 output pairs, folding rounds from 2^19); ZKHIP_ROUND_DOT=0 = the vector form"
+                                                           if os.environ.get("ZKHIP_ROUND_DOT", "1") != "0" else "vector form (ZKHIP_ROUND_DOT=0)"}
         del tabs, poly
     n = 1 << 20
     tabs = [zk.Multilinear(_synthetic(zk, torch, n, SEED_TABLE + 0x520 + k)) for k in range(5)]

@@ -863,7 +863,10 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
             });
             // how many second halves stay back: enough sums passes in front of a fold that its proof's first rounds are over when its turn
             // comes (1-3 tables), few enough that the host, which stops at its depth, still has passes queued (depth 3 / 4: 1, 5: 2, 6+: 3)
-            return c->flush_deferred((size_t)std::min(3, std::max(1, in_flight - 3)));
+            // (a second half that cannot be enqueued is its OWN proof's failure -- recorded in deferred_rc, reported by that proof's prove_end --
+            // not this proof's: this one's second half is in the queue now and the ticket must reach the caller)
+            (void)c->flush_deferred((size_t)std::min(3, std::max(1, in_flight - 3)));
+            return ZKHIP_OK;
         }
         ZK_HIP(c, hipStreamWaitEvent(F, fork_ev, 0));
         ZK_TRY(launch_multifold(c, F, d_evals, n, k1, d_w, tabA, partA, &n_parts));
