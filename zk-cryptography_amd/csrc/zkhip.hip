@@ -222,9 +222,15 @@ static int launch_fold(zkhip_ctx* c, const uint64_t* d_in, size_t n, const uint6
     if (with_sums)
         hipLaunchKernelGGL(fold_kernel<true>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_in, d_out, n_out, log_half,
                            d_r, rv, d_partials);
-    else
-        hipLaunchKernelGGL(fold_kernel<false>, dim3(grid), dim3(MLE_BLOCK), 0, c->stream, d_in, d_out, n_out, log_half,
+    else {
+        // at most THREE workgroups per CU (a 40 KiB LDS request the kernel never touches; section 7 of profiles/r06/NOTES.md found the sums pass
+        // no slower with a quarter of the loads in flight): 0.1427 -> 0.1372 ms at 2^24, 0.70 -> 0.73 of HBM; two per CU 0.161, four 0.137, no cap 0.143.
+        // ZKHIP_FOLD_LDS=<bytes> overrides (diagnostics; 0 = no cap).
+        static const long fold_lds = [] { const char* e = getenv("ZKHIP_FOLD_LDS"); return e ? std::min(std::max(atol(e), 0L), 158L * 1024) : 40960L; }();
+        if (fold_lds > 64 * 1024) ZK_TRY(c->allow_big_lds((const void*)fold_kernel<false>, 158 * 1024));
+        hipLaunchKernelGGL(fold_kernel<false>, dim3(grid), dim3(MLE_BLOCK), (size_t)fold_lds, c->stream, d_in, d_out, n_out, log_half,
                            d_r, rv, d_partials);
+    }
     if (np) *np = (uint32_t)grid;
     ZK_HIP(c, hipGetLastError());
     return ZKHIP_OK;
