@@ -977,6 +977,29 @@ def main():
     batch_s, res = _batches(step, args.steps, barrier, dist, world, torch)
     dt = sorted(batch_s)[len(batch_s) // 2]
     step_stats = _stats([b / args.steps for b in batch_s], 1e3)
+    # ---- roofline of the dominant kernel: HIP events around every fold launch on the launch stream
+    # (BEFORE the proofs-in-flight leg: once its lanes exist -- four more low-priority fold streams beside the synchronous prover's on four hardware queues --
+    # the events around the big fold span ~7 us more than the kernel runs (91.5 against 84.9 us; rocprofv3's kernel trace: 80.4 us either way).  The
+    # kernels are measured in the state the timed steps above ran in.)
+    ctx = N.Context.get()
+    N.check(N.lib().zkhip_profile_enable(ctx.handle, 1), "profile_enable")
+    prof_steps = max(1, min(args.steps, 5))
+    for _ in range(prof_steps):
+        step()
+    ms, cnt, by = _profile(N, ctx, b"multifold")
+    per_kernel = {}
+    step_bytes = 0.0
+    for kname, label in ((b"fine_sums", "fine_sums_kernel (poly_sum: sums of every run of 256 entries, 32 n B)"),
+                         (b"multifold", "multifold_mfma_kernel<4, 4> (k-variable fold, 32 (n + n / 2^k) B)"),
+                         (b"chunk_sums", "chunk_sums_kernel (block sums of the generic plan, 32 n B)"),
+                         (b"multifold_small", "multifold_kernel<16> (k-variable fold, few outputs)"), (b"blockfold", "blockfold_kernel (L2-resident)")):
+        kms, kcnt, kby = _profile(N, ctx, kname)
+        step_bytes += kby / prof_steps
+        if kcnt and kby > 0 and kname in (b"fine_sums", b"multifold", b"chunk_sums"):
+            kgbs = kby / (kms * 1e-3) / 1e9
+            per_kernel[kname.decode()] = {"kernel": label, "achieved": round(kgbs, 1), "frac": round(kgbs / HBM_PEAK_GBS, 4), "launches": kcnt,
+                                          "avg_launch_us": round(1e3 * kms / kcnt, 2), "bytes_per_launch": kby / kcnt}
+    N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
     # informational: the same steps with several proofs in flight (zkhip_sumcheck_prove_begin / _end) -- the way a prover with
     # several tables calls the library; the device runs the proofs in stream order, the idle time between them shrinks
     pipelined = None
@@ -1033,26 +1056,6 @@ def main():
                                                                                   np.asarray(ch_, dtype=np.uint64).reshape(-1)]))
         assert transcript_same, "rank %d: the sharded proof differs from rank 0's" % rank
 
-    # ---- roofline of the dominant kernel: HIP events around every fold launch on the launch stream
-    ctx = N.Context.get()
-    N.check(N.lib().zkhip_profile_enable(ctx.handle, 1), "profile_enable")
-    prof_steps = max(1, min(args.steps, 5))
-    for _ in range(prof_steps):
-        step()
-    ms, cnt, by = _profile(N, ctx, b"multifold")
-    per_kernel = {}
-    step_bytes = 0.0
-    for kname, label in ((b"fine_sums", "fine_sums_kernel (poly_sum: sums of every run of 256 entries, 32 n B)"),
-                         (b"multifold", "multifold_mfma_kernel<4, 4> (k-variable fold, 32 (n + n / 2^k) B)"),
-                         (b"chunk_sums", "chunk_sums_kernel (block sums of the generic plan, 32 n B)"),
-                         (b"multifold_small", "multifold_kernel<16> (k-variable fold, few outputs)"), (b"blockfold", "blockfold_kernel (L2-resident)")):
-        kms, kcnt, kby = _profile(N, ctx, kname)
-        step_bytes += kby / prof_steps
-        if kcnt and kby > 0 and kname in (b"fine_sums", b"multifold", b"chunk_sums"):
-            kgbs = kby / (kms * 1e-3) / 1e9
-            per_kernel[kname.decode()] = {"kernel": label, "achieved": round(kgbs, 1), "frac": round(kgbs / HBM_PEAK_GBS, 4), "launches": kcnt,
-                                          "avg_launch_us": round(1e3 * kms / kcnt, 2), "bytes_per_launch": kby / kcnt}
-    N.check(N.lib().zkhip_profile_enable(ctx.handle, 0), "profile_enable")
     achieved = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     # HBM bytes per launch from the PMC counters: separate rocprofv3 --pmc passes of this command, committed under profiles/rNN
     # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); the NEWEST round's file is read and named -- a file constant of that

@@ -12,6 +12,11 @@ mixed = os.environ.get("INFLIGHT_MIXED") == "1"        # tables 3 and 7 half as 
 polys = [zk.Multilinear(torch.randint(0, 2 ** 62, (1 << (log_n - (1 if mixed and t % 4 == 3 else 0)), 4), dtype=torch.int64, device="cuda")) for t in range(max(8, depth))]
 
 
+extra = [torch.cuda.Stream() for _ in range(int(os.environ.get("INFLIGHT_EXTRA_STREAMS", "0")))]      # idle streams of the caller's: do they cost the pipeline its hardware queues?
+if os.environ.get("INFLIGHT_SYNC_FIRST") == "1":        # a synchronous proof first: the context's own fold stream and side streams come into being before the lanes
+    sc = zk.Sumcheck(polys[0]); sc.poly_sum(); sc.prove()
+
+
 def run(k):
     pend = []
     for i in range(k):
