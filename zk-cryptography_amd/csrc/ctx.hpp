@@ -172,7 +172,7 @@ struct zkhip_ctx {
         if (k >= LANE_STREAMS) {
             const int rc = ensure_lane_streams(k - LANE_STREAMS);
             if (rc != ZKHIP_OK) return rc;
-            L.serial = lanes[k - LANE_STREAMS].serial; L.fold = lanes[k - LANE_STREAMS].fold; L.borrowed = true;
+            L.serial = lanes[k - LANE_STREAMS].serial; L.borrowed = true;
             return ZKHIP_OK;
         }
         int least = 0, greatest = 0;
@@ -180,6 +180,23 @@ struct zkhip_ctx {
         if (hipStreamCreateWithPriority(&L.serial, hipStreamNonBlocking, greatest) != hipSuccess) return ZKHIP_ERR_HIP;
         // (measured and dropped, profiles/r06/NOTES.md: some lanes' serial stream at normal instead of high priority, or their fold stream at
         // normal instead of low: 0.27-0.32 ms per proof in flight instead of 0.23; the serial kernels must get in front of every streaming pass)
+        return ZKHIP_OK;
+    }
+    // The fold stream of a lane comes into being when a proof needs it: only a proof that begins with at most one other in flight keeps
+    // its big fold on a stream of its own (sumcheck_enqueue), and such a proof gets ticket 0 or 1 -- so a context ends up with at most
+    // three low-priority streams (these two and the synchronous prover's) on the four hardware queues of that priority.  With all
+    // eight lanes' fold streams created up front the synchronous proof's fork cost 4 us more from the moment the lanes existed.
+    int ensure_lane_fold(int k) {
+        ProofLane& L = lanes[k];
+        if (L.fold) return ZKHIP_OK;
+        if (k >= LANE_STREAMS) {
+            const int rc = ensure_lane_fold(k - LANE_STREAMS);
+            if (rc != ZKHIP_OK) return rc;
+            L.fold = lanes[k - LANE_STREAMS].fold;
+            return ZKHIP_OK;
+        }
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return ZKHIP_ERR_HIP;
         if (hipStreamCreateWithPriority(&L.fold, hipStreamNonBlocking, least) != hipSuccess) return ZKHIP_ERR_HIP;
         return ZKHIP_OK;
     }
@@ -193,7 +210,7 @@ struct zkhip_ctx {
             if (hipMalloc(&L.small, ZK_SMALL_BYTES) != hipSuccess) return ZKHIP_ERR_NOMEM;
         }
         if (ws_need > L.ws_bytes) {                 // grow-only; the lane is idle here (its ticket is free)
-            if (L.ws) { if (hipStreamSynchronize(L.serial) != hipSuccess || hipStreamSynchronize(L.fold) != hipSuccess) return ZKHIP_ERR_HIP; hipFree(L.ws); }
+            if (L.ws) { if (hipStreamSynchronize(L.serial) != hipSuccess || (L.fold && hipStreamSynchronize(L.fold) != hipSuccess)) return ZKHIP_ERR_HIP; hipFree(L.ws); }
             L.ws = nullptr; L.ws_bytes = 0;
             if (hipMalloc(&L.ws, ws_need) != hipSuccess) return ZKHIP_ERR_NOMEM;
             L.ws_bytes = ws_need;

@@ -844,6 +844,7 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
         SmallArgs b = {};
         b.src = d_p1; b.group = ny; b.stride = 1u << k2; b.canon = 1; b.log_n = k2; b.n_rounds = k2; b.round0 = k1; b.first = 0;
         b.weights_out = d_w2; b.final_out = nullptr;
+        if (lane >= 0 && in_flight < 3) { ZK_TRY(c->ensure_lane_fold(lane)); F = c->lanes[lane].fold; }
         if (lane >= 0 && in_flight >= 3) {
             // Three or more proofs in flight: the streaming passes of ALL of them on ONE stream, the caller's -- where poly_sum() puts the sums
             // passes already.  The big fold and what follows it are enqueued LATER (zkhip_ctx::deferred), behind the sums passes of the next
