@@ -7,6 +7,15 @@ import zk_cryptography_amd as zk
 from zk_cryptography_amd import _native as N
 from zk_cryptography_amd.gkr import GKRProtocol
 
+if os.environ.get("GKR_BATCH_AFTER_IN_FLIGHT"):        # Sumcheck proofs in flight first: their lanes' streams exist when the batch's lanes come into being
+    _polys = [zk.Multilinear(torch.randint(0, 2 ** 62, (1 << 24, 4), dtype=torch.int64, device="cuda")) for _ in range(8)]
+    _pend = []
+    for _i in range(int(os.environ["GKR_BATCH_AFTER_IN_FLIGHT"]) * 3):
+        _sc = zk.Sumcheck(_polys[_i % 8]); _sc.poly_sum(); _pend.append(_sc.prove_begin())
+        if len(_pend) == int(os.environ["GKR_BATCH_AFTER_IN_FLIGHT"]): _pend.pop(0).wait()
+    for _h in _pend: _h.wait()
+    torch.cuda.synchronize()
+    del _polys
 cases = [tuple(int(x) for x in a.split(":")) for a in sys.argv[1:]] or [(8, 8, 8), (8, 32, 8), (8, 32, 4), (8, 32, 2), (8, 32, 1), (20, 8, 8), (20, 8, 4), (20, 8, 2), (20, 8, 1)]
 p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
 circuits = {}

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -944,9 +945,12 @@ extern "C" int zkhip_gkr_prove_batch(zkhip_circuit* cir, uint32_t n_proofs, uint
     for (uint32_t l = 0; l < lanes; ++l) ZK_HIP(c, hipStreamWaitEvent(c->gkr_lanes[l]->stream, c->done_ev, 0));
     std::vector<int> rcs(n_proofs, ZKHIP_OK);
     const size_t o_sums = 4 * (size_t)nl, o_rounds = nl, o_lens = (size_t)nl * stride, o_polys = (size_t)nl * stride * GKR_MONO * 8, o_ch = (size_t)nl * stride * 4;
+    // proofs are handed out one by one: a lane whose hardware queue gets less of the command processor (the lanes' busy shares in a kernel
+    // trace range from 35 to 75 %, and differently from process to process) takes fewer of them instead of holding the call up
+    std::atomic<uint32_t> next_proof{0};
     auto lane_work = [&](unsigned l) {
         zkhip_ctx* lc = c->gkr_lanes[l];
-        for (uint32_t b = l; b < n_proofs; b += lanes) {
+        for (uint32_t b = next_proof.fetch_add(1); b < n_proofs; b = next_proof.fetch_add(1)) {
             rcs[b] = lc->activate();
             if (rcs[b] != ZKHIP_OK) continue;
             rcs[b] = gkr_prove_circuit_on(lc, cir, h_layer_ptrs + (size_t)b * (nl + 1), h_layer_len, h_sums + b * o_sums, h_n_rounds + b * o_rounds,
