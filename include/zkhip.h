@@ -242,7 +242,7 @@ int zkhip_sumcheck_prove(zkhip_ctx *ctx, const uint64_t *d_evals, size_t n, cons
 
 /* Sumcheck::prove in flight: begin enqueues the whole proof (same inputs as zkhip_sumcheck_prove) and returns a ticket, end
  * waits for that proof and delivers the same outputs (all-NULL outputs abandon it).  Up to eight proofs may be in flight.  Each
- * runs on streams, workspace and scratch of its own behind what the caller's stream held at `begin`, so the streaming passes
+ * runs with workspace and scratch of its own (and on the library's internal streams) behind what the caller's stream held at `begin`, so the streaming passes
  * of one proof (and the zkhip_mle_block_sums of the next table, on the caller's stream) overlap the transcript rounds of the
  * others; `end` orders the caller's stream behind the proof again.  The table, its block sums and a device-resident claimed sum
  * must stay untouched between begin and end.  While a proof is in flight zkhip_sumcheck_prove returns ZKHIP_ERR_BUSY (the
