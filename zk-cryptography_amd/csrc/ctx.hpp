@@ -182,10 +182,14 @@ struct zkhip_ctx {
         // normal instead of low: 0.27-0.32 ms per proof in flight instead of 0.23; the serial kernels must get in front of every streaming pass)
         return ZKHIP_OK;
     }
-    // The fold stream of a lane comes into being when a proof needs it: only a proof that begins with at most one other in flight keeps
-    // its big fold on a stream of its own (sumcheck_enqueue), and such a proof gets ticket 0 or 1 -- so a context ends up with at most
-    // three low-priority streams (these two and the synchronous prover's) on the four hardware queues of that priority.  With all
-    // eight lanes' fold streams created up front the synchronous proof's fork cost 4 us more from the moment the lanes existed.
+    // A lane's low-priority fold stream (only a proof that begins with at most one other in flight keeps its big fold on a stream of its
+    // own: tickets 0 and 1) -- created WITH the lane all the same, for lanes 0..3: the runtime serves the streams of one priority from at
+    // most four hardware queues, gives a new stream the queue with the fewest streams on it, the FIRST such queue on a tie -- and a queue it
+    // has just created for one stream ties with every other single-stream queue.  With the four fold streams the low-priority pool is full
+    // when the lanes exist (as the high-priority one is with the four serial streams), and lanes created later by somebody else -- the GKR
+    // batch's -- spread over the queues: with fold streams on demand two of its eight lanes landed on ONE queue in bench.py's process
+    // (46 % busy each, the others 80-90 %: 0.47 instead of 0.34 ms per depth-8 proof; profiles/r06/NOTES.md).  The price: the synchronous
+    // proof's fork onto its own fold stream costs 4 us more once the lanes exist (five low-priority streams on four queues, tools/ab_lanes.py).
     int ensure_lane_fold(int k) {
         ProofLane& L = lanes[k];
         if (L.fold) return ZKHIP_OK;
@@ -203,6 +207,7 @@ struct zkhip_ctx {
     int ensure_lane(int k, size_t ws_need) {
         ProofLane& L = lanes[k];
         { const int rc = ensure_lane_streams(k); if (rc != ZKHIP_OK) return rc; }
+        { const int rc = ensure_lane_fold(k); if (rc != ZKHIP_OK) return rc; }
         if (!L.small) {
             if (hipEventCreateWithFlags(&L.begin_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
             if (hipEventCreateWithFlags(&L.fork_ev, hipEventDisableTiming) != hipSuccess) return ZKHIP_ERR_HIP;
