@@ -7,6 +7,7 @@
 #include <deque>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <set>
 #include <vector>
@@ -258,6 +259,8 @@ struct zkhip_ctx {
     std::vector<zkhip_ctx*> gkr_lanes;   // child contexts of zkhip_gkr_prove_batch (a stream, scratch and transcript state each), destroyed with this one
     // a lane replays a circuit's launch chain as a HIP graph (gkr.hip): its own copy of the layer values + the graph and the addresses it holds
     bool gkr_lane = false;
+    zkhip_ctx* gkr_parent = nullptr;            // a lane's owner: the lanes' proofs that allocate or record a graph take turns under its gkr_warm_mu
+    std::mutex gkr_warm_mu;
     void* d_gkr_in = nullptr; size_t gkr_in_bytes = 0;
     struct GkrGraph {
         void* exec = nullptr;                       // hipGraphExec_t

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -682,6 +683,13 @@ static int gkr_prove_circuit_on(zkhip_ctx* c, zkhip_circuit* cir, const uint64_t
     for (uint32_t k = 1; k <= n_layers; ++k)
         if (!is_pow2(h_layer_len[k])) return ZKHIP_ERR_SHAPE;  // Multilinear::new (evaluation_form.rs:16-20)
     ZK_TRY(c->activate());
+    // The lanes of a batch run on threads of their own, and since proofs are handed out one by one they are no longer in step: a lane's first
+    // proof of a circuit allocates (workspace, pinned slots, the lane's copy of the layer values), its second RECORDS the chain -- and a
+    // stream capture in one thread is invalidated by allocations in another whatever the capture mode (hipErrorStreamCaptureInvalidated, and the
+    // allocating proof fails with it too: tools/stress_parity.py, 9 proofs on 8 lanes).  So a lane that has no graph of this circuit yet takes
+    // its turn under the owner's mutex; a lane that replays (the steady state) does not.
+    std::unique_lock<std::mutex> warm_turn;
+    if (c->gkr_lane && c->gkr_parent && !(c->gkr_graph.exec && c->gkr_graph.cir == cir)) warm_turn = std::unique_lock<std::mutex>(c->gkr_parent->gkr_warm_mu);
     // A lane of zkhip_gkr_prove_batch REPLAYS the proof's launch chain as a HIP graph (one hipGraphLaunch instead of 130-400 launches of
     // 3-5 us of host time each: with eight chains side by side the process's launch rate was the bound, tools/perf_gkr_batch.py).  A graph
     // holds addresses: the layer values are first copied to a buffer of the lane's own, so that every proof of the circuit on this lane is
@@ -937,6 +945,7 @@ extern "C" int zkhip_gkr_prove_batch(zkhip_circuit* cir, uint32_t n_proofs, uint
         lc->stream = s;
         lc->own_stream = true;
         lc->gkr_lane = true;
+        lc->gkr_parent = c;
         c->gkr_lanes.push_back(lc);
     }
     // the lanes start behind what the caller's stream holds now (the layer values may still be on their way there)
