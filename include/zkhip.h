@@ -506,9 +506,11 @@ int zkhip_kzg_commit(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t 
  * variable ZKHIP_LEVEL_TABLE_DELTA (read once per process), and every entry point that takes a table compares the header with the
  * geometry it is about to address the table with -- a table built for another size, of the other kind, by a process that ran with
  * another value, or a buffer that is no table -> ZKHIP_ERR_ARG instead of a wrong commitment.  (One 128-byte read the first time the
- * process sees a (table, size) pair, remembered until a table is built at that address again; a buffer the library did not build,
- * placed at a remembered address, is not read again.) */
+ * process sees a (table, size) pair, remembered until a table is built at that address again or the owner RELEASES it:
+ * zkhip_table_release(table) before the buffer is freed or reused -- the caller's allocator may hand the same address to something
+ * that is no table, and a remembered address is not read again.) */
 size_t zkhip_srs_table_bytes(size_t n_points);
+int zkhip_table_release(zkhip_ctx *ctx, const void *d_table);
 /* Content check for a host-side cache of what is derived from an SRS (the table above, the folded levels): the first two and the last
  * two points with their infinity flags, h_out[52] = 4 x (12 coordinate words, flag) -- one small launch, one copy, ~20 us.  A wrapper
  * that keeps such caches compares it before every use to catch writes into the SRS buffers that its own bookkeeping cannot see. */

@@ -123,7 +123,8 @@ def test_tables_carry_a_header_that_is_checked_against_the_geometry(zk, ora):
     lib = N.lib()
     lib.zkhip_srs_table_bytes.restype = C.c_size_t
     lib.zkhip_srs_level_tables_bytes.restype = C.c_size_t
-    junk = torch.zeros(lib.zkhip_srs_table_bytes(C.c_size_t(1 << 10)), dtype=torch.uint8, device="cuda")   # (first: an address no table has been seen at)
+    junk = torch.zeros(lib.zkhip_srs_table_bytes(C.c_size_t(1 << 10)), dtype=torch.uint8, device="cuda")
+    N.check(lib.zkhip_table_release(N.Context.get(0).handle, N.ptr(junk)), "table_release")   # (whatever an earlier test's table left behind at this address)
     srs10 = zk.TrustedSetup.setup(ora.random_fr(10, 4501)).precompute().precompute_open()
     srs9 = zk.TrustedSetup.setup(ora.random_fr(9, 4502)).precompute()
     ctx = N.Context.get(0)
@@ -159,3 +160,14 @@ def test_tables_carry_a_header_that_is_checked_against_the_geometry(zk, ora):
     N.check(lib.zkhip_srs_precompute(ctx.handle, N.ptr(srs9.powers_of_tau_in_g1), N.ptr(srs9.inf), C.c_size_t(1 << 9), N.ptr(srs10._table)), "precompute")
     assert commit(srs10._table, srs10, 1 << 10, 1 << 10) == N.ERR_ARG
     assert commit(srs10._table, srs9, 1 << 9, 1 << 9) == N.ZKHIP_OK
+    # a table that is DROPPED releases its address: the allocator hands it to a buffer that is no table, and that buffer is read and refused
+    srs8 = zk.TrustedSetup.setup(ora.random_fr(8, 4506)).precompute()
+    sc8 = torch.from_numpy(ora.random_fr(1 << 8, 4507).view(np.int64)).cuda()
+    commit8 = lambda table: lib.zkhip_kzg_commit_table(ctx.handle, N.ptr(table), N.ptr(srs8.inf), C.c_size_t(1 << 8), N.ptr(sc8), C.c_size_t(1 << 8), C.c_int(0), p(xy), C.byref(inf))   # noqa: E731
+    assert commit8(srs8._table) == N.ZKHIP_OK
+    addr, nbytes = srs8._table.data_ptr(), srs8._table.numel()
+    inf8 = srs8.inf
+    srs8.invalidate()                                                             # the table goes (zkhip_table_release), its memory back to the caching allocator
+    again = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    if again.data_ptr() == addr:                                                  # (the allocator is free to choose: checked when it does reuse the block)
+        assert lib.zkhip_kzg_commit_table(ctx.handle, N.ptr(again), N.ptr(inf8), C.c_size_t(1 << 8), N.ptr(sc8), C.c_size_t(1 << 8), C.c_int(0), p(xy), C.byref(inf)) == N.ERR_ARG

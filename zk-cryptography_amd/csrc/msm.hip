@@ -313,6 +313,12 @@ void table_forget(const zkhip_ctx* c, const void* p) {
     for (size_t i = g_table_ok.size(); i-- > 0;) if (g_table_ok[i].p == p && g_table_ok[i].device == c->device) g_table_ok.erase(g_table_ok.begin() + i);
 }
 }  // namespace
+// the owner is about to free (or reuse) the buffer of a shifted-SRS table or of level tables: its address is no longer a known table
+extern "C" int zkhip_table_release(zkhip_ctx* c, const void* d_table) {
+    if (!c || !d_table) return ZKHIP_ERR_ARG;
+    table_forget(c, d_table);
+    return ZKHIP_OK;
+}
 static size_t level_tables_first(size_t n_points, size_t* lvl_off);
 static ZkTableHeader table_header_for(uint32_t kind, size_t n_points) {
     ZkTableHeader h;

@@ -111,16 +111,30 @@ class TrustedSetup:
         N.check(N.lib().zkhip_srs_fingerprint(ctx.handle, N.ptr(p), N.ptr(i), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)), "srs_fingerprint")
         return out.tobytes()
 
+    def _drop_tables(self):
+        """The derived tables go: their addresses are released first (zkhip_table_release) -- the allocator may hand them to a buffer that
+        is no table, and the library does not read the header of an address it remembers."""
+        for t in (getattr(self, "_table", None), getattr(self, "_level_tables", None)):
+            if t is not None:
+                try:
+                    N.lib().zkhip_table_release(N.Context.get(t.device.index).handle, N.ptr(t))
+                except Exception:       # noqa: BLE001 -- interpreter shutdown
+                    pass
+        self._table = self._folded = self._level_tables = None
+
+    def __del__(self):
+        self._drop_tables()
+
     def invalidate(self):
         """Drops the shifted table and the folded levels (call after writing the SRS through raw pointers; commitments in flight
         keep the table they were started with alive through their PendingCommitment)."""
-        self._table = self._folded = self._level_tables = None
+        self._drop_tables()
         self._cache_stamp = self._cache_print = None
 
     def _check_caches(self):
         have = getattr(self, "_table", None) is not None or getattr(self, "_folded", None) is not None
         if getattr(self, "_cache_stamp", None) != self._stamp() or (have and getattr(self, "_cache_print", None) != self._fingerprint()):
-            self._table = self._folded = self._level_tables = None
+            self._drop_tables()
             self._cache_stamp = self._stamp()
             self._cache_print = None
 
