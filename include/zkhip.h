@@ -508,7 +508,7 @@ int zkhip_kzg_commit(zkhip_ctx *ctx, const uint64_t *d_points_xy, const uint8_t 
  * another value, or a buffer that is no table -> ZKHIP_ERR_ARG instead of a wrong commitment.  (One 128-byte read the first time the
  * process sees a (table, size) pair, remembered until a table is built at that address again or the owner RELEASES it:
  * zkhip_table_release(table) before the buffer is freed or reused -- the caller's allocator may hand the same address to something
- * that is no table, and a remembered address is not read again.) */
+ * that is no table, and a remembered address is not read again; zkhip_free does it for a buffer of zkhip_malloc's.) */
 size_t zkhip_srs_table_bytes(size_t n_points);
 int zkhip_table_release(zkhip_ctx *ctx, const void *d_table);
 /* Content check for a host-side cache of what is derived from an SRS (the table above, the folded levels): the first two and the last

@@ -145,6 +145,7 @@ extern "C" int zkhip_malloc(zkhip_ctx* c, void** d_ptr, size_t bytes) {
 }
 extern "C" int zkhip_free(zkhip_ctx* c, void* d_ptr) {
     if (!c) return ZKHIP_ERR_ARG;
+    if (d_ptr) (void)zkhip_table_release(c, d_ptr);      // (a table of the commit path: its address is no longer a known table, msm.hip)
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     ZK_HIP(c, hipFree(d_ptr));
     return ZKHIP_OK;
