@@ -221,8 +221,12 @@ static __global__ __launch_bounds__(CDT_ROWS) __attribute__((amdgpu_waves_per_eu
         __builtin_amdgcn_wave_barrier();
         if (lane < 63) {                     // anti-diagonal c = lane
             unsigned long long sacc = 0;
-            const int lo = (int)lane - 31 < 0 ? 0 : (int)lane - 31, hi = lane < 31 ? (int)lane : 31;
-            for (int a = lo; a <= hi; ++a) sacc += tmat[a * 33 + (lane - a)];
+#pragma unroll
+            for (int a = 0; a < 32; ++a) {       // (all 32 rows, predicated: the loads are independent of each other and of the running sum)
+                const int b = (int)lane - a;
+                const uint32_t v = tmat[a * 33 + (b & 31)];
+                sacc += (b >= 0 && b < 32) ? v : 0u;
+            }
             cols[u * 64 + lane] = sacc;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -214,8 +214,12 @@ static __global__ __launch_bounds__(256) void composed_cross2_mfma_kernel(MultiT
         __builtin_amdgcn_wave_barrier();
         if (lane < 63) {                     // anti-diagonal c = lane
             unsigned long long sacc = 0;
-            const int lo = (int)lane - 31 < 0 ? 0 : (int)lane - 31, hi = lane < 31 ? (int)lane : 31;
-            for (int d = lo; d <= hi; ++d) sacc += tmat[wave][d * 33 + (lane - d)];
+#pragma unroll
+            for (int d = 0; d < 32; ++d) {       // (all 32 rows, predicated: the loads are independent of each other and of the running sum)
+                const int i = (int)lane - d;
+                const uint32_t v = tmat[wave][d * 33 + (i & 31)];
+                sacc += (i >= 0 && i < 32) ? v : 0u;
+            }
             cols[wave][b][lane] = sacc;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
