@@ -185,6 +185,14 @@ def test_proofs_in_flight_at_2_24_keep_their_folds_on_the_callers_stream(zk):
     torch.cuda.synchronize()
     for j in range(5):
         assert same(hs[j].wait(), j)
+    hs = [begin(j) for j in range(4)]                             # the caller moves to another stream with halves held back: they go onto the old one first
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        hs.append(begin(4))                                       # (Context.get() follows torch's current stream: zkhip_ctx_set_stream)
+        for j in (4, 0, 2):
+            assert same(hs[j].wait(), j)
+    assert same(hs[1].wait(), 1) and same(hs[3].wait(), 3)        # ... and back on the default stream
+    torch.cuda.synchronize()
     hs = [begin(j) for j in range(5)]                             # tickets dropped uncollected: waited out, lanes and slots free again
     del hs
     sc = zk.Sumcheck(polys[1])
