@@ -185,6 +185,12 @@ def test_proofs_in_flight_at_2_24_keep_their_folds_on_the_callers_stream(zk):
     torch.cuda.synchronize()
     for j in range(5):
         assert same(hs[j].wait(), j)
+    hs = [zk.Sumcheck(polys[j]) for j in range(5)]                # without poly_sum(): the sums pass is the prover's own, on the caller's stream from the third proof on
+    for sc in hs:
+        sc._sum_deferred = True                                   # (absorb the TRUE sum, as after poly_sum(): no claimed sum, no block sums handed in)
+    hs = [sc.prove_begin() for sc in hs]
+    for j in range(5):
+        assert same(hs[j].wait(), j)
     hs = [begin(j) for j in range(4)]                             # the caller moves to another stream with halves held back: they go onto the old one first
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):

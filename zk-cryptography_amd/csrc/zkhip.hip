@@ -811,7 +811,14 @@ static int sumcheck_enqueue(zkhip_ctx* c, const uint64_t* d_evals, size_t n, con
         const uint32_t g = n_vars - 8, k2 = overlapped_k2(n), k1 = g - k2;
         const uint64_t* fine = d_block_sums;
         if (!fine || log_blocks != g) {             // poly_sum() was not called (or with another granularity)
-            ZK_TRY(launch_fine_sums(c, d_evals, n, g, d_fine, nullptr, S));
+            // three or more proofs in flight: this streaming pass belongs onto the caller's stream like every other one (below); the
+            // serial stream follows it
+            const bool on_callers = lane >= 0 && in_flight >= 3;
+            ZK_TRY(launch_fine_sums(c, d_evals, n, g, d_fine, nullptr, on_callers ? c->stream : S));
+            if (on_callers) {
+                ZK_HIP(c, hipEventRecord(c->lanes[lane].begin_ev, c->stream));
+                ZK_HIP(c, hipStreamWaitEvent(S, c->lanes[lane].begin_ev, 0));
+            }
             fine = d_fine;
         }
         // the coarse sums poly_sum() left for this table (the newest ring entry that names its fine sums), or our own
